@@ -1,0 +1,211 @@
+/*
+ * trlda_hip.h -- C ABI of libtrlda_hip.so, the MI355X (gfx950) implementation of
+ * trlda's per-document variational E-step and the lambda M-step around it.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, status-code returns
+ * (0 = ok, negative = error, message via trlda_last_error()), no exceptions and
+ * no torch / Eigen / CPython types cross it.  Each entry point names the
+ * reference interface it replaces (paths relative to the reference repository).
+ *
+ * Conventions (identical to the reference's in-memory layout):
+ *   - every matrix is column-major fp64 (Eigen default; python/src/pyutils.cpp:22-26):
+ *       lambda, sstats : K x V, element (k, w) at [k + K*w]
+ *       gamma          : K x B, element (k, d) at [k + K*d]
+ *   - a batch of documents is CSR int32: indptr[B+1], ids[nnz], cnts[nnz]; this is
+ *     the flat form of LDA::Documents = vector<vector<pair<int,int>>>
+ *     (include/lda.h:21-23) that PyList_ToDocuments builds
+ *     (python/src/ldainterface.cpp:152-190).  Duplicate ids inside a document and
+ *     zero counts are legal.  Word ids are validated (0 <= id < V); the reference
+ *     has undefined behaviour there.
+ *   - "host" pointers are ordinary memory; "dev" pointers are HIP device
+ *     addresses on the model's device (hipMalloc'ed by trlda_dev_alloc or by
+ *     anyone else, e.g. a torch tensor's data_ptr()).
+ *   - functions taking a trlda_model enqueue work on the model's stream and
+ *     return without synchronising unless they copy to host memory.
+ *
+ * There is NO CPU fallback behind this header: with no usable GPU every compute
+ * entry point returns TRLDA_ERR_NO_DEVICE.
+ */
+#ifndef TRLDA_HIP_H
+#define TRLDA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRLDA_OK               0
+#define TRLDA_ERR_ARG         -1  /* bad argument (null pointer, negative size ...)       */
+#define TRLDA_ERR_SHAPE       -2  /* TRLDA::Exception("... wrong dimensionality.")         */
+#define TRLDA_ERR_WORD_ID     -3  /* word id outside [0, V)                                */
+#define TRLDA_ERR_NO_DEVICE   -4  /* no HIP device / HIP runtime error at init             */
+#define TRLDA_ERR_HIP         -5  /* a HIP call failed; see trlda_last_error()             */
+#define TRLDA_ERR_VALUE       -6  /* TRLDA::Exception("... should not be negative.")       */
+
+/* how sufficient statistics are accumulated (trlda_model_set_sstats_mode) */
+#define TRLDA_SSTATS_SEGMENTED 0  /* per-word ordered sums via the batch's word-major index:
+                                     bitwise reproducible, same addition order as the
+                                     reference's serial loop (lda.cpp:207-213)              */
+#define TRLDA_SSTATS_ATOMIC    1  /* fp64 global atomics from the document kernel           */
+
+typedef struct trlda_model trlda_model;   /* device-resident lambda, alpha, workspaces */
+typedef struct trlda_batch trlda_batch;   /* device-resident CSR batch + word-major index */
+
+/* ---- library ---------------------------------------------------------- */
+
+const char *trlda_last_error(void);       /* thread-local, never NULL */
+int trlda_version(void);
+int trlda_device_count(void);             /* number of HIP devices, 0 if none */
+
+/* ---- host-side RNG: bit-compatible with the reference ------------------ */
+
+/* trlda.seed(): srand(seed).  python/src/module.cpp:332-342 */
+void trlda_seed(unsigned int seed);
+
+/* sampleGamma(m, n, k): -sum_{i<k} log|U_i|, U = -1 + 2*rand()/RAND_MAX, k passes over
+ * an m x n column-major matrix, libc rand() consumed in exactly the reference's order.
+ * src/utils.cpp:224-231, Eigen/src/Core/MathFunctions.h:439-446.  Host memory. */
+void trlda_sample_gamma(int m, int n, int k, double *out);
+
+/* sampleGamma(m, n, 100) / 100.: the lambda init of LDA::LDA (src/lda.cpp:71) and the
+ * default gamma init of LDA::updateVariables (src/lda.cpp:135).  Host memory. */
+void trlda_sample_gamma_init(int m, int n, double *out);
+
+/* ---- one-shot, host pointers ------------------------------------------- */
+
+/*
+ * LDA::updateVariables(documents, latents, parameters) with inferenceMethod == VI:
+ * include/lda.h:109-112 -> src/lda.cpp:142-156 -> LDA::updateVariablesVI,
+ * src/lda.cpp:160-220.  Called by python/src/ldainterface.cpp:367-370
+ * (update_variables / do_e_step).
+ *   gamma     in: initial gamma (K x B);  out: gamma after inference
+ *   sstats    out: K x V sufficient statistics (already multiplied by exp E[log beta])
+ *   iters_out optional (may be NULL): fixed-point iterations executed per document
+ *   device    HIP device ordinal
+ * Uploads, runs the HIP kernels, downloads, synchronises.
+ */
+int trlda_estep(int K, int V, int B,
+                const int32_t *indptr, const int32_t *ids, const int32_t *cnts,
+                const double *lambda, const double *alpha,
+                double *gamma, double *sstats,
+                int max_iter, double threshold, int32_t *iters_out, int device);
+
+/* lambda = (1-rho) lambda' + rho (eta + scale * sstats): src/onlinelda.cpp:99-100 and
+ * :108-109 (scale = D / B); src/batchlda.cpp:60 is the rho = 1, scale = 1 case. */
+int trlda_mstep_blend(int K, int V, double rho, double eta, double scale,
+                      const double *lambda_prime, const double *sstats,
+                      double *lambda_out, int device);
+
+/* Trust-region initial step, src/onlinelda.cpp:79-86:
+ * lambda[:, w] = (1-rho) lambda'[:, w] + rho (eta + D/B/K * wordcounts[w]). */
+int trlda_tr_init(int K, int V, int B, int num_documents, double rho, double eta,
+                  const int32_t *indptr, const int32_t *ids, const int32_t *cnts,
+                  const double *lambda_prime, double *lambda_out, int device);
+
+/* ---- device memory helpers (so a host program needs no HIP headers) ---- */
+
+int trlda_dev_alloc(int device, size_t bytes, void **dev_out);
+int trlda_dev_free(int device, void *dev);
+int trlda_dev_upload(int device, void *dev_dst, const void *host_src, size_t bytes);
+int trlda_dev_download(int device, void *host_dst, const void *dev_src, size_t bytes);
+int trlda_dev_synchronize(int device);
+
+/* ---- batches ------------------------------------------------------------ */
+
+/* Validates (monotone indptr, 0 <= id < V), uploads the CSR arrays and builds the
+ * word-major index (stable counting sort by word id) used by the segmented
+ * sufficient-statistics kernel.  Replaces PyList_ToDocuments' deep copy
+ * (python/src/ldainterface.cpp:152-190). */
+int trlda_batch_create(trlda_batch **out, int device, int V, int B,
+                       const int32_t *indptr, const int32_t *ids, const int32_t *cnts);
+int trlda_batch_destroy(trlda_batch *batch);
+int trlda_batch_num_docs(const trlda_batch *batch);
+int64_t trlda_batch_nnz(const trlda_batch *batch);
+int trlda_batch_max_doc_len(const trlda_batch *batch);
+
+/* ---- device-resident model ---------------------------------------------- */
+
+/* State of TRLDA::LDA (include/lda.h:196-199: mAlpha, mEta, mLambda) kept in HBM.
+ * lambda is NOT initialised here: the host mirror draws it with
+ * trlda_sample_gamma_init (as src/lda.cpp:71 does) and uploads it. */
+int trlda_model_create(trlda_model **out, int device, int K, int V);
+int trlda_model_destroy(trlda_model *model);
+int trlda_model_set_stream(trlda_model *model, void *hip_stream /* hipStream_t */);
+int trlda_model_set_sstats_mode(trlda_model *model, int mode);
+/* threads per document workgroup in the E-step kernel: 0 = auto, else 64..1024 (x64) */
+int trlda_model_set_doc_threads(trlda_model *model, int threads);
+int trlda_model_synchronize(trlda_model *model);
+
+int trlda_model_set_lambda(trlda_model *model, const double *host_lambda /* K x V */);
+int trlda_model_get_lambda(trlda_model *model, double *host_lambda /* K x V */);
+int trlda_model_set_alpha(trlda_model *model, const double *host_alpha /* K */);
+void *trlda_model_lambda_dev(trlda_model *model);   /* K x V fp64, device */
+
+/*
+ * Device-pointer E-step on the model's current lambda: src/lda.cpp:160-220.
+ *   gamma_dev  K x B in/out;  sstats_dev K x V out;  iters_dev B int32 or NULL.
+ * Launch sequence: row sums -> exp E[log beta] -> per-document
+ * fixed point -> per-word sufficient statistics (x exp E[log beta]).
+ */
+int trlda_model_estep(trlda_model *model, const trlda_batch *batch,
+                      double *gamma_dev, double *sstats_dev,
+                      int max_iter, double threshold, int32_t *iters_dev);
+
+/* Host-pointer convenience around trlda_model_estep (uploads gamma0, downloads
+ * gamma / sstats / iters, synchronises). */
+int trlda_model_estep_host(trlda_model *model, const trlda_batch *batch,
+                           double *gamma, double *sstats,
+                           int max_iter, double threshold, int32_t *iters_out);
+
+/* model.lambda = (1-rho) lambda' + rho (eta + scale * sstats), all device pointers.
+ * src/onlinelda.cpp:99-100, :108-109; src/batchlda.cpp:60 (rho = 1, scale = 1). */
+int trlda_model_blend(trlda_model *model, const double *lambda_prime_dev,
+                      const double *sstats_dev, double rho, double eta, double scale);
+
+/* model.lambda = (1-rho) lambda' (+row) rho (eta + D/B/K * wordcounts): src/onlinelda.cpp:79-86 */
+int trlda_model_tr_init(trlda_model *model, const trlda_batch *batch,
+                        const double *lambda_prime_dev, double rho, double eta,
+                        int num_documents);
+
+/*
+ * OnlineLDA::updateParameters, lambda path: src/onlinelda.cpp:53-111, 177-179 (the
+ * caller of python/src/onlineldainterface.cpp:204-256).  Runs the whole
+ * trust-region loop on the device; gamma initial values are drawn on the host from
+ * libc rand() at exactly the points the reference draws them (src/lda.cpp:135) so
+ * trlda_seed() pins the trajectory.  threshold is the reference's fixed 0.001
+ * unless overridden.  Returns rho through *rho_out and increments *update_count
+ * (not for an empty batch: src/onlinelda.cpp:54-56, which returns 1.0).
+ *   gamma_out  optional host K x B: gamma of the last E-step
+ * Single GPU.  The multi-GPU composition (E-step -> RCCL all-reduce of sstats ->
+ * blend) is done by the host mirror from the three calls above.
+ */
+int trlda_model_online_update(trlda_model *model, const trlda_batch *batch,
+                              int num_documents, double eta,
+                              int max_iter_tr, int max_iter_inference,
+                              double kappa, double tau, double rho,
+                              int init_gamma, int update_lambda, double threshold,
+                              int *update_count, double *rho_out, double *gamma_out);
+
+/*
+ * BatchLDA::updateParameters, lambda path: src/batchlda.cpp:43-61 -- max_epochs x
+ * { E-step from a fresh random gamma; lambda = eta + sstats }.
+ */
+int trlda_model_batch_update(trlda_model *model, const trlda_batch *batch, double eta,
+                             int max_epochs, int max_iter_inference, int update_lambda,
+                             double threshold, double *gamma_out);
+
+/* ---- measurement --------------------------------------------------------- */
+
+/* Average duration in microseconds (HIP events on the model's stream) of the
+ * kernels launched by the most recent trlda_model_estep when timing is on:
+ * which = 0 row sums, 1 exp E[log beta], 2 per-document fixed point,
+ * 3 sufficient statistics.  Timing adds event records to the stream. */
+int trlda_model_set_timing(trlda_model *model, int enabled);
+int trlda_model_get_timing(trlda_model *model, int which, double *usec_sum, int64_t *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRLDA_HIP_H */

@@ -1,0 +1,114 @@
+"""ctypes binding of libtrlda_hip.so (include/trlda_hip.h).
+
+The library is the product: there is no Python or CPU fallback.  If the shared
+object is missing, or no GPU is visible, the functions here raise
+``RuntimeError`` -- loudly, by design.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libtrlda_hip.so")
+
+OK = 0
+ERR_ARG, ERR_SHAPE, ERR_WORD_ID, ERR_NO_DEVICE, ERR_HIP, ERR_VALUE = -1, -2, -3, -4, -5, -6
+SSTATS_SEGMENTED, SSTATS_ATOMIC = 0, 1
+
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+f64p = np.ctypeslib.ndpointer(np.float64, flags="F_CONTIGUOUS")
+vp = C.c_void_p
+
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "trlda_last_error": (C.c_char_p, []),
+    "trlda_version": (C.c_int, []),
+    "trlda_device_count": (C.c_int, []),
+    "trlda_seed": (None, [C.c_uint]),
+    "trlda_sample_gamma": (None, [C.c_int, C.c_int, C.c_int, f64p]),
+    "trlda_sample_gamma_init": (None, [C.c_int, C.c_int, f64p]),
+    "trlda_estep": (C.c_int, [C.c_int, C.c_int, C.c_int, i32p, i32p, i32p, f64p, f64p, f64p, f64p,
+                              C.c_int, C.c_double, vp, C.c_int]),
+    "trlda_mstep_blend": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, f64p,
+                                    f64p, f64p, C.c_int]),
+    "trlda_tr_init": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, i32p,
+                                i32p, i32p, f64p, f64p, C.c_int]),
+    "trlda_dev_alloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(vp)]),
+    "trlda_dev_free": (C.c_int, [C.c_int, vp]),
+    "trlda_dev_upload": (C.c_int, [C.c_int, vp, vp, C.c_size_t]),
+    "trlda_dev_download": (C.c_int, [C.c_int, vp, vp, C.c_size_t]),
+    "trlda_dev_synchronize": (C.c_int, [C.c_int]),
+    "trlda_batch_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, i32p, i32p, i32p]),
+    "trlda_batch_destroy": (C.c_int, [vp]),
+    "trlda_batch_num_docs": (C.c_int, [vp]),
+    "trlda_batch_nnz": (C.c_int64, [vp]),
+    "trlda_batch_max_doc_len": (C.c_int, [vp]),
+    "trlda_model_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int]),
+    "trlda_model_destroy": (C.c_int, [vp]),
+    "trlda_model_set_stream": (C.c_int, [vp, vp]),
+    "trlda_model_set_sstats_mode": (C.c_int, [vp, C.c_int]),
+    "trlda_model_set_doc_threads": (C.c_int, [vp, C.c_int]),
+    "trlda_model_synchronize": (C.c_int, [vp]),
+    "trlda_model_set_lambda": (C.c_int, [vp, f64p]),
+    "trlda_model_get_lambda": (C.c_int, [vp, f64p]),
+    "trlda_model_set_alpha": (C.c_int, [vp, f64p]),
+    "trlda_model_lambda_dev": (vp, [vp]),
+    "trlda_model_estep": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_double, vp]),
+    "trlda_model_estep_host": (C.c_int, [vp, vp, f64p, f64p, C.c_int, C.c_double, vp]),
+    "trlda_model_blend": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, C.c_double]),
+    "trlda_model_tr_init": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, C.c_int]),
+    "trlda_model_online_update": (C.c_int, [vp, vp, C.c_int, C.c_double, C.c_int, C.c_int,
+                                            C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
+                                            C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                            vp]),
+    "trlda_model_batch_update": (C.c_int, [vp, vp, C.c_double, C.c_int, C.c_int, C.c_int,
+                                           C.c_double, vp]),
+    "trlda_model_set_timing": (C.c_int, [vp, C.c_int]),
+    "trlda_model_get_timing": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double),
+                                         C.POINTER(C.c_int64)]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the .so was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "trlda_amd: %s not found -- build it with `python -m trlda_amd.build` "
+                "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = L
+    return _lib
+
+
+class TrldaError(RuntimeError):
+    """A TRLDA::Exception-equivalent (reference include/exception.h -> RuntimeError)."""
+
+    def __init__(self, code, message):
+        RuntimeError.__init__(self, message)
+        self.code = code
+
+
+def check(rc):
+    if rc != OK:
+        raise TrldaError(rc, lib().trlda_last_error().decode() or "trlda_hip error %d" % rc)
+
+
+def device_count():
+    return lib().trlda_device_count()
+
+
+def require_gpu():
+    if device_count() < 1:
+        raise TrldaError(ERR_NO_DEVICE, "trlda_amd needs an AMD GPU (gfx950); no HIP device is "
+                                        "visible and there is no CPU fallback")

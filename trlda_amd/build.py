@@ -1,0 +1,47 @@
+"""Build libtrlda_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m trlda_amd.build            # build if stale
+    python -m trlda_amd.build --force
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_PKG, "csrc")
+LIB_PATH = os.path.join(_PKG, "libtrlda_hip.so")
+SOURCES = ["trlda_hip.hip"]
+HEADERS = ["estep_kernels.h", "psi.h", os.path.join("..", "..", "include", "trlda_hip.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+               "-munsafe-fp-atomics", "-Wall"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm >= 7.0)")
+
+
+def is_stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    built = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(_CSRC, f) for f in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > built for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile the HIP kernels + C ABI into trlda_amd/libtrlda_hip.so."""
+    if not force and not is_stale():
+        return LIB_PATH
+    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH] + [os.path.join(_CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=_CSRC)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,918 @@
+// trlda_hip.hip -- C ABI (include/trlda_hip.h) over the gfx950 kernels in
+// estep_kernels.h.  Host logic only: validation, device memory, launch sequences,
+// and the control loops of OnlineLDA::updateParameters (reference
+// src/onlinelda.cpp:53-111) and BatchLDA::updateParameters (src/batchlda.cpp:43-61).
+//
+// There is no CPU compute path in this file: if HIP cannot see a device, every
+// compute entry point fails with TRLDA_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/trlda_hip.h"
+#include "estep_kernels.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string &msg)
+{
+    g_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t err__ = (expr);                                                      \
+        if (err__ != hipSuccess)                                                        \
+            return fail(err__ == hipErrorNoDevice || err__ == hipErrorInvalidDevice     \
+                            ? TRLDA_ERR_NO_DEVICE                                       \
+                            : TRLDA_ERR_HIP,                                            \
+                        std::string(#expr) + ": " + hipGetErrorString(err__));          \
+    } while (0)
+
+constexpr int kLdsBytes = 160 * 1024;   // LDS per workgroup on gfx950
+constexpr int kDenseThreads = 256;
+constexpr int kMaxRowsumBlocks = 256;
+
+template <typename T>
+int dev_alloc(T **p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0)
+        count = 1;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T)));
+    return TRLDA_OK;
+}
+
+int use_device(int device)
+{
+    int n = 0;
+    hipError_t err = hipGetDeviceCount(&n);
+    if (err != hipSuccess || n <= 0)
+        return fail(TRLDA_ERR_NO_DEVICE,
+                    "no HIP device available (libtrlda_hip has no CPU fallback)");
+    if (device < 0 || device >= n)
+        return fail(TRLDA_ERR_NO_DEVICE, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    return TRLDA_OK;
+}
+
+}  // namespace
+
+struct trlda_batch {
+    int device = 0;
+    int V = 0, B = 0, max_n = 0;
+    int64_t nnz = 0;
+    int32_t *indptr = nullptr, *ids = nullptr, *cnts = nullptr;
+    int32_t *order = nullptr;   // documents by decreasing length
+    int32_t *wrank = nullptr;   // CSR position -> rank in word-major order
+    int32_t *wptr = nullptr;    // V+1 word segment offsets
+    int32_t *wdoc = nullptr;    // document of each word-major entry
+};
+
+struct trlda_model {
+    int device = 0;
+    int K = 0, V = 0;
+    hipStream_t stream = nullptr;
+    int sstats_mode = TRLDA_SSTATS_SEGMENTED;
+    int doc_threads = 0;
+    double *lambda = nullptr, *alpha = nullptr;
+    double *eeb = nullptr, *psi_sum = nullptr, *partial = nullptr;
+    unsigned int *counter = nullptr;
+    // per-batch workspaces, grown on demand
+    size_t cap_docs = 0, cap_nnz = 0;
+    double *epg = nullptr, *tw_csr = nullptr, *tw_word = nullptr;
+    // update_parameters workspaces
+    double *lambda_prime = nullptr, *sstats = nullptr, *gamma = nullptr, *wordcounts = nullptr;
+    size_t cap_gamma = 0;
+    // timing
+    bool timing = false;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    double usec_sum[4] = {0, 0, 0, 0};
+    int64_t usec_cnt[4] = {0, 0, 0, 0};
+    bool ev_pending = false;
+};
+
+namespace {
+
+int ensure_batch_workspace(trlda_model *m, const trlda_batch *b)
+{
+    if ((size_t)b->B > m->cap_docs) {
+        if (m->epg)
+            HIP_TRY(hipFree(m->epg));
+        int rc = dev_alloc(&m->epg, (size_t)b->B * m->K);
+        if (rc)
+            return rc;
+        m->cap_docs = (size_t)b->B;
+    }
+    if ((size_t)b->nnz > m->cap_nnz) {
+        if (m->tw_csr)
+            HIP_TRY(hipFree(m->tw_csr));
+        if (m->tw_word)
+            HIP_TRY(hipFree(m->tw_word));
+        int rc = dev_alloc(&m->tw_csr, (size_t)b->nnz);
+        if (rc)
+            return rc;
+        rc = dev_alloc(&m->tw_word, (size_t)b->nnz);
+        if (rc)
+            return rc;
+        m->cap_nnz = (size_t)b->nnz;
+    }
+    return TRLDA_OK;
+}
+
+int ensure_update_workspace(trlda_model *m, int B)
+{
+    size_t KV = (size_t)m->K * m->V;
+    if (!m->lambda_prime) {
+        int rc = dev_alloc(&m->lambda_prime, KV);
+        if (rc)
+            return rc;
+        rc = dev_alloc(&m->sstats, KV);
+        if (rc)
+            return rc;
+        rc = dev_alloc(&m->wordcounts, (size_t)m->V);
+        if (rc)
+            return rc;
+    }
+    if ((size_t)B * m->K > m->cap_gamma) {
+        if (m->gamma)
+            HIP_TRY(hipFree(m->gamma));
+        int rc = dev_alloc(&m->gamma, (size_t)B * m->K);
+        if (rc)
+            return rc;
+        m->cap_gamma = (size_t)B * m->K;
+    }
+    return TRLDA_OK;
+}
+
+void collect_timing(trlda_model *m)
+{
+    if (!m->ev_pending)
+        return;
+    if (hipEventSynchronize(m->ev[4]) == hipSuccess) {
+        for (int i = 0; i < 4; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, m->ev[i], m->ev[i + 1]) == hipSuccess) {
+                m->usec_sum[i] += 1e3 * (double)ms;
+                m->usec_cnt[i] += 1;
+            }
+        }
+    }
+    m->ev_pending = false;
+}
+
+template <int T>
+int launch_docs(trlda_model *m, const trlda::DocKernelArgs &args, int B, size_t lds_bytes)
+{
+    auto kern = trlda::estep_docs_kernel<T>;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(B), dim3(T), lds_bytes, m->stream, args);
+    HIP_TRY(hipGetLastError());
+    return TRLDA_OK;
+}
+
+size_t docs_lds_bytes(int K, int Kp, int n_cap, int T)
+{
+    size_t doubles = (size_t)n_cap * Kp + 2 * (size_t)K + (size_t)n_cap + (size_t)std::max(T, K) +
+                     (size_t)(T / trlda::kWave);
+    return doubles * sizeof(double);
+}
+
+// The E-step launch sequence on the model's stream (no synchronisation).
+int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double *sstats_dev,
+                 int max_iter, double threshold, int32_t *iters_dev)
+{
+    using namespace trlda;
+    const int K = m->K, V = m->V, B = b->B;
+    const size_t KV = (size_t)K * V;
+    if (b->V != V)
+        return fail(TRLDA_ERR_SHAPE, "batch was created for a different vocabulary size");
+    if (b->device != m->device)
+        return fail(TRLDA_ERR_ARG, "batch and model live on different devices");
+    int rc = ensure_batch_workspace(m, b);
+    if (rc)
+        return rc;
+    if (m->timing)
+        collect_timing(m);
+
+    const bool atomic = m->sstats_mode == TRLDA_SSTATS_ATOMIC;
+    if (m->timing)
+        HIP_TRY(hipEventRecord(m->ev[0], m->stream));
+
+    // 1. psiSum (lda.cpp:172)
+    {
+        int G = std::min(kMaxRowsumBlocks, std::max(1, V));
+        int wpb = (V + G - 1) / G;
+        G = (V + wpb - 1) / wpb;
+        hipLaunchKernelGGL(rowsum_psi_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads), 0,
+                           m->stream, K, V, wpb, m->lambda, m->partial, m->psi_sum, m->counter);
+        HIP_TRY(hipGetLastError());
+    }
+    if (m->timing)
+        HIP_TRY(hipEventRecord(m->ev[1], m->stream));
+
+    // 2. exp E[log beta] (lda.cpp:173)
+    {
+        size_t blocks = (KV + kDenseThreads - 1) / kDenseThreads;
+        int G = (int)std::min<size_t>(blocks, 256 * 16);
+        hipLaunchKernelGGL(exp_elog_beta_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads), 0,
+                           m->stream, K, KV, m->lambda, m->psi_sum, m->eeb);
+        HIP_TRY(hipGetLastError());
+    }
+    if (m->timing)
+        HIP_TRY(hipEventRecord(m->ev[2], m->stream));
+
+    // 3. per-document fixed point (lda.cpp:174-204)
+    if (atomic)
+        HIP_TRY(hipMemsetAsync(sstats_dev, 0, KV * sizeof(double), m->stream));  // lda.cpp:169
+    if (B > 0) {
+        int T = m->doc_threads;
+        if (T <= 0)
+            T = 256;
+        const int Kp = K | 1;
+        size_t fixed = docs_lds_bytes(K, Kp, 0, T);
+        int n_fit = fixed >= (size_t)kLdsBytes
+                        ? 0
+                        : (int)(((size_t)kLdsBytes - fixed) / ((size_t)(Kp + 1) * sizeof(double)));
+        int n_cap = std::min(b->max_n, n_fit);
+        size_t lds_bytes = docs_lds_bytes(K, Kp, n_cap, T);
+        if (lds_bytes > (size_t)kLdsBytes)
+            return fail(TRLDA_ERR_ARG, "num_topics too large for the document kernel's LDS layout");
+
+        DocKernelArgs a;
+        a.K = K; a.Kp = Kp; a.n_cap = n_cap; a.B = B;
+        a.indptr = b->indptr; a.ids = b->ids; a.cnts = b->cnts; a.order = b->order;
+        a.eeb = m->eeb; a.alpha = m->alpha;
+        a.gamma = gamma_dev; a.epg = m->epg; a.tw_csr = m->tw_csr;
+        a.wrank = b->wrank; a.tw_word = m->tw_word;
+        a.sstats_acc = atomic ? sstats_dev : nullptr;
+        a.max_iter = max_iter; a.threshold = threshold; a.iters_out = iters_dev;
+        switch (T) {
+        case 64: rc = launch_docs<64>(m, a, B, lds_bytes); break;
+        case 128: rc = launch_docs<128>(m, a, B, lds_bytes); break;
+        case 256: rc = launch_docs<256>(m, a, B, lds_bytes); break;
+        case 512: rc = launch_docs<512>(m, a, B, lds_bytes); break;
+        case 1024: rc = launch_docs<1024>(m, a, B, lds_bytes); break;
+        default: return fail(TRLDA_ERR_ARG, "doc_threads must be 64, 128, 256, 512 or 1024");
+        }
+        if (rc)
+            return rc;
+    }
+    if (m->timing)
+        HIP_TRY(hipEventRecord(m->ev[3], m->stream));
+
+    // 4. sufficient statistics (lda.cpp:207-217)
+    if (atomic) {
+        size_t blocks = (KV + kDenseThreads - 1) / kDenseThreads;
+        int G = (int)std::min<size_t>(blocks, 256 * 8);
+        hipLaunchKernelGGL(finish_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads), 0, m->stream,
+                           KV, m->eeb, sstats_dev);
+    } else {
+        constexpr int wpb = kDenseThreads / kWave;
+        int G = (V + wpb - 1) / wpb;
+        hipLaunchKernelGGL(sstats_words_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads), 0,
+                           m->stream, K, V, b->wptr, b->wdoc, m->tw_word, m->epg, m->eeb,
+                           sstats_dev);
+    }
+    HIP_TRY(hipGetLastError());
+    if (m->timing) {
+        HIP_TRY(hipEventRecord(m->ev[4], m->stream));
+        m->ev_pending = true;
+    }
+    return TRLDA_OK;
+}
+
+int blend_device(trlda_model *m, const double *lambda_prime, const double *sstats, double rho,
+                 double eta, double scale)
+{
+    size_t KV = (size_t)m->K * m->V;
+    size_t blocks = (KV + kDenseThreads - 1) / kDenseThreads;
+    int G = (int)std::min<size_t>(blocks, 256 * 8);
+    hipLaunchKernelGGL(trlda::blend_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads), 0,
+                       m->stream, KV, rho, eta, scale, lambda_prime, sstats, m->lambda);
+    HIP_TRY(hipGetLastError());
+    return TRLDA_OK;
+}
+
+int tr_init_device(trlda_model *m, const trlda_batch *b, const double *lambda_prime, double rho,
+                   double eta, int num_documents)
+{
+    int rc = ensure_update_workspace(m, b->B);
+    if (rc)
+        return rc;
+    size_t KV = (size_t)m->K * m->V;
+    HIP_TRY(hipMemsetAsync(m->wordcounts, 0, (size_t)m->V * sizeof(double), m->stream));
+    if (b->nnz > 0) {
+        size_t blocks = ((size_t)b->nnz + kDenseThreads - 1) / kDenseThreads;
+        int G = (int)std::min<size_t>(blocks, 256 * 8);
+        hipLaunchKernelGGL(trlda::wordcount_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads), 0,
+                           m->stream, b->nnz, b->ids, b->cnts, m->wordcounts);
+    }
+    // static_cast<double>(D) / B / K, evaluated in the reference's order (onlinelda.cpp:86)
+    double coef = (double)num_documents / (double)b->B / (double)m->K;
+    size_t blocks = (KV + kDenseThreads - 1) / kDenseThreads;
+    int G = (int)std::min<size_t>(blocks, 256 * 8);
+    hipLaunchKernelGGL(trlda::tr_init_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads), 0,
+                       m->stream, m->K, KV, rho, eta, coef, m->wordcounts, lambda_prime, m->lambda);
+    HIP_TRY(hipGetLastError());
+    return TRLDA_OK;
+}
+
+int check_model(const trlda_model *m)
+{
+    if (!m)
+        return fail(TRLDA_ERR_ARG, "model is NULL");
+    return use_device(m->device);
+}
+
+}  // namespace
+
+// ===========================================================================
+extern "C" {
+
+const char *trlda_last_error(void) { return g_error.c_str(); }
+
+int trlda_version(void) { return 100; }
+
+int trlda_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+// ---- host RNG ---------------------------------------------------------------
+
+void trlda_seed(unsigned int seed) { srand(seed); }
+
+void trlda_sample_gamma(int m, int n, int k, double *out)
+{
+    const int64_t total = (int64_t)m * n;
+    for (int64_t i = 0; i < total; ++i)
+        out[i] = 0.0;
+    for (int pass = 0; pass < k; ++pass)
+        for (int64_t i = 0; i < total; ++i) {
+            const double u = -1.0 + 2.0 * (double)rand() / (double)RAND_MAX;
+            out[i] -= std::log(std::fabs(u));
+        }
+}
+
+void trlda_sample_gamma_init(int m, int n, double *out)
+{
+    trlda_sample_gamma(m, n, 100, out);
+    const int64_t total = (int64_t)m * n;
+    for (int64_t i = 0; i < total; ++i)
+        out[i] /= 100.;
+}
+
+// ---- device memory helpers ----------------------------------------------------
+
+int trlda_dev_alloc(int device, size_t bytes, void **dev_out)
+{
+    if (!dev_out)
+        return fail(TRLDA_ERR_ARG, "dev_out is NULL");
+    int rc = use_device(device);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMalloc(dev_out, bytes ? bytes : 1));
+    return TRLDA_OK;
+}
+
+int trlda_dev_free(int device, void *dev)
+{
+    int rc = use_device(device);
+    if (rc)
+        return rc;
+    HIP_TRY(hipFree(dev));
+    return TRLDA_OK;
+}
+
+int trlda_dev_upload(int device, void *dev_dst, const void *host_src, size_t bytes)
+{
+    int rc = use_device(device);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
+    return TRLDA_OK;
+}
+
+int trlda_dev_download(int device, void *host_dst, const void *dev_src, size_t bytes)
+{
+    int rc = use_device(device);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
+    return TRLDA_OK;
+}
+
+int trlda_dev_synchronize(int device)
+{
+    int rc = use_device(device);
+    if (rc)
+        return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    return TRLDA_OK;
+}
+
+// ---- batches ------------------------------------------------------------------
+
+int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_t *indptr,
+                       const int32_t *ids, const int32_t *cnts)
+{
+    if (!out)
+        return fail(TRLDA_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (V <= 0 || B < 0 || !indptr)
+        return fail(TRLDA_ERR_ARG, "bad batch dimensions");
+    if (indptr[0] != 0)
+        return fail(TRLDA_ERR_ARG, "indptr[0] must be 0");
+    int max_n = 0;
+    for (int d = 0; d < B; ++d) {
+        if (indptr[d + 1] < indptr[d])
+            return fail(TRLDA_ERR_ARG, "indptr must be non-decreasing");
+        max_n = std::max(max_n, indptr[d + 1] - indptr[d]);
+    }
+    const int64_t nnz = indptr[B];
+    if (nnz > 0 && (!ids || !cnts))
+        return fail(TRLDA_ERR_ARG, "ids / cnts are NULL");
+    for (int64_t i = 0; i < nnz; ++i)
+        if (ids[i] < 0 || ids[i] >= V)
+            return fail(TRLDA_ERR_WORD_ID, "word id outside [0, num_words)");
+
+    int rc = use_device(device);
+    if (rc)
+        return rc;
+
+    // word-major index: stable counting sort of the CSR positions by word id
+    std::vector<int32_t> wptr((size_t)V + 1, 0), wrank((size_t)std::max<int64_t>(nnz, 1)),
+        wdoc((size_t)std::max<int64_t>(nnz, 1)), order((size_t)std::max(B, 1));
+    for (int64_t i = 0; i < nnz; ++i)
+        ++wptr[(size_t)ids[i] + 1];
+    for (int w = 0; w < V; ++w)
+        wptr[(size_t)w + 1] += wptr[(size_t)w];
+    {
+        std::vector<int32_t> cursor(wptr.begin(), wptr.end() - 1);
+        for (int d = 0; d < B; ++d)
+            for (int32_t p = indptr[d]; p < indptr[d + 1]; ++p) {
+                int32_t q = cursor[(size_t)ids[p]]++;
+                wrank[(size_t)p] = q;
+                wdoc[(size_t)q] = d;
+            }
+    }
+    std::iota(order.begin(), order.begin() + B, 0);
+    std::stable_sort(order.begin(), order.begin() + B, [&](int32_t x, int32_t y) {
+        return indptr[x + 1] - indptr[x] > indptr[y + 1] - indptr[y];
+    });
+
+    trlda_batch *b = new trlda_batch();
+    b->device = device; b->V = V; b->B = B; b->nnz = nnz; b->max_n = max_n;
+    auto up = [&](int32_t **dst, const int32_t *src, size_t count) -> int {
+        int r = dev_alloc(dst, count);
+        if (r)
+            return r;
+        if (count)
+            HIP_TRY(hipMemcpy(*dst, src, count * sizeof(int32_t), hipMemcpyHostToDevice));
+        return TRLDA_OK;
+    };
+    rc = up(&b->indptr, indptr, (size_t)B + 1);
+    if (!rc) rc = up(&b->ids, ids, (size_t)nnz);
+    if (!rc) rc = up(&b->cnts, cnts, (size_t)nnz);
+    if (!rc) rc = up(&b->order, order.data(), (size_t)B);
+    if (!rc) rc = up(&b->wrank, wrank.data(), (size_t)nnz);
+    if (!rc) rc = up(&b->wptr, wptr.data(), (size_t)V + 1);
+    if (!rc) rc = up(&b->wdoc, wdoc.data(), (size_t)nnz);
+    if (rc) {
+        trlda_batch_destroy(b);
+        return rc;
+    }
+    *out = b;
+    return TRLDA_OK;
+}
+
+int trlda_batch_destroy(trlda_batch *b)
+{
+    if (!b)
+        return TRLDA_OK;
+    if (hipSetDevice(b->device) == hipSuccess) {
+        (void)hipFree(b->indptr); (void)hipFree(b->ids); (void)hipFree(b->cnts); (void)hipFree(b->order);
+        (void)hipFree(b->wrank); (void)hipFree(b->wptr); (void)hipFree(b->wdoc);
+    }
+    delete b;
+    return TRLDA_OK;
+}
+
+int trlda_batch_num_docs(const trlda_batch *b) { return b ? b->B : 0; }
+int64_t trlda_batch_nnz(const trlda_batch *b) { return b ? b->nnz : 0; }
+int trlda_batch_max_doc_len(const trlda_batch *b) { return b ? b->max_n : 0; }
+
+// ---- model --------------------------------------------------------------------
+
+int trlda_model_create(trlda_model **out, int device, int K, int V)
+{
+    if (!out)
+        return fail(TRLDA_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    if (K <= 0 || V <= 0)
+        return fail(TRLDA_ERR_ARG, "num_topics and num_words must be positive");
+    int rc = use_device(device);
+    if (rc)
+        return rc;
+    trlda_model *m = new trlda_model();
+    m->device = device; m->K = K; m->V = V;
+    size_t KV = (size_t)K * V;
+    rc = dev_alloc(&m->lambda, KV);
+    if (!rc) rc = dev_alloc(&m->eeb, KV);
+    if (!rc) rc = dev_alloc(&m->alpha, (size_t)K);
+    if (!rc) rc = dev_alloc(&m->psi_sum, (size_t)K);
+    if (!rc) rc = dev_alloc(&m->partial, (size_t)kMaxRowsumBlocks * K);
+    if (!rc) rc = dev_alloc(&m->counter, 1);
+    if (rc) {
+        trlda_model_destroy(m);
+        return rc;
+    }
+    HIP_TRY(hipMemset(m->counter, 0, sizeof(unsigned int)));
+    for (auto &e : m->ev)
+        HIP_TRY(hipEventCreate(&e));
+    *out = m;
+    return TRLDA_OK;
+}
+
+int trlda_model_destroy(trlda_model *m)
+{
+    if (!m)
+        return TRLDA_OK;
+    if (hipSetDevice(m->device) == hipSuccess) {
+        (void)hipStreamSynchronize(m->stream);
+        (void)hipFree(m->lambda); (void)hipFree(m->alpha); (void)hipFree(m->eeb); (void)hipFree(m->psi_sum);
+        (void)hipFree(m->partial); (void)hipFree(m->counter); (void)hipFree(m->epg); (void)hipFree(m->tw_csr);
+        (void)hipFree(m->tw_word); (void)hipFree(m->lambda_prime); (void)hipFree(m->sstats); (void)hipFree(m->gamma);
+        (void)hipFree(m->wordcounts);
+        for (auto &e : m->ev)
+            if (e)
+                (void)hipEventDestroy(e);
+    }
+    delete m;
+    return TRLDA_OK;
+}
+
+int trlda_model_set_stream(trlda_model *m, void *hip_stream)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    m->stream = static_cast<hipStream_t>(hip_stream);
+    return TRLDA_OK;
+}
+
+int trlda_model_set_sstats_mode(trlda_model *m, int mode)
+{
+    if (!m)
+        return fail(TRLDA_ERR_ARG, "model is NULL");
+    if (mode != TRLDA_SSTATS_SEGMENTED && mode != TRLDA_SSTATS_ATOMIC)
+        return fail(TRLDA_ERR_ARG, "unknown sstats mode");
+    m->sstats_mode = mode;
+    return TRLDA_OK;
+}
+
+int trlda_model_set_doc_threads(trlda_model *m, int threads)
+{
+    if (!m)
+        return fail(TRLDA_ERR_ARG, "model is NULL");
+    if (threads != 0 && threads != 64 && threads != 128 && threads != 256 && threads != 512 &&
+        threads != 1024)
+        return fail(TRLDA_ERR_ARG, "doc_threads must be 0, 64, 128, 256, 512 or 1024");
+    m->doc_threads = threads;
+    return TRLDA_OK;
+}
+
+int trlda_model_synchronize(trlda_model *m)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return TRLDA_OK;
+}
+
+int trlda_model_set_lambda(trlda_model *m, const double *host_lambda)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!host_lambda)
+        return fail(TRLDA_ERR_ARG, "lambda is NULL");
+    HIP_TRY(hipMemcpyAsync(m->lambda, host_lambda, (size_t)m->K * m->V * sizeof(double),
+                           hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return TRLDA_OK;
+}
+
+int trlda_model_get_lambda(trlda_model *m, double *host_lambda)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!host_lambda)
+        return fail(TRLDA_ERR_ARG, "lambda is NULL");
+    HIP_TRY(hipMemcpyAsync(host_lambda, m->lambda, (size_t)m->K * m->V * sizeof(double),
+                           hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return TRLDA_OK;
+}
+
+int trlda_model_set_alpha(trlda_model *m, const double *host_alpha)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!host_alpha)
+        return fail(TRLDA_ERR_ARG, "alpha is NULL");
+    for (int k = 0; k < m->K; ++k)
+        if (host_alpha[k] < 0.)
+            return fail(TRLDA_ERR_VALUE, "Alpha should not be negative.");  // lda.h:147-159
+    HIP_TRY(hipMemcpyAsync(m->alpha, host_alpha, (size_t)m->K * sizeof(double),
+                           hipMemcpyHostToDevice, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return TRLDA_OK;
+}
+
+void *trlda_model_lambda_dev(trlda_model *m) { return m ? m->lambda : nullptr; }
+
+int trlda_model_estep(trlda_model *m, const trlda_batch *b, double *gamma_dev, double *sstats_dev,
+                      int max_iter, double threshold, int32_t *iters_dev)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!b || !sstats_dev || (b->B > 0 && !gamma_dev))
+        return fail(TRLDA_ERR_ARG, "NULL batch / gamma / sstats");
+    return estep_device(m, b, gamma_dev, sstats_dev, max_iter, threshold, iters_dev);
+}
+
+int trlda_model_estep_host(trlda_model *m, const trlda_batch *b, double *gamma, double *sstats,
+                           int max_iter, double threshold, int32_t *iters_out)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!b || !sstats || (b->B > 0 && !gamma))
+        return fail(TRLDA_ERR_ARG, "NULL batch / gamma / sstats");
+    rc = ensure_update_workspace(m, b->B);
+    if (rc)
+        return rc;
+    const size_t gbytes = (size_t)m->K * b->B * sizeof(double);
+    const size_t sbytes = (size_t)m->K * m->V * sizeof(double);
+    int32_t *iters_dev = nullptr;
+    if (iters_out) {
+        rc = dev_alloc(&iters_dev, (size_t)b->B);
+        if (rc)
+            return rc;
+    }
+    if (gbytes)
+        HIP_TRY(hipMemcpyAsync(m->gamma, gamma, gbytes, hipMemcpyHostToDevice, m->stream));
+    rc = estep_device(m, b, m->gamma, m->sstats, max_iter, threshold, iters_dev);
+    if (!rc) {
+        if (gbytes)
+            HIP_TRY(hipMemcpyAsync(gamma, m->gamma, gbytes, hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipMemcpyAsync(sstats, m->sstats, sbytes, hipMemcpyDeviceToHost, m->stream));
+        if (iters_out && b->B)
+            HIP_TRY(hipMemcpyAsync(iters_out, iters_dev, (size_t)b->B * sizeof(int32_t),
+                                   hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+    }
+    if (iters_dev)
+        (void)hipFree(iters_dev);
+    return rc;
+}
+
+int trlda_model_blend(trlda_model *m, const double *lambda_prime_dev, const double *sstats_dev,
+                      double rho, double eta, double scale)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!lambda_prime_dev || !sstats_dev)
+        return fail(TRLDA_ERR_ARG, "NULL lambda_prime / sstats");
+    return blend_device(m, lambda_prime_dev, sstats_dev, rho, eta, scale);
+}
+
+int trlda_model_tr_init(trlda_model *m, const trlda_batch *b, const double *lambda_prime_dev,
+                        double rho, double eta, int num_documents)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!b || !lambda_prime_dev || b->B <= 0)
+        return fail(TRLDA_ERR_ARG, "NULL or empty batch / lambda_prime");
+    return tr_init_device(m, b, lambda_prime_dev, rho, eta, num_documents);
+}
+
+int trlda_model_online_update(trlda_model *m, const trlda_batch *b, int num_documents, double eta,
+                              int max_iter_tr, int max_iter_inference, double kappa, double tau,
+                              double rho, int init_gamma, int update_lambda, double threshold,
+                              int *update_count, double *rho_out, double *gamma_out)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!b || !update_count || !rho_out)
+        return fail(TRLDA_ERR_ARG, "NULL batch / update_count / rho_out");
+    if (b->B == 0) {                                         // onlinelda.cpp:54-56
+        *rho_out = 1.0;
+        return TRLDA_OK;
+    }
+    if (rho < 0.)                                            // onlinelda.cpp:59-66
+        rho = std::pow(tau + (double)*update_count, -kappa);
+    *rho_out = rho;
+
+    if (update_lambda) {
+        rc = ensure_update_workspace(m, b->B);
+        if (rc)
+            return rc;
+        const int K = m->K, B = b->B;
+        const size_t KV = (size_t)K * m->V;
+        const size_t gbytes = (size_t)K * B * sizeof(double);
+        std::vector<double> gamma0((size_t)K * B);
+        const double scale = (double)num_documents / (double)B;
+
+        HIP_TRY(hipMemcpyAsync(m->lambda_prime, m->lambda, KV * sizeof(double),
+                               hipMemcpyDeviceToDevice, m->stream));
+        auto fresh_gamma = [&]() -> int {                    // lda.cpp:135
+            trlda_sample_gamma_init(K, B, gamma0.data());
+            // gamma0 is reused by the next draw: finish the upload before returning
+            HIP_TRY(hipMemcpyAsync(m->gamma, gamma0.data(), gbytes, hipMemcpyHostToDevice,
+                                   m->stream));
+            HIP_TRY(hipStreamSynchronize(m->stream));
+            return TRLDA_OK;
+        };
+        if (max_iter_tr > 0) {
+            rc = tr_init_device(m, b, m->lambda_prime, rho, eta, num_documents);
+            for (int i = 0; !rc && i < max_iter_tr; ++i) {   // onlinelda.cpp:89-101
+                if (!(i > 0 && init_gamma))
+                    rc = fresh_gamma();
+                if (!rc)
+                    rc = estep_device(m, b, m->gamma, m->sstats, max_iter_inference, threshold,
+                                      nullptr);
+                if (!rc)
+                    rc = blend_device(m, m->lambda_prime, m->sstats, rho, eta, scale);
+            }
+        } else {                                             // onlinelda.cpp:103-109
+            rc = fresh_gamma();
+            if (!rc)
+                rc = estep_device(m, b, m->gamma, m->sstats, max_iter_inference, threshold,
+                                  nullptr);
+            if (!rc)
+                rc = blend_device(m, m->lambda_prime, m->sstats, rho, eta, scale);
+        }
+        if (rc)
+            return rc;
+        if (gamma_out)
+            HIP_TRY(hipMemcpyAsync(gamma_out, m->gamma, gbytes, hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+    }
+    ++*update_count;                                         // onlinelda.cpp:177
+    return TRLDA_OK;
+}
+
+int trlda_model_batch_update(trlda_model *m, const trlda_batch *b, double eta, int max_epochs,
+                             int max_iter_inference, int update_lambda, double threshold,
+                             double *gamma_out)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!b)
+        return fail(TRLDA_ERR_ARG, "NULL batch");
+    if (b->B == 0)                                           // batchlda.cpp:44-46
+        return TRLDA_OK;
+    rc = ensure_update_workspace(m, b->B);
+    if (rc)
+        return rc;
+    const int K = m->K, B = b->B;
+    const size_t gbytes = (size_t)K * B * sizeof(double);
+    std::vector<double> gamma0((size_t)K * B);
+    for (int epoch = 0; epoch < max_epochs; ++epoch) {       // batchlda.cpp:48-61
+        if (!update_lambda)
+            continue;
+        trlda_sample_gamma_init(K, B, gamma0.data());
+        HIP_TRY(hipMemcpyAsync(m->gamma, gamma0.data(), gbytes, hipMemcpyHostToDevice, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        rc = estep_device(m, b, m->gamma, m->sstats, max_iter_inference, threshold, nullptr);
+        if (rc)
+            return rc;
+        // lambda = eta + sstats  ==  blend with rho = 1, scale = 1 (lambda' term is * 0)
+        rc = blend_device(m, m->lambda, m->sstats, 1.0, eta, 1.0);
+        if (rc)
+            return rc;
+    }
+    if (gamma_out && update_lambda && max_epochs > 0)
+        HIP_TRY(hipMemcpyAsync(gamma_out, m->gamma, gbytes, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return TRLDA_OK;
+}
+
+// ---- one-shot host-pointer entry points ---------------------------------------
+
+int trlda_estep(int K, int V, int B, const int32_t *indptr, const int32_t *ids,
+                const int32_t *cnts, const double *lambda, const double *alpha, double *gamma,
+                double *sstats, int max_iter, double threshold, int32_t *iters_out, int device)
+{
+    if (!lambda || !alpha || !sstats)
+        return fail(TRLDA_ERR_ARG, "NULL lambda / alpha / sstats");
+    trlda_model *m = nullptr;
+    trlda_batch *b = nullptr;
+    int rc = trlda_model_create(&m, device, K, V);
+    if (!rc) rc = trlda_batch_create(&b, device, V, B, indptr, ids, cnts);
+    if (!rc) rc = trlda_model_set_lambda(m, lambda);
+    if (!rc) rc = trlda_model_set_alpha(m, alpha);
+    if (!rc) rc = trlda_model_estep_host(m, b, gamma, sstats, max_iter, threshold, iters_out);
+    trlda_batch_destroy(b);
+    trlda_model_destroy(m);
+    return rc;
+}
+
+int trlda_mstep_blend(int K, int V, double rho, double eta, double scale,
+                      const double *lambda_prime, const double *sstats, double *lambda_out,
+                      int device)
+{
+    if (!lambda_prime || !sstats || !lambda_out)
+        return fail(TRLDA_ERR_ARG, "NULL lambda_prime / sstats / lambda_out");
+    trlda_model *m = nullptr;
+    int rc = trlda_model_create(&m, device, K, V);
+    if (!rc) rc = ensure_update_workspace(m, 0);
+    const size_t bytes = (size_t)K * V * sizeof(double);
+    if (!rc) {
+        hipError_t e1 = hipMemcpy(m->lambda_prime, lambda_prime, bytes, hipMemcpyHostToDevice);
+        hipError_t e2 = hipMemcpy(m->sstats, sstats, bytes, hipMemcpyHostToDevice);
+        if (e1 != hipSuccess || e2 != hipSuccess)
+            rc = fail(TRLDA_ERR_HIP, "upload failed");
+    }
+    if (!rc) rc = blend_device(m, m->lambda_prime, m->sstats, rho, eta, scale);
+    if (!rc) rc = trlda_model_get_lambda(m, lambda_out);
+    trlda_model_destroy(m);
+    return rc;
+}
+
+int trlda_tr_init(int K, int V, int B, int num_documents, double rho, double eta,
+                  const int32_t *indptr, const int32_t *ids, const int32_t *cnts,
+                  const double *lambda_prime, double *lambda_out, int device)
+{
+    if (!lambda_prime || !lambda_out)
+        return fail(TRLDA_ERR_ARG, "NULL lambda_prime / lambda_out");
+    if (B <= 0)
+        return fail(TRLDA_ERR_ARG, "empty batch");
+    trlda_model *m = nullptr;
+    trlda_batch *b = nullptr;
+    int rc = trlda_model_create(&m, device, K, V);
+    if (!rc) rc = trlda_batch_create(&b, device, V, B, indptr, ids, cnts);
+    if (!rc) rc = ensure_update_workspace(m, B);
+    if (!rc && hipMemcpy(m->lambda_prime, lambda_prime, (size_t)K * V * sizeof(double),
+                         hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(TRLDA_ERR_HIP, "upload failed");
+    if (!rc) rc = tr_init_device(m, b, m->lambda_prime, rho, eta, num_documents);
+    if (!rc) rc = trlda_model_get_lambda(m, lambda_out);
+    trlda_batch_destroy(b);
+    trlda_model_destroy(m);
+    return rc;
+}
+
+// ---- measurement ----------------------------------------------------------------
+
+int trlda_model_set_timing(trlda_model *m, int enabled)
+{
+    if (!m)
+        return fail(TRLDA_ERR_ARG, "model is NULL");
+    if (m->timing)
+        collect_timing(m);
+    m->timing = enabled != 0;
+    for (int i = 0; i < 4; ++i) {
+        m->usec_sum[i] = 0;
+        m->usec_cnt[i] = 0;
+    }
+    return TRLDA_OK;
+}
+
+int trlda_model_get_timing(trlda_model *m, int which, double *usec_sum, int64_t *count)
+{
+    if (!m || which < 0 || which > 3 || !usec_sum || !count)
+        return fail(TRLDA_ERR_ARG, "bad timing query");
+    collect_timing(m);
+    *usec_sum = m->usec_sum[which];
+    *count = m->usec_cnt[which];
+    return TRLDA_OK;
+}
+
+}  // extern "C"

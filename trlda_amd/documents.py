@@ -1,0 +1,122 @@
+"""Documents: list-of-lists-of-(id, count) tuples  <->  CSR int32  <->  device batch.
+
+Host-side counterpart of ``PyList_ToDocuments`` (reference
+python/src/ldainterface.cpp:152-190): same accepted input, same ``TypeError``
+messages, but the result is the flat CSR form of ``LDA::Documents``
+(include/lda.h:21-23) that the HIP kernels consume.
+"""
+import numpy as np
+
+from . import _ffi
+
+
+class CSRDocuments(object):
+    """A batch already in CSR form: ``indptr[B+1]``, ``ids[nnz]``, ``cnts[nnz]`` (int32).
+
+    Accepted wherever the reference accepts ``docs``; skips the per-tuple Python
+    conversion (the fast path SURVEY.md §7 "host-side document conversion" asks for).
+    """
+
+    __slots__ = ("indptr", "ids", "cnts")
+
+    def __init__(self, indptr, ids, cnts):
+        self.indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+        self.ids = np.ascontiguousarray(ids, dtype=np.int32)
+        self.cnts = np.ascontiguousarray(cnts, dtype=np.int32)
+        if self.indptr.ndim != 1 or len(self.indptr) < 1 or self.indptr[0] != 0:
+            raise TypeError("indptr must be a 1-D array starting at 0.")
+        if len(self.ids) != self.indptr[-1] or len(self.cnts) != self.indptr[-1]:
+            raise TypeError("ids / cnts length must equal indptr[-1].")
+
+    def __len__(self):
+        return len(self.indptr) - 1
+
+    def shard(self, rank, world_size):
+        """Contiguous range of documents for ``rank``, balanced by nnz."""
+        B = len(self)
+        if world_size <= 1:
+            return self
+        # cut points at equal shares of the cumulative entry count (+1 per doc so that
+        # empty documents still spread)
+        weight = self.indptr.astype(np.int64) + np.arange(B + 1, dtype=np.int64)
+        targets = weight[-1] * np.arange(world_size + 1, dtype=np.int64) // world_size
+        cuts = np.searchsorted(weight, targets, side="left")
+        cuts[0], cuts[-1] = 0, B
+        lo, hi = int(cuts[rank]), int(cuts[rank + 1])
+        p0, p1 = int(self.indptr[lo]), int(self.indptr[hi])
+        return CSRDocuments(self.indptr[lo:hi + 1] - p0, self.ids[p0:p1], self.cnts[p0:p1])
+
+    def to_list(self):
+        ip, ids, cnts = self.indptr, self.ids, self.cnts
+        return [[(int(ids[i]), int(cnts[i])) for i in range(ip[d], ip[d + 1])]
+                for d in range(len(self))]
+
+
+def as_csr(docs):
+    """Validate ``docs`` exactly as PyList_ToDocuments does and flatten it to CSR."""
+    if isinstance(docs, CSRDocuments):
+        return docs
+    if isinstance(docs, DeviceBatch):
+        return docs.csr
+    if not isinstance(docs, list):
+        raise TypeError("Documents must be stored in a list.")
+    lengths = np.empty(len(docs), dtype=np.int64)
+    for i, doc in enumerate(docs):
+        if not isinstance(doc, list):
+            raise TypeError("Each document must be a list of tuples.")
+        lengths[i] = len(doc)
+    indptr = np.zeros(len(docs) + 1, dtype=np.int64)
+    np.cumsum(lengths, out=indptr[1:])
+    nnz = int(indptr[-1])
+    if nnz >= 2 ** 31:
+        raise TypeError("Not enough memory.")
+    flat = np.empty((nnz, 2), dtype=np.int32)
+    pos = 0
+    for doc in docs:
+        for word in doc:
+            # PyArg_ParseTuple(word, "ii", ...): a tuple of exactly two integers
+            if not isinstance(word, tuple) or len(word) != 2:
+                raise TypeError("Each document must be a list of tuples.")
+            wid, cnt = word
+            if isinstance(wid, (float, np.floating)) or isinstance(cnt, (float, np.floating)):
+                raise TypeError("integer argument expected, got float")
+            flat[pos, 0] = wid
+            flat[pos, 1] = cnt
+            pos += 1
+    return CSRDocuments(indptr.astype(np.int32), flat[:, 0], flat[:, 1])
+
+
+class DeviceBatch(object):
+    """A batch resident in HBM (``trlda_batch``): CSR arrays + word-major index.
+
+    Build once with ``model.upload(docs)`` and pass it as ``docs`` to
+    ``update_parameters`` / ``update_variables`` to skip conversion and upload.
+    """
+
+    def __init__(self, docs, num_words, device):
+        self.csr = as_csr(docs)
+        self.device = device
+        self.num_words = num_words
+        self.handle = _ffi.vp()
+        L = _ffi.lib()
+        _ffi.check(L.trlda_batch_create(_ffi.C.byref(self.handle), device, num_words,
+                                        len(self.csr), self.csr.indptr, self.csr.ids,
+                                        self.csr.cnts))
+
+    def __len__(self):
+        return len(self.csr)
+
+    @property
+    def nnz(self):
+        return int(self.csr.indptr[-1])
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _ffi.lib().trlda_batch_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,350 @@
+"""``trlda_amd.models`` -- host-side mirror of ``trlda.models`` (reference
+python/models/__init__.py:1-5) for the accelerated path.
+
+Same class names, constructor arguments, properties, method signatures, defaults and
+error behaviour as the reference's CPython types (python/src/module.cpp,
+ldainterface.cpp, onlineldainterface.cpp, batchldainterface.cpp); the computation
+goes through ``libtrlda_hip.so`` (include/trlda_hip.h) to the gfx950 kernels.  State
+(lambda) lives in HBM; getters return fresh, read-only, Fortran-ordered copies just
+like ``PyArray_FromMatrixXd`` (python/src/pyutils.cpp:15-36).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .. import _ffi
+from ..documents import CSRDocuments, DeviceBatch, as_csr
+
+__all__ = ["Distribution", "LDA", "OnlineLDA", "BatchLDA"]
+
+
+def _default_device():
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def _alpha_vector(alpha, num_topics):
+    """alpha argument handling of OnlineLDA_init (onlineldainterface.cpp:58-83).
+
+    Returns (K, alpha[K]).  A scalar keeps ``num_topics``; an array *defines* K
+    (the reference calls the ArrayXd constructor and ignores num_topics)."""
+    if alpha is None:
+        alpha = .1
+    if isinstance(alpha, (float, int, np.floating, np.integer)) and not isinstance(alpha, bool):
+        return int(num_topics), np.full(int(num_topics), float(alpha), dtype=np.float64)
+    try:
+        arr = np.asarray(alpha, dtype=np.float64)
+    except (TypeError, ValueError):
+        raise TypeError("Alpha should be of type `ndarray`.")
+    if arr.ndim == 0:
+        return int(num_topics), np.full(int(num_topics), float(arr), dtype=np.float64)
+    if arr.ndim == 1:
+        arr = arr.reshape(-1, 1)
+    if arr.ndim != 2:
+        raise TypeError("Alpha should be one-dimensional.")
+    if arr.shape[0] == 1:
+        arr = arr.T
+    if arr.shape[1] != 1:
+        raise TypeError("Alpha should be one-dimensional.")
+    return arr.shape[0], np.ascontiguousarray(arr[:, 0])
+
+
+def _inference_method(name):
+    """ldainterface.cpp:343-359: first letter decides; returns 'VI' or 'GIBBS'."""
+    if name is None:
+        return "VI"
+    if not isinstance(name, str):
+        raise TypeError("`inference_method` should be either 'GIBBS' or 'VI'.")
+    first = name[:1]
+    if first in ("v", "V"):
+        return "VI"
+    if first in ("g", "G"):
+        return "GIBBS"
+    raise TypeError("`inference_method` should be either 'GIBBS' or 'VI'.")
+
+
+class Distribution(object):
+    """Abstract base (reference include/distribution.h, distributioninterface.cpp)."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("This is an abstract class.")
+
+
+class LDA(Distribution):
+    """Base of the LDA models: state + the E-step (reference include/lda.h)."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("This is an abstract class.")      # ldainterface.cpp:35-38
+
+    # -- construction shared by the subclasses --------------------------------------
+    def _setup(self, num_words, num_topics, alpha, eta, device, _lambda=None):
+        if int(num_words) <= 0:
+            raise RuntimeError("Number of words should be positive.")
+        K, alpha_vec = _alpha_vector(alpha, num_topics)
+        if K <= 0:
+            raise RuntimeError("Number of topics should be positive.")
+        self._V = int(num_words)
+        self._K = int(K)
+        self._alpha = alpha_vec
+        self._eta = float(eta)
+        self._device = _default_device() if device is None else int(device)
+        self._handle = _ffi.vp()
+        L = _ffi.lib()
+        _ffi.require_gpu()
+        _ffi.check(L.trlda_model_create(C.byref(self._handle), self._device, self._K, self._V))
+        _ffi.check(L.trlda_model_set_alpha(self._handle, self._alpha))
+        if _lambda is None:
+            # lambda = sampleGamma(K, V, 100) / 100 from libc rand()       (lda.cpp:71)
+            lam = np.empty((self._K, self._V), dtype=np.float64, order="F")
+            L.trlda_sample_gamma_init(self._K, self._V, lam)
+        else:
+            lam = np.asfortranarray(_lambda, dtype=np.float64)
+        _ffi.check(L.trlda_model_set_lambda(self._handle, lam))
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            _ffi.lib().trlda_model_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- properties (ldainterface.cpp:41-148, module.cpp:67-90) ---------------------
+    @property
+    def num_topics(self):
+        return self._K
+
+    @property
+    def num_words(self):
+        return self._V
+
+    @property
+    def device(self):
+        return self._device
+
+    def _get_lambda(self):
+        lam = np.empty((self._K, self._V), dtype=np.float64, order="F")
+        _ffi.check(_ffi.lib().trlda_model_get_lambda(self._handle, lam))
+        lam.flags.writeable = False                                  # ldainterface.cpp:57
+        return lam
+
+    def _set_lambda(self, value):
+        try:
+            arr = np.asarray(value, dtype=np.float64)
+        except (TypeError, ValueError):
+            raise TypeError("Lambda should be of type `ndarray`.")
+        if arr.ndim == 1:
+            arr = arr.reshape(-1, 1)                                 # pyutils.cpp:91-128
+        if arr.ndim != 2 or arr.shape != (self._K, self._V):
+            raise RuntimeError("Lambda has wrong dimensionality.")   # lda.h:186-187
+        _ffi.check(_ffi.lib().trlda_model_set_lambda(self._handle, np.asfortranarray(arr)))
+
+    lambdas = property(_get_lambda, _set_lambda,
+                       doc="Parameters governing beliefs over topics (K x V).")
+    _lambda = property(_get_lambda, _set_lambda, doc="Alias for `lambdas`.")
+
+    @property
+    def alpha(self):
+        return self._alpha.reshape(-1, 1).copy(order="F")            # K x 1, ldainterface.cpp:87
+
+    @alpha.setter
+    def alpha(self, value):
+        if isinstance(value, (float, int, np.floating, np.integer)) and \
+                not isinstance(value, bool):
+            if value < 0.:
+                raise RuntimeError("Alpha should not be negative.")  # lda.h:147-151
+            new = np.full(self._K, float(value), dtype=np.float64)
+        else:
+            _, new = _alpha_vector(value, self._K)
+            if new.size != self._K:
+                raise RuntimeError("Alpha has wrong dimensionality.")  # lda.h:155-156
+            if (new < 0.).any():
+                raise RuntimeError("Alpha should not be negative.")
+        _ffi.check(_ffi.lib().trlda_model_set_alpha(self._handle, new))
+        self._alpha = new
+
+    @property
+    def eta(self):
+        return self._eta
+
+    @eta.setter
+    def eta(self, value):
+        value = float(value)
+        if value < 0.:
+            raise RuntimeError("Eta should not be negative.")        # lda.h:172-173
+        self._eta = value
+
+    # -- documents ---------------------------------------------------------------
+    def upload(self, docs):
+        """Convert + upload a batch once; the result can be passed as ``docs``."""
+        if isinstance(docs, DeviceBatch):
+            return docs
+        return DeviceBatch(docs, self._V, self._device)
+
+    def _batch(self, docs):
+        if isinstance(docs, DeviceBatch):
+            if docs.num_words != self._V or docs.device != self._device:
+                raise RuntimeError("Batch was uploaded for a different model.")
+            return docs, False
+        return DeviceBatch(docs, self._V, self._device), True
+
+    # -- E-step (ldainterface.cpp:311-390 -> lda.cpp:119-220) ------------------------
+    def update_variables(self, docs, latents=None, inference_method='VI', max_iter=100,
+                         threshold=0.001, num_samples=1, burn_in=2, return_iterations=False):
+        """E-step: returns ``(gamma K x N, sstats K x V)`` as Fortran-ordered float64."""
+        method = _inference_method(inference_method)
+        if method != "VI":
+            raise NotImplementedError(
+                "Gibbs inference (lda.cpp:224-293) is outside the accelerated path.")
+        batch, owned = self._batch(docs)
+        try:
+            B = len(batch)
+            L = _ffi.lib()
+            if latents is not None:
+                try:
+                    g = np.array(latents, dtype=np.float64, order="F", copy=True)
+                except (TypeError, ValueError):
+                    raise TypeError("`latents` should be of type `ndarray`.")
+                if g.ndim == 1:
+                    g = g.reshape(-1, 1, order="F")
+                if g.ndim != 2 or g.shape != (self._K, B):
+                    raise RuntimeError("Initial gamma has wrong dimensionality.")  # lda.cpp:165
+                gamma = np.asfortranarray(g)
+            else:
+                gamma = np.empty((self._K, B), dtype=np.float64, order="F")
+                L.trlda_sample_gamma_init(self._K, B, gamma)          # lda.cpp:135
+            sstats = np.empty((self._K, self._V), dtype=np.float64, order="F")
+            iters = np.zeros(B, dtype=np.int32)
+            _ffi.check(L.trlda_model_estep_host(self._handle, batch.handle, gamma, sstats,
+                                                int(max_iter), float(threshold),
+                                                iters.ctypes.data))
+        finally:
+            if owned:
+                batch.close()
+        if return_iterations:
+            return gamma, sstats, iters
+        return gamma, sstats
+
+    do_e_step = update_variables                                     # module.cpp:103-106
+
+    # -- not on the accelerated path ----------------------------------------------
+    def lower_bound(self, docs, num_documents=-1, inference_method='VI', max_iter=100,
+                    num_samples=1, burn_in=2):
+        raise NotImplementedError("lower_bound (lda.cpp:297-360) is not on the accelerated path "
+                                  "yet (SURVEY.md 8f rank 3).")
+
+    def sample(self, num_documents, length):
+        raise NotImplementedError("sample (lda.cpp:88-115) is outside the accelerated path.")
+
+    def __str__(self):                                               # ldainterface.cpp:473-490
+        return "Number of topics: %d\nEta: %.4g\nAlpha: %.4g, %.4g (min, max)\n" % (
+            self._K, self._eta, self._alpha.min(), self._alpha.max())
+
+
+class OnlineLDA(LDA):
+    """Online trust-region LDA (reference src/onlinelda.cpp, onlineldainterface.cpp).
+
+        >>> model = OnlineLDA(num_words=7000, num_topics=100, num_documents=10000,
+        ...                   alpha=.1, eta=.3)
+
+    ``alpha`` can be a scalar or an array with one entry for each topic.
+    """
+
+    def __init__(self, num_words, num_topics, num_documents, alpha=.1, eta=.3, kappa_=0.,
+                 tau_=0., device=None):
+        # kappa_ / tau_ are accepted and ignored (old pickles; onlineldainterface.cpp:50-52)
+        self._num_documents = int(num_documents)
+        self._update_count = 0
+        self._setup(num_words, num_topics, alpha, eta, device)
+
+    @property
+    def num_documents(self):
+        return self._num_documents
+
+    @num_documents.setter
+    def num_documents(self, value):
+        value = int(value)
+        if value < 0:                                                # onlinelda.h:57-58
+            raise RuntimeError("The number of documents should not be negative.")
+        self._num_documents = value
+
+    @property
+    def update_count(self):
+        return self._update_count
+
+    @update_count.setter
+    def update_count(self, value):
+        value = int(value)
+        if value < 0:                                                # onlinelda.h:71-72
+            raise RuntimeError("The update count should not be negative.")
+        self._update_count = value
+
+    def update_parameters(self, docs, max_iter_tr=10, max_iter_inference=20, kappa=.7,
+                          tau=100., rho=-1., adaptive=False, init_gamma=True,
+                          update_lambda=True, update_alpha=False, update_eta=False,
+                          min_alpha=1e-6, min_eta=1e-6, verbosity=0):
+        """One online update; returns the learning rate used
+        (onlineldainterface.cpp:204-256 -> onlinelda.cpp:53-179)."""
+        if adaptive or update_alpha or update_eta:
+            raise NotImplementedError(
+                "adaptive / update_alpha / update_eta (onlinelda.cpp:116-175) are not on the "
+                "accelerated path yet (SURVEY.md 8f rank 1).")
+        batch, owned = self._batch(docs)
+        try:
+            count = C.c_int(self._update_count)
+            rho_out = C.c_double(0.)
+            _ffi.check(_ffi.lib().trlda_model_online_update(
+                self._handle, batch.handle, self._num_documents, self._eta, int(max_iter_tr),
+                int(max_iter_inference), float(kappa), float(tau), float(rho),
+                int(bool(init_gamma)), int(bool(update_lambda)), 0.001,  # lda.h:56: fixed
+                C.byref(count), C.byref(rho_out), None))
+            self._update_count = count.value
+        finally:
+            if owned:
+                batch.close()
+        return rho_out.value
+
+    def __reduce__(self):                                            # onlineldainterface.cpp:265
+        args = (self._V, self._K, self._num_documents, self.alpha, self._eta)
+        state = (self.lambdas, self._update_count)
+        return (self.__class__, args, state)
+
+    def __setstate__(self, state):                                   # onlineldainterface.cpp:296
+        lam, count = state
+        self.lambdas = lam
+        self.update_count = count
+
+
+class BatchLDA(LDA):
+    """Batch variational LDA (reference src/batchlda.cpp, batchldainterface.cpp)."""
+
+    def __init__(self, num_words, num_topics, alpha=.1, eta=.3, device=None):
+        self._setup(num_words, num_topics, alpha, eta, device)
+
+    def update_parameters(self, docs, max_epochs=100, max_iter_inference=100, max_iter_alpha=10,
+                          max_iter_eta=20, update_lambda=True, update_alpha=False,
+                          update_eta=False, min_alpha=1e-6, min_eta=1e-6,
+                          emp_bayes_threshold=1e-8, verbosity=0):
+        """batchldainterface.cpp:126-172 -> batchlda.cpp:43-208 (lambda path :48-61)."""
+        if update_alpha or update_eta:
+            raise NotImplementedError(
+                "update_alpha / update_eta line searches (batchlda.cpp:66-205) are host-side "
+                "scalar math outside the accelerated path (SURVEY.md 8f rank 4).")
+        batch, owned = self._batch(docs)
+        try:
+            _ffi.check(_ffi.lib().trlda_model_batch_update(
+                self._handle, batch.handle, self._eta, int(max_epochs), int(max_iter_inference),
+                int(bool(update_lambda)), 0.001, None))
+        finally:
+            if owned:
+                batch.close()
+        return 1.                                                    # batchlda.cpp:207
+
+    def __reduce__(self):                                            # batchldainterface.cpp:181
+        return (self.__class__, (self._V, self._K, self.alpha, self._eta), (self.lambdas,))
+
+    def __setstate__(self, state):
+        self.lambdas = state[0]
