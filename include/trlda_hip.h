@@ -169,6 +169,19 @@ int trlda_model_tr_init(trlda_model *model, const trlda_batch *batch,
                         const double *lambda_prime_dev, double rho, double eta,
                         int num_documents);
 
+/* The two halves of trlda_model_tr_init, for the multi-GPU composition where the word
+ * counts of the whole mini-batch are the sum over ranks (src/onlinelda.cpp:79-82 is a sum
+ * over documents): local counts -> all-reduce -> apply.
+ *   wordcounts_dev  V fp64 (integer-valued, so the sum is exact in any order)
+ *   coef            D / B_total / K, evaluated by the caller in that order (onlinelda.cpp:86) */
+int trlda_model_wordcounts(trlda_model *model, const trlda_batch *batch, double *wordcounts_dev);
+int trlda_model_tr_init_wc(trlda_model *model, const double *wordcounts_dev,
+                           const double *lambda_prime_dev, double rho, double eta, double coef);
+
+/* dst_dev[K x V] = model.lambda (device-to-device, on the model's stream): the
+ * `lambdaPrime = mLambda` snapshot of src/onlinelda.cpp:68. */
+int trlda_model_copy_lambda(trlda_model *model, double *dst_dev);
+
 /*
  * OnlineLDA::updateParameters, lambda path: src/onlinelda.cpp:53-111, 177-179 (the
  * caller of python/src/onlineldainterface.cpp:204-256).  Runs the whole

@@ -1,0 +1,218 @@
+"""Generate tests/golden/*.npz from the REFERENCE ITSELF (run in the build container only).
+
+    python tests/golden/make_golden.py
+
+Sources of truth, none of which travel to the GPU box:
+  * oracle/_ref/libtrlda_ref.so -- the reference's unmodified C++ core
+    (/root/reference/code/trlda/src/*.cpp) behind oracle/ref_shim.cpp, built by
+    oracle/Makefile;
+  * /root/reference/code/trlda/python/tests/onlineldavb.py -- M. Hoffman's NumPy
+    online LDA, the cross-implementation oracle of the reference's own test_vi
+    (onlinelda_test.py:39-68); imported here, never copied (GPL-3).
+
+The fixtures are DATA only: inputs (or the srand() seed that reproduces them through the
+libc-rand() sampleGamma stream) and the reference's outputs.  Where lambda would be large
+it is stored as a seed: `srand(seed); sampleGamma(K, V, 100) / 100` is bit-reproducible
+(F0 checks that against the reference).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import pyoracle  # noqa: E402
+from trlda_amd.utils.synthetic import make_corpus  # noqa: E402
+
+REF_TESTS = "/root/reference/code/trlda/python/tests"
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("%-28s %7.1f kB" % (name + ".npz", os.path.getsize(path) / 1e3))
+
+
+def edge_corpus(V, rng):
+    """Edge documents of SURVEY.md 8c (F3)."""
+    docs = [
+        [],                                                   # empty document
+        [(3, 2), (3, 1), (7, 4), (3, 5)],                     # duplicate ids
+        [(1, 0), (2, 0), (5, 3)],                             # zero counts
+        [(V - 1, 1)],                                         # single word, id = V-1
+        [(0, 7)],                                             # id = 0
+        [(int(w), int(1 + rng.integers(4))) for w in rng.permutation(V)[:70]],   # n_d > 64
+        [(int(w), int(1 + rng.integers(4))) for w in rng.permutation(V)[:min(V, 260)]],  # > LDS tile
+        [(int(w), 0) for w in rng.permutation(V)[:5]],        # all counts zero
+    ]
+    n = np.array([len(d) for d in docs])
+    indptr = np.zeros(len(docs) + 1, np.int32)
+    indptr[1:] = np.cumsum(n)
+    flat = np.array([t for d in docs for t in d], dtype=np.int32).reshape(-1, 2)
+    return indptr, flat[:, 0].copy(), flat[:, 1].copy()
+
+
+def main():
+    pyoracle.build(ref=True)
+    ref = pyoracle.Reference()
+    orc = pyoracle.Oracle()
+
+    # ---- F0: sampleGamma stream + F6: psi table ---------------------------------------
+    ref.seed(42)
+    sg = ref.sample_gamma(3, 2, 100)
+    ref.seed(7)
+    sg2 = ref.sample_gamma(5, 4, 3)
+    x = np.concatenate([np.logspace(-6, 6, 241), np.arange(1, 13, dtype=float),
+                        [0.1, 0.5, 9.999999, 10.000001, 1e17, 2e17, -0.5, -1.5, -2.25, -0.75]])
+    psi = np.array([ref.digamma(v) for v in x])
+    # the reference's own known-answer values (utils_test.py:33-51, rows with n = 0)
+    kat_x = np.array([0.1, 1.0, 120.0])
+    kat_y = np.array([-10.423754940411, -0.5772156649015329, 4.7833192891185])
+    save("f0_rng_psi", sg_seed42_3x2x100=sg, sg_seed7_5x4x3=sg2, psi_x=x, psi_y=psi,
+         kat_x=kat_x, kat_y=kat_y)
+
+    # ---- F1: do_e_step parity, full inputs -------------------------------------------
+    for tag, (K, V, B, mu) in {"a": (10, 1000, 100, 40), "b": (20, 300, 16, 60)}.items():
+        indptr, ids, cnts = make_corpus(B, V, seed=20150706, mean_unique=mu)
+        ref.seed(101)
+        m = ref.online(V, K, 1000, alpha=.1, eta=.3)          # draws lambda from rand()
+        lam = m.lambdas
+        alpha = np.linspace(0.05, 0.3, K) if tag == "b" else np.full(K, .1)
+        m.alpha = alpha
+        ref.seed(202)
+        g0 = ref.sample_gamma(K, B, 100) / 100.
+        out = dict(K=K, V=V, B=B, indptr=indptr, ids=ids, cnts=cnts, lambda_seed=101,
+                   gamma0_seed=202, alpha=alpha)
+        if tag == "b":
+            out["lam"] = lam                                  # one fixture with lambda stored
+        for (it, thr) in [(0, 1e-3), (1, 1e-3), (20, 1e-3), (50, 0.0), (100, 1e-3)]:
+            g, s = m.estep(indptr, ids, cnts, g0, it, thr)
+            _, _, iters = orc.estep(lam, alpha, indptr, ids, cnts, g0, it, thr)
+            key = "it%d_thr%g" % (it, thr)
+            out["gamma_" + key] = g
+            out["sstats_" + key] = s
+            out["iters_" + key] = iters
+        save("f1%s_estep" % tag, **out)
+
+    # ---- F2: bench shape K=100, V=7000, B=8; outputs on active columns ---------------
+    K, V, B = 100, 7000, 8
+    indptr, ids, cnts = make_corpus(B, V, seed=20150707, mean_unique=100)
+    ref.seed(1)
+    m = ref.online(V, K, 1000000, alpha=.1, eta=.3)
+    ref.seed(2)
+    g0 = ref.sample_gamma(K, B, 100) / 100.
+    g, s = m.estep(indptr, ids, cnts, g0, 20, 1e-3)
+    active = np.unique(ids)
+    save("f2_bench_shape", K=K, V=V, B=B, indptr=indptr, ids=ids, cnts=cnts, lambda_seed=1,
+         gamma0_seed=2, gamma=g, active=active, sstats_active=s[:, active],
+         sstats_sum=s.sum(), gamma_sum=g.sum())
+
+    # ---- F3: edge documents (two K: all staged in LDS / some streamed) ---------------
+    for tag, (K, V) in {"a": (12, 300), "b": (160, 400)}.items():
+        rng = np.random.Generator(np.random.PCG64(5))
+        indptr, ids, cnts = edge_corpus(V, rng)
+        B = len(indptr) - 1
+        ref.seed(11)
+        m = ref.online(V, K, 500, alpha=.1, eta=.3)
+        ref.seed(12)
+        g0 = ref.sample_gamma(K, B, 100) / 100.
+        out = dict(K=K, V=V, B=B, indptr=indptr, ids=ids, cnts=cnts, lambda_seed=11,
+                   gamma0_seed=12)
+        for (it, thr) in [(0, 1e-3), (30, 1e-3), (7, 0.0)]:
+            g, s = m.estep(indptr, ids, cnts, g0, it, thr)
+            key = "it%d_thr%g" % (it, thr)
+            active = np.unique(ids)
+            out["gamma_" + key] = g
+            if it > 0 or tag == "a":
+                out["sstats_active_" + key] = s[:, active]
+            out["sstats_sum_" + key] = s.sum()
+        out["active"] = np.unique(ids)
+        save("f3%s_edge" % tag, **out)
+
+    # ---- F4: OnlineLDA.update_parameters trajectories ---------------------------------
+    K, V, D, B = 10, 200, 1000, 25
+    batches = [make_corpus(B, V, seed=20150706 + i, mean_unique=30) for i in range(3)]
+    out = dict(K=K, V=V, D=D, B=B)
+    for i, (ip, ii, cc) in enumerate(batches):
+        out["indptr%d" % i], out["ids%d" % i], out["cnts%d" % i] = ip, ii, cc
+    case = 0
+    for tr in (0, 3):
+        for init_gamma in (True, False):
+            for rho in (-1., 0.1):
+                ref.seed(1000 + case)
+                m = ref.online(V, K, D, alpha=.1, eta=.3)
+                out["c%d_lambda0" % case] = m.lambdas
+                rhos = []
+                for i, (ip, ii, cc) in enumerate(batches):
+                    r = m.update_parameters(ip, ii, cc, max_iter_tr=tr, max_iter_inference=20,
+                                            kappa=.7, tau=100., rho=rho, init_gamma=init_gamma)
+                    rhos.append(r)
+                    out["c%d_lambda%d" % (case, i + 1)] = m.lambdas
+                # an empty batch neither counts nor changes lambda (onlinelda.cpp:54-56)
+                r_empty = m.update_parameters(np.zeros(1, np.int32), np.zeros(0, np.int32),
+                                              np.zeros(0, np.int32), max_iter_tr=tr)
+                out["c%d_meta" % case] = np.array([tr, int(init_gamma), rho, 1000 + case,
+                                                   m.update_count, r_empty])
+                out["c%d_rhos" % case] = np.array(rhos)
+                case += 1
+    out["num_cases"] = case
+    save("f4_online_trajectory", **out)
+
+    # config 1 of BASELINE.json: K=10, V=1000, 1k docs, batch 100, TR=10, 20 inner iterations
+    K, V, D, B = 10, 1000, 1000, 100
+    ip, ii, cc = make_corpus(D, V, seed=20150706, mean_unique=50)
+    ref.seed(77)
+    m = ref.online(V, K, D, alpha=.1, eta=.3)
+    rhos = []
+    for b in range(D // B):
+        lo, hi = ip[b * B], ip[(b + 1) * B]
+        rhos.append(m.update_parameters(ip[b * B:(b + 1) * B + 1] - lo, ii[lo:hi], cc[lo:hi],
+                                        max_iter_tr=10, max_iter_inference=20))
+    save("f4b_config1", K=K, V=V, D=D, B=B, corpus_seed=20150706, mean_unique=50, seed=77,
+         rhos=np.array(rhos), lambda_final=m.lambdas, update_count=m.update_count)
+
+    # ---- F5: BatchLDA, 2 epochs --------------------------------------------------------
+    K, V, B = 8, 150, 40
+    ip, ii, cc = make_corpus(B, V, seed=20150709, mean_unique=25)
+    ref.seed(31)
+    m = ref.batch(V, K, alpha=.1, eta=.3)
+    lam0 = m.lambdas
+    m.update_parameters(ip, ii, cc, max_epochs=2, max_iter_inference=100)
+    save("f5_batch", K=K, V=V, B=B, indptr=ip, ids=ii, cnts=cc, seed=31, lambda0=lam0,
+         lambda2=m.lambdas)
+
+    # ---- F7: Hoffman's onlineldavb on the reference's own test_vi set-up ----------------
+    sys.path.insert(0, REF_TESTS)
+    import onlineldavb  # noqa: E402  (GPL-3: imported to generate vectors, not vendored)
+    W, K, D, N = 100, 20, 10, 100                               # onlinelda_test.py:40-43
+    rs = np.random.RandomState(12345)
+    # Hoffman's constructor keeps [a-z] only, so the vocabulary must be purely alphabetic
+    vocab = ["w" + chr(97 + i // 26) + chr(97 + i % 26) for i in range(W)]
+    hm = onlineldavb.OnlineLDA(vocab, K, D, 0.1, 0.3, 1024., 0.9)
+    lam = np.asfortranarray(hm._lambda)
+    docs = [[(int(w), int(rs.randint(10))) for w in rs.permutation(W)[:1 + rs.randint(N)]]
+            for _ in range(D)]
+    g0 = rs.gamma(100., 1. / 100., [K, D])
+    docs0 = [tuple(zip(*doc)) for doc in docs]
+    gh, sh = hm.do_e_step(docs0, max_steps=50, gamma=g0.T.copy())
+    n = np.array([len(d) for d in docs])
+    indptr = np.zeros(D + 1, np.int32)
+    indptr[1:] = np.cumsum(n)
+    flat = np.array([t for d in docs for t in d], dtype=np.int32)
+    # the compiled reference on the same inputs (threshold 1e-3, 50 iterations)
+    m = ref.online(W, K, D, alpha=.1, eta=.3)
+    m.lambdas = lam
+    gr, sr = m.estep(indptr, flat[:, 0].copy(), flat[:, 1].copy(), g0, 50, 1e-3)
+    save("f7_hoffman_test_vi", K=K, V=W, B=D, indptr=indptr, ids=flat[:, 0].copy(),
+         cnts=flat[:, 1].copy(), lam=lam, gamma0=g0, gamma_hoffman=np.asfortranarray(gh.T),
+         sstats_hoffman=np.asfortranarray(sh), gamma_ref=gr, sstats_ref=sr)
+    print("hoffman vs compiled reference: gamma %.2e sstats %.2e" % (
+        np.max(np.abs(gh.T - gr) / np.abs(gr)),
+        np.max(np.abs(sh - sr)[sr > 0] / sr[sr > 0])))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,199 @@
+"""The CPU oracle (oracle/cpu_ref.c) against the reference's golden vectors.
+
+CPU-only.  This is what pins the oracle: every fixture under tests/golden/ was produced
+by the reference's own compiled C++ core (tests/golden/make_golden.py); where the
+compiled reference itself is present (this container) the oracle is also compared with
+it live on fresh seeded inputs.
+"""
+import numpy as np
+import pytest
+
+from helpers import golden, relerr, seeded_gamma, seeded_lambda
+from trlda_amd.utils.synthetic import make_corpus
+
+RTOL = 5e-11      # oracle vs reference: two fp64 implementations of the same arithmetic
+
+
+def test_digamma_known_answers(oracle):
+    """utils_test.py:33-51 (n = 0 rows): the reference's own KATs, to 7 decimals there."""
+    f = golden("f0_rng_psi")
+    for x, y in zip(f["kat_x"], f["kat_y"]):
+        assert abs(oracle.digamma(x) - y) < 1e-12
+
+
+def test_digamma_table_bit_exact(oracle):
+    """psi on a log grid, small integers, x<=0 reflection: identical doubles."""
+    f = golden("f0_rng_psi")
+    got = np.array([oracle.digamma(x) for x in f["psi_x"]])
+    want = f["psi_y"]
+    assert np.array_equal(got[np.isfinite(want)], want[np.isfinite(want)])
+    assert np.array_equal(np.isfinite(got), np.isfinite(want))
+
+
+def test_sample_gamma_stream_bit_exact(oracle):
+    f = golden("f0_rng_psi")
+    oracle.seed(42)
+    assert np.array_equal(oracle.sample_gamma(3, 2, 100), f["sg_seed42_3x2x100"])
+    oracle.seed(7)
+    assert np.array_equal(oracle.sample_gamma(5, 4, 3), f["sg_seed7_5x4x3"])
+
+
+@pytest.mark.parametrize("name", ["f1a_estep", "f1b_estep"])
+def test_estep_golden(oracle, name):
+    f = golden(name)
+    K, V, B = int(f["K"]), int(f["V"]), int(f["B"])
+    lam = seeded_lambda(oracle, f["lambda_seed"], K, V)
+    if "lam" in f:
+        assert np.array_equal(lam, f["lam"])          # the seed really reproduces lambda
+    g0 = seeded_gamma(oracle, f["gamma0_seed"], K, B)
+    for (it, thr) in [(0, 1e-3), (1, 1e-3), (20, 1e-3), (50, 0.0), (100, 1e-3)]:
+        key = "it%d_thr%g" % (it, thr)
+        g, s, iters = oracle.estep(lam, f["alpha"], f["indptr"], f["ids"], f["cnts"], g0, it, thr)
+        assert relerr(g, f["gamma_" + key]) < RTOL
+        want = f["sstats_" + key]
+        assert relerr(s[want > 0], want[want > 0]) < RTOL
+        assert np.array_equal(s == 0, want == 0)
+        assert np.array_equal(iters, f["iters_" + key])
+        assert iters.max() <= it
+
+
+def test_estep_bench_shape_golden(oracle):
+    f = golden("f2_bench_shape")
+    K, V, B = int(f["K"]), int(f["V"]), int(f["B"])
+    lam = seeded_lambda(oracle, f["lambda_seed"], K, V)
+    g0 = seeded_gamma(oracle, f["gamma0_seed"], K, B)
+    g, s, _ = oracle.estep(lam, .1, f["indptr"], f["ids"], f["cnts"], g0, 20, 1e-3)
+    assert relerr(g, f["gamma"]) < RTOL
+    assert relerr(s[:, f["active"]], f["sstats_active"]) < RTOL
+    inactive = np.setdiff1d(np.arange(V), f["active"])
+    assert (s[:, inactive] == 0).all()
+    assert abs(s.sum() - f["sstats_sum"]) < 1e-9 * f["sstats_sum"]
+    # invariants of SURVEY.md 8(a17)
+    total = f["cnts"].sum()
+    assert abs(s.sum() - total) < 1e-9 * total
+    assert abs(g.sum() - (total + B * K * .1)) < 1e-9 * total
+
+
+@pytest.mark.parametrize("name", ["f3a_edge", "f3b_edge"])
+def test_estep_edge_documents_golden(oracle, name):
+    """empty doc, duplicate ids, zero counts, single word, id = V-1, n_d > 64, long doc."""
+    f = golden(name)
+    K, V, B = int(f["K"]), int(f["V"]), int(f["B"])
+    lam = seeded_lambda(oracle, f["lambda_seed"], K, V)
+    g0 = seeded_gamma(oracle, f["gamma0_seed"], K, B)
+    for (it, thr) in [(0, 1e-3), (30, 1e-3), (7, 0.0)]:
+        key = "it%d_thr%g" % (it, thr)
+        g, s, _ = oracle.estep(lam, .1, f["indptr"], f["ids"], f["cnts"], g0, it, thr)
+        assert relerr(g, f["gamma_" + key]) < RTOL
+        if "sstats_active_" + key in f:
+            want = f["sstats_active_" + key]
+            got = s[:, f["active"]]
+            assert relerr(got[want > 0], want[want > 0]) < RTOL
+            assert np.array_equal(got == 0, want == 0)
+        assert abs(s.sum() - f["sstats_sum_" + key]) <= 1e-9 * max(1., abs(f["sstats_sum_" + key]))
+
+
+def test_estep_rejects_bad_word_id(oracle):
+    lam = np.ones((3, 5), order="F")
+    with pytest.raises(RuntimeError):
+        oracle.estep(lam, .1, [0, 1], [5], [1], np.ones((3, 1)), 5, 1e-3)
+
+
+def test_hoffman_cross_implementation(oracle):
+    """The reference's test_vi set-up (onlinelda_test.py:39-68) at 1e-9 instead of corr>0.99:
+    Hoffman's NumPy E-step, the compiled reference and the oracle agree."""
+    f = golden("f7_hoffman_test_vi")
+    g, s, _ = oracle.estep(f["lam"], .1, f["indptr"], f["ids"], f["cnts"], f["gamma0"], 50, 1e-3)
+    for tag in ("hoffman", "ref"):
+        assert relerr(g, f["gamma_" + tag]) < 1e-9
+        want = f["sstats_" + tag]
+        assert relerr(s[want > 0], want[want > 0]) < 1e-9
+    assert np.corrcoef(g.ravel(), f["gamma_hoffman"].ravel())[0, 1] > 0.99   # the reference's bar
+
+
+def test_online_trajectories_golden(oracle):
+    """OnlineLDA.update_parameters: TR in {0,3} x init_gamma x rho, 3 calls + an empty batch."""
+    f = golden("f4_online_trajectory")
+    K, V, D = int(f["K"]), int(f["V"]), int(f["D"])
+    for case in range(int(f["num_cases"])):
+        tr, init_gamma, rho, seed, count_want, r_empty = f["c%d_meta" % case]
+        lam = seeded_lambda(oracle, seed, K, V)
+        assert np.array_equal(lam, f["c%d_lambda0" % case])
+        count = 0
+        for i in range(3):
+            r, lam, count, _ = oracle.online_update_parameters(
+                lam, .1, .3, D, f["indptr%d" % i], f["ids%d" % i], f["cnts%d" % i], count,
+                max_iter_tr=int(tr), max_iter_inference=20, kappa=.7, tau=100., rho=rho,
+                init_gamma=bool(init_gamma))
+            assert abs(r - f["c%d_rhos" % case][i]) < 1e-15
+            assert relerr(lam, f["c%d_lambda%d" % (case, i + 1)]) < RTOL
+        r, lam2, count2, _ = oracle.online_update_parameters(
+            lam, .1, .3, D, [0], [], [], count, max_iter_tr=int(tr))
+        assert r == r_empty == 1.0 and count2 == count == int(count_want)
+        assert np.array_equal(lam2, lam)
+
+
+def test_config1_golden(oracle):
+    """BASELINE.json configs[0]: K=10, V=1000, 1k docs, batch 100, TR=10, 20 inner iterations."""
+    f = golden("f4b_config1")
+    K, V, D, B = int(f["K"]), int(f["V"]), int(f["D"]), int(f["B"])
+    ip, ii, cc = make_corpus(D, V, seed=int(f["corpus_seed"]), mean_unique=int(f["mean_unique"]))
+    lam = seeded_lambda(oracle, f["seed"], K, V)
+    count = 0
+    for b in range(D // B):
+        lo, hi = ip[b * B], ip[(b + 1) * B]
+        r, lam, count, _ = oracle.online_update_parameters(
+            lam, .1, .3, D, ip[b * B:(b + 1) * B + 1] - lo, ii[lo:hi], cc[lo:hi], count,
+            max_iter_tr=10, max_iter_inference=20)
+        assert abs(r - f["rhos"][b]) < 1e-15
+    assert count == int(f["update_count"])
+    assert relerr(lam, f["lambda_final"]) < 1e-8
+
+
+def test_batch_golden(oracle):
+    f = golden("f5_batch")
+    K, V = int(f["K"]), int(f["V"])
+    lam = seeded_lambda(oracle, f["seed"], K, V)
+    assert np.array_equal(lam, f["lambda0"])
+    _, lam, _ = oracle.batch_update_parameters(lam, .1, .3, f["indptr"], f["ids"], f["cnts"],
+                                               max_epochs=2, max_iter_inference=100)
+    assert relerr(lam, f["lambda2"]) < RTOL
+
+
+def test_multithread_variant_matches(oracle):
+    ip, ii, cc = make_corpus(64, 500, seed=9, mean_unique=40)
+    lam = seeded_lambda(oracle, 3, 16, 500)
+    g0 = seeded_gamma(oracle, 4, 16, 64)
+    g1, s1, it1 = oracle.estep(lam, .1, ip, ii, cc, g0, 20, 1e-3)
+    g2, s2, it2 = oracle.estep(lam, .1, ip, ii, cc, g0, 20, 1e-3, nthreads=3)
+    assert np.array_equal(g1, g2) and np.array_equal(it1, it2)
+    assert relerr(s2[s1 > 0], s1[s1 > 0]) < 1e-12
+
+
+# ---- live comparison with the compiled reference (this container only) ----------------
+
+def test_live_reference_estep(oracle, reference):
+    for (K, V, B, it, thr, seed) in [(13, 211, 37, 25, 1e-3, 1), (64, 900, 20, 10, 0.0, 2)]:
+        ip, ii, cc = make_corpus(B, V, seed=seed, mean_unique=35)
+        reference.seed(seed)
+        m = reference.online(V, K, 1000)
+        lam = m.lambdas
+        g0 = seeded_gamma(oracle, seed + 100, K, B)
+        gr, sr = m.estep(ip, ii, cc, g0, it, thr)
+        go, so, _ = oracle.estep(lam, .1, ip, ii, cc, g0, it, thr)
+        assert relerr(go, gr) < RTOL
+        assert relerr(so[sr > 0], sr[sr > 0]) < RTOL
+
+
+def test_live_reference_default_gamma_stream(oracle, reference):
+    """update_variables without latents draws gamma0 from rand() (lda.cpp:135)."""
+    K, V, B = 6, 80, 9
+    ip, ii, cc = make_corpus(B, V, seed=5, mean_unique=20)
+    reference.seed(9)
+    m = reference.online(V, K, 100)
+    lam = m.lambdas
+    reference.seed(10)
+    gr, sr = m.estep(ip, ii, cc, None, 15, 1e-3)
+    g0 = seeded_gamma(oracle, 10, K, B)
+    go, so, _ = oracle.estep(lam, .1, ip, ii, cc, g0, 15, 1e-3)
+    assert relerr(go, gr) < RTOL

@@ -58,6 +58,9 @@ _SIGNATURES = {
     "trlda_model_estep_host": (C.c_int, [vp, vp, f64p, f64p, C.c_int, C.c_double, vp]),
     "trlda_model_blend": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, C.c_double]),
     "trlda_model_tr_init": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, C.c_int]),
+    "trlda_model_wordcounts": (C.c_int, [vp, vp, vp]),
+    "trlda_model_tr_init_wc": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, C.c_double]),
+    "trlda_model_copy_lambda": (C.c_int, [vp, vp]),
     "trlda_model_online_update": (C.c_int, [vp, vp, C.c_int, C.c_double, C.c_int, C.c_int,
                                             C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
                                             C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double),

@@ -305,28 +305,43 @@ int blend_device(trlda_model *m, const double *lambda_prime, const double *sstat
     return TRLDA_OK;
 }
 
+int wordcounts_device(trlda_model *m, const trlda_batch *b, double *wc)
+{
+    HIP_TRY(hipMemsetAsync(wc, 0, (size_t)m->V * sizeof(double), m->stream));
+    if (b->nnz > 0) {
+        size_t blocks = ((size_t)b->nnz + kDenseThreads - 1) / kDenseThreads;
+        int G = (int)std::min<size_t>(blocks, 256 * 8);
+        hipLaunchKernelGGL(trlda::wordcount_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads), 0,
+                           m->stream, b->nnz, b->ids, b->cnts, wc);
+        HIP_TRY(hipGetLastError());
+    }
+    return TRLDA_OK;
+}
+
+int tr_init_wc_device(trlda_model *m, const double *wc, const double *lambda_prime, double rho,
+                      double eta, double coef)
+{
+    size_t KV = (size_t)m->K * m->V;
+    size_t blocks = (KV + kDenseThreads - 1) / kDenseThreads;
+    int G = (int)std::min<size_t>(blocks, 256 * 8);
+    hipLaunchKernelGGL(trlda::tr_init_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads), 0,
+                       m->stream, m->K, KV, rho, eta, coef, wc, lambda_prime, m->lambda);
+    HIP_TRY(hipGetLastError());
+    return TRLDA_OK;
+}
+
 int tr_init_device(trlda_model *m, const trlda_batch *b, const double *lambda_prime, double rho,
                    double eta, int num_documents)
 {
     int rc = ensure_update_workspace(m, b->B);
     if (rc)
         return rc;
-    size_t KV = (size_t)m->K * m->V;
-    HIP_TRY(hipMemsetAsync(m->wordcounts, 0, (size_t)m->V * sizeof(double), m->stream));
-    if (b->nnz > 0) {
-        size_t blocks = ((size_t)b->nnz + kDenseThreads - 1) / kDenseThreads;
-        int G = (int)std::min<size_t>(blocks, 256 * 8);
-        hipLaunchKernelGGL(trlda::wordcount_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads), 0,
-                           m->stream, b->nnz, b->ids, b->cnts, m->wordcounts);
-    }
+    rc = wordcounts_device(m, b, m->wordcounts);
+    if (rc)
+        return rc;
     // static_cast<double>(D) / B / K, evaluated in the reference's order (onlinelda.cpp:86)
     double coef = (double)num_documents / (double)b->B / (double)m->K;
-    size_t blocks = (KV + kDenseThreads - 1) / kDenseThreads;
-    int G = (int)std::min<size_t>(blocks, 256 * 8);
-    hipLaunchKernelGGL(trlda::tr_init_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads), 0,
-                       m->stream, m->K, KV, rho, eta, coef, m->wordcounts, lambda_prime, m->lambda);
-    HIP_TRY(hipGetLastError());
-    return TRLDA_OK;
+    return tr_init_wc_device(m, m->wordcounts, lambda_prime, rho, eta, coef);
 }
 
 int check_model(const trlda_model *m)
@@ -718,6 +733,41 @@ int trlda_model_tr_init(trlda_model *m, const trlda_batch *b, const double *lamb
     if (!b || !lambda_prime_dev || b->B <= 0)
         return fail(TRLDA_ERR_ARG, "NULL or empty batch / lambda_prime");
     return tr_init_device(m, b, lambda_prime_dev, rho, eta, num_documents);
+}
+
+int trlda_model_wordcounts(trlda_model *m, const trlda_batch *b, double *wordcounts_dev)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!b || !wordcounts_dev)
+        return fail(TRLDA_ERR_ARG, "NULL batch / wordcounts");
+    if (b->V != m->V)
+        return fail(TRLDA_ERR_SHAPE, "batch was created for a different vocabulary size");
+    return wordcounts_device(m, b, wordcounts_dev);
+}
+
+int trlda_model_tr_init_wc(trlda_model *m, const double *wordcounts_dev,
+                           const double *lambda_prime_dev, double rho, double eta, double coef)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!wordcounts_dev || !lambda_prime_dev)
+        return fail(TRLDA_ERR_ARG, "NULL wordcounts / lambda_prime");
+    return tr_init_wc_device(m, wordcounts_dev, lambda_prime_dev, rho, eta, coef);
+}
+
+int trlda_model_copy_lambda(trlda_model *m, double *dst_dev)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!dst_dev)
+        return fail(TRLDA_ERR_ARG, "NULL destination");
+    HIP_TRY(hipMemcpyAsync(dst_dev, m->lambda, (size_t)m->K * m->V * sizeof(double),
+                           hipMemcpyDeviceToDevice, m->stream));
+    return TRLDA_OK;
 }
 
 int trlda_model_online_update(trlda_model *m, const trlda_batch *b, int num_documents, double eta,

@@ -31,20 +31,28 @@ class CSRDocuments(object):
     def __len__(self):
         return len(self.indptr) - 1
 
-    def shard(self, rank, world_size):
-        """Contiguous range of documents for ``rank``, balanced by nnz."""
+    def shard_cuts(self, world_size):
+        """Document cut points ``c[0..world_size]`` of a contiguous split balanced by nnz
+        (SURVEY.md §8e); rank r owns documents ``[c[r], c[r+1])``."""
         B = len(self)
-        if world_size <= 1:
-            return self
-        # cut points at equal shares of the cumulative entry count (+1 per doc so that
-        # empty documents still spread)
+        # equal shares of the cumulative entry count (+1 per document so that empty
+        # documents still spread)
         weight = self.indptr.astype(np.int64) + np.arange(B + 1, dtype=np.int64)
         targets = weight[-1] * np.arange(world_size + 1, dtype=np.int64) // world_size
         cuts = np.searchsorted(weight, targets, side="left")
         cuts[0], cuts[-1] = 0, B
-        lo, hi = int(cuts[rank]), int(cuts[rank + 1])
+        return np.maximum.accumulate(cuts)
+
+    def slice(self, lo, hi):
         p0, p1 = int(self.indptr[lo]), int(self.indptr[hi])
         return CSRDocuments(self.indptr[lo:hi + 1] - p0, self.ids[p0:p1], self.cnts[p0:p1])
+
+    def shard(self, rank, world_size):
+        """Contiguous range of documents for ``rank``."""
+        if world_size <= 1:
+            return self
+        cuts = self.shard_cuts(world_size)
+        return self.slice(int(cuts[rank]), int(cuts[rank + 1]))
 
     def to_list(self):
         ip, ids, cnts = self.indptr, self.ids, self.cnts
