@@ -1,0 +1,227 @@
+"""The drop-in boundary on CPU: the C-ABI library builds, loads and exports every symbol
+include/trlda_hip.h declares; host-side logic (document conversion, argument handling,
+sharding, text loader, libc-rand sampler); the product never touches oracle/; and without
+a GPU everything fails loudly instead of falling back."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import HipSampler, golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "trlda_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(trlda_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    names = header_symbols()
+    assert len(names) >= 30
+    for name in names:
+        assert hasattr(hip_lib, name), "libtrlda_hip.so does not export %s" % name
+
+
+def test_python_binding_covers_the_header(hip_lib):
+    from trlda_amd import _ffi
+    assert sorted(_ffi.EXPORTED_SYMBOLS) == header_symbols()
+
+
+def test_library_has_no_torch_or_python_dependency(hip_lib):
+    from trlda_amd import _ffi
+    out = subprocess.run(["ldd", _ffi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "libamdhip64" in out
+    assert "torch" not in out and "python" not in out
+
+
+def test_library_contains_gfx950_code_object(hip_lib):
+    from trlda_amd import _ffi
+    blob = open(_ffi.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    assert b"estep_docs_kernel" in blob
+
+
+def test_product_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use oracle/."""
+    pkg = os.path.join(ROOT, "trlda_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp", ".c")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert "pyoracle" not in text, fn
+                assert "liboracle" not in text and "libtrlda_ref" not in text, fn
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), fn
+    code = "import sys; import trlda_amd, trlda_amd.distributed; " \
+           "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules)"
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
+
+
+def test_sampler_matches_reference_stream(hip_lib):
+    """trlda_sample_gamma == the reference's sampleGamma on libc rand(), bit for bit."""
+    f = golden("f0_rng_psi")
+    s = HipSampler(hip_lib)
+    s.seed(42)
+    assert np.array_equal(s.sample_gamma(3, 2, 100), f["sg_seed42_3x2x100"])
+    s.seed(7)
+    assert np.array_equal(s.sample_gamma(5, 4, 3), f["sg_seed7_5x4x3"])
+    import trlda_amd
+    trlda_amd.seed(42)
+    out = np.zeros((3, 2), order="F")
+    hip_lib.trlda_sample_gamma_init(3, 2, out)
+    assert np.array_equal(out, f["sg_seed42_3x2x100"] / 100.)
+    with pytest.raises(TypeError):
+        trlda_amd.seed(1.5)
+
+
+def test_batch_validation_happens_before_any_gpu_work(hip_lib):
+    from trlda_amd import _ffi
+    h = _ffi.vp()
+    ip = np.array([0, 2], np.int32)
+    bad = hip_lib.trlda_batch_create(ctypes.byref(h), 0, 5, 1, ip, np.array([1, 5], np.int32),
+                                     np.array([1, 1], np.int32))
+    assert bad == _ffi.ERR_WORD_ID and b"word id" in hip_lib.trlda_last_error()
+    bad = hip_lib.trlda_batch_create(ctypes.byref(h), 0, 5, 1, ip, np.array([1, -1], np.int32),
+                                     np.array([1, 1], np.int32))
+    assert bad == _ffi.ERR_WORD_ID
+    bad = hip_lib.trlda_batch_create(ctypes.byref(h), 0, 5, 2, np.array([0, 2, 1], np.int32),
+                                     np.array([1, 2], np.int32), np.array([1, 1], np.int32))
+    assert bad == _ffi.ERR_ARG
+
+
+@pytest.mark.skipif(os.environ.get("TRLDA_EXPECT_GPU") == "1", reason="GPU box")
+def test_no_gpu_means_loud_failure_not_fallback(hip_lib):
+    from trlda_amd import _ffi
+    if _ffi.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    from trlda_amd.models import BatchLDA, OnlineLDA
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        OnlineLDA(num_words=50, num_topics=4, num_documents=10)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        BatchLDA(num_words=50, num_topics=4)
+    lam = np.ones((2, 3), order="F")
+    g = np.ones((2, 1), order="F")
+    s = np.zeros((2, 3), order="F")
+    rc = hip_lib.trlda_estep(2, 3, 1, np.array([0, 1], np.int32), np.array([0], np.int32),
+                             np.array([1], np.int32), lam, np.ones(2), g, s, 5, 1e-3, None, 0)
+    assert rc == _ffi.ERR_NO_DEVICE
+    assert b"no CPU fallback" in hip_lib.trlda_last_error() or b"no HIP device" in \
+        hip_lib.trlda_last_error()
+    h = _ffi.vp()
+    assert hip_lib.trlda_model_create(ctypes.byref(h), 0, 2, 3) == _ffi.ERR_NO_DEVICE
+
+
+def test_missing_library_is_an_error(tmp_path, monkeypatch):
+    from trlda_amd import _ffi
+    monkeypatch.setattr(_ffi, "_lib", None)
+    monkeypatch.setattr(_ffi, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _ffi.lib()
+
+
+# ---- documents ------------------------------------------------------------------------
+
+def test_docs_conversion_matches_pylist_to_documents():
+    from trlda_amd.documents import as_csr
+    docs = [[(3, 1), (7, 2)], [], [(0, 5)]]
+    csr = as_csr(docs)
+    assert csr.indptr.tolist() == [0, 2, 2, 3]
+    assert csr.ids.tolist() == [3, 7, 0] and csr.cnts.tolist() == [1, 2, 5]
+    assert csr.indptr.dtype == csr.ids.dtype == csr.cnts.dtype == np.int32
+    assert csr.to_list() == docs
+    assert len(as_csr([])) == 0
+    with pytest.raises(TypeError, match="Documents must be stored in a list."):
+        as_csr(((1, 2),))
+    with pytest.raises(TypeError, match="Each document must be a list of tuples."):
+        as_csr([((1, 2),)])
+    with pytest.raises(TypeError):
+        as_csr([[(1, 2, 3)]])
+    with pytest.raises(TypeError):
+        as_csr([[[1, 2]]])
+    with pytest.raises(TypeError):
+        as_csr([[(1.5, 2)]])
+
+
+def test_shards_are_contiguous_balanced_and_complete():
+    from trlda_amd.documents import CSRDocuments
+    from trlda_amd.utils.synthetic import make_corpus
+    csr = CSRDocuments(*make_corpus(203, 500, seed=1, mean_unique=40))
+    for world in (1, 2, 3, 8):
+        parts = [csr.shard(r, world) for r in range(world)]
+        assert sum(len(p) for p in parts) == len(csr)
+        assert np.array_equal(np.concatenate([p.ids for p in parts]), csr.ids)
+        assert np.array_equal(np.concatenate([p.cnts for p in parts]), csr.cnts)
+        nnz = np.array([p.indptr[-1] for p in parts], dtype=float)
+        assert nnz.max() <= 1.15 * nnz.mean() + 100
+    # more ranks than documents: some shards are empty, nothing is lost
+    tiny = CSRDocuments([0, 1, 3], [1, 2, 3], [1, 1, 1])
+    parts = [tiny.shard(r, 8) for r in range(8)]
+    assert sum(len(p) for p in parts) == 2
+
+
+def test_alpha_argument_handling():
+    from trlda_amd.models import _alpha_vector, _inference_method
+    K, a = _alpha_vector(None, 7)
+    assert K == 7 and np.allclose(a, .1)
+    K, a = _alpha_vector(2, 5)
+    assert K == 5 and np.allclose(a, 2.)
+    K, a = _alpha_vector([.1, .2], 10)          # an array DEFINES K (onlineldainterface.cpp:83)
+    assert K == 2
+    K, a = _alpha_vector(np.ones((1, 4)), 3)
+    assert K == 4
+    K, a = _alpha_vector(np.ones((4, 1)), 3)
+    assert K == 4
+    with pytest.raises(TypeError, match="one-dimensional"):
+        _alpha_vector(np.ones((2, 3)), 3)
+    assert _inference_method("vi") == "VI" and _inference_method("Gibbs") == "GIBBS"
+    assert _inference_method(None) == "VI"
+    with pytest.raises(TypeError):
+        _inference_method("map")
+
+
+def test_abstract_classes():
+    from trlda_amd.models import LDA, Distribution
+    with pytest.raises(NotImplementedError):
+        Distribution()
+    with pytest.raises(NotImplementedError):
+        LDA()
+
+
+def test_load_documents(tmp_path):
+    from trlda_amd.utils import load_documents, load_documents_csr
+    path = tmp_path / "corpus.dat"
+    lines = ["6 5600:2 293:1 5548:1 2577:1 3733:3 2677:2", "2 1:1 2:7", "0", "1 9:9", "3 4:1 5:1 6:2"]
+    path.write_text("\n".join(lines) + "\n")
+    docs = load_documents(str(path))
+    assert len(docs) == 5
+    assert docs[0][:2] == [(5600, 2), (293, 1)] and docs[2] == [] and docs[3] == [(9, 9)]
+    batches = list(load_documents(str(path), 2))
+    assert [len(b) for b in batches] == [2, 2, 1]
+    assert batches[0] == docs[:2] and batches[2] == docs[4:]
+    # a file whose length is a multiple of the batch size ends with an empty batch, as in the
+    # reference's generator (load_documents.py:66)
+    assert [len(b) for b in load_documents(str(path), 5)] == [5, 0]
+    csr = load_documents_csr(str(path))
+    assert csr.to_list() == docs
+    np.random.seed(0)
+    sizes = [len(b) for b in load_documents(str(path), 2, stochastic=True)]
+    assert sum(sizes) == 5
+
+
+def test_synthetic_corpus_properties():
+    from trlda_amd.utils.synthetic import make_corpus
+    ip, ii, cc = make_corpus(50, 300, seed=3, mean_unique=40)
+    ip2, ii2, cc2 = make_corpus(50, 300, seed=3, mean_unique=40)
+    assert np.array_equal(ii, ii2) and np.array_equal(cc, cc2)          # seeded
+    assert ii.min() >= 0 and ii.max() < 300 and cc.min() >= 1
+    for d in range(50):
+        seg = ii[ip[d]:ip[d + 1]]
+        assert len(seg) >= 1 and len(np.unique(seg)) == len(seg)        # unique ids per doc
+    # Zipf: low ids are far more frequent than high ids
+    assert (ii < 30).sum() > 3 * (ii >= 270).sum()

@@ -1,0 +1,386 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the reference's golden
+vectors and the pinned CPU oracle, on a real MI355X.
+
+Bars: BASELINE.json's north star asks for gamma / lambda within 1e-5 relative (fp64); these
+tests hold the kernels to TIGHT_RTOL = 1e-9, and iteration counts must be identical.
+"""
+import ctypes as C
+import pickle
+
+import numpy as np
+import pytest
+
+from helpers import (NORTH_STAR_RTOL, TIGHT_RTOL, HipSampler, golden, relerr, seeded_gamma,
+                     seeded_lambda)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip(hip_lib):
+    from trlda_amd import _ffi
+    assert _ffi.device_count() >= 1, "GPU tests need a visible MI355X"
+    return hip_lib
+
+
+@pytest.fixture(scope="module")
+def sampler(hip):
+    return HipSampler(hip)
+
+
+def make_model(K, V, lam, alpha=.1, eta=.3, D=1000):
+    from trlda_amd.models import OnlineLDA
+    m = OnlineLDA(num_words=V, num_topics=K, num_documents=D, alpha=alpha, eta=eta)
+    m.lambdas = lam
+    return m
+
+
+def csr(f, suffix=""):
+    from trlda_amd.documents import CSRDocuments
+    return CSRDocuments(f["indptr" + suffix], f["ids" + suffix], f["cnts" + suffix])
+
+
+def check_sstats(got, want, rtol=TIGHT_RTOL):
+    assert relerr(got[want > 0], want[want > 0]) < rtol
+    assert np.array_equal(got == 0, want == 0)
+
+
+def test_native_library_is_loaded(hip):
+    maps = open("/proc/self/maps").read()
+    assert "libtrlda_hip.so" in maps
+
+
+@pytest.mark.parametrize("name", ["f1a_estep", "f1b_estep"])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_estep_golden(hip, sampler, name, mode):
+    f = golden(name)
+    K, V, B = int(f["K"]), int(f["V"]), int(f["B"])
+    lam = seeded_lambda(sampler, f["lambda_seed"], K, V)
+    g0 = seeded_gamma(sampler, f["gamma0_seed"], K, B)
+    m = make_model(K, V, lam, alpha=f["alpha"])
+    hip.trlda_model_set_sstats_mode(m._handle, mode)
+    batch = m.upload(csr(f))
+    for threads in (0, 64, 512):
+        hip.trlda_model_set_doc_threads(m._handle, threads)
+        for (it, thr) in [(0, 1e-3), (1, 1e-3), (20, 1e-3), (50, 0.0), (100, 1e-3)]:
+            key = "it%d_thr%g" % (it, thr)
+            g, s, iters = m.update_variables(batch, latents=g0, max_iter=it, threshold=thr,
+                                             return_iterations=True)
+            assert g.flags.f_contiguous and s.flags.f_contiguous
+            assert g.shape == (K, B) and s.shape == (K, V)
+            assert relerr(g, f["gamma_" + key]) < TIGHT_RTOL
+            check_sstats(s, f["sstats_" + key])
+            assert np.array_equal(iters, f["iters_" + key])
+
+
+def test_estep_bench_shape_golden(hip, sampler):
+    f = golden("f2_bench_shape")
+    K, V, B = int(f["K"]), int(f["V"]), int(f["B"])
+    lam = seeded_lambda(sampler, f["lambda_seed"], K, V)
+    g0 = seeded_gamma(sampler, f["gamma0_seed"], K, B)
+    m = make_model(K, V, lam)
+    g, s = m.do_e_step(csr(f), latents=g0, max_iter=20)
+    assert relerr(g, f["gamma"]) < TIGHT_RTOL
+    check_sstats(s[:, f["active"]], f["sstats_active"])
+    inactive = np.setdiff1d(np.arange(V), f["active"])
+    assert (s[:, inactive] == 0).all()
+
+
+@pytest.mark.parametrize("name", ["f3a_edge", "f3b_edge"])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_estep_edge_documents(hip, sampler, name, mode):
+    """empty document, duplicate ids, zero counts, single word, id = V-1 and 0, n_d > 64, a
+    document longer than the LDS tile (streamed path in f3b), all-zero counts."""
+    f = golden(name)
+    K, V, B = int(f["K"]), int(f["V"]), int(f["B"])
+    lam = seeded_lambda(sampler, f["lambda_seed"], K, V)
+    g0 = seeded_gamma(sampler, f["gamma0_seed"], K, B)
+    m = make_model(K, V, lam)
+    hip.trlda_model_set_sstats_mode(m._handle, mode)
+    for threads in (0, 128, 1024):
+        hip.trlda_model_set_doc_threads(m._handle, threads)
+        for (it, thr) in [(0, 1e-3), (30, 1e-3), (7, 0.0)]:
+            key = "it%d_thr%g" % (it, thr)
+            g, s = m.update_variables(csr(f), latents=g0, max_iter=it, threshold=thr)
+            assert relerr(g, f["gamma_" + key]) < TIGHT_RTOL
+            if "sstats_active_" + key in f:
+                check_sstats(s[:, f["active"]], f["sstats_active_" + key])
+            want_sum = float(f["sstats_sum_" + key])
+            assert abs(s.sum() - want_sum) <= 1e-9 * max(1., abs(want_sum))
+
+
+def test_hoffman_cross_implementation(hip):
+    """The reference's own test_vi (onlinelda_test.py:39-68), list-of-tuples input."""
+    f = golden("f7_hoffman_test_vi")
+    m = make_model(int(f["K"]), int(f["V"]), f["lam"], D=int(f["B"]))
+    docs = csr(f).to_list()
+    g, s = m.do_e_step(docs, max_iter=50, latents=f["gamma0"])
+    for tag in ("hoffman", "ref"):
+        assert relerr(g, f["gamma_" + tag]) < TIGHT_RTOL
+        check_sstats(s, f["sstats_" + tag])
+    assert np.corrcoef(f["gamma_hoffman"].ravel(), g.ravel())[0, 1] > 0.99
+    assert np.corrcoef(f["sstats_hoffman"].ravel(), s.ravel())[0, 1] > 0.99
+
+
+def test_one_shot_c_abi(hip, oracle, sampler):
+    """trlda_estep / trlda_mstep_blend / trlda_tr_init with plain host pointers."""
+    from trlda_amd.utils.synthetic import make_corpus
+    K, V, B, D = 9, 140, 17, 300
+    ip, ii, cc = make_corpus(B, V, seed=8, mean_unique=30)
+    lam = seeded_lambda(sampler, 21, K, V)
+    g0 = seeded_gamma(sampler, 22, K, B)
+    alpha = np.linspace(.05, .5, K)
+    g = g0.copy(order="F")
+    s = np.zeros((K, V), order="F")
+    iters = np.zeros(B, np.int32)
+    rc = hip.trlda_estep(K, V, B, ip, ii, cc, lam, alpha, g, s, 40, 1e-3, iters.ctypes.data, 0)
+    assert rc == 0, hip.trlda_last_error()
+    go, so, ito = oracle.estep(lam, alpha, ip, ii, cc, g0, 40, 1e-3)
+    assert relerr(g, go) < TIGHT_RTOL
+    check_sstats(s, so)
+    assert np.array_equal(iters, ito)
+    out = np.zeros((K, V), order="F")
+    assert hip.trlda_mstep_blend(K, V, .3, .25, D / B, lam, s, out, 0) == 0
+    assert relerr(out, oracle.mstep_blend(lam, so, .3, .25, D / B)) < TIGHT_RTOL
+    assert hip.trlda_tr_init(K, V, B, D, .3, .25, ip, ii, cc, lam, out, 0) == 0
+    assert relerr(out, oracle.tr_init(lam, ip, ii, cc, D, .3, .25)) < 1e-14
+    # an out-of-range word id is an error, not UB
+    bad = ii.copy()
+    bad[3] = V
+    assert hip.trlda_estep(K, V, B, ip, bad, cc, lam, alpha, g, s, 5, 1e-3, None, 0) == -3
+
+
+def test_online_trajectories_golden(hip):
+    """update_parameters under trlda_amd.seed(): TR in {0,3} x init_gamma x rho."""
+    import trlda_amd
+    from trlda_amd.models import OnlineLDA
+    f = golden("f4_online_trajectory")
+    K, V, D = int(f["K"]), int(f["V"]), int(f["D"])
+    for case in range(int(f["num_cases"])):
+        tr, init_gamma, rho, seed, count_want, r_empty = f["c%d_meta" % case]
+        trlda_amd.seed(int(seed))
+        m = OnlineLDA(num_words=V, num_topics=K, num_documents=D, alpha=.1, eta=.3)
+        assert np.array_equal(m.lambdas, f["c%d_lambda0" % case])      # libc stream, bit-exact
+        for i in range(3):
+            r = m.update_parameters(csr(f, str(i)), max_iter_tr=int(tr), max_iter_inference=20,
+                                    kappa=.7, tau=100., rho=float(rho),
+                                    init_gamma=bool(init_gamma))
+            assert abs(r - f["c%d_rhos" % case][i]) < 1e-15
+            assert relerr(m.lambdas, f["c%d_lambda%d" % (case, i + 1)]) < TIGHT_RTOL
+        before = m.lambdas
+        assert m.update_parameters([], max_iter_tr=int(tr)) == 1.0      # onlinelda.cpp:54-56
+        assert m.update_count == int(count_want) == 3
+        assert np.array_equal(m.lambdas, before)
+
+
+def test_config1_golden(hip):
+    """BASELINE.json configs[0] end to end: K=10, V=1000, 1k docs, batch 100, TR=10."""
+    import trlda_amd
+    from trlda_amd.documents import CSRDocuments
+    from trlda_amd.models import OnlineLDA
+    from trlda_amd.utils.synthetic import make_corpus
+    f = golden("f4b_config1")
+    K, V, D, B = int(f["K"]), int(f["V"]), int(f["D"]), int(f["B"])
+    docs = CSRDocuments(*make_corpus(D, V, seed=int(f["corpus_seed"]),
+                                     mean_unique=int(f["mean_unique"])))
+    trlda_amd.seed(int(f["seed"]))
+    m = OnlineLDA(num_words=V, num_topics=K, num_documents=D)
+    for b in range(D // B):
+        r = m.update_parameters(docs.slice(b * B, (b + 1) * B), max_iter_tr=10,
+                                max_iter_inference=20)
+        assert abs(r - f["rhos"][b]) < 1e-15
+    assert m.update_count == int(f["update_count"])
+    assert relerr(m.lambdas, f["lambda_final"]) < 1e-7 < NORTH_STAR_RTOL
+
+
+def test_batch_lda_golden(hip):
+    import trlda_amd
+    from trlda_amd.models import BatchLDA
+    f = golden("f5_batch")
+    trlda_amd.seed(int(f["seed"]))
+    m = BatchLDA(num_words=int(f["V"]), num_topics=int(f["K"]), alpha=.1, eta=.3)
+    assert np.array_equal(m.lambdas, f["lambda0"])
+    assert m.update_parameters(csr(f), max_epochs=2, max_iter_inference=100) == 1.
+    assert relerr(m.lambdas, f["lambda2"]) < TIGHT_RTOL
+    assert m.update_parameters([]) == 1.
+
+
+def test_default_gamma_comes_from_the_seeded_libc_stream(hip, oracle):
+    import trlda_amd
+    from trlda_amd.utils.synthetic import make_corpus
+    K, V, B = 6, 80, 9
+    ip, ii, cc = make_corpus(B, V, seed=5, mean_unique=20)
+    lam = seeded_lambda(oracle, 9, K, V)
+    m = make_model(K, V, lam, D=100)
+    from trlda_amd.documents import CSRDocuments
+    trlda_amd.seed(10)
+    g, s = m.update_variables(CSRDocuments(ip, ii, cc), max_iter=15)
+    g0 = seeded_gamma(oracle, 10, K, B)
+    go, so, _ = oracle.estep(lam, .1, ip, ii, cc, g0, 15, 1e-3)
+    assert relerr(g, go) < TIGHT_RTOL
+    check_sstats(s, so)
+
+
+# ---- BASELINE.json full sizes: size-independent properties ---------------------------
+
+@pytest.fixture(scope="module")
+def bench_case(hip, sampler):
+    from trlda_amd.documents import CSRDocuments
+    from trlda_amd.utils.synthetic import make_corpus
+    K, V, B = 100, 7000, 200
+    docs = CSRDocuments(*make_corpus(B, V, seed=20150707, mean_unique=100))
+    lam = seeded_lambda(sampler, 1, K, V)
+    g0 = seeded_gamma(sampler, 2, K, B)
+    return K, V, B, docs, lam, g0
+
+
+def test_full_size_invariants_and_oracle(hip, oracle, bench_case):
+    K, V, B, docs, lam, g0 = bench_case
+    m = make_model(K, V, lam, D=1000000)
+    g, s, iters = m.update_variables(docs, latents=g0, max_iter=20, return_iterations=True)
+    total = float(docs.cnts.sum())
+    # sum sstats = sum counts; sum gamma = sum counts + B*sum(alpha)
+    assert abs(s.sum() - total) < 1e-9 * total
+    assert abs(g.sum() - (total + B * K * .1)) < 1e-9 * total
+    assert (g > 0).all() and (s >= 0).all()
+    go, so, ito = oracle.estep(lam, .1, docs.indptr, docs.ids, docs.cnts, g0, 20, 1e-3)
+    assert relerr(g, go) < TIGHT_RTOL
+    check_sstats(s, so)
+    assert np.array_equal(iters, ito)
+
+
+def test_full_size_bitwise_reproducible_and_mode_agreement(hip, bench_case):
+    K, V, B, docs, lam, g0 = bench_case
+    m = make_model(K, V, lam, D=1000000)
+    batch = m.upload(docs)
+    g1, s1 = m.update_variables(batch, latents=g0, max_iter=20)
+    g2, s2 = m.update_variables(batch, latents=g0, max_iter=20)
+    assert np.array_equal(g1, g2) and np.array_equal(s1, s2)      # segmented mode: bitwise
+    hip.trlda_model_set_sstats_mode(m._handle, 1)
+    g3, s3 = m.update_variables(batch, latents=g0, max_iter=20)
+    assert np.array_equal(g1, g3)
+    assert relerr(s3[s1 > 0], s1[s1 > 0]) < 1e-12                  # atomics: order only
+
+
+def test_full_size_document_permutation(hip, bench_case):
+    """Documents are independent given lambda: permuting the batch permutes gamma and leaves
+    the statistics unchanged up to summation order."""
+    from trlda_amd.documents import CSRDocuments
+    K, V, B, docs, lam, g0 = bench_case
+    m = make_model(K, V, lam, D=1000000)
+    g1, s1 = m.update_variables(docs, latents=g0, max_iter=20)
+    perm = np.random.RandomState(0).permutation(B)
+    lens = np.diff(docs.indptr)
+    ip = np.zeros(B + 1, np.int32)
+    ip[1:] = np.cumsum(lens[perm])
+    ids = np.concatenate([docs.ids[docs.indptr[d]:docs.indptr[d + 1]] for d in perm])
+    cnts = np.concatenate([docs.cnts[docs.indptr[d]:docs.indptr[d + 1]] for d in perm])
+    g2, s2 = m.update_variables(CSRDocuments(ip, ids, cnts), latents=g0[:, perm], max_iter=20)
+    assert np.array_equal(g2, g1[:, perm])
+    assert relerr(s2[s1 > 0], s1[s1 > 0]) < 1e-12
+
+
+def test_converged_documents_stop_early(hip, oracle, sampler):
+    """The data-dependent break (lda.cpp:202-203): iteration counts below max_iter, equal to
+    the oracle's, per document."""
+    from trlda_amd.utils.synthetic import make_corpus
+    K, V, B = 8, 400, 64
+    ip, ii, cc = make_corpus(B, V, seed=13, mean_unique=12)
+    lam = seeded_lambda(sampler, 5, K, V)
+    g0 = seeded_gamma(sampler, 6, K, B)
+    m = make_model(K, V, lam)
+    from trlda_amd.documents import CSRDocuments
+    g, s, iters = m.update_variables(CSRDocuments(ip, ii, cc), latents=g0, max_iter=200,
+                                     threshold=1e-3, return_iterations=True)
+    go, so, ito = oracle.estep(lam, .1, ip, ii, cc, g0, 200, 1e-3)
+    assert iters.max() < 200 and len(np.unique(iters)) > 1
+    assert np.array_equal(iters, ito)
+    assert relerr(g, go) < TIGHT_RTOL
+
+
+# ---- the Python surface (onlinelda_test.py:14-35, 113-124, 176-200) ------------------
+
+def test_basics_like_the_reference(hip):
+    from trlda_amd.models import OnlineLDA
+    W, D, K, alpha, eta = 102, 1010, 11, .27, 3.1
+    model = OnlineLDA(num_words=W, num_topics=K, num_documents=D, alpha=alpha, eta=eta)
+    assert model.num_topics == K and model.alpha.size == K
+    assert model.num_documents == D and model.num_words == W
+    assert model.alpha.ravel()[3] == alpha and model.alpha.shape == (K, 1)
+    assert model.eta == eta
+    with pytest.raises(RuntimeError):
+        model.alpha = np.random.rand(K + 1)
+    with pytest.raises(RuntimeError):
+        model.alpha = -1.
+    new_alpha = np.random.rand(K, 1)
+    model.alpha = new_alpha
+    assert np.max(np.abs(model.alpha.ravel() - new_alpha.ravel())) < 1e-20
+    lam = model.lambdas
+    assert lam.shape == (K, W) and lam.flags.f_contiguous and not lam.flags.writeable
+    assert np.array_equal(model._lambda, lam)
+    with pytest.raises(RuntimeError, match="Lambda has wrong dimensionality."):
+        model.lambdas = np.ones((K, W + 1))
+    model.lambdas = [[1.5] * W] * K                                  # nested lists are fine
+    assert (model.lambdas == 1.5).all()
+    with pytest.raises(RuntimeError):
+        model.eta = -1.
+    with pytest.raises(RuntimeError):
+        model.num_documents = -5
+    with pytest.raises(RuntimeError):
+        model.update_count = -1
+    with pytest.raises(RuntimeError, match="Initial gamma has wrong dimensionality."):
+        model.update_variables([[(1, 1)]], latents=np.ones((K + 1, 1)))
+    with pytest.raises(TypeError):
+        model.update_variables([[(1, 1)]], inference_method="x")
+    with pytest.raises(TypeError, match="Documents must be stored in a list."):
+        model.update_parameters("nope")
+    with pytest.raises(RuntimeError, match="word id"):
+        model.update_variables([[(W, 1)]])
+    assert "Number of topics: 11" in str(model)
+    # an alpha array defines K (onlineldainterface.cpp:83)
+    assert OnlineLDA(num_words=20, num_topics=10, num_documents=5, alpha=[.1, .1]).num_topics == 2
+
+
+def test_m_step_counter(hip):
+    from trlda_amd.models import OnlineLDA
+    model = OnlineLDA(num_words=100, num_topics=10, num_documents=1000)
+    model.update_parameters([])                                     # used to FPE in the reference
+    docs = [[(int(w), 1) for w in np.random.permutation(100)[:5]] for _ in range(10)]
+    model.update_parameters(docs)
+    model.update_parameters(docs)
+    assert model.update_count == 2
+
+
+def test_pickle(hip):
+    from trlda_amd.models import BatchLDA, OnlineLDA
+    model0 = OnlineLDA(num_words=300, num_topics=50, num_documents=11110, alpha=np.random.rand(),
+                       eta=np.random.rand())
+    model0.update_count = 7
+    model1 = pickle.loads(pickle.dumps({'model': model0}))['model']
+    assert model0.num_words == model1.num_words and model0.num_topics == model1.num_topics
+    assert model0.num_documents == model1.num_documents and model1.update_count == 7
+    assert np.max(np.abs(model0.lambdas - model1.lambdas)) < 1e-20
+    assert np.max(np.abs(model0.alpha - model1.alpha)) < 1e-20
+    assert abs(model0.eta - model1.eta) < 1e-20
+    b0 = BatchLDA(num_words=40, num_topics=5, alpha=.2, eta=.4)
+    b1 = pickle.loads(pickle.dumps(b0))
+    assert np.array_equal(b0.lambdas, b1.lambdas) and b1.eta == .4
+
+
+def test_sharded_model_single_rank_matches_online_lda(hip):
+    """trlda_amd.distributed with the real HIP engine (world size 1, no collective)."""
+    import trlda_amd
+    from trlda_amd.distributed import ShardedOnlineLDA
+    from trlda_amd.documents import CSRDocuments
+    from trlda_amd.models import OnlineLDA
+    from trlda_amd.utils.synthetic import make_corpus
+    K, V, D, B = 12, 300, 2000, 40
+    docs = [CSRDocuments(*make_corpus(B, V, seed=60 + i, mean_unique=30)) for i in range(2)]
+    trlda_amd.seed(3)
+    a = OnlineLDA(num_words=V, num_topics=K, num_documents=D)
+    ra = [a.update_parameters(d, max_iter_tr=3) for d in docs]
+    trlda_amd.seed(3)
+    b = ShardedOnlineLDA(V, K, D, device=0)
+    rb = [b.update_parameters(d, max_iter_tr=3) for d in docs]
+    assert ra == rb and b.update_count == 2
+    assert np.array_equal(a.lambdas, b.lambdas)
