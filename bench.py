@@ -1,0 +1,297 @@
+#!/usr/bin/env python3
+"""bench.py -- E-step docs/sec (mini-batch) at K=100, V=7000 on MI355X.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): OnlineLDA K=100, V=7000, mini-batches of
+200 synthetic documents per GPU (Zipf-1.07 vocabulary, ~100 unique words per document),
+max_iter_inference=20, threshold=1e-3.  A *step* is one full E-step of the reference's
+LDA::updateVariablesVI (lda.cpp:160-220) over one mini-batch per GPU: row sums + exp E[log
+beta] preamble, per-document gamma fixed point, sufficient statistics -- and, for N > 1, the
+RCCL all-reduce of the K x V statistics (the path's one exchange step).  Inputs (lambda,
+CSR batches and their word-major index, gamma0) are resident in HBM before the timed region;
+nothing is cached across steps (lambda's preamble is recomputed every step, as in the
+reference).  Weak scaling: 200 documents per GPU per step.
+
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel
+(estep_docs_kernel) from HIP events on the launch stream; `cpu_baseline` is the reference's
+own C++ core (oracle/_ref, kind "reference") or, when that was not built, the plain-C port
+(oracle/cpu_ref.c) timed on this box's host cores on a bounded sample of the same batches.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+KERNEL_NAMES = ["rowsum_psi_kernel", "exp_elog_beta_kernel", "estep_docs_kernel",
+                "sstats_words_kernel"]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--topics", type=int, default=100)
+    ap.add_argument("--words", type=int, default=7000)
+    ap.add_argument("--batch", type=int, default=200, help="documents per GPU per step")
+    ap.add_argument("--max-iter", type=int, default=20)
+    ap.add_argument("--threshold", type=float, default=1e-3)
+    ap.add_argument("--mean-unique", type=int, default=100)
+    ap.add_argument("--uniform", action="store_true", help="uniform instead of Zipf vocabulary")
+    ap.add_argument("--num-batches", type=int, default=8, help="distinct mini-batches cycled")
+    ap.add_argument("--sstats-mode", choices=["segmented", "atomic"], default="segmented")
+    ap.add_argument("--doc-threads", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def algorithmic_bytes(K, V, indptr):
+    """bytes_alg = 32 K V + sum_d (16 K n_d + 8 n_d + 16 K) per E-step call,
+    and the share of it that the document kernel itself moves (DESIGN.md 'Kernels')."""
+    n = np.diff(indptr).astype(np.float64)
+    B = len(n)
+    per_doc = float((16. * K * n + 8. * n + 16. * K).sum())
+    estep = 32. * K * V + per_doc
+    # document kernel: gather beta_d once (8 K n), ids + counts (8 n), gamma in/out (16 K),
+    # exp(psi(gamma)) out (8 K) and the per-word weights handed to the sstats kernel (8 n)
+    docs_kernel = float((8. * K * n + 16. * n + 24. * K).sum())
+    return estep, docs_kernel, B
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
+                             "--nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    from trlda_amd import _ffi, build
+    from trlda_amd.documents import CSRDocuments, DeviceBatch
+    from trlda_amd.utils.synthetic import SEED_BASE, make_corpus
+
+    if not os.path.exists(_ffi.LIB_PATH):
+        build.build()
+    L = _ffi.lib()
+    _ffi.require_gpu()
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    K, V, B = args.topics, args.words, args.batch
+    KV = K * V
+
+    # ---- inputs, resident in HBM before the timed region ---------------------------------
+    L.trlda_seed(1)                                   # libc stream: lambda0 then gamma0s
+    lam = np.empty((K, V), order="F")
+    L.trlda_sample_gamma_init(K, V, lam)              # replicated lambda (same seed per rank)
+    model = _ffi.vp()
+    _ffi.check(L.trlda_model_create(C.byref(model), local_rank, K, V))
+    stream = torch.cuda.current_stream(device).cuda_stream
+    _ffi.check(L.trlda_model_set_stream(model, _ffi.vp(stream)))
+    _ffi.check(L.trlda_model_set_lambda(model, lam))
+    _ffi.check(L.trlda_model_set_alpha(model, np.full(K, .1)))
+    _ffi.check(L.trlda_model_set_sstats_mode(model, 1 if args.sstats_mode == "atomic" else 0))
+    _ffi.check(L.trlda_model_set_doc_threads(model, args.doc_threads))
+
+    batches, csrs, gamma0s = [], [], []
+    for i in range(args.num_batches):
+        seed = SEED_BASE + 1 + 1000 * rank + i       # config index 1; distinct per rank
+        csr = CSRDocuments(*make_corpus(B, V, seed=seed, mean_unique=args.mean_unique,
+                                        zipf=not args.uniform))
+        csrs.append(csr)
+        batches.append(DeviceBatch(csr, V, local_rank))
+        g0 = np.empty((K, B), order="F")
+        L.trlda_sample_gamma_init(K, B, g0)
+        gamma0s.append(torch.from_numpy(np.ascontiguousarray(g0.T)).to(device))
+    gamma = torch.empty(B * K, dtype=torch.float64, device=device)
+    sstats = torch.empty(KV, dtype=torch.float64, device=device)
+    iters_dev = torch.zeros(B, dtype=torch.int32, device=device)
+
+    def step(i, want_iters=False):
+        j = i % args.num_batches
+        gamma.copy_(gamma0s[j].view(-1))              # gamma is in/out: restore gamma0
+        _ffi.check(L.trlda_model_estep(model, batches[j].handle, gamma.data_ptr(),
+                                       sstats.data_ptr(), args.max_iter, args.threshold,
+                                       iters_dev.data_ptr() if want_iters else None))
+        if world > 1:
+            dist.all_reduce(sstats)                   # RCCL over xGMI: K x V fp64 sum
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    docs_per_s = world * B * args.steps / elapsed
+
+    # ---- per-kernel durations: HIP events on the launch stream, same steps replayed -------
+    _ffi.check(L.trlda_model_set_timing(model, 1))
+    for i in range(args.steps):
+        step(i)
+    fence()
+    kernel_us = []
+    for w in range(4):
+        us, cnt = C.c_double(), C.c_int64()
+        _ffi.check(L.trlda_model_get_timing(model, w, C.byref(us), C.byref(cnt)))
+        kernel_us.append(us.value / max(cnt.value, 1))
+    _ffi.check(L.trlda_model_set_timing(model, 0))
+
+    step(0, want_iters=True)
+    fence()
+    mean_iters = float(iters_dev.float().mean().item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    estep_bytes, docs_bytes, _ = algorithmic_bytes(K, V, csrs[0].indptr)
+    all_e, all_d = zip(*[algorithmic_bytes(K, V, c.indptr)[:2] for c in csrs])
+    estep_bytes, docs_bytes = float(np.mean(all_e)), float(np.mean(all_d))
+    docs_us = kernel_us[2]
+    achieved = docs_bytes / (docs_us * 1e-6) / 1e9 if docs_us > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("estep_docs_kernel_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    kernel_names = list(KERNEL_NAMES)
+    if args.sstats_mode == "atomic":
+        kernel_names[3] = "finish_kernel"
+    roofline = {
+        "bound": "hbm", "kernel": "estep_docs_kernel",
+        "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "algorithmic_bytes_per_launch": docs_bytes,
+        "avg_launch_us": round(docs_us, 2),
+        "method": "HIP events on the launch stream; replay of the timed steps with stamps on",
+        "kernels_us": {n: round(u, 2) for n, u in zip(kernel_names, kernel_us)},
+        "estep": {   # the whole path against SURVEY.md 8(d)'s bytes_alg
+            "algorithmic_bytes_per_step": estep_bytes,
+            "achieved": round(estep_bytes * args.steps / elapsed / 1e9, 2),
+            "frac": round(estep_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5)},
+    }
+
+    # ---- parity + CPU baseline (rank 0, N = 1 only): the checker, timed beside the GPU ----
+    cpu_baseline, parity = None, None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle                   # test infrastructure: checker + baseline
+        orc = pyoracle.Oracle()
+        c = csrs[0]
+        g0 = np.asfortranarray(gamma0s[0].cpu().numpy().T)
+        go, so, ito = orc.estep(lam, .1, c.indptr, c.ids, c.cnts, g0, args.max_iter,
+                                args.threshold)
+        step(0, want_iters=True)
+        fence()
+        gg = np.asfortranarray(gamma.cpu().numpy().reshape(B, K).T)
+        sg = sstats.cpu().numpy().reshape(K, V, order="F")
+        nz = so > 0
+        parity = {"gamma_max_rel_err": float(np.max(np.abs(gg - go) / np.abs(go))),
+                  "sstats_max_rel_err": float(np.max(np.abs(sg[nz] - so[nz]) / so[nz])),
+                  "iteration_counts_equal": bool(np.array_equal(iters_dev.cpu().numpy(), ito)),
+                  "against": "oracle/cpu_ref.c on the first timed batch"}
+
+        def time_cpu(fn, budget):
+            n, t_start = 0, time.perf_counter()
+            while True:
+                cc = csrs[n % len(csrs)]
+                g_init = np.asfortranarray(gamma0s[n % len(csrs)].cpu().numpy().T)
+                fn(cc, g_init)
+                n += 1
+                dt = time.perf_counter() - t_start
+                if dt >= budget or n >= 400:
+                    return n, dt
+
+        ncores = os.cpu_count() or 1
+        if pyoracle.Reference.available():
+            ref = pyoracle.Reference()
+            rm = ref.online(V, K, 1000000, alpha=.1, eta=.3)
+            rm.lambdas = lam
+            n1, t1 = time_cpu(lambda cc, g: rm.estep(cc.indptr, cc.ids, cc.cnts, g, args.max_iter,
+                                                     args.threshold), args.cpu_seconds)
+            kind = "reference"
+        else:
+            n1, t1 = time_cpu(lambda cc, g: orc.estep(lam, .1, cc.indptr, cc.ids, cc.cnts, g,
+                                                      args.max_iter, args.threshold),
+                              args.cpu_seconds)
+            kind = "port"
+        nm, tm = time_cpu(lambda cc, g: orc.estep(lam, .1, cc.indptr, cc.ids, cc.cnts, g,
+                                                  args.max_iter, args.threshold,
+                                                  nthreads=ncores), args.cpu_seconds / 2)
+        cpu_baseline = {
+            "value": round(n1 * B / t1, 1), "unit": "docs/s", "cores": 1, "kind": kind,
+            "sample": "%d E-step calls over the bench's own %d-document mini-batches "
+                      "(%.1f s), single thread" % (n1, B, t1),
+            "all_cores": {"value": round(nm * B / tm, 1), "cores": ncores, "kind": "port",
+                          "note": "oracle/cpu_ref.c doc-parallel variant (thread-private "
+                                  "accumulators); the reference's own OpenMP path is slower "
+                                  "than its single thread (BASELINE.md)"},
+            "gpu_over_cpu_1thread": round(docs_per_s / (n1 * B / t1), 1),
+        }
+        try:
+            cpu_baseline["cpu_model"] = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo")
+                                         if l.startswith("model name")][0]
+        except Exception:
+            pass
+
+    out = {
+        "metric": "E-step docs/sec (mini-batch) at K=100, V=7000",
+        "value": round(docs_per_s, 1), "unit": "docs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 5),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "OnlineLDA E-step (LDA::updateVariablesVI) K=%d V=%d batch=%d "
+                               "docs/GPU, max_iter_inference=%d, threshold=%g, %s vocabulary, "
+                               "~%d unique words/doc" % (K, V, B, args.max_iter, args.threshold,
+                                                         "uniform" if args.uniform else
+                                                         "Zipf-1.07", args.mean_unique),
+                   "num_topics": K, "num_words": V, "batch_per_gpu": B, "global_batch": B * world,
+                   "max_iter_inference": args.max_iter, "threshold": args.threshold,
+                   "mean_iterations_executed": round(mean_iters, 2),
+                   "sstats": args.sstats_mode, "parallelism": "dp%d" % world,
+                   "exchange": "RCCL all-reduce of K x V fp64 sstats" if world > 1 else "none"},
+        "roofline": roofline,
+        "cpu_baseline": cpu_baseline,
+        "parity": parity,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

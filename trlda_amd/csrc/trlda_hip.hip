@@ -94,12 +94,12 @@ struct trlda_model {
     // update_parameters workspaces
     double *lambda_prime = nullptr, *sstats = nullptr, *gamma = nullptr, *wordcounts = nullptr;
     size_t cap_gamma = 0;
-    // timing
+    // timing: five events per E-step from a pool, resolved lazily (no host sync per step)
     bool timing = false;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> ev_pool;   // all events ever created
+    size_t ev_used = 0;                // events recorded since the last collect
     double usec_sum[4] = {0, 0, 0, 0};
     int64_t usec_cnt[4] = {0, 0, 0, 0};
-    bool ev_pending = false;
 };
 
 namespace {
@@ -157,18 +157,35 @@ int ensure_update_workspace(trlda_model *m, int B)
 
 void collect_timing(trlda_model *m)
 {
-    if (!m->ev_pending)
+    if (m->ev_used == 0)
         return;
-    if (hipEventSynchronize(m->ev[4]) == hipSuccess) {
-        for (int i = 0; i < 4; ++i) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, m->ev[i], m->ev[i + 1]) == hipSuccess) {
-                m->usec_sum[i] += 1e3 * (double)ms;
-                m->usec_cnt[i] += 1;
+    if (hipEventSynchronize(m->ev_pool[m->ev_used - 1]) == hipSuccess) {
+        for (size_t base = 0; base + 5 <= m->ev_used; base += 5)
+            for (int i = 0; i < 4; ++i) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, m->ev_pool[base + i], m->ev_pool[base + i + 1]) ==
+                    hipSuccess) {
+                    m->usec_sum[i] += 1e3 * (double)ms;
+                    m->usec_cnt[i] += 1;
+                }
             }
-        }
     }
-    m->ev_pending = false;
+    m->ev_used = 0;
+}
+
+// next event of the current E-step's group of five (grows the pool on demand)
+int stamp(trlda_model *m)
+{
+    if (m->ev_used == m->ev_pool.size()) {
+        if (m->ev_pool.size() >= 5 * 8192)
+            return fail(TRLDA_ERR_ARG, "timing: collect (trlda_model_get_timing) at least every "
+                                       "8192 E-steps");
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        m->ev_pool.push_back(e);
+    }
+    HIP_TRY(hipEventRecord(m->ev_pool[m->ev_used++], m->stream));
+    return TRLDA_OK;
 }
 
 template <int T>
@@ -203,12 +220,9 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
     int rc = ensure_batch_workspace(m, b);
     if (rc)
         return rc;
-    if (m->timing)
-        collect_timing(m);
-
     const bool atomic = m->sstats_mode == TRLDA_SSTATS_ATOMIC;
-    if (m->timing)
-        HIP_TRY(hipEventRecord(m->ev[0], m->stream));
+    if (m->timing && (rc = stamp(m)))
+        return rc;
 
     // 1. psiSum (lda.cpp:172)
     {
@@ -219,8 +233,8 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
                            m->stream, K, V, wpb, m->lambda, m->partial, m->psi_sum, m->counter);
         HIP_TRY(hipGetLastError());
     }
-    if (m->timing)
-        HIP_TRY(hipEventRecord(m->ev[1], m->stream));
+    if (m->timing && (rc = stamp(m)))
+        return rc;
 
     // 2. exp E[log beta] (lda.cpp:173)
     {
@@ -230,8 +244,8 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
                            m->stream, K, KV, m->lambda, m->psi_sum, m->eeb);
         HIP_TRY(hipGetLastError());
     }
-    if (m->timing)
-        HIP_TRY(hipEventRecord(m->ev[2], m->stream));
+    if (m->timing && (rc = stamp(m)))
+        return rc;
 
     // 3. per-document fixed point (lda.cpp:174-204)
     if (atomic)
@@ -269,8 +283,8 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
         if (rc)
             return rc;
     }
-    if (m->timing)
-        HIP_TRY(hipEventRecord(m->ev[3], m->stream));
+    if (m->timing && (rc = stamp(m)))
+        return rc;
 
     // 4. sufficient statistics (lda.cpp:207-217)
     if (atomic) {
@@ -286,10 +300,8 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
                            sstats_dev);
     }
     HIP_TRY(hipGetLastError());
-    if (m->timing) {
-        HIP_TRY(hipEventRecord(m->ev[4], m->stream));
-        m->ev_pending = true;
-    }
+    if (m->timing && (rc = stamp(m)))
+        return rc;
     return TRLDA_OK;
 }
 
@@ -558,8 +570,6 @@ int trlda_model_create(trlda_model **out, int device, int K, int V)
         return rc;
     }
     HIP_TRY(hipMemset(m->counter, 0, sizeof(unsigned int)));
-    for (auto &e : m->ev)
-        HIP_TRY(hipEventCreate(&e));
     *out = m;
     return TRLDA_OK;
 }
@@ -574,9 +584,8 @@ int trlda_model_destroy(trlda_model *m)
         (void)hipFree(m->partial); (void)hipFree(m->counter); (void)hipFree(m->epg); (void)hipFree(m->tw_csr);
         (void)hipFree(m->tw_word); (void)hipFree(m->lambda_prime); (void)hipFree(m->sstats); (void)hipFree(m->gamma);
         (void)hipFree(m->wordcounts);
-        for (auto &e : m->ev)
-            if (e)
-                (void)hipEventDestroy(e);
+        for (auto &e : m->ev_pool)
+            (void)hipEventDestroy(e);
     }
     delete m;
     return TRLDA_OK;
