@@ -1,0 +1,32 @@
+"""Diagnostic: per-segment cycle shares of estep_docs_kernel (needs the -DTRLDA_STAMPS build).
+   build:  hipcc ... -DTRLDA_STAMPS -o gpurun_tmp/libtrlda_hip_stamps.so   (see tools/stamps.sh)"""
+import os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from trlda_amd import _ffi
+_ffi.LIB_PATH = os.path.join(os.path.dirname(_ffi.LIB_PATH), "libtrlda_hip_stamps.so")
+from trlda_amd.models import OnlineLDA
+from trlda_amd.documents import CSRDocuments
+from trlda_amd.utils.synthetic import make_corpus
+L = _ffi.lib()
+L.trlda_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
+K, V, B = 100, 7000, 200
+indptr, ids, cnts = make_corpus(B, V, seed=20150707, mean_unique=100)
+L.trlda_seed(1)
+m = OnlineLDA(V, K, 1000000)
+g0 = np.empty((K, B), order="F"); L.trlda_sample_gamma_init(K, B, g0)
+batch = m.upload(CSRDocuments(indptr, ids, cnts))
+names = ["init psi(gamma0)", "stage beta", "product E (first)", "product B", "gamma/psi update", "product E", "outputs", "-"]
+for T in (0, 256):
+    L.trlda_model_set_doc_threads(m._handle, T)
+    m.update_variables(batch, latents=g0, max_iter=20)
+    buf = np.zeros((B, 8), dtype=np.uint64)
+    L.trlda_debug_read_stamps(buf.ctypes.data, B)
+    m.update_variables(batch, latents=g0, max_iter=20)
+    L.trlda_debug_read_stamps(buf.ctypes.data, B)
+    mean = buf.astype(np.float64).mean(axis=0)
+    print("T=%d  total %.0f cycles/doc" % (T, mean.sum()))
+    for i, nme in enumerate(names[:7]):
+        per = mean[i] / 20 if i in (3, 4, 5) else mean[i]
+        print("   %-20s %9.0f cycles (%4.1f%%)%s" % (nme, mean[i], 100 * mean[i] / mean.sum(),
+              "  = %.0f / iteration" % per if i in (3, 4, 5) else ""))

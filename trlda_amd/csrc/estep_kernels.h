@@ -56,9 +56,21 @@ __global__ __launch_bounds__(T) void rowsum_psi_kernel(
         const int slot = tid / kc;
         const int k = kbase + tid % kc;
         double acc = 0.0;
-        if (slot < slots)
-            for (int w = w0 + slot; w < w1; w += slots)
+        if (slot < slots) {
+            int w = w0 + slot;
+            // eight independent loads in flight, added in word order
+            for (; w + 7 * slots < w1; w += 8 * slots) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = lambda[(size_t)(w + u * slots) * K + k];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    acc += v[u];
+            }
+            for (; w < w1; w += slots)
                 acc += lambda[(size_t)w * K + k];
+        }
         red[tid] = acc;
         __syncthreads();
         if (tid < kc) {
@@ -80,10 +92,21 @@ __global__ __launch_bounds__(T) void rowsum_psi_kernel(
     if (!is_last)
         return;
     __threadfence();
+    const int G = (int)gridDim.x;
     for (int k = tid; k < K; k += T) {
         double s = 0.0;
-        for (unsigned int b = 0; b < gridDim.x; ++b)
-            s += __builtin_nontemporal_load(&partial[(size_t)b * K + k]);
+        int b = 0;
+        for (; b + 16 <= G; b += 16) {             // sixteen loads in flight, block order
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                v[u] = partial[(size_t)(b + u) * K + k];
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                s += v[u];
+        }
+        for (; b < G; ++b)
+            s += partial[(size_t)b * K + k];
         psi_sum[k] = digamma(s);
     }
     if (tid == 0)
@@ -128,15 +151,32 @@ __global__ __launch_bounds__(T) void exp_elog_beta_kernel(
 // path: beta is re-read from eeb (L2 / Infinity Cache) each iteration with lanes
 // over k, and tw lives in the global tw_csr scratch.
 // ---------------------------------------------------------------------------
+// Diagnostic builds only (-DTRLDA_STAMPS, tools/stamps.sh): thread 0 of every workgroup adds
+// the s_memtime cycles of each segment into stamps[block][8].  Never compiled into the
+// shipped library; the values go to a buffer nothing else reads.
+#ifdef TRLDA_STAMPS
+#define TRLDA_STAMP(i)                                                        \
+    do {                                                                      \
+        if (threadIdx.x == 0) {                                               \
+            unsigned long long now__ = __builtin_amdgcn_s_memtime();         \
+            a.stamps[blockIdx.x * 8 + (i)] += now__ - stamp_last;            \
+            stamp_last = now__;                                               \
+        }                                                                     \
+    } while (0)
+#else
+#define TRLDA_STAMP(i) do { } while (0)
+#endif
+
 struct DocKernelArgs {
     int K, Kp, n_cap, B;
+    unsigned long long *stamps;   // diagnostic builds only, else nullptr
     const int32_t *indptr, *ids, *cnts;
     const int32_t *order;     // optional processing order (long documents first)
     const double *eeb;        // K x V
     const double *alpha;      // K
     double *gamma;            // K x B in/out
     double *epg;              // K x B out: exp(psi(gamma)) of the returned gamma
-    double *tw_csr;           // nnz: cnt/phinorm in CSR order (scratch + output)
+    double *tw_csr;           // nnz: cnt/phinorm in CSR order (streaming-path scratch)
     const int32_t *wrank;     // nnz: CSR position -> word-major rank (segmented mode)
     double *tw_word;          // nnz: cnt/phinorm in word-major order (segmented mode)
     double *sstats_acc;       // K x V atomic target (atomic mode) or nullptr
@@ -144,6 +184,234 @@ struct DocKernelArgs {
     double threshold;
     int32_t *iters_out;       // B or nullptr
 };
+
+// sum_{i<count} a[i] * b[i * stride] with NA independent accumulators.  A dependent fp64
+// fma chain on gfx950 advances one link per ~37 cycles while a wave can issue one every
+// ~9 (tools/probes): NA >= 4 chains keep the pipe busy.  Element i goes to chain i % NA and
+// the chains are combined pairwise -- a fixed order, so results are reproducible.
+template <int NA>
+__device__ __forceinline__ double lds_dot(const double *a, const double *b, int stride, int count)
+{
+    double acc[NA];
+#pragma unroll
+    for (int u = 0; u < NA; ++u)
+        acc[u] = 0.0;
+    int i = 0;
+    for (; i + NA <= count; i += NA) {
+        double x[NA], y[NA];
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            x[u] = a[i + u];
+            y[u] = b[(i + u) * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < NA; ++u)
+            acc[u] = fma(x[u], y[u], acc[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < NA - 1; ++u)
+        if (i + u < count)
+            acc[u] = fma(a[i + u], b[(i + u) * stride], acc[u]);
+#pragma unroll
+    for (int w = NA / 2; w > 0; w >>= 1)
+#pragma unroll
+        for (int u = 0; u < w; ++u)
+            acc[u] += acc[u + w];
+    return acc[0];
+}
+
+// The fixed point of one document whose beta slice is staged in LDS.
+// Work split (W = T/64 wavefronts):
+//   product B: wave -> (k block of 64 topics, contiguous j part); partials part[jp][k]
+//   product E: wave -> (j block of 64 words,  contiguous k part); partials part[kp][j]
+// A wave's lanes read 64 consecutive topics of one word (B) or one topic of 64
+// consecutive words at stride Kp (odd) (E): both conflict-free.  The other operand
+// (tw_j resp. e_k) is the same LDS address in every lane (broadcast).
+template <int T>
+__device__ __forceinline__ int doc_fixed_point_lds(
+    const DocKernelArgs &a, int n, const int32_t *__restrict__ ids,
+    const int32_t *__restrict__ cnts, double *__restrict__ beta, double *__restrict__ g,
+    double *__restrict__ e, double *__restrict__ tw, double *__restrict__ cntd,
+    double *__restrict__ part, double *__restrict__ wsum, unsigned long long &stamp_last)
+{
+    constexpr int W = T / kWave;
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wid = tid / kWave;
+    const int K = a.K, Kp = a.Kp;
+
+    // stage the slice: one wave per word, lanes over topics          lda.cpp:179-181
+    for (int j = wid; j < n; j += W) {
+        const double *src = a.eeb + (size_t)ids[j] * K;
+        double *dst = beta + j * Kp;
+        for (int k = lane; k < K; k += kWave)
+            dst[k] = src[k];
+    }
+    for (int j = tid; j < n; j += T)
+        cntd[j] = (double)cnts[j];
+
+    // wave roles
+    const int KB = (K + kWave - 1) / kWave;          // topic blocks
+    const int JP = KB <= W ? W / KB : 1;             // j parts (product B)
+    const int JC = (n + JP - 1) / JP;
+    const int JB = (n + kWave - 1) / kWave;          // word blocks
+    const int KPn = (JB > 0 && JB <= W) ? W / JB : 1;  // k parts (product E)
+    const int KC = (K + KPn - 1) / KPn;
+
+    auto product_E = [&]() {                         // lda.cpp:183 / :199
+        if (JB <= W) {
+            if (wid < JB * KPn) {
+                const int jb = wid % JB, kp = wid / JB;
+                const int j = jb * kWave + lane;
+                const int k0 = kp * KC, k1 = min(K, k0 + KC);
+                if (j < n)
+                    part[kp * n + j] = lds_dot<8>(e + k0, beta + j * Kp + k0, 1, k1 - k0);
+            }
+            __syncthreads();
+            for (int j = tid; j < n; j += T) {
+                double s = part[j];
+                for (int q = 1; q < KPn; ++q)
+                    s += part[q * n + j];
+                tw[j] = cntd[j] / (s + 1e-100);
+            }
+        } else {
+            // more word blocks than waves: every wave owns whole words, no partials
+            for (int jb = wid; jb < JB; jb += W) {
+                const int j = jb * kWave + lane;
+                if (j < n)
+                    tw[j] = cntd[j] / (lds_dot<8>(e, beta + j * Kp, 1, K) + 1e-100);
+            }
+        }
+        __syncthreads();
+    };
+
+    __syncthreads();
+    TRLDA_STAMP(1);
+    product_E();
+    TRLDA_STAMP(2);
+
+    int it = 0;
+    while (it < a.max_iter) {                        // lda.cpp:185-204
+        // product B: acc_k = sum_j tw_j beta[j][k]                   lda.cpp:189-193
+        if (KB <= W) {
+            if (wid < KB * JP) {
+                const int kb = wid % KB, jp = wid / KB;
+                const int k = kb * kWave + lane;
+                const int j0 = min(n, jp * JC), j1 = min(n, j0 + JC);
+                if (k < K)
+                    part[jp * K + k] = lds_dot<8>(tw + j0, beta + j0 * Kp + k, Kp, j1 - j0);
+            }
+        } else {
+            for (int kb = wid; kb < KB; kb += W) {
+                const int k = kb * kWave + lane;
+                if (k < K)
+                    part[k] = lds_dot<8>(tw, beta + k, Kp, n);
+            }
+        }
+        __syncthreads();
+        TRLDA_STAMP(3);
+
+        // gamma_k = alpha_k + e_k * acc_k ; e_k = exp(psi(gamma_k))   lda.cpp:194-197
+        double diff = 0.0;
+        for (int k = tid; k < K; k += T) {
+            double acc = part[k];
+            for (int q = 1; q < JP; ++q)
+                acc += part[q * K + k];
+            const double gnew = acc * e[k] + a.alpha[k];
+            diff += fabs(g[k] - gnew);
+            g[k] = gnew;
+            e[k] = exp_digamma(gnew);
+        }
+        diff = wave_sum(diff);
+        if (lane == 0)
+            wsum[wid] = diff;
+        __syncthreads();
+        TRLDA_STAMP(4);
+
+        double change = 0.0;                         // lda.cpp:202-203
+#pragma unroll
+        for (int q = 0; q < W; ++q)
+            change += wsum[q];
+
+        product_E();                                 // ends with a barrier
+        TRLDA_STAMP(5);
+        ++it;
+        if (change / (double)K < a.threshold)
+            break;
+    }
+    return it;
+}
+
+// Streaming variant for documents whose slice exceeds the LDS budget: beta is re-read
+// from eeb (L2 / Infinity Cache) in both products, lanes over topics so that every
+// access is a coalesced K-vector; tw lives in global scratch.
+template <int T>
+__device__ __forceinline__ int doc_fixed_point_stream(
+    const DocKernelArgs &a, int n, const int32_t *__restrict__ ids,
+    const int32_t *__restrict__ cnts, double *__restrict__ g, double *__restrict__ e,
+    double *__restrict__ tw, double *__restrict__ part, double *__restrict__ wsum)
+{
+    constexpr int W = T / kWave;
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wid = tid / kWave;
+    const int K = a.K;
+    const int kslots = min((K + kWave - 1) / kWave * kWave, T);
+    const int jparts = T / kslots;
+    const int ks = tid % kslots, jp = tid / kslots;
+
+    auto product_E = [&]() {
+        for (int j = wid; j < n; j += W) {
+            const double *col = a.eeb + (size_t)ids[j] * K;
+            double s = 0.0;
+            for (int k = lane; k < K; k += kWave)
+                s = fma(e[k], col[k], s);
+            s = wave_sum(s);
+            if (lane == 0)
+                tw[j] = (double)cnts[j] / (s + 1e-100);
+        }
+        __syncthreads();
+    };
+
+    __syncthreads();
+    product_E();
+
+    int it = 0;
+    while (it < a.max_iter) {
+        for (int k = ks; k < K; k += kslots) {
+            if (jp < jparts) {
+                double acc = 0.0;
+                for (int j = jp; j < n; j += jparts)
+                    acc = fma(tw[j], a.eeb[(size_t)ids[j] * K + k], acc);
+                part[jp * K + k] = acc;
+            }
+        }
+        __syncthreads();
+        double diff = 0.0;
+        for (int k = tid; k < K; k += T) {
+            double acc = part[k];
+            for (int q = 1; q < jparts; ++q)
+                acc += part[q * K + k];
+            const double gnew = acc * e[k] + a.alpha[k];
+            diff += fabs(g[k] - gnew);
+            g[k] = gnew;
+            e[k] = exp_digamma(gnew);
+        }
+        diff = wave_sum(diff);
+        if (lane == 0)
+            wsum[wid] = diff;
+        __syncthreads();
+        double change = 0.0;
+#pragma unroll
+        for (int q = 0; q < W; ++q)
+            change += wsum[q];
+        product_E();
+        ++it;
+        if (change / (double)K < a.threshold)
+            break;
+    }
+    return it;
+}
 
 template <int T>
 __global__ __launch_bounds__(T) void estep_docs_kernel(DocKernelArgs a)
@@ -155,7 +423,7 @@ __global__ __launch_bounds__(T) void estep_docs_kernel(DocKernelArgs a)
     constexpr int W = T / kWave;
 
     const int d = a.order ? a.order[blockIdx.x] : blockIdx.x;
-    const int K = a.K, Kp = a.Kp;
+    const int K = a.K;
     const int p0 = a.indptr[d];
     const int n = a.indptr[d + 1] - p0;
     const bool staged = n <= a.n_cap;
@@ -164,124 +432,31 @@ __global__ __launch_bounds__(T) void estep_docs_kernel(DocKernelArgs a)
 
     // LDS carve-up (beta first: its size depends on the launch's n_cap)
     double *beta = lds;
-    double *g = beta + (size_t)a.n_cap * Kp;
+    double *g = beta + a.n_cap * a.Kp;
     double *e = g + K;
     double *tw_l = e + K;
-    double *part = tw_l + a.n_cap;
+    double *cntd = tw_l + a.n_cap;
+    double *part = cntd + a.n_cap;
     double *wsum = part + (K > T ? K : T);
-    double *tw = staged ? tw_l : a.tw_csr + p0;
 
+    [[maybe_unused]] unsigned long long stamp_last = 0;
+#ifdef TRLDA_STAMPS
+    stamp_last = __builtin_amdgcn_s_memtime();
+#endif
     double *gamma_d = a.gamma + (size_t)d * K;
-
     for (int k = tid; k < K; k += T) {               // lda.cpp:174
-        double gk = gamma_d[k];
+        const double gk = gamma_d[k];
         g[k] = gk;
         e[k] = exp_digamma(gk);
     }
-    if (staged) {                                    // lda.cpp:179-181
-        for (int j = wid; j < n; j += W) {
-            const double *src = a.eeb + (size_t)ids[j] * K;
-            double *dst = beta + (size_t)j * Kp;
-            for (int k = lane; k < K; k += kWave)
-                dst[k] = src[k];
-        }
-    }
-    __syncthreads();
+    TRLDA_STAMP(0);
 
-    // geometry of the two products
-    const int kslots = min((K + kWave - 1) / kWave * kWave, T);
-    const int jparts = T / kslots;                   // >= 1
-    const int ks = tid % kslots, jp = tid / kslots;
-    const int jslots = min((n + kWave - 1) / kWave * kWave, T);
-    const int kparts = n > 0 ? T / jslots : 1;
-    const int js = n > 0 ? tid % jslots : 0, kp = n > 0 ? tid / jslots : 0;
-    const int kchunk = (K + kparts - 1) / kparts;
-
-    // phinorm / tw from the current e (lda.cpp:183 and :199)
-    auto phase_E = [&]() {
-        if (staged) {
-            for (int j0 = 0; j0 < n; j0 += jslots) {
-                const int j = j0 + js;
-                double s = 0.0;
-                if (j < n && kp < kparts) {
-                    const int klo = kp * kchunk, khi = min(K, klo + kchunk);
-                    const double *row = beta + (size_t)j * Kp;
-                    for (int k = klo; k < khi; ++k)
-                        s += e[k] * row[k];
-                }
-                if (kparts > 1) {
-                    part[tid] = s;
-                    __syncthreads();
-                    if (kp == 0 && j < n)
-                        for (int q = 1; q < kparts; ++q)
-                            s += part[q * jslots + js];
-                }
-                if (kp == 0 && j < n)
-                    tw[j] = (double)cnts[j] / (s + 1e-100);
-                if (kparts > 1 && j0 + jslots < n)
-                    __syncthreads();
-            }
-        } else {
-            for (int j = wid; j < n; j += W) {
-                const double *col = a.eeb + (size_t)ids[j] * K;
-                double s = 0.0;
-                for (int k = lane; k < K; k += kWave)
-                    s += e[k] * col[k];
-                s = wave_sum(s);
-                if (lane == 0)
-                    tw[j] = (double)cnts[j] / (s + 1e-100);
-            }
-        }
-    };
-
-    phase_E();
-    __syncthreads();
-
-    int it = 0;
-    while (it < a.max_iter) {                        // lda.cpp:185-204
-        // B: acc_k = sum_j tw_j * beta[j][k]
-        for (int k = ks; k < K; k += kslots) {
-            double acc = 0.0;
-            if (jp < jparts) {
-                if (staged) {
-                    for (int j = jp; j < n; j += jparts)
-                        acc += tw[j] * beta[(size_t)j * Kp + k];
-                } else {
-                    for (int j = jp; j < n; j += jparts)
-                        acc += tw[j] * a.eeb[(size_t)ids[j] * K + k];
-                }
-                part[jp * K + k] = acc;
-            }
-        }
-        __syncthreads();
-
-        // gamma_k = alpha_k + e_k * acc_k ; e_k = exp(psi(gamma_k))   lda.cpp:194-197
-        double diff = 0.0;
-        for (int k = tid; k < K; k += T) {
-            double acc = part[k];
-            for (int q = 1; q < jparts; ++q)
-                acc += part[q * K + k];
-            double gnew = acc * e[k] + a.alpha[k];
-            diff += fabs(g[k] - gnew);
-            g[k] = gnew;
-            e[k] = exp_digamma(gnew);
-        }
-        diff = wave_sum(diff);
-        if (lane == 0)
-            wsum[wid] = diff;
-        __syncthreads();
-
-        phase_E();
-        ++it;
-
-        double change = 0.0;                         // lda.cpp:202-203
-#pragma unroll
-        for (int q = 0; q < W; ++q)
-            change += wsum[q];
-        __syncthreads();
-        if (change / (double)K < a.threshold)
-            break;
-    }
+    int it;
+    if (staged)
+        it = doc_fixed_point_lds<T>(a, n, ids, cnts, beta, g, e, tw_l, cntd, part, wsum,
+                                    stamp_last);
+    else
+        it = doc_fixed_point_stream<T>(a, n, ids, cnts, g, e, a.tw_csr + p0, part, wsum);
 
     // results
     for (int k = tid; k < K; k += T) {
@@ -293,6 +468,269 @@ __global__ __launch_bounds__(T) void estep_docs_kernel(DocKernelArgs a)
 
     if (a.sstats_acc) {                              // lda.cpp:207-213, atomic form
         for (int j = wid; j < n; j += W) {
+            const double c = staged ? tw_l[j] : a.tw_csr[p0 + j];
+            double *col = a.sstats_acc + (size_t)ids[j] * K;
+            for (int k = lane; k < K; k += kWave)
+                unsafeAtomicAdd(&col[k], c * e[k]);
+        }
+    } else {
+        for (int j = tid; j < n; j += T)
+            a.tw_word[a.wrank[p0 + j]] = staged ? tw_l[j] : a.tw_csr[p0 + j];
+    }
+    TRLDA_STAMP(6);
+}
+
+// ---------------------------------------------------------------------------
+// 3b. The lean kernel for documents whose slice fits in LDS (the common case), built
+// around what tools/probes measured on gfx950: a wave issues one fp64 op per ~9 cycles and
+// a dependent fp64 chain advances one link per ~37, while a SIMD interleaves four waves at
+// no loss.  So: T = 1024 (four waves per SIMD), every per-thread loop is short with
+// independent accumulators, and psi -- whose serial form costs ~3000 cycles per iteration
+// for just 2 of the waves -- is cut into NP pieces evaluated by NP waves at once
+// (psi.h: psi_piece).
+//
+// Roles of wave w (KB = ceil(K/64) topic blocks, JP = W/KB):   kb = w % KB, jp = w / KB
+//   product B : topics kb*64+lane, words [jp*JC, (jp+1)*JC)        -> part[jp][k]
+//   psi piece : piece jp (< NP) of psi(gamma_k) for the same topics -> rpart[jp][k]
+//   combine   : waves with jp == 0: e_k = exp(sum of pieces)
+// and (JB = ceil(n/64) word blocks, KPn = W/JB):               jb = w % JB, kp = w / JB
+//   product E : words jb*64+lane, topics [kp*KC, (kp+1)*KC)         -> part[kp][j]
+// Host guarantees KB <= W and ceil(n_cap/64) <= W.
+// ---------------------------------------------------------------------------
+
+// sum of count values v[q * stride], q < count, through four chains + pairwise combine
+__device__ __forceinline__ double lds_strided_sum(const double *v, int stride, int count)
+{
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+    int q = 0;
+    for (; q + 4 <= count; q += 4) {
+        const double a0 = v[q * stride], a1 = v[(q + 1) * stride], a2 = v[(q + 2) * stride],
+                     a3 = v[(q + 3) * stride];
+        p0 += a0;
+        p1 += a1;
+        p2 += a2;
+        p3 += a3;
+    }
+    if (q < count)
+        p0 += v[q * stride];
+    if (q + 1 < count)
+        p1 += v[(q + 1) * stride];
+    if (q + 2 < count)
+        p2 += v[(q + 2) * stride];
+    return (p0 + p1) + (p2 + p3);
+}
+
+// 8 * chunks products wgt[i] * col[i * STRIDE]: `wgt` is read at the same address by every
+// lane (LDS broadcast), `col` is this lane's column with a compile-time stride, so all
+// sixteen reads of a chunk are base + immediate offset (no per-element address
+// arithmetic: a lone wave issues only one instruction per ~5 cycles, tools/probes).
+// Operands beyond the logical end are zero-filled by the caller.  Four chains.
+template <int STRIDE>
+__device__ __forceinline__ double lds_dot_chunks(const double *__restrict__ wgt,
+                                                 const double *__restrict__ col, int chunks)
+{
+    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+    for (int c = 0; c < chunks; ++c) {
+        double x[8], y[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            x[u] = wgt[u];
+            y[u] = col[u * STRIDE];
+        }
+        wgt += 8;
+        col += 8 * STRIDE;
+        acc0 = fma(x[0], y[0], acc0);
+        acc1 = fma(x[1], y[1], acc1);
+        acc2 = fma(x[2], y[2], acc2);
+        acc3 = fma(x[3], y[3], acc3);
+        acc0 = fma(x[4], y[4], acc0);
+        acc1 = fma(x[5], y[5], acc1);
+        acc2 = fma(x[6], y[6], acc2);
+        acc3 = fma(x[7], y[7], acc3);
+    }
+    return (acc0 + acc1) + (acc2 + acc3);
+}
+
+// LDS doubles needed by estep_docs_lds_kernel<T, KP, *> for a given n_cap (host + device)
+__host__ __device__ constexpr size_t lean_lds_doubles(int T, int KP, int K, int n_cap)
+{
+    return (size_t)(n_cap + 8) * KP   // beta rows (8 zero rows after the last word)
+           + (size_t)K                // g
+           + (size_t)K                // alpha
+           + (size_t)K + 8            // e, zero padded
+           + (size_t)n_cap + 8        // tw, zero padded
+           + (size_t)n_cap            // counts as doubles
+           + (size_t)K                // |gamma - last| per topic
+           + 2 * (size_t)T            // part, rpart
+           + 8;                       // change
+}
+
+template <int T, int KP, int NP>
+__global__ __launch_bounds__(T) void estep_docs_lds_kernel(DocKernelArgs a)
+{
+    extern __shared__ double lds[];
+    constexpr int W = T / kWave;
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(tid / kWave);
+
+    const int d = a.order[blockIdx.x];
+    const int K = a.K;
+    const int p0 = a.indptr[d];
+    const int n = a.indptr[d + 1] - p0;
+    const int32_t *__restrict__ ids = a.ids + p0;
+    const int32_t *__restrict__ cnts = a.cnts + p0;
+
+    double *beta = lds;                              // (n_cap + 8) x KP
+    double *g = beta + (a.n_cap + 8) * KP;
+    double *alpha_l = g + K;
+    double *e = alpha_l + K;                         // K + 8
+    double *tw = e + K + 8;                          // n_cap + 8
+    double *cntd = tw + a.n_cap + 8;
+    double *diffs = cntd + a.n_cap;
+    double *part = diffs + K;                        // T
+    double *rpart = part + T;                        // T
+    double *misc = rpart + T;                        // 8
+
+    [[maybe_unused]] unsigned long long stamp_last = 0;
+#ifdef TRLDA_STAMPS
+    stamp_last = __builtin_amdgcn_s_memtime();
+#endif
+
+    // roles (all wave-uniform)
+    const int KB = (K + kWave - 1) / kWave;
+    const int JP = W / KB;
+    const int kb = wid % KB, jp = wid / KB;
+    const bool in_b = jp < JP;
+    const int k_mine = kb * kWave + lane;
+    const bool k_on = in_b && k_mine < K;
+    const int JC = ((n + JP - 1) / JP + 7) & ~7;     // words per part, multiple of 8
+    const int j0 = jp * JC;
+    const int chunks_b = in_b ? min(JC, max(0, n - j0) + 7) / 8 : 0;
+    const double *col_b = beta + j0 * KP + min(k_mine, K - 1);
+    const double *wgt_b = tw + j0;
+    const int JB = max(1, (n + kWave - 1) / kWave);
+    const int KPn = W / JB;
+    const int jb = wid % JB, kp = wid / JB;
+    const int j_mine = jb * kWave + lane;
+    const bool in_e = kp < KPn;
+    const bool j_on = in_e && j_mine < n;
+    const int KC = ((K + KPn - 1) / KPn + 7) & ~7;   // topics per part, multiple of 8
+    const int k0 = kp * KC;
+    const int chunks_e = in_e ? min(KC, max(0, K - k0) + 7) / 8 : 0;
+    const double *col_e = beta + min(j_mine, max(n - 1, 0)) * KP + k0;
+    const double *wgt_e = e + k0;
+
+    double *gamma_d = a.gamma + (size_t)d * K;
+    for (int k = tid; k < K; k += T) {               // lda.cpp:174
+        const double gk = gamma_d[k];
+        g[k] = gk;
+        alpha_l[k] = a.alpha[k];
+        e[k] = exp_digamma(gk);
+    }
+    if (tid < 8) {
+        e[K + tid] = 0.0;
+        tw[n + tid] = 0.0;
+    }
+    TRLDA_STAMP(0);
+
+    // stage the slice, four words of a wave in flight                lda.cpp:179-181
+    for (int jbase = wid; jbase < n; jbase += 4 * W) {
+        int wordid[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = jbase + u * W;
+            wordid[u] = j < n ? ids[j] : 0;
+        }
+        for (int kk = lane; kk < KP; kk += kWave) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                v[u] = kk < K ? a.eeb[(size_t)wordid[u] * K + kk] : 0.0;   // pad columns = 0
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = jbase + u * W;
+                if (j < n)
+                    beta[j * KP + kk] = v[u];
+            }
+        }
+    }
+    for (int i = tid; i < 8 * KP; i += T)            // eight zero rows after the last word
+        beta[n * KP + i] = 0.0;
+    for (int j = tid; j < n; j += T)
+        cntd[j] = (double)cnts[j];
+    __syncthreads();
+    TRLDA_STAMP(1);
+
+    // phinorm_j = sum_k e_k beta[j][k] ; tw_j = cnt_j / phinorm_j     lda.cpp:183 / :199
+    auto product_E = [&](bool reduce_change) {
+        const double s = lds_dot_chunks<1>(wgt_e, col_e, chunks_e);
+        if (j_on)
+            part[kp * n + j_mine] = s;
+        __syncthreads();
+        for (int j = tid; j < n; j += T)
+            tw[j] = cntd[j] / (lds_strided_sum(part + j, n, KPn) + 1e-100);
+        if (reduce_change && wid == W - 1) {         // mean |gamma - last|   lda.cpp:202
+            double v = 0.0;
+            for (int k = lane; k < K; k += kWave)
+                v += diffs[k];
+            v = wave_sum(v);
+            if (lane == 0)
+                misc[0] = v;
+        }
+        __syncthreads();
+    };
+
+    product_E(false);
+    TRLDA_STAMP(2);
+
+    int it = 0;
+    while (it < a.max_iter) {                        // lda.cpp:185-204
+        // acc_k = sum_j tw_j beta[j][k]                               lda.cpp:189-193
+        {
+            const double s = lds_dot_chunks<KP>(wgt_b, col_b, chunks_b);
+            if (k_on)
+                part[jp * K + k_mine] = s;
+        }
+        __syncthreads();
+        TRLDA_STAMP(3);
+
+        // gamma_k = alpha_k + e_k * acc_k (lda.cpp:194-195), psi(gamma_k) in NP pieces
+        double gnew = 0.0;
+        if (k_on && jp < NP) {
+            const double acc = lds_strided_sum(part + k_mine, K, JP);
+            gnew = acc * e[k_mine] + alpha_l[k_mine];
+            rpart[jp * K + k_mine] = psi_piece<NP>(gnew, jp);
+        }
+        __syncthreads();
+        if (k_on && jp == 0) {                       // lda.cpp:197
+            double psi = rpart[k_mine];
+#pragma unroll
+            for (int p = 1; p < NP; ++p)
+                psi += rpart[p * K + k_mine];
+            diffs[k_mine] = fabs(g[k_mine] - gnew);
+            g[k_mine] = gnew;
+            e[k_mine] = exp(psi);
+        }
+        __syncthreads();
+        TRLDA_STAMP(4);
+
+        product_E(true);                             // ends with a barrier
+        TRLDA_STAMP(5);
+        ++it;
+        if (misc[0] / (double)K < a.threshold)       // lda.cpp:202-203
+            break;
+    }
+
+    // results
+    for (int k = tid; k < K; k += T) {
+        gamma_d[k] = g[k];
+        a.epg[(size_t)d * K + k] = e[k];
+    }
+    if (tid == 0 && a.iters_out)
+        a.iters_out[d] = it;
+    if (a.sstats_acc) {                              // lda.cpp:207-213, atomic form
+        for (int j = wid; j < n; j += W) {
             const double c = tw[j];
             double *col = a.sstats_acc + (size_t)ids[j] * K;
             for (int k = lane; k < K; k += kWave)
@@ -302,6 +740,211 @@ __global__ __launch_bounds__(T) void estep_docs_kernel(DocKernelArgs a)
         for (int j = tid; j < n; j += T)
             a.tw_word[a.wrank[p0 + j]] = tw[j];
     }
+    TRLDA_STAMP(6);
+}
+
+// ---------------------------------------------------------------------------
+// 3c. Register-resident kernel: K <= 128 topics, documents of at most 128 words.
+//
+// tools/probes on gfx950: the two products of 3b are bound by LDS bandwidth -- every
+// iteration re-reads the 8*K*n-byte slice twice, and each broadcast operand costs a full
+// 512-byte LDS access per wave.  Here the slice lives in VGPRs, in BOTH orientations
+// (2 x 64 doubles per thread, 512 threads), read from eeb once; per iteration LDS only
+// carries the two K- resp. n-vectors, the partial sums and the psi pieces.
+//
+//   lane l owns topics l and l+64 and words l and l+64
+//   wave w (0..7), product B: words [w*JC, (w+1)*JC) of the document, JC <= 16
+//                  product E: topics [w*KC, (w+1)*KC),               KC <= 16
+//                  psi      : topic half w & 1, piece w >> 1 of psi_piece<4>
+// ---------------------------------------------------------------------------
+constexpr int kRegThreads = 512;
+constexpr int kRegMaxK = 128;
+constexpr int kRegMaxN = 128;
+
+__host__ __device__ constexpr size_t reg_lds_doubles()
+{
+    // g | alpha | e (+16 zero pad) | tw (+16 zero pad) | cnt | diffs | part[8][128] | rpart[4][128] | misc
+    return 128 + 128 + 144 + 144 + 128 + 128 + 1024 + 512 + 8;
+}
+
+__global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelArgs a)
+{
+    __shared__ double lds[reg_lds_doubles()];
+    constexpr int T = kRegThreads, W = T / kWave;    // 8 waves
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(tid / kWave);
+
+    const int d = a.order[blockIdx.x];
+    const int K = a.K;
+    const int p0 = a.indptr[d];
+    const int n = a.indptr[d + 1] - p0;
+    const int32_t *__restrict__ ids = a.ids + p0;
+    const int32_t *__restrict__ cnts = a.cnts + p0;
+
+    double *g = lds;
+    double *alpha_l = g + 128;
+    double *e = alpha_l + 128;        // 144
+    double *tw = e + 144;             // 144
+    double *cntd = tw + 144;          // 128
+    double *diffs = cntd + 128;       // 128
+    double *part = diffs + 128;       // 8 x 128
+    double *rpart = part + 1024;      // 4 x 128
+    double *misc = rpart + 512;
+
+    [[maybe_unused]] unsigned long long stamp_last = 0;
+#ifdef TRLDA_STAMPS
+    stamp_last = __builtin_amdgcn_s_memtime();
+#endif
+
+    const int JC = (((n + W - 1) / W) + 1) & ~1;     // words per wave (even), <= 16
+    const int KC = (((K + W - 1) / W) + 1) & ~1;     // topics per wave (even), <= 16
+    const int j0 = wid * JC, k0 = wid * KC;
+    const bool k_lo = lane < K, k_hi = lane + 64 < K;
+    const bool j_lo = lane < n, j_hi = lane + 64 < n;
+
+    // ---- the slice, both orientations, straight from eeb into registers  lda.cpp:179-181
+    double bB0[16], bB1[16];          // beta[j0+i][lane], beta[j0+i][lane+64]
+    double bE0[16], bE1[16];          // beta[lane][k0+i], beta[lane+64][k0+i]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int j = j0 + i;
+        const bool row = i < JC && j < n;
+        const size_t base = row ? (size_t)ids[j] * K : 0;
+        bB0[i] = (row && k_lo) ? a.eeb[base + lane] : 0.0;
+        bB1[i] = (row && k_hi) ? a.eeb[base + lane + 64] : 0.0;
+    }
+    {
+        const size_t r0 = j_lo ? (size_t)ids[lane] * K : 0;
+        const size_t r1 = j_hi ? (size_t)ids[lane + 64] * K : 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int k = k0 + i;
+            const bool colv = i < KC && k < K;
+            bE0[i] = (colv && j_lo) ? a.eeb[r0 + k] : 0.0;
+            bE1[i] = (colv && j_hi) ? a.eeb[r1 + k] : 0.0;
+        }
+    }
+
+    double *gamma_d = a.gamma + (size_t)d * K;
+    for (int k = tid; k < 144; k += T) {             // lda.cpp:174
+        double ev = 0.0;
+        if (k < K) {
+            const double gk = gamma_d[k];
+            g[k] = gk;
+            alpha_l[k] = a.alpha[k];
+            ev = exp_digamma(gk);
+        }
+        e[k] = ev;                                   // zero beyond K
+    }
+    for (int j = tid; j < 144; j += T) {
+        tw[j] = 0.0;
+        if (j < 128)
+            cntd[j] = j < n ? (double)cnts[j] : 0.0;
+    }
+    __syncthreads();
+    TRLDA_STAMP(1);
+
+    // phinorm_j = sum_k e_k beta[j][k] ; tw_j = cnt_j / phinorm_j     lda.cpp:183 / :199
+    auto product_E = [&](bool reduce_change) {
+        double s0a = 0.0, s0b = 0.0, s1a = 0.0, s1b = 0.0;
+        const double *ep = e + k0;
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            if (i < KC) {                            // wave-uniform
+                const double ea = ep[i], eb = ep[i + 1];
+                s0a = fma(ea, bE0[i], s0a);
+                s1a = fma(ea, bE1[i], s1a);
+                s0b = fma(eb, bE0[i + 1], s0b);
+                s1b = fma(eb, bE1[i + 1], s1b);
+            }
+        }
+        part[wid * 128 + lane] = s0a + s0b;
+        part[wid * 128 + 64 + lane] = s1a + s1b;
+        __syncthreads();
+        if (tid < n)
+            tw[tid] = cntd[tid] / (lds_strided_sum(part + tid, 128, W) + 1e-100);
+        if (reduce_change && wid == W - 1) {         // mean |gamma - last|   lda.cpp:202
+            double v = (k_lo ? diffs[lane] : 0.0) + (k_hi ? diffs[lane + 64] : 0.0);
+            v = wave_sum(v);
+            if (lane == 0)
+                misc[0] = v;
+        }
+        __syncthreads();
+    };
+
+    product_E(false);
+    TRLDA_STAMP(2);
+
+    const int half = wid & 1, piece = wid >> 1;      // psi role
+    const int k_psi = half * 64 + lane;
+
+    int it = 0;
+    while (it < a.max_iter) {                        // lda.cpp:185-204
+        // acc_k = sum_j tw_j beta[j][k]                               lda.cpp:189-193
+        {
+            double a0a = 0.0, a0b = 0.0, a1a = 0.0, a1b = 0.0;
+            const double *tp = tw + j0;
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                if (i < JC) {                        // wave-uniform
+                    const double ta = tp[i], tb = tp[i + 1];
+                    a0a = fma(ta, bB0[i], a0a);
+                    a1a = fma(ta, bB1[i], a1a);
+                    a0b = fma(tb, bB0[i + 1], a0b);
+                    a1b = fma(tb, bB1[i + 1], a1b);
+                }
+            }
+            part[wid * 128 + lane] = a0a + a0b;
+            part[wid * 128 + 64 + lane] = a1a + a1b;
+        }
+        __syncthreads();
+        TRLDA_STAMP(3);
+
+        // gamma_k = alpha_k + e_k * acc_k (lda.cpp:194-195), psi(gamma_k) in 4 pieces
+        double gnew = 0.0;
+        if (k_psi < K) {
+            const double acc = lds_strided_sum(part + k_psi, 128, W);
+            gnew = acc * e[k_psi] + alpha_l[k_psi];
+            rpart[piece * 128 + k_psi] = psi_piece<4>(gnew, piece);
+        }
+        __syncthreads();
+        if (piece == 0 && k_psi < K) {               // lda.cpp:197
+            const double psi = ((rpart[k_psi] + rpart[128 + k_psi]) + rpart[256 + k_psi]) +
+                               rpart[384 + k_psi];
+            diffs[k_psi] = fabs(g[k_psi] - gnew);
+            g[k_psi] = gnew;
+            e[k_psi] = exp(psi);
+        }
+        __syncthreads();
+        TRLDA_STAMP(4);
+
+        product_E(true);                             // ends with a barrier
+        TRLDA_STAMP(5);
+        ++it;
+        if (misc[0] / (double)K < a.threshold)       // lda.cpp:202-203
+            break;
+    }
+
+    // results
+    for (int k = tid; k < K; k += T) {
+        gamma_d[k] = g[k];
+        a.epg[(size_t)d * K + k] = e[k];
+    }
+    if (tid == 0 && a.iters_out)
+        a.iters_out[d] = it;
+    if (a.sstats_acc) {                              // lda.cpp:207-213, atomic form
+        for (int j = wid; j < n; j += W) {
+            const double c = tw[j];
+            double *col = a.sstats_acc + (size_t)ids[j] * K;
+            for (int k = lane; k < K; k += kWave)
+                unsafeAtomicAdd(&col[k], c * e[k]);
+        }
+    } else {
+        if (tid < n)
+            a.tw_word[a.wrank[p0 + tid]] = tw[tid];
+    }
+    TRLDA_STAMP(6);
 }
 
 // ---------------------------------------------------------------------------
@@ -313,44 +956,102 @@ __global__ __launch_bounds__(T) void estep_docs_kernel(DocKernelArgs a)
 // Optionally fuses the M-step blend (onlinelda.cpp:99-100):
 //   lambda_out = (1-rho) lambda' + rho (eta + scale * sstats)
 // ---------------------------------------------------------------------------
+// sum_{q in [q0, q1)} tw_word[q] * epg[k, wdoc[q]] for this lane's topic k; q0, q1 are
+// wave-uniform (SGPRs), so wdoc / tw_word are scalar loads; eight gathers in flight.
+__device__ __forceinline__ double word_segment_sum(int q0, int q1, int K, int k, bool on,
+                                                   const int32_t *__restrict__ wdoc,
+                                                   const double *__restrict__ tw_word,
+                                                   const double *__restrict__ epg)
+{
+    double acc = 0.0;
+    int q = q0;
+    for (; q + 8 <= q1; q += 8) {
+        double t[8], ev[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            t[u] = tw_word[q + u];
+            ev[u] = on ? epg[(size_t)wdoc[q + u] * K + k] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            acc += t[u] * ev[u];
+    }
+    for (; q < q1; ++q) {
+        const double ev = on ? epg[(size_t)wdoc[q] * K + k] : 0.0;
+        acc += tw_word[q] * ev;
+    }
+    return acc;
+}
+
+constexpr int kLongWord = 24;   // entries above which a word's list is split over the block
+
 template <int T>
 __global__ __launch_bounds__(T) void sstats_words_kernel(
     int K, int V, const int32_t *__restrict__ wptr, const int32_t *__restrict__ wdoc,
     const double *__restrict__ tw_word, const double *__restrict__ epg,
     const double *__restrict__ eeb, double *__restrict__ sstats)
 {
+    constexpr int W = T / kWave;
+    extern __shared__ double wpart[];                // W x K partial sums (long words)
+    __shared__ int s_q0[W], s_len[W];
     const int lane = threadIdx.x & (kWave - 1);
-    // wave-uniform word index in an SGPR: wptr / wdoc / tw_word become scalar loads
-    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * (T / kWave) + threadIdx.x / kWave);
-    if (w >= V)
-        return;
-    const int q0 = wptr[w], q1 = wptr[w + 1];
-    for (int kb = 0; kb < K; kb += kWave) {
-        const int k = kb + lane;
-        const bool on = k < K;
-        double acc = 0.0;
-        int q = q0;
-        for (; q + 4 <= q1; q += 4) {               // four gathers in flight
-            const int d0 = wdoc[q], d1 = wdoc[q + 1], d2 = wdoc[q + 2], d3 = wdoc[q + 3];
-            const double t0 = tw_word[q], t1 = tw_word[q + 1], t2 = tw_word[q + 2],
-                         t3 = tw_word[q + 3];
-            const double e0 = on ? epg[(size_t)d0 * K + k] : 0.0;
-            const double e1 = on ? epg[(size_t)d1 * K + k] : 0.0;
-            const double e2 = on ? epg[(size_t)d2 * K + k] : 0.0;
-            const double e3 = on ? epg[(size_t)d3 * K + k] : 0.0;
-            acc += t0 * e0;
-            acc += t1 * e1;
-            acc += t2 * e2;
-            acc += t3 * e3;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int G = (int)gridDim.x;
+    // words are dealt round-robin over blocks (w = wave * G + block) so that the frequent
+    // (low-id, under Zipf) words land in different blocks
+    const int w = wid * G + (int)blockIdx.x;
+    int q0 = 0, len = 0;
+    if (w < V) {
+        q0 = wptr[w];
+        len = wptr[w + 1] - q0;
+    }
+    q0 = __builtin_amdgcn_readfirstlane(q0);
+    len = __builtin_amdgcn_readfirstlane(len);
+    if (lane == 0) {
+        s_q0[wid] = q0;
+        s_len[wid] = (w < V) ? len : 0;
+    }
+    if (w < V && len <= kLongWord) {
+        for (int kb = 0; kb < K; kb += kWave) {
+            const int k = kb + lane;
+            const bool on = k < K;
+            const double acc = word_segment_sum(q0, q0 + len, K, k, on, wdoc, tw_word, epg);
+            if (on) {
+                const size_t i = (size_t)w * K + k;
+                sstats[i] = acc * eeb[i];
+            }
         }
-        for (; q < q1; ++q) {
-            const double ev = on ? epg[(size_t)wdoc[q] * K + k] : 0.0;
-            acc += tw_word[q] * ev;
+    }
+    __syncthreads();
+    // long lists: the whole block splits the entries into W contiguous chunks; chunk sums
+    // are combined in chunk order (fixed by the list length -> bitwise reproducible)
+    for (int i = 0; i < W; ++i) {
+        const int L = s_len[i];
+        if (L <= kLongWord)
+            continue;                                // block-uniform
+        const int base = s_q0[i];
+        const int chunk = (L + W - 1) / W;
+        const int c0 = __builtin_amdgcn_readfirstlane(min(L, wid * chunk));
+        const int c1 = __builtin_amdgcn_readfirstlane(min(L, c0 + chunk));
+        for (int kb = 0; kb < K; kb += kWave) {
+            const int k = kb + lane;
+            const bool on = k < K;
+            const double acc = word_segment_sum(base + c0, base + c1, K, k, on, wdoc, tw_word, epg);
+            if (on)
+                wpart[wid * K + k] = acc;
         }
-        if (on) {
-            const size_t i = (size_t)w * K + k;
-            sstats[i] = acc * eeb[i];
+        __syncthreads();
+        if (wid == i) {
+            const int wi = i * G + (int)blockIdx.x;
+            for (int k = lane; k < K; k += kWave) {
+                double acc = wpart[k];
+                for (int c = 1; c < W; ++c)
+                    acc += wpart[c * K + k];
+                const size_t idx = (size_t)wi * K + k;
+                sstats[idx] = acc * eeb[idx];
+            }
         }
+        __syncthreads();
     }
 }
 

@@ -40,8 +40,14 @@ int fail(int code, const std::string &msg)
     } while (0)
 
 constexpr int kLdsBytes = 160 * 1024;   // LDS per workgroup on gfx950
+#ifndef TRLDA_LEAN_THREADS
+#define TRLDA_LEAN_THREADS 512          // threads per document in the lean kernel
+#endif
+#ifdef TRLDA_STAMPS
+unsigned long long *g_stamp_buf = nullptr;
+#endif
 constexpr int kDenseThreads = 256;
-constexpr int kMaxRowsumBlocks = 256;
+constexpr int kMaxRowsumBlocks = 128;
 
 template <typename T>
 int dev_alloc(T **p, size_t count)
@@ -77,6 +83,7 @@ struct trlda_batch {
     int32_t *wrank = nullptr;   // CSR position -> rank in word-major order
     int32_t *wptr = nullptr;    // V+1 word segment offsets
     int32_t *wdoc = nullptr;    // document of each word-major entry
+    std::vector<int32_t> sorted_len;   // host copy: document lengths in `order`
 };
 
 struct trlda_model {
@@ -201,8 +208,9 @@ int launch_docs(trlda_model *m, const trlda::DocKernelArgs &args, int B, size_t 
 
 size_t docs_lds_bytes(int K, int Kp, int n_cap, int T)
 {
-    size_t doubles = (size_t)n_cap * Kp + 2 * (size_t)K + (size_t)n_cap + (size_t)std::max(T, K) +
-                     (size_t)(T / trlda::kWave);
+    // beta[n_cap][Kp] | g[K] | e[K] | tw[n_cap] | cnt[n_cap] | part[max(T,K)] | wsum[T/64]
+    size_t doubles = (size_t)n_cap * Kp + 2 * (size_t)K + 2 * (size_t)n_cap +
+                     (size_t)std::max(T, K) + (size_t)(T / trlda::kWave);
     return doubles * sizeof(double);
 }
 
@@ -226,7 +234,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
 
     // 1. psiSum (lda.cpp:172)
     {
-        int G = std::min(kMaxRowsumBlocks, std::max(1, V));
+        int G = std::min(kMaxRowsumBlocks, std::max(1, V / 32));
         int wpb = (V + G - 1) / G;
         G = (V + wpb - 1) / wpb;
         hipLaunchKernelGGL(rowsum_psi_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads), 0,
@@ -251,37 +259,123 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
     if (atomic)
         HIP_TRY(hipMemsetAsync(sstats_dev, 0, KV * sizeof(double), m->stream));  // lda.cpp:169
     if (B > 0) {
-        int T = m->doc_threads;
-        if (T <= 0)
-            T = 256;
-        const int Kp = K | 1;
-        size_t fixed = docs_lds_bytes(K, Kp, 0, T);
-        int n_fit = fixed >= (size_t)kLdsBytes
-                        ? 0
-                        : (int)(((size_t)kLdsBytes - fixed) / ((size_t)(Kp + 1) * sizeof(double)));
-        int n_cap = std::min(b->max_n, n_fit);
-        size_t lds_bytes = docs_lds_bytes(K, Kp, n_cap, T);
-        if (lds_bytes > (size_t)kLdsBytes)
-            return fail(TRLDA_ERR_ARG, "num_topics too large for the document kernel's LDS layout");
-
         DocKernelArgs a;
-        a.K = K; a.Kp = Kp; a.n_cap = n_cap; a.B = B;
-        a.indptr = b->indptr; a.ids = b->ids; a.cnts = b->cnts; a.order = b->order;
+        a.K = K; a.B = B;
+        a.stamps = nullptr;
+#ifdef TRLDA_STAMPS
+        {
+            static unsigned long long *stamp_buf = nullptr;   // diagnostic build only
+            if (!stamp_buf) {
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&stamp_buf), 65536 * 8 * 8));
+                HIP_TRY(hipMemset(stamp_buf, 0, 65536 * 8 * 8));
+            }
+            a.stamps = stamp_buf;
+            g_stamp_buf = stamp_buf;
+        }
+#endif
+        a.indptr = b->indptr; a.ids = b->ids; a.cnts = b->cnts;
         a.eeb = m->eeb; a.alpha = m->alpha;
         a.gamma = gamma_dev; a.epg = m->epg; a.tw_csr = m->tw_csr;
         a.wrank = b->wrank; a.tw_word = m->tw_word;
         a.sstats_acc = atomic ? sstats_dev : nullptr;
         a.max_iter = max_iter; a.threshold = threshold; a.iters_out = iters_dev;
-        switch (T) {
-        case 64: rc = launch_docs<64>(m, a, B, lds_bytes); break;
-        case 128: rc = launch_docs<128>(m, a, B, lds_bytes); break;
-        case 256: rc = launch_docs<256>(m, a, B, lds_bytes); break;
-        case 512: rc = launch_docs<512>(m, a, B, lds_bytes); break;
-        case 1024: rc = launch_docs<1024>(m, a, B, lds_bytes); break;
-        default: return fail(TRLDA_ERR_ARG, "doc_threads must be 64, 128, 256, 512 or 1024");
+        const int Kp = K | 1;
+
+        // Documents are ordered by decreasing length and split into three runs:
+        //   [0, n_stream)            too long for LDS (or an explicit doc_threads override):
+        //                            general kernel, streams beta from L2 when it has to
+        //   [n_stream, B - n_reg)    slice fits in LDS: lean kernel (compile-time row stride)
+        //   [B - n_reg, B)           K <= 128 and at most 128 words: slice in registers
+        int n_reg = 0;
+        if (m->doc_threads == 0 && K <= kRegMaxK)
+            while (n_reg < B && b->sorted_len[(size_t)(B - 1 - n_reg)] <= kRegMaxN)
+                ++n_reg;
+
+        constexpr int TL = TRLDA_LEAN_THREADS, WL = TL / kWave;
+        const int KB = (K + kWave - 1) / kWave;
+        static const int kStrides[] = {9, 17, 33, 65, 101, 129, 201, 257};
+        int KPl = 0;
+        for (int cand : kStrides)
+            if (!KPl && cand >= K)
+                KPl = cand;
+        const bool lean = m->doc_threads == 0 && KPl != 0 && K <= 256 && KB <= WL;
+        int n_cap = 0;
+        if (lean) {
+            size_t fixed = lean_lds_doubles(TL, KPl, K, 0) * sizeof(double);
+            size_t n_fit = ((size_t)kLdsBytes - fixed) / ((size_t)(KPl + 2) * sizeof(double));
+            n_cap = (int)std::min<size_t>({n_fit, (size_t)b->max_n, (size_t)WL * kWave});
         }
-        if (rc)
-            return rc;
+        int n_stream = B - n_reg;
+        if (lean) {
+            n_stream = 0;
+            while (n_stream < B - n_reg && b->sorted_len[(size_t)n_stream] > n_cap)
+                ++n_stream;
+        }
+        const int n_lean = B - n_reg - n_stream;
+
+        if (n_stream > 0) {
+            int T = m->doc_threads > 0 ? m->doc_threads : 256;
+            size_t fixed = docs_lds_bytes(K, Kp, 0, T);
+            int n_fit = fixed >= (size_t)kLdsBytes
+                            ? 0
+                            : (int)(((size_t)kLdsBytes - fixed) /
+                                    ((size_t)(Kp + 2) * sizeof(double)));
+            int gen_cap = lean ? 0 : std::min(b->max_n, n_fit);
+            size_t lds_bytes = docs_lds_bytes(K, Kp, gen_cap, T);
+            if (lds_bytes > (size_t)kLdsBytes)
+                return fail(TRLDA_ERR_ARG,
+                            "num_topics too large for the document kernel's LDS layout");
+            a.n_cap = gen_cap;
+            a.Kp = Kp;
+            a.order = b->order;
+            switch (T) {
+            case 64: rc = launch_docs<64>(m, a, n_stream, lds_bytes); break;
+            case 128: rc = launch_docs<128>(m, a, n_stream, lds_bytes); break;
+            case 256: rc = launch_docs<256>(m, a, n_stream, lds_bytes); break;
+            case 512: rc = launch_docs<512>(m, a, n_stream, lds_bytes); break;
+            case 1024: rc = launch_docs<1024>(m, a, n_stream, lds_bytes); break;
+            default: return fail(TRLDA_ERR_ARG, "doc_threads must be 64, 128, 256, 512 or 1024");
+            }
+            if (rc)
+                return rc;
+        }
+        if (n_lean > 0) {
+            a.n_cap = n_cap;
+            a.Kp = KPl;
+            a.order = b->order + n_stream;
+            const size_t lds_bytes = lean_lds_doubles(TL, KPl, K, n_cap) * sizeof(double);
+#define TRLDA_LAUNCH_LEAN(KPV, NP)                                                         \
+    do {                                                                                   \
+        auto kern = estep_docs_lds_kernel<TL, KPV, NP>;                                    \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                  \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,            \
+                                    (int)lds_bytes));                                      \
+        hipLaunchKernelGGL(kern, dim3(n_lean), dim3(TL), lds_bytes, m->stream, a);         \
+    } while (0)
+            constexpr int NPA = WL >= 8 ? 8 : WL;             // pieces when K <= 64
+            constexpr int NPB = WL / 2 >= 8 ? 8 : WL / 2;     // K <= 128
+            constexpr int NPC = WL / 4 >= 8 ? 8 : (WL / 4 >= 1 ? WL / 4 : 1);   // K <= 256
+            switch (KPl) {
+            case 9: TRLDA_LAUNCH_LEAN(9, NPA); break;
+            case 17: TRLDA_LAUNCH_LEAN(17, NPA); break;
+            case 33: TRLDA_LAUNCH_LEAN(33, NPA); break;
+            case 65: TRLDA_LAUNCH_LEAN(65, NPA); break;
+            case 101: TRLDA_LAUNCH_LEAN(101, NPB); break;
+            case 129: TRLDA_LAUNCH_LEAN(129, NPB); break;
+            case 201: TRLDA_LAUNCH_LEAN(201, NPC); break;
+            default: TRLDA_LAUNCH_LEAN(257, NPC); break;
+            }
+#undef TRLDA_LAUNCH_LEAN
+            HIP_TRY(hipGetLastError());
+        }
+        if (n_reg > 0) {
+            a.n_cap = 0;
+            a.Kp = K;
+            a.order = b->order + (B - n_reg);
+            hipLaunchKernelGGL(estep_docs_reg_kernel, dim3(n_reg), dim3(kRegThreads), 0, m->stream,
+                               a);
+            HIP_TRY(hipGetLastError());
+        }
     }
     if (m->timing && (rc = stamp(m)))
         return rc;
@@ -293,11 +387,16 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
         hipLaunchKernelGGL(finish_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads), 0, m->stream,
                            KV, m->eeb, sstats_dev);
     } else {
-        constexpr int wpb = kDenseThreads / kWave;
+        constexpr int kSstatsThreads = 1024;
+        constexpr int wpb = kSstatsThreads / kWave;
         int G = (V + wpb - 1) / wpb;
-        hipLaunchKernelGGL(sstats_words_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads), 0,
-                           m->stream, K, V, b->wptr, b->wdoc, m->tw_word, m->epg, m->eeb,
-                           sstats_dev);
+        size_t lds = (size_t)wpb * K * sizeof(double);
+        auto kern = sstats_words_kernel<kSstatsThreads>;
+        if (lds > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(G), dim3(kSstatsThreads), lds, m->stream, K, V, b->wptr,
+                           b->wdoc, m->tw_word, m->epg, m->eeb, sstats_dev);
     }
     HIP_TRY(hipGetLastError());
     if (m->timing && (rc = stamp(m)))
@@ -505,6 +604,9 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
 
     trlda_batch *b = new trlda_batch();
     b->device = device; b->V = V; b->B = B; b->nnz = nnz; b->max_n = max_n;
+    b->sorted_len.resize((size_t)B);
+    for (int i = 0; i < B; ++i)
+        b->sorted_len[(size_t)i] = indptr[order[(size_t)i] + 1] - indptr[order[(size_t)i]];
     auto up = [&](int32_t **dst, const int32_t *src, size_t count) -> int {
         int r = dev_alloc(dst, count);
         if (r)
@@ -947,6 +1049,19 @@ int trlda_tr_init(int K, int V, int B, int num_documents, double rho, double eta
     trlda_model_destroy(m);
     return rc;
 }
+
+#ifdef TRLDA_STAMPS
+// diagnostic build only: copy out and clear the per-block segment cycle sums
+extern "C" int trlda_debug_read_stamps(unsigned long long *host, int blocks)
+{
+    if (!g_stamp_buf)
+        return -1;
+    if (hipMemcpy(host, g_stamp_buf, (size_t)blocks * 64, hipMemcpyDeviceToHost) != hipSuccess)
+        return -2;
+    (void)hipMemset(g_stamp_buf, 0, 65536 * 8 * 8);
+    return 0;
+}
+#endif
 
 // ---- measurement ----------------------------------------------------------------
 
