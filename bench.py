@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
-KERNEL_NAMES = ["rowsum_psi_kernel", "exp_elog_beta_kernel", "estep_docs_kernel",
+KERNEL_NAMES = ["rowsum_partial_kernel+rowsum_finish_kernel", "exp_elog_beta_kernel", "estep_docs_kernel",
                 "sstats_words_kernel"]
 
 

@@ -209,6 +209,15 @@ int trlda_model_batch_update(trlda_model *model, const trlda_batch *batch, doubl
                              int max_epochs, int max_iter_inference, int update_lambda,
                              double threshold, double *gamma_out);
 
+/* ---- test hook ----------------------------------------------------------- */
+
+/* The device digamma (TRLDA::digamma, src/digamma.cpp:116-178, as compiled for gfx950)
+ * evaluated at n host points: whole[i] = psi(x[i]); piecesN[i] = psi assembled from the N
+ * independent pieces the document kernels distribute over wavefronts.  Lets the parity
+ * tests check the special functions against the reference's table directly. */
+int trlda_debug_digamma(int device, int n, const double *x, double *whole, double *pieces2,
+                        double *pieces4, double *pieces8);
+
 /* ---- measurement --------------------------------------------------------- */
 
 /* Average duration in microseconds (HIP events on the model's stream) of the

@@ -50,6 +50,29 @@ def test_native_library_is_loaded(hip):
     assert "libtrlda_hip.so" in maps
 
 
+def test_device_digamma_table(hip):
+    """The device psi -- whole, and assembled from the 2 / 4 / 8 pieces the document kernels
+    spread over wavefronts -- against the reference's table (log grid 1e-6..1e6, small
+    integers, reflection branch) and its three known answers (utils_test.py:33-51)."""
+    f = golden("f0_rng_psi")
+    x = np.ascontiguousarray(f["psi_x"])
+    want = f["psi_y"]
+    outs = [np.zeros_like(x) for _ in range(4)]
+    rc = hip.trlda_debug_digamma(0, len(x), x.ctypes.data, *[o.ctypes.data for o in outs])
+    assert rc == 0, hip.trlda_last_error()
+    fin = np.isfinite(want)
+    for got in outs:
+        assert np.array_equal(np.isfinite(got), fin)
+        # psi crosses zero near x = 1.4616: use an absolute + relative bound
+        err = np.abs(got[fin] - want[fin]) / np.maximum(np.abs(want[fin]), 1.0)
+        assert err.max() < 5e-15, (err.max(), x[fin][err.argmax()])
+    kx = np.ascontiguousarray(f["kat_x"])
+    ko = [np.zeros_like(kx) for _ in range(4)]
+    assert hip.trlda_debug_digamma(0, len(kx), kx.ctypes.data, *[o.ctypes.data for o in ko]) == 0
+    for got in ko:
+        assert np.max(np.abs(got - f["kat_y"])) < 1e-12
+
+
 @pytest.mark.parametrize("name", ["f1a_estep", "f1b_estep"])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_estep_golden(hip, sampler, name, mode):
@@ -278,6 +301,36 @@ def test_full_size_document_permutation(hip, bench_case):
     g2, s2 = m.update_variables(CSRDocuments(ip, ids, cnts), latents=g0[:, perm], max_iter=20)
     assert np.array_equal(g2, g1[:, perm])
     assert relerr(s2[s1 > 0], s1[s1 > 0]) < 1e-12
+
+
+@pytest.mark.parametrize("K", [100, 128, 7])
+def test_document_length_boundaries(hip, oracle, sampler, K):
+    """Documents right at the limits of the document kernels' tiers: 128 words (all in
+    registers), 129..192 (register part + LDS tail), 193 (LDS kernel), and a mixed batch."""
+    from trlda_amd.documents import CSRDocuments
+    V = 3000
+    rng = np.random.RandomState(K)
+    lam = seeded_lambda(sampler, 31, K, V)
+    lens = [1, 2, 63, 64, 65, 127, 128, 129, 130, 137, 150, 191, 192, 193, 250]
+    docs, ip = [], [0]
+    for n in lens:
+        ids = rng.permutation(V)[:n]
+        cnts = 1 + rng.randint(3, size=n)
+        docs.append((ids, cnts))
+        ip.append(ip[-1] + n)
+    ids = np.concatenate([d[0] for d in docs]).astype(np.int32)
+    cnts = np.concatenate([d[1] for d in docs]).astype(np.int32)
+    ip = np.array(ip, np.int32)
+    g0 = seeded_gamma(sampler, 32, K, len(lens))
+    m = make_model(K, V, lam)
+    for (it, thr) in [(0, 0.), (1, 0.), (25, 1e-3)]:
+        g, s, iters = m.update_variables(CSRDocuments(ip, ids, cnts), latents=g0, max_iter=it,
+                                         threshold=thr, return_iterations=True)
+        go, so, ito = oracle.estep(lam, .1, ip, ids, cnts, g0, it, thr)
+        per_doc = np.max(np.abs(g - go) / np.abs(go), axis=0)
+        assert per_doc.max() < TIGHT_RTOL, list(zip(lens, per_doc))
+        check_sstats(s, so)
+        assert np.array_equal(iters, ito)
 
 
 def test_converged_documents_stop_early(hip, oracle, sampler):

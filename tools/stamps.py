@@ -16,8 +16,8 @@ L.trlda_seed(1)
 m = OnlineLDA(V, K, 1000000)
 g0 = np.empty((K, B), order="F"); L.trlda_sample_gamma_init(K, B, g0)
 batch = m.upload(CSRDocuments(indptr, ids, cnts))
-names = ["init psi(gamma0)", "stage beta", "product E (first)", "product B", "gamma/psi update", "product E", "outputs", "-"]
-for T in (0, 256):
+names = ["psi: partials->gnew", "stage beta", "product E (first)", "product B", "psi: combine+exp+barrier", "product E", "outputs", "psi: piece+barrier"]
+for T in (0,):
     L.trlda_model_set_doc_threads(m._handle, T)
     m.update_variables(batch, latents=g0, max_iter=20)
     buf = np.zeros((B, 8), dtype=np.uint64)
@@ -26,7 +26,7 @@ for T in (0, 256):
     L.trlda_debug_read_stamps(buf.ctypes.data, B)
     mean = buf.astype(np.float64).mean(axis=0)
     print("T=%d  total %.0f cycles/doc" % (T, mean.sum()))
-    for i, nme in enumerate(names[:7]):
-        per = mean[i] / 20 if i in (3, 4, 5) else mean[i]
+    for i, nme in enumerate(names[:8]):
+        per = mean[i] / 20 if i in (0, 3, 4, 5, 7) else mean[i]
         print("   %-20s %9.0f cycles (%4.1f%%)%s" % (nme, mean[i], 100 * mean[i] / mean.sum(),
-              "  = %.0f / iteration" % per if i in (3, 4, 5) else ""))
+              "  = %.0f / iteration" % per if i in (0, 3, 4, 5, 7) else ""))

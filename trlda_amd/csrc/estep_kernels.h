@@ -34,18 +34,15 @@ __device__ __forceinline__ double wave_sum(double v)
 // Grid of G blocks; block b owns words [b*wpb, (b+1)*wpb).  Thread t covers topic
 // k = t % K of word slot t / K, so a block pass reads floor(T/K)*K consecutive
 // doubles (fully coalesced) and each thread keeps one running sum.  Block partials
-// go to partial[b][k]; the last block to arrive (agent-scope counter) adds the
-// partials in block order -- a fixed order, so psiSum is bitwise reproducible --
-// and applies psi.  For K > T the topics are tiled in chunks of T.
+// go to partial[b][k]; rowsum_finish_kernel adds them in block order -- a fixed
+// order, so psiSum is bitwise reproducible -- and applies psi.  For K > T the topics
+// are tiled in chunks of T.
 // ---------------------------------------------------------------------------
 template <int T>
-__global__ __launch_bounds__(T) void rowsum_psi_kernel(
-    int K, int V, int wpb, const double *__restrict__ lambda,
-    double *__restrict__ partial /* G x K */, double *__restrict__ psi_sum /* K */,
-    unsigned int *__restrict__ counter)
+__global__ __launch_bounds__(T) void rowsum_partial_kernel(
+    int K, int V, int wpb, const double *__restrict__ lambda, double *__restrict__ partial /* G x K */)
 {
     __shared__ double red[T];
-    __shared__ bool is_last;
     const int tid = threadIdx.x;
     const int w0 = blockIdx.x * wpb;
     const int w1 = min(V, w0 + wpb);
@@ -81,36 +78,32 @@ __global__ __launch_bounds__(T) void rowsum_psi_kernel(
         }
         __syncthreads();
     }
+}
 
-    // publish partials, find out whether this block is the last one
-    __threadfence();
-    if (tid == 0) {
-        unsigned int prev = atomicAdd(counter, 1u);
-        is_last = (prev == gridDim.x - 1);
-    }
-    __syncthreads();
-    if (!is_last)
+// psiSum_k = psi(sum over the G block partials, in block order).  One small launch instead of
+// a last-block-done epilogue: two agent-scope fences cost more than a kernel boundary here.
+template <int T>
+__global__ __launch_bounds__(T) void rowsum_finish_kernel(int K, int G,
+                                                          const double *__restrict__ partial,
+                                                          double *__restrict__ psi_sum)
+{
+    const int k = blockIdx.x * T + threadIdx.x;
+    if (k >= K)
         return;
-    __threadfence();
-    const int G = (int)gridDim.x;
-    for (int k = tid; k < K; k += T) {
-        double s = 0.0;
-        int b = 0;
-        for (; b + 16 <= G; b += 16) {             // sixteen loads in flight, block order
-            double v[16];
+    double s = 0.0;
+    int b = 0;
+    for (; b + 16 <= G; b += 16) {                 // sixteen loads in flight, block order
+        double v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
-                v[u] = partial[(size_t)(b + u) * K + k];
+        for (int u = 0; u < 16; ++u)
+            v[u] = partial[(size_t)(b + u) * K + k];
 #pragma unroll
-            for (int u = 0; u < 16; ++u)
-                s += v[u];
-        }
-        for (; b < G; ++b)
-            s += partial[(size_t)b * K + k];
-        psi_sum[k] = digamma(s);
+        for (int u = 0; u < 16; ++u)
+            s += v[u];
     }
-    if (tid == 0)
-        *counter = 0;  // ready for the next launch on this stream
+    for (; b < G; ++b)
+        s += partial[(size_t)b * K + k];
+    psi_sum[k] = digamma(s);
 }
 
 // ---------------------------------------------------------------------------
@@ -155,16 +148,24 @@ __global__ __launch_bounds__(T) void exp_elog_beta_kernel(
 // the s_memtime cycles of each segment into stamps[block][8].  Never compiled into the
 // shipped library; the values go to a buffer nothing else reads.
 #ifdef TRLDA_STAMPS
+// segment sums stay in registers; one global write per segment at the very end
+#define TRLDA_STAMP_DECL unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define TRLDA_STAMP(i)                                                        \
     do {                                                                      \
-        if (threadIdx.x == 0) {                                               \
-            unsigned long long now__ = __builtin_amdgcn_s_memtime();         \
-            a.stamps[blockIdx.x * 8 + (i)] += now__ - stamp_last;            \
-            stamp_last = now__;                                               \
-        }                                                                     \
+        unsigned long long now__ = __builtin_amdgcn_s_memtime();             \
+        stamp_acc[i] += now__ - stamp_last;                                   \
+        stamp_last = now__;                                                   \
+    } while (0)
+#define TRLDA_STAMP_FLUSH                                                     \
+    do {                                                                      \
+        if (threadIdx.x == 0)                                                 \
+            for (int q__ = 0; q__ < 8; ++q__)                                 \
+                a.stamps[blockIdx.x * 8 + q__] += stamp_acc[q__];             \
     } while (0)
 #else
+#define TRLDA_STAMP_DECL do { } while (0)
 #define TRLDA_STAMP(i) do { } while (0)
+#define TRLDA_STAMP_FLUSH do { } while (0)
 #endif
 
 struct DocKernelArgs {
@@ -232,7 +233,7 @@ __device__ __forceinline__ int doc_fixed_point_lds(
     const DocKernelArgs &a, int n, const int32_t *__restrict__ ids,
     const int32_t *__restrict__ cnts, double *__restrict__ beta, double *__restrict__ g,
     double *__restrict__ e, double *__restrict__ tw, double *__restrict__ cntd,
-    double *__restrict__ part, double *__restrict__ wsum, unsigned long long &stamp_last)
+    double *__restrict__ part, double *__restrict__ wsum)
 {
     constexpr int W = T / kWave;
     const int tid = threadIdx.x;
@@ -286,9 +287,7 @@ __device__ __forceinline__ int doc_fixed_point_lds(
     };
 
     __syncthreads();
-    TRLDA_STAMP(1);
     product_E();
-    TRLDA_STAMP(2);
 
     int it = 0;
     while (it < a.max_iter) {                        // lda.cpp:185-204
@@ -309,7 +308,6 @@ __device__ __forceinline__ int doc_fixed_point_lds(
             }
         }
         __syncthreads();
-        TRLDA_STAMP(3);
 
         // gamma_k = alpha_k + e_k * acc_k ; e_k = exp(psi(gamma_k))   lda.cpp:194-197
         double diff = 0.0;
@@ -326,7 +324,6 @@ __device__ __forceinline__ int doc_fixed_point_lds(
         if (lane == 0)
             wsum[wid] = diff;
         __syncthreads();
-        TRLDA_STAMP(4);
 
         double change = 0.0;                         // lda.cpp:202-203
 #pragma unroll
@@ -334,7 +331,6 @@ __device__ __forceinline__ int doc_fixed_point_lds(
             change += wsum[q];
 
         product_E();                                 // ends with a barrier
-        TRLDA_STAMP(5);
         ++it;
         if (change / (double)K < a.threshold)
             break;
@@ -449,12 +445,10 @@ __global__ __launch_bounds__(T) void estep_docs_kernel(DocKernelArgs a)
         g[k] = gk;
         e[k] = exp_digamma(gk);
     }
-    TRLDA_STAMP(0);
 
     int it;
     if (staged)
-        it = doc_fixed_point_lds<T>(a, n, ids, cnts, beta, g, e, tw_l, cntd, part, wsum,
-                                    stamp_last);
+        it = doc_fixed_point_lds<T>(a, n, ids, cnts, beta, g, e, tw_l, cntd, part, wsum);
     else
         it = doc_fixed_point_stream<T>(a, n, ids, cnts, g, e, a.tw_csr + p0, part, wsum);
 
@@ -477,7 +471,6 @@ __global__ __launch_bounds__(T) void estep_docs_kernel(DocKernelArgs a)
         for (int j = tid; j < n; j += T)
             a.tw_word[a.wrank[p0 + j]] = staged ? tw_l[j] : a.tw_csr[p0 + j];
     }
-    TRLDA_STAMP(6);
 }
 
 // ---------------------------------------------------------------------------
@@ -632,7 +625,6 @@ __global__ __launch_bounds__(T) void estep_docs_lds_kernel(DocKernelArgs a)
         e[K + tid] = 0.0;
         tw[n + tid] = 0.0;
     }
-    TRLDA_STAMP(0);
 
     // stage the slice, four words of a wave in flight                lda.cpp:179-181
     for (int jbase = wid; jbase < n; jbase += 4 * W) {
@@ -660,7 +652,6 @@ __global__ __launch_bounds__(T) void estep_docs_lds_kernel(DocKernelArgs a)
     for (int j = tid; j < n; j += T)
         cntd[j] = (double)cnts[j];
     __syncthreads();
-    TRLDA_STAMP(1);
 
     // phinorm_j = sum_k e_k beta[j][k] ; tw_j = cnt_j / phinorm_j     lda.cpp:183 / :199
     auto product_E = [&](bool reduce_change) {
@@ -682,7 +673,6 @@ __global__ __launch_bounds__(T) void estep_docs_lds_kernel(DocKernelArgs a)
     };
 
     product_E(false);
-    TRLDA_STAMP(2);
 
     int it = 0;
     while (it < a.max_iter) {                        // lda.cpp:185-204
@@ -693,7 +683,6 @@ __global__ __launch_bounds__(T) void estep_docs_lds_kernel(DocKernelArgs a)
                 part[jp * K + k_mine] = s;
         }
         __syncthreads();
-        TRLDA_STAMP(3);
 
         // gamma_k = alpha_k + e_k * acc_k (lda.cpp:194-195), psi(gamma_k) in NP pieces
         double gnew = 0.0;
@@ -713,10 +702,8 @@ __global__ __launch_bounds__(T) void estep_docs_lds_kernel(DocKernelArgs a)
             e[k_mine] = exp(psi);
         }
         __syncthreads();
-        TRLDA_STAMP(4);
 
         product_E(true);                             // ends with a barrier
-        TRLDA_STAMP(5);
         ++it;
         if (misc[0] / (double)K < a.threshold)       // lda.cpp:202-203
             break;
@@ -740,7 +727,6 @@ __global__ __launch_bounds__(T) void estep_docs_lds_kernel(DocKernelArgs a)
         for (int j = tid; j < n; j += T)
             a.tw_word[a.wrank[p0 + j]] = tw[j];
     }
-    TRLDA_STAMP(6);
 }
 
 // ---------------------------------------------------------------------------
@@ -759,17 +745,56 @@ __global__ __launch_bounds__(T) void estep_docs_lds_kernel(DocKernelArgs a)
 // ---------------------------------------------------------------------------
 constexpr int kRegThreads = 512;
 constexpr int kRegMaxK = 128;
-constexpr int kRegMaxN = 128;
+constexpr int kRegMaxN = 192;      // 128 words in registers + a tail of up to 64 in LDS
+constexpr int kRegStride = 129;    // LDS row stride of the transposition / tail buffer (odd)
+constexpr int kRegPart = 192;      // row length of the partial-sum arrays
 
-__host__ __device__ constexpr size_t reg_lds_doubles()
+// g | alpha | e (+16 zero pad) | tw (+16 zero pad) | cnt | diffs | part[8][192] | rpart[4][128] |
+// misc[8] | buffer [128][129]: transposition scratch while the registers are filled, then
+// the rows of words 128.. of a long document
+constexpr int kRegSmallDoubles = 128 + 128 + 144 + 208 + 192 + 128 + 8 * kRegPart + 512 + 8;
+constexpr size_t kRegLdsBytes = (size_t)(kRegSmallDoubles + 128 * kRegStride) * sizeof(double);
+
+// Sum over the 64 lanes of a wave in 6 DPP steps (row shifts, then row broadcasts); the total
+// ends up in lane 63 and is returned to every lane through two v_readlane.  __shfl_down on a
+// double goes through ds_bpermute, i.e. an LDS round trip per step.
+__device__ __forceinline__ double dpp_shift_add(double v, int)
 {
-    // g | alpha | e (+16 zero pad) | tw (+16 zero pad) | cnt | diffs | part[8][128] | rpart[4][128] | misc
-    return 128 + 128 + 144 + 144 + 128 + 128 + 1024 + 512 + 8;
+    return v;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    // lanes outside ROW_MASK (or shifted in from outside the row) receive +0.0
+    return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v)
+{
+    v = dpp_add<0x111, 0xf>(v);      // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);      // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);      // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);      // row_shr:8  -> lane 15 of every row holds the row sum
+    v = dpp_add<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3 -> lane 63 = total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+// eight partial sums at a compile-time stride, all reads in flight, pairwise combine
+template <int STRIDE>
+__device__ __forceinline__ double sum8_strided(const double *p)
+{
+    const double v0 = p[0], v1 = p[STRIDE], v2 = p[2 * STRIDE], v3 = p[3 * STRIDE],
+                 v4 = p[4 * STRIDE], v5 = p[5 * STRIDE], v6 = p[6 * STRIDE], v7 = p[7 * STRIDE];
+    return ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
 }
 
 __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelArgs a)
 {
-    __shared__ double lds[reg_lds_doubles()];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int T = kRegThreads, W = T / kWave;    // 8 waves
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -785,44 +810,49 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
     double *g = lds;
     double *alpha_l = g + 128;
     double *e = alpha_l + 128;        // 144
-    double *tw = e + 144;             // 144
-    double *cntd = tw + 144;          // 128
-    double *diffs = cntd + 128;       // 128
-    double *part = diffs + 128;       // 8 x 128
-    double *rpart = part + 1024;      // 4 x 128
-    double *misc = rpart + 512;
+    double *tw = e + 144;             // 208
+    double *cntd = tw + 208;          // 192
+    double *diffs = cntd + 192;       // 128
+    double *part = diffs + 128;       // 8 x 192
+    double *rpart = part + 8 * kRegPart;   // 4 x 128
+    double *misc = rpart + 512;       // 8
+    double *tbuf = misc + 8;          // 128 x 129
 
     [[maybe_unused]] unsigned long long stamp_last = 0;
+    TRLDA_STAMP_DECL;
 #ifdef TRLDA_STAMPS
     stamp_last = __builtin_amdgcn_s_memtime();
 #endif
 
-    const int JC = (((n + W - 1) / W) + 1) & ~1;     // words per wave (even), <= 16
+    const int nm = min(n, 128);                      // words held in registers
+    const int nt = n - nm;                           // tail words (LDS), <= 64
+    const int JC = (((nm + W - 1) / W) + 1) & ~1;    // words per wave (even), <= 16
     const int KC = (((K + W - 1) / W) + 1) & ~1;     // topics per wave (even), <= 16
     const int j0 = wid * JC, k0 = wid * KC;
     const bool k_lo = lane < K, k_hi = lane + 64 < K;
-    const bool j_lo = lane < n, j_hi = lane + 64 < n;
+    const int TC = (nt + W - 1) / W;                 // tail words per wave, <= 8
 
-    // ---- the slice, both orientations, straight from eeb into registers  lda.cpp:179-181
+    // ---- the slice: orientation B straight from eeb (coalesced K-vectors)  lda.cpp:179-181
     double bB0[16], bB1[16];          // beta[j0+i][lane], beta[j0+i][lane+64]
-    double bE0[16], bE1[16];          // beta[lane][k0+i], beta[lane+64][k0+i]
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int j = j0 + i;
-        const bool row = i < JC && j < n;
-        const size_t base = row ? (size_t)ids[j] * K : 0;
-        bB0[i] = (row && k_lo) ? a.eeb[base + lane] : 0.0;
-        bB1[i] = (row && k_hi) ? a.eeb[base + lane + 64] : 0.0;
-    }
     {
-        const size_t r0 = j_lo ? (size_t)ids[lane] * K : 0;
-        const size_t r1 = j_hi ? (size_t)ids[lane + 64] * K : 0;
+        // every load is unconditional (clamped word / topic index) so that all 32 are in
+        // flight together; out-of-range elements are zeroed afterwards
+        int wordid[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            wordid[i] = nm > 0 ? ids[min(j0 + i, nm - 1)] : 0;
+        const int kl = min(lane, K - 1), kh = min(lane + 64, K - 1);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int k = k0 + i;
-            const bool colv = i < KC && k < K;
-            bE0[i] = (colv && j_lo) ? a.eeb[r0 + k] : 0.0;
-            bE1[i] = (colv && j_hi) ? a.eeb[r1 + k] : 0.0;
+            const double *rowp = a.eeb + (size_t)wordid[i] * K;
+            bB0[i] = rowp[kl];
+            bB1[i] = rowp[kh];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bool row = i < JC && j0 + i < nm;
+            bB0[i] = (row && k_lo) ? bB0[i] : 0.0;
+            bB1[i] = (row && k_hi) ? bB1[i] : 0.0;
         }
     }
 
@@ -837,38 +867,97 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
         }
         e[k] = ev;                                   // zero beyond K
     }
-    for (int j = tid; j < 144; j += T) {
+    for (int j = tid; j < 208; j += T) {
         tw[j] = 0.0;
-        if (j < 128)
+        if (j < 192)
             cntd[j] = j < n ? (double)cnts[j] : 0.0;
     }
+
+    // ---- orientation E through an LDS transposition (stride 129: conflict-free both ways)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        if (i < JC) {                                // wave-uniform; rows >= n hold zeros
+            tbuf[(j0 + i) * kRegStride + lane] = bB0[i];
+            tbuf[(j0 + i) * kRegStride + 64 + lane] = bB1[i];
+        }
+    }
     __syncthreads();
+    double bE0[16], bE1[16];          // beta[lane][k0+i], beta[lane+64][k0+i]
+    {
+        // rows at or beyond W*JC were never written: read row 0 instead and zero the value
+        const int rows = W * JC;
+        const bool r_lo = lane < rows, r_hi = lane + 64 < rows;
+        const double *t0 = tbuf + (r_lo ? lane : 0) * kRegStride + k0;
+        const double *t1 = tbuf + (r_hi ? lane + 64 : 0) * kRegStride + k0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bool colv = i < KC && k0 + i < K;  // wave-uniform
+            const double v0 = t0[colv ? i : 0], v1 = t1[colv ? i : 0];
+            bE0[i] = (colv && r_lo) ? v0 : 0.0;
+            bE1[i] = (colv && r_hi) ? v1 : 0.0;
+        }
+    }
+    __syncthreads();
+    // ---- words 128.. of a long document: rows of the same LDS buffer, read by both products
+    if (nt > 0) {                                    // block-uniform
+        for (int r = wid; r < 8 * TC; r += W) {      // rows beyond the document are zero
+            const bool row = r < nt;
+            const double *rowp = a.eeb + (size_t)(row ? ids[128 + r] : 0) * K;
+            const double v0 = rowp[min(lane, K - 1)], v1 = rowp[min(lane + 64, K - 1)];
+            tbuf[r * kRegStride + lane] = (row && k_lo) ? v0 : 0.0;
+            tbuf[r * kRegStride + 64 + lane] = (row && k_hi) ? v1 : 0.0;
+        }
+        if (tid < 64)
+            tbuf[tid * kRegStride + 128] = 0.0;      // pad column read by nobody but keep finite
+        __syncthreads();
+    }
     TRLDA_STAMP(1);
 
     // phinorm_j = sum_k e_k beta[j][k] ; tw_j = cnt_j / phinorm_j     lda.cpp:183 / :199
     auto product_E = [&](bool reduce_change) {
-        double s0a = 0.0, s0b = 0.0, s1a = 0.0, s1b = 0.0;
-        const double *ep = e + k0;
+        // k0 is even and e is 16-byte aligned: one ds_read_b128 broadcasts two weights.  All
+        // eight reads are issued before the first fma and nothing is branched over: weights
+        // past K are zero in LDS and the matching registers are zero.  Eight chains.
+        const double2 *ep = reinterpret_cast<const double2 *>(e + k0);
+        double2 ew[8];
 #pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-            if (i < KC) {                            // wave-uniform
-                const double ea = ep[i], eb = ep[i + 1];
-                s0a = fma(ea, bE0[i], s0a);
-                s1a = fma(ea, bE1[i], s1a);
-                s0b = fma(eb, bE0[i + 1], s0b);
-                s1b = fma(eb, bE1[i + 1], s1b);
-            }
+        for (int i = 0; i < 8; ++i)
+            ew[i] = ep[i];
+        double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            s0[(2 * i) & 3] = fma(ew[i].x, bE0[2 * i], s0[(2 * i) & 3]);
+            s1[(2 * i) & 3] = fma(ew[i].x, bE1[2 * i], s1[(2 * i) & 3]);
+            s0[(2 * i + 1) & 3] = fma(ew[i].y, bE0[2 * i + 1], s0[(2 * i + 1) & 3]);
+            s1[(2 * i + 1) & 3] = fma(ew[i].y, bE1[2 * i + 1], s1[(2 * i + 1) & 3]);
         }
-        part[wid * 128 + lane] = s0a + s0b;
-        part[wid * 128 + 64 + lane] = s1a + s1b;
+        part[wid * kRegPart + lane] = (s0[0] + s0[1]) + (s0[2] + s0[3]);
+        part[wid * kRegPart + 64 + lane] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
+        if (nt > 0) {                                // tail word 128 + lane from LDS
+            const double *rowp = tbuf + min(lane, 8 * TC - 1) * kRegStride + min(k0, K - 1);
+            double tv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const bool colv = i < KC && k0 + i < K;      // wave-uniform, as for bE0 / bE1
+                const double v = rowp[colv ? i : 0];
+                tv[i] = colv ? v : 0.0;
+            }
+            double s2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                s2[(2 * i) & 3] = fma(ew[i].x, tv[2 * i], s2[(2 * i) & 3]);
+                s2[(2 * i + 1) & 3] = fma(ew[i].y, tv[2 * i + 1], s2[(2 * i + 1) & 3]);
+            }
+            part[wid * kRegPart + 128 + lane] = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+        }
         __syncthreads();
-        if (tid < n)
-            tw[tid] = cntd[tid] / (lds_strided_sum(part + tid, 128, W) + 1e-100);
+        if (tid < 128 || tid < n)                    // 0 beyond n (cnt is 0 there)
+            tw[tid] = cntd[tid] * rcp_pos<true>(sum8_strided<kRegPart>(part + tid) + 1e-100);
         if (reduce_change && wid == W - 1) {         // mean |gamma - last|   lda.cpp:202
-            double v = (k_lo ? diffs[lane] : 0.0) + (k_hi ? diffs[lane + 64] : 0.0);
-            v = wave_sum(v);
+            const double v = (k_lo ? diffs[lane] : 0.0) + (k_hi ? diffs[lane + 64] : 0.0);
+            const double mean = wave_sum_dpp(v) / (double)K;
             if (lane == 0)
-                misc[0] = v;
+                misc[0] = mean;
         }
         __syncthreads();
     };
@@ -878,41 +967,66 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
 
     const int half = wid & 1, piece = wid >> 1;      // psi role
     const int k_psi = half * 64 + lane;
+    const bool psi_on = k_psi < K;
 
     int it = 0;
     while (it < a.max_iter) {                        // lda.cpp:185-204
         // acc_k = sum_j tw_j beta[j][k]                               lda.cpp:189-193
         {
-            double a0a = 0.0, a0b = 0.0, a1a = 0.0, a1b = 0.0;
-            const double *tp = tw + j0;
+            const double2 *tp = reinterpret_cast<const double2 *>(tw + j0);
+            double2 tv[8];
 #pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-                if (i < JC) {                        // wave-uniform
-                    const double ta = tp[i], tb = tp[i + 1];
-                    a0a = fma(ta, bB0[i], a0a);
-                    a1a = fma(ta, bB1[i], a1a);
-                    a0b = fma(tb, bB0[i + 1], a0b);
-                    a1b = fma(tb, bB1[i + 1], a1b);
+            for (int i = 0; i < 8; ++i)
+                tv[i] = tp[i];
+            double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                a0[(2 * i) & 3] = fma(tv[i].x, bB0[2 * i], a0[(2 * i) & 3]);
+                a1[(2 * i) & 3] = fma(tv[i].x, bB1[2 * i], a1[(2 * i) & 3]);
+                a0[(2 * i + 1) & 3] = fma(tv[i].y, bB0[2 * i + 1], a0[(2 * i + 1) & 3]);
+                a1[(2 * i + 1) & 3] = fma(tv[i].y, bB1[2 * i + 1], a1[(2 * i + 1) & 3]);
+            }
+            if (nt > 0) {                            // tail rows of this wave, from LDS
+                const double *rowp = tbuf + (wid * TC) * kRegStride + lane;
+                double lo[8], hi[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int r = (i < TC) ? i : 0;  // wave-uniform clamp, weight zeroed below
+                    lo[i] = rowp[r * kRegStride];
+                    hi[i] = rowp[r * kRegStride + 64];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const double wgt = (i < TC) ? tw[128 + wid * TC + i] : 0.0;
+                    a0[i & 3] = fma(wgt, lo[i], a0[i & 3]);
+                    a1[i & 3] = fma(wgt, hi[i], a1[i & 3]);
                 }
             }
-            part[wid * 128 + lane] = a0a + a0b;
-            part[wid * 128 + 64 + lane] = a1a + a1b;
+            part[wid * kRegPart + lane] = (a0[0] + a0[1]) + (a0[2] + a0[3]);
+            part[wid * kRegPart + 64 + lane] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
         }
         __syncthreads();
         TRLDA_STAMP(3);
 
         // gamma_k = alpha_k + e_k * acc_k (lda.cpp:194-195), psi(gamma_k) in 4 pieces
         double gnew = 0.0;
-        if (k_psi < K) {
-            const double acc = lds_strided_sum(part + k_psi, 128, W);
-            gnew = acc * e[k_psi] + alpha_l[k_psi];
-            rpart[piece * 128 + k_psi] = psi_piece<4>(gnew, piece);
+        {
+            const int kk = psi_on ? k_psi : 0;
+            const double ek = e[kk], ak = alpha_l[kk];
+            const double acc = sum8_strided<kRegPart>(part + kk);
+            gnew = acc * ek + ak;
+            TRLDA_STAMP(0);
+            const double pc = psi_piece<4>(psi_on ? gnew : 1.5, piece);
+            if (psi_on)
+                rpart[piece * 128 + k_psi] = pc;
         }
         __syncthreads();
-        if (piece == 0 && k_psi < K) {               // lda.cpp:197
-            const double psi = ((rpart[k_psi] + rpart[128 + k_psi]) + rpart[256 + k_psi]) +
-                               rpart[384 + k_psi];
-            diffs[k_psi] = fabs(g[k_psi] - gnew);
+        TRLDA_STAMP(7);
+        if (piece == 0 && psi_on) {                  // lda.cpp:197
+            const double r0 = rpart[k_psi], r1 = rpart[128 + k_psi], r2 = rpart[256 + k_psi],
+                         r3 = rpart[384 + k_psi], gold = g[k_psi];
+            const double psi = ((r0 + r1) + r2) + r3;
+            diffs[k_psi] = fabs(gold - gnew);
             g[k_psi] = gnew;
             e[k_psi] = exp(psi);
         }
@@ -922,7 +1036,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
         product_E(true);                             // ends with a barrier
         TRLDA_STAMP(5);
         ++it;
-        if (misc[0] / (double)K < a.threshold)       // lda.cpp:202-203
+        if (misc[0] < a.threshold)                   // lda.cpp:202-203
             break;
     }
 
@@ -945,6 +1059,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
             a.tw_word[a.wrank[p0 + tid]] = tw[tid];
     }
     TRLDA_STAMP(6);
+    TRLDA_STAMP_FLUSH;
 }
 
 // ---------------------------------------------------------------------------
@@ -957,28 +1072,31 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
 //   lambda_out = (1-rho) lambda' + rho (eta + scale * sstats)
 // ---------------------------------------------------------------------------
 // sum_{q in [q0, q1)} tw_word[q] * epg[k, wdoc[q]] for this lane's topic k; q0, q1 are
-// wave-uniform (SGPRs), so wdoc / tw_word are scalar loads; eight gathers in flight.
+// wave-uniform (SGPRs), so wdoc / tw_word are scalar loads.  Lists of up to 24 entries --
+// all of them after the long-word split -- have every gather in flight at once (one memory
+// latency instead of one per batch); the products are still added in list order.
 __device__ __forceinline__ double word_segment_sum(int q0, int q1, int K, int k, bool on,
                                                    const int32_t *__restrict__ wdoc,
                                                    const double *__restrict__ tw_word,
                                                    const double *__restrict__ epg)
 {
     double acc = 0.0;
-    int q = q0;
-    for (; q + 8 <= q1; q += 8) {
-        double t[8], ev[8];
+    for (int q = q0; q < q1; q += 24) {
+        double t[24], ev[24];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            t[u] = tw_word[q + u];
-            ev[u] = on ? epg[(size_t)wdoc[q + u] * K + k] : 0.0;
+        for (int u = 0; u < 24; ++u) {
+            const bool in = q + u < q1;              // wave-uniform
+            t[u] = in ? tw_word[q + u] : 0.0;
+            ev[u] = (in && on) ? epg[(size_t)wdoc[in ? q + u : q] * K + k] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            acc += t[u] * ev[u];
-    }
-    for (; q < q1; ++q) {
-        const double ev = on ? epg[(size_t)wdoc[q] * K + k] : 0.0;
-        acc += tw_word[q] * ev;
+        for (int grp = 0; grp < 3; ++grp) {
+            if (q + 8 * grp < q1) {                  // wave-uniform: skip empty groups
+#pragma unroll
+                for (int u = 8 * grp; u < 8 * grp + 8; ++u)
+                    acc += t[u] * ev[u];             // zero terms past the end are exact no-ops
+            }
+        }
     }
     return acc;
 }
@@ -1063,6 +1181,29 @@ __global__ __launch_bounds__(T) void finish_kernel(size_t total, const double *_
     const size_t stride = (size_t)gridDim.x * T;
     for (size_t i = (size_t)blockIdx.x * T + threadIdx.x; i < total; i += stride)
         sstats[i] *= eeb[i];
+}
+
+// out[i] = psi(x[i]) and, through the pieces, sum_p psi_piece<NP>(x[i], p): test hook for the
+// device special functions (tests/test_gpu_parity.py::test_device_digamma_table).
+__global__ void digamma_table_kernel(int n, const double *__restrict__ x, double *__restrict__ whole,
+                                     double *__restrict__ pieces2, double *__restrict__ pieces4,
+                                     double *__restrict__ pieces8)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const double v = x[i];
+    whole[i] = digamma(v);
+    double s2 = 0.0, s4 = 0.0, s8 = 0.0;
+    for (int p = 0; p < 2; ++p)
+        s2 += psi_piece<2>(v, p);
+    for (int p = 0; p < 4; ++p)
+        s4 += psi_piece<4>(v, p);
+    for (int p = 0; p < 8; ++p)
+        s8 += psi_piece<8>(v, p);
+    pieces2[i] = s2;
+    pieces4[i] = s4;
+    pieces8[i] = s8;
 }
 
 // ---------------------------------------------------------------------------

@@ -237,8 +237,10 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
         int G = std::min(kMaxRowsumBlocks, std::max(1, V / 32));
         int wpb = (V + G - 1) / G;
         G = (V + wpb - 1) / wpb;
-        hipLaunchKernelGGL(rowsum_psi_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads), 0,
-                           m->stream, K, V, wpb, m->lambda, m->partial, m->psi_sum, m->counter);
+        hipLaunchKernelGGL(rowsum_partial_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads), 0,
+                           m->stream, K, V, wpb, m->lambda, m->partial);
+        hipLaunchKernelGGL(rowsum_finish_kernel<64>, dim3((K + 63) / 64), dim3(64), 0, m->stream,
+                           K, G, m->partial, m->psi_sum);
         HIP_TRY(hipGetLastError());
     }
     if (m->timing && (rc = stamp(m)))
@@ -372,8 +374,11 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
             a.n_cap = 0;
             a.Kp = K;
             a.order = b->order + (B - n_reg);
-            hipLaunchKernelGGL(estep_docs_reg_kernel, dim3(n_reg), dim3(kRegThreads), 0, m->stream,
-                               a);
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(estep_docs_reg_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)kRegLdsBytes));
+            hipLaunchKernelGGL(estep_docs_reg_kernel, dim3(n_reg), dim3(kRegThreads), kRegLdsBytes,
+                               m->stream, a);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -1062,6 +1067,33 @@ extern "C" int trlda_debug_read_stamps(unsigned long long *host, int blocks)
     return 0;
 }
 #endif
+
+// ---- device special functions (test hook) -----------------------------------------------
+
+int trlda_debug_digamma(int device, int n, const double *x, double *whole, double *pieces2,
+                        double *pieces4, double *pieces8)
+{
+    int rc = use_device(device);
+    if (rc)
+        return rc;
+    if (n <= 0 || !x || !whole || !pieces2 || !pieces4 || !pieces8)
+        return fail(TRLDA_ERR_ARG, "bad digamma table arguments");
+    double *d = nullptr;
+    rc = dev_alloc(&d, (size_t)n * 5);
+    if (rc)
+        return rc;
+    const size_t bytes = (size_t)n * sizeof(double);
+    HIP_TRY(hipMemcpy(d, x, bytes, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(trlda::digamma_table_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, n,
+                       d, d + n, d + 2 * (size_t)n, d + 3 * (size_t)n, d + 4 * (size_t)n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(whole, d + n, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pieces2, d + 2 * (size_t)n, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pieces4, d + 3 * (size_t)n, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pieces8, d + 4 * (size_t)n, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipFree(d));
+    return TRLDA_OK;
+}
 
 // ---- measurement ----------------------------------------------------------------
 
