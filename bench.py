@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
-KERNEL_NAMES = ["rowsum_partial_kernel+rowsum_finish_kernel", "exp_elog_beta_kernel", "estep_docs_kernel",
+KERNEL_NAMES = ["rowsum_partial_kernel", "exp_elog_beta_kernel", "estep_docs_kernel",
                 "sstats_words_kernel"]
 
 
@@ -129,10 +129,11 @@ def main():
 
     def step(i, want_iters=False):
         j = i % args.num_batches
-        gamma.copy_(gamma0s[j].view(-1))              # gamma is in/out: restore gamma0
-        _ffi.check(L.trlda_model_estep(model, batches[j].handle, gamma.data_ptr(),
-                                       sstats.data_ptr(), args.max_iter, args.threshold,
-                                       iters_dev.data_ptr() if want_iters else None))
+        # gamma0 is read-only input, gamma the output (lda.cpp:168 copies, we do not)
+        _ffi.check(L.trlda_model_estep_io(model, batches[j].handle, gamma0s[j].data_ptr(),
+                                          gamma.data_ptr(), sstats.data_ptr(), args.max_iter,
+                                          args.threshold,
+                                          iters_dev.data_ptr() if want_iters else None))
         if world > 1:
             dist.all_reduce(sstats)                   # RCCL over xGMI: K x V fp64 sum
 

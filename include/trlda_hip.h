@@ -153,6 +153,12 @@ int trlda_model_estep(trlda_model *model, const trlda_batch *batch,
                       double *gamma_dev, double *sstats_dev,
                       int max_iter, double threshold, int32_t *iters_dev);
 
+/* Same, with the initial gamma read from a separate device array (K x B) that is left
+ * untouched -- `ArrayXXd gamma = initialGamma` of src/lda.cpp:168 without a device copy. */
+int trlda_model_estep_io(trlda_model *model, const trlda_batch *batch,
+                         const double *gamma0_dev, double *gamma_dev, double *sstats_dev,
+                         int max_iter, double threshold, int32_t *iters_dev);
+
 /* Host-pointer convenience around trlda_model_estep (uploads gamma0, downloads
  * gamma / sstats / iters, synchronises). */
 int trlda_model_estep_host(trlda_model *model, const trlda_batch *batch,

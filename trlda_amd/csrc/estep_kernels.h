@@ -52,23 +52,21 @@ __global__ __launch_bounds__(T) void rowsum_partial_kernel(
         const int slots = T / kc;              // word slots per pass
         const int slot = tid / kc;
         const int k = kbase + tid % kc;
-        double acc = 0.0;
+        // sixteen loads in flight (clamped word index, masked value: no branch between
+        // loads), four accumulation chains combined pairwise -- a fixed order
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
         if (slot < slots) {
-            int w = w0 + slot;
-            // eight independent loads in flight, added in word order
-            for (; w + 7 * slots < w1; w += 8 * slots) {
-                double v[8];
+            for (int w = w0 + slot; w < w1; w += 16 * slots) {
+                double v[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    v[u] = lambda[(size_t)(w + u * slots) * K + k];
+                for (int u = 0; u < 16; ++u)
+                    v[u] = lambda[(size_t)min(w + u * slots, w1 - 1) * K + k];
 #pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    acc += v[u];
+                for (int u = 0; u < 16; ++u)
+                    acc[u & 3] += (w + u * slots < w1) ? v[u] : 0.0;
             }
-            for (; w < w1; w += slots)
-                acc += lambda[(size_t)w * K + k];
         }
-        red[tid] = acc;
+        red[tid] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
         __syncthreads();
         if (tid < kc) {
             double s = red[tid];
@@ -80,41 +78,57 @@ __global__ __launch_bounds__(T) void rowsum_partial_kernel(
     }
 }
 
-// psiSum_k = psi(sum over the G block partials, in block order).  One small launch instead of
-// a last-block-done epilogue: two agent-scope fences cost more than a kernel boundary here.
-template <int T>
-__global__ __launch_bounds__(T) void rowsum_finish_kernel(int K, int G,
-                                                          const double *__restrict__ partial,
-                                                          double *__restrict__ psi_sum)
-{
-    const int k = blockIdx.x * T + threadIdx.x;
-    if (k >= K)
-        return;
-    double s = 0.0;
-    int b = 0;
-    for (; b + 16 <= G; b += 16) {                 // sixteen loads in flight, block order
-        double v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-            v[u] = partial[(size_t)(b + u) * K + k];
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-            s += v[u];
-    }
-    for (; b < G; ++b)
-        s += partial[(size_t)b * K + k];
-    psi_sum[k] = digamma(s);
-}
-
 // ---------------------------------------------------------------------------
 // 2. eeb[i] = exp(psi(lambda[i]) - psiSum[i % K]) over the flat K*V array.
-// Grid-stride; the topic index advances incrementally (no per-element modulo).
+//
+// Prologue: every block forms psiSum_k = psi(sum_b partial[b][k]) itself (G loads in flight
+// per topic, four chains, pairwise combine -- the same fixed order in every block) and
+// keeps it in LDS.  That costs each block about a microsecond of latency but saves a
+// launch plus a single-block reduction kernel; the grid is one fat block per CU so the
+// redundant psi evaluations stay below 4 % of the element work.
+// Main loop: grid-stride; the topic index advances incrementally (no per-element modulo).
 // ---------------------------------------------------------------------------
+constexpr int kRowsumBlocks = 64;
+
 template <int T>
 __global__ __launch_bounds__(T) void exp_elog_beta_kernel(
-    int K, size_t total, const double *__restrict__ lambda,
-    const double *__restrict__ psi_sum, double *__restrict__ eeb)
+    int K, size_t total, int G, const double *__restrict__ lambda,
+    const double *__restrict__ partial, double *__restrict__ psi_sum_out,
+    double *__restrict__ eeb)
 {
+    extern __shared__ double psi_sum[];             // K, then 8 x K scratch
+    double *scratch = psi_sum + K;
+    // eight threads per topic, each adds G/8 block partials (all loads in flight), then
+    // one thread per topic combines the eight in order and applies psi
+    const int per = (G + 7) / 8;
+    for (int t = threadIdx.x; t < 8 * K; t += T) {
+        const int k = t % K, part = t / K;
+        const int b0 = part * per, b1 = min(G, b0 + per);
+        double acc[2] = {0.0, 0.0};
+        for (int b = b0; b < b1; b += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = partial[(size_t)min(b + u, G - 1) * K + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                acc[u & 1] += (b + u < b1) ? v[u] : 0.0;
+        }
+        scratch[part * K + k] = acc[0] + acc[1];
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += T) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            v[u] = scratch[u * K + k];
+        const double ps = digamma(((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
+        psi_sum[k] = ps;
+        if (blockIdx.x == 0)
+            psi_sum_out[k] = ps;                     // kept for inspection / later kernels
+    }
+    __syncthreads();
+
     const size_t stride = (size_t)gridDim.x * T;
     size_t i = (size_t)blockIdx.x * T + threadIdx.x;
     int k = (int)(i % (size_t)K);
@@ -175,7 +189,8 @@ struct DocKernelArgs {
     const int32_t *order;     // optional processing order (long documents first)
     const double *eeb;        // K x V
     const double *alpha;      // K
-    double *gamma;            // K x B in/out
+    const double *gamma_in;   // K x B initial gamma (may alias gamma)
+    double *gamma;            // K x B out
     double *epg;              // K x B out: exp(psi(gamma)) of the returned gamma
     double *tw_csr;           // nnz: cnt/phinorm in CSR order (streaming-path scratch)
     const int32_t *wrank;     // nnz: CSR position -> word-major rank (segmented mode)
@@ -440,8 +455,9 @@ __global__ __launch_bounds__(T) void estep_docs_kernel(DocKernelArgs a)
     stamp_last = __builtin_amdgcn_s_memtime();
 #endif
     double *gamma_d = a.gamma + (size_t)d * K;
+    const double *gamma0_d = a.gamma_in + (size_t)d * K;
     for (int k = tid; k < K; k += T) {               // lda.cpp:174
-        const double gk = gamma_d[k];
+        const double gk = gamma0_d[k];
         g[k] = gk;
         e[k] = exp_digamma(gk);
     }
@@ -615,8 +631,9 @@ __global__ __launch_bounds__(T) void estep_docs_lds_kernel(DocKernelArgs a)
     const double *wgt_e = e + k0;
 
     double *gamma_d = a.gamma + (size_t)d * K;
+    const double *gamma0_d = a.gamma_in + (size_t)d * K;
     for (int k = tid; k < K; k += T) {               // lda.cpp:174
-        const double gk = gamma_d[k];
+        const double gk = gamma0_d[k];
         g[k] = gk;
         alpha_l[k] = a.alpha[k];
         e[k] = exp_digamma(gk);
@@ -857,10 +874,11 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
     }
 
     double *gamma_d = a.gamma + (size_t)d * K;
+    const double *gamma0_d = a.gamma_in + (size_t)d * K;
     for (int k = tid; k < 144; k += T) {             // lda.cpp:174
         double ev = 0.0;
         if (k < K) {
-            const double gk = gamma_d[k];
+            const double gk = gamma0_d[k];
             g[k] = gk;
             alpha_l[k] = a.alpha[k];
             ev = exp_digamma(gk);
@@ -1071,37 +1089,55 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
 // Optionally fuses the M-step blend (onlinelda.cpp:99-100):
 //   lambda_out = (1-rho) lambda' + rho (eta + scale * sstats)
 // ---------------------------------------------------------------------------
-// sum_{q in [q0, q1)} tw_word[q] * epg[k, wdoc[q]] for this lane's topic k; q0, q1 are
-// wave-uniform (SGPRs), so wdoc / tw_word are scalar loads.  Lists of up to 24 entries --
-// all of them after the long-word split -- have every gather in flight at once (one memory
-// latency instead of one per batch); the products are still added in list order.
-__device__ __forceinline__ double word_segment_sum(int q0, int q1, int K, int k, bool on,
-                                                   const int32_t *__restrict__ wdoc,
-                                                   const double *__restrict__ tw_word,
-                                                   const double *__restrict__ epg)
+// acc[h] += sum_{q in [q0, q1)} tw_word[q] * epg[kbase + 64 h + lane, wdoc[q]], h < NH topic
+// halves; q0, q1 are wave-uniform.  Per pass of 16 entries: lane u fetches (document,
+// weight) of entry u with one coalesced load each -- one memory latency for the whole list
+// instead of a dependent scalar load per entry -- v_readlane hands entry u to every lane,
+// the row gathers of a group of four are in flight together (groups past the end are
+// skipped: most words have a handful of entries), products are added in list order.
+template <int NH>
+__device__ __forceinline__ void word_segment_sum(int q0, int q1, int K, int kbase,
+                                                 const int32_t *__restrict__ wdoc,
+                                                 const double *__restrict__ tw_word,
+                                                 const double *__restrict__ epg, double *acc)
 {
-    double acc = 0.0;
-    for (int q = q0; q < q1; q += 24) {
-        double t[24], ev[24];
+    const int lane = threadIdx.x & (kWave - 1);
+    int kk[NH];
 #pragma unroll
-        for (int u = 0; u < 24; ++u) {
-            const bool in = q + u < q1;              // wave-uniform
-            t[u] = in ? tw_word[q + u] : 0.0;
-            ev[u] = (in && on) ? epg[(size_t)wdoc[in ? q + u : q] * K + k] : 0.0;
-        }
+    for (int h = 0; h < NH; ++h)
+        kk[h] = min(kbase + 64 * h + lane, K - 1);  // lanes past K gather topic K-1, unused
+    for (int q = q0; q < q1; q += 16) {
+        const int cnt = min(16, q1 - q);
+        const bool mine = lane < cnt;
+        const int dl = mine ? wdoc[q + lane] : 0;    // entries past the end: row 0, weight 0
+        const double tl = mine ? tw_word[q + lane] : 0.0;
+        const int tlo = __double2loint(tl), thi = __double2hiint(tl);
 #pragma unroll
-        for (int grp = 0; grp < 3; ++grp) {
-            if (q + 8 * grp < q1) {                  // wave-uniform: skip empty groups
+        for (int grp = 0; grp < 4; ++grp) {
+            if (4 * grp < cnt) {                     // wave-uniform
+                double ev[4][NH];
 #pragma unroll
-                for (int u = 8 * grp; u < 8 * grp + 8; ++u)
-                    acc += t[u] * ev[u];             // zero terms past the end are exact no-ops
+                for (int u = 0; u < 4; ++u) {
+                    const size_t row = (size_t)__builtin_amdgcn_readlane(dl, 4 * grp + u) * K;
+#pragma unroll
+                    for (int h = 0; h < NH; ++h)
+                        ev[u][h] = epg[row + kk[h]];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double tu =
+                        __hiloint2double(__builtin_amdgcn_readlane(thi, 4 * grp + u),
+                                         __builtin_amdgcn_readlane(tlo, 4 * grp + u));
+#pragma unroll
+                    for (int h = 0; h < NH; ++h)
+                        acc[h] = fma(tu, ev[u][h], acc[h]);   // +0 * finite past the end
+                }
             }
         }
     }
-    return acc;
 }
 
-constexpr int kLongWord = 24;   // entries above which a word's list is split over the block
+constexpr int kLongWord = 16;   // entries above which a word's list is split over the block
 
 template <int T>
 __global__ __launch_bounds__(T) void sstats_words_kernel(
@@ -1130,13 +1166,18 @@ __global__ __launch_bounds__(T) void sstats_words_kernel(
         s_len[wid] = (w < V) ? len : 0;
     }
     if (w < V && len <= kLongWord) {
-        for (int kb = 0; kb < K; kb += kWave) {
-            const int k = kb + lane;
-            const bool on = k < K;
-            const double acc = word_segment_sum(q0, q0 + len, K, k, on, wdoc, tw_word, epg);
-            if (on) {
-                const size_t i = (size_t)w * K + k;
-                sstats[i] = acc * eeb[i];
+        for (int kb = 0; kb < K; kb += 2 * kWave) {
+            double acc[2] = {0.0, 0.0};
+            if (len > 0)
+                word_segment_sum<2>(q0, q0 + len, K, kb, wdoc, tw_word, epg, acc);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = kb + 64 * h + lane;
+                if (k < K) {
+                    const size_t i = (size_t)w * K + k;
+                    // lda.cpp:169: words the batch does not touch are 0 (eeb is not read)
+                    sstats[i] = len > 0 ? acc[h] * eeb[i] : 0.0;
+                }
             }
         }
     }
@@ -1151,12 +1192,15 @@ __global__ __launch_bounds__(T) void sstats_words_kernel(
         const int chunk = (L + W - 1) / W;
         const int c0 = __builtin_amdgcn_readfirstlane(min(L, wid * chunk));
         const int c1 = __builtin_amdgcn_readfirstlane(min(L, c0 + chunk));
-        for (int kb = 0; kb < K; kb += kWave) {
-            const int k = kb + lane;
-            const bool on = k < K;
-            const double acc = word_segment_sum(base + c0, base + c1, K, k, on, wdoc, tw_word, epg);
-            if (on)
-                wpart[wid * K + k] = acc;
+        for (int kb = 0; kb < K; kb += 2 * kWave) {
+            double acc[2] = {0.0, 0.0};
+            word_segment_sum<2>(base + c0, base + c1, K, kb, wdoc, tw_word, epg, acc);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int k = kb + 64 * h + lane;
+                if (k < K)
+                    wpart[wid * K + k] = acc[h];
+            }
         }
         __syncthreads();
         if (wid == i) {

@@ -75,21 +75,19 @@ __device__ __forceinline__ double log_normal(double s)
 template <bool FAST>
 __device__ __forceinline__ double psi_positive_impl(double x)
 {
-    // The reference's `while (s < 10) { w += 1/s; s += 1; }` (src/digamma.cpp:158-163) laid
-    // out for instruction-level parallelism: a dependent fp64 op costs ~37 cycles on gfx950,
-    // so the ten shifted arguments are formed directly (s_i = x + i), their reciprocals are
-    // independent, and w is a pairwise sum.  Against the serial loop this moves psi by a few
-    // 1e-16 relative (one rounding in s_i, summation order).
+    // psi(x) = psi(x + 10) - sum_{i<10} 1/(x + i).  The reference's
+    // `while (s < 10) { w += 1/s; s += 1; }` (src/digamma.cpp:158-163) shifts by the
+    // smallest m that reaches s >= 10; the identity holds for every m, and always taking
+    // ten steps removes every data-dependent select from the hot path (s then lies in
+    // [10, 20) for x < 10, where the series is even more accurate).  Laid out for
+    // instruction-level parallelism -- a dependent fp64 op costs ~37 cycles on gfx950 -- the
+    // ten reciprocals are independent and w is a pairwise sum.  Against the serial loop
+    // this moves psi by a few 1e-16 relative.
     double ri[10];
-    int m = 0;
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        const double si = x + (double)i;
-        const bool below = si < 10.0;
-        m += below ? 1 : 0;
-        ri[i] = below ? rcp_pos<FAST>(si) : 0.0;
-    }
-    const double s = x + (double)m;
+    for (int i = 0; i < 10; ++i)
+        ri[i] = rcp_pos<FAST>(x + (double)i);
+    const double s = x + 10.0;
     const double w = (((ri[0] + ri[1]) + (ri[2] + ri[3])) + ((ri[4] + ri[5]) + (ri[6] + ri[7]))) +
                      (ri[8] + ri[9]);
     double y = 0.0;
@@ -161,12 +159,10 @@ __device__ __forceinline__ double exp_digamma(double x) { return exp(digamma(x))
 // psi(x) cut into NP independent pieces so that NP wavefronts can each evaluate one piece
 // for the same 64 arguments and a single wavefront combines them:
 //     psi(x) = sum_p psi_piece<NP>(x, p)          (added in the order p = 0 .. NP-1)
-// The pieces are the independent dependency chains of src/digamma.cpp:158-171: the
-// reciprocals of the upward recurrence (negated), log(s) and the asymptotic series.  The
-// number of recurrence steps is m = 10 - floor(x) for x < 10 (so s = x + m lies in
-// [10, 11)), the closed form of the reference's `while (s < 10)`; psi(x) = psi(x + m) -
-// sum_{i<m} 1/(x+i) holds for every m, so the two can differ only in the last bits when
-// x + i rounds across 10.  Arguments on the rare branches (x <= 0, small integers, outside
+// The pieces are the independent dependency chains of src/digamma.cpp:158-171 in the
+// ten-step form psi(x) = psi(x + 10) - sum_{i<10} 1/(x+i) (see psi_positive_impl): the
+// reciprocals of the recurrence (negated), log(x + 10) and the asymptotic series at
+// x + 10.  Arguments on the rare branches (x <= 0, small integers, outside
 // [1e-290, 1e290]) are evaluated whole by piece NP-1; the other pieces contribute 0.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ bool psi_is_regular(double x)
@@ -174,16 +170,14 @@ __device__ __forceinline__ bool psi_is_regular(double x)
     return x > 1e-290 && x < 1e290 && !(x <= 10.0 && x == floor(x));
 }
 
-__device__ __forceinline__ int psi_steps(double x) { return x < 10.0 ? 10 - (int)x : 0; }
-
-// -(sum of 1/(x+i) over i in [I0, I1) with i < m)
+// -(sum of 1/(x+i) over i in [I0, I1))
 template <int I0, int I1>
-__device__ __forceinline__ double psi_recurrence_piece(double x, int m)
+__device__ __forceinline__ double psi_recurrence_piece(double x)
 {
     double r[I1 - I0];
 #pragma unroll
     for (int i = I0; i < I1; ++i)
-        r[i - I0] = (i < m) ? rcp_pos<true>(x + (double)i) : 0.0;
+        r[i - I0] = rcp_pos<true>(x + (double)i);
 #pragma unroll
     for (int w = 1; w < I1 - I0; w <<= 1)
 #pragma unroll
@@ -192,14 +186,11 @@ __device__ __forceinline__ double psi_recurrence_piece(double x, int m)
     return -r[0];
 }
 
-__device__ __forceinline__ double psi_log_piece(double x, int m)
-{
-    return log_normal(x + (double)m);
-}
+__device__ __forceinline__ double psi_log_piece(double x) { return log_normal(x + 10.0); }
 
-__device__ __forceinline__ double psi_series_piece(double x, int m)
+__device__ __forceinline__ double psi_series_piece(double x)
 {
-    const double s = x + (double)m;
+    const double s = x + 10.0;
     const double r = rcp_pos<true>(s);
     double y = 0.0;
     if (s < 1.0e17) {
@@ -217,29 +208,28 @@ __device__ __forceinline__ double psi_piece(double x, int p)
         return digamma(x);
     if (__builtin_expect(!psi_is_regular(x), 0))
         return p == NP - 1 ? digamma(x) : 0.0;
-    const int m = psi_steps(x);
     if (NP == 2) {
         if (p == 0)
-            return psi_recurrence_piece<0, 10>(x, m) + psi_series_piece(x, m);
-        return psi_log_piece(x, m);
+            return psi_recurrence_piece<0, 10>(x) + psi_series_piece(x);
+        return psi_log_piece(x);
     }
     if (NP == 4) {
         switch (p) {
-        case 0: return psi_recurrence_piece<0, 5>(x, m);
-        case 1: return psi_recurrence_piece<5, 10>(x, m);
-        case 2: return psi_series_piece(x, m);
-        default: return psi_log_piece(x, m);
+        case 0: return psi_recurrence_piece<0, 5>(x);
+        case 1: return psi_recurrence_piece<5, 10>(x);
+        case 2: return psi_series_piece(x);
+        default: return psi_log_piece(x);
         }
     }
     switch (p) {
-    case 0: return psi_recurrence_piece<0, 2>(x, m);
-    case 1: return psi_recurrence_piece<2, 4>(x, m);
-    case 2: return psi_recurrence_piece<4, 6>(x, m);
-    case 3: return psi_recurrence_piece<6, 8>(x, m);
-    case 4: return psi_recurrence_piece<8, 10>(x, m);
-    case 5: return psi_series_piece(x, m);
+    case 0: return psi_recurrence_piece<0, 2>(x);
+    case 1: return psi_recurrence_piece<2, 4>(x);
+    case 2: return psi_recurrence_piece<4, 6>(x);
+    case 3: return psi_recurrence_piece<6, 8>(x);
+    case 4: return psi_recurrence_piece<8, 10>(x);
+    case 5: return psi_series_piece(x);
     case 6: return 0.0;
-    default: return psi_log_piece(x, m);
+    default: return psi_log_piece(x);
     }
 }
 

@@ -47,7 +47,7 @@ constexpr int kLdsBytes = 160 * 1024;   // LDS per workgroup on gfx950
 unsigned long long *g_stamp_buf = nullptr;
 #endif
 constexpr int kDenseThreads = 256;
-constexpr int kMaxRowsumBlocks = 128;
+constexpr int kMaxRowsumBlocks = trlda::kRowsumBlocks;
 
 template <typename T>
 int dev_alloc(T **p, size_t count)
@@ -216,7 +216,8 @@ size_t docs_lds_bytes(int K, int Kp, int n_cap, int T)
 
 // The E-step launch sequence on the model's stream (no synchronisation).
 int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double *sstats_dev,
-                 int max_iter, double threshold, int32_t *iters_dev)
+                 int max_iter, double threshold, int32_t *iters_dev,
+                 const double *gamma_in_dev = nullptr)
 {
     using namespace trlda;
     const int K = m->K, V = m->V, B = b->B;
@@ -232,26 +233,29 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
     if (m->timing && (rc = stamp(m)))
         return rc;
 
-    // 1. psiSum (lda.cpp:172)
+    // 1. row sums of lambda, per block of words (lda.cpp:172)
+    int G = std::min(trlda::kRowsumBlocks, std::max(1, V / 32));
     {
-        int G = std::min(kMaxRowsumBlocks, std::max(1, V / 32));
         int wpb = (V + G - 1) / G;
         G = (V + wpb - 1) / wpb;
         hipLaunchKernelGGL(rowsum_partial_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads), 0,
                            m->stream, K, V, wpb, m->lambda, m->partial);
-        hipLaunchKernelGGL(rowsum_finish_kernel<64>, dim3((K + 63) / 64), dim3(64), 0, m->stream,
-                           K, G, m->partial, m->psi_sum);
         HIP_TRY(hipGetLastError());
     }
     if (m->timing && (rc = stamp(m)))
         return rc;
 
-    // 2. exp E[log beta] (lda.cpp:173)
+    // 2. psiSum + exp E[log beta] (lda.cpp:172-173)
     {
-        size_t blocks = (KV + kDenseThreads - 1) / kDenseThreads;
-        int G = (int)std::min<size_t>(blocks, 256 * 16);
-        hipLaunchKernelGGL(exp_elog_beta_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads), 0,
-                           m->stream, K, KV, m->lambda, m->psi_sum, m->eeb);
+        constexpr int TE = 1024;
+        size_t blocks = (KV + TE - 1) / TE;
+        int GE = (int)std::min<size_t>(blocks, 256);
+        size_t lds = (size_t)K * 9 * sizeof(double);
+        if (lds > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(exp_elog_beta_kernel<TE>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(exp_elog_beta_kernel<TE>, dim3(GE), dim3(TE), lds, m->stream, K, KV, G,
+                           m->lambda, m->partial, m->psi_sum, m->eeb);
         HIP_TRY(hipGetLastError());
     }
     if (m->timing && (rc = stamp(m)))
@@ -277,7 +281,8 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
 #endif
         a.indptr = b->indptr; a.ids = b->ids; a.cnts = b->cnts;
         a.eeb = m->eeb; a.alpha = m->alpha;
-        a.gamma = gamma_dev; a.epg = m->epg; a.tw_csr = m->tw_csr;
+        a.gamma = gamma_dev; a.gamma_in = gamma_in_dev ? gamma_in_dev : gamma_dev;
+        a.epg = m->epg; a.tw_csr = m->tw_csr;
         a.wrank = b->wrank; a.tw_word = m->tw_word;
         a.sstats_acc = atomic ? sstats_dev : nullptr;
         a.max_iter = max_iter; a.threshold = threshold; a.iters_out = iters_dev;
@@ -791,6 +796,18 @@ int trlda_model_estep(trlda_model *m, const trlda_batch *b, double *gamma_dev, d
     if (!b || !sstats_dev || (b->B > 0 && !gamma_dev))
         return fail(TRLDA_ERR_ARG, "NULL batch / gamma / sstats");
     return estep_device(m, b, gamma_dev, sstats_dev, max_iter, threshold, iters_dev);
+}
+
+int trlda_model_estep_io(trlda_model *m, const trlda_batch *b, const double *gamma0_dev,
+                         double *gamma_dev, double *sstats_dev, int max_iter, double threshold,
+                         int32_t *iters_dev)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!b || !sstats_dev || (b->B > 0 && (!gamma_dev || !gamma0_dev)))
+        return fail(TRLDA_ERR_ARG, "NULL batch / gamma / sstats");
+    return estep_device(m, b, gamma_dev, sstats_dev, max_iter, threshold, iters_dev, gamma0_dev);
 }
 
 int trlda_model_estep_host(trlda_model *m, const trlda_batch *b, double *gamma, double *sstats,
