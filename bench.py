@@ -93,9 +93,18 @@ def main():
     _ffi.require_gpu()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # TRLDA_BENCH_FORCE_DIST=1: exercise the N > 1 code path (process group, all-reduce,
+    # barrier) on a single GPU -- a development aid for boxes with one device
+    force_dist = world == 1 and os.environ.get("TRLDA_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if force_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        else:
+            dist.init_process_group("nccl", device_id=device)
+    collective = world > 1 or force_dist
 
     K, V, B = args.topics, args.words, args.batch
     KV = K * V
@@ -134,11 +143,11 @@ def main():
                                           gamma.data_ptr(), sstats.data_ptr(), args.max_iter,
                                           args.threshold,
                                           iters_dev.data_ptr() if want_iters else None))
-        if world > 1:
+        if collective:
             dist.all_reduce(sstats)                   # RCCL over xGMI: K x V fp64 sum
 
     def fence():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -150,7 +159,7 @@ def main():
         step(i)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if collective:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -173,8 +182,7 @@ def main():
     mean_iters = float(iters_dev.float().mean().item())
 
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     estep_bytes, docs_bytes, _ = algorithmic_bytes(K, V, csrs[0].indptr)
@@ -284,14 +292,15 @@ def main():
                    "max_iter_inference": args.max_iter, "threshold": args.threshold,
                    "mean_iterations_executed": round(mean_iters, 2),
                    "sstats": args.sstats_mode, "parallelism": "dp%d" % world,
-                   "exchange": "RCCL all-reduce of K x V fp64 sstats" if world > 1 else "none"},
+                   "exchange": "RCCL all-reduce of K x V fp64 sstats" if collective else "none"},
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
         "parity": parity,
     }
-    print(json.dumps(out))
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)                # the one JSON line, last on stdout
 
 
 if __name__ == "__main__":

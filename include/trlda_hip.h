@@ -218,9 +218,10 @@ int trlda_model_batch_update(trlda_model *model, const trlda_batch *batch, doubl
 /* ---- test hook ----------------------------------------------------------- */
 
 /* The device digamma (TRLDA::digamma, src/digamma.cpp:116-178, as compiled for gfx950)
- * evaluated at n host points: whole[i] = psi(x[i]); piecesN[i] = psi assembled from the N
- * independent pieces the document kernels distribute over wavefronts.  Lets the parity
- * tests check the special functions against the reference's table directly. */
+ * evaluated at n host points: whole[i] = psi(x[i]); piecesN[i] = exp(psi(x[i])) assembled
+ * from the N independent pieces the document kernels distribute over wavefronts (the form
+ * the hot path uses: lda.cpp:173-174, :197 only ever need exp(psi)).  Lets the parity tests
+ * check the special functions against the reference's table directly. */
 int trlda_debug_digamma(int device, int n, const double *x, double *whole, double *pieces2,
                         double *pieces4, double *pieces8);
 

@@ -253,8 +253,11 @@ int oracle_estep(int K, int V, int B, const int32_t *indptr, const int32_t *ids,
 }
 
 /*
- * Same computation, documents spread over `nthreads` OpenMP threads with
- * thread-private accumulators (no critical section, unlike lda.cpp:211).
+ * Same computation, documents spread over `nthreads` OpenMP threads without the
+ * reference's critical section (lda.cpp:211): phase 1 runs the per-document fixed points
+ * in parallel and keeps exp(psi(gamma_d)) and the per-word weights cnt/phinorm; phase 2
+ * sums every word's contributions in document order (a counting sort by word id gives the
+ * lists), so the result is identical to the serial function for any thread count.
  * Only used for the "all host cores" CPU baseline line of bench.py.
  */
 int oracle_estep_mt(int K, int V, int B, const int32_t *indptr, const int32_t *ids,
@@ -275,8 +278,9 @@ int oracle_estep_mt(int K, int V, int B, const int32_t *indptr, const int32_t *i
 
     size_t KV = (size_t)K * V;
     double *eeb = (double *)malloc(sizeof(double) * KV);
-    double *priv = (double *)calloc(KV * (size_t)nthreads, sizeof(double));
     double *psi_sum = (double *)malloc(sizeof(double) * (size_t)K);
+    double *epg_all = (double *)malloc(sizeof(double) * (size_t)K * (B > 0 ? B : 1));
+    double *tw = (double *)malloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1));
 
     for (int k = 0; k < K; ++k) {
         double s = 0.0;
@@ -293,13 +297,6 @@ int oracle_estep_mt(int K, int V, int B, const int32_t *indptr, const int32_t *i
 
 #pragma omp parallel num_threads(nthreads)
     {
-        int tid = 0;
-#ifdef _OPENMP
-        extern int omp_get_thread_num(void);
-        tid = omp_get_thread_num();
-#endif
-        double *acc = priv + KV * (size_t)tid;
-        double *epg = (double *)malloc(sizeof(double) * (size_t)K);
         double *last = (double *)malloc(sizeof(double) * (size_t)K);
         double *beta_d = (double *)malloc(sizeof(double) * (size_t)K * (max_n + 1));
         double *phinorm = (double *)malloc(sizeof(double) * (size_t)(max_n + 1));
@@ -309,29 +306,53 @@ int oracle_estep_mt(int K, int V, int B, const int32_t *indptr, const int32_t *i
             const int32_t *dids = ids + indptr[d];
             const int32_t *dcnt = cnts + indptr[d];
             double *g = gamma + (int64_t)K * d;
+            double *epg = epg_all + (int64_t)K * d;
             for (int k = 0; k < K; ++k)
                 epg[k] = exp(oracle_digamma(g[k]));
-            int it = estep_one_doc(K, n, dids, dcnt, eeb, alpha, g, epg, beta_d,
-                                   phinorm, last, max_iter, threshold);
+            int it = estep_one_doc(K, n, dids, dcnt, eeb, alpha, g, epg, beta_d, phinorm, last,
+                                   max_iter, threshold);
             if (iters_out)
                 iters_out[d] = it;
-            for (int j = 0; j < n; ++j) {
-                double c = (double)dcnt[j] / phinorm[j];
-                double *col = acc + (int64_t)K * dids[j];
-                for (int k = 0; k < K; ++k)
-                    col[k] += c * epg[k];
-            }
+            for (int j = 0; j < n; ++j)
+                tw[indptr[d] + j] = (double)dcnt[j] / phinorm[j];
         }
-        free(epg); free(last); free(beta_d); free(phinorm);
+        free(last); free(beta_d); free(phinorm);
     }
-#pragma omp parallel for num_threads(nthreads) schedule(static)
-    for (int64_t i = 0; i < (int64_t)KV; ++i) {
-        double s = 0.0;
-        for (int t = 0; t < nthreads; ++t)
-            s += priv[KV * (size_t)t + i];
-        sstats[i] = s * eeb[i];
+
+    /* word-major lists (stable counting sort: document order within a word) */
+    int32_t *wptr = (int32_t *)calloc((size_t)V + 1, sizeof(int32_t));
+    int32_t *wpos = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1));
+    int32_t *wdoc = (int32_t *)malloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1));
+    for (int64_t i = 0; i < nnz; ++i)
+        ++wptr[ids[i] + 1];
+    for (int w = 0; w < V; ++w)
+        wptr[w + 1] += wptr[w];
+    {
+        int32_t *cur = (int32_t *)malloc(sizeof(int32_t) * (size_t)V);
+        memcpy(cur, wptr, sizeof(int32_t) * (size_t)V);
+        for (int d = 0; d < B; ++d)
+            for (int p = indptr[d]; p < indptr[d + 1]; ++p) {
+                int32_t q = cur[ids[p]]++;
+                wpos[q] = p;
+                wdoc[q] = d;
+            }
+        free(cur);
     }
-    free(eeb); free(priv); free(psi_sum);
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 64)
+    for (int w = 0; w < V; ++w) {
+        double *col = sstats + (int64_t)K * w;
+        for (int k = 0; k < K; ++k)
+            col[k] = 0.0;
+        for (int q = wptr[w]; q < wptr[w + 1]; ++q) {
+            double c = tw[wpos[q]];
+            const double *epg = epg_all + (int64_t)K * wdoc[q];
+            for (int k = 0; k < K; ++k)
+                col[k] += c * epg[k];
+        }
+        for (int k = 0; k < K; ++k)
+            col[k] *= eeb[k + (int64_t)K * w];
+    }
+    free(eeb); free(psi_sum); free(epg_all); free(tw); free(wptr); free(wpos); free(wdoc);
     return 0;
 }
 

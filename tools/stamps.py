@@ -19,10 +19,10 @@ batch = m.upload(CSRDocuments(indptr, ids, cnts))
 names = ["psi: partials->gnew", "stage beta", "product E (first)", "product B", "psi: combine+exp+barrier", "product E", "outputs", "psi: piece+barrier"]
 for T in (0,):
     L.trlda_model_set_doc_threads(m._handle, T)
-    m.update_variables(batch, latents=g0, max_iter=20)
+    m.update_variables(batch, latents=g0, max_iter=20, threshold=0.0)
     buf = np.zeros((B, 8), dtype=np.uint64)
     L.trlda_debug_read_stamps(buf.ctypes.data, B)
-    m.update_variables(batch, latents=g0, max_iter=20)
+    m.update_variables(batch, latents=g0, max_iter=20, threshold=0.0)
     L.trlda_debug_read_stamps(buf.ctypes.data, B)
     mean = buf.astype(np.float64).mean(axis=0)
     print("T=%d  total %.0f cycles/doc" % (T, mean.sum()))

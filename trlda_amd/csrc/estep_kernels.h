@@ -134,7 +134,7 @@ __global__ __launch_bounds__(T) void exp_elog_beta_kernel(
     int k = (int)(i % (size_t)K);
     const int kstep = (int)(stride % (size_t)K);
     for (; i < total; i += stride) {
-        eeb[i] = exp(digamma(lambda[i]) - psi_sum[k]);
+        eeb[i] = exp_digamma_minus(lambda[i], psi_sum[k]);
         k += kstep;
         if (k >= K)
             k -= K;
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(T) void estep_docs_lds_kernel(DocKernelArgs a)
                 psi += rpart[p * K + k_mine];
             diffs[k_mine] = fabs(g[k_mine] - gnew);
             g[k_mine] = gnew;
-            e[k_mine] = exp(psi);
+            e[k_mine] = exp_psi_from_pieces(gnew, psi);
         }
         __syncthreads();
 
@@ -842,7 +842,11 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
 #endif
 
     const int nm = min(n, 128);                      // words held in registers
+#ifdef TRLDA_NO_TAIL
+    const int nt = 0;                                // experiment: no tail support
+#else
     const int nt = n - nm;                           // tail words (LDS), <= 64
+#endif
     const int JC = (((nm + W - 1) / W) + 1) & ~1;    // words per wave (even), <= 16
     const int KC = (((K + W - 1) / W) + 1) & ~1;     // topics per wave (even), <= 16
     const int j0 = wid * JC, k0 = wid * KC;
@@ -953,20 +957,24 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
         part[wid * kRegPart + 64 + lane] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
         if (nt > 0) {                                // tail word 128 + lane from LDS
             const double *rowp = tbuf + min(lane, 8 * TC - 1) * kRegStride + min(k0, K - 1);
-            double tv[16];
+            double s2a = 0.0, s2b = 0.0;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const bool colv = i < KC && k0 + i < K;      // wave-uniform, as for bE0 / bE1
-                const double v = rowp[colv ? i : 0];
-                tv[i] = colv ? v : 0.0;
-            }
-            double s2[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int hb = 0; hb < 2; ++hb) {         // two halves of eight: fewer live registers
+                double tv[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                s2[(2 * i) & 3] = fma(ew[i].x, tv[2 * i], s2[(2 * i) & 3]);
-                s2[(2 * i + 1) & 3] = fma(ew[i].y, tv[2 * i + 1], s2[(2 * i + 1) & 3]);
+                for (int i = 0; i < 8; ++i) {
+                    const int c = 8 * hb + i;
+                    const bool colv = c < KC && k0 + c < K;   // wave-uniform, as for bE0 / bE1
+                    const double v = rowp[colv ? c : 0];
+                    tv[i] = colv ? v : 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s2a = fma(ew[4 * hb + i].x, tv[2 * i], s2a);
+                    s2b = fma(ew[4 * hb + i].y, tv[2 * i + 1], s2b);
+                }
             }
-            part[wid * kRegPart + 128 + lane] = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+            part[wid * kRegPart + 128 + lane] = s2a + s2b;
         }
         __syncthreads();
         if (tid < 128 || tid < n)                    // 0 beyond n (cnt is 0 there)
@@ -1006,18 +1014,22 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
             }
             if (nt > 0) {                            // tail rows of this wave, from LDS
                 const double *rowp = tbuf + (wid * TC) * kRegStride + lane;
-                double lo[8], hi[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int r = (i < TC) ? i : 0;  // wave-uniform clamp, weight zeroed below
-                    lo[i] = rowp[r * kRegStride];
-                    hi[i] = rowp[r * kRegStride + 64];
-                }
+                for (int hb = 0; hb < 2; ++hb) {     // two halves of four rows
+                    double lo[4], hi[4];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const double wgt = (i < TC) ? tw[128 + wid * TC + i] : 0.0;
-                    a0[i & 3] = fma(wgt, lo[i], a0[i & 3]);
-                    a1[i & 3] = fma(wgt, hi[i], a1[i & 3]);
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = (4 * hb + i < TC) ? 4 * hb + i : 0;   // wave-uniform clamp
+                        lo[i] = rowp[r * kRegStride];
+                        hi[i] = rowp[r * kRegStride + 64];
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 4 * hb + i;
+                        const double wgt = (r < TC) ? tw[128 + wid * TC + r] : 0.0;
+                        a0[i] = fma(wgt, lo[i], a0[i]);
+                        a1[i] = fma(wgt, hi[i], a1[i]);
+                    }
                 }
             }
             part[wid * kRegPart + lane] = (a0[0] + a0[1]) + (a0[2] + a0[3]);
@@ -1034,7 +1046,11 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
             const double acc = sum8_strided<kRegPart>(part + kk);
             gnew = acc * ek + ak;
             TRLDA_STAMP(0);
+#ifdef TRLDA_EXP_NOPIECE
+            const double pc = gnew * 1e-3;           // timing experiment only
+#else
             const double pc = psi_piece<4>(psi_on ? gnew : 1.5, piece);
+#endif
             if (psi_on)
                 rpart[piece * 128 + k_psi] = pc;
         }
@@ -1046,7 +1062,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
             const double psi = ((r0 + r1) + r2) + r3;
             diffs[k_psi] = fabs(gold - gnew);
             g[k_psi] = gnew;
-            e[k_psi] = exp(psi);
+            e[k_psi] = exp_psi_from_pieces(gnew, psi);
         }
         __syncthreads();
         TRLDA_STAMP(4);
@@ -1227,7 +1243,7 @@ __global__ __launch_bounds__(T) void finish_kernel(size_t total, const double *_
         sstats[i] *= eeb[i];
 }
 
-// out[i] = psi(x[i]) and, through the pieces, sum_p psi_piece<NP>(x[i], p): test hook for the
+// whole[i] = psi(x[i]); piecesN[i] = exp(psi(x[i])) assembled from N pieces: test hook for the
 // device special functions (tests/test_gpu_parity.py::test_device_digamma_table).
 __global__ void digamma_table_kernel(int n, const double *__restrict__ x, double *__restrict__ whole,
                                      double *__restrict__ pieces2, double *__restrict__ pieces4,
@@ -1245,9 +1261,10 @@ __global__ void digamma_table_kernel(int n, const double *__restrict__ x, double
         s4 += psi_piece<4>(v, p);
     for (int p = 0; p < 8; ++p)
         s8 += psi_piece<8>(v, p);
-    pieces2[i] = s2;
-    pieces4[i] = s4;
-    pieces8[i] = s8;
+    // the pieces assemble exp(psi(x)) = (x + 10) exp(sum)
+    pieces2[i] = exp_psi_from_pieces(v, s2);
+    pieces4[i] = exp_psi_from_pieces(v, s4);
+    pieces8[i] = exp_psi_from_pieces(v, s8);
 }
 
 // ---------------------------------------------------------------------------

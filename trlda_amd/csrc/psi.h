@@ -153,17 +153,47 @@ __device__ __forceinline__ double digamma(double x)
     return psi_positive(x);
 }
 
-__device__ __forceinline__ double exp_digamma(double x) { return exp(digamma(x)); }
+// exp(psi(x) - c) without the logarithm: with s = x + 10 and
+//   psi(x) = log(s) - 1/(2s) - series(1/s^2) - sum_{i<10} 1/(x+i)      (digamma.cpp:158-171)
+// the log comes straight back out of the exponential, exp(psi(x) - c) = s * exp(-(t + c)),
+// t = 1/(2s) + series + sum >= 0.  One exp instead of log + exp -- the log is the longest
+// dependency chain of psi -- and no cancellation between log(s) and t.  Both callers of the
+// reference's digamma on the hot path only ever want exp(psi(.)) (lda.cpp:173-174, :197).
+__device__ __forceinline__ double exp_psi_regular(double x, double c)
+{
+    double ri[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i)
+        ri[i] = rcp_pos<true>(x + (double)i);
+    const double s = x + 10.0;
+    const double w = (((ri[0] + ri[1]) + (ri[2] + ri[3])) + ((ri[4] + ri[5]) + (ri[6] + ri[7]))) +
+                     (ri[8] + ri[9]);
+    const double r = rcp_pos<true>(s);
+    double y = 0.0;
+    if (s < 1.0e17) {
+        const double z = r * r;
+        y = z * psi_series(z);
+    }
+    return s * exp(-(((0.5 * r) + y) + w) - c);
+}
+
+__device__ __forceinline__ double exp_digamma_minus(double x, double c)
+{
+    if (__builtin_expect(!(x > 1e-290 && x < 1e290) || (x <= 10.0 && x == floor(x)), 0))
+        return exp(digamma(x) - c);
+    return exp_psi_regular(x, c);
+}
+
+__device__ __forceinline__ double exp_digamma(double x) { return exp_digamma_minus(x, 0.0); }
 
 // ---------------------------------------------------------------------------------------
-// psi(x) cut into NP independent pieces so that NP wavefronts can each evaluate one piece
+// exp(psi(x)) cut into independent pieces so that NP wavefronts can each evaluate one piece
 // for the same 64 arguments and a single wavefront combines them:
-//     psi(x) = sum_p psi_piece<NP>(x, p)          (added in the order p = 0 .. NP-1)
-// The pieces are the independent dependency chains of src/digamma.cpp:158-171 in the
-// ten-step form psi(x) = psi(x + 10) - sum_{i<10} 1/(x+i) (see psi_positive_impl): the
-// reciprocals of the recurrence (negated), log(x + 10) and the asymptotic series at
-// x + 10.  Arguments on the rare branches (x <= 0, small integers, outside
-// [1e-290, 1e290]) are evaluated whole by piece NP-1; the other pieces contribute 0.
+//     exp(psi(x)) = (x + 10) * exp(sum_p psi_piece<NP>(x, p))      (p = 0 .. NP-1 in order)
+// The pieces are the independent dependency chains of exp_psi_regular: slices of the
+// reciprocal sum (negated) and the 1/(2s) + series term (negated).  Arguments on the rare
+// branches (x <= 0, small integers, outside [1e-290, 1e290]) are evaluated whole by piece
+// NP-1, which returns psi(x) - log(x + 10); the other pieces contribute 0.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ bool psi_is_regular(double x)
 {
@@ -186,8 +216,6 @@ __device__ __forceinline__ double psi_recurrence_piece(double x)
     return -r[0];
 }
 
-__device__ __forceinline__ double psi_log_piece(double x) { return log_normal(x + 10.0); }
-
 __device__ __forceinline__ double psi_series_piece(double x)
 {
     const double s = x + 10.0;
@@ -204,21 +232,21 @@ template <int NP>
 __device__ __forceinline__ double psi_piece(double x, int p)
 {
     static_assert(NP == 1 || NP == 2 || NP == 4 || NP == 8, "pieces");
-    if (NP == 1)
-        return digamma(x);
     if (__builtin_expect(!psi_is_regular(x), 0))
-        return p == NP - 1 ? digamma(x) : 0.0;
+        return p == NP - 1 ? digamma(x) - log(x + 10.0) : 0.0;
+    if (NP == 1)
+        return psi_recurrence_piece<0, 10>(x) + psi_series_piece(x);
     if (NP == 2) {
         if (p == 0)
-            return psi_recurrence_piece<0, 10>(x) + psi_series_piece(x);
-        return psi_log_piece(x);
+            return psi_recurrence_piece<0, 6>(x);
+        return psi_recurrence_piece<6, 10>(x) + psi_series_piece(x);
     }
     if (NP == 4) {
         switch (p) {
-        case 0: return psi_recurrence_piece<0, 5>(x);
-        case 1: return psi_recurrence_piece<5, 10>(x);
-        case 2: return psi_series_piece(x);
-        default: return psi_log_piece(x);
+        case 0: return psi_recurrence_piece<0, 4>(x);
+        case 1: return psi_recurrence_piece<4, 7>(x);
+        case 2: return psi_recurrence_piece<7, 10>(x);
+        default: return psi_series_piece(x);
         }
     }
     switch (p) {
@@ -227,10 +255,16 @@ __device__ __forceinline__ double psi_piece(double x, int p)
     case 2: return psi_recurrence_piece<4, 6>(x);
     case 3: return psi_recurrence_piece<6, 8>(x);
     case 4: return psi_recurrence_piece<8, 10>(x);
-    case 5: return psi_series_piece(x);
+    case 5: return 0.0;
     case 6: return 0.0;
-    default: return psi_log_piece(x);
+    default: return psi_series_piece(x);
     }
+}
+
+// combine: exp(psi(x)) from the summed pieces
+__device__ __forceinline__ double exp_psi_from_pieces(double x, double piece_sum)
+{
+    return (x + 10.0) * exp(piece_sum);
 }
 
 }  // namespace trlda
