@@ -16,7 +16,7 @@ L.trlda_seed(1)
 m = OnlineLDA(V, K, 1000000)
 g0 = np.empty((K, B), order="F"); L.trlda_sample_gamma_init(K, B, g0)
 batch = m.upload(CSRDocuments(indptr, ids, cnts))
-names = ["psi: partials->gnew", "stage beta", "product E (first)", "product B", "psi: combine+exp+barrier", "product E", "outputs", "psi: piece+barrier"]
+names = ["psi: partials->gnew (w0)", "stage beta", "product E (first)", "product B", "psi: barrier", "product E", "outputs", "psi: exp(psi) (w0)"]
 for T in (0,):
     L.trlda_model_set_doc_threads(m._handle, T)
     m.update_variables(batch, latents=g0, max_iter=20, threshold=0.0)

@@ -991,8 +991,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
     product_E(false);
     TRLDA_STAMP(2);
 
-    const int half = wid & 1, piece = wid >> 1;      // psi role
-    const int k_psi = half * 64 + lane;
+    const int k_psi = (wid & 1) * 64 + lane;         // topic of this lane in the psi stage
     const bool psi_on = k_psi < K;
 
     int it = 0;
@@ -1038,32 +1037,24 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
         __syncthreads();
         TRLDA_STAMP(3);
 
-        // gamma_k = alpha_k + e_k * acc_k (lda.cpp:194-195), psi(gamma_k) in 4 pieces
-        double gnew = 0.0;
-        {
+        // gamma_k = alpha_k + e_k * acc_k ; e_k = exp(psi(gamma_k))     lda.cpp:194-197
+        // Two waves (topics 0..63, 64..127).  tools/probes/probe6: the whole log-free
+        // exp(psi) chain is ~670 cycles for one thread, no more than its slowest piece plus
+        // the exchange when it is spread over four waves -- so it is not split.
+        if (wid < 2) {
             const int kk = psi_on ? k_psi : 0;
-            const double ek = e[kk], ak = alpha_l[kk];
+            const double ek = e[kk], ak = alpha_l[kk], gold = g[kk];
             const double acc = sum8_strided<kRegPart>(part + kk);
-            gnew = acc * ek + ak;
+            const double gnew = acc * ek + ak;
             TRLDA_STAMP(0);
-#ifdef TRLDA_EXP_NOPIECE
-            const double pc = gnew * 1e-3;           // timing experiment only
-#else
-            const double pc = psi_piece<4>(psi_on ? gnew : 1.5, piece);
-#endif
-            if (psi_on)
-                rpart[piece * 128 + k_psi] = pc;
+            const double enew = exp_digamma(gnew);
+            if (psi_on) {
+                diffs[k_psi] = fabs(gold - gnew);
+                g[k_psi] = gnew;
+                e[k_psi] = enew;
+            }
         }
-        __syncthreads();
         TRLDA_STAMP(7);
-        if (piece == 0 && psi_on) {                  // lda.cpp:197
-            const double r0 = rpart[k_psi], r1 = rpart[128 + k_psi], r2 = rpart[256 + k_psi],
-                         r3 = rpart[384 + k_psi], gold = g[k_psi];
-            const double psi = ((r0 + r1) + r2) + r3;
-            diffs[k_psi] = fabs(gold - gnew);
-            g[k_psi] = gnew;
-            e[k_psi] = exp_psi_from_pieces(gnew, psi);
-        }
         __syncthreads();
         TRLDA_STAMP(4);
 

@@ -179,9 +179,12 @@ __device__ __forceinline__ double exp_psi_regular(double x, double c)
 
 __device__ __forceinline__ double exp_digamma_minus(double x, double c)
 {
+    // the regular value is computed unconditionally so that the (rare-branch) test runs
+    // beside the main dependency chain instead of in front of it
+    const double v = exp_psi_regular(x, c);
     if (__builtin_expect(!(x > 1e-290 && x < 1e290) || (x <= 10.0 && x == floor(x)), 0))
         return exp(digamma(x) - c);
-    return exp_psi_regular(x, c);
+    return v;
 }
 
 __device__ __forceinline__ double exp_digamma(double x) { return exp_digamma_minus(x, 0.0); }
@@ -200,14 +203,17 @@ __device__ __forceinline__ bool psi_is_regular(double x)
     return x > 1e-290 && x < 1e290 && !(x <= 10.0 && x == floor(x));
 }
 
-// -(sum of 1/(x+i) over i in [I0, I1))
+// -(sum over i in [I0, I1) of c_i / (x + i)), c_i = 1 for the ten recurrence terms i < 10 and
+// c_10 = 1/2: the -1/(2s) term of psi at s = x + 10 is one more reciprocal of the same family
 template <int I0, int I1>
 __device__ __forceinline__ double psi_recurrence_piece(double x)
 {
     double r[I1 - I0];
 #pragma unroll
-    for (int i = I0; i < I1; ++i)
-        r[i - I0] = rcp_pos<true>(x + (double)i);
+    for (int i = I0; i < I1; ++i) {
+        const double ri = rcp_pos<true>(x + (double)i);
+        r[i - I0] = (i == 10) ? 0.5 * ri : ri;
+    }
 #pragma unroll
     for (int w = 1; w < I1 - I0; w <<= 1)
 #pragma unroll
@@ -216,16 +222,19 @@ __device__ __forceinline__ double psi_recurrence_piece(double x)
     return -r[0];
 }
 
+// -(z * P(z)), z = 1/s^2, s = x + 10: at most 8.4e-4, so z only needs ~1e-13 relative
+// accuracy -- one Newton step on the v_rcp_f64 seed instead of two shortens the chain
 __device__ __forceinline__ double psi_series_piece(double x)
 {
     const double s = x + 10.0;
-    const double r = rcp_pos<true>(s);
+    double r = __builtin_amdgcn_rcp(s);
+    r = fma(fma(-s, r, 1.0), r, r);
     double y = 0.0;
     if (s < 1.0e17) {
         const double z = r * r;
         y = z * psi_series(z);
     }
-    return -(0.5 * r) - y;
+    return -y;
 }
 
 template <int NP>
@@ -235,17 +244,17 @@ __device__ __forceinline__ double psi_piece(double x, int p)
     if (__builtin_expect(!psi_is_regular(x), 0))
         return p == NP - 1 ? digamma(x) - log(x + 10.0) : 0.0;
     if (NP == 1)
-        return psi_recurrence_piece<0, 10>(x) + psi_series_piece(x);
+        return psi_recurrence_piece<0, 11>(x) + psi_series_piece(x);
     if (NP == 2) {
         if (p == 0)
             return psi_recurrence_piece<0, 6>(x);
-        return psi_recurrence_piece<6, 10>(x) + psi_series_piece(x);
+        return psi_recurrence_piece<6, 11>(x) + psi_series_piece(x);
     }
     if (NP == 4) {
         switch (p) {
         case 0: return psi_recurrence_piece<0, 4>(x);
-        case 1: return psi_recurrence_piece<4, 7>(x);
-        case 2: return psi_recurrence_piece<7, 10>(x);
+        case 1: return psi_recurrence_piece<4, 8>(x);
+        case 2: return psi_recurrence_piece<8, 11>(x);
         default: return psi_series_piece(x);
         }
     }
@@ -255,7 +264,7 @@ __device__ __forceinline__ double psi_piece(double x, int p)
     case 2: return psi_recurrence_piece<4, 6>(x);
     case 3: return psi_recurrence_piece<6, 8>(x);
     case 4: return psi_recurrence_piece<8, 10>(x);
-    case 5: return 0.0;
+    case 5: return psi_recurrence_piece<10, 11>(x);
     case 6: return 0.0;
     default: return psi_series_piece(x);
     }

@@ -359,9 +359,9 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
                                     (int)lds_bytes));                                      \
         hipLaunchKernelGGL(kern, dim3(n_lean), dim3(TL), lds_bytes, m->stream, a);         \
     } while (0)
-            constexpr int NPA = WL >= 8 ? 8 : WL;             // pieces when K <= 64
-            constexpr int NPB = WL / 2 >= 8 ? 8 : WL / 2;     // K <= 128
-            constexpr int NPC = WL / 4 >= 8 ? 8 : (WL / 4 >= 1 ? WL / 4 : 1);   // K <= 256
+            // exp(psi) is evaluated whole by the topic's own wave (NP = 1): probe6 shows the
+            // pieces buy nothing once the logarithm is gone
+            constexpr int NPA = 1, NPB = 1, NPC = 1;
             switch (KPl) {
             case 9: TRLDA_LAUNCH_LEAN(9, NPA); break;
             case 17: TRLDA_LAUNCH_LEAN(17, NPA); break;
