@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--num-batches", type=int, default=8, help="distinct mini-batches cycled")
     ap.add_argument("--sstats-mode", choices=["segmented", "atomic"], default="segmented")
     ap.add_argument("--doc-threads", type=int, default=0)
+    ap.add_argument("--dense-preamble", action="store_true",
+                    help="exp E[log beta] for all V words (reference behaviour) instead of the "
+                         "batch's active words")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -121,6 +124,7 @@ def main():
     _ffi.check(L.trlda_model_set_alpha(model, np.full(K, .1)))
     _ffi.check(L.trlda_model_set_sstats_mode(model, 1 if args.sstats_mode == "atomic" else 0))
     _ffi.check(L.trlda_model_set_doc_threads(model, args.doc_threads))
+    _ffi.check(L.trlda_model_set_dense_preamble(model, int(args.dense_preamble)))
 
     batches, csrs, gamma0s = [], [], []
     for i in range(args.num_batches):
@@ -291,7 +295,11 @@ def main():
                    "num_topics": K, "num_words": V, "batch_per_gpu": B, "global_batch": B * world,
                    "max_iter_inference": args.max_iter, "threshold": args.threshold,
                    "mean_iterations_executed": round(mean_iters, 2),
-                   "sstats": args.sstats_mode, "parallelism": "dp%d" % world,
+                   "sstats": args.sstats_mode,
+                   "exp_elog_beta": "all V words" if args.dense_preamble else
+                   "active words of the batch (mean %d of %d)" % (
+                       int(np.mean([len(np.unique(c.ids)) for c in csrs])), V),
+                   "parallelism": "dp%d" % world,
                    "exchange": "RCCL all-reduce of K x V fp64 sstats" if collective else "none"},
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,

@@ -134,6 +134,10 @@ int trlda_model_create(trlda_model **out, int device, int K, int V);
 int trlda_model_destroy(trlda_model *model);
 int trlda_model_set_stream(trlda_model *model, void *hip_stream /* hipStream_t */);
 int trlda_model_set_sstats_mode(trlda_model *model, int mode);
+/* exp E[log beta] (src/lda.cpp:173) is computed for the words that occur in the batch (the
+ * only columns the path reads); dense = 1 fills all V columns like the reference.  The
+ * outputs (gamma, sstats) are identical either way. */
+int trlda_model_set_dense_preamble(trlda_model *model, int dense);
 /* threads per document workgroup in the E-step kernel: 0 = auto, else 64..1024 (x64) */
 int trlda_model_set_doc_threads(trlda_model *model, int threads);
 int trlda_model_synchronize(trlda_model *model);

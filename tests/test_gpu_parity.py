@@ -295,6 +295,23 @@ def test_full_size_bitwise_reproducible_and_mode_agreement(hip, bench_case):
     assert relerr(s3[s1 > 0], s1[s1 > 0]) < 1e-12                  # atomics: order only
 
 
+def test_active_word_preamble_changes_nothing(hip, bench_case):
+    """exp E[log beta] on the batch's words only vs on all V words: identical gamma / sstats."""
+    K, V, B, docs, lam, g0 = bench_case
+    m = make_model(K, V, lam, D=1000000)
+    batch = m.upload(docs)
+    g1, s1 = m.update_variables(batch, latents=g0, max_iter=20)
+    assert hip.trlda_model_set_dense_preamble(m._handle, 1) == 0
+    g2, s2 = m.update_variables(batch, latents=g0, max_iter=20)
+    assert np.array_equal(g1, g2) and np.array_equal(s1, s2)
+    for mode in (1,):
+        hip.trlda_model_set_sstats_mode(m._handle, mode)
+        hip.trlda_model_set_dense_preamble(m._handle, 0)
+        g3, s3 = m.update_variables(batch, latents=g0, max_iter=20)
+        assert np.array_equal(g1, g3) and np.isfinite(s3).all()
+        assert relerr(s3[s1 > 0], s1[s1 > 0]) < 1e-12 and (s3[s1 == 0] == 0).all()
+
+
 def test_full_size_document_permutation(hip, bench_case):
     """Documents are independent given lambda: permuting the batch permutes gamma and leaves
     the statistics unchanged up to summation order."""

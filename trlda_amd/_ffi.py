@@ -48,6 +48,7 @@ _SIGNATURES = {
     "trlda_model_destroy": (C.c_int, [vp]),
     "trlda_model_set_stream": (C.c_int, [vp, vp]),
     "trlda_model_set_sstats_mode": (C.c_int, [vp, C.c_int]),
+    "trlda_model_set_dense_preamble": (C.c_int, [vp, C.c_int]),
     "trlda_model_set_doc_threads": (C.c_int, [vp, C.c_int]),
     "trlda_model_synchronize": (C.c_int, [vp]),
     "trlda_model_set_lambda": (C.c_int, [vp, f64p]),

@@ -87,6 +87,12 @@ __global__ __launch_bounds__(T) void rowsum_partial_kernel(
 // launch plus a single-block reduction kernel; the grid is one fat block per CU so the
 // redundant psi evaluations stay below 4 % of the element work.
 // Main loop: grid-stride; the topic index advances incrementally (no per-element modulo).
+//
+// Only the columns of words that occur in the batch are ever read (by the document kernels
+// and, times the word's statistics, by the statistics kernel; untouched words get
+// sstats = 0 without reading eeb), so by default only those columns are computed: the
+// `active` list comes with the batch.  gamma and sstats are unchanged by this; eeb is not an
+// output.  trlda_model_set_dense_preamble(model, 1) fills all V columns as the reference does.
 // ---------------------------------------------------------------------------
 constexpr int kRowsumBlocks = 64;
 
@@ -94,7 +100,7 @@ template <int T>
 __global__ __launch_bounds__(T) void exp_elog_beta_kernel(
     int K, size_t total, int G, const double *__restrict__ lambda,
     const double *__restrict__ partial, double *__restrict__ psi_sum_out,
-    double *__restrict__ eeb)
+    double *__restrict__ eeb, const int32_t *__restrict__ active /* word ids or nullptr */)
 {
     extern __shared__ double psi_sum[];             // K, then 8 x K scratch
     double *scratch = psi_sum + K;
@@ -129,15 +135,23 @@ __global__ __launch_bounds__(T) void exp_elog_beta_kernel(
     }
     __syncthreads();
 
+    // `total` = K * (number of columns to fill).  With `active` the flat index i walks the
+    // batch's active words only: column a = i / K is word active[a].
     const size_t stride = (size_t)gridDim.x * T;
     size_t i = (size_t)blockIdx.x * T + threadIdx.x;
     int k = (int)(i % (size_t)K);
+    size_t a = i / (size_t)K;
     const int kstep = (int)(stride % (size_t)K);
+    const size_t astep = stride / (size_t)K;
     for (; i < total; i += stride) {
-        eeb[i] = exp_digamma_minus(lambda[i], psi_sum[k]);
+        const size_t idx = active ? (size_t)active[a] * K + k : i;
+        eeb[idx] = exp_digamma_minus(lambda[idx], psi_sum[k]);
         k += kstep;
-        if (k >= K)
+        a += astep;
+        if (k >= K) {
             k -= K;
+            a += 1;
+        }
     }
 }
 

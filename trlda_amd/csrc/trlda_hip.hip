@@ -83,6 +83,8 @@ struct trlda_batch {
     int32_t *wrank = nullptr;   // CSR position -> rank in word-major order
     int32_t *wptr = nullptr;    // V+1 word segment offsets
     int32_t *wdoc = nullptr;    // document of each word-major entry
+    int32_t *active = nullptr;  // ids of the words that occur in the batch (ascending)
+    int n_active = 0;
     std::vector<int32_t> sorted_len;   // host copy: document lengths in `order`
 };
 
@@ -92,6 +94,7 @@ struct trlda_model {
     hipStream_t stream = nullptr;
     int sstats_mode = TRLDA_SSTATS_SEGMENTED;
     int doc_threads = 0;
+    bool dense_preamble = false;   // true: exp E[log beta] for all V words, as the reference
     double *lambda = nullptr, *alpha = nullptr;
     double *eeb = nullptr, *psi_sum = nullptr, *partial = nullptr;
     unsigned int *counter = nullptr;
@@ -245,17 +248,21 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
     if (m->timing && (rc = stamp(m)))
         return rc;
 
-    // 2. psiSum + exp E[log beta] (lda.cpp:172-173)
+    // 2. psiSum + exp E[log beta] (lda.cpp:172-173), on the batch's active words unless the
+    // dense preamble was asked for
     {
         constexpr int TE = 1024;
-        size_t blocks = (KV + TE - 1) / TE;
-        int GE = (int)std::min<size_t>(blocks, 256);
+        const bool dense = m->dense_preamble;
+        const size_t total = dense ? KV : (size_t)K * (size_t)b->n_active;
+        size_t blocks = (total + TE - 1) / TE;
+        int GE = (int)std::max<size_t>(1, std::min<size_t>(blocks, 256));
         size_t lds = (size_t)K * 9 * sizeof(double);
         if (lds > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(exp_elog_beta_kernel<TE>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(exp_elog_beta_kernel<TE>, dim3(GE), dim3(TE), lds, m->stream, K, KV, G,
-                           m->lambda, m->partial, m->psi_sum, m->eeb);
+        hipLaunchKernelGGL(exp_elog_beta_kernel<TE>, dim3(GE), dim3(TE), lds, m->stream, K, total, G,
+                           m->lambda, m->partial, m->psi_sum, m->eeb,
+                           dense ? nullptr : b->active);
         HIP_TRY(hipGetLastError());
     }
     if (m->timing && (rc = stamp(m)))
@@ -632,6 +639,14 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     if (!rc) rc = up(&b->wrank, wrank.data(), (size_t)nnz);
     if (!rc) rc = up(&b->wptr, wptr.data(), (size_t)V + 1);
     if (!rc) rc = up(&b->wdoc, wdoc.data(), (size_t)nnz);
+    {
+        std::vector<int32_t> active;
+        for (int w = 0; w < V; ++w)
+            if (wptr[(size_t)w + 1] > wptr[(size_t)w])
+                active.push_back(w);
+        b->n_active = (int)active.size();
+        if (!rc) rc = up(&b->active, active.data(), active.size());
+    }
     if (rc) {
         trlda_batch_destroy(b);
         return rc;
@@ -647,6 +662,7 @@ int trlda_batch_destroy(trlda_batch *b)
     if (hipSetDevice(b->device) == hipSuccess) {
         (void)hipFree(b->indptr); (void)hipFree(b->ids); (void)hipFree(b->cnts); (void)hipFree(b->order);
         (void)hipFree(b->wrank); (void)hipFree(b->wptr); (void)hipFree(b->wdoc);
+        (void)hipFree(b->active);
     }
     delete b;
     return TRLDA_OK;
@@ -682,6 +698,9 @@ int trlda_model_create(trlda_model **out, int device, int K, int V)
         return rc;
     }
     HIP_TRY(hipMemset(m->counter, 0, sizeof(unsigned int)));
+    // columns of words no batch has touched yet are never read for their value, but the
+    // atomic-mode finish multiplies them by 0: keep them finite
+    HIP_TRY(hipMemset(m->eeb, 0, KV * sizeof(double)));
     *out = m;
     return TRLDA_OK;
 }
@@ -720,6 +739,14 @@ int trlda_model_set_sstats_mode(trlda_model *m, int mode)
     if (mode != TRLDA_SSTATS_SEGMENTED && mode != TRLDA_SSTATS_ATOMIC)
         return fail(TRLDA_ERR_ARG, "unknown sstats mode");
     m->sstats_mode = mode;
+    return TRLDA_OK;
+}
+
+int trlda_model_set_dense_preamble(trlda_model *m, int dense)
+{
+    if (!m)
+        return fail(TRLDA_ERR_ARG, "model is NULL");
+    m->dense_preamble = dense != 0;
     return TRLDA_OK;
 }
 
