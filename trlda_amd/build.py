@@ -13,7 +13,7 @@ _CSRC = os.path.join(_PKG, "csrc")
 LIB_PATH = os.path.join(_PKG, "libtrlda_hip.so")
 SOURCES = ["trlda_hip.hip"]
 HEADERS = ["estep_kernels.h", "psi.h", os.path.join("..", "..", "include", "trlda_hip.h")]
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
                "-munsafe-fp-atomics", "-Wall"]
 
 

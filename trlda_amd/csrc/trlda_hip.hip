@@ -14,6 +14,8 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <thread>
+#include <time.h>
 #include <vector>
 
 #include "../../include/trlda_hip.h"
@@ -497,19 +499,116 @@ int trlda_device_count(void)
 }
 
 // ---- host RNG ---------------------------------------------------------------
+//
+// The reference draws lambda0 and every default gamma0 from libc rand() through
+// Eigen::Random (src/utils.cpp:224-231, Eigen/src/Core/MathFunctions.h:439-446).  glibc's
+// rand() is the TYPE_3 additive-feedback generator of random_r.c (x[i] = x[i-3] + x[i-31],
+// output x >> 1) behind a lock that costs ~20 ns per call -- 2*10^6 calls per default gamma0 at
+// K=100, B=200.  The same recurrence is reproduced here without the lock (the stream is
+// checked against libc's in tests/test_boundary.py), and the logarithms -- glibc's own
+// log(), so the values stay bit-identical -- are taken by a few threads over disjoint
+// elements, each element accumulating its passes in order.
+} // extern "C"
 
-void trlda_seed(unsigned int seed) { srand(seed); }
+namespace {
+
+struct GlibcRandom {
+    uint32_t x[31];
+    int f = 3, b = 0;
+    void seed(unsigned int s)
+    {
+        // srandom_r, TYPE_3
+        int32_t word = s == 0 ? 1 : (int32_t)s;
+        x[0] = (uint32_t)word;
+        for (int i = 1; i < 31; ++i) {
+            const long hi = word / 127773, lo = word % 127773;
+            long w = 16807 * lo - 2836 * hi;
+            if (w < 0)
+                w += 2147483647;
+            word = (int32_t)w;
+            x[i] = (uint32_t)word;
+        }
+        f = 3;
+        b = 0;
+        for (int i = 0; i < 310; ++i)
+            (void)next();
+    }
+    inline uint32_t next()
+    {
+        x[f] += x[b];
+        const uint32_t out = x[f] >> 1;
+        if (++f == 31)
+            f = 0;
+        if (++b == 31)
+            b = 0;
+        return out;
+    }
+};
+
+GlibcRandom g_rng;
+
+struct RngInit {
+    RngInit()
+    {
+        // module import seeds with the clock (python/src/module.cpp:356-359)
+        timespec t;
+        clock_gettime(CLOCK_REALTIME, &t);
+        const unsigned int s = (unsigned int)((t.tv_nsec / 1000) * t.tv_sec);
+        srand(s);
+        g_rng.seed(s);
+    }
+} g_rng_init;
+
+}  // namespace
+
+extern "C" {
+
+void trlda_seed(unsigned int seed)
+{
+    srand(seed);          // keep libc's own stream in step for anything else that uses it
+    g_rng.seed(seed);
+}
 
 void trlda_sample_gamma(int m, int n, int k, double *out)
 {
     const int64_t total = (int64_t)m * n;
     for (int64_t i = 0; i < total; ++i)
         out[i] = 0.0;
-    for (int pass = 0; pass < k; ++pass)
-        for (int64_t i = 0; i < total; ++i) {
-            const double u = -1.0 + 2.0 * (double)rand() / (double)RAND_MAX;
-            out[i] -= std::log(std::fabs(u));
+    if (total <= 0 || k <= 0)
+        return;
+    // passes are generated in blocks (sequentially: the stream order is pass-major) and the
+    // logs of a block are accumulated element-parallel
+    const int64_t block_passes = std::max<int64_t>(1, std::min<int64_t>(k, (4 << 20) / total));
+    std::vector<double> u((size_t)(block_passes * total));
+    unsigned int nthreads = std::thread::hardware_concurrency();
+    nthreads = std::max(1u, std::min(nthreads, 16u));
+    if (total * block_passes < (1 << 16))
+        nthreads = 1;
+    for (int pass0 = 0; pass0 < k; pass0 += (int)block_passes) {
+        const int np = (int)std::min<int64_t>(block_passes, k - pass0);
+        for (int64_t i = 0; i < (int64_t)np * total; ++i)
+            u[(size_t)i] = -1.0 + 2.0 * (double)g_rng.next() / (double)2147483647;
+        auto work = [&](int64_t lo, int64_t hi) {
+            for (int p = 0; p < np; ++p) {
+                const double *up = u.data() + (size_t)p * total;
+                for (int64_t i = lo; i < hi; ++i)
+                    out[i] -= std::log(std::fabs(up[i]));
+            }
+        };
+        if (nthreads == 1) {
+            work(0, total);
+        } else {
+            std::vector<std::thread> pool;
+            const int64_t chunk = (total + nthreads - 1) / nthreads;
+            for (unsigned int t = 0; t < nthreads; ++t) {
+                const int64_t lo = (int64_t)t * chunk, hi = std::min<int64_t>(total, lo + chunk);
+                if (lo < hi)
+                    pool.emplace_back(work, lo, hi);
+            }
+            for (auto &th : pool)
+                th.join();
         }
+    }
 }
 
 void trlda_sample_gamma_init(int m, int n, double *out)
