@@ -146,6 +146,10 @@ int trlda_model_set_lambda(trlda_model *model, const double *host_lambda /* K x 
 int trlda_model_get_lambda(trlda_model *model, double *host_lambda /* K x V */);
 int trlda_model_set_alpha(trlda_model *model, const double *host_alpha /* K */);
 void *trlda_model_lambda_dev(trlda_model *model);   /* K x V fp64, device */
+/* sufficient statistics of the last E-step run by trlda_model_online_update /
+ * trlda_model_batch_update / trlda_model_estep_host (the model's own workspace): what the
+ * adaptive learning rate of src/onlinelda.cpp:167-175 needs (lambdaHat = eta + D/B sstats). */
+int trlda_model_get_sstats(trlda_model *model, double *host_sstats /* K x V */);
 
 /*
  * Device-pointer E-step on the model's current lambda: src/lda.cpp:160-220.

@@ -174,6 +174,33 @@ def main():
     save("f4b_config1", K=K, V=V, D=D, B=B, corpus_seed=20150706, mean_unique=50, seed=77,
          rhos=np.array(rhos), lambda_final=m.lambdas, update_count=m.update_count)
 
+    # ---- F8: empirical-Bayes alpha / eta and the adaptive learning rate ------------------
+    K, V, D, B = 8, 120, 800, 30
+    batches = [make_corpus(B, V, seed=20150800 + i, mean_unique=25) for i in range(4)]
+    out = dict(K=K, V=V, D=D, B=B)
+    for i, (ip, ii, cc) in enumerate(batches):
+        out["indptr%d" % i], out["ids%d" % i], out["cnts%d" % i] = ip, ii, cc
+    cases = [dict(update_alpha=True), dict(update_eta=True), dict(update_alpha=True, update_eta=True),
+             dict(adaptive=True), dict(adaptive=True, update_alpha=True, update_eta=True),
+             dict(update_alpha=True, update_lambda=False, rho=.1),
+             dict(update_alpha=True, update_eta=True, max_iter_tr=0)]
+    for c, kw in enumerate(cases):
+        ref.seed(3000 + c)
+        m = ref.online(V, K, D, alpha=np.linspace(.05, .4, K), eta=.25)
+        out["c%d_lambda0" % c] = m.lambdas
+        rhos = []
+        for i, (ip, ii, cc) in enumerate(batches):
+            args = dict(max_iter_tr=2, max_iter_inference=20, kappa=.7, tau=10., rho=-1.)
+            args.update(kw)
+            rhos.append(m.update_parameters(ip, ii, cc, **args))
+            out["c%d_lambda%d" % (c, i + 1)] = m.lambdas
+            out["c%d_alpha%d" % (c, i + 1)] = m.alpha
+            out["c%d_eta%d" % (c, i + 1)] = np.array(m.ref.lib.ref_model_get_eta(m.h))
+        out["c%d_rhos" % c] = np.array(rhos)
+        out["c%d_kwargs" % c] = np.array(sorted(kw.items()), dtype=object).astype(str)
+    out["num_cases"] = len(cases)
+    save("f8_empirical_bayes", **out)
+
     # ---- F5: BatchLDA, 2 epochs --------------------------------------------------------
     K, V, B = 8, 150, 40
     ip, ii, cc = make_corpus(B, V, seed=20150709, mean_unique=25)

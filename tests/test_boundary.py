@@ -205,6 +205,24 @@ def test_alpha_argument_handling():
         _inference_method("map")
 
 
+def test_host_special_functions():
+    """trlda_amd._special (alpha / eta Newton steps) against the reference's psi table and its
+    polygamma known answers (utils_test.py:33-51)."""
+    from trlda_amd._special import digamma, trigamma
+    f = golden("f0_rng_psi")
+    x, want = f["psi_x"], f["psi_y"]
+    pos = (x > 0) & np.isfinite(want) & (x != np.floor(x))
+    err = np.abs(digamma(x[pos]) - want[pos]) / np.maximum(1.0, np.abs(want[pos]))
+    assert err.max() < 2e-15
+    kats = {.01: 10001.6212135283, .1: 101.433299150792758817215450106, .4: 7.275356590529597,
+            11.: 0.09516633568168575}
+    for xv, y in kats.items():
+        assert abs(trigamma(xv) - y) < 1e-9 * y
+    # psi'(x) = -d/dx of the recurrence: check psi'(x) - psi'(x+1) = 1/x^2
+    xs = np.logspace(-3, 3, 50)
+    assert np.max(np.abs(trigamma(xs) - trigamma(xs + 1) - 1 / xs ** 2) * xs ** 2) < 1e-12
+
+
 def test_abstract_classes():
     from trlda_amd.models import LDA, Distribution
     with pytest.raises(NotImplementedError):

@@ -206,6 +206,50 @@ def test_online_trajectories_golden(hip):
         assert np.array_equal(m.lambdas, before)
 
 
+def test_empirical_bayes_and_adaptive_rate_golden(hip):
+    """update_alpha / update_eta / adaptive (onlinelda.cpp:116-175) against trajectories of the
+    compiled reference: alpha, eta, lambda and the returned rho after every call."""
+    import ast
+    import trlda_amd
+    from trlda_amd.models import OnlineLDA
+    f = golden("f8_empirical_bayes")
+    K, V, D = int(f["K"]), int(f["V"]), int(f["D"])
+    for case in range(int(f["num_cases"])):
+        kw = {}
+        for key, val in f["c%d_kwargs" % case]:
+            kw[str(key)] = ast.literal_eval(str(val))
+        trlda_amd.seed(3000 + case)
+        m = OnlineLDA(num_words=V, num_topics=K, num_documents=D, alpha=np.linspace(.05, .4, K),
+                      eta=.25)
+        assert np.array_equal(m.lambdas, f["c%d_lambda0" % case])
+        for i in range(4):
+            args = dict(max_iter_tr=2, max_iter_inference=20, kappa=.7, tau=10., rho=-1.)
+            args.update(kw)
+            r = m.update_parameters(csr(f, str(i)), **args)
+            assert abs(r - f["c%d_rhos" % case][i]) <= 1e-9 * abs(r), (case, i, kw)
+            assert relerr(m.lambdas, f["c%d_lambda%d" % (case, i + 1)]) < 1e-8, (case, i, kw)
+            assert relerr(m.alpha.ravel(), f["c%d_alpha%d" % (case, i + 1)]) < 1e-8, (case, i, kw)
+            assert abs(m.eta - float(f["c%d_eta%d" % (case, i + 1)])) < 1e-8 * m.eta, (case, i, kw)
+        assert m.update_count == 4
+
+
+def test_reference_readme_example(hip, tmp_path):
+    """README.md:36-59 of the reference, verbatim but for the package name and sizes."""
+    from trlda_amd.models import OnlineLDA
+    from trlda_amd.utils import load_documents
+    from trlda_amd.utils.synthetic import csr_to_docs, make_corpus
+    path = tmp_path / "data_train.dat"
+    docs = csr_to_docs(*make_corpus(120, 700, seed=3, mean_unique=30))
+    path.write_text("".join("%d %s\n" % (len(d), " ".join("%d:%d" % t for t in d)) for d in docs))
+    model = OnlineLDA(num_words=700, num_topics=10, num_documents=120, alpha=.1, eta=.2)
+    for epoch in range(2):
+        for documents in load_documents(str(path), 50):
+            model.update_parameters(docs=documents, max_iter_tr=3, max_iter_inference=20, kappa=.7,
+                                    tau=100., update_alpha=True, update_eta=True)
+    assert model.update_count == 6 and np.isfinite(model.lambdas).all()
+    assert (model.alpha > 0).all() and model.eta > 0
+
+
 def test_config1_golden(hip):
     """BASELINE.json configs[0] end to end: K=10, V=1000, 1k docs, batch 100, TR=10."""
     import trlda_amd

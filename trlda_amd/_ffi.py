@@ -55,6 +55,7 @@ _SIGNATURES = {
     "trlda_model_get_lambda": (C.c_int, [vp, f64p]),
     "trlda_model_set_alpha": (C.c_int, [vp, f64p]),
     "trlda_model_lambda_dev": (vp, [vp]),
+    "trlda_model_get_sstats": (C.c_int, [vp, f64p]),
     "trlda_model_estep": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_double, vp]),
     "trlda_model_estep_io": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_double, vp]),
     "trlda_model_estep_host": (C.c_int, [vp, vp, f64p, f64p, C.c_int, C.c_double, vp]),

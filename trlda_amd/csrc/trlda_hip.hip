@@ -913,6 +913,21 @@ int trlda_model_set_alpha(trlda_model *m, const double *host_alpha)
 
 void *trlda_model_lambda_dev(trlda_model *m) { return m ? m->lambda : nullptr; }
 
+int trlda_model_get_sstats(trlda_model *m, double *host_sstats)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!host_sstats)
+        return fail(TRLDA_ERR_ARG, "sstats is NULL");
+    if (!m->sstats)
+        return fail(TRLDA_ERR_ARG, "no E-step has run through this model's own workspace yet");
+    HIP_TRY(hipMemcpyAsync(host_sstats, m->sstats, (size_t)m->K * m->V * sizeof(double),
+                           hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return TRLDA_OK;
+}
+
 int trlda_model_estep(trlda_model *m, const trlda_batch *b, double *gamma_dev, double *sstats_dev,
                       int max_iter, double threshold, int32_t *iters_dev)
 {

@@ -258,6 +258,11 @@ class OnlineLDA(LDA):
         # kappa_ / tau_ are accepted and ignored (old pickles; onlineldainterface.cpp:50-52)
         self._num_documents = int(num_documents)
         self._update_count = 0
+        # adaptive learning rate state (onlinelda.cpp:28-31; not pickled, like the reference)
+        self._ada_tau = 1000.
+        self._ada_rho = 1. / self._ada_tau
+        self._ada_sq_norm = 1.
+        self._ada_gradient = None
         self._setup(num_words, num_topics, alpha, eta, device)
 
     @property
@@ -287,25 +292,79 @@ class OnlineLDA(LDA):
                           update_lambda=True, update_alpha=False, update_eta=False,
                           min_alpha=1e-6, min_eta=1e-6, verbosity=0):
         """One online update; returns the learning rate used
-        (onlineldainterface.cpp:204-256 -> onlinelda.cpp:53-179)."""
-        if adaptive or update_alpha or update_eta:
-            raise NotImplementedError(
-                "adaptive / update_alpha / update_eta (onlinelda.cpp:116-175) are not on the "
-                "accelerated path yet (SURVEY.md 8f rank 1).")
+        (onlineldainterface.cpp:204-256 -> onlinelda.cpp:53-179).
+
+        The lambda path (E-steps, trust-region loop, blend) runs on the GPU.  The
+        empirical-Bayes steps for alpha and eta and the adaptive learning rate
+        (onlinelda.cpp:116-175) are K- and scalar-sized Newton updates: they run on the host
+        from the device results (gamma of the last E-step, lambda, sstats)."""
+        from .. import _special
         batch, owned = self._batch(docs)
         try:
+            B = len(batch)
+            if B == 0:
+                return 1.0                                           # onlinelda.cpp:54-56
+            L = _ffi.lib()
+            K, V = self._K, self._V
+            rho_arg = float(rho)
+            if rho_arg < 0. and adaptive:
+                rho_arg = self._ada_rho                              # onlinelda.cpp:61-62
+            lam_prime = self.lambdas if (adaptive and update_lambda) else None
+            eta_old = self._eta
+            gamma = None
+            if update_alpha and update_lambda:
+                gamma = np.empty((K, B), dtype=np.float64, order="F")
             count = C.c_int(self._update_count)
             rho_out = C.c_double(0.)
-            _ffi.check(_ffi.lib().trlda_model_online_update(
+            _ffi.check(L.trlda_model_online_update(
                 self._handle, batch.handle, self._num_documents, self._eta, int(max_iter_tr),
-                int(max_iter_inference), float(kappa), float(tau), float(rho),
+                int(max_iter_inference), float(kappa), float(tau), rho_arg,
                 int(bool(init_gamma)), int(bool(update_lambda)), 0.001,  # lda.h:56: fixed
-                C.byref(count), C.byref(rho_out), None))
+                C.byref(count), C.byref(rho_out),
+                gamma.ctypes.data if gamma is not None else None))
+            rho_used = rho_out.value
+
+            if update_alpha:                                         # onlinelda.cpp:116-142
+                if not update_lambda:
+                    gamma, _ = self.update_variables(batch, max_iter=max_iter_inference)
+                psi_gamma = _special.digamma(gamma)
+                psi_gamma_sum = _special.digamma(gamma.sum(axis=0))
+                alpha = self._alpha
+                g = (psi_gamma - psi_gamma_sum[None, :]).sum(axis=1) \
+                    - B * (_special.digamma(alpha) - _special.digamma(alpha.sum()))
+                h = -float(B) * _special.trigamma(alpha)
+                z = B * _special.trigamma(alpha.sum())
+                c = (g / h).sum() / (1. / z + (1. / h).sum())
+                alpha = np.maximum(alpha - rho_used * (g - c) / h, min_alpha)
+                _ffi.check(L.trlda_model_set_alpha(self._handle, np.ascontiguousarray(alpha)))
+                self._alpha = alpha
+
+            if update_eta:                                           # onlinelda.cpp:147-162
+                lam = self.lambdas
+                eta = self._eta
+                g = _special.digamma(lam).sum() - V * _special.digamma(lam.sum(axis=1)).sum() \
+                    - K * V * (_special.digamma(eta) - _special.digamma(V * eta))
+                h = K * V * (_special.trigamma(V * eta) - _special.trigamma(eta))
+                self._eta = max(float(eta - rho_used * g / h), min_eta)
+
+            if update_lambda and adaptive:                           # onlinelda.cpp:167-175
+                sstats = np.empty((K, V), dtype=np.float64, order="F")
+                _ffi.check(L.trlda_model_get_sstats(self._handle, sstats))
+                lam_hat = eta_old + float(self._num_documents) / B * sstats
+                upd = lam_hat - lam_prime
+                if self._ada_gradient is None:
+                    self._ada_gradient = np.zeros((K, V), order="F")
+                t = self._ada_tau
+                self._ada_gradient = (1. - 1. / t) * self._ada_gradient + 1. / t * upd
+                self._ada_sq_norm = (1. - 1. / t) * self._ada_sq_norm + 1. / t * float((upd * upd).sum())
+                self._ada_rho = float((self._ada_gradient * self._ada_gradient).sum()) / self._ada_sq_norm
+                self._ada_tau = t * (1. - self._ada_rho) + 1.
+
             self._update_count = count.value
         finally:
             if owned:
                 batch.close()
-        return rho_out.value
+        return rho_used
 
     def __reduce__(self):                                            # onlineldainterface.cpp:265
         args = (self._V, self._K, self._num_documents, self.alpha, self._eta)
