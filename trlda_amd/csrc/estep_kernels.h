@@ -823,6 +823,10 @@ __device__ __forceinline__ double sum8_strided(const double *p)
     return ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
 }
 
+// TAIL = false: documents of at most 128 words (no tail code, no register spills);
+// TAIL = true : also handles 129..192 words (a few spilled registers).  The host picks the
+// variant per batch, by whether the batch contains such a document.
+template <bool TAIL>
 __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -856,11 +860,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
 #endif
 
     const int nm = min(n, 128);                      // words held in registers
-#ifdef TRLDA_NO_TAIL
-    const int nt = 0;                                // experiment: no tail support
-#else
-    const int nt = n - nm;                           // tail words (LDS), <= 64
-#endif
+    const int nt = TAIL ? n - nm : 0;                // tail words (LDS), <= 64
     const int JC = (((nm + W - 1) / W) + 1) & ~1;    // words per wave (even), <= 16
     const int KC = (((K + W - 1) / W) + 1) & ~1;     // topics per wave (even), <= 16
     const int j0 = wid * JC, k0 = wid * KC;

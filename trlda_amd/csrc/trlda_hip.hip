@@ -387,12 +387,20 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
         if (n_reg > 0) {
             a.n_cap = 0;
             a.Kp = K;
-            a.order = b->order + (B - n_reg);
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(estep_docs_reg_kernel),
+            // within the register tier the documents with a tail (129..192 words) come first
+            int n_tail = 0;
+            while (n_tail < n_reg && b->sorted_len[(size_t)(B - n_reg + n_tail)] > 128)
+                ++n_tail;
+            // One launch: the tail-capable variant (it spills a few registers, ~7 % slower)
+            // only when the batch actually contains a 129..192-word document.  Running the two
+            // variants on two streams was measured and lost: the event fork/join costs more
+            // (~12 us) than it saves.
+            auto kern = n_tail > 0 ? estep_docs_reg_kernel<true> : estep_docs_reg_kernel<false>;
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)kRegLdsBytes));
-            hipLaunchKernelGGL(estep_docs_reg_kernel, dim3(n_reg), dim3(kRegThreads), kRegLdsBytes,
-                               m->stream, a);
+            a.order = b->order + (B - n_reg);
+            hipLaunchKernelGGL(kern, dim3(n_reg), dim3(kRegThreads), kRegLdsBytes, m->stream, a);
             HIP_TRY(hipGetLastError());
         }
     }
@@ -816,6 +824,7 @@ int trlda_model_destroy(trlda_model *m)
         (void)hipFree(m->wordcounts);
         for (auto &e : m->ev_pool)
             (void)hipEventDestroy(e);
+
     }
     delete m;
     return TRLDA_OK;
