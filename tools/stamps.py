@@ -11,12 +11,13 @@ from trlda_amd.utils.synthetic import make_corpus
 L = _ffi.lib()
 L.trlda_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
 K, V, B = 100, 7000, 200
-indptr, ids, cnts = make_corpus(B, V, seed=20150707, mean_unique=100)
+indptr, ids, cnts = make_corpus(B, V, seed=20150707, mean_unique=int(os.environ.get("STAMPS_MEAN", "95")))
+print("max doc length", np.diff(indptr).max())
 L.trlda_seed(1)
 m = OnlineLDA(V, K, 1000000)
 g0 = np.empty((K, B), order="F"); L.trlda_sample_gamma_init(K, B, g0)
 batch = m.upload(CSRDocuments(indptr, ids, cnts))
-names = ["psi: partials->gnew (w0)", "stage beta", "product E (first)", "product B", "psi: barrier", "product E", "outputs", "psi: exp(psi) (w0)"]
+names = ["psi: gnew + diffs + barrier", "stage beta", "product E (first)", "product B", "psi: barrier", "product E", "outputs", "psi: exp(psi) | reduce"]
 for T in (0,):
     L.trlda_model_set_doc_threads(m._handle, T)
     m.update_variables(batch, latents=g0, max_iter=20, threshold=0.0)

@@ -868,26 +868,19 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
     const int TC = (nt + W - 1) / W;                 // tail words per wave, <= 8
 
     // ---- the slice: orientation B straight from eeb (coalesced K-vectors)  lda.cpp:179-181
+    // Word ids of this wave's 16 rows: one vector load (lane i -> row i), handed to every lane
+    // by v_readlane -- one memory latency for the ids, then all 32 row loads are in flight
+    // while the gamma / alpha / count initialisation below runs.  Every load is unconditional
+    // (clamped indices); out-of-range elements are zeroed after the loads have landed.
     double bB0[16], bB1[16];          // beta[j0+i][lane], beta[j0+i][lane+64]
     {
-        // every load is unconditional (clamped word / topic index) so that all 32 are in
-        // flight together; out-of-range elements are zeroed afterwards
-        int wordid[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            wordid[i] = nm > 0 ? ids[min(j0 + i, nm - 1)] : 0;
+        const int myid = nm > 0 ? ids[min(j0 + (lane & 15), nm - 1)] : 0;
         const int kl = min(lane, K - 1), kh = min(lane + 64, K - 1);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const double *rowp = a.eeb + (size_t)wordid[i] * K;
+            const double *rowp = a.eeb + (size_t)__builtin_amdgcn_readlane(myid, i) * K;
             bB0[i] = rowp[kl];
             bB1[i] = rowp[kh];
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const bool row = i < JC && j0 + i < nm;
-            bB0[i] = (row && k_lo) ? bB0[i] : 0.0;
-            bB1[i] = (row && k_hi) ? bB1[i] : 0.0;
         }
     }
 
@@ -907,6 +900,12 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
         tw[j] = 0.0;
         if (j < 192)
             cntd[j] = j < n ? (double)cnts[j] : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const bool row = i < JC && j0 + i < nm;
+        bB0[i] = (row && k_lo) ? bB0[i] : 0.0;
+        bB1[i] = (row && k_hi) ? bB1[i] : 0.0;
     }
 
     // ---- orientation E through an LDS transposition (stride 129: conflict-free both ways)
@@ -993,12 +992,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
         __syncthreads();
         if (tid < 128 || tid < n)                    // 0 beyond n (cnt is 0 there)
             tw[tid] = cntd[tid] * rcp_pos<true>(sum8_strided<kRegPart>(part + tid) + 1e-100);
-        if (reduce_change && wid == W - 1) {         // mean |gamma - last|   lda.cpp:202
-            const double v = (k_lo ? diffs[lane] : 0.0) + (k_hi ? diffs[lane + 64] : 0.0);
-            const double mean = wave_sum_dpp(v) / (double)K;
-            if (lane == 0)
-                misc[0] = mean;
-        }
+        (void)reduce_change;
         __syncthreads();
     };
 
@@ -1055,27 +1049,41 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
         // Two waves (topics 0..63, 64..127).  tools/probes/probe6: the whole log-free
         // exp(psi) chain is ~670 cycles for one thread, no more than its slowest piece plus
         // the exchange when it is spread over four waves -- so it is not split.
+        double gnew = 0.0;
         if (wid < 2) {
             const int kk = psi_on ? k_psi : 0;
             const double ek = e[kk], ak = alpha_l[kk], gold = g[kk];
             const double acc = sum8_strided<kRegPart>(part + kk);
-            const double gnew = acc * ek + ak;
-            TRLDA_STAMP(0);
-            const double enew = exp_digamma(gnew);
-            if (psi_on) {
+            gnew = acc * ek + ak;
+            if (psi_on)
                 diffs[k_psi] = fabs(gold - gnew);
+        }
+        // |gamma - last| is known before the long exp(psi) chain starts: publish it now so
+        // that an otherwise idle wave forms the mean (DPP reduction + one division, ~600
+        // cycles) underneath that chain instead of after it
+        __syncthreads();
+        TRLDA_STAMP(0);
+        if (wid < 2) {
+            const double enew = exp_digamma(psi_on ? gnew : 1.5);
+            if (psi_on) {
                 g[k_psi] = gnew;
                 e[k_psi] = enew;
             }
+        } else if (wid == W - 1) {                   // mean |gamma - last|   lda.cpp:202
+            const double v = (k_lo ? diffs[lane] : 0.0) + (k_hi ? diffs[lane + 64] : 0.0);
+            const double mean = wave_sum_dpp(v) / (double)K;
+            if (lane == 0)
+                misc[0] = mean;
         }
         TRLDA_STAMP(7);
         __syncthreads();
         TRLDA_STAMP(4);
+        const double mean_change = misc[0];          // read now: off the loop-end critical path
 
         product_E(true);                             // ends with a barrier
         TRLDA_STAMP(5);
         ++it;
-        if (misc[0] < a.threshold)                   // lda.cpp:202-203
+        if (mean_change < a.threshold)               // lda.cpp:202-203
             break;
     }
 
