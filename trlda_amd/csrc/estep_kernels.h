@@ -1170,31 +1170,25 @@ constexpr int kLongWord = 16;   // entries above which a word's list is split ov
 
 template <int T>
 __global__ __launch_bounds__(T) void sstats_words_kernel(
-    int K, int V, const int32_t *__restrict__ wptr, const int32_t *__restrict__ wdoc,
-    const double *__restrict__ tw_word, const double *__restrict__ epg,
-    const double *__restrict__ eeb, double *__restrict__ sstats)
+    int K, int V, int G_short, const int32_t *__restrict__ wptr, const int32_t *__restrict__ wdoc,
+    const int32_t *__restrict__ long_words, const double *__restrict__ tw_word,
+    const double *__restrict__ epg, const double *__restrict__ eeb, double *__restrict__ sstats)
 {
     constexpr int W = T / kWave;
     extern __shared__ double wpart[];                // W x K partial sums (long words)
-    __shared__ int s_q0[W], s_len[W];
     const int lane = threadIdx.x & (kWave - 1);
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const int G = (int)gridDim.x;
-    // words are dealt round-robin over blocks (w = wave * G + block) so that the frequent
-    // (low-id, under Zipf) words land in different blocks
-    const int w = wid * G + (int)blockIdx.x;
-    int q0 = 0, len = 0;
-    if (w < V) {
-        q0 = wptr[w];
-        len = wptr[w + 1] - q0;
-    }
-    q0 = __builtin_amdgcn_readfirstlane(q0);
-    len = __builtin_amdgcn_readfirstlane(len);
-    if (lane == 0) {
-        s_q0[wid] = q0;
-        s_len[wid] = (w < V) ? len : 0;
-    }
-    if (w < V && len <= kLongWord) {
+
+    if ((int)blockIdx.x < G_short) {
+        // ---- one wavefront per word; lists longer than kLongWord are left to the blocks
+        // below.  Words are dealt round-robin over blocks (w = wave * G + block).
+        const int w = wid * G_short + (int)blockIdx.x;
+        if (w >= V)
+            return;
+        const int q0 = __builtin_amdgcn_readfirstlane(wptr[w]);
+        const int len = __builtin_amdgcn_readfirstlane(wptr[w + 1]) - q0;
+        if (len > kLongWord)
+            return;
         for (int kb = 0; kb < K; kb += 2 * kWave) {
             double acc[2] = {0.0, 0.0};
             if (len > 0)
@@ -1209,40 +1203,40 @@ __global__ __launch_bounds__(T) void sstats_words_kernel(
                 }
             }
         }
+        return;
+    }
+
+    // ---- one block per long list (they start together with the short-word blocks): the
+    // entries are split into W contiguous chunks, chunk sums are combined in chunk order
+    // (fixed by the list length -> bitwise reproducible)
+    const int w = long_words[(int)blockIdx.x - G_short];
+    const int base = __builtin_amdgcn_readfirstlane(wptr[w]);
+    const int L = __builtin_amdgcn_readfirstlane(wptr[w + 1]) - base;
+    const int chunk = (L + W - 1) / W;
+    const int c0 = __builtin_amdgcn_readfirstlane(min(L, wid * chunk));
+    const int c1 = __builtin_amdgcn_readfirstlane(min(L, c0 + chunk));
+    for (int kb = 0; kb < K; kb += 2 * kWave) {
+        double acc[2] = {0.0, 0.0};
+        word_segment_sum<2>(base + c0, base + c1, K, kb, wdoc, tw_word, epg, acc);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = kb + 64 * h + lane;
+            if (k < K)
+                wpart[wid * K + k] = acc[h];
+        }
     }
     __syncthreads();
-    // long lists: the whole block splits the entries into W contiguous chunks; chunk sums
-    // are combined in chunk order (fixed by the list length -> bitwise reproducible)
-    for (int i = 0; i < W; ++i) {
-        const int L = s_len[i];
-        if (L <= kLongWord)
-            continue;                                // block-uniform
-        const int base = s_q0[i];
-        const int chunk = (L + W - 1) / W;
-        const int c0 = __builtin_amdgcn_readfirstlane(min(L, wid * chunk));
-        const int c1 = __builtin_amdgcn_readfirstlane(min(L, c0 + chunk));
-        for (int kb = 0; kb < K; kb += 2 * kWave) {
-            double acc[2] = {0.0, 0.0};
-            word_segment_sum<2>(base + c0, base + c1, K, kb, wdoc, tw_word, epg, acc);
+    for (int k = threadIdx.x; k < K; k += T) {
+        double p[W];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int k = kb + 64 * h + lane;
-                if (k < K)
-                    wpart[wid * K + k] = acc[h];
-            }
-        }
-        __syncthreads();
-        if (wid == i) {
-            const int wi = i * G + (int)blockIdx.x;
-            for (int k = lane; k < K; k += kWave) {
-                double acc = wpart[k];
-                for (int c = 1; c < W; ++c)
-                    acc += wpart[c * K + k];
-                const size_t idx = (size_t)wi * K + k;
-                sstats[idx] = acc * eeb[idx];
-            }
-        }
-        __syncthreads();
+        for (int c = 0; c < W; ++c)
+            p[c] = wpart[c * K + k];
+        double acc = p[0];
+#pragma unroll
+        for (int c = 1; c < W; ++c)
+            acc += p[c];
+        const size_t idx = (size_t)w * K + k;
+        sstats[idx] = acc * eeb[idx];
     }
 }
 

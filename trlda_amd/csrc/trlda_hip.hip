@@ -87,6 +87,8 @@ struct trlda_batch {
     int32_t *wdoc = nullptr;    // document of each word-major entry
     int32_t *active = nullptr;  // ids of the words that occur in the batch (ascending)
     int n_active = 0;
+    int32_t *long_words = nullptr;   // words with more than kLongWord entries
+    int n_long = 0;
     std::vector<int32_t> sorted_len;   // host copy: document lengths in `order`
 };
 
@@ -416,14 +418,15 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
     } else {
         constexpr int kSstatsThreads = 1024;
         constexpr int wpb = kSstatsThreads / kWave;
-        int G = (V + wpb - 1) / wpb;
+        const int G_short = (V + wpb - 1) / wpb;
         size_t lds = (size_t)wpb * K * sizeof(double);
         auto kern = sstats_words_kernel<kSstatsThreads>;
         if (lds > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(G), dim3(kSstatsThreads), lds, m->stream, K, V, b->wptr,
-                           b->wdoc, m->tw_word, m->epg, m->eeb, sstats_dev);
+        hipLaunchKernelGGL(kern, dim3(G_short + b->n_long), dim3(kSstatsThreads), lds, m->stream, K,
+                           V, G_short, b->wptr, b->wdoc, b->long_words, m->tw_word, m->epg, m->eeb,
+                           sstats_dev);
     }
     HIP_TRY(hipGetLastError());
     if (m->timing && (rc = stamp(m)))
@@ -753,6 +756,12 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
                 active.push_back(w);
         b->n_active = (int)active.size();
         if (!rc) rc = up(&b->active, active.data(), active.size());
+        std::vector<int32_t> longw;
+        for (int w : active)
+            if (wptr[(size_t)w + 1] - wptr[(size_t)w] > trlda::kLongWord)
+                longw.push_back(w);
+        b->n_long = (int)longw.size();
+        if (!rc) rc = up(&b->long_words, longw.data(), longw.size());
     }
     if (rc) {
         trlda_batch_destroy(b);
@@ -769,7 +778,7 @@ int trlda_batch_destroy(trlda_batch *b)
     if (hipSetDevice(b->device) == hipSuccess) {
         (void)hipFree(b->indptr); (void)hipFree(b->ids); (void)hipFree(b->cnts); (void)hipFree(b->order);
         (void)hipFree(b->wrank); (void)hipFree(b->wptr); (void)hipFree(b->wdoc);
-        (void)hipFree(b->active);
+        (void)hipFree(b->active); (void)hipFree(b->long_words);
     }
     delete b;
     return TRLDA_OK;
