@@ -14,6 +14,7 @@ from helpers import (NORTH_STAR_RTOL, TIGHT_RTOL, HipSampler, golden, relerr, se
                      seeded_lambda)
 
 pytestmark = pytest.mark.gpu
+ROOT_DIR = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -508,3 +509,47 @@ def test_sharded_model_single_rank_matches_online_lda(hip):
     rb = [b.update_parameters(d, max_iter_tr=3) for d in docs]
     assert ra == rb and b.update_count == 2
     assert np.array_equal(a.lambdas, b.lambdas)
+
+
+def test_sharded_model_through_rccl_world_1(hip, tmp_path):
+    """The multi-GPU composition end to end on the one GPU there is: a 1-rank NCCL (= RCCL)
+    process group, HipEngine, the word-count and statistics all-reduces on device tensors.
+    Run in a child process so that the process group does not leak into this one."""
+    import subprocess
+    import sys
+    script = tmp_path / "rccl1.py"
+    script.write_text("""
+import os, sys
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+import numpy as np, torch, torch.distributed as dist
+import trlda_amd
+from trlda_amd.distributed import ShardedOnlineLDA
+from trlda_amd.documents import CSRDocuments
+from trlda_amd.models import OnlineLDA
+from trlda_amd.utils.synthetic import make_corpus
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+K, V, D, B = 12, 300, 2000, 40
+docs = [CSRDocuments(*make_corpus(B, V, seed=60 + i, mean_unique=30)) for i in range(2)]
+trlda_amd.seed(3)
+a = OnlineLDA(num_words=V, num_topics=K, num_documents=D)
+ra = [a.update_parameters(d, max_iter_tr=3) for d in docs]
+trlda_amd.seed(3)
+b = ShardedOnlineLDA(V, K, D, device=0)
+assert b.world == 1 and dist.is_initialized()
+b._all_reduce_calls = 0
+orig = b._all_reduce
+def counted(t):
+    b._all_reduce_calls += 1
+    dist.all_reduce(t)            # world 1: identity, but through RCCL on the device tensor
+    return t
+b._all_reduce = counted
+rb = [b.update_parameters(d, max_iter_tr=3) for d in docs]
+assert ra == rb and b.update_count == 2
+assert b._all_reduce_calls == 2 * (1 + 3)      # word counts + one per trust-region E-step
+assert np.array_equal(a.lambdas, b.lambdas)
+dist.destroy_process_group()
+print("RCCL1-OK")
+""" % ROOT_DIR)
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert "RCCL1-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

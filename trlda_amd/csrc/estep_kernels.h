@@ -789,10 +789,6 @@ constexpr size_t kRegLdsBytes = (size_t)(kRegSmallDoubles + 128 * kRegStride) * 
 // Sum over the 64 lanes of a wave in 6 DPP steps (row shifts, then row broadcasts); the total
 // ends up in lane 63 and is returned to every lane through two v_readlane.  __shfl_down on a
 // double goes through ds_bpermute, i.e. an LDS round trip per step.
-__device__ __forceinline__ double dpp_shift_add(double v, int)
-{
-    return v;
-}
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_add(double v)
 {
@@ -949,7 +945,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
     TRLDA_STAMP(1);
 
     // phinorm_j = sum_k e_k beta[j][k] ; tw_j = cnt_j / phinorm_j     lda.cpp:183 / :199
-    auto product_E = [&](bool reduce_change) {
+    auto product_E = [&]() {
         // k0 is even and e is 16-byte aligned: one ds_read_b128 broadcasts two weights.  All
         // eight reads are issued before the first fma and nothing is branched over: weights
         // past K are zero in LDS and the matching registers are zero.  Eight chains.
@@ -992,11 +988,10 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
         __syncthreads();
         if (tid < 128 || tid < n)                    // 0 beyond n (cnt is 0 there)
             tw[tid] = cntd[tid] * rcp_pos<true>(sum8_strided<kRegPart>(part + tid) + 1e-100);
-        (void)reduce_change;
         __syncthreads();
     };
 
-    product_E(false);
+    product_E();
     TRLDA_STAMP(2);
 
     const int k_psi = (wid & 1) * 64 + lane;         // topic of this lane in the psi stage
@@ -1080,7 +1075,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
         TRLDA_STAMP(4);
         const double mean_change = misc[0];          // read now: off the loop-end critical path
 
-        product_E(true);                             // ends with a barrier
+        product_E();                                 // ends with a barrier
         TRLDA_STAMP(5);
         ++it;
         if (mean_change < a.threshold)               // lda.cpp:202-203
