@@ -223,6 +223,16 @@ int trlda_model_batch_update(trlda_model *model, const trlda_batch *batch, doubl
                              int max_epochs, int max_iter_inference, int update_lambda,
                              double threshold, double *gamma_out);
 
+/*
+ * CumulativeLDA::updateParameters, lambda path: src/cumulativelda.cpp:49-72 -- lambda' =
+ * lambda; lambda = sampleGamma(K, V, 100)/100 (drawn whether or not update_lambda is set,
+ * like the reference); max_epochs x { E-step from a fresh random gamma; lambda = lambda' +
+ * sstats }.
+ */
+int trlda_model_cumulative_update(trlda_model *model, const trlda_batch *batch, int max_epochs,
+                                  int max_iter_inference, int update_lambda, double threshold,
+                                  double *gamma_out);
+
 /* ---- test hook ----------------------------------------------------------- */
 
 /* The device digamma (TRLDA::digamma, src/digamma.cpp:116-178, as compiled for gfx950)

@@ -174,6 +174,16 @@ class Reference:
         L.ref_online_create.argtypes = [C.c_int, C.c_int, C.c_int, _f64p, C.c_double]
         L.ref_batch_create.restype = C.c_void_p
         L.ref_batch_create.argtypes = [C.c_int, C.c_int, _f64p, C.c_double]
+        L.ref_cumulative_create.restype = C.c_void_p
+        L.ref_cumulative_create.argtypes = [C.c_int, C.c_int, _f64p, C.c_double]
+        L.ref_batch_update_parameters_full.restype = C.c_double
+        L.ref_batch_update_parameters_full.argtypes = [
+            C.c_void_p, C.c_int, _i32p, _i32p, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+            C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
+        L.ref_cumulative_update_parameters.restype = C.c_double
+        L.ref_cumulative_update_parameters.argtypes = [
+            C.c_void_p, C.c_int, _i32p, _i32p, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+            C.c_double, C.c_double, C.c_double]
         L.ref_model_destroy.argtypes = [C.c_void_p]
         L.ref_model_get_lambda.argtypes = [C.c_void_p, _f64p]
         L.ref_model_set_lambda.argtypes = [C.c_void_p, C.c_int, C.c_int, _f64p]
@@ -212,6 +222,9 @@ class Reference:
     def batch(self, V, K, alpha=.1, eta=.3):
         return RefModel(self, "batch", V, K, 0, alpha, eta)
 
+    def cumulative(self, V, K, alpha=.1, eta=.3):
+        return RefModel(self, "cumulative", V, K, 0, alpha, eta)
+
 
 class RefModel:
     def __init__(self, ref, kind, V, K, D, alpha, eta):
@@ -219,6 +232,8 @@ class RefModel:
         a = _f(np.broadcast_to(np.asarray(alpha, np.float64).ravel(), (K,)).copy())
         if kind == "online":
             self.h = ref.lib.ref_online_create(V, K, D, a, float(eta))
+        elif kind == "cumulative":
+            self.h = ref.lib.ref_cumulative_create(V, K, a, float(eta))
         else:
             self.h = ref.lib.ref_batch_create(V, K, a, float(eta))
         if not self.h:
@@ -254,6 +269,10 @@ class RefModel:
             raise RuntimeError(self.ref.lib.ref_last_error().decode())
 
     @property
+    def eta(self):
+        return self.ref.lib.ref_model_get_eta(self.h)
+
+    @property
     def update_count(self):
         return self.ref.lib.ref_online_update_count(self.h)
 
@@ -274,9 +293,20 @@ class RefModel:
     def update_parameters(self, indptr, ids, cnts, max_iter_tr=10, max_iter_inference=20,
                           kappa=.7, tau=100., rho=-1., adaptive=False, init_gamma=True,
                           update_lambda=True, update_alpha=False, update_eta=False,
-                          min_alpha=1e-6, min_eta=1e-6, max_epochs=100):
+                          min_alpha=1e-6, min_eta=1e-6, max_epochs=100, max_iter_alpha=10,
+                          max_iter_eta=20, emp_bayes_threshold=1e-8, inference_threshold=1e-3):
         indptr, ids, cnts = _csr(indptr, ids, cnts)
         B = len(indptr) - 1
+        if self.kind == "cumulative":
+            return self.ref.lib.ref_cumulative_update_parameters(
+                self.h, B, indptr, ids, cnts, max_epochs, max_iter_inference, max_iter_alpha,
+                int(update_lambda), int(update_alpha), min_alpha, emp_bayes_threshold,
+                inference_threshold)
+        if self.kind == "batch":
+            return self.ref.lib.ref_batch_update_parameters_full(
+                self.h, B, indptr, ids, cnts, max_epochs, max_iter_inference, max_iter_alpha,
+                max_iter_eta, int(update_lambda), int(update_alpha), int(update_eta), min_alpha,
+                min_eta, emp_bayes_threshold)
         if self.kind == "online":
             return self.ref.lib.ref_online_update_parameters(
                 self.h, B, indptr, ids, cnts, max_iter_tr, max_iter_inference, kappa, tau, rho,

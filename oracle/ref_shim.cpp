@@ -23,6 +23,7 @@ using Eigen::ArrayXd;
 using Eigen::ArrayXXd;
 using Eigen::Map;
 using TRLDA::BatchLDA;
+using TRLDA::CumulativeLDA;
 using TRLDA::LDA;
 using TRLDA::OnlineLDA;
 
@@ -73,6 +74,17 @@ void *ref_batch_create(int V, int K, const double *alpha, double eta)
     try {
         ArrayXd a = Map<const ArrayXd>(alpha, K);
         return new BatchLDA(V, a, eta);
+    } catch (TRLDA::Exception &e) {
+        g_last_error = e.message();
+        return 0;
+    }
+}
+
+void *ref_cumulative_create(int V, int K, const double *alpha, double eta)
+{
+    try {
+        ArrayXd a = Map<const ArrayXd>(alpha, K);
+        return new CumulativeLDA(V, a, eta);
     } catch (TRLDA::Exception &e) {
         g_last_error = e.message();
         return 0;
@@ -192,6 +204,61 @@ double ref_batch_update_parameters(void *h, int B, const int *indptr, const int 
         p.updateLambda = update_lambda != 0;
         p.updateAlpha = update_alpha != 0;
         p.updateEta = update_eta != 0;
+        return m->updateParameters(docs, p);
+    } catch (TRLDA::Exception &e) {
+        g_last_error = e.message();
+        return -1.;
+    }
+}
+
+/* BatchLDA::updateParameters with every kwarg of batchldainterface.cpp:126-172 */
+double ref_batch_update_parameters_full(void *h, int B, const int *indptr, const int *ids,
+                                        const int *cnts, int max_epochs, int max_iter_inference,
+                                        int max_iter_alpha, int max_iter_eta, int update_lambda,
+                                        int update_alpha, int update_eta, double min_alpha,
+                                        double min_eta, double emp_bayes_threshold)
+{
+    BatchLDA *m = static_cast<BatchLDA *>(h);
+    try {
+        LDA::Documents docs = to_documents(B, indptr, ids, cnts);
+        LDA::Parameters p;
+        p.maxEpochs = max_epochs;
+        p.maxIterInference = max_iter_inference;
+        p.maxIterAlpha = max_iter_alpha;
+        p.maxIterEta = max_iter_eta;
+        p.updateLambda = update_lambda != 0;
+        p.updateAlpha = update_alpha != 0;
+        p.updateEta = update_eta != 0;
+        p.minAlpha = min_alpha;
+        p.minEta = min_eta;
+        p.empBayesThreshold = emp_bayes_threshold;
+        return m->updateParameters(docs, p);
+    } catch (TRLDA::Exception &e) {
+        g_last_error = e.message();
+        return -1.;
+    }
+}
+
+/* CumulativeLDA::updateParameters -- cumulativelda.cpp:49-153, kwargs of
+ * cumulativeldainterface.cpp:115-160 */
+double ref_cumulative_update_parameters(void *h, int B, const int *indptr, const int *ids,
+                                        const int *cnts, int max_epochs, int max_iter_inference,
+                                        int max_iter_alpha, int update_lambda, int update_alpha,
+                                        double min_alpha, double emp_bayes_threshold,
+                                        double inference_threshold)
+{
+    CumulativeLDA *m = static_cast<CumulativeLDA *>(h);
+    try {
+        LDA::Documents docs = to_documents(B, indptr, ids, cnts);
+        LDA::Parameters p;
+        p.maxEpochs = max_epochs;
+        p.maxIterInference = max_iter_inference;
+        p.maxIterAlpha = max_iter_alpha;
+        p.updateLambda = update_lambda != 0;
+        p.updateAlpha = update_alpha != 0;
+        p.minAlpha = min_alpha;
+        p.empBayesThreshold = emp_bayes_threshold;
+        p.threshold = inference_threshold;
         return m->updateParameters(docs, p);
     } catch (TRLDA::Exception &e) {
         g_last_error = e.message();

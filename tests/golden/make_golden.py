@@ -201,6 +201,44 @@ def main():
     out["num_cases"] = len(cases)
     save("f8_empirical_bayes", **out)
 
+    # ---- F9: BatchLDA with the alpha / eta line searches; F10: CumulativeLDA ------------
+    K, V, B = 6, 90, 35
+    ip, ii, cc = make_corpus(B, V, seed=20150900, mean_unique=20)
+    out = dict(K=K, V=V, B=B, indptr=ip, ids=ii, cnts=cc)
+    cases = [dict(update_alpha=True), dict(update_eta=True), dict(update_alpha=True, update_eta=True),
+             dict(update_alpha=True, update_lambda=False)]
+    for c, kw in enumerate(cases):
+        ref.seed(4000 + c)
+        m = ref.batch(V, K, alpha=np.linspace(.1, .6, K), eta=.2)
+        args = dict(max_epochs=3, max_iter_inference=50)
+        args.update(kw)
+        m.update_parameters(ip, ii, cc, **args)
+        out["c%d_lambda" % c], out["c%d_alpha" % c], out["c%d_eta" % c] = m.lambdas, m.alpha, np.array(m.eta)
+        out["c%d_kwargs" % c] = np.array(sorted(kw.items()), dtype=object).astype(str)
+    out["num_cases"] = len(cases)
+    save("f9_batch_empirical_bayes", **out)
+
+    K, V, B = 7, 110, 30
+    batches = [make_corpus(B, V, seed=20151000 + i, mean_unique=22) for i in range(3)]
+    out = dict(K=K, V=V, B=B)
+    for i, (ip, ii, cc) in enumerate(batches):
+        out["indptr%d" % i], out["ids%d" % i], out["cnts%d" % i] = ip, ii, cc
+    cases = [dict(), dict(update_alpha=True), dict(update_alpha=True, update_lambda=False),
+             dict(max_epochs=1, inference_threshold=0.)]
+    for c, kw in enumerate(cases):
+        ref.seed(5000 + c)
+        m = ref.cumulative(V, K, alpha=.15, eta=.3)
+        for i, (ip, ii, cc) in enumerate(batches):
+            args = dict(max_epochs=2, max_iter_inference=40)
+            args.update(kw)
+            m.update_parameters(ip, ii, cc, **args)
+            out["c%d_lambda%d" % (c, i + 1)] = m.lambdas
+            out["c%d_alpha%d" % (c, i + 1)] = m.alpha
+        out["c%d_kwargs" % c] = np.array(sorted(kw.items()), dtype=object).astype(str) \
+            if kw else np.zeros((0, 2), dtype=str)
+    out["num_cases"] = len(cases)
+    save("f10_cumulative", **out)
+
     # ---- F5: BatchLDA, 2 epochs --------------------------------------------------------
     K, V, B = 8, 150, 40
     ip, ii, cc = make_corpus(B, V, seed=20150709, mean_unique=25)

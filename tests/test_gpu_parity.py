@@ -234,6 +234,53 @@ def test_empirical_bayes_and_adaptive_rate_golden(hip):
         assert m.update_count == 4
 
 
+def _kwargs(arr):
+    import ast
+    return {str(k): ast.literal_eval(str(v)) for k, v in arr}
+
+
+def test_batch_lda_line_searches_golden(hip):
+    """BatchLDA with update_alpha / update_eta (batchlda.cpp:64-205) vs the compiled reference."""
+    import trlda_amd
+    from trlda_amd.models import BatchLDA
+    f = golden("f9_batch_empirical_bayes")
+    K, V = int(f["K"]), int(f["V"])
+    for case in range(int(f["num_cases"])):
+        kw = _kwargs(f["c%d_kwargs" % case])
+        trlda_amd.seed(4000 + case)
+        m = BatchLDA(num_words=V, num_topics=K, alpha=np.linspace(.1, .6, K), eta=.2)
+        args = dict(max_epochs=3, max_iter_inference=50)
+        args.update(kw)
+        assert m.update_parameters(csr(f), **args) == 1.
+        assert relerr(m.lambdas, f["c%d_lambda" % case]) < 1e-7, (case, kw)
+        assert relerr(m.alpha.ravel(), f["c%d_alpha" % case]) < 1e-7, (case, kw)
+        assert abs(m.eta - float(f["c%d_eta" % case])) < 1e-7 * m.eta, (case, kw)
+
+
+def test_cumulative_lda_golden(hip):
+    """CumulativeLDA (cumulativelda.cpp:49-153): lambda = lambda' + sstats from a re-drawn
+    lambda each call, cumulative alpha statistics."""
+    import pickle
+    import trlda_amd
+    from trlda_amd.models import CumulativeLDA
+    f = golden("f10_cumulative")
+    K, V = int(f["K"]), int(f["V"])
+    for case in range(int(f["num_cases"])):
+        kw = _kwargs(f["c%d_kwargs" % case])
+        trlda_amd.seed(5000 + case)
+        m = CumulativeLDA(num_words=V, num_topics=K, alpha=.15, eta=.3)
+        assert (m.lambdas == .3).all()
+        for i in range(3):
+            args = dict(max_epochs=2, max_iter_inference=40)
+            args.update(kw)
+            assert m.update_parameters(csr(f, str(i)), **args) == 1.
+            assert relerr(m.lambdas, f["c%d_lambda%d" % (case, i + 1)]) < 1e-7, (case, i, kw)
+            assert relerr(m.alpha.ravel(), f["c%d_alpha%d" % (case, i + 1)]) < 1e-7, (case, i, kw)
+        assert m.update_parameters([]) == 1.
+        m2 = pickle.loads(pickle.dumps(m))
+        assert np.array_equal(m2.lambdas, m.lambdas)
+
+
 def test_reference_readme_example(hip, tmp_path):
     """README.md:36-59 of the reference, verbatim but for the package name and sizes."""
     from trlda_amd.models import OnlineLDA

@@ -70,6 +70,8 @@ _SIGNATURES = {
                                             vp]),
     "trlda_model_batch_update": (C.c_int, [vp, vp, C.c_double, C.c_int, C.c_int, C.c_int,
                                            C.c_double, vp]),
+    "trlda_model_cumulative_update": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double,
+                                                vp]),
     "trlda_debug_digamma": (C.c_int, [C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "trlda_model_set_timing": (C.c_int, [vp, C.c_int]),
     "trlda_model_get_timing": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double),

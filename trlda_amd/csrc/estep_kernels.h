@@ -1288,6 +1288,18 @@ __global__ __launch_bounds__(T) void blend_kernel(size_t total, double rho, doub
     }
 }
 
+// lambda = lambda' + sstats                                     cumulativelda.cpp:70
+template <int T>
+__global__ __launch_bounds__(T) void accumulate_kernel(size_t total,
+                                                       const double *__restrict__ lambda_prime,
+                                                       const double *__restrict__ sstats,
+                                                       double *__restrict__ lambda)
+{
+    const size_t stride = (size_t)gridDim.x * T;
+    for (size_t i = (size_t)blockIdx.x * T + threadIdx.x; i < total; i += stride)
+        lambda[i] = lambda_prime[i] + sstats[i];
+}
+
 // wordcounts[w] += cnt (integers in fp64: exact, order-free)   onlinelda.cpp:79-82
 template <int T>
 __global__ __launch_bounds__(T) void wordcount_kernel(int64_t nnz, const int32_t *__restrict__ ids,

@@ -1166,6 +1166,58 @@ int trlda_model_batch_update(trlda_model *m, const trlda_batch *b, double eta, i
     return TRLDA_OK;
 }
 
+int trlda_model_cumulative_update(trlda_model *m, const trlda_batch *b, int max_epochs,
+                                  int max_iter_inference, int update_lambda, double threshold,
+                                  double *gamma_out)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!b)
+        return fail(TRLDA_ERR_ARG, "NULL batch");
+    if (b->B == 0)                                           // cumulativelda.cpp:50-52
+        return TRLDA_OK;
+    rc = ensure_update_workspace(m, b->B);
+    if (rc)
+        return rc;
+    const int K = m->K, B = b->B;
+    const size_t KV = (size_t)K * m->V;
+    const size_t gbytes = (size_t)K * B * sizeof(double);
+    // lambdaPrime = mLambda; mLambda = sampleGamma(K, V, 100) / 100   cumulativelda.cpp:57-60
+    HIP_TRY(hipMemcpyAsync(m->lambda_prime, m->lambda, KV * sizeof(double),
+                           hipMemcpyDeviceToDevice, m->stream));
+    {
+        std::vector<double> lam0(KV);
+        trlda_sample_gamma_init(K, m->V, lam0.data());
+        HIP_TRY(hipMemcpyAsync(m->lambda, lam0.data(), KV * sizeof(double), hipMemcpyHostToDevice,
+                               m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));
+    }
+    std::vector<double> gamma0((size_t)K * B);
+    bool ran = false;
+    if (update_lambda) {
+        for (int epoch = 0; epoch < max_epochs; ++epoch) {    // cumulativelda.cpp:62-71
+            trlda_sample_gamma_init(K, B, gamma0.data());
+            HIP_TRY(hipMemcpyAsync(m->gamma, gamma0.data(), gbytes, hipMemcpyHostToDevice,
+                                   m->stream));
+            HIP_TRY(hipStreamSynchronize(m->stream));
+            rc = estep_device(m, b, m->gamma, m->sstats, max_iter_inference, threshold, nullptr);
+            if (rc)
+                return rc;
+            size_t blocks = (KV + kDenseThreads - 1) / kDenseThreads;
+            int G = (int)std::min<size_t>(blocks, 256 * 8);
+            hipLaunchKernelGGL(trlda::accumulate_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads),
+                               0, m->stream, KV, m->lambda_prime, m->sstats, m->lambda);
+            HIP_TRY(hipGetLastError());
+            ran = true;
+        }
+    }
+    if (gamma_out && ran)
+        HIP_TRY(hipMemcpyAsync(gamma_out, m->gamma, gbytes, hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return TRLDA_OK;
+}
+
 // ---- one-shot host-pointer entry points ---------------------------------------
 
 int trlda_estep(int K, int V, int B, const int32_t *indptr, const int32_t *ids,

@@ -16,7 +16,7 @@ import numpy as np
 from .. import _ffi
 from ..documents import CSRDocuments, DeviceBatch, as_csr
 
-__all__ = ["Distribution", "LDA", "OnlineLDA", "BatchLDA"]
+__all__ = ["Distribution", "LDA", "OnlineLDA", "BatchLDA", "CumulativeLDA"]
 
 
 def _default_device():
@@ -377,6 +377,49 @@ class OnlineLDA(LDA):
         self.update_count = count
 
 
+def _lngamma(x):
+    """elementwise log Gamma (utils.cpp:75-91 -> libm lgamma)."""
+    import math
+    arr = np.asarray(x, dtype=np.float64)
+    return np.array([math.lgamma(v) for v in arr.ravel()]).reshape(arr.shape)
+
+
+def _alpha_line_search(alpha, psi_gamma_diff, num_docs, max_iter_alpha, min_alpha, threshold):
+    """Newton / natural-gradient steps on alpha with a step-halving line search on the lower
+    bound: batchlda.cpp:81-141 == cumulativelda.cpp:90-150."""
+    from .. import _special
+    L = num_docs * (_lngamma(alpha.sum()) - _lngamma(alpha).sum()) + \
+        (psi_gamma_diff * (alpha - 1.)).sum()
+    Lprime = L
+    for _ in range(int(max_iter_alpha)):
+        g = psi_gamma_diff - num_docs * (_special.digamma(alpha) - _special.digamma(alpha.sum()))
+        h = -float(num_docs) * _special.trigamma(alpha)
+        z = num_docs * _special.trigamma(alpha.sum())
+        c = (g / h).sum() / (1. / z + (1. / h).sum())
+        rho = .2
+        for _j in range(20):
+            cand = alpha - rho * (g - c) / h
+            if (cand < min_alpha).any():
+                rho /= 2.
+                continue
+            Lprime = num_docs * (_lngamma(cand.sum()) - _lngamma(cand).sum()) + \
+                (psi_gamma_diff * (cand - 1.)).sum()
+            if L <= Lprime:
+                alpha = cand
+                break
+            rho /= 2.
+        if Lprime - L < threshold:
+            break
+        L = Lprime
+    return alpha
+
+
+def _psi_gamma_diff(gamma):
+    """sum_d (psi(gamma_dk) - psi(sum_k gamma_dk)), batchlda.cpp:72-74."""
+    from .. import _special
+    return (_special.digamma(gamma) - _special.digamma(gamma.sum(axis=0))[None, :]).sum(axis=1)
+
+
 class BatchLDA(LDA):
     """Batch variational LDA (reference src/batchlda.cpp, batchldainterface.cpp)."""
 
@@ -387,22 +430,120 @@ class BatchLDA(LDA):
                           max_iter_eta=20, update_lambda=True, update_alpha=False,
                           update_eta=False, min_alpha=1e-6, min_eta=1e-6,
                           emp_bayes_threshold=1e-8, verbosity=0):
-        """batchldainterface.cpp:126-172 -> batchlda.cpp:43-208 (lambda path :48-61)."""
-        if update_alpha or update_eta:
-            raise NotImplementedError(
-                "update_alpha / update_eta line searches (batchlda.cpp:66-205) are host-side "
-                "scalar math outside the accelerated path (SURVEY.md 8f rank 4).")
+        """batchldainterface.cpp:126-172 -> batchlda.cpp:43-208.  The E-steps and
+        lambda = eta + sstats run on the GPU; the alpha / eta line searches
+        (batchlda.cpp:66-205) are K- and scalar-sized and run on the host."""
+        from .. import _special
         batch, owned = self._batch(docs)
         try:
-            _ffi.check(_ffi.lib().trlda_model_batch_update(
-                self._handle, batch.handle, self._eta, int(max_epochs), int(max_iter_inference),
-                int(bool(update_lambda)), 0.001, None))
+            B = len(batch)
+            if B == 0:
+                return 1.                                            # batchlda.cpp:44-46
+            L = _ffi.lib()
+            K, V = self._K, self._V
+            if not (update_alpha or update_eta):
+                _ffi.check(L.trlda_model_batch_update(
+                    self._handle, batch.handle, self._eta, int(max_epochs),
+                    int(max_iter_inference), int(bool(update_lambda)), 0.001, None))
+                return 1.
+            gamma = np.empty((K, B), dtype=np.float64, order="F")
+            for _epoch in range(int(max_epochs)):                    # batchlda.cpp:48
+                if update_lambda:
+                    _ffi.check(L.trlda_model_batch_update(
+                        self._handle, batch.handle, self._eta, 1, int(max_iter_inference), 1,
+                        0.001, gamma.ctypes.data))
+                if update_alpha:                                     # batchlda.cpp:64-142
+                    if not update_lambda:
+                        gamma, _ = self.update_variables(batch, max_iter=max_iter_inference)
+                    alpha = _alpha_line_search(self._alpha, _psi_gamma_diff(gamma), B,
+                                               max_iter_alpha, min_alpha, emp_bayes_threshold)
+                    _ffi.check(L.trlda_model_set_alpha(self._handle, np.ascontiguousarray(alpha)))
+                    self._alpha = alpha
+                if update_eta:                                       # batchlda.cpp:147-205
+                    lam = self.lambdas
+                    c = _special.digamma(lam).sum() - V * _special.digamma(lam.sum(axis=1)).sum()
+                    eta = self._eta
+
+                    def bound(e):
+                        return (e - 1) * c + K * float(_lngamma(V * e)) - K * V * float(_lngamma(e))
+                    Lb = bound(eta)
+                    Lprime = Lb
+                    for _i in range(int(max_iter_eta)):
+                        g = c - K * V * (_special.digamma(eta) - _special.digamma(V * eta))
+                        h = K * V * (_special.trigamma(V * eta) - _special.trigamma(eta))
+                        rho = .5
+                        for _j in range(20):
+                            cand = float(eta - rho * g / h)
+                            if cand < min_eta:
+                                rho /= 2.
+                                continue
+                            Lprime = bound(cand)
+                            if Lb <= Lprime:
+                                eta = cand
+                                break
+                            rho /= 2.
+                        if Lprime - Lb < emp_bayes_threshold:
+                            break
+                        Lb = Lprime
+                    self._eta = float(eta)
         finally:
             if owned:
                 batch.close()
         return 1.                                                    # batchlda.cpp:207
 
     def __reduce__(self):                                            # batchldainterface.cpp:181
+        return (self.__class__, (self._V, self._K, self.alpha, self._eta), (self.lambdas,))
+
+    def __setstate__(self, state):
+        self.lambdas = state[0]
+
+
+class CumulativeLDA(LDA):
+    """SDA-Bayes streaming LDA (reference src/cumulativelda.cpp, cumulativeldainterface.cpp).
+
+        >>> model = CumulativeLDA(num_words=7000, num_topics=100, alpha=.1, eta=.3)
+        >>> for documents in load_documents('data_train.dat', 1000):
+        ...     model.update_parameters(documents, max_epochs=100)
+
+    In contrast to OnlineLDA, each document should be processed only once.
+    """
+
+    def __init__(self, num_words, num_topics, alpha=.1, eta=.3, device=None):
+        # the base constructor draws a random lambda from the libc stream (lda.cpp:71) before
+        # CumulativeLDA overwrites it with eta (cumulativelda.cpp:30): keep the stream in step
+        self._setup(num_words, num_topics, alpha, eta, device)
+        self.lambdas = np.full((self._K, self._V), float(eta))
+        self._psi_gamma_diff = np.zeros(self._K)
+        self._num_documents = 0
+
+    def update_parameters(self, docs, max_epochs=100, max_iter_inference=100, max_iter_alpha=10,
+                          update_lambda=True, update_alpha=False, min_alpha=1e-6,
+                          emp_bayes_threshold=1e-8, inference_threshold=0.001, verbosity=0):
+        """cumulativeldainterface.cpp:115-160 -> cumulativelda.cpp:49-153."""
+        batch, owned = self._batch(docs)
+        try:
+            B = len(batch)
+            if B == 0:
+                return 1.                                            # cumulativelda.cpp:50-52
+            L = _ffi.lib()
+            _ffi.check(L.trlda_model_cumulative_update(
+                self._handle, batch.handle, int(max_epochs), int(max_iter_inference),
+                int(bool(update_lambda)), float(inference_threshold), None))
+            if update_alpha:                                         # cumulativelda.cpp:76-150
+                gamma, _ = self.update_variables(batch, max_iter=max_iter_inference,
+                                                 threshold=inference_threshold)
+                self._psi_gamma_diff = self._psi_gamma_diff + _psi_gamma_diff(gamma)
+                self._num_documents += B
+                alpha = _alpha_line_search(self._alpha, self._psi_gamma_diff, self._num_documents,
+                                           max_iter_alpha, min_alpha, emp_bayes_threshold)
+                _ffi.check(L.trlda_model_set_alpha(self._handle, np.ascontiguousarray(alpha)))
+                self._alpha = alpha
+        finally:
+            if owned:
+                batch.close()
+        return 1.
+
+    def __reduce__(self):                                            # cumulativeldainterface.cpp
         return (self.__class__, (self._V, self._K, self.alpha, self._eta), (self.lambdas,))
 
     def __setstate__(self, state):
