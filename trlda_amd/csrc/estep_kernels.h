@@ -780,10 +780,12 @@ constexpr int kRegMaxN = 192;      // 128 words in registers + a tail of up to 6
 constexpr int kRegStride = 129;    // LDS row stride of the transposition / tail buffer (odd)
 constexpr int kRegPart = 192;      // row length of the partial-sum arrays
 
-// g | alpha | e (+16 zero pad) | tw (+16 zero pad) | cnt | diffs | part[8][192] | rpart[4][128] |
-// misc[8] | buffer [128][129]: transposition scratch while the registers are filled, then
-// the rows of words 128.. of a long document
-constexpr int kRegSmallDoubles = 128 + 128 + 144 + 208 + 192 + 128 + 8 * kRegPart + 512 + 8;
+// g[2] | alpha | e[2] (+16 zero pad each) | tw (+16 zero pad) | cnt | part[8][192] | misc[8] |
+// buffer [128][129]: transposition scratch while the registers are filled, then the rows
+// of words 128.. of a long document.  g and e are double-buffered (iteration parity) so
+// that the wave forming mean|gamma - last| can read the old values while the two waves that
+// own the topics write the new ones -- no barrier in between.
+constexpr int kRegSmallDoubles = 2 * 128 + 128 + 2 * 144 + 208 + 192 + 8 * kRegPart + 8;
 constexpr size_t kRegLdsBytes = (size_t)(kRegSmallDoubles + 128 * kRegStride) * sizeof(double);
 
 // Sum over the 64 lanes of a wave in 6 DPP steps (row shifts, then row broadcasts); the total
@@ -838,15 +840,13 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
     const int32_t *__restrict__ ids = a.ids + p0;
     const int32_t *__restrict__ cnts = a.cnts + p0;
 
-    double *g = lds;
-    double *alpha_l = g + 128;
-    double *e = alpha_l + 128;        // 144
-    double *tw = e + 144;             // 208
+    double *gbuf = lds;               // 2 x 128
+    double *alpha_l = gbuf + 256;     // 128
+    double *ebuf = alpha_l + 128;     // 2 x 144
+    double *tw = ebuf + 288;          // 208
     double *cntd = tw + 208;          // 192
-    double *diffs = cntd + 192;       // 128
-    double *part = diffs + 128;       // 8 x 192
-    double *rpart = part + 8 * kRegPart;   // 4 x 128
-    double *misc = rpart + 512;       // 8
+    double *part = cntd + 192;        // 8 x 192
+    double *misc = part + 8 * kRegPart;    // 8
     double *tbuf = misc + 8;          // 128 x 129
 
     [[maybe_unused]] unsigned long long stamp_last = 0;
@@ -886,11 +886,12 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
         double ev = 0.0;
         if (k < K) {
             const double gk = gamma0_d[k];
-            g[k] = gk;
+            gbuf[k] = gk;
             alpha_l[k] = a.alpha[k];
             ev = exp_digamma(gk);
         }
-        e[k] = ev;                                   // zero beyond K
+        ebuf[k] = ev;                                // zero beyond K, in both buffers
+        ebuf[144 + k] = 0.0;
     }
     for (int j = tid; j < 208; j += T) {
         tw[j] = 0.0;
@@ -945,7 +946,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
     TRLDA_STAMP(1);
 
     // phinorm_j = sum_k e_k beta[j][k] ; tw_j = cnt_j / phinorm_j     lda.cpp:183 / :199
-    auto product_E = [&]() {
+    auto product_E = [&](const double *e) {
         // k0 is even and e is 16-byte aligned: one ds_read_b128 broadcasts two weights.  All
         // eight reads are issued before the first fma and nothing is branched over: weights
         // past K are zero in LDS and the matching registers are zero.  Eight chains.
@@ -991,7 +992,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
         __syncthreads();
     };
 
-    product_E();
+    product_E(ebuf);
     TRLDA_STAMP(2);
 
     const int k_psi = (wid & 1) * 64 + lane;         // topic of this lane in the psi stage
@@ -1044,28 +1045,26 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
         // Two waves (topics 0..63, 64..127).  tools/probes/probe6: the whole log-free
         // exp(psi) chain is ~670 cycles for one thread, no more than its slowest piece plus
         // the exchange when it is spread over four waves -- so it is not split.
-        double gnew = 0.0;
+        const double *g_old = gbuf + (it & 1) * 128, *e_old = ebuf + (it & 1) * 144;
+        double *g_new = gbuf + ((it + 1) & 1) * 128, *e_new = ebuf + ((it + 1) & 1) * 144;
         if (wid < 2) {
             const int kk = psi_on ? k_psi : 0;
-            const double ek = e[kk], ak = alpha_l[kk], gold = g[kk];
+            const double ek = e_old[kk], ak = alpha_l[kk];
             const double acc = sum8_strided<kRegPart>(part + kk);
-            gnew = acc * ek + ak;
-            if (psi_on)
-                diffs[k_psi] = fabs(gold - gnew);
-        }
-        // |gamma - last| is known before the long exp(psi) chain starts: publish it now so
-        // that an otherwise idle wave forms the mean (DPP reduction + one division, ~600
-        // cycles) underneath that chain instead of after it
-        __syncthreads();
-        TRLDA_STAMP(0);
-        if (wid < 2) {
-            const double enew = exp_digamma(psi_on ? gnew : 1.5);
+            const double gnew = acc * ek + ak;
+            const double enew = exp_digamma(gnew);
             if (psi_on) {
-                g[k_psi] = gnew;
-                e[k_psi] = enew;
+                g_new[k_psi] = gnew;
+                e_new[k_psi] = enew;
             }
-        } else if (wid == W - 1) {                   // mean |gamma - last|   lda.cpp:202
-            const double v = (k_lo ? diffs[lane] : 0.0) + (k_hi ? diffs[lane + 64] : 0.0);
+        } else if (wid == W - 1) {
+            // mean |gamma - last| (lda.cpp:202): this otherwise idle wave recomputes gamma for
+            // two topics per lane from the same partial sums (bitwise the same value as the
+            // owners'), reduces with DPP and divides -- all underneath the exp(psi) chain
+            const int ka = k_lo ? lane : 0, kb2 = k_hi ? lane + 64 : 0;
+            const double ga = sum8_strided<kRegPart>(part + ka) * e_old[ka] + alpha_l[ka];
+            const double gb = sum8_strided<kRegPart>(part + kb2) * e_old[kb2] + alpha_l[kb2];
+            const double v = (k_lo ? fabs(g_old[ka] - ga) : 0.0) + (k_hi ? fabs(g_old[kb2] - gb) : 0.0);
             const double mean = wave_sum_dpp(v) / (double)K;
             if (lane == 0)
                 misc[0] = mean;
@@ -1075,12 +1074,13 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
         TRLDA_STAMP(4);
         const double mean_change = misc[0];          // read now: off the loop-end critical path
 
-        product_E();                                 // ends with a barrier
+        product_E(e_new);                            // ends with a barrier
         TRLDA_STAMP(5);
         ++it;
         if (mean_change < a.threshold)               // lda.cpp:202-203
             break;
     }
+    const double *g = gbuf + (it & 1) * 128, *e = ebuf + (it & 1) * 144;
 
     // results
     for (int k = tid; k < K; k += T) {
