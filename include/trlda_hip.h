@@ -140,6 +140,15 @@ int trlda_model_set_sstats_mode(trlda_model *model, int mode);
 int trlda_model_set_dense_preamble(trlda_model *model, int dense);
 /* threads per document workgroup in the E-step kernel: 0 = auto, else 64..1024 (x64) */
 int trlda_model_set_doc_threads(trlda_model *model, int threads);
+/* which document kernels the E-step may use (all give the same results; tests and tuning):
+ * AUTO = dual-orientation register kernel for K <= 128 and at most 192 words, else the
+ * single-orientation register kernel up to K = 512, else the LDS / streaming kernels;
+ * LDS = never the single-orientation kernel; WIDE = the single-orientation kernel for
+ * every document (K <= 512). */
+#define TRLDA_DOCS_AUTO 0
+#define TRLDA_DOCS_LDS 1
+#define TRLDA_DOCS_WIDE 2
+int trlda_model_set_doc_kernel(trlda_model *model, int kind);
 int trlda_model_synchronize(trlda_model *model);
 
 int trlda_model_set_lambda(trlda_model *model, const double *host_lambda /* K x V */);
@@ -240,6 +249,10 @@ int trlda_model_cumulative_update(trlda_model *model, const trlda_batch *batch, 
  * from the N independent pieces the document kernels distribute over wavefronts (the form
  * the hot path uses: lda.cpp:173-174, :197 only ever need exp(psi)).  Lets the parity tests
  * check the special functions against the reference's table directly. */
+/* test hook: the transposing wave reductions of csrc/estep_wide.h on a 64 x 16 table
+ * (row = lane); out16 / out4 / out2 [64] = what each lane receives from the 16-, 4- and
+ * 2-value folds of its row's leading values */
+int trlda_debug_fold16(int device, const double *in, double *out16, double *out4, double *out2);
 int trlda_debug_digamma(int device, int n, const double *x, double *whole, double *pieces2,
                         double *pieces4, double *pieces8);
 

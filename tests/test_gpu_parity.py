@@ -452,6 +452,59 @@ def test_document_length_boundaries(hip, oracle, sampler, K):
         assert np.array_equal(iters, ito)
 
 
+def test_transposing_wave_reductions(hip):
+    """The wave-level building block of the single-orientation document kernel
+    (csrc/estep_wide.h): 16 (4, 2) sums over the 64 lanes in one butterfly, the result for
+    value i delivered to the lanes whose bits 5,4,3,2 spell i."""
+    rng = np.random.RandomState(7)
+    x = rng.standard_normal((64, 16))
+    outs = [np.zeros(64) for _ in range(3)]
+    rc = hip.trlda_debug_fold16(0, np.ascontiguousarray(x).ctypes.data, *[o.ctypes.data for o in outs])
+    assert rc == 0, hip.trlda_last_error()
+    lane = np.arange(64)
+    idx16 = ((lane >> 5) & 1) | ((lane >> 3) & 2) | ((lane >> 1) & 4) | ((lane << 1) & 8)
+    idx4 = ((lane >> 5) & 1) | ((lane >> 3) & 2)
+    idx2 = (lane >> 5) & 1
+    tot = x.sum(axis=0)
+    for got, idx in zip(outs, (idx16, idx4, idx2)):
+        assert np.allclose(got, tot[idx], rtol=0, atol=1e-13), (got, tot[idx])
+
+
+@pytest.mark.parametrize("K", [5, 64, 100, 129, 200, 257, 320, 333, 400, 500, 512])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_single_orientation_kernel(hip, oracle, sampler, K, mode):
+    """estep_docs_wide_kernel forced for every document: every slot count (ceil(K/64) = 1..8),
+    documents that end inside the registers, inside the LDS rows and in the streamed part,
+    the empty document, zero counts, max_iter 0 / 1 / until convergence."""
+    from trlda_amd.documents import CSRDocuments
+    V = 2500
+    rng = np.random.RandomState(1000 + K)
+    lam = seeded_lambda(sampler, 41, K, V)
+    lens = [0, 1, 3, 7, 8, 9, 31, 64, 79, 80, 81, 100, 127, 160, 161, 200, 255, 256, 257, 300,
+            420, 700, 1200]
+    docs, ip = [], [0]
+    for n in lens:
+        ids = rng.permutation(V)[:n]
+        cnts = rng.randint(4, size=n)            # zero counts are legal (onlinelda_test.py:57)
+        docs.append((ids, cnts))
+        ip.append(ip[-1] + n)
+    ids = np.concatenate([d[0] for d in docs]).astype(np.int32)
+    cnts = np.concatenate([d[1] for d in docs]).astype(np.int32)
+    ip = np.array(ip, np.int32)
+    g0 = seeded_gamma(sampler, 42, K, len(lens))
+    m = make_model(K, V, lam)
+    hip.trlda_model_set_sstats_mode(m._handle, mode)
+    assert hip.trlda_model_set_doc_kernel(m._handle, 2) == 0
+    for (it, thr) in [(0, 0.), (1, 0.), (30, 1e-3)]:
+        g, s, iters = m.update_variables(CSRDocuments(ip, ids, cnts), latents=g0, max_iter=it,
+                                         threshold=thr, return_iterations=True)
+        go, so, ito = oracle.estep(lam, .1, ip, ids, cnts, g0, it, thr)
+        per_doc = np.max(np.abs(g - go) / np.abs(go), axis=0)
+        assert per_doc.max() < TIGHT_RTOL, list(zip(lens, per_doc))
+        check_sstats(s, so, rtol=TIGHT_RTOL if mode == 0 else 1e-8)
+        assert np.array_equal(iters, ito)
+
+
 def test_converged_documents_stop_early(hip, oracle, sampler):
     """The data-dependent break (lda.cpp:202-203): iteration counts below max_iter, equal to
     the oracle's, per document."""

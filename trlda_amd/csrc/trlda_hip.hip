@@ -20,6 +20,7 @@
 
 #include "../../include/trlda_hip.h"
 #include "estep_kernels.h"
+#include "estep_wide.h"
 
 namespace {
 
@@ -98,6 +99,7 @@ struct trlda_model {
     hipStream_t stream = nullptr;
     int sstats_mode = TRLDA_SSTATS_SEGMENTED;
     int doc_threads = 0;
+    int doc_kernel = 0;    // TRLDA_DOCS_*
     bool dense_preamble = false;   // true: exp E[log beta] for all V words, as the reference
     double *lambda = nullptr, *alpha = nullptr;
     double *eeb = nullptr, *psi_sum = nullptr, *partial = nullptr;
@@ -305,7 +307,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
         //   [n_stream, B - n_reg)    slice fits in LDS: lean kernel (compile-time row stride)
         //   [B - n_reg, B)           K <= 128 and at most 128 words: slice in registers
         int n_reg = 0;
-        if (m->doc_threads == 0 && K <= kRegMaxK)
+        if (m->doc_threads == 0 && K <= kRegMaxK && m->doc_kernel != TRLDA_DOCS_WIDE)
             while (n_reg < B && b->sorted_len[(size_t)(B - 1 - n_reg)] <= kRegMaxN)
                 ++n_reg;
 
@@ -316,7 +318,10 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
         for (int cand : kStrides)
             if (!KPl && cand >= K)
                 KPl = cand;
-        const bool lean = m->doc_threads == 0 && KPl != 0 && K <= 256 && KB <= WL;
+        // 128 < K <= 512, or K <= 128 with more than 192 words: registers in one orientation
+        // (estep_wide.h); it takes every document the register tier does not
+        const bool wide = m->doc_threads == 0 && K <= kWideMaxK && m->doc_kernel != TRLDA_DOCS_LDS;
+        const bool lean = !wide && m->doc_threads == 0 && KPl != 0 && K <= 256 && KB <= WL;
         int n_cap = 0;
         if (lean) {
             size_t fixed = lean_lds_doubles(TL, KPl, K, 0) * sizeof(double);
@@ -331,7 +336,50 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
         }
         const int n_lean = B - n_reg - n_stream;
 
-        if (n_stream > 0) {
+        if (wide && B - n_reg > 0) {
+            const int n_wide = B - n_reg;
+            const int KS = (K + kWave - 1) / kWave;
+            int jw = 0;
+            switch (KS) {
+            case 1: jw = wide_cfg<1>::JW; break;
+            case 2: jw = wide_cfg<2>::JW; break;
+            case 3: jw = wide_cfg<3>::JW; break;
+            case 4: jw = wide_cfg<4>::JW; break;
+            case 5: jw = wide_cfg<5>::JW; break;
+            case 6: jw = wide_cfg<6>::JW; break;
+            case 7: jw = wide_cfg<7>::JW; break;
+            default: jw = wide_cfg<8>::JW; break;
+            }
+            // LDS rows for the words past the registers, as many as the longest document needs
+            const size_t fixed = wide_lds_doubles(KS, 0) * sizeof(double);
+            const int fit = (int)(((size_t)kLdsBytes - fixed) / ((size_t)(64 * KS + 1) * sizeof(double)));
+            const int tail_cap = std::max(0, std::min(fit, b->max_n - kWideWaves * jw));
+            const size_t lds_bytes = wide_lds_doubles(KS, tail_cap) * sizeof(double);
+            a.n_cap = 0;
+            a.Kp = 64 * KS;
+            a.order = b->order;
+#define TRLDA_LAUNCH_WIDE(KSV)                                                             \
+    do {                                                                                   \
+        auto kern = estep_docs_wide_kernel<KSV>;                                           \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                  \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,            \
+                                    (int)lds_bytes));                                      \
+        hipLaunchKernelGGL(kern, dim3(n_wide), dim3(kWideThreads), lds_bytes, m->stream, a, \
+                           tail_cap);                                                      \
+    } while (0)
+            switch (KS) {
+            case 1: TRLDA_LAUNCH_WIDE(1); break;
+            case 2: TRLDA_LAUNCH_WIDE(2); break;
+            case 3: TRLDA_LAUNCH_WIDE(3); break;
+            case 4: TRLDA_LAUNCH_WIDE(4); break;
+            case 5: TRLDA_LAUNCH_WIDE(5); break;
+            case 6: TRLDA_LAUNCH_WIDE(6); break;
+            case 7: TRLDA_LAUNCH_WIDE(7); break;
+            default: TRLDA_LAUNCH_WIDE(8); break;
+            }
+#undef TRLDA_LAUNCH_WIDE
+            HIP_TRY(hipGetLastError());
+        } else if (n_stream > 0) {
             int T = m->doc_threads > 0 ? m->doc_threads : 256;
             size_t fixed = docs_lds_bytes(K, Kp, 0, T);
             int n_fit = fixed >= (size_t)kLdsBytes
@@ -357,7 +405,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
             if (rc)
                 return rc;
         }
-        if (n_lean > 0) {
+        if (!wide && n_lean > 0) {
             a.n_cap = n_cap;
             a.Kp = KPl;
             a.order = b->order + n_stream;
@@ -867,6 +915,16 @@ int trlda_model_set_dense_preamble(trlda_model *m, int dense)
     return TRLDA_OK;
 }
 
+int trlda_model_set_doc_kernel(trlda_model *m, int kind)
+{
+    if (!m)
+        return fail(TRLDA_ERR_ARG, "null model");
+    if (kind != TRLDA_DOCS_AUTO && kind != TRLDA_DOCS_LDS && kind != TRLDA_DOCS_WIDE)
+        return fail(TRLDA_ERR_ARG, "doc_kernel must be TRLDA_DOCS_AUTO, _LDS or _WIDE");
+    m->doc_kernel = kind;
+    return TRLDA_OK;
+}
+
 int trlda_model_set_doc_threads(trlda_model *m, int threads)
 {
     if (!m)
@@ -1319,6 +1377,29 @@ int trlda_debug_digamma(int device, int n, const double *x, double *whole, doubl
     HIP_TRY(hipMemcpy(pieces2, d + 2 * (size_t)n, bytes, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(pieces4, d + 3 * (size_t)n, bytes, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(pieces8, d + 4 * (size_t)n, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipFree(d));
+    return TRLDA_OK;
+}
+
+int trlda_debug_fold16(int device, const double *in, double *out16, double *out4, double *out2)
+{
+    int rc = use_device(device);
+    if (rc)
+        return rc;
+    if (!in || !out16 || !out4 || !out2)
+        return fail(TRLDA_ERR_ARG, "bad fold table arguments");
+    double *d = nullptr;
+    rc = dev_alloc(&d, 64 * 16 + 3 * 64);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpy(d, in, 64 * 16 * sizeof(double), hipMemcpyHostToDevice));
+    double *o = d + 64 * 16;
+    hipLaunchKernelGGL(trlda::debug_fold16_kernel, dim3(1), dim3(64), 0, nullptr, d, o, o + 64,
+                       o + 128);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out16, o, 64 * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out4, o + 64, 64 * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out2, o + 128, 64 * sizeof(double), hipMemcpyDeviceToHost));
     HIP_TRY(hipFree(d));
     return TRLDA_OK;
 }
