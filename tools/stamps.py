@@ -10,14 +10,18 @@ from trlda_amd.documents import CSRDocuments
 from trlda_amd.utils.synthetic import make_corpus
 L = _ffi.lib()
 L.trlda_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
-K, V, B = 100, 7000, 200
+K, V, B = (int(os.environ.get(k, d)) for k, d in (("STAMPS_K", "100"), ("STAMPS_V", "7000"), ("STAMPS_B", "200")))
+WIDE = int(os.environ.get("STAMPS_WIDE", "0")) or K > 128
 indptr, ids, cnts = make_corpus(B, V, seed=20150707, mean_unique=int(os.environ.get("STAMPS_MEAN", "95")))
 print("max doc length", np.diff(indptr).max())
 L.trlda_seed(1)
 m = OnlineLDA(V, K, 1000000)
 g0 = np.empty((K, B), order="F"); L.trlda_sample_gamma_init(K, B, g0)
 batch = m.upload(CSRDocuments(indptr, ids, cnts))
-names = ["psi: gnew + diffs + barrier", "stage beta", "product E (first)", "product B", "psi: barrier", "product E", "outputs", "psi: exp(psi) | reduce"]
+if WIDE:
+    L.trlda_model_set_doc_kernel.argtypes = [C.c_void_p, C.c_int]
+    L.trlda_model_set_doc_kernel(m._handle, 2)
+names = ["stage beta", "E: dots + folds", "E/B: words past the unrolled groups", "B: axpy + part", "barrier 1", "psi", "barrier 2", "outputs"] if WIDE else ["psi: gnew + diffs + barrier", "stage beta", "product E (first)", "product B", "psi: barrier", "product E", "outputs", "psi: exp(psi) | reduce"]
 for T in (0,):
     L.trlda_model_set_doc_threads(m._handle, T)
     m.update_variables(batch, latents=g0, max_iter=20, threshold=0.0)
@@ -28,6 +32,7 @@ for T in (0,):
     mean = buf.astype(np.float64).mean(axis=0)
     print("T=%d  total %.0f cycles/doc" % (T, mean.sum()))
     for i, nme in enumerate(names[:8]):
-        per = mean[i] / 20 if i in (0, 3, 4, 5, 7) else mean[i]
-        print("   %-20s %9.0f cycles (%4.1f%%)%s" % (nme, mean[i], 100 * mean[i] / mean.sum(),
-              "  = %.0f / iteration" % per if i in (0, 3, 4, 5, 7) else ""))
+        it_segs = (1, 2, 3, 4, 5, 6) if WIDE else (0, 3, 4, 5, 7)
+        per = mean[i] / 20 if i in it_segs else mean[i]
+        print("   %-38s %9.0f cycles (%4.1f%%)%s" % (nme, mean[i], 100 * mean[i] / mean.sum(),
+              "  = %.0f / iteration" % per if i in it_segs else ""))

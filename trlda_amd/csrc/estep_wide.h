@@ -30,19 +30,26 @@ constexpr int kWideMaxK = 512;
 
 template <int KS>
 struct wide_cfg {
-    // words per wave held in registers
-    static constexpr int JW = KS <= 2 ? 32 : KS == 3 ? 24 : KS == 4 ? 20 : KS == 5 ? 16
-                              : KS == 6 ? 12 : KS == 7 ? 11 : 10;
-    static constexpr int NG = (JW + 15) / 16;        // groups of 16 words (one fold each)
+    // words per wave held in registers (JW * KS doubles per lane: about half of the register
+    // file; the rest is needed by exp(psi) and the in-flight rows of the tail).  Chosen with
+    // tools/jw_sweep.sh: more slots start to spill and lose.
+#ifdef TRLDA_WIDE_JW
+    static constexpr int JW = TRLDA_WIDE_JW;
+#else
+    static constexpr int JW = KS == 1 ? 32 : KS == 2 ? 28 : KS == 3 ? 18 : KS == 4 ? 12
+                              : KS == 5 ? 12 : KS == 6 ? 10 : 8;
+#endif
+    static constexpr bool LEAN_PSI = KS > 1;
+    static constexpr int NH = (JW + 7) / 8;          // groups of 8 register slots (one fold each)
     static constexpr int NSET = KS >= 8 ? 1 : KS >= 4 ? 2 : KS >= 2 ? 4 : 8;   // >= 8 fma chains
-    static constexpr int TCH = KS <= 4 ? 4 : 2;      // words of a tail chunk
+    static constexpr int TCH = KS <= 4 ? 4 : 2;      // words of a tail chunk (TCH * KS <= 16)
     static constexpr int KP = 64 * KS;               // padded topic count
 };
 
-// LDS carve (doubles): part[8][KP] | ebuf[2][KP] | misc[2][8] | cnt_tail[tail] | rows[tail][KP]
-__host__ __device__ constexpr size_t wide_lds_doubles(int KS, int tail_words)
+// LDS carve (doubles): part[8][KP] | ebuf[2][KP] | misc[2][8] | rows[lds_rows][KP]
+__host__ __device__ constexpr size_t wide_lds_doubles(int KS, int lds_rows)
 {
-    return (size_t)(kWideWaves + 2) * 64 * KS + 16 + (size_t)tail_words * (64 * KS + 1);
+    return (size_t)(kWideWaves + 2) * 64 * KS + 16 + (size_t)lds_rows * (64 * KS);
 }
 
 // ---------------------------------------------------------------------------
@@ -134,6 +141,37 @@ __host__ __device__ constexpr int fold16_lane(int idx)
     return ((idx & 1) << 5) | ((idx & 2) << 3) | ((idx & 4) << 1) | ((idx & 8) >> 1);
 }
 
+// Eight values: lane l receives the total of value bit5(l) + 2 bit4(l) + 4 bit3(l).
+template <int NV>
+__device__ __forceinline__ double fold8(const double (&v)[8])
+{
+    double a[4], b[2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+        a[p] = (2 * p < NV) ? fold<32>(v[2 * p], v[2 * p + 1]) : 0.0;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+        b[p] = (4 * p < NV) ? fold<16>(a[2 * p], a[2 * p + 1]) : 0.0;
+    const double c = fold<8>(b[0], b[1]);
+    return quad_sum(fold<4>(c, c));
+}
+__device__ __forceinline__ int fold8_index(int lane)
+{
+    return ((lane >> 5) & 1) | ((lane >> 3) & 2) | ((lane >> 1) & 4);
+}
+__host__ __device__ constexpr int fold8_lane(int idx)
+{
+    return ((idx & 1) << 5) | ((idx & 2) << 3) | ((idx & 4) << 1);
+}
+// all 64 lanes receive the total
+__device__ __forceinline__ double wave_sum_all(double v)
+{
+    v = fold<32>(v, v);
+    v = fold<16>(v, v);
+    v = fold<8>(v, v);
+    return quad_sum(fold<4>(v, v));
+}
+
 // The same for a chunk of 4 (or 2) values: index = bit5 + 2 bit4 (or bit5), all-reduce below.
 template <int N>
 __device__ __forceinline__ double fold_chunk(const double (&v)[N])
@@ -185,11 +223,16 @@ __global__ void debug_fold16_kernel(const double *in, double *out, double *out4,
 }
 
 // ---------------------------------------------------------------------------
+// The first 8 JW words of the document live in registers: word j belongs to wave j % 8, slot
+// j / 8.  The words after them ("tail") are dealt to the waves in chunks of TCH consecutive
+// words; their rows sit in LDS (the first lds_rows of them) or are streamed from eeb (L2) in
+// every iteration -- one read of a row serves its phinorm and its update of acc.
+// ---------------------------------------------------------------------------
 template <int KS>
-__global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernelArgs a, int tail_cap)
+__global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernelArgs a, int lds_rows)
 {
     using cfg = wide_cfg<KS>;
-    constexpr int JW = cfg::JW, NG = cfg::NG, NSET = cfg::NSET, TCH = cfg::TCH, KP = cfg::KP;
+    constexpr int JW = cfg::JW, NH = cfg::NH, NSET = cfg::NSET, TCH = cfg::TCH, KP = cfg::KP;
     constexpr int W = kWideWaves;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
@@ -206,21 +249,26 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
     double *part = lds;                              // 8 x KP
     double *ebuf = part + W * KP;                    // 2 x KP
     double *misc = ebuf + 2 * KP;                    // 2 x 8
-    double *cnt_tail = misc + 16;                    // tail_cap
-    double *rows = cnt_tail + tail_cap;              // tail_cap x KP
+    double *rows = misc + 16;                        // lds_rows x KP
 
-    const int n_reg = min(n, W * JW);                // words in registers: j = i * 8 + wid
-    const int n_lds = min(n - n_reg, tail_cap);      // words in LDS rows
-    // register words of a wave are used in chunks of four: bound (wave-uniform, block-uniform)
+    [[maybe_unused]] unsigned long long stamp_last = 0;
+    TRLDA_STAMP_DECL;
+#ifdef TRLDA_STAMPS
+    stamp_last = __builtin_amdgcn_s_memtime();
+#endif
+
+    const int n_reg = min(n, W * JW);                // words in registers
+    const int n_lds = min(n - n_reg, lds_rows);      // tail words with their row in LDS
+    // register slots are used in chunks of four: bound (block-uniform)
     const int JE = min(JW, (((n_reg + W - 1) / W) + 3) & ~3);
 
-    bool kv[KS];                                     // topic l + 64 s exists
+    bool kv[KS];                                     // topic lane + 64 s exists
 #pragma unroll
     for (int s = 0; s < KS; ++s)
         kv[s] = lane + 64 * s < K;
 
     // ---- the slice (lda.cpp:179-181): JW x KS coalesced loads per lane, all independent.
-    // Word ids: one vector load (lane i -> word i of this wave), handed out with v_readlane.
+    // Word ids: one vector load (lane i -> slot i of this wave), handed out with v_readlane.
     double beta[JW][KS];
     {
         const int jl = (lane < JW ? lane : 0) * W + wid;
@@ -233,18 +281,18 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
                 beta[i][s] = rowp[min(lane + 64 * s, K - 1)];
         }
     }
-    // counts of the words whose phinorm this lane will hold after the fold
-    double cntv[NG];
-    int jv[NG];
+    // counts of the words whose phinorm this lane holds after the fold of group g
+    double cntv[NH];
+    int jv[NH];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int i = 16 * g + fold16_index(lane);
+    for (int g = 0; g < NH; ++g) {
+        const int i = 8 * g + fold8_index(lane);
         jv[g] = i * W + wid;
-        const bool ok = i < JW && jv[g] < n_reg;
         cntv[g] = 0.0;
-        if (ok)
+        if (i < JW && jv[g] < n_reg)
             cntv[g] = (double)cnts[jv[g]];
-        jv[g] = ok ? jv[g] : -1;
+        else
+            jv[g] = -1;
     }
     // gamma / alpha / exp(psi(gamma)) of topic tid                       lda.cpp:174
     const bool k_on = tid < K;
@@ -253,11 +301,12 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
         if (k_on) {
             gk = a.gamma_in[(size_t)d * K + tid];
             ak = a.alpha[tid];
-            ek = exp_digamma(gk);
         }
+        const double e0 = cfg::LEAN_PSI ? exp_digamma_minus_lean(gk, 0.0) : exp_digamma(gk);
+        ek = k_on ? e0 : 0.0;
         ebuf[tid] = ek;                              // zero beyond K
     }
-    // tail rows in LDS, zero beyond K
+    // rows of the first tail words, zero beyond K
     for (int t = wid; t < n_lds; t += W) {
         const double *rowp = a.eeb + (size_t)ids[n_reg + t] * K;
 #pragma unroll
@@ -265,8 +314,6 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
             const double v = rowp[min(lane + 64 * s, K - 1)];
             rows[(size_t)t * KP + lane + 64 * s] = kv[s] ? v : 0.0;
         }
-        if (lane == 0)
-            cnt_tail[t] = (double)cnts[n_reg + t];
     }
 #pragma unroll
     for (int i = 0; i < JW; ++i) {
@@ -276,10 +323,67 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
             beta[i][s] = (row && kv[s]) ? beta[i][s] : 0.0;
     }
     __syncthreads();
+    TRLDA_STAMP(0);
 
-    double twv[NG];                                  // cnt / phinorm of word jv[g]
-    double acc[NSET][KS];
     double e[KS];
+    double acc[NSET][KS];
+    // Tail words n_reg + t0 + u, u < TCH: those at or beyond `end` (n_lds for LDS rows, the
+    // document's tail length for streamed rows) contribute zero.
+    auto tail_chunk = [&](int t0, bool from_lds) {
+        double r[TCH][KS];
+        const int my_u = fold_chunk_index<TCH>(lane);
+        const int end = from_lds ? n_lds : n - n_reg;
+        double my_cnt = 0.0;
+        if (t0 + my_u < end)
+            my_cnt = (double)cnts[n_reg + t0 + my_u];
+        if (from_lds) {
+#pragma unroll
+            for (int u = 0; u < TCH; ++u) {
+                const double *rowp = rows + (size_t)min(t0 + u, n_lds - 1) * KP + lane;
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+                    r[u][s] = rowp[64 * s];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < TCH; ++u) {
+                const double *rowp = a.eeb + (size_t)ids[min(n_reg + t0 + u, n - 1)] * K;
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+                    r[u][s] = rowp[min(lane + 64 * s, K - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < TCH; ++u)
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+                    r[u][s] = kv[s] ? r[u][s] : 0.0;
+        }
+        double sv[TCH];
+#pragma unroll
+        for (int u = 0; u < TCH; ++u) {
+            double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (s & 1)
+                    d1 = fma(e[s], r[u][s], d1);
+                else
+                    d0 = fma(e[s], r[u][s], d0);
+            }
+            sv[u] = d0 + d1;
+        }
+        const double tw = my_cnt * rcp_pos<true>(fold_chunk<TCH>(sv) + 1e-100);
+        if ((lane & (TCH == 4 ? 15 : 31)) == 0 && t0 + my_u < end)    // one lane per word
+            a.tw_csr[p0 + n_reg + t0 + my_u] = tw;
+#pragma unroll
+        for (int u = 0; u < TCH; ++u) {
+            const double twu = readlane_f64(tw, fold_chunk_lane<TCH>(u));
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                acc[u % NSET][s] = fma(twu, r[u][s], acc[u % NSET][s]);
+        }
+    };
+
+    double twv[NH];                                  // cnt / phinorm of word jv[g]
     int it = 0;
     int cur = 0;                                     // ebuf / misc buffer holding the current e
     double mean_change = 0.0;
@@ -302,90 +406,37 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
 
         // ---- phinorm and cnt / phinorm of the register words           lda.cpp:183 / :199
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            double sv[16];
+        for (int g = 0; g < NH; ++g) {
+            twv[g] = 0.0;
+            if (8 * g < JE) {                        // wave-uniform: the group has words
+                double sv[8];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const bool live = 16 * g + 4 * c < JE;           // wave-uniform
+                for (int c = 0; c < 2; ++c) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    sv[4 * c + u] = 0.0;
-                if (16 * g + 4 * c < JW && live) {
+                    for (int u = 0; u < 4; ++u)
+                        sv[4 * c + u] = 0.0;
+                    const int i0 = 8 * g + 4 * c;
+                    if (i0 < JW && i0 < JE) {
 #pragma unroll
-                    for (int s = 0; s < KS; ++s)
+                        for (int s = 0; s < KS; ++s)
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int i = 16 * g + 4 * c + u;
-                            if (i < JW)
-                                sv[4 * c + u] = fma(e[s], beta[i < JW ? i : 0][s], sv[4 * c + u]);
-                        }
+                            for (int u = 0; u < 4; ++u)
+                                if (i0 + u < JW)
+                                    sv[4 * c + u] = fma(e[s], beta[i0 + u < JW ? i0 + u : 0][s],
+                                                        sv[4 * c + u]);
+                    }
                 }
+                const double tot = (8 * g + 8 <= JW) ? fold8<8>(sv) : fold8<((JW & 7) ? (JW & 7) : 8)>(sv);
+                twv[g] = cntv[g] * rcp_pos<true>(tot + 1e-100);
             }
-            const double tot = (g == NG - 1 && (JW & 15) != 0) ? fold16<(JW & 15)>(sv)
-                                                               : fold16<16>(sv);
-            twv[g] = cntv[g] * rcp_pos<true>(tot + 1e-100);
         }
-
-        // ---- words in LDS rows and streamed words: phinorm, weight and the update of acc
-        // from one read of the row
-        auto tail_chunk = [&](int t0, bool from_lds) {
-            // words j_t = n_reg + t0 + u, u < TCH (those at or beyond n contribute zero)
-            double r[TCH][KS];
-            const int my_u = fold_chunk_index<TCH>(lane);
-            double my_cnt;
-            if (from_lds) {
-#pragma unroll
-                for (int u = 0; u < TCH; ++u) {
-                    const int t = min(t0 + u, n_lds - 1);
-#pragma unroll
-                    for (int s = 0; s < KS; ++s)
-                        r[u][s] = rows[(size_t)t * KP + lane + 64 * s];
-                }
-                my_cnt = t0 + my_u < n_lds ? cnt_tail[t0 + my_u] : 0.0;
-            } else {
-#pragma unroll
-                for (int u = 0; u < TCH; ++u) {
-                    const int j = min(n_reg + t0 + u, n - 1);
-                    const double *rowp = a.eeb + (size_t)ids[j] * K;
-#pragma unroll
-                    for (int s = 0; s < KS; ++s)
-                        r[u][s] = rowp[min(lane + 64 * s, K - 1)];
-                }
-                const int j = n_reg + t0 + my_u;
-                my_cnt = j < n ? (double)cnts[j] : 0.0;
-#pragma unroll
-                for (int u = 0; u < TCH; ++u)
-#pragma unroll
-                    for (int s = 0; s < KS; ++s)
-                        r[u][s] = kv[s] ? r[u][s] : 0.0;
-            }
-            double sv[TCH];
-#pragma unroll
-            for (int u = 0; u < TCH; ++u) {
-                sv[u] = 0.0;
-#pragma unroll
-                for (int s = 0; s < KS; ++s)
-                    sv[u] = fma(e[s], r[u][s], sv[u]);
-            }
-            const double tw = my_cnt * rcp_pos<true>(fold_chunk<TCH>(sv) + 1e-100);
-            if ((lane & (TCH == 4 ? 15 : 31)) == 0) {     // one lane per word of the chunk
-                const int j = n_reg + t0 + my_u;
-                if (from_lds ? t0 + my_u < n_lds : j < n)
-                    a.tw_csr[p0 + j] = tw;
-            }
-#pragma unroll
-            for (int u = 0; u < TCH; ++u) {
-                const double twu = readlane_f64(tw, fold_chunk_lane<TCH>(u));
-#pragma unroll
-                for (int s = 0; s < KS; ++s)
-                    acc[u % NSET][s] = fma(twu, r[u][s], acc[u % NSET][s]);
-            }
-        };
+        TRLDA_STAMP(1);
+        // ---- tail words: phinorm, weight and update of acc from one read of the row
         for (int t0 = wid * TCH; t0 < n_lds; t0 += W * TCH)
             tail_chunk(t0, true);
         for (int t0 = n_lds + wid * TCH; n_reg + t0 < n; t0 += W * TCH)
             tail_chunk(t0, false);
-
+        TRLDA_STAMP(2);
         if (it >= a.max_iter || (it > 0 && mean_change < a.threshold))    // lda.cpp:185, :202-203
             break;
 
@@ -397,10 +448,10 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
                 for (int u = 0; u < 4; ++u) {
                     const int i = 4 * c + u;
                     if (i < JW) {
-                        const double twi = readlane_f64(twv[i / 16], fold16_lane(i & 15));
+                        const double twi = readlane_f64(twv[i / 8], fold8_lane(i & 7));
 #pragma unroll
                         for (int s = 0; s < KS; ++s)
-                            acc[i % NSET][s] = fma(twi, beta[i][s], acc[i % NSET][s]);
+                            acc[i % NSET][s] = fma(twi, beta[i < JW ? i : 0][s], acc[i % NSET][s]);
                     }
                 }
             }
@@ -417,7 +468,9 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
                     ((acc[4][s] + acc[5][s]) + (acc[6][s] + acc[7][s]));
             part[wid * KP + lane + 64 * s] = v;
         }
+        TRLDA_STAMP(3);
         __syncthreads();
+        TRLDA_STAMP(4);
 
         // ---- gamma_k = alpha_k + e_k acc_k ; e_k = exp(psi(gamma_k))     lda.cpp:194-197
         const int nxt = cur ^ 1;
@@ -426,14 +479,16 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
             const double gnew = k_on ? fma(accs, ek, ak) : 1.0;
             const double diff = k_on ? fabs(gk - gnew) : 0.0;
             gk = gnew;
-            const double enew = exp_digamma(gnew);
+            const double enew = cfg::LEAN_PSI ? exp_digamma_minus_lean(gnew, 0.0) : exp_digamma(gnew);
             ek = k_on ? enew : 0.0;
             ebuf[nxt * KP + tid] = ek;
             const double dsum = wave_sum_dpp(diff);
             if (lane == 0)
                 misc[nxt * 8 + wid] = dsum;
         }
+        TRLDA_STAMP(5);
         __syncthreads();
+        TRLDA_STAMP(6);
         cur = nxt;
         ++it;
     }
@@ -449,7 +504,7 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
         __syncthreads();                             // tw_csr of the tail words
 #pragma unroll
         for (int i = 0; i < JW; ++i) {
-            const double twi = readlane_f64(twv[i / 16], fold16_lane(i & 15));
+            const double twi = readlane_f64(twv[i / 8], fold8_lane(i & 7));
             const int j = i * W + wid;
             if (j < n_reg) {
                 double *col = a.sstats_acc + (size_t)ids[j] * K;
@@ -468,9 +523,9 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
                     unsafeAtomicAdd(&col[lane + 64 * s], twj * e[s]);
         }
     } else {
-        if ((lane & 3) == 0) {
+        if ((lane & 7) == 0) {
 #pragma unroll
-            for (int g = 0; g < NG; ++g)
+            for (int g = 0; g < NH; ++g)
                 if (jv[g] >= 0)
                     a.tw_word[a.wrank[p0 + jv[g]]] = twv[g];
         }
@@ -478,6 +533,8 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
         for (int j = n_reg + tid; j < n; j += kWideThreads)
             a.tw_word[a.wrank[p0 + j]] = a.tw_csr[p0 + j];
     }
+    TRLDA_STAMP(7);
+    TRLDA_STAMP_FLUSH;
 }
 
 }  // namespace trlda

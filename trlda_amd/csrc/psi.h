@@ -189,6 +189,35 @@ __device__ __forceinline__ double exp_digamma_minus(double x, double c)
 
 __device__ __forceinline__ double exp_digamma(double x) { return exp_digamma_minus(x, 0.0); }
 
+// The same value, bit for bit, scheduled for few live registers instead of for latency: the
+// reciprocals are formed four at a time (same pairwise summation tree) with scheduling
+// barriers in between, and the rare branch is a call.  For kernels that hold most of the
+// register file as data (estep_wide.h) and hide latency with the other waves instead.
+__device__ __noinline__ double exp_digamma_rare(double x, double c) { return exp(digamma(x) - c); }
+
+__device__ __forceinline__ double exp_digamma_minus_lean(double x, double c)
+{
+    const double wa = (rcp_pos<true>(x) + rcp_pos<true>(x + 1.0)) +
+                      (rcp_pos<true>(x + 2.0) + rcp_pos<true>(x + 3.0));
+    __builtin_amdgcn_sched_barrier(0);
+    const double wb = (rcp_pos<true>(x + 4.0) + rcp_pos<true>(x + 5.0)) +
+                      (rcp_pos<true>(x + 6.0) + rcp_pos<true>(x + 7.0));
+    __builtin_amdgcn_sched_barrier(0);
+    double w = wa + wb;
+    w += rcp_pos<true>(x + 8.0) + rcp_pos<true>(x + 9.0);
+    const double s = x + 10.0;
+    const double r = rcp_pos<true>(s);
+    double y = 0.0;
+    if (s < 1.0e17) {
+        const double z = r * r;
+        y = z * psi_series(z);
+    }
+    const double v = s * exp(-(((0.5 * r) + y) + w) - c);
+    if (__builtin_expect(!(x > 1e-290 && x < 1e290) || (x <= 10.0 && x == floor(x)), 0))
+        return exp_digamma_rare(x, c);
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------
 // exp(psi(x)) cut into independent pieces so that NP wavefronts can each evaluate one piece
 // for the same 64 arguments and a single wavefront combines them:
