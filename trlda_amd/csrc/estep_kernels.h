@@ -78,6 +78,44 @@ __global__ __launch_bounds__(T) void rowsum_partial_kernel(
     }
 }
 
+// 1b. Large K x V only: the row-sum grid is wider than 64 blocks there (it has to pull
+// hundreds of MB through HBM) and the eeb blocks should not each re-add that many partials.
+// combined[k] = sum_b partial[b][k]: eight threads per topic add G/8 block partials each
+// (all loads in flight), one thread combines the eight in order -- a fixed order.
+template <int T>
+__global__ __launch_bounds__(T) void rowsum_combine_kernel(int K, int G,
+                                                           const double *__restrict__ partial,
+                                                           double *__restrict__ combined)
+{
+    __shared__ double scratch[T];
+    constexpr int TPB = T / 8;                       // topics per block
+    const int kl = threadIdx.x % TPB, part = threadIdx.x / TPB;
+    const int k = blockIdx.x * TPB + kl;
+    const int per = (G + 7) / 8;
+    const int b0 = part * per, b1 = min(G, b0 + per);
+    double acc[2] = {0.0, 0.0};
+    if (k < K) {
+        for (int b = b0; b < b1; b += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = partial[(size_t)min(b + u, G - 1) * K + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                acc[u & 1] += (b + u < b1) ? v[u] : 0.0;
+        }
+    }
+    scratch[part * TPB + kl] = acc[0] + acc[1];
+    __syncthreads();
+    if (part == 0 && k < K) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            v[u] = scratch[u * TPB + kl];
+        combined[k] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+}
+
 // ---------------------------------------------------------------------------
 // 2. eeb[i] = exp(psi(lambda[i]) - psiSum[i % K]) over the flat K*V array.
 //

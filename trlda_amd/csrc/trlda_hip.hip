@@ -50,7 +50,7 @@ constexpr int kLdsBytes = 160 * 1024;   // LDS per workgroup on gfx950
 unsigned long long *g_stamp_buf = nullptr;
 #endif
 constexpr int kDenseThreads = 256;
-constexpr int kMaxRowsumBlocks = trlda::kRowsumBlocks;
+constexpr int kMaxRowsumBlocks = 1025;   // 1024 blocks on large tables + the combined row
 
 template <typename T>
 int dev_alloc(T **p, size_t count)
@@ -242,14 +242,27 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
     if (m->timing && (rc = stamp(m)))
         return rc;
 
-    // 1. row sums of lambda, per block of words (lda.cpp:172)
-    int G = std::min(trlda::kRowsumBlocks, std::max(1, V / 32));
+    // 1. row sums of lambda, per block of words (lda.cpp:172).  Small tables: 64 blocks whose
+    // partials every eeb block adds up itself (saves a launch).  Large ones (tens of MB and
+    // more): up to 1024 blocks to fill HBM, then one small kernel combines the partials.
+    const bool big = KV >= ((size_t)1 << 22);
+    int G = std::min(big ? kMaxRowsumBlocks - 1 : trlda::kRowsumBlocks, std::max(1, V / 32));
+    const double *partial_in = m->partial;
     {
         int wpb = (V + G - 1) / G;
         G = (V + wpb - 1) / wpb;
         hipLaunchKernelGGL(rowsum_partial_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads), 0,
                            m->stream, K, V, wpb, m->lambda, m->partial);
         HIP_TRY(hipGetLastError());
+        if (G > trlda::kRowsumBlocks) {
+            double *combined = m->partial + (size_t)G * K;       // row G of the same buffer
+            hipLaunchKernelGGL(rowsum_combine_kernel<kDenseThreads>,
+                               dim3((K + kDenseThreads / 8 - 1) / (kDenseThreads / 8)),
+                               dim3(kDenseThreads), 0, m->stream, K, G, m->partial, combined);
+            HIP_TRY(hipGetLastError());
+            partial_in = combined;
+            G = 1;
+        }
     }
     if (m->timing && (rc = stamp(m)))
         return rc;
@@ -267,7 +280,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(exp_elog_beta_kernel<TE>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(exp_elog_beta_kernel<TE>, dim3(GE), dim3(TE), lds, m->stream, K, total, G,
-                           m->lambda, m->partial, m->psi_sum, m->eeb,
+                           m->lambda, partial_in, m->psi_sum, m->eeb,
                            dense ? nullptr : b->active);
         HIP_TRY(hipGetLastError());
     }
