@@ -142,11 +142,11 @@ int trlda_model_set_dense_preamble(trlda_model *model, int dense);
 int trlda_model_set_doc_threads(trlda_model *model, int threads);
 /* which document kernels the E-step may use (all give the same results; tests and tuning):
  * AUTO = dual-orientation register kernel for K <= 128 and at most 192 words, else the
- * single-orientation register kernel up to K = 512, else the LDS / streaming kernels;
- * LDS = never the single-orientation kernel; WIDE = the single-orientation kernel for
- * every document (K <= 512). */
+ * single-orientation register kernel up to K = 512, else the general (LDS / streaming)
+ * kernel; GENERAL = never the single-orientation kernel; WIDE = the single-orientation
+ * kernel for every document (K <= 512). */
 #define TRLDA_DOCS_AUTO 0
-#define TRLDA_DOCS_LDS 1
+#define TRLDA_DOCS_GENERAL 1
 #define TRLDA_DOCS_WIDE 2
 int trlda_model_set_doc_kernel(trlda_model *model, int kind);
 int trlda_model_synchronize(trlda_model *model);

@@ -425,7 +425,8 @@ def test_full_size_document_permutation(hip, bench_case):
 @pytest.mark.parametrize("K", [100, 128, 7])
 def test_document_length_boundaries(hip, oracle, sampler, K):
     """Documents right at the limits of the document kernels' tiers: 128 words (all in
-    registers), 129..192 (register part + LDS tail), 193 (LDS kernel), and a mixed batch."""
+    registers), 129..192 (register part + LDS tail), 193 and up (single-orientation kernel), all
+    in one batch; once more with everything forced through the general kernel."""
     from trlda_amd.documents import CSRDocuments
     V = 3000
     rng = np.random.RandomState(K)
@@ -442,14 +443,16 @@ def test_document_length_boundaries(hip, oracle, sampler, K):
     ip = np.array(ip, np.int32)
     g0 = seeded_gamma(sampler, 32, K, len(lens))
     m = make_model(K, V, lam)
-    for (it, thr) in [(0, 0.), (1, 0.), (25, 1e-3)]:
-        g, s, iters = m.update_variables(CSRDocuments(ip, ids, cnts), latents=g0, max_iter=it,
-                                         threshold=thr, return_iterations=True)
-        go, so, ito = oracle.estep(lam, .1, ip, ids, cnts, g0, it, thr)
-        per_doc = np.max(np.abs(g - go) / np.abs(go), axis=0)
-        assert per_doc.max() < TIGHT_RTOL, list(zip(lens, per_doc))
-        check_sstats(s, so)
-        assert np.array_equal(iters, ito)
+    for kind in (0, 1):                          # TRLDA_DOCS_AUTO, TRLDA_DOCS_GENERAL
+        assert hip.trlda_model_set_doc_kernel(m._handle, kind) == 0
+        for (it, thr) in [(0, 0.), (1, 0.), (25, 1e-3)]:
+            g, s, iters = m.update_variables(CSRDocuments(ip, ids, cnts), latents=g0, max_iter=it,
+                                             threshold=thr, return_iterations=True)
+            go, so, ito = oracle.estep(lam, .1, ip, ids, cnts, g0, it, thr)
+            per_doc = np.max(np.abs(g - go) / np.abs(go), axis=0)
+            assert per_doc.max() < TIGHT_RTOL, list(zip(lens, per_doc))
+            check_sstats(s, so)
+            assert np.array_equal(iters, ito)
 
 
 def test_transposing_wave_reductions(hip):

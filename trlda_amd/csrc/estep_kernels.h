@@ -542,263 +542,6 @@ __global__ __launch_bounds__(T) void estep_docs_kernel(DocKernelArgs a)
 }
 
 // ---------------------------------------------------------------------------
-// 3b. The lean kernel for documents whose slice fits in LDS (the common case), built
-// around what tools/probes measured on gfx950: a wave issues one fp64 op per ~9 cycles and
-// a dependent fp64 chain advances one link per ~37, while a SIMD interleaves four waves at
-// no loss.  So: T = 1024 (four waves per SIMD), every per-thread loop is short with
-// independent accumulators, and psi -- whose serial form costs ~3000 cycles per iteration
-// for just 2 of the waves -- is cut into NP pieces evaluated by NP waves at once
-// (psi.h: psi_piece).
-//
-// Roles of wave w (KB = ceil(K/64) topic blocks, JP = W/KB):   kb = w % KB, jp = w / KB
-//   product B : topics kb*64+lane, words [jp*JC, (jp+1)*JC)        -> part[jp][k]
-//   psi piece : piece jp (< NP) of psi(gamma_k) for the same topics -> rpart[jp][k]
-//   combine   : waves with jp == 0: e_k = exp(sum of pieces)
-// and (JB = ceil(n/64) word blocks, KPn = W/JB):               jb = w % JB, kp = w / JB
-//   product E : words jb*64+lane, topics [kp*KC, (kp+1)*KC)         -> part[kp][j]
-// Host guarantees KB <= W and ceil(n_cap/64) <= W.
-// ---------------------------------------------------------------------------
-
-// sum of count values v[q * stride], q < count, through four chains + pairwise combine
-__device__ __forceinline__ double lds_strided_sum(const double *v, int stride, int count)
-{
-    double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
-    int q = 0;
-    for (; q + 4 <= count; q += 4) {
-        const double a0 = v[q * stride], a1 = v[(q + 1) * stride], a2 = v[(q + 2) * stride],
-                     a3 = v[(q + 3) * stride];
-        p0 += a0;
-        p1 += a1;
-        p2 += a2;
-        p3 += a3;
-    }
-    if (q < count)
-        p0 += v[q * stride];
-    if (q + 1 < count)
-        p1 += v[(q + 1) * stride];
-    if (q + 2 < count)
-        p2 += v[(q + 2) * stride];
-    return (p0 + p1) + (p2 + p3);
-}
-
-// 8 * chunks products wgt[i] * col[i * STRIDE]: `wgt` is read at the same address by every
-// lane (LDS broadcast), `col` is this lane's column with a compile-time stride, so all
-// sixteen reads of a chunk are base + immediate offset (no per-element address
-// arithmetic: a lone wave issues only one instruction per ~5 cycles, tools/probes).
-// Operands beyond the logical end are zero-filled by the caller.  Four chains.
-template <int STRIDE>
-__device__ __forceinline__ double lds_dot_chunks(const double *__restrict__ wgt,
-                                                 const double *__restrict__ col, int chunks)
-{
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-    for (int c = 0; c < chunks; ++c) {
-        double x[8], y[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            x[u] = wgt[u];
-            y[u] = col[u * STRIDE];
-        }
-        wgt += 8;
-        col += 8 * STRIDE;
-        acc0 = fma(x[0], y[0], acc0);
-        acc1 = fma(x[1], y[1], acc1);
-        acc2 = fma(x[2], y[2], acc2);
-        acc3 = fma(x[3], y[3], acc3);
-        acc0 = fma(x[4], y[4], acc0);
-        acc1 = fma(x[5], y[5], acc1);
-        acc2 = fma(x[6], y[6], acc2);
-        acc3 = fma(x[7], y[7], acc3);
-    }
-    return (acc0 + acc1) + (acc2 + acc3);
-}
-
-// LDS doubles needed by estep_docs_lds_kernel<T, KP, *> for a given n_cap (host + device)
-__host__ __device__ constexpr size_t lean_lds_doubles(int T, int KP, int K, int n_cap)
-{
-    return (size_t)(n_cap + 8) * KP   // beta rows (8 zero rows after the last word)
-           + (size_t)K                // g
-           + (size_t)K                // alpha
-           + (size_t)K + 8            // e, zero padded
-           + (size_t)n_cap + 8        // tw, zero padded
-           + (size_t)n_cap            // counts as doubles
-           + (size_t)K                // |gamma - last| per topic
-           + 2 * (size_t)T            // part, rpart
-           + 8;                       // change
-}
-
-template <int T, int KP, int NP>
-__global__ __launch_bounds__(T) void estep_docs_lds_kernel(DocKernelArgs a)
-{
-    extern __shared__ double lds[];
-    constexpr int W = T / kWave;
-    const int tid = threadIdx.x;
-    const int lane = tid & (kWave - 1);
-    const int wid = __builtin_amdgcn_readfirstlane(tid / kWave);
-
-    const int d = a.order[blockIdx.x];
-    const int K = a.K;
-    const int p0 = a.indptr[d];
-    const int n = a.indptr[d + 1] - p0;
-    const int32_t *__restrict__ ids = a.ids + p0;
-    const int32_t *__restrict__ cnts = a.cnts + p0;
-
-    double *beta = lds;                              // (n_cap + 8) x KP
-    double *g = beta + (a.n_cap + 8) * KP;
-    double *alpha_l = g + K;
-    double *e = alpha_l + K;                         // K + 8
-    double *tw = e + K + 8;                          // n_cap + 8
-    double *cntd = tw + a.n_cap + 8;
-    double *diffs = cntd + a.n_cap;
-    double *part = diffs + K;                        // T
-    double *rpart = part + T;                        // T
-    double *misc = rpart + T;                        // 8
-
-    [[maybe_unused]] unsigned long long stamp_last = 0;
-#ifdef TRLDA_STAMPS
-    stamp_last = __builtin_amdgcn_s_memtime();
-#endif
-
-    // roles (all wave-uniform)
-    const int KB = (K + kWave - 1) / kWave;
-    const int JP = W / KB;
-    const int kb = wid % KB, jp = wid / KB;
-    const bool in_b = jp < JP;
-    const int k_mine = kb * kWave + lane;
-    const bool k_on = in_b && k_mine < K;
-    const int JC = ((n + JP - 1) / JP + 7) & ~7;     // words per part, multiple of 8
-    const int j0 = jp * JC;
-    const int chunks_b = in_b ? min(JC, max(0, n - j0) + 7) / 8 : 0;
-    const double *col_b = beta + j0 * KP + min(k_mine, K - 1);
-    const double *wgt_b = tw + j0;
-    const int JB = max(1, (n + kWave - 1) / kWave);
-    const int KPn = W / JB;
-    const int jb = wid % JB, kp = wid / JB;
-    const int j_mine = jb * kWave + lane;
-    const bool in_e = kp < KPn;
-    const bool j_on = in_e && j_mine < n;
-    const int KC = ((K + KPn - 1) / KPn + 7) & ~7;   // topics per part, multiple of 8
-    const int k0 = kp * KC;
-    const int chunks_e = in_e ? min(KC, max(0, K - k0) + 7) / 8 : 0;
-    const double *col_e = beta + min(j_mine, max(n - 1, 0)) * KP + k0;
-    const double *wgt_e = e + k0;
-
-    double *gamma_d = a.gamma + (size_t)d * K;
-    const double *gamma0_d = a.gamma_in + (size_t)d * K;
-    for (int k = tid; k < K; k += T) {               // lda.cpp:174
-        const double gk = gamma0_d[k];
-        g[k] = gk;
-        alpha_l[k] = a.alpha[k];
-        e[k] = exp_digamma(gk);
-    }
-    if (tid < 8) {
-        e[K + tid] = 0.0;
-        tw[n + tid] = 0.0;
-    }
-
-    // stage the slice, four words of a wave in flight                lda.cpp:179-181
-    for (int jbase = wid; jbase < n; jbase += 4 * W) {
-        int wordid[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = jbase + u * W;
-            wordid[u] = j < n ? ids[j] : 0;
-        }
-        for (int kk = lane; kk < KP; kk += kWave) {
-            double v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                v[u] = kk < K ? a.eeb[(size_t)wordid[u] * K + kk] : 0.0;   // pad columns = 0
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = jbase + u * W;
-                if (j < n)
-                    beta[j * KP + kk] = v[u];
-            }
-        }
-    }
-    for (int i = tid; i < 8 * KP; i += T)            // eight zero rows after the last word
-        beta[n * KP + i] = 0.0;
-    for (int j = tid; j < n; j += T)
-        cntd[j] = (double)cnts[j];
-    __syncthreads();
-
-    // phinorm_j = sum_k e_k beta[j][k] ; tw_j = cnt_j / phinorm_j     lda.cpp:183 / :199
-    auto product_E = [&](bool reduce_change) {
-        const double s = lds_dot_chunks<1>(wgt_e, col_e, chunks_e);
-        if (j_on)
-            part[kp * n + j_mine] = s;
-        __syncthreads();
-        for (int j = tid; j < n; j += T)
-            tw[j] = cntd[j] / (lds_strided_sum(part + j, n, KPn) + 1e-100);
-        if (reduce_change && wid == W - 1) {         // mean |gamma - last|   lda.cpp:202
-            double v = 0.0;
-            for (int k = lane; k < K; k += kWave)
-                v += diffs[k];
-            v = wave_sum(v);
-            if (lane == 0)
-                misc[0] = v;
-        }
-        __syncthreads();
-    };
-
-    product_E(false);
-
-    int it = 0;
-    while (it < a.max_iter) {                        // lda.cpp:185-204
-        // acc_k = sum_j tw_j beta[j][k]                               lda.cpp:189-193
-        {
-            const double s = lds_dot_chunks<KP>(wgt_b, col_b, chunks_b);
-            if (k_on)
-                part[jp * K + k_mine] = s;
-        }
-        __syncthreads();
-
-        // gamma_k = alpha_k + e_k * acc_k (lda.cpp:194-195), psi(gamma_k) in NP pieces
-        double gnew = 0.0;
-        if (k_on && jp < NP) {
-            const double acc = lds_strided_sum(part + k_mine, K, JP);
-            gnew = acc * e[k_mine] + alpha_l[k_mine];
-            rpart[jp * K + k_mine] = psi_piece<NP>(gnew, jp);
-        }
-        __syncthreads();
-        if (k_on && jp == 0) {                       // lda.cpp:197
-            double psi = rpart[k_mine];
-#pragma unroll
-            for (int p = 1; p < NP; ++p)
-                psi += rpart[p * K + k_mine];
-            diffs[k_mine] = fabs(g[k_mine] - gnew);
-            g[k_mine] = gnew;
-            e[k_mine] = exp_psi_from_pieces(gnew, psi);
-        }
-        __syncthreads();
-
-        product_E(true);                             // ends with a barrier
-        ++it;
-        if (misc[0] / (double)K < a.threshold)       // lda.cpp:202-203
-            break;
-    }
-
-    // results
-    for (int k = tid; k < K; k += T) {
-        gamma_d[k] = g[k];
-        a.epg[(size_t)d * K + k] = e[k];
-    }
-    if (tid == 0 && a.iters_out)
-        a.iters_out[d] = it;
-    if (a.sstats_acc) {                              // lda.cpp:207-213, atomic form
-        for (int j = wid; j < n; j += W) {
-            const double c = tw[j];
-            double *col = a.sstats_acc + (size_t)ids[j] * K;
-            for (int k = lane; k < K; k += kWave)
-                unsafeAtomicAdd(&col[k], c * e[k]);
-        }
-    } else {
-        for (int j = tid; j < n; j += T)
-            a.tw_word[a.wrank[p0 + j]] = tw[j];
-    }
-}
-
-// ---------------------------------------------------------------------------
 // 3c. Register-resident kernel: K <= 128 topics, documents of at most 128 words.
 //
 // tools/probes on gfx950: the two products of 3b are bound by LDS bandwidth -- every

@@ -43,9 +43,6 @@ int fail(int code, const std::string &msg)
     } while (0)
 
 constexpr int kLdsBytes = 160 * 1024;   // LDS per workgroup on gfx950
-#ifndef TRLDA_LEAN_THREADS
-#define TRLDA_LEAN_THREADS 512          // threads per document in the lean kernel
-#endif
 #ifdef TRLDA_STAMPS
 unsigned long long *g_stamp_buf = nullptr;
 #endif
@@ -314,40 +311,20 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
         a.max_iter = max_iter; a.threshold = threshold; a.iters_out = iters_dev;
         const int Kp = K | 1;
 
-        // Documents are ordered by decreasing length and split into three runs:
-        //   [0, n_stream)            too long for LDS (or an explicit doc_threads override):
-        //                            general kernel, streams beta from L2 when it has to
-        //   [n_stream, B - n_reg)    slice fits in LDS: lean kernel (compile-time row stride)
-        //   [B - n_reg, B)           K <= 128 and at most 128 words: slice in registers
+        // Documents are ordered by decreasing length and split into two runs:
+        //   [B - n_reg, B)   K <= 128 and at most 192 words: slice in registers, both
+        //                    orientations (estep_docs_reg_kernel)
+        //   [0, B - n_reg)   everything else
         int n_reg = 0;
         if (m->doc_threads == 0 && K <= kRegMaxK && m->doc_kernel != TRLDA_DOCS_WIDE)
             while (n_reg < B && b->sorted_len[(size_t)(B - 1 - n_reg)] <= kRegMaxN)
                 ++n_reg;
 
-        constexpr int TL = TRLDA_LEAN_THREADS, WL = TL / kWave;
-        const int KB = (K + kWave - 1) / kWave;
-        static const int kStrides[] = {9, 17, 33, 65, 101, 129, 201, 257};
-        int KPl = 0;
-        for (int cand : kStrides)
-            if (!KPl && cand >= K)
-                KPl = cand;
         // 128 < K <= 512, or K <= 128 with more than 192 words: registers in one orientation
-        // (estep_wide.h); it takes every document the register tier does not
-        const bool wide = m->doc_threads == 0 && K <= kWideMaxK && m->doc_kernel != TRLDA_DOCS_LDS;
-        const bool lean = !wide && m->doc_threads == 0 && KPl != 0 && K <= 256 && KB <= WL;
-        int n_cap = 0;
-        if (lean) {
-            size_t fixed = lean_lds_doubles(TL, KPl, K, 0) * sizeof(double);
-            size_t n_fit = ((size_t)kLdsBytes - fixed) / ((size_t)(KPl + 2) * sizeof(double));
-            n_cap = (int)std::min<size_t>({n_fit, (size_t)b->max_n, (size_t)WL * kWave});
-        }
-        int n_stream = B - n_reg;
-        if (lean) {
-            n_stream = 0;
-            while (n_stream < B - n_reg && b->sorted_len[(size_t)n_stream] > n_cap)
-                ++n_stream;
-        }
-        const int n_lean = B - n_reg - n_stream;
+        // (estep_wide.h); it takes every document the register tier does not.  Beyond 512
+        // topics (or on request): the general kernel, slice in LDS when it fits, else streamed.
+        const bool wide = m->doc_threads == 0 && K <= kWideMaxK && m->doc_kernel != TRLDA_DOCS_GENERAL;
+        const int n_stream = B - n_reg;
 
         if (wide && B - n_reg > 0) {
             const int n_wide = B - n_reg;
@@ -399,7 +376,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
                             ? 0
                             : (int)(((size_t)kLdsBytes - fixed) /
                                     ((size_t)(Kp + 2) * sizeof(double)));
-            int gen_cap = lean ? 0 : std::min(b->max_n, n_fit);
+            int gen_cap = std::min(b->max_n, n_fit);
             size_t lds_bytes = docs_lds_bytes(K, Kp, gen_cap, T);
             if (lds_bytes > (size_t)kLdsBytes)
                 return fail(TRLDA_ERR_ARG,
@@ -417,35 +394,6 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
             }
             if (rc)
                 return rc;
-        }
-        if (!wide && n_lean > 0) {
-            a.n_cap = n_cap;
-            a.Kp = KPl;
-            a.order = b->order + n_stream;
-            const size_t lds_bytes = lean_lds_doubles(TL, KPl, K, n_cap) * sizeof(double);
-#define TRLDA_LAUNCH_LEAN(KPV, NP)                                                         \
-    do {                                                                                   \
-        auto kern = estep_docs_lds_kernel<TL, KPV, NP>;                                    \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                  \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,            \
-                                    (int)lds_bytes));                                      \
-        hipLaunchKernelGGL(kern, dim3(n_lean), dim3(TL), lds_bytes, m->stream, a);         \
-    } while (0)
-            // exp(psi) is evaluated whole by the topic's own wave (NP = 1): probe6 shows the
-            // pieces buy nothing once the logarithm is gone
-            constexpr int NPA = 1, NPB = 1, NPC = 1;
-            switch (KPl) {
-            case 9: TRLDA_LAUNCH_LEAN(9, NPA); break;
-            case 17: TRLDA_LAUNCH_LEAN(17, NPA); break;
-            case 33: TRLDA_LAUNCH_LEAN(33, NPA); break;
-            case 65: TRLDA_LAUNCH_LEAN(65, NPA); break;
-            case 101: TRLDA_LAUNCH_LEAN(101, NPB); break;
-            case 129: TRLDA_LAUNCH_LEAN(129, NPB); break;
-            case 201: TRLDA_LAUNCH_LEAN(201, NPC); break;
-            default: TRLDA_LAUNCH_LEAN(257, NPC); break;
-            }
-#undef TRLDA_LAUNCH_LEAN
-            HIP_TRY(hipGetLastError());
         }
         if (n_reg > 0) {
             a.n_cap = 0;
@@ -932,7 +880,7 @@ int trlda_model_set_doc_kernel(trlda_model *m, int kind)
 {
     if (!m)
         return fail(TRLDA_ERR_ARG, "null model");
-    if (kind != TRLDA_DOCS_AUTO && kind != TRLDA_DOCS_LDS && kind != TRLDA_DOCS_WIDE)
+    if (kind != TRLDA_DOCS_AUTO && kind != TRLDA_DOCS_GENERAL && kind != TRLDA_DOCS_WIDE)
         return fail(TRLDA_ERR_ARG, "doc_kernel must be TRLDA_DOCS_AUTO, _LDS or _WIDE");
     m->doc_kernel = kind;
     return TRLDA_OK;
