@@ -182,6 +182,15 @@ int trlda_model_estep_host(trlda_model *model, const trlda_batch *batch,
                            double *gamma, double *sstats,
                            int max_iter, double threshold, int32_t *iters_out);
 
+/* LDA::lowerBound (src/lda.cpp:297-360; python/src/ldainterface.cpp:420-470): an E-step on
+ * the batch from gamma (K x B host, in: gamma0, out: gamma), then the variational lower
+ * bound with the correction factor = num_documents / B of :302-303 (pass 1 for none).
+ * phi is recomputed with the column of the word (the reference's :334 indexes the row; see
+ * DESIGN.md "lower bound"). */
+int trlda_model_lower_bound(trlda_model *model, const trlda_batch *batch, double *gamma,
+                            double eta, double factor, int max_iter, double threshold,
+                            double *bound_out);
+
 /* model.lambda = (1-rho) lambda' + rho (eta + scale * sstats), all device pointers.
  * src/onlinelda.cpp:99-100, :108-109; src/batchlda.cpp:60 (rho = 1, scale = 1). */
 int trlda_model_blend(trlda_model *model, const double *lambda_prime_dev,

@@ -477,3 +477,87 @@ double oracle_batch_update_parameters(
     free(sstats); free(gamma);
     return 1.;
 }
+
+/* ------------------------------------------------------------------------
+ * LDA::lowerBound given the E-step's outputs -- src/lda.cpp:304-360 (the
+ * E-step itself, :309, is oracle_estep).  factor = numDocuments / B (:302-303).
+ *
+ * reference_indexing != 0 reproduces what the reference computes when built
+ * the way its setup.py builds it (distutils passes -DNDEBUG, so Eigen's bounds
+ * assertion is compiled out): lda.cpp:334 reads `psiLambda.row(id)` of the
+ * K x V matrix where column id is meant, i.e. element c of "the row" is the
+ * flat element id + c*K.  That mode exists to pin this restatement against
+ * the compiled reference; reference_indexing == 0 is the intended formula
+ * (phi_kj proportional to exp(E[log beta_k,w_j] + psi(gamma_k))) and is what
+ * the product implements.  The two differ by about 1e-4 relative.
+ * ---------------------------------------------------------------------- */
+double oracle_lower_bound(int K, int V, int B, const int32_t *indptr, const int32_t *ids,
+                          const int32_t *cnts, const double *lambda, const double *alpha,
+                          double eta, const double *gamma, const double *sstats, double factor,
+                          int reference_indexing)
+{
+    const size_t KV = (size_t)K * V;
+    double *psi_lambda = (double *)malloc(sizeof(double) * KV);
+    double *lambda_sum = (double *)calloc((size_t)K, sizeof(double));
+    double *psi_lambda_sum = (double *)malloc(sizeof(double) * (size_t)K);
+    double *psi_gamma = (double *)malloc(sizeof(double) * (size_t)K);
+    double *phi = (double *)malloc(sizeof(double) * (size_t)K);
+    for (size_t i = 0; i < KV; ++i) {                          /* :312-314 */
+        psi_lambda[i] = oracle_digamma(lambda[i]);
+        lambda_sum[i % K] += lambda[i];
+    }
+    for (int k = 0; k < K; ++k)
+        psi_lambda_sum[k] = oracle_digamma(lambda_sum[k]);
+
+    double pw_pb = 0.0;                                        /* :317 */
+    for (size_t i = 0; i < KV; ++i)
+        pw_pb += (eta + factor * sstats[i] - lambda[i]) * (psi_lambda[i] - psi_lambda_sum[i % K]);
+
+    double pz = 0.0, ptheta = 0.0;
+    for (int d = 0; d < B; ++d) {                              /* :325-351 */
+        const double *g = gamma + (size_t)d * K;
+        double gamma_sum = 0.0;
+        for (int k = 0; k < K; ++k) {
+            gamma_sum += g[k];
+            psi_gamma[k] = oracle_digamma(g[k]);
+        }
+        const double psi_gamma_sum = oracle_digamma(gamma_sum);
+        for (int p = indptr[d]; p < indptr[d + 1]; ++p) {
+            const int id = ids[p];
+            double mx = -HUGE_VAL;
+            for (int k = 0; k < K; ++k) {                      /* :332-337 */
+                const double pl = reference_indexing ? psi_lambda[(size_t)id + (size_t)k * K]
+                                                     : psi_lambda[(size_t)id * K + k];
+                phi[k] = pl - psi_lambda_sum[k] + psi_gamma[k];
+                if (phi[k] > mx)
+                    mx = phi[k];
+            }
+            double se = 0.0;                                   /* logSumExp, :338 */
+            for (int k = 0; k < K; ++k)
+                se += exp(phi[k] - mx);
+            const double lse = mx + log(se);
+            double tmp = 0.0;                                  /* :343-344 */
+            for (int k = 0; k < K; ++k) {
+                const double lp = phi[k] - lse, ph = exp(lp);
+                tmp += (psi_gamma[k] - psi_gamma_sum) * ph - ph * lp;
+            }
+            pz += (double)cnts[p] * tmp;                       /* :347 */
+        }
+        for (int k = 0; k < K; ++k)                            /* :349-351 */
+            ptheta += (alpha[k] - g[k]) * (psi_gamma[k] - psi_gamma_sum) + lgamma(g[k]);
+        ptheta -= lgamma(gamma_sum);
+    }
+    double alpha_sum = 0.0, lg_alpha = 0.0, lg_lambda_sum = 0.0, lg_lambda = 0.0;
+    for (int k = 0; k < K; ++k) {
+        alpha_sum += alpha[k];
+        lg_alpha += lgamma(alpha[k]);
+        lg_lambda_sum += lgamma(lambda_sum[k]);
+    }
+    for (size_t i = 0; i < KV; ++i)
+        lg_lambda += lgamma(lambda[i]);
+    ptheta += (lgamma(alpha_sum) - lg_alpha) * B;              /* :355 */
+    pw_pb += K * lgamma(V * eta) - lg_lambda_sum;              /* :356 */
+    pw_pb -= (double)K * V * lgamma(eta) - lg_lambda;          /* :357 */
+    free(psi_lambda); free(lambda_sum); free(psi_lambda_sum); free(psi_gamma); free(phi);
+    return pw_pb + factor * pz + factor * ptheta;              /* :359 */
+}

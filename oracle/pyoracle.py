@@ -103,6 +103,20 @@ class Oracle:
             raise RuntimeError("oracle_estep: word id out of range")
         return gamma, sstats, iters
 
+    def lower_bound(self, lam, alpha, eta, indptr, ids, cnts, gamma, sstats, factor=1.,
+                    reference_indexing=False):
+        """LDA::lowerBound (lda.cpp:304-360) from the E-step's gamma and sstats"""
+        lam = _f(lam)
+        K, V = lam.shape
+        indptr, ids, cnts = _csr(indptr, ids, cnts)
+        alpha = _f(np.broadcast_to(np.asarray(alpha, np.float64).ravel(), (K,)).copy())
+        f = self.lib.oracle_lower_bound
+        f.restype = C.c_double
+        f.argtypes = [C.c_int, C.c_int, C.c_int, _i32p, _i32p, _i32p, _f64p, _f64p, C.c_double,
+                      _f64p, _f64p, C.c_double, C.c_int]
+        return f(K, V, len(indptr) - 1, indptr, ids, cnts, lam, alpha, float(eta), _f(gamma),
+                 _f(sstats), float(factor), int(reference_indexing))
+
     def tr_init(self, lam_prime, indptr, ids, cnts, D, rho, eta):
         lam_prime = _f(lam_prime)
         K, V = lam_prime.shape
@@ -194,6 +208,9 @@ class Reference:
         L.ref_online_update_count.argtypes = [C.c_void_p]
         L.ref_model_estep.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p, _i32p, C.c_int, _f64p,
                                       _f64p, C.c_int, C.c_double]
+        L.ref_model_lower_bound.restype = C.c_double
+        L.ref_model_lower_bound.argtypes = [C.c_void_p, C.c_int, C.c_int, _i32p, _i32p, _i32p,
+                                            C.c_int, C.c_int]
         L.ref_online_update_parameters.restype = C.c_double
         L.ref_online_update_parameters.argtypes = [
             C.c_void_p, C.c_int, _i32p, _i32p, _i32p, C.c_int, C.c_int, C.c_double, C.c_double,
@@ -289,6 +306,13 @@ class RefModel:
         if rc != 0:
             raise RuntimeError(self.ref.lib.ref_last_error().decode())
         return gamma, sstats
+
+    def lower_bound(self, indptr, ids, cnts, num_documents=-1, max_iter=100):
+        """LDA::lowerBound (lda.cpp:297-360); gamma0 from the seeded libc stream"""
+        indptr, ids, cnts = _csr(indptr, ids, cnts)
+        return self.ref.lib.ref_model_lower_bound(self.h, int(self.kind == "online"),
+                                                  len(indptr) - 1, indptr, ids, cnts,
+                                                  int(num_documents), int(max_iter))
 
     def update_parameters(self, indptr, ids, cnts, max_iter_tr=10, max_iter_inference=20,
                           kappa=.7, tau=100., rho=-1., adaptive=False, init_gamma=True,

@@ -158,6 +158,24 @@ int ref_model_estep(void *h, int B, const int *indptr, const int *ids, const int
     }
 }
 
+/* LDA::lowerBound -- lda.cpp:297-360 (OnlineLDA overrides the default of num_documents,
+ * onlinelda.cpp:184-191; is_online selects that virtual).  gamma0 is drawn from libc rand(). */
+double ref_model_lower_bound(void *h, int is_online, int B, const int *indptr, const int *ids,
+                             const int *cnts, int num_documents, int max_iter)
+{
+    try {
+        LDA::Documents docs = to_documents(B, indptr, ids, cnts);
+        LDA::Parameters p;
+        p.maxIterInference = max_iter;
+        if (is_online)
+            return static_cast<OnlineLDA *>(h)->lowerBound(docs, p, num_documents);
+        return static_cast<LDA *>(h)->lowerBound(docs, p, num_documents);
+    } catch (TRLDA::Exception &e) {
+        g_last_error = e.message();
+        return 0.;
+    }
+}
+
 /* OnlineLDA::updateParameters -- onlinelda.cpp:53-179, all kwargs of
  * onlineldainterface.cpp:204-256. */
 double ref_online_update_parameters(void *h, int B, const int *indptr, const int *ids,

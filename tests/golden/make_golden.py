@@ -278,6 +278,60 @@ def main():
         np.max(np.abs(gh.T - gr) / np.abs(gr)),
         np.max(np.abs(sh - sr)[sr > 0] / sr[sr > 0])))
 
+    # ---- F11: lower bound on the reference's own test_lower_bound set-up --------------
+    # (onlinelda_test.py:72-95: K=22, W=100, D=30, 15 documents; the test asks for 1 %
+    # agreement with Hoffman's approx_bound).  Values recorded:
+    #   elbo_ref      the compiled reference (release build, -DNDEBUG as distutils passes:
+    #                 lda.cpp:334 then reads psiLambda by row -- see DESIGN.md)
+    #   elbo_oracle   oracle/cpu_ref.c with the column indexing (what the product computes);
+    #                 the same restatement with reference_indexing=1 equals elbo_ref
+    #   elbo_hoffman  onlineldavb.approx_bound on the reference's gamma
+    W, K, D, N = 100, 22, 30, 60
+    rs = np.random.RandomState(777)
+    vocab = ["w" + chr(97 + i // 26) + chr(97 + i % 26) for i in range(W)]
+    hm = onlineldavb.OnlineLDA(vocab, K, D, 0.1, 0.3, 1024., 0.9)
+    lam = np.asfortranarray(hm._lambda)
+    docs = [[(int(w), 1 + int(rs.randint(4))) for w in rs.permutation(W)[:1 + rs.randint(N)]]
+            for _ in range(D // 2)]
+    n = np.array([len(d) for d in docs])
+    indptr = np.zeros(len(docs) + 1, np.int32)
+    indptr[1:] = np.cumsum(n)
+    flat = np.array([t for d in docs for t in d], dtype=np.int32)
+    ids11, cnts11 = flat[:, 0].copy(), flat[:, 1].copy()
+    m = ref.online(W, K, D, alpha=.1, eta=.3)
+    m.lambdas = lam
+    ref.seed(2024)
+    elbo_ref = m.lower_bound(indptr, ids11, cnts11, -1, 100)
+    ref.seed(2024)
+    g11, s11 = m.estep(indptr, ids11, cnts11, None, 100)
+    orc = pyoracle.Oracle()
+    factor = D / float(len(docs))
+    e_same = orc.lower_bound(lam, .1, .3, indptr, ids11, cnts11, g11, s11, factor, True)
+    assert abs(e_same - elbo_ref) < 1e-10 * abs(elbo_ref), (e_same, elbo_ref)
+    elbo_oracle = orc.lower_bound(lam, .1, .3, indptr, ids11, cnts11, g11, s11, factor, False)
+    docs0 = [tuple(zip(*doc)) for doc in docs]
+    elbo_hoffman = hm.approx_bound(docs0, gamma=np.ascontiguousarray(g11.T))
+    # a second case with K > 64 and ids well beyond K, not from Hoffman
+    K2, V2, B2 = 70, 900, 24
+    ip2, ii2, cc2 = make_corpus(B2, V2, seed=99, mean_unique=40)
+    ref.seed(5)
+    m2 = ref.online(V2, K2, 1000, alpha=.1, eta=.3)
+    lam2 = m2.lambdas
+    ref.seed(6)
+    elbo_ref2 = m2.lower_bound(ip2, ii2, cc2, 500, 100)
+    ref.seed(6)
+    g12, s12 = m2.estep(ip2, ii2, cc2, None, 100)
+    e_same2 = orc.lower_bound(lam2, .1, .3, ip2, ii2, cc2, g12, s12, 500. / B2, True)
+    assert abs(e_same2 - elbo_ref2) < 1e-10 * abs(elbo_ref2), (e_same2, elbo_ref2)
+    elbo_oracle2 = orc.lower_bound(lam2, .1, .3, ip2, ii2, cc2, g12, s12, 500. / B2, False)
+    save("f11_lower_bound", K=K, V=W, D=D, indptr=indptr, ids=ids11, cnts=cnts11, lam=lam,
+         seed=2024, gamma_ref=g11, sstats_ref=s11, elbo_ref=elbo_ref, elbo_oracle=elbo_oracle,
+         elbo_hoffman=elbo_hoffman,
+         K2=K2, V2=V2, indptr2=ip2, ids2=ii2, cnts2=cc2, lam2=lam2, seed2=6, num_documents2=500,
+         gamma_ref2=g12, sstats_ref2=s12, elbo_ref2=elbo_ref2, elbo_oracle2=elbo_oracle2)
+    print("lower bound: reference %.6f  column-indexed %.6f  hoffman %.6f" % (
+        elbo_ref, elbo_oracle, elbo_hoffman))
+
 
 if __name__ == "__main__":
     main()

@@ -281,6 +281,37 @@ def test_cumulative_lda_golden(hip):
         assert np.array_equal(m2.lambdas, m.lambdas)
 
 
+def test_lower_bound_golden(hip, oracle):
+    """model.lower_bound (lda.cpp:297-360) on the reference's own test_lower_bound set-up and
+    on a K > 64 case with a target num_documents: equal to the pinned oracle (which equals
+    Hoffman's approx_bound, the reference test's yardstick, onlinelda_test.py:94-95), and
+    within 1e-3 of the compiled reference, whose lda.cpp:334 reads a row where the word's
+    column is meant."""
+    import trlda_amd
+    from trlda_amd.models import OnlineLDA
+    f = golden("f11_lower_bound")
+    m = OnlineLDA(num_words=int(f["V"]), num_topics=int(f["K"]), num_documents=int(f["D"]),
+                  alpha=.1, eta=.3)
+    m.lambdas = f["lam"]
+    trlda_amd.seed(int(f["seed"]))
+    got = m.lower_bound(csr(f))
+    assert abs(got - float(f["elbo_oracle"])) < 1e-9 * abs(float(f["elbo_oracle"]))
+    assert abs(got - float(f["elbo_hoffman"])) < 1e-9 * abs(float(f["elbo_hoffman"]))
+    assert abs(got - float(f["elbo_ref"])) < 1e-3 * abs(float(f["elbo_ref"]))
+    m2 = OnlineLDA(num_words=int(f["V2"]), num_topics=int(f["K2"]), num_documents=1000,
+                   alpha=.1, eta=.3)
+    m2.lambdas = f["lam2"]
+    trlda_amd.seed(int(f["seed2"]))
+    got2 = m2.lower_bound(csr(f, "2"), num_documents=int(f["num_documents2"]))
+    assert abs(got2 - float(f["elbo_oracle2"])) < 1e-9 * abs(float(f["elbo_oracle2"]))
+    # the default target of an OnlineLDA is its own num_documents (onlinelda.cpp:184-191)
+    trlda_amd.seed(int(f["seed2"]))
+    m2.num_documents = int(f["num_documents2"])
+    assert m2.lower_bound(csr(f, "2")) == got2
+    with pytest.raises(NotImplementedError):
+        m2.lower_bound(csr(f, "2"), inference_method="gibbs")
+
+
 def test_reference_readme_example(hip, tmp_path):
     """README.md:36-59 of the reference, verbatim but for the package name and sizes."""
     from trlda_amd.models import OnlineLDA

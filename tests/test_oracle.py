@@ -197,3 +197,25 @@ def test_live_reference_default_gamma_stream(oracle, reference):
     g0 = seeded_gamma(oracle, 10, K, B)
     go, so, _ = oracle.estep(lam, .1, ip, ii, cc, g0, 15, 1e-3)
     assert relerr(go, gr) < RTOL
+
+
+def test_lower_bound_restatement(oracle):
+    """oracle_lower_bound against the compiled reference's LDA::lowerBound (lda.cpp:297-360)
+    on the reference's own test_lower_bound set-up (onlinelda_test.py:72-95) and on a case with
+    word ids far beyond K.  With reference_indexing it reproduces the reference's release
+    build, including the row-for-column read of lda.cpp:334; without it (the formula the
+    product implements) it lands on Hoffman's approx_bound, which is the yardstick of the
+    reference's own test (1 %)."""
+    f = golden("f11_lower_bound")
+    for sfx, factor in (("", float(f["D"]) / (len(f["indptr"]) - 1)),
+                        ("2", float(f["num_documents2"]) / (len(f["indptr2"]) - 1))):
+        args = (f["lam" + sfx], .1, .3, f["indptr" + sfx], f["ids" + sfx], f["cnts" + sfx],
+                f["gamma_ref" + sfx], f["sstats_ref" + sfx], factor)
+        same = oracle.lower_bound(*args, reference_indexing=True)
+        fixed = oracle.lower_bound(*args, reference_indexing=False)
+        ref, want = float(f["elbo_ref" + sfx]), float(f["elbo_oracle" + sfx])
+        assert abs(same - ref) < 1e-12 * abs(ref)
+        assert abs(fixed - want) < 1e-12 * abs(want)
+        assert 0 < abs(fixed - ref) < 1e-3 * abs(ref)     # the indexing matters, a little
+    assert abs(float(f["elbo_oracle"]) - float(f["elbo_hoffman"])) < 1e-9 * abs(float(f["elbo_hoffman"]))
+

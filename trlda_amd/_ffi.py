@@ -72,6 +72,8 @@ _SIGNATURES = {
                                            C.c_double, vp]),
     "trlda_model_cumulative_update": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double,
                                                 vp]),
+    "trlda_model_lower_bound": (C.c_int, [vp, vp, f64p, C.c_double, C.c_double, C.c_int, C.c_double,
+                                C.POINTER(C.c_double)]),
     "trlda_debug_fold16": (C.c_int, [C.c_int, vp, vp, vp, vp]),
     "trlda_model_set_doc_kernel": (C.c_int, [vp, C.c_int]),
     "trlda_debug_digamma": (C.c_int, [C.c_int, C.c_int, vp, vp, vp, vp, vp]),

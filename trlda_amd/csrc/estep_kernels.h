@@ -137,7 +137,7 @@ constexpr int kRowsumBlocks = 64;
 template <int T>
 __global__ __launch_bounds__(T) void exp_elog_beta_kernel(
     int K, size_t total, int G, const double *__restrict__ lambda,
-    const double *__restrict__ partial, double *__restrict__ psi_sum_out,
+    const double *__restrict__ partial, double *__restrict__ psi_sum_out /* 2K: psi, then sums */,
     double *__restrict__ eeb, const int32_t *__restrict__ active /* word ids or nullptr */)
 {
     extern __shared__ double psi_sum[];             // K, then 8 x K scratch
@@ -166,10 +166,13 @@ __global__ __launch_bounds__(T) void exp_elog_beta_kernel(
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             v[u] = scratch[u * K + k];
-        const double ps = digamma(((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])));
+        const double rs = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        const double ps = digamma(rs);
         psi_sum[k] = ps;
-        if (blockIdx.x == 0)
-            psi_sum_out[k] = ps;                     // kept for inspection / later kernels
+        if (blockIdx.x == 0) {
+            psi_sum_out[k] = ps;                     // kept for later kernels (elbo_kernels.h)
+            psi_sum_out[K + k] = rs;
+        }
     }
     __syncthreads();
 

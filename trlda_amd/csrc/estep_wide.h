@@ -36,10 +36,17 @@ struct wide_cfg {
 #ifdef TRLDA_WIDE_JW
     static constexpr int JW = TRLDA_WIDE_JW;
 #else
-    static constexpr int JW = KS == 1 ? 32 : KS == 2 ? 28 : KS == 3 ? 18 : KS == 4 ? 12
+    static constexpr int JW = KS == 1 ? 32 : KS == 2 ? 24 : KS == 3 ? 16 : KS == 4 ? 12
                               : KS == 5 ? 12 : KS == 6 ? 10 : 8;
 #endif
-    static constexpr bool LEAN_PSI = KS > 1;
+#ifdef TRLDA_WIDE_LEAN_PSI
+    static constexpr bool LEAN_PSI = TRLDA_WIDE_LEAN_PSI;
+#else
+    // up to 256 topics exp(psi) runs on four waves that sit on four different SIMDs: latency
+    // bound, so the version scheduled for instruction-level parallelism; beyond that two
+    // waves share a SIMD and the register-lean version is as fast and leaves room for data
+    static constexpr bool LEAN_PSI = KS > 4;
+#endif
     static constexpr int NH = (JW + 7) / 8;          // groups of 8 register slots (one fold each)
     static constexpr int NSET = KS >= 8 ? 1 : KS >= 4 ? 2 : KS >= 2 ? 4 : 8;   // >= 8 fma chains
     static constexpr int TCH = KS <= 4 ? 4 : 2;      // words of a tail chunk (TCH * KS <= 16)

@@ -21,6 +21,7 @@
 #include "../../include/trlda_hip.h"
 #include "estep_kernels.h"
 #include "estep_wide.h"
+#include "elbo_kernels.h"
 
 namespace {
 
@@ -815,7 +816,7 @@ int trlda_model_create(trlda_model **out, int device, int K, int V)
     rc = dev_alloc(&m->lambda, KV);
     if (!rc) rc = dev_alloc(&m->eeb, KV);
     if (!rc) rc = dev_alloc(&m->alpha, (size_t)K);
-    if (!rc) rc = dev_alloc(&m->psi_sum, (size_t)K);
+    if (!rc) rc = dev_alloc(&m->psi_sum, 2 * (size_t)K);   // psi(row sums), then the row sums
     if (!rc) rc = dev_alloc(&m->partial, (size_t)kMaxRowsumBlocks * K);
     if (!rc) rc = dev_alloc(&m->counter, 1);
     if (rc) {
@@ -1022,6 +1023,72 @@ int trlda_model_estep_host(trlda_model *m, const trlda_batch *b, double *gamma, 
     if (iters_dev)
         (void)hipFree(iters_dev);
     return rc;
+}
+
+// LDA::lowerBound, src/lda.cpp:297-360 (see csrc/elbo_kernels.h)
+int trlda_model_lower_bound(trlda_model *m, const trlda_batch *b, double *gamma, double eta,
+                            double factor, int max_iter, double threshold, double *bound_out)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!b || !bound_out || (b->B > 0 && !gamma))
+        return fail(TRLDA_ERR_ARG, "NULL batch / gamma / bound");
+    if (b->B <= 0)
+        return fail(TRLDA_ERR_ARG, "the lower bound needs at least one document");
+    rc = ensure_update_workspace(m, b->B);
+    if (rc)
+        return rc;
+    const int K = m->K, V = m->V, B = b->B;
+    const size_t KV = (size_t)K * V;
+    const size_t gbytes = (size_t)K * B * sizeof(double);
+    HIP_TRY(hipMemcpyAsync(m->gamma, gamma, gbytes, hipMemcpyHostToDevice, m->stream));
+    rc = estep_device(m, b, m->gamma, m->sstats, max_iter, threshold, nullptr);   // :309
+    if (rc)
+        return rc;
+    const int G = (int)std::min<size_t>((KV + kDenseThreads - 1) / kDenseThreads, 1024);
+    double *out = nullptr;
+    rc = dev_alloc(&out, 2 * (size_t)G + 2 * (size_t)B);
+    if (rc)
+        return rc;
+    hipLaunchKernelGGL(trlda::elbo_dense_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads), 0,
+                       m->stream, K, KV, eta, factor, m->lambda, m->psi_sum, m->sstats, out);
+    const size_t lds = ((size_t)K + 4 * (kDenseThreads / trlda::kWave)) * sizeof(double);
+    hipLaunchKernelGGL(trlda::elbo_docs_kernel<kDenseThreads>, dim3(B), dim3(kDenseThreads), lds,
+                       m->stream, K, b->indptr, b->ids, b->cnts, m->lambda, m->psi_sum, m->alpha,
+                       m->gamma, out + 2 * (size_t)G);
+    std::vector<double> h(2 * (size_t)G + 2 * (size_t)B), lam_sum((size_t)K), alpha_h((size_t)K);
+    hipError_t e1 = hipMemcpyAsync(h.data(), out, h.size() * sizeof(double), hipMemcpyDeviceToHost,
+                                   m->stream);
+    hipError_t e2 = hipMemcpyAsync(gamma, m->gamma, gbytes, hipMemcpyDeviceToHost, m->stream);
+    hipError_t e3 = hipMemcpyAsync(alpha_h.data(), m->alpha, (size_t)K * sizeof(double),
+                                   hipMemcpyDeviceToHost, m->stream);
+    hipError_t e4 = hipStreamSynchronize(m->stream);
+    (void)hipFree(out);
+    HIP_TRY(e1); HIP_TRY(e2); HIP_TRY(e3); HIP_TRY(e4);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(lam_sum.data(), m->psi_sum + K, (size_t)K * sizeof(double),
+                      hipMemcpyDeviceToHost));
+    double pw_pb = 0.0, lg_lambda = 0.0, pz = 0.0, ptheta = 0.0;
+    for (int g = 0; g < G; ++g) {
+        pw_pb += h[2 * (size_t)g];
+        lg_lambda += h[2 * (size_t)g + 1];
+    }
+    for (int d = 0; d < B; ++d) {
+        pz += h[2 * (size_t)G + 2 * (size_t)d];
+        ptheta += h[2 * (size_t)G + 2 * (size_t)d + 1];
+    }
+    double alpha_sum = 0.0, lg_alpha = 0.0, lg_lambda_sum = 0.0;
+    for (int k = 0; k < K; ++k) {
+        alpha_sum += alpha_h[(size_t)k];
+        lg_alpha += std::lgamma(alpha_h[(size_t)k]);
+        lg_lambda_sum += std::lgamma(lam_sum[(size_t)k]);
+    }
+    ptheta += (std::lgamma(alpha_sum) - lg_alpha) * B;                     // :355
+    pw_pb += K * std::lgamma(V * eta) - lg_lambda_sum;                     // :356
+    pw_pb -= (double)K * V * std::lgamma(eta) - lg_lambda;                 // :357
+    *bound_out = pw_pb + factor * pz + factor * ptheta;                    // :359
+    return TRLDA_OK;
 }
 
 int trlda_model_blend(trlda_model *m, const double *lambda_prime_dev, const double *sstats_dev,

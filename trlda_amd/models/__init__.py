@@ -230,12 +230,40 @@ class LDA(Distribution):
 
     do_e_step = update_variables                                     # module.cpp:103-106
 
-    # -- not on the accelerated path ----------------------------------------------
+    # -- the variational lower bound (ldainterface.cpp:394-470 -> lda.cpp:297-360) ----------
+    def _default_num_documents(self):
+        return -1                                                    # lda.h: numDocuments = -1
+
     def lower_bound(self, docs, num_documents=-1, inference_method='VI', max_iter=100,
                     num_samples=1, burn_in=2):
-        raise NotImplementedError("lower_bound (lda.cpp:297-360) is not on the accelerated path "
-                                  "yet (SURVEY.md 8f rank 3).")
+        """Estimate of the lower bound on the given documents (fresh E-step from a random
+        gamma drawn from the seeded libc stream, as the reference does), scaled to
+        ``num_documents`` when that is given."""
+        method = _inference_method(inference_method)
+        if method != "VI":
+            raise NotImplementedError(
+                "Gibbs inference (lda.cpp:224-293) is outside the accelerated path.")
+        num_documents = int(num_documents)
+        if num_documents < 0:
+            num_documents = self._default_num_documents()            # onlinelda.cpp:184-191
+        batch, owned = self._batch(docs)
+        try:
+            B = len(batch)
+            if B == 0:
+                raise RuntimeError("The lower bound needs at least one document.")
+            L = _ffi.lib()
+            gamma = np.empty((self._K, B), dtype=np.float64, order="F")
+            L.trlda_sample_gamma_init(self._K, B, gamma)              # lda.cpp:309 -> :135
+            factor = num_documents / float(B) if num_documents >= 0 else 1.   # lda.cpp:302-303
+            bound = C.c_double(0.)
+            _ffi.check(L.trlda_model_lower_bound(self._handle, batch.handle, gamma, self._eta,
+                                                 factor, int(max_iter), 0.001, C.byref(bound)))
+        finally:
+            if owned:
+                batch.close()
+        return bound.value
 
+    # -- not on the accelerated path ----------------------------------------------
     def sample(self, num_documents, length):
         raise NotImplementedError("sample (lda.cpp:88-115) is outside the accelerated path.")
 
@@ -264,6 +292,9 @@ class OnlineLDA(LDA):
         self._ada_sq_norm = 1.
         self._ada_gradient = None
         self._setup(num_words, num_topics, alpha, eta, device)
+
+    def _default_num_documents(self):
+        return self._num_documents                                   # onlinelda.cpp:184-191
 
     @property
     def num_documents(self):
