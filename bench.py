@@ -198,14 +198,20 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("estep_docs_kernel_hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            # measured for the default workload only
+            if tj.get("kernel", "").endswith(doc_kernel) and (K, V, args.batch) == (100, 7000, 200):
+                traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     kernel_names = list(KERNEL_NAMES)
+    # the document stage under the name rocprofv3 lists it by (profiles/*_kernel_stats.csv)
+    doc_kernel = (L.trlda_model_last_doc_kernel(model) or b"estep_docs_kernel").decode()
+    kernel_names[2] = doc_kernel
     if args.sstats_mode == "atomic":
         kernel_names[3] = "finish_kernel"
     roofline = {
-        "bound": "hbm", "kernel": "estep_docs_kernel",
+        "bound": "hbm", "kernel": "trlda::" + doc_kernel,
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
         "algorithmic_bytes_per_launch": docs_bytes,

@@ -149,6 +149,9 @@ int trlda_model_set_doc_threads(trlda_model *model, int threads);
 #define TRLDA_DOCS_GENERAL 1
 #define TRLDA_DOCS_WIDE 2
 int trlda_model_set_doc_kernel(trlda_model *model, int kind);
+/* name (as a profiler lists it, without template arguments) of the document kernel that
+ * took most documents of the model's last E-step; "" before the first */
+const char *trlda_model_last_doc_kernel(const trlda_model *model);
 int trlda_model_synchronize(trlda_model *model);
 
 int trlda_model_set_lambda(trlda_model *model, const double *host_lambda /* K x V */);

@@ -1,0 +1,34 @@
+"""profiles/traffic.json from the two PMC summaries of tools/make_profiles.sh:
+   python tools/make_traffic.py <fetch summary> <write summary> <doc kernel name> > profiles/traffic.json
+HBM bytes per launch of the dominant kernel, with the gfx950 correction of
+MI355X_MICROARCH.md (HBM section): FETCH_SIZE tallies 128-B requests at 64 B."""
+import json
+import sys
+
+
+def parse(path):
+    out, name = {}, None
+    for line in open(path):
+        if not line.startswith(" "):
+            name = line.strip().replace("void ", "").split("<")[0]
+        elif name:
+            parts = line.split()
+            out.setdefault(name, {})[parts[0]] = float(parts[2])
+    return out
+
+
+fetch, write = parse(sys.argv[1]), parse(sys.argv[2])
+kernel = "trlda::" + sys.argv[3]
+per = {k: {"FETCH_SIZE": fetch[k]["FETCH_SIZE"], "WRITE_SIZE": write.get(k, {}).get("WRITE_SIZE")}
+       for k in fetch}
+f, w = per[kernel]["FETCH_SIZE"], per[kernel]["WRITE_SIZE"]
+print(json.dumps({
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, kernel-trace only "
+              "(tools/make_profiles.sh); counters are in KB per dispatch, mean over dispatches",
+    "workload": "python3 bench.py --no-cpu-baseline --steps 50 --warmup 5 (K=100, V=7000, 200 documents/step)",
+    "kernel": kernel,
+    "fetch_size_kb": f, "write_size_kb": w,
+    "correction": "MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, "
+                  "i.e. reports half the bytes of a coalesced stream: doubled here; WRITE_SIZE taken as is",
+    "hbm_bytes_per_launch": (2 * f + w) * 1024.0,
+    "per_kernel_kb": per}, indent=1))

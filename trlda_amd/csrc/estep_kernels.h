@@ -836,7 +836,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
             const double ek = e_old[kk], ak = alpha_l[kk];
             const double acc = sum8_strided<kRegPart>(part + kk);
             const double gnew = acc * ek + ak;
-            const double enew = exp_digamma(gnew);
+            const double enew = TAIL ? exp_digamma_minus_lean(gnew, 0.0) : exp_digamma(gnew);
             if (psi_on) {
                 g_new[k_psi] = gnew;
                 e_new[k_psi] = enew;

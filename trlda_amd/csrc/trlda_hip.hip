@@ -98,6 +98,7 @@ struct trlda_model {
     int sstats_mode = TRLDA_SSTATS_SEGMENTED;
     int doc_threads = 0;
     int doc_kernel = 0;    // TRLDA_DOCS_*
+    const char *last_doc_kernel = "";   // kernel that took most documents of the last E-step
     bool dense_preamble = false;   // true: exp E[log beta] for all V words, as the reference
     double *lambda = nullptr, *alpha = nullptr;
     double *eeb = nullptr, *psi_sum = nullptr, *partial = nullptr;
@@ -327,6 +328,10 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
         const bool wide = m->doc_threads == 0 && K <= kWideMaxK && m->doc_kernel != TRLDA_DOCS_GENERAL;
         const int n_stream = B - n_reg;
 
+        if (B - n_reg >= n_reg)
+            m->last_doc_kernel = wide ? "estep_docs_wide_kernel" : "estep_docs_kernel";
+        else
+            m->last_doc_kernel = "estep_docs_reg_kernel";
         if (wide && B - n_reg > 0) {
             const int n_wide = B - n_reg;
             const int KS = (K + kWave - 1) / kWave;
@@ -876,6 +881,8 @@ int trlda_model_set_dense_preamble(trlda_model *m, int dense)
     m->dense_preamble = dense != 0;
     return TRLDA_OK;
 }
+
+const char *trlda_model_last_doc_kernel(const trlda_model *m) { return m ? m->last_doc_kernel : ""; }
 
 int trlda_model_set_doc_kernel(trlda_model *m, int kind)
 {
