@@ -539,6 +539,40 @@ def test_single_orientation_kernel(hip, oracle, sampler, K, mode):
         assert np.array_equal(iters, ito)
 
 
+@pytest.mark.parametrize("K,V,lens", [
+    (1, 50, [3, 0, 7, 50]), (2, 1, [1, 1, 0]), (3, 5, [0, 0, 0]), (513, 700, [5, 130, 300]),
+    (600, 900, [1, 64, 200]), (100, 3000, [2500]), (128, 400, [400, 399, 1]),
+    (129, 400, [400, 12]), (64, 2000, [1999, 1500, 3])])
+def test_odd_shapes(hip, oracle, K, V, lens):
+    """One topic, one word, a batch of empty documents, more than 512 topics (general kernel),
+    a document holding most of the vocabulary: both statistics modes against the oracle."""
+    from trlda_amd.documents import CSRDocuments
+    rng = np.random.RandomState(3 + K)
+    ip, ids, cnts = [0], [], []
+    for n in lens:
+        ids += list(rng.permutation(V)[:n])
+        cnts += list(rng.randint(5, size=n))
+        ip.append(ip[-1] + n)
+    ip, ids, cnts = np.array(ip, np.int32), np.array(ids, np.int32), np.array(cnts, np.int32)
+    hip.trlda_seed(K)
+    lam = np.empty((K, V), order="F")
+    hip.trlda_sample_gamma_init(K, V, lam)
+    g0 = np.empty((K, len(lens)), order="F")
+    hip.trlda_sample_gamma_init(K, len(lens), g0)
+    m = make_model(K, V, lam)
+    go, so, ito = oracle.estep(lam, .1, ip, ids, cnts, g0, 30, 1e-3)
+    for mode in (0, 1):
+        hip.trlda_model_set_sstats_mode(m._handle, mode)
+        g, s, it = m.update_variables(CSRDocuments(ip, ids, cnts), latents=g0, max_iter=30,
+                                      threshold=1e-3, return_iterations=True)
+        assert relerr(g, go) < TIGHT_RTOL
+        if (so > 0).any():
+            check_sstats(s, so, rtol=TIGHT_RTOL if mode == 0 else 1e-8)
+        else:
+            assert not s.any()
+        assert np.array_equal(it, ito)
+
+
 def test_converged_documents_stop_early(hip, oracle, sampler):
     """The data-dependent break (lda.cpp:202-203): iteration counts below max_iter, equal to
     the oracle's, per document."""
