@@ -257,16 +257,17 @@ int trlda_model_cumulative_update(trlda_model *model, const trlda_batch *batch, 
 /* ---- test hook ----------------------------------------------------------- */
 
 /* The device digamma (TRLDA::digamma, src/digamma.cpp:116-178, as compiled for gfx950)
- * evaluated at n host points: whole[i] = psi(x[i]); piecesN[i] = exp(psi(x[i])) assembled
- * from the N independent pieces the document kernels distribute over wavefronts (the form
- * the hot path uses: lda.cpp:173-174, :197 only ever need exp(psi)).  Lets the parity tests
- * check the special functions against the reference's table directly. */
+ * evaluated at n host points: psi[i] = psi(x[i]); epsi[i] = exp(psi(x[i])) in the log-free
+ * form the hot path uses (lda.cpp:173-174, :197 only ever need exp(psi)); epsi_lean[i] = the
+ * register-lean schedule of the same value (bitwise equal); eminus[i] = exp(psi(x[i]) - c)
+ * (lda.cpp:173).  Lets the parity tests check the special functions against the reference's
+ * table directly. */
+int trlda_debug_digamma(int device, int n, double c, const double *x, double *psi, double *epsi,
+                        double *epsi_lean, double *eminus);
 /* test hook: the transposing wave reductions of csrc/estep_wide.h on a 64 x 16 table
  * (row = lane); out16 / out4 / out2 [64] = what each lane receives from the 16-, 4- and
  * 2-value folds of its row's leading values */
 int trlda_debug_fold16(int device, const double *in, double *out16, double *out4, double *out2);
-int trlda_debug_digamma(int device, int n, const double *x, double *whole, double *pieces2,
-                        double *pieces4, double *pieces8);
 
 /* ---- measurement --------------------------------------------------------- */
 

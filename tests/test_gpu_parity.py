@@ -52,33 +52,36 @@ def test_native_library_is_loaded(hip):
 
 
 def test_device_digamma_table(hip):
-    """The device psi -- whole, and assembled from the 2 / 4 / 8 pieces the document kernels
-    spread over wavefronts -- against the reference's table (log grid 1e-6..1e6, small
-    integers, reflection branch) and its three known answers (utils_test.py:33-51)."""
+    """The device psi, and exp(psi) in the log-free form the kernels use -- latency-scheduled,
+    register-lean (bitwise the same) and with the subtrahend of lda.cpp:173 -- against the
+    reference's table (log grid 1e-6..1e6, small integers, reflection branch) and its three
+    known answers (utils_test.py:33-51)."""
     f = golden("f0_rng_psi")
     x = np.ascontiguousarray(f["psi_x"])
     want = f["psi_y"]
+    c = 1.75
     outs = [np.zeros_like(x) for _ in range(4)]
-    rc = hip.trlda_debug_digamma(0, len(x), x.ctypes.data, *[o.ctypes.data for o in outs])
+    rc = hip.trlda_debug_digamma(0, len(x), c, x.ctypes.data, *[o.ctypes.data for o in outs])
     assert rc == 0, hip.trlda_last_error()
     fin = np.isfinite(want)
-    whole, pieces = outs[0], outs[1:]
-    assert np.array_equal(np.isfinite(whole), fin)
+    psi, epsi, epsi_lean, eminus = outs
+    assert np.array_equal(np.isfinite(psi), fin)
     # psi crosses zero near x = 1.4616: use an absolute + relative bound
-    err = np.abs(whole[fin] - want[fin]) / np.maximum(np.abs(want[fin]), 1.0)
+    err = np.abs(psi[fin] - want[fin]) / np.maximum(np.abs(want[fin]), 1.0)
     assert err.max() < 5e-15, (err.max(), x[fin][err.argmax()])
-    # exp(psi) as the kernels compute it: (x + 10) * exp(-t), from 2 / 4 / 8 pieces
     with np.errstate(over="ignore", under="ignore"):
         ewant = np.exp(want)
+        emwant = np.exp(want - c)
     ok = fin & (ewant > 1e-300) & (ewant < 1e300)
-    for got in pieces:
+    for got, ref in ((epsi, ewant), (epsi_lean, ewant), (eminus, emwant)):
         # exp amplifies an absolute error in psi: the bound is relative to max(1, |psi|)
-        rel = np.abs(got[ok] - ewant[ok]) / ewant[ok] / np.maximum(1.0, np.abs(want[ok]))
+        rel = np.abs(got[ok] - ref[ok]) / ref[ok] / np.maximum(1.0, np.abs(want[ok]))
         assert rel.max() < 2e-15, (rel.max(), x[ok][rel.argmax()])
-        assert (got[fin & (ewant == 0)] == 0).all()
+        assert (got[fin & (ref == 0)] == 0).all()
+    assert np.array_equal(epsi[fin], epsi_lean[fin])          # same operations, same order
     kx = np.ascontiguousarray(f["kat_x"])
     ko = [np.zeros_like(kx) for _ in range(4)]
-    assert hip.trlda_debug_digamma(0, len(kx), kx.ctypes.data, *[o.ctypes.data for o in ko]) == 0
+    assert hip.trlda_debug_digamma(0, len(kx), 0., kx.ctypes.data, *[o.ctypes.data for o in ko]) == 0
     assert np.max(np.abs(ko[0] - f["kat_y"])) < 1e-12
     for got in ko[1:]:
         assert np.max(np.abs(got - np.exp(f["kat_y"])) / np.exp(f["kat_y"])) < 1e-13

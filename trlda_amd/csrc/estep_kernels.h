@@ -556,7 +556,7 @@ __global__ __launch_bounds__(T) void estep_docs_kernel(DocKernelArgs a)
 //   lane l owns topics l and l+64 and words l and l+64
 //   wave w (0..7), product B: words [w*JC, (w+1)*JC) of the document, JC <= 16
 //                  product E: topics [w*KC, (w+1)*KC),               KC <= 16
-//                  psi      : topic half w & 1, piece w >> 1 of psi_piece<4>
+//                  psi      : waves 0 and 1, topics 0..63 and 64..127
 // ---------------------------------------------------------------------------
 constexpr int kRegThreads = 512;
 constexpr int kRegMaxK = 128;
@@ -1029,28 +1029,22 @@ __global__ __launch_bounds__(T) void finish_kernel(size_t total, const double *_
         sstats[i] *= eeb[i];
 }
 
-// whole[i] = psi(x[i]); piecesN[i] = exp(psi(x[i])) assembled from N pieces: test hook for the
-// device special functions (tests/test_gpu_parity.py::test_device_digamma_table).
-__global__ void digamma_table_kernel(int n, const double *__restrict__ x, double *__restrict__ whole,
-                                     double *__restrict__ pieces2, double *__restrict__ pieces4,
-                                     double *__restrict__ pieces8)
+// psi[i] = psi(x[i]); epsi[i] = exp(psi(x[i])) as the document kernels compute it (no
+// logarithm); epsi_lean[i] = the register-lean schedule of the same value; eminus[i] =
+// exp(psi(x[i]) - c): test hook for the device special functions
+// (tests/test_gpu_parity.py::test_device_digamma_table).
+__global__ void digamma_table_kernel(int n, double c, const double *__restrict__ x,
+                                     double *__restrict__ psi, double *__restrict__ epsi,
+                                     double *__restrict__ epsi_lean, double *__restrict__ eminus)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
     const double v = x[i];
-    whole[i] = digamma(v);
-    double s2 = 0.0, s4 = 0.0, s8 = 0.0;
-    for (int p = 0; p < 2; ++p)
-        s2 += psi_piece<2>(v, p);
-    for (int p = 0; p < 4; ++p)
-        s4 += psi_piece<4>(v, p);
-    for (int p = 0; p < 8; ++p)
-        s8 += psi_piece<8>(v, p);
-    // the pieces assemble exp(psi(x)) = (x + 10) exp(sum)
-    pieces2[i] = exp_psi_from_pieces(v, s2);
-    pieces4[i] = exp_psi_from_pieces(v, s4);
-    pieces8[i] = exp_psi_from_pieces(v, s8);
+    psi[i] = digamma(v);
+    epsi[i] = exp_digamma(v);
+    epsi_lean[i] = exp_digamma_minus_lean(v, 0.0);
+    eminus[i] = exp_digamma_minus(v, c);
 }
 
 // ---------------------------------------------------------------------------

@@ -218,91 +218,4 @@ __device__ __forceinline__ double exp_digamma_minus_lean(double x, double c)
     return v;
 }
 
-// ---------------------------------------------------------------------------------------
-// exp(psi(x)) cut into independent pieces so that NP wavefronts can each evaluate one piece
-// for the same 64 arguments and a single wavefront combines them:
-//     exp(psi(x)) = (x + 10) * exp(sum_p psi_piece<NP>(x, p))      (p = 0 .. NP-1 in order)
-// The pieces are the independent dependency chains of exp_psi_regular: slices of the
-// reciprocal sum (negated) and the 1/(2s) + series term (negated).  Arguments on the rare
-// branches (x <= 0, small integers, outside [1e-290, 1e290]) are evaluated whole by piece
-// NP-1, which returns psi(x) - log(x + 10); the other pieces contribute 0.
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ bool psi_is_regular(double x)
-{
-    return x > 1e-290 && x < 1e290 && !(x <= 10.0 && x == floor(x));
-}
-
-// -(sum over i in [I0, I1) of c_i / (x + i)), c_i = 1 for the ten recurrence terms i < 10 and
-// c_10 = 1/2: the -1/(2s) term of psi at s = x + 10 is one more reciprocal of the same family
-template <int I0, int I1>
-__device__ __forceinline__ double psi_recurrence_piece(double x)
-{
-    double r[I1 - I0];
-#pragma unroll
-    for (int i = I0; i < I1; ++i) {
-        const double ri = rcp_pos<true>(x + (double)i);
-        r[i - I0] = (i == 10) ? 0.5 * ri : ri;
-    }
-#pragma unroll
-    for (int w = 1; w < I1 - I0; w <<= 1)
-#pragma unroll
-        for (int u = 0; u + w < I1 - I0; u += 2 * w)
-            r[u] += r[u + w];
-    return -r[0];
-}
-
-// -(z * P(z)), z = 1/s^2, s = x + 10: at most 8.4e-4, so z only needs ~1e-13 relative
-// accuracy -- one Newton step on the v_rcp_f64 seed instead of two shortens the chain
-__device__ __forceinline__ double psi_series_piece(double x)
-{
-    const double s = x + 10.0;
-    double r = __builtin_amdgcn_rcp(s);
-    r = fma(fma(-s, r, 1.0), r, r);
-    double y = 0.0;
-    if (s < 1.0e17) {
-        const double z = r * r;
-        y = z * psi_series(z);
-    }
-    return -y;
-}
-
-template <int NP>
-__device__ __forceinline__ double psi_piece(double x, int p)
-{
-    static_assert(NP == 1 || NP == 2 || NP == 4 || NP == 8, "pieces");
-    if (__builtin_expect(!psi_is_regular(x), 0))
-        return p == NP - 1 ? digamma(x) - log(x + 10.0) : 0.0;
-    if (NP == 1)
-        return psi_recurrence_piece<0, 11>(x) + psi_series_piece(x);
-    if (NP == 2) {
-        if (p == 0)
-            return psi_recurrence_piece<0, 6>(x);
-        return psi_recurrence_piece<6, 11>(x) + psi_series_piece(x);
-    }
-    if (NP == 4) {
-        switch (p) {
-        case 0: return psi_recurrence_piece<0, 4>(x);
-        case 1: return psi_recurrence_piece<4, 8>(x);
-        case 2: return psi_recurrence_piece<8, 11>(x);
-        default: return psi_series_piece(x);
-        }
-    }
-    switch (p) {
-    case 0: return psi_recurrence_piece<0, 2>(x);
-    case 1: return psi_recurrence_piece<2, 4>(x);
-    case 2: return psi_recurrence_piece<4, 6>(x);
-    case 3: return psi_recurrence_piece<6, 8>(x);
-    case 4: return psi_recurrence_piece<8, 10>(x);
-    case 5: return psi_recurrence_piece<10, 11>(x);
-    case 6: return 0.0;
-    default: return psi_series_piece(x);
-    }
-}
-
-// combine: exp(psi(x)) from the summed pieces
-__device__ __forceinline__ double exp_psi_from_pieces(double x, double piece_sum)
-{
-    return (x + 10.0) * exp(piece_sum);
-}
-
 }  // namespace trlda

@@ -1391,13 +1391,13 @@ extern "C" int trlda_debug_read_stamps(unsigned long long *host, int blocks)
 
 // ---- device special functions (test hook) -----------------------------------------------
 
-int trlda_debug_digamma(int device, int n, const double *x, double *whole, double *pieces2,
-                        double *pieces4, double *pieces8)
+int trlda_debug_digamma(int device, int n, double c, const double *x, double *psi, double *epsi,
+                        double *epsi_lean, double *eminus)
 {
     int rc = use_device(device);
     if (rc)
         return rc;
-    if (n <= 0 || !x || !whole || !pieces2 || !pieces4 || !pieces8)
+    if (n <= 0 || !x || !psi || !epsi || !epsi_lean || !eminus)
         return fail(TRLDA_ERR_ARG, "bad digamma table arguments");
     double *d = nullptr;
     rc = dev_alloc(&d, (size_t)n * 5);
@@ -1406,12 +1406,12 @@ int trlda_debug_digamma(int device, int n, const double *x, double *whole, doubl
     const size_t bytes = (size_t)n * sizeof(double);
     HIP_TRY(hipMemcpy(d, x, bytes, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(trlda::digamma_table_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, n,
-                       d, d + n, d + 2 * (size_t)n, d + 3 * (size_t)n, d + 4 * (size_t)n);
+                       c, d, d + n, d + 2 * (size_t)n, d + 3 * (size_t)n, d + 4 * (size_t)n);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(whole, d + n, bytes, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(pieces2, d + 2 * (size_t)n, bytes, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(pieces4, d + 3 * (size_t)n, bytes, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(pieces8, d + 4 * (size_t)n, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(psi, d + n, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(epsi, d + 2 * (size_t)n, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(epsi_lean, d + 3 * (size_t)n, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(eminus, d + 4 * (size_t)n, bytes, hipMemcpyDeviceToHost));
     HIP_TRY(hipFree(d));
     return TRLDA_OK;
 }
