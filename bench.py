@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--num-batches", type=int, default=8, help="distinct mini-batches cycled")
     ap.add_argument("--sstats-mode", choices=["segmented", "atomic"], default="segmented")
     ap.add_argument("--doc-threads", type=int, default=0)
+    ap.add_argument("--split-preamble", action="store_true",
+                    help="row sums and exp E[log beta] as two kernels even where one fused launch would do")
     ap.add_argument("--dense-preamble", action="store_true",
                     help="exp E[log beta] for all V words (reference behaviour) instead of the "
                          "batch's active words")
@@ -125,6 +127,7 @@ def main():
     _ffi.check(L.trlda_model_set_sstats_mode(model, 1 if args.sstats_mode == "atomic" else 0))
     _ffi.check(L.trlda_model_set_doc_threads(model, args.doc_threads))
     _ffi.check(L.trlda_model_set_dense_preamble(model, int(args.dense_preamble)))
+    _ffi.check(L.trlda_model_set_split_preamble(model, int(args.split_preamble)))
 
     batches, csrs, gamma0s = [], [], []
     for i in range(args.num_batches):
@@ -210,6 +213,9 @@ def main():
     kernel_names[2] = doc_kernel
     if args.sstats_mode == "atomic":
         kernel_names[3] = "finish_kernel"
+    kernel_pairs = list(zip(kernel_names, kernel_us))
+    if L.trlda_model_last_preamble_fused(model):      # kernels 1 and 2 ran as one launch
+        kernel_pairs = [("preamble_fused_kernel", kernel_us[0])] + kernel_pairs[2:]
     roofline = {
         "bound": "hbm", "kernel": "trlda::" + doc_kernel,
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -217,7 +223,7 @@ def main():
         "algorithmic_bytes_per_launch": docs_bytes,
         "avg_launch_us": round(docs_us, 2),
         "method": "HIP events on the launch stream; replay of the timed steps with stamps on",
-        "kernels_us": {n: round(u, 2) for n, u in zip(kernel_names, kernel_us)},
+        "kernels_us": {n: round(u, 2) for n, u in kernel_pairs},
         "estep": {   # the whole path against SURVEY.md 8(d)'s bytes_alg
             "algorithmic_bytes_per_step": estep_bytes,
             "achieved": round(estep_bytes * args.steps / elapsed / 1e9, 2),

@@ -152,6 +152,12 @@ int trlda_model_set_doc_kernel(trlda_model *model, int kind);
 /* name (as a profiler lists it, without template arguments) of the document kernel that
  * took most documents of the model's last E-step; "" before the first */
 const char *trlda_model_last_doc_kernel(const trlda_model *model);
+/* Small tables whose whole batch fits the register-resident document kernel run the row
+ * sums and exp(psi(lambda)) in one launch (preamble_fused_kernel) and apply the topic factors
+ * exp(-psiSum) in the document kernel; results agree with the two-kernel preamble to a few
+ * ulp.  split = 1 always uses the two kernels.  last_preamble_fused: what the last E-step did. */
+int trlda_model_set_split_preamble(trlda_model *model, int split);
+int trlda_model_last_preamble_fused(const trlda_model *model);
 int trlda_model_synchronize(trlda_model *model);
 
 int trlda_model_set_lambda(trlda_model *model, const double *host_lambda /* K x V */);

@@ -576,6 +576,50 @@ def test_odd_shapes(hip, oracle, K, V, lens):
         assert np.array_equal(it, ito)
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_fused_preamble_agrees_with_the_two_kernel_one(hip, oracle, sampler, mode):
+    """Small tables run row sums + exp(psi(lambda)) as one launch and fold exp(-psiSum) into
+    exp(psi(gamma)) in the document kernel (estep_kernels.h 2b): same gamma / sstats /
+    iteration counts as the two-kernel preamble (a few ulp apart) and as the oracle; a batch
+    with a long document falls back to the two kernels by itself."""
+    from trlda_amd.documents import CSRDocuments
+    from trlda_amd.utils.synthetic import make_corpus
+    K, V, B = 100, 1500, 60
+    ip, ii, cc = make_corpus(B, V, seed=21, mean_unique=70)
+    lam = seeded_lambda(sampler, 51, K, V)
+    g0 = seeded_gamma(sampler, 52, K, B)
+    m = make_model(K, V, lam)
+    hip.trlda_model_set_sstats_mode(m._handle, mode)
+    docs = CSRDocuments(ip, ii, cc)
+    out = {}
+    for split in (0, 1):
+        assert hip.trlda_model_set_split_preamble(m._handle, split) == 0
+        out[split] = m.update_variables(docs, latents=g0, max_iter=40, threshold=1e-3,
+                                        return_iterations=True)
+        assert hip.trlda_model_last_preamble_fused(m._handle) == 1 - split
+    (g1, s1, i1), (g2, s2, i2) = out[0], out[1]
+    assert relerr(g1, g2) < 1e-10 and np.array_equal(i1, i2)     # ulps, 40 iterations on
+    assert relerr(s1[s2 > 0], s2[s2 > 0]) < 1e-10 and np.array_equal(s1 == 0, s2 == 0)
+    go, so, ito = oracle.estep(lam, .1, ip, ii, cc, g0, 40, 1e-3)
+    assert relerr(g1, go) < TIGHT_RTOL and np.array_equal(i1, ito)
+    check_sstats(s1, so, rtol=TIGHT_RTOL if mode == 0 else 1e-8)
+    # the lower bound reads psiSum / the row sums the document kernel left behind
+    import trlda_amd
+    hip.trlda_model_set_split_preamble(m._handle, 0)
+    trlda_amd.seed(9)
+    lb_fused = m.lower_bound(docs)
+    hip.trlda_model_set_split_preamble(m._handle, 1)
+    trlda_amd.seed(9)
+    lb_split = m.lower_bound(docs)
+    assert abs(lb_fused - lb_split) < 1e-11 * abs(lb_split)
+    # one document of 300 words: not the register kernel's batch any more
+    hip.trlda_model_set_split_preamble(m._handle, 0)
+    ip2 = np.array([0, 300], np.int32)
+    ids2 = np.arange(300, dtype=np.int32)
+    m.update_variables(CSRDocuments(ip2, ids2, np.ones(300, np.int32)), max_iter=3)
+    assert hip.trlda_model_last_preamble_fused(m._handle) == 0
+
+
 def test_converged_documents_stop_early(hip, oracle, sampler):
     """The data-dependent break (lda.cpp:202-203): iteration counts below max_iter, equal to
     the oracle's, per document."""

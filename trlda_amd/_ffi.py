@@ -77,6 +77,8 @@ _SIGNATURES = {
     "trlda_debug_fold16": (C.c_int, [C.c_int, vp, vp, vp, vp]),
     "trlda_model_set_doc_kernel": (C.c_int, [vp, C.c_int]),
     "trlda_model_last_doc_kernel": (C.c_char_p, [vp]),
+    "trlda_model_set_split_preamble": (C.c_int, [vp, C.c_int]),
+    "trlda_model_last_preamble_fused": (C.c_int, [vp]),
     "trlda_debug_digamma": (C.c_int, [C.c_int, C.c_int, C.c_double, vp, vp, vp, vp, vp]),
     "trlda_model_set_timing": (C.c_int, [vp, C.c_int]),
     "trlda_model_get_timing": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double),

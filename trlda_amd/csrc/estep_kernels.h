@@ -197,6 +197,137 @@ __global__ __launch_bounds__(T) void exp_elog_beta_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// 2b. Small tables (the register-resident document kernel takes the whole batch): ONE launch
+// instead of kernels 1 and 2.  exp(psi(lambda) - psiSum) = exp(psi(lambda)) * exp(-psiSum):
+// the first factor does not need the row sums, so G workgroups add up the row sums while the
+// others fill u = exp(psi(lambda)) for the batch's active words.  The K factors
+// c_k = exp(-psi(sum_b partial[b][k])) are formed by every document workgroup between two
+// barriers it has anyway (topic_scale_load / _finish) and folded into exp(psi(gamma)):
+//   phinorm_j = sum_k (c_k e_k) u_jk,   gamma_k = alpha_k + (c_k e_k) sum_j tw_j u_jk,
+// so the document kernel works on u with e~ = c e in place of e, leaves e~ in epg, and the
+// statistics kernel's product with "eeb" (= u here) is again sstats (lda.cpp:207-217).
+// Both kernels this replaces spend most of their few microseconds on launch and on waiting
+// for the row sums.  Against the one-exponential form the results move by a few ulp.
+// ---------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(T) void preamble_fused_kernel(
+    int K, int V, int G, int wpb, size_t total, const double *__restrict__ lambda,
+    double *__restrict__ partial /* G x K */, double *__restrict__ u,
+    const int32_t *__restrict__ active /* word ids or nullptr */)
+{
+    __shared__ double red[T];
+    const int tid = threadIdx.x;
+    // row sums: the first G workgroups, words [b * wpb, (b + 1) * wpb) each (K <= T here),
+    // as rowsum_partial_kernel
+    if ((int)blockIdx.x < G) {                       // block-uniform
+        const int w0 = blockIdx.x * wpb;
+        const int w1 = min(V, w0 + wpb);
+        const int slots = T / K;
+        const int slot = tid / K;
+        const int k = tid % K;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        if (slot < slots) {
+            for (int w = w0 + slot; w < w1; w += 16 * slots) {
+                double v[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    v[q] = lambda[(size_t)min(w + q * slots, w1 - 1) * K + k];
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    acc[q & 3] += (w + q * slots < w1) ? v[q] : 0.0;
+            }
+        }
+        red[tid] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        __syncthreads();
+        if (tid < K) {
+            double sum = red[tid];
+            for (int sl = 1; sl < slots; ++sl)
+                sum += red[sl * K + tid];
+            partial[(size_t)blockIdx.x * K + tid] = sum;
+        }
+        return;
+    }
+    // u = exp(psi(lambda)) on the active words, the other workgroups: grid-stride over the
+    // flat index i = a * K + k of (active word a, topic k), two elements per pass so that
+    // their loads overlap
+    // (total < 2^22 here: 32-bit index arithmetic, a 64-bit division costs as much as psi)
+    const unsigned stride = (gridDim.x - G) * T, tot = (unsigned)total, Ku = (unsigned)K;
+    for (unsigned i = (blockIdx.x - G) * T + tid; i < tot; i += 2 * stride) {
+        const unsigned i2 = i + stride;
+        const bool two = i2 < tot;
+        const unsigned j2 = two ? i2 : i;
+        const unsigned a1 = i / Ku, a2 = j2 / Ku;
+        const size_t idx = active ? (size_t)active[a1] * K + (i - a1 * Ku) : i;
+        const size_t idx2 = active ? (size_t)active[a2] * K + (j2 - a2 * Ku) : j2;
+        const double l1 = lambda[idx], l2 = lambda[idx2];
+        const double u1 = exp_digamma(l1), u2 = exp_digamma(l2);
+        u[idx] = u1;
+        if (two)
+            u[idx2] = u2;
+    }
+}
+
+// c[k] = exp(-psi(sum_b partial[b][k])), k < K <= 128, G <= 64 block partials, formed by a
+// workgroup of T = 512 threads in two steps so that the loads can be issued before the
+// workgroup's other (dependent) global loads and consumed after them:
+//   topic_scale_load    task t = (part, k), part < 8: thread t and t + T each fetch the up to
+//                       eight partials of their task (clamped, masked later)
+//   topic_scale_partials  adds them in a fixed order into scratch (8 K doubles of LDS)
+//   topic_scale_combine   (after a barrier) thread k combines the eight parts of topic k in
+//                       order, psi, exp.  Workgroup 0 also leaves psi(sum), the sum and c in
+//                       out[0..3K).
+// The order of additions is the same in every workgroup, so every document sees the same c.
+template <int T>
+__device__ __forceinline__ void topic_scale_load(int K, int G, const double *__restrict__ partial,
+                                                 double (&v)[2][8])
+{
+    const int per = (G + 7) / 8;                     // <= 8
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int t = min((int)threadIdx.x + h * T, 8 * K - 1);
+        const int k = t % K, b0 = (t / K) * per;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            v[h][q] = partial[(size_t)min(b0 + q, G - 1) * K + k];
+    }
+}
+template <int T>
+__device__ __forceinline__ void topic_scale_partials(int K, int G, const double (&v)[2][8],
+                                                     double *scratch)
+{
+    const int per = (G + 7) / 8;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int t = threadIdx.x + h * T;
+        if (t < 8 * K) {
+            const int b0 = (t / K) * per, b1 = min(G, b0 + per);
+            double acc[2] = {0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                acc[q & 1] += (b0 + q < b1) ? v[h][q] : 0.0;
+            scratch[t] = acc[0] + acc[1];            // scratch[part * K + k]
+        }
+    }
+}
+// after a barrier: thread k < K combines the eight parts of topic k -> c_k
+__device__ __forceinline__ double topic_scale_combine(int K, int k, const double *scratch, double *out)
+{
+    double w[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        w[q] = scratch[q * K + k];
+    const double rs = ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
+    const double ps = digamma(rs);
+    const double ck = exp(-ps);
+    if (blockIdx.x == 0 && out) {
+        out[k] = ps;
+        out[K + k] = rs;
+        out[2 * K + k] = ck;
+    }
+    return ck;
+}
+
+// ---------------------------------------------------------------------------
 // 3. Per-document fixed point.  One workgroup of T threads per document.
 //
 // LDS (doubles):  beta[n][Kp] (the document's slice of eeb, row = word, Kp odd so
@@ -254,6 +385,11 @@ struct DocKernelArgs {
     int max_iter;
     double threshold;
     int32_t *iters_out;       // B or nullptr
+    // fused preamble (preamble_fused_kernel): eeb holds exp(psi(lambda)) and the document
+    // kernel scales by c_k = exp(-psiSum_k) itself; nullptr = eeb is already exp E[log beta]
+    const double *partial;    // G x K block partials of the row sums of lambda
+    int G;
+    double *scale_out;        // 3K: psi(sum), sum, c (written by workgroup 0)
 };
 
 // sum_{i<count} a[i] * b[i * stride] with NA independent accumulators.  A dependent fp64
@@ -569,7 +705,7 @@ constexpr int kRegPart = 192;      // row length of the partial-sum arrays
 // of words 128.. of a long document.  g and e are double-buffered (iteration parity) so
 // that the wave forming mean|gamma - last| can read the old values while the two waves that
 // own the topics write the new ones -- no barrier in between.
-constexpr int kRegSmallDoubles = 2 * 128 + 128 + 2 * 144 + 208 + 192 + 8 * kRegPart + 8;
+constexpr int kRegSmallDoubles = 2 * 128 + 2 * 128 + 2 * 144 + 208 + 192 + 8 * kRegPart + 8;
 constexpr size_t kRegLdsBytes = (size_t)(kRegSmallDoubles + 128 * kRegStride) * sizeof(double);
 
 // Sum over the 64 lanes of a wave in 6 DPP steps (row shifts, then row broadcasts); the total
@@ -617,8 +753,14 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
     const int lane = tid & (kWave - 1);
     const int wid = __builtin_amdgcn_readfirstlane(tid / kWave);
 
-    const int d = a.order[blockIdx.x];
     const int K = a.K;
+    // fused preamble: the block partials of the row sums are fetched first -- they depend on
+    // nothing -- and consumed once the row loads below are in flight
+    double pv[2][8];
+    if (a.partial)                                   // launch-uniform
+        topic_scale_load<T>(K, a.G, a.partial, pv);
+
+    const int d = a.order[blockIdx.x];
     const int p0 = a.indptr[d];
     const int n = a.indptr[d + 1] - p0;
     const int32_t *__restrict__ ids = a.ids + p0;
@@ -626,7 +768,8 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
 
     double *gbuf = lds;               // 2 x 128
     double *alpha_l = gbuf + 256;     // 128
-    double *ebuf = alpha_l + 128;     // 2 x 144
+    double *c_l = alpha_l + 128;      // 128: exp(-psiSum_k) (fused preamble) or 1
+    double *ebuf = c_l + 128;         // 2 x 144
     double *tw = ebuf + 288;          // 208
     double *cntd = tw + 208;          // 192
     double *part = cntd + 192;        // 8 x 192
@@ -666,17 +809,20 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
 
     double *gamma_d = a.gamma + (size_t)d * K;
     const double *gamma0_d = a.gamma_in + (size_t)d * K;
-    for (int k = tid; k < 144; k += T) {             // lda.cpp:174
-        double ev = 0.0;
-        if (k < K) {
-            const double gk = gamma0_d[k];
-            gbuf[k] = gk;
-            alpha_l[k] = a.alpha[k];
-            ev = exp_digamma(gk);
+    double e0 = 0.0;                                 // thread k < K: exp(psi(gamma0_k))
+    if (tid < 144) {                                 // lda.cpp:174
+        if (tid < K) {
+            const double gk = gamma0_d[tid];
+            gbuf[tid] = gk;
+            alpha_l[tid] = a.alpha[tid];
+            e0 = exp_digamma(gk);
         }
-        ebuf[k] = ev;                                // zero beyond K, in both buffers
-        ebuf[144 + k] = 0.0;
+        ebuf[144 + tid] = 0.0;                       // zero beyond K, in both buffers
+        if (!a.partial || tid >= K)
+            ebuf[tid] = e0;
     }
+    if (a.partial)                                   // launch-uniform; `part` is idle until
+        topic_scale_partials<T>(K, a.G, pv, part);   // the first product
     for (int j = tid; j < 208; j += T) {
         tw[j] = 0.0;
         if (j < 192)
@@ -698,6 +844,16 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
         }
     }
     __syncthreads();
+    // fused preamble: thread k forms c_k = exp(-psiSum_k) from the partial sums parked in
+    // `part` and scales its exp(psi(gamma0_k)) -- while the other waves read the transposition
+    if (tid < K) {
+        double ck = 1.0;
+        if (a.partial) {                             // launch-uniform
+            ck = topic_scale_combine(K, tid, part, a.scale_out);
+            ebuf[tid] = e0 * ck;
+        }
+        c_l[tid] = ck;
+    }
     double bE0[16], bE1[16];          // beta[lane][k0+i], beta[lane+64][k0+i]
     {
         // rows at or beyond W*JC were never written: read row 0 instead and zero the value
@@ -781,6 +937,8 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
 
     const int k_psi = (wid & 1) * 64 + lane;         // topic of this lane in the psi stage
     const bool psi_on = k_psi < K;
+    // e is kept as c_k exp(psi(gamma_k)) throughout (c = 1 without the fused preamble)
+    const double c_psi = c_l[psi_on ? k_psi : 0];
 
     int it = 0;
     while (it < a.max_iter) {                        // lda.cpp:185-204
@@ -836,7 +994,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
             const double ek = e_old[kk], ak = alpha_l[kk];
             const double acc = sum8_strided<kRegPart>(part + kk);
             const double gnew = acc * ek + ak;
-            const double enew = TAIL ? exp_digamma_minus_lean(gnew, 0.0) : exp_digamma(gnew);
+            const double enew = (TAIL ? exp_digamma_minus_lean(gnew, 0.0) : exp_digamma(gnew)) * c_psi;
             if (psi_on) {
                 g_new[k_psi] = gnew;
                 e_new[k_psi] = enew;

@@ -99,6 +99,8 @@ struct trlda_model {
     int doc_threads = 0;
     int doc_kernel = 0;    // TRLDA_DOCS_*
     const char *last_doc_kernel = "";   // kernel that took most documents of the last E-step
+    bool last_preamble_fused = false;
+    bool split_preamble = false;        // never fuse kernels 1 and 2 (tests, comparisons)
     bool dense_preamble = false;   // true: exp E[log beta] for all V words, as the reference
     double *lambda = nullptr, *alpha = nullptr;
     double *eeb = nullptr, *psi_sum = nullptr, *partial = nullptr;
@@ -247,6 +249,28 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
     const bool big = KV >= ((size_t)1 << 22);
     int G = std::min(big ? kMaxRowsumBlocks - 1 : trlda::kRowsumBlocks, std::max(1, V / 32));
     const double *partial_in = m->partial;
+    // Small table and every document in the register-resident kernel's range: kernels 1 and
+    // 2 become one launch and the topic factors exp(-psiSum) are applied by the document
+    // kernel (estep_kernels.h, 2b)
+    const bool fused = !big && B > 0 && m->doc_threads == 0 && m->doc_kernel == TRLDA_DOCS_AUTO &&
+                       !m->split_preamble && K <= trlda::kRegMaxK && b->max_n <= trlda::kRegMaxN;
+    m->last_preamble_fused = fused;
+    if (fused) {
+        constexpr int TP = 1024;
+        G = std::min(trlda::kRowsumBlocks, std::max(1, V / 32));
+        int wpb = (V + G - 1) / G;
+        G = (V + wpb - 1) / wpb;
+        const bool dense = m->dense_preamble;
+        const size_t total = dense ? KV : (size_t)K * (size_t)b->n_active;
+        // G workgroups add up the row sums, the others fill exp(psi(lambda)): 256 in all, one
+        // per CU (a 1024-thread workgroup of this kernel fills a CU's registers)
+        const int GP = G + (int)std::max<size_t>(1, std::min<size_t>((total + TP - 1) / TP, 256 - G));
+        hipLaunchKernelGGL(preamble_fused_kernel<TP>, dim3(GP), dim3(TP), 0, m->stream, K, V, G, wpb,
+                           total, m->lambda, m->partial, m->eeb, dense ? nullptr : b->active);
+        HIP_TRY(hipGetLastError());
+        if (m->timing && ((rc = stamp(m)) || (rc = stamp(m))))
+            return rc;
+    } else {
     {
         int wpb = (V + G - 1) / G;
         G = (V + wpb - 1) / wpb;
@@ -285,6 +309,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
     }
     if (m->timing && (rc = stamp(m)))
         return rc;
+    }
 
     // 3. per-document fixed point (lda.cpp:174-204)
     if (atomic)
@@ -311,6 +336,9 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
         a.wrank = b->wrank; a.tw_word = m->tw_word;
         a.sstats_acc = atomic ? sstats_dev : nullptr;
         a.max_iter = max_iter; a.threshold = threshold; a.iters_out = iters_dev;
+        a.partial = fused ? m->partial : nullptr;
+        a.G = G;
+        a.scale_out = fused ? m->psi_sum : nullptr;
         const int Kp = K | 1;
 
         // Documents are ordered by decreasing length and split into two runs:
@@ -821,7 +849,7 @@ int trlda_model_create(trlda_model **out, int device, int K, int V)
     rc = dev_alloc(&m->lambda, KV);
     if (!rc) rc = dev_alloc(&m->eeb, KV);
     if (!rc) rc = dev_alloc(&m->alpha, (size_t)K);
-    if (!rc) rc = dev_alloc(&m->psi_sum, 2 * (size_t)K);   // psi(row sums), then the row sums
+    if (!rc) rc = dev_alloc(&m->psi_sum, 3 * (size_t)K);   // psi(row sums), the row sums, exp(-psi)
     if (!rc) rc = dev_alloc(&m->partial, (size_t)kMaxRowsumBlocks * K);
     if (!rc) rc = dev_alloc(&m->counter, 1);
     if (rc) {
@@ -883,6 +911,16 @@ int trlda_model_set_dense_preamble(trlda_model *m, int dense)
 }
 
 const char *trlda_model_last_doc_kernel(const trlda_model *m) { return m ? m->last_doc_kernel : ""; }
+
+int trlda_model_last_preamble_fused(const trlda_model *m) { return m && m->last_preamble_fused; }
+
+int trlda_model_set_split_preamble(trlda_model *m, int split)
+{
+    if (!m)
+        return fail(TRLDA_ERR_ARG, "null model");
+    m->split_preamble = split != 0;
+    return TRLDA_OK;
+}
 
 int trlda_model_set_doc_kernel(trlda_model *m, int kind)
 {
