@@ -279,8 +279,10 @@ int trlda_debug_fold16(int device, const double *in, double *out16, double *out4
 
 /* Average duration in microseconds (HIP events on the model's stream) of the
  * kernels launched by the most recent trlda_model_estep when timing is on:
- * which = 0 row sums, 1 exp E[log beta], 2 per-document fixed point,
- * 3 sufficient statistics.  Timing adds event records to the stream. */
+ * which = 0 row sums (or the fused preamble, then 1 is empty), 1 exp E[log beta],
+ * 2 per-document fixed point, 3 sufficient statistics, 4 nothing: two event records back to
+ * back, i.e. the part of every other figure that is the events' own cost.  Timing adds
+ * event records to the stream. */
 int trlda_model_set_timing(trlda_model *model, int enabled);
 int trlda_model_get_timing(trlda_model *model, int which, double *usec_sum, int64_t *count);
 

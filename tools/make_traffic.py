@@ -7,14 +7,18 @@ import sys
 
 
 def parse(path):
-    out, name = {}, None
+    """per kernel (template variants merged, weighted by their dispatch counts) -> counter means"""
+    acc, name = {}, None
     for line in open(path):
         if not line.startswith(" "):
             name = line.strip().replace("void ", "").split("<")[0]
         elif name:
             parts = line.split()
-            out.setdefault(name, {})[parts[0]] = float(parts[2])
-    return out
+            n = int(parts[3].strip("()n="))
+            tot = acc.setdefault(name, {}).setdefault(parts[0], [0.0, 0])
+            tot[0] += float(parts[2]) * n
+            tot[1] += n
+    return {k: {c: t[0] / t[1] for c, t in d.items()} for k, d in acc.items()}
 
 
 fetch, write = parse(sys.argv[1]), parse(sys.argv[2])
