@@ -333,7 +333,10 @@ def main():
     }
     if collective:
         dist.destroy_process_group()
+    # RCCL prints its banner through C stdio, which is block-buffered on a pipe and would
+    # otherwise come out at exit, after the JSON: drain it first
     sys.stdout.flush()
+    C.CDLL(None).fflush(None)
     print(json.dumps(out), flush=True)                # the one JSON line, last on stdout
 
 
