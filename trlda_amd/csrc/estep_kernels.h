@@ -390,6 +390,8 @@ struct DocKernelArgs {
     const double *partial;    // G x K block partials of the row sums of lambda
     int G;
     double *scale_out;        // 3K: psi(sum), sum, c (written by workgroup 0)
+    // register kernel: per workgroup (document, length, CSR offset, 0) and kRegMaxN padded ids
+    const int32_t *pad_meta, *pad_ids;
 };
 
 // sum_{i<count} a[i] * b[i * stride] with NA independent accumulators.  A dependent fp64
@@ -760,10 +762,13 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
     if (a.partial)                                   // launch-uniform
         topic_scale_load<T>(K, a.G, a.partial, pv);
 
-    const int d = a.order[blockIdx.x];
-    const int p0 = a.indptr[d];
-    const int n = a.indptr[d + 1] - p0;
-    const int32_t *__restrict__ ids = a.ids + p0;
+    // One load gives (document, length, CSR offset); the word ids sit at an address that
+    // depends on the workgroup index only, so they are fetched at the same time: two dependent
+    // memory latencies (descriptor | ids -> rows) instead of four (order -> indptr -> ids -> rows)
+    const int4 meta = reinterpret_cast<const int4 *>(a.pad_meta)[blockIdx.x];
+    const int32_t *__restrict__ pids = a.pad_ids + (size_t)blockIdx.x * kRegMaxN;
+    const int myid = pids[wid * 16 + (lane & 15)];   // word wid * 16 + i of the document
+    const int d = meta.x, n = meta.y, p0 = meta.z;
     const int32_t *__restrict__ cnts = a.cnts + p0;
 
     double *gbuf = lds;               // 2 x 128
@@ -784,7 +789,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
 
     const int nm = min(n, 128);                      // words held in registers
     const int nt = TAIL ? n - nm : 0;                // tail words (LDS), <= 64
-    const int JC = (((nm + W - 1) / W) + 1) & ~1;    // words per wave (even), <= 16
+    constexpr int JC = 16;                           // words per wave: wave w owns [16 w, 16 w + 16)
     const int KC = (((K + W - 1) / W) + 1) & ~1;     // topics per wave (even), <= 16
     const int j0 = wid * JC, k0 = wid * KC;
     const bool k_lo = lane < K, k_hi = lane + 64 < K;
@@ -797,7 +802,6 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
     // (clamped indices); out-of-range elements are zeroed after the loads have landed.
     double bB0[16], bB1[16];          // beta[j0+i][lane], beta[j0+i][lane+64]
     {
-        const int myid = nm > 0 ? ids[min(j0 + (lane & 15), nm - 1)] : 0;
         const int kl = min(lane, K - 1), kh = min(lane + 64, K - 1);
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -874,7 +878,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
     if (nt > 0) {                                    // block-uniform
         for (int r = wid; r < 8 * TC; r += W) {      // rows beyond the document are zero
             const bool row = r < nt;
-            const double *rowp = a.eeb + (size_t)(row ? ids[128 + r] : 0) * K;
+            const double *rowp = a.eeb + (size_t)pids[128 + min(r, 63)] * K;
             const double v0 = rowp[min(lane, K - 1)], v1 = rowp[min(lane + 64, K - 1)];
             tbuf[r * kRegStride + lane] = (row && k_lo) ? v0 : 0.0;
             tbuf[r * kRegStride + 64 + lane] = (row && k_hi) ? v1 : 0.0;
@@ -1034,7 +1038,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
     if (a.sstats_acc) {                              // lda.cpp:207-213, atomic form
         for (int j = wid; j < n; j += W) {
             const double c = tw[j];
-            double *col = a.sstats_acc + (size_t)ids[j] * K;
+            double *col = a.sstats_acc + (size_t)pids[j] * K;
             for (int k = lane; k < K; k += kWave)
                 unsafeAtomicAdd(&col[k], c * e[k]);
         }

@@ -88,6 +88,11 @@ struct trlda_batch {
     int n_active = 0;
     int32_t *long_words = nullptr;   // words with more than kLongWord entries
     int n_long = 0;
+    // per document, in `order`: (document, length, CSR offset, 0) and its first kRegMaxN word
+    // ids padded to that length -- the register kernel's workgroup finds everything it needs
+    // at an address that depends on its index only
+    int32_t *pad_meta = nullptr;     // B x 4
+    int32_t *pad_ids = nullptr;      // B x kRegMaxN
     std::vector<int32_t> sorted_len;   // host copy: document lengths in `order`
 };
 
@@ -445,6 +450,8 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
                                         hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)kRegLdsBytes));
             a.order = b->order + (B - n_reg);
+            a.pad_meta = b->pad_meta + (size_t)(B - n_reg) * 4;
+            a.pad_ids = b->pad_ids + (size_t)(B - n_reg) * kRegMaxN;
             hipLaunchKernelGGL(kern, dim3(n_reg), dim3(kRegThreads), kRegLdsBytes, m->stream, a);
             HIP_TRY(hipGetLastError());
         }
@@ -795,6 +802,21 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     if (!rc) rc = up(&b->wptr, wptr.data(), (size_t)V + 1);
     if (!rc) rc = up(&b->wdoc, wdoc.data(), (size_t)nnz);
     {
+        std::vector<int32_t> meta((size_t)std::max(B, 1) * 4, 0),
+            pids((size_t)std::max(B, 1) * trlda::kRegMaxN, 0);
+        for (int i = 0; i < B; ++i) {
+            const int d = order[(size_t)i], p0 = indptr[d], n = indptr[d + 1] - p0;
+            meta[(size_t)i * 4] = d;
+            meta[(size_t)i * 4 + 1] = n;
+            meta[(size_t)i * 4 + 2] = p0;
+            // words past the document repeat its last id (rows that exist; masked by length)
+            for (int j = 0; j < trlda::kRegMaxN; ++j)
+                pids[(size_t)i * trlda::kRegMaxN + j] = n > 0 ? ids[p0 + std::min(j, n - 1)] : 0;
+        }
+        if (!rc) rc = up(&b->pad_meta, meta.data(), (size_t)B * 4);
+        if (!rc) rc = up(&b->pad_ids, pids.data(), (size_t)B * trlda::kRegMaxN);
+    }
+    {
         std::vector<int32_t> active;
         for (int w = 0; w < V; ++w)
             if (wptr[(size_t)w + 1] > wptr[(size_t)w])
@@ -824,6 +846,7 @@ int trlda_batch_destroy(trlda_batch *b)
         (void)hipFree(b->indptr); (void)hipFree(b->ids); (void)hipFree(b->cnts); (void)hipFree(b->order);
         (void)hipFree(b->wrank); (void)hipFree(b->wptr); (void)hipFree(b->wdoc);
         (void)hipFree(b->active); (void)hipFree(b->long_words);
+        (void)hipFree(b->pad_meta); (void)hipFree(b->pad_ids);
     }
     delete b;
     return TRLDA_OK;
