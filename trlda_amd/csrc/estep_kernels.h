@@ -911,7 +911,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
         part[wid * kRegPart + 64 + lane] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
         if (nt > 0) {                                // tail word 128 + lane from LDS
             const double *rowp = tbuf + min(lane, 8 * TC - 1) * kRegStride + min(k0, K - 1);
-            double s2a = 0.0, s2b = 0.0;
+            double s2[4] = {0.0, 0.0, 0.0, 0.0};     // four chains
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb) {         // two halves of eight: fewer live registers
                 double tv[8];
@@ -924,11 +924,11 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    s2a = fma(ew[4 * hb + i].x, tv[2 * i], s2a);
-                    s2b = fma(ew[4 * hb + i].y, tv[2 * i + 1], s2b);
+                    s2[(2 * i) & 3] = fma(ew[4 * hb + i].x, tv[2 * i], s2[(2 * i) & 3]);
+                    s2[(2 * i + 1) & 3] = fma(ew[4 * hb + i].y, tv[2 * i + 1], s2[(2 * i + 1) & 3]);
                 }
             }
-            part[wid * kRegPart + 128 + lane] = s2a + s2b;
+            part[wid * kRegPart + 128 + lane] = (s2[0] + s2[1]) + (s2[2] + s2[3]);
         }
         __syncthreads();
         if (tid < 128 || tid < n)                    // 0 beyond n (cnt is 0 there)
@@ -962,22 +962,22 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
                 a1[(2 * i + 1) & 3] = fma(tv[i].y, bB1[2 * i + 1], a1[(2 * i + 1) & 3]);
             }
             if (nt > 0) {                            // tail rows of this wave, from LDS
+                // rows wid * TC + r, r < TC <= 8, two at a time: a document a little over 128
+                // words (the usual long one) has TC = 1 or 2 and pays for one pair only
                 const double *rowp = tbuf + (wid * TC) * kRegStride + lane;
+                const double *twp = tw + 128 + wid * TC;
 #pragma unroll
-                for (int hb = 0; hb < 2; ++hb) {     // two halves of four rows
-                    double lo[4], hi[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int r = (4 * hb + i < TC) ? 4 * hb + i : 0;   // wave-uniform clamp
-                        lo[i] = rowp[r * kRegStride];
-                        hi[i] = rowp[r * kRegStride + 64];
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int r = 4 * hb + i;
-                        const double wgt = (r < TC) ? tw[128 + wid * TC + r] : 0.0;
-                        a0[i] = fma(wgt, lo[i], a0[i]);
-                        a1[i] = fma(wgt, hi[i], a1[i]);
+                for (int pr = 0; pr < 4; ++pr) {
+                    if (2 * pr < TC) {               // wave-uniform
+                        const int r1 = (2 * pr + 1 < TC) ? 2 * pr + 1 : 2 * pr;
+                        const double lo0 = rowp[2 * pr * kRegStride], hi0 = rowp[2 * pr * kRegStride + 64];
+                        const double lo1 = rowp[r1 * kRegStride], hi1 = rowp[r1 * kRegStride + 64];
+                        const double w0 = twp[2 * pr];
+                        const double w1 = (2 * pr + 1 < TC) ? twp[r1] : 0.0;
+                        a0[0] = fma(w0, lo0, a0[0]);
+                        a1[0] = fma(w0, hi0, a1[0]);
+                        a0[1] = fma(w1, lo1, a0[1]);
+                        a1[1] = fma(w1, hi1, a1[1]);
                     }
                 }
             }
