@@ -287,17 +287,25 @@ def main():
                                                       args.max_iter, args.threshold),
                               args.cpu_seconds)
             kind = "port"
-        nm, tm = time_cpu(lambda cc, g: orc.estep(lam, .1, cc.indptr, cc.ids, cc.cnts, g,
-                                                  args.max_iter, args.threshold,
-                                                  nthreads=ncores), args.cpu_seconds / 2)
+        # doc-parallel port: a 200-document batch does not feed hundreds of threads; take the
+        # best of a few thread counts (each a short sample)
+        best = None
+        for nthr in sorted({t for t in (8, 16, 32, 64, ncores) if t <= ncores}):
+            nm, tm = time_cpu(lambda cc, g: orc.estep(lam, .1, cc.indptr, cc.ids, cc.cnts, g,
+                                                      args.max_iter, args.threshold,
+                                                      nthreads=nthr), args.cpu_seconds / 8)
+            if best is None or nm / tm > best[0] / best[1]:
+                best = (nm, tm, nthr)
+        nm, tm, best_threads = best
         cpu_baseline = {
             "value": round(n1 * B / t1, 1), "unit": "docs/s", "cores": 1, "kind": kind,
             "sample": "%d E-step calls over the bench's own %d-document mini-batches "
                       "(%.1f s), single thread" % (n1, B, t1),
-            "all_cores": {"value": round(nm * B / tm, 1), "cores": ncores, "kind": "port",
-                          "note": "oracle/cpu_ref.c doc-parallel variant (thread-private "
-                                  "accumulators); the reference's own OpenMP path is slower "
-                                  "than its single thread (BASELINE.md)"},
+            "all_cores": {"value": round(nm * B / tm, 1), "cores": best_threads,
+                          "cores_available": ncores, "kind": "port",
+                          "note": "oracle/cpu_ref.c doc-parallel variant, best of 8..%d threads; "
+                                  "the reference's own OpenMP path is slower than its single "
+                                  "thread (BASELINE.md)" % ncores},
             "gpu_over_cpu_1thread": round(docs_per_s / (n1 * B / t1), 1),
         }
         try:
