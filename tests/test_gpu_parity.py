@@ -620,6 +620,31 @@ def test_fused_preamble_agrees_with_the_two_kernel_one(hip, oracle, sampler, mod
     assert hip.trlda_model_last_preamble_fused(m._handle) == 0
 
 
+@pytest.mark.parametrize("K,V,B", [(200, 50000, 48), (500, 100000, 40)])
+def test_baseline_config_shapes(hip, oracle, K, V, B):
+    """BASELINE.json's configs 4 and 5 at their full K and V (the single-orientation kernel,
+    the wide row-sum grid with its combine kernel, 8 words per statistics workgroup at K=500),
+    a small batch so that the oracle finishes in seconds; plus the size-independent
+    invariants of SURVEY.md a17."""
+    from trlda_amd.documents import CSRDocuments
+    from trlda_amd.utils.synthetic import make_corpus
+    ip, ii, cc = make_corpus(B, V, seed=2015 + K, mean_unique=100)
+    rng = np.random.RandomState(K)                 # (the libc-stream sampler would need 5e9 draws)
+    lam = np.asfortranarray(rng.gamma(100., .01, (K, V)))
+    g0 = np.asfortranarray(rng.gamma(100., .01, (K, B)))
+    m = make_model(K, V, lam)
+    g, s, it = m.update_variables(CSRDocuments(ip, ii, cc), latents=g0, max_iter=20,
+                                  threshold=1e-3, return_iterations=True)
+    assert hip.trlda_model_last_doc_kernel(m._handle) == b"estep_docs_wide_kernel"
+    go, so, ito = oracle.estep(lam, .1, ip, ii, cc, g0, 20, 1e-3, nthreads=8)
+    assert relerr(g, go) < TIGHT_RTOL
+    check_sstats(s, so)
+    assert np.array_equal(it, ito)
+    total = float(cc.sum())
+    assert abs(s.sum() - total) < 1e-9 * total
+    assert abs(g.sum() - (total + B * K * .1)) < 1e-9 * total
+
+
 def test_converged_documents_stop_early(hip, oracle, sampler):
     """The data-dependent break (lda.cpp:202-203): iteration counts below max_iter, equal to
     the oracle's, per document."""
