@@ -3,13 +3,18 @@
 // (src/onlinelda.cpp:79-110).  fp64 throughout; matrices column-major (a word's
 // K values are contiguous), documents CSR int32.
 //
-// Launch sequence of one E-step (host side: trlda_hip.hip):
-//   1. rowsum_psi_kernel      psiSum_k = psi(sum_w lambda_kw)            lda.cpp:172
-//   2. exp_elog_beta_kernel   eeb = exp(psi(lambda) - psiSum)            lda.cpp:173
-//   3. estep_docs_kernel      per-document gamma fixed point             lda.cpp:174-204
-//                             (+ atomics into sstats in ATOMIC mode,     lda.cpp:207-213)
-//   4. sstats_words_kernel    ordered per-word sums * eeb                lda.cpp:207-217
-//      or finish_kernel       sstats *= eeb (ATOMIC mode)                lda.cpp:217
+// Launch sequence of one E-step (host side: trlda_hip.hip, estep_device):
+//   1. rowsum_partial_kernel  block partials of sum_w lambda_kw           lda.cpp:172
+//      (+ rowsum_combine_kernel on large tables)
+//   2. exp_elog_beta_kernel   psiSum, eeb = exp(psi(lambda) - psiSum)     lda.cpp:172-173
+//      -- or, on small tables, 1 + 2 as preamble_fused_kernel (section 2b)
+//   3. the per-document gamma fixed point                                 lda.cpp:174-204
+//        estep_docs_reg_kernel   K <= 128, at most 192 words (section 3c)
+//        estep_docs_wide_kernel  K <= 512, any length (estep_wide.h)
+//        estep_docs_kernel       any K (section 3)
+//      (+ atomics into sstats in ATOMIC mode,                             lda.cpp:207-213)
+//   4. sstats_words_kernel    ordered per-word sums * eeb                 lda.cpp:207-217
+//      or finish_kernel       sstats *= eeb (ATOMIC mode)                 lda.cpp:217
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -683,16 +688,17 @@ __global__ __launch_bounds__(T) void estep_docs_kernel(DocKernelArgs a)
 }
 
 // ---------------------------------------------------------------------------
-// 3c. Register-resident kernel: K <= 128 topics, documents of at most 128 words.
+// 3c. Register-resident kernel: K <= 128 topics, documents of at most 128 words (192 with
+// the LDS tail of the <true> variant).
 //
-// tools/probes on gfx950: the two products of 3b are bound by LDS bandwidth -- every
-// iteration re-reads the 8*K*n-byte slice twice, and each broadcast operand costs a full
-// 512-byte LDS access per wave.  Here the slice lives in VGPRs, in BOTH orientations
+// tools/probes on gfx950: with the slice in LDS the two products are bound by LDS bandwidth
+// -- every iteration re-reads the 8*K*n-byte slice twice, and each broadcast operand costs a
+// full 512-byte LDS access per wave.  Here the slice lives in VGPRs, in BOTH orientations
 // (2 x 64 doubles per thread, 512 threads), read from eeb once; per iteration LDS only
-// carries the two K- resp. n-vectors, the partial sums and the psi pieces.
+// carries the two K- resp. n-vectors and the partial sums.
 //
 //   lane l owns topics l and l+64 and words l and l+64
-//   wave w (0..7), product B: words [w*JC, (w+1)*JC) of the document, JC <= 16
+//   wave w (0..7), product B: words [16 w, 16 w + 16) of the document
 //                  product E: topics [w*KC, (w+1)*KC),               KC <= 16
 //                  psi      : waves 0 and 1, topics 0..63 and 64..127
 // ---------------------------------------------------------------------------
