@@ -263,3 +263,23 @@ def test_synthetic_corpus_properties():
         assert len(seg) >= 1 and len(np.unique(seg)) == len(seg)        # unique ids per doc
     # Zipf: low ids are far more frequent than high ids
     assert (ii < 30).sum() > 3 * (ii >= 270).sum()
+
+
+def test_parallel_gamma_draw_is_the_serial_stream(hip_lib, monkeypatch):
+    """sampleGamma's K*B*100 libc draws (utils.cpp:224-231, lda.cpp:135) are produced by several
+    host threads that jump ahead in the TYPE_3 generator (s_n = s_{n-31} + s_{n-3}): the result
+    and the state the stream is left in are bit-identical to one thread walking the stream."""
+    def draw(m, n, k, threads):
+        monkeypatch.setenv("TRLDA_SAMPLE_THREADS", str(threads))
+        hip_lib.trlda_seed(42)
+        a = np.empty((m, n), order="F")
+        hip_lib.trlda_sample_gamma(m, n, k, a)
+        b = np.empty((m, n), order="F")
+        hip_lib.trlda_sample_gamma(m, n, 3, b)       # what comes next in the stream
+        return a, b
+    for (m, n, k) in [(100, 40, 50), (7, 3, 100), (13, 77, 31), (1, 5, 4)]:
+        a1, b1 = draw(m, n, k, 1)
+        for threads in (2, 3, 8, 64):
+            a, b = draw(m, n, k, threads)
+            assert np.array_equal(a, a1) and np.array_equal(b, b1), (m, n, k, threads)
+

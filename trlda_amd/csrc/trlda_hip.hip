@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <thread>
@@ -618,6 +620,92 @@ struct GlibcRandom {
     }
 };
 
+// ---- jump-ahead for the generator above ---------------------------------------------
+// The unshifted sequence obeys s_n = s_{n-31} + s_{n-3} (mod 2^32): the window
+// W_n = (s_{n-31} .. s_{n-1}) advances by a 31 x 31 companion matrix A over Z / 2^32, and
+// A^N (square and multiply, cached per N) jumps N draws ahead.  sampleGamma's K*B*100 draws
+// are consumed pass by pass (utils.cpp:224-231); with the jumps every host thread produces
+// the draws of its own element range for all passes -- the same numbers in the same order of
+// additions as one serial stream, so seeded trajectories stay bit-identical.
+struct JumpMatrix {
+    uint32_t a[31][31];
+};
+
+void jump_identity(JumpMatrix &m)
+{
+    std::memset(m.a, 0, sizeof(m.a));
+    for (int i = 0; i < 31; ++i)
+        m.a[i][i] = 1;
+}
+
+void jump_multiply(const JumpMatrix &x, const JumpMatrix &y, JumpMatrix &out)
+{
+    for (int i = 0; i < 31; ++i) {
+        uint32_t row[31] = {0};
+        for (int k = 0; k < 31; ++k) {
+            const uint32_t xik = x.a[i][k];
+            if (xik == 0)
+                continue;
+            for (int j = 0; j < 31; ++j)
+                row[j] += xik * y.a[k][j];
+        }
+        std::memcpy(out.a[i], row, sizeof(row));
+    }
+}
+
+const JumpMatrix &jump_power(uint64_t n)
+{
+    static std::mutex mu;
+    static std::map<uint64_t, JumpMatrix> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(n);
+    if (it != cache.end())
+        return it->second;
+    JumpMatrix base, result, tmp;
+    std::memset(base.a, 0, sizeof(base.a));
+    for (int i = 0; i < 30; ++i)
+        base.a[i][i + 1] = 1;                        // shift
+    base.a[30][0] = 1;                               // s_n = s_{n-31} + s_{n-3}
+    base.a[30][28] = 1;
+    jump_identity(result);
+    for (uint64_t e = n; e; e >>= 1) {
+        if (e & 1) {
+            jump_multiply(result, base, tmp);
+            result = tmp;
+        }
+        jump_multiply(base, base, tmp);
+        base = tmp;
+    }
+    if (cache.size() > 64)
+        cache.clear();
+    return cache.emplace(n, result).first->second;
+}
+
+// window (oldest first) <-> the circular buffer of GlibcRandom
+void rng_to_window(const GlibcRandom &g, uint32_t (&w)[31])
+{
+    for (int j = 0; j < 31; ++j)
+        w[j] = g.x[(g.f + j) % 31];
+}
+void window_to_rng(const uint32_t (&w)[31], GlibcRandom &g)
+{
+    g.f = 3;
+    g.b = 0;
+    for (int j = 0; j < 31; ++j)
+        g.x[(3 + j) % 31] = w[j];
+}
+void jump_apply(const JumpMatrix &m, uint32_t (&w)[31])
+{
+    uint32_t out[31];
+    for (int i = 0; i < 31; ++i) {
+        uint32_t acc = 0;
+        for (int j = 0; j < 31; ++j)
+            acc += m.a[i][j] * w[j];
+        out[i] = acc;
+    }
+    std::memcpy(w, out, sizeof(out));
+}
+
 GlibcRandom g_rng;
 
 struct RngInit {
@@ -649,39 +737,72 @@ void trlda_sample_gamma(int m, int n, int k, double *out)
         out[i] = 0.0;
     if (total <= 0 || k <= 0)
         return;
-    // passes are generated in blocks (sequentially: the stream order is pass-major) and the
-    // logs of a block are accumulated element-parallel
-    const int64_t block_passes = std::max<int64_t>(1, std::min<int64_t>(k, (4 << 20) / total));
-    std::vector<double> u((size_t)(block_passes * total));
-    unsigned int nthreads = std::thread::hardware_concurrency();
-    nthreads = std::max(1u, std::min(nthreads, 16u));
-    if (total * block_passes < (1 << 16))
-        nthreads = 1;
-    for (int pass0 = 0; pass0 < k; pass0 += (int)block_passes) {
-        const int np = (int)std::min<int64_t>(block_passes, k - pass0);
-        for (int64_t i = 0; i < (int64_t)np * total; ++i)
-            u[(size_t)i] = -1.0 + 2.0 * (double)g_rng.next() / (double)2147483647;
-        auto work = [&](int64_t lo, int64_t hi) {
-            for (int p = 0; p < np; ++p) {
-                const double *up = u.data() + (size_t)p * total;
-                for (int64_t i = lo; i < hi; ++i)
-                    out[i] -= std::log(std::fabs(up[i]));
+    // out[i] = - sum_{p < k} log |u_{p, i}|, u_{p, i} the (p * total + i)-th draw of the stream
+    // (utils.cpp:224-231).  Small requests: one thread, straight through the stream.
+    unsigned int hw = std::thread::hardware_concurrency();
+    // (16..24 threads are the sweet spot on a 2 x 64-core host: beyond that starting them costs
+    // more than they save)
+    int64_t T = std::max<int64_t>(1, std::min<int64_t>({(int64_t)hw, (int64_t)20, total / 512}));
+    if (total * k < (1 << 17))
+        T = 1;
+    if (const char *env = std::getenv("TRLDA_SAMPLE_THREADS"))   // tests: force a thread count
+        T = std::max<int64_t>(1, std::min<int64_t>(std::atoi(env), total));
+    if (T == 1) {
+        for (int p = 0; p < k; ++p)
+            for (int64_t i = 0; i < total; ++i) {
+                const double u = -1.0 + 2.0 * (double)g_rng.next() / (double)2147483647;
+                out[i] -= std::log(std::fabs(u));
             }
-        };
-        if (nthreads == 1) {
-            work(0, total);
-        } else {
-            std::vector<std::thread> pool;
-            const int64_t chunk = (total + nthreads - 1) / nthreads;
-            for (unsigned int t = 0; t < nthreads; ++t) {
-                const int64_t lo = (int64_t)t * chunk, hi = std::min<int64_t>(total, lo + chunk);
-                if (lo < hi)
-                    pool.emplace_back(work, lo, hi);
-            }
-            for (auto &th : pool)
-                th.join();
+        return;
+    }
+    // Thread t owns the elements [t * len, min(total, (t + 1) * len)) in every pass: it starts
+    // lo_t draws into the stream and, after the draws of a pass, jumps over the other threads'
+    // share (total - its own length) to the next pass.  Per element the logs are added in pass
+    // order, exactly as the serial loop does.
+    const int64_t len = (total + T - 1) / T;
+    T = (total + len - 1) / len;
+    const int64_t last_len = total - (T - 1) * len;
+    const JumpMatrix &hop = jump_power((uint64_t)len);                     // thread t -> t + 1
+    const JumpMatrix &skip = jump_power((uint64_t)(total - len));          // pass p -> p + 1
+    const JumpMatrix &skip_last = jump_power((uint64_t)(total - last_len));
+    std::vector<GlibcRandom> start((size_t)T);
+    {
+        uint32_t w[31];
+        rng_to_window(g_rng, w);
+        for (int64_t t = 0; t < T; ++t) {
+            window_to_rng(w, start[(size_t)t]);
+            jump_apply(hop, w);
         }
     }
+    GlibcRandom final_state;
+    auto work = [&](int64_t t) {
+        GlibcRandom g = start[(size_t)t];
+        const int64_t lo = t * len, hi = std::min<int64_t>(total, lo + len);
+        const JumpMatrix &sk = (t == T - 1) ? skip_last : skip;
+        for (int p = 0; p < k; ++p) {
+            for (int64_t i = lo; i < hi; ++i) {
+                const double u = -1.0 + 2.0 * (double)g.next() / (double)2147483647;
+                out[i] -= std::log(std::fabs(u));
+            }
+            if (p + 1 < k || t == T - 1) {
+                if (p + 1 == k)
+                    break;                           // the last thread ends where the stream ends
+                uint32_t w[31];
+                rng_to_window(g, w);
+                jump_apply(sk, w);
+                window_to_rng(w, g);
+            }
+        }
+        if (t == T - 1)
+            final_state = g;
+    };
+    std::vector<std::thread> pool;
+    for (int64_t t = 1; t < T; ++t)
+        pool.emplace_back(work, t);
+    work(0);
+    for (auto &th : pool)
+        th.join();
+    g_rng = final_state;
 }
 
 void trlda_sample_gamma_init(int m, int n, double *out)
