@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <numeric>
@@ -708,6 +710,85 @@ void jump_apply(const JumpMatrix &m, uint32_t (&w)[31])
 
 GlibcRandom g_rng;
 
+// A few persistent host threads for the gamma draw: starting 20 threads costs ~0.3 ms, as
+// much as the draw itself.  run(n, job) executes job(0) on the caller and job(1..n-1) on the
+// workers and returns when all are done.  One caller at a time (the Python surface holds the
+// GIL across the call, as the reference does).
+class HostPool {
+public:
+    ~HostPool()
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_)
+            t.join();
+    }
+    void run(int n, const std::function<void(int)> &job)
+    {
+        std::lock_guard<std::mutex> serial(run_mu_);
+        if (n <= 1) {
+            job(0);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            while ((int)workers_.size() < n - 1) {
+                const int id = (int)workers_.size() + 1;
+                workers_.emplace_back([this, id] { loop(id); });
+            }
+            job_ = &job;
+            active_ = n;
+            pending_ = n - 1;
+            ++generation_;
+        }
+        cv_.notify_all();
+        job(0);
+        std::unique_lock<std::mutex> lock(mu_);
+        done_.wait(lock, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+
+private:
+    void loop(int id)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int)> *job = nullptr;
+            {
+                std::unique_lock<std::mutex> lock(mu_);
+                cv_.wait(lock, [&] { return stop_ || generation_ != seen; });
+                if (stop_)
+                    return;
+                seen = generation_;
+                if (id < active_)
+                    job = job_;
+            }
+            if (job) {
+                (*job)(id);
+                std::lock_guard<std::mutex> lock(mu_);
+                if (--pending_ == 0)
+                    done_.notify_one();
+            }
+        }
+    }
+    std::mutex mu_, run_mu_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> workers_;
+    const std::function<void(int)> *job_ = nullptr;
+    uint64_t generation_ = 0;
+    int active_ = 0, pending_ = 0;
+    bool stop_ = false;
+};
+
+HostPool &host_pool()
+{
+    static HostPool pool;
+    return pool;
+}
+
 struct RngInit {
     RngInit()
     {
@@ -740,9 +821,8 @@ void trlda_sample_gamma(int m, int n, int k, double *out)
     // out[i] = - sum_{p < k} log |u_{p, i}|, u_{p, i} the (p * total + i)-th draw of the stream
     // (utils.cpp:224-231).  Small requests: one thread, straight through the stream.
     unsigned int hw = std::thread::hardware_concurrency();
-    // (16..24 threads are the sweet spot on a 2 x 64-core host: beyond that starting them costs
-    // more than they save)
-    int64_t T = std::max<int64_t>(1, std::min<int64_t>({(int64_t)hw, (int64_t)20, total / 512}));
+    // (the threads are persistent, host_pool(): their number is bounded by the work per thread)
+    int64_t T = std::max<int64_t>(1, std::min<int64_t>({(int64_t)hw, (int64_t)64, total / 256}));
     if (total * k < (1 << 17))
         T = 1;
     if (const char *env = std::getenv("TRLDA_SAMPLE_THREADS"))   // tests: force a thread count
@@ -796,12 +876,7 @@ void trlda_sample_gamma(int m, int n, int k, double *out)
         if (t == T - 1)
             final_state = g;
     };
-    std::vector<std::thread> pool;
-    for (int64_t t = 1; t < T; ++t)
-        pool.emplace_back(work, t);
-    work(0);
-    for (auto &th : pool)
-        th.join();
+    host_pool().run((int)T, [&](int t) { work(t); });
     g_rng = final_state;
 }
 
