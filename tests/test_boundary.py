@@ -283,3 +283,19 @@ def test_parallel_gamma_draw_is_the_serial_stream(hip_lib, monkeypatch):
             a, b = draw(m, n, k, threads)
             assert np.array_equal(a, a1) and np.array_equal(b, b1), (m, n, k, threads)
 
+
+def test_gamma_draw_survives_fork(hip_lib):
+    """The draw's host threads are persistent; a child of fork() has none of them and must
+    still produce the stream (it builds its own pool)."""
+    a = np.empty((100, 200), order="F")
+    hip_lib.trlda_seed(3)
+    hip_lib.trlda_sample_gamma_init(100, 200, a)
+    pid = os.fork()
+    if pid == 0:
+        b = np.empty((100, 200), order="F")
+        hip_lib.trlda_seed(3)
+        hip_lib.trlda_sample_gamma_init(100, 200, b)
+        os._exit(0 if np.array_equal(a, b) else 1)
+    _, status = os.waitpid(pid, 0)
+    assert status == 0
+

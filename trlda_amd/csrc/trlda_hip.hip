@@ -20,6 +20,7 @@
 #include <string>
 #include <thread>
 #include <time.h>
+#include <unistd.h>
 #include <vector>
 
 #include "../../include/trlda_hip.h"
@@ -785,8 +786,18 @@ private:
 
 HostPool &host_pool()
 {
-    static HostPool pool;
-    return pool;
+    // On the heap and never destroyed: worker threads blocked on a condition variable must not
+    // be joined from a static destructor at exit, and a child of fork() has no workers at all
+    // -- it gets a pool of its own (the parent's object is left alone).
+    static HostPool *pool = nullptr;
+    static pid_t owner = 0;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!pool || owner != getpid()) {
+        pool = new HostPool();
+        owner = getpid();
+    }
+    return *pool;
 }
 
 struct RngInit {
