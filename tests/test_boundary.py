@@ -284,6 +284,7 @@ def test_parallel_gamma_draw_is_the_serial_stream(hip_lib, monkeypatch):
             assert np.array_equal(a, a1) and np.array_equal(b, b1), (m, n, k, threads)
 
 
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="no fork() from a process on a GPU box")
 def test_gamma_draw_survives_fork(hip_lib):
     """The draw's host threads are persistent; a child of fork() has none of them and must
     still produce the stream (it builds its own pool)."""
