@@ -465,7 +465,7 @@ def test_document_length_boundaries(hip, oracle, sampler, K):
     V = 3000
     rng = np.random.RandomState(K)
     lam = seeded_lambda(sampler, 31, K, V)
-    lens = [1, 2, 63, 64, 65, 127, 128, 129, 130, 137, 150, 191, 192, 193, 250]
+    lens = [1, 2, 63, 64, 65, 127, 128, 129, 130, 137, 143, 144, 145, 150, 191, 192, 193, 250]
     docs, ip = [], [0]
     for n in lens:
         ids = rng.permutation(V)[:n]
@@ -486,6 +486,41 @@ def test_document_length_boundaries(hip, oracle, sampler, K):
             per_doc = np.max(np.abs(g - go) / np.abs(go), axis=0)
             assert per_doc.max() < TIGHT_RTOL, list(zip(lens, per_doc))
             check_sstats(s, so)
+            assert np.array_equal(iters, ito)
+
+
+@pytest.mark.parametrize("K", [100, 128, 7])
+@pytest.mark.parametrize("longest", [129, 137, 144])
+def test_register_kernel_144_word_variant(hip, oracle, sampler, K, longest):
+    """Batches whose longest document has 129..144 words run the register kernel's variant
+    with 18 words per wave and a third register block (no LDS tail): document lengths around
+    the wave boundaries (18, 36, ..) and the 128 / 144 limits, both statistics modes, fused and
+    two-kernel preamble."""
+    from trlda_amd.documents import CSRDocuments
+    V = 2000
+    rng = np.random.RandomState(100 * K + longest)
+    lam = seeded_lambda(sampler, 61, K, V)
+    lens = [0, 1, 17, 18, 19, 35, 36, 37, 125, 126, 127, 128, 129, 130, longest]
+    docs, ip = [], [0]
+    for n in lens:
+        docs.append((rng.permutation(V)[:n], rng.randint(4, size=n)))
+        ip.append(ip[-1] + n)
+    ids = np.concatenate([d[0] for d in docs]).astype(np.int32)
+    cnts = np.concatenate([d[1] for d in docs]).astype(np.int32)
+    ip = np.array(ip, np.int32)
+    g0 = seeded_gamma(sampler, 62, K, len(lens))
+    m = make_model(K, V, lam)
+    go, so, ito = oracle.estep(lam, .1, ip, ids, cnts, g0, 25, 1e-3)
+    for mode in (0, 1):
+        for split in (0, 1):
+            hip.trlda_model_set_sstats_mode(m._handle, mode)
+            hip.trlda_model_set_split_preamble(m._handle, split)
+            g, s, iters = m.update_variables(CSRDocuments(ip, ids, cnts), latents=g0, max_iter=25,
+                                             threshold=1e-3, return_iterations=True)
+            assert hip.trlda_model_last_doc_kernel(m._handle) == b"estep_docs_reg_kernel"
+            per_doc = np.max(np.abs(g - go) / np.abs(go), axis=0)
+            assert per_doc.max() < TIGHT_RTOL, list(zip(lens, per_doc))
+            check_sstats(s, so, rtol=TIGHT_RTOL if mode == 0 else 1e-8)
             assert np.array_equal(iters, ito)
 
 

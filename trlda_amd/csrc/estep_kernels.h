@@ -752,10 +752,18 @@ __device__ __forceinline__ double sum8_strided(const double *p)
 // TAIL = false: documents of at most 128 words (no tail code, no register spills);
 // TAIL = true : also handles 129..192 words (a few spilled registers).  The host picks the
 // variant per batch, by whether the batch contains such a document.
-template <bool TAIL>
+// MODE 0: documents of at most 128 words.  MODE 1: at most 144 words, all in registers (18
+// words per wave, a third register block for the words 128..143 in the second orientation;
+// needs the register-lean exp(psi)).  MODE 2: up to 192 words, the words past 128 as rows in
+// LDS.  The host picks the variant per batch by its longest document: a launch lasts as long
+// as its longest document, and the variants cost 33 / 36 / 42 us on the bench's documents.
+template <int MODE>
 __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr bool TAIL = MODE == 2, MID = MODE == 1;
+    constexpr int JC = MID ? 18 : 16;                // words per wave: wave w owns [JC w, JC w + JC)
+    constexpr int NREG = 8 * JC;                     // words held in registers
     constexpr int T = kRegThreads, W = T / kWave;    // 8 waves
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
@@ -773,7 +781,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
     // memory latencies (descriptor | ids -> rows) instead of four (order -> indptr -> ids -> rows)
     const int4 meta = reinterpret_cast<const int4 *>(a.pad_meta)[blockIdx.x];
     const int32_t *__restrict__ pids = a.pad_ids + (size_t)blockIdx.x * kRegMaxN;
-    const int myid = pids[wid * 16 + (lane & 15)];   // word wid * 16 + i of the document
+    const int myid = pids[wid * JC + min(lane, JC - 1)];   // word wid * JC + i of the document
     const int d = meta.x, n = meta.y, p0 = meta.z;
     const int32_t *__restrict__ cnts = a.cnts + p0;
 
@@ -793,9 +801,8 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
     stamp_last = __builtin_amdgcn_s_memtime();
 #endif
 
-    const int nm = min(n, 128);                      // words held in registers
+    const int nm = min(n, NREG);                     // words held in registers
     const int nt = TAIL ? n - nm : 0;                // tail words (LDS), <= 64
-    constexpr int JC = 16;                           // words per wave: wave w owns [16 w, 16 w + 16)
     const int KC = (((K + W - 1) / W) + 1) & ~1;     // topics per wave (even), <= 16
     const int j0 = wid * JC, k0 = wid * KC;
     const bool k_lo = lane < K, k_hi = lane + 64 < K;
@@ -806,11 +813,11 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
     // by v_readlane -- one memory latency for the ids, then all 32 row loads are in flight
     // while the gamma / alpha / count initialisation below runs.  Every load is unconditional
     // (clamped indices); out-of-range elements are zeroed after the loads have landed.
-    double bB0[16], bB1[16];          // beta[j0+i][lane], beta[j0+i][lane+64]
+    double bB0[JC], bB1[JC];          // beta[j0+i][lane], beta[j0+i][lane+64]
     {
         const int kl = min(lane, K - 1), kh = min(lane + 64, K - 1);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < JC; ++i) {
             const double *rowp = a.eeb + (size_t)__builtin_amdgcn_readlane(myid, i) * K;
             bB0[i] = rowp[kl];
             bB1[i] = rowp[kh];
@@ -839,16 +846,16 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
             cntd[j] = j < n ? (double)cnts[j] : 0.0;
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const bool row = i < JC && j0 + i < nm;
+    for (int i = 0; i < JC; ++i) {
+        const bool row = j0 + i < nm;
         bB0[i] = (row && k_lo) ? bB0[i] : 0.0;
         bB1[i] = (row && k_hi) ? bB1[i] : 0.0;
     }
 
     // ---- orientation E through an LDS transposition (stride 129: conflict-free both ways)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        if (i < JC) {                                // wave-uniform; rows >= n hold zeros
+    for (int i = 0; i < JC; ++i) {
+        if (j0 + i < 128) {                          // wave-uniform; rows >= n hold zeros
             tbuf[(j0 + i) * kRegStride + lane] = bB0[i];
             tbuf[(j0 + i) * kRegStride + 64 + lane] = bB1[i];
         }
@@ -866,11 +873,9 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
     }
     double bE0[16], bE1[16];          // beta[lane][k0+i], beta[lane+64][k0+i]
     {
-        // rows at or beyond W*JC were never written: read row 0 instead and zero the value
-        const int rows = W * JC;
-        const bool r_lo = lane < rows, r_hi = lane + 64 < rows;
-        const double *t0 = tbuf + (r_lo ? lane : 0) * kRegStride + k0;
-        const double *t1 = tbuf + (r_hi ? lane + 64 : 0) * kRegStride + k0;
+        const double *t0 = tbuf + lane * kRegStride + k0;
+        const double *t1 = tbuf + (lane + 64) * kRegStride + k0;
+        constexpr bool r_lo = true, r_hi = true;     // all 128 rows were written
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const bool colv = i < KC && k0 + i < K;  // wave-uniform
@@ -880,6 +885,26 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
         }
     }
     __syncthreads();
+    // ---- MODE 1: the words 128..143 in the second orientation, through the same buffer
+    [[maybe_unused]] double bE2[16];  // beta[128 + lane][k0+i], lanes 0..15
+    if constexpr (MID) {
+#pragma unroll
+        for (int i = 0; i < JC; ++i) {
+            if (j0 + i >= 128) {                     // wave-uniform (wave 7: words 126..143)
+                tbuf[(j0 + i - 128) * kRegStride + lane] = bB0[i];
+                tbuf[(j0 + i - 128) * kRegStride + 64 + lane] = bB1[i];
+            }
+        }
+        __syncthreads();
+        const double *t2 = tbuf + (lane & 15) * kRegStride + k0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bool colv = i < KC && k0 + i < K;  // wave-uniform
+            const double v2 = t2[colv ? i : 0];
+            bE2[i] = (colv && lane < 16) ? v2 : 0.0;
+        }
+        __syncthreads();
+    }
     // ---- words 128.. of a long document: rows of the same LDS buffer, read by both products
     if (nt > 0) {                                    // block-uniform
         for (int r = wid; r < 8 * TC; r += W) {      // rows beyond the document are zero
@@ -915,6 +940,16 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
         }
         part[wid * kRegPart + lane] = (s0[0] + s0[1]) + (s0[2] + s0[3]);
         part[wid * kRegPart + 64 + lane] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
+        if constexpr (MID) {                         // words 128 + lane, lanes 0..15
+            double s2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                s2[(2 * i) & 3] = fma(ew[i].x, bE2[2 * i], s2[(2 * i) & 3]);
+                s2[(2 * i + 1) & 3] = fma(ew[i].y, bE2[2 * i + 1], s2[(2 * i + 1) & 3]);
+            }
+            if (lane < 16)
+                part[wid * kRegPart + 128 + lane] = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+        }
         if (nt > 0) {                                // tail word 128 + lane from LDS
             const double *rowp = tbuf + min(lane, 8 * TC - 1) * kRegStride + min(k0, K - 1);
             double s2[4] = {0.0, 0.0, 0.0, 0.0};     // four chains
@@ -955,13 +990,13 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
         // acc_k = sum_j tw_j beta[j][k]                               lda.cpp:189-193
         {
             const double2 *tp = reinterpret_cast<const double2 *>(tw + j0);
-            double2 tv[8];
+            double2 tv[JC / 2];
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < JC / 2; ++i)
                 tv[i] = tp[i];
             double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < JC / 2; ++i) {
                 a0[(2 * i) & 3] = fma(tv[i].x, bB0[2 * i], a0[(2 * i) & 3]);
                 a1[(2 * i) & 3] = fma(tv[i].x, bB1[2 * i], a1[(2 * i) & 3]);
                 a0[(2 * i + 1) & 3] = fma(tv[i].y, bB0[2 * i + 1], a0[(2 * i + 1) & 3]);
@@ -1004,7 +1039,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
             const double ek = e_old[kk], ak = alpha_l[kk];
             const double acc = sum8_strided<kRegPart>(part + kk);
             const double gnew = acc * ek + ak;
-            const double enew = (TAIL ? exp_digamma_minus_lean(gnew, 0.0) : exp_digamma(gnew)) * c_psi;
+            const double enew = (MODE != 0 ? exp_digamma_minus_lean(gnew, 0.0) : exp_digamma(gnew)) * c_psi;
             if (psi_on) {
                 g_new[k_psi] = gnew;
                 e_new[k_psi] = enew;

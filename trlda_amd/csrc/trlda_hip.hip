@@ -442,15 +442,15 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
         if (n_reg > 0) {
             a.n_cap = 0;
             a.Kp = K;
-            // within the register tier the documents with a tail (129..192 words) come first
-            int n_tail = 0;
-            while (n_tail < n_reg && b->sorted_len[(size_t)(B - n_reg + n_tail)] > 128)
-                ++n_tail;
-            // One launch: the tail-capable variant (it spills a few registers, ~7 % slower)
-            // only when the batch actually contains a 129..192-word document.  Running the two
-            // variants on two streams was measured and lost: the event fork/join costs more
-            // (~12 us) than it saves.
-            auto kern = n_tail > 0 ? estep_docs_reg_kernel<true> : estep_docs_reg_kernel<false>;
+            // One launch; the variant follows the longest document of the tier (it comes first):
+            // up to 128 words, up to 144 (all in registers still), up to 192 (LDS tail).  A
+            // launch lasts as long as its longest document and the variants cost 33 / 36 / 42 us
+            // at K = 100.  Running two variants on two streams was measured and lost: the event
+            // fork/join costs more (~12 us) than it saves.
+            const int longest = b->sorted_len[(size_t)(B - n_reg)];
+            auto kern = longest <= 128   ? estep_docs_reg_kernel<0>
+                        : longest <= 144 ? estep_docs_reg_kernel<1>
+                                         : estep_docs_reg_kernel<2>;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)kRegLdsBytes));
