@@ -447,10 +447,12 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
             // launch lasts as long as its longest document and the variants cost 33 / 36 / 42 us
             // at K = 100.  Running two variants on two streams was measured and lost: the event
             // fork/join costs more (~12 us) than it saves.
+            // (With more documents than CUs it is throughput that counts, and there <2> wins over
+            // <1>: it only charges the long documents for their tail.)
             const int longest = b->sorted_len[(size_t)(B - n_reg)];
-            auto kern = longest <= 128   ? estep_docs_reg_kernel<0>
-                        : longest <= 144 ? estep_docs_reg_kernel<1>
-                                         : estep_docs_reg_kernel<2>;
+            auto kern = longest <= 128                    ? estep_docs_reg_kernel<0>
+                        : longest <= 144 && n_reg <= 256 ? estep_docs_reg_kernel<1>
+                                                          : estep_docs_reg_kernel<2>;
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                         hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)kRegLdsBytes));
