@@ -740,6 +740,56 @@ __device__ __forceinline__ double wave_sum_dpp(double v)
     return __hiloint2double(hi, lo);
 }
 
+// ---------------------------------------------------------------------------
+// Transposing butterfly steps.  fold<D>(a, b): lanes whose bit D of the lane number is clear
+// return a(l) + a(l ^ D), the others b(l ^ D) + b(l).  fold<D>(v, v) is the plain all-reduce
+// step.  D = 32, 16: gfx950's v_permlane{32,16}_swap; D = 8, 4: DPP row rotation / shifts with
+// bank masks; D = 2, 1: quad permutes after a select.
+// ---------------------------------------------------------------------------
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ double dpp_merge(double old, double src)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xf,
+                                               BANK_MASK, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xf,
+                                               BANK_MASK, false);
+    return __hiloint2double(hi, lo);
+}
+
+template <int D>
+__device__ __forceinline__ double fold(double a, double b)
+{
+    if constexpr (D == 32) {
+        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a),
+                                                         (unsigned)__double2loint(b), false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a),
+                                                         (unsigned)__double2hiint(b), false, false);
+        return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+    } else if constexpr (D == 16) {
+        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a),
+                                                         (unsigned)__double2loint(b), false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a),
+                                                         (unsigned)__double2hiint(b), false, false);
+        return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+    } else if constexpr (D == 8) {
+        const double a2 = dpp_merge<0x128, 0xc>(a, b);   // row_ror:8 into lanes 8..15: b(l-8)
+        const double b2 = dpp_merge<0x128, 0x3>(b, a);   // row_ror:8 into lanes 0..7 : a(l+8)
+        return a2 + b2;
+    } else if constexpr (D == 4) {
+        const double a2 = dpp_merge<0x114, 0xa>(a, b);   // row_shr:4 into quads 1, 3: b(l-4)
+        const double b2 = dpp_merge<0x104, 0x5>(b, a);   // row_shl:4 into quads 0, 2: a(l+4)
+        return a2 + b2;
+    } else {
+        static_assert(D == 2 || D == 1, "fold distance");
+        const bool up = (threadIdx.x & D) != 0;
+        const double keep = up ? b : a, send = up ? a : b;
+        constexpr int CTRL = D == 2 ? 0x4e : 0xb1;       // quad_perm [2,3,0,1] / [1,0,3,2]
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(send), CTRL, 0xf, 0xf, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(send), CTRL, 0xf, 0xf, true);
+        return keep + __hiloint2double(hi, lo);
+    }
+}
+
 // eight partial sums at a compile-time stride, all reads in flight, pairwise combine
 template <int STRIDE>
 __device__ __forceinline__ double sum8_strided(const double *p)
@@ -753,10 +803,10 @@ __device__ __forceinline__ double sum8_strided(const double *p)
 // TAIL = true : also handles 129..192 words (a few spilled registers).  The host picks the
 // variant per batch, by whether the batch contains such a document.
 // MODE 0: documents of at most 128 words.  MODE 1: at most 144 words, all in registers (18
-// words per wave, a third register block for the words 128..143 in the second orientation;
-// needs the register-lean exp(psi)).  MODE 2: up to 192 words, the words past 128 as rows in
-// LDS.  The host picks the variant per batch by its longest document: a launch lasts as long
-// as its longest document, and the variants cost 33 / 36 / 42 us on the bench's documents.
+// words per wave, a third register block for the words 128..143 in the second orientation).
+// MODE 2: up to 192 words, the words past 128 as rows in LDS (register-lean exp(psi)).  The
+// host picks the variant per batch by its longest document: a launch lasts as long as its
+// longest document, and the variants cost 33 / 37 / 42 us on the bench's documents.
 template <int MODE>
 __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelArgs a)
 {
@@ -886,7 +936,11 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
     }
     __syncthreads();
     // ---- MODE 1: the words 128..143 in the second orientation, through the same buffer
-    [[maybe_unused]] double bE2[16];  // beta[128 + lane][k0+i], lanes 0..15
+    // Only 16 words: four lane groups share them, each with four of the wave's 16 topics --
+    // lane l holds word 128 + (l & 15), topics k0 + 4 (l >> 4) + {0..3}: 4 doubles per lane
+    // instead of 16 that three quarters of the lanes would not use.
+    [[maybe_unused]] double bE2[4];
+    [[maybe_unused]] const int kq = 4 * (lane >> 4); // this lane group's topic offset
     if constexpr (MID) {
 #pragma unroll
         for (int i = 0; i < JC; ++i) {
@@ -898,10 +952,10 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
         __syncthreads();
         const double *t2 = tbuf + (lane & 15) * kRegStride + k0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const bool colv = i < KC && k0 + i < K;  // wave-uniform
-            const double v2 = t2[colv ? i : 0];
-            bE2[i] = (colv && lane < 16) ? v2 : 0.0;
+        for (int i = 0; i < 4; ++i) {
+            const bool colv = kq + i < KC && k0 + kq + i < K;
+            const double v2 = t2[colv ? kq + i : 0];
+            bE2[i] = colv ? v2 : 0.0;
         }
         __syncthreads();
     }
@@ -940,15 +994,15 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
         }
         part[wid * kRegPart + lane] = (s0[0] + s0[1]) + (s0[2] + s0[3]);
         part[wid * kRegPart + 64 + lane] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
-        if constexpr (MID) {                         // words 128 + lane, lanes 0..15
-            double s2[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                s2[(2 * i) & 3] = fma(ew[i].x, bE2[2 * i], s2[(2 * i) & 3]);
-                s2[(2 * i + 1) & 3] = fma(ew[i].y, bE2[2 * i + 1], s2[(2 * i + 1) & 3]);
-            }
+        if constexpr (MID) {                         // words 128 + (lane & 15)
+            // the lane group's four weights (not a broadcast: they differ between groups)
+            const double2 *eq = reinterpret_cast<const double2 *>(e + k0 + kq);
+            const double2 ea = eq[0], eb = eq[1];
+            double s2 = fma(ea.x, bE2[0], ea.y * bE2[1]) + fma(eb.x, bE2[2], eb.y * bE2[3]);
+            s2 = fold<32>(s2, s2);                   // + the other lane groups (estep_wide.h)
+            s2 = fold<16>(s2, s2);
             if (lane < 16)
-                part[wid * kRegPart + 128 + lane] = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+                part[wid * kRegPart + 128 + lane] = s2;
         }
         if (nt > 0) {                                // tail word 128 + lane from LDS
             const double *rowp = tbuf + min(lane, 8 * TC - 1) * kRegStride + min(k0, K - 1);
@@ -1039,7 +1093,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
             const double ek = e_old[kk], ak = alpha_l[kk];
             const double acc = sum8_strided<kRegPart>(part + kk);
             const double gnew = acc * ek + ak;
-            const double enew = (MODE != 0 ? exp_digamma_minus_lean(gnew, 0.0) : exp_digamma(gnew)) * c_psi;
+            const double enew = (MODE == 2 ? exp_digamma_minus_lean(gnew, 0.0) : exp_digamma(gnew)) * c_psi;
             if (psi_on) {
                 g_new[k_psi] = gnew;
                 e_new[k_psi] = enew;

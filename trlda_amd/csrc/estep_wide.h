@@ -59,55 +59,8 @@ __host__ __device__ constexpr size_t wide_lds_doubles(int KS, int lds_rows)
     return (size_t)(kWideWaves + 2) * 64 * KS + 16 + (size_t)lds_rows * (64 * KS);
 }
 
-// ---------------------------------------------------------------------------
-// Transposing butterfly steps.  fold<D>(a, b): lanes whose bit D of the lane number is clear
-// return a(l) + a(l ^ D), the others b(l ^ D) + b(l).  fold<D>(v, v) is the plain all-reduce
-// step.  D = 32, 16: gfx950's v_permlane{32,16}_swap; D = 8, 4: DPP row rotation / shifts with
-// bank masks; D = 2, 1: quad permutes after a select.
-// ---------------------------------------------------------------------------
-template <int CTRL, int BANK_MASK>
-__device__ __forceinline__ double dpp_merge(double old, double src)
-{
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xf,
-                                               BANK_MASK, false);
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xf,
-                                               BANK_MASK, false);
-    return __hiloint2double(hi, lo);
-}
-
-template <int D>
-__device__ __forceinline__ double fold(double a, double b)
-{
-    if constexpr (D == 32) {
-        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a),
-                                                         (unsigned)__double2loint(b), false, false);
-        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a),
-                                                         (unsigned)__double2hiint(b), false, false);
-        return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
-    } else if constexpr (D == 16) {
-        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a),
-                                                         (unsigned)__double2loint(b), false, false);
-        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a),
-                                                         (unsigned)__double2hiint(b), false, false);
-        return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
-    } else if constexpr (D == 8) {
-        const double a2 = dpp_merge<0x128, 0xc>(a, b);   // row_ror:8 into lanes 8..15: b(l-8)
-        const double b2 = dpp_merge<0x128, 0x3>(b, a);   // row_ror:8 into lanes 0..7 : a(l+8)
-        return a2 + b2;
-    } else if constexpr (D == 4) {
-        const double a2 = dpp_merge<0x114, 0xa>(a, b);   // row_shr:4 into quads 1, 3: b(l-4)
-        const double b2 = dpp_merge<0x104, 0x5>(b, a);   // row_shl:4 into quads 0, 2: a(l+4)
-        return a2 + b2;
-    } else {
-        static_assert(D == 2 || D == 1, "fold distance");
-        const bool up = (threadIdx.x & D) != 0;
-        const double keep = up ? b : a, send = up ? a : b;
-        constexpr int CTRL = D == 2 ? 0x4e : 0xb1;       // quad_perm [2,3,0,1] / [1,0,3,2]
-        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(send), CTRL, 0xf, 0xf, true);
-        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(send), CTRL, 0xf, 0xf, true);
-        return keep + __hiloint2double(hi, lo);
-    }
-}
+// (fold<D>, the transposing butterfly step, lives in estep_kernels.h: the register kernel uses
+// it too.)
 
 // sum over the quad (lanes l ^ 1, l ^ 2): the value every lane holds afterwards
 __device__ __forceinline__ double quad_sum(double v)
