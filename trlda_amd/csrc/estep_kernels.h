@@ -984,6 +984,16 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             ew[i] = ep[i];
+        [[maybe_unused]] double s2 = 0.0;
+        if constexpr (MID) {                         // words 128 + (lane & 15)
+            // the lane group's four weights (not a broadcast: they differ between groups); the
+            // dependent chain of the two folds is started first and runs under the products
+            const double2 *eq = reinterpret_cast<const double2 *>(e + k0 + kq);
+            const double2 ea = eq[0], eb = eq[1];
+            s2 = fma(ea.x, bE2[0], ea.y * bE2[1]) + fma(eb.x, bE2[2], eb.y * bE2[3]);
+            s2 = fold<32>(s2, s2);                   // + the other lane groups
+            s2 = fold<16>(s2, s2);
+        }
         double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -994,13 +1004,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
         }
         part[wid * kRegPart + lane] = (s0[0] + s0[1]) + (s0[2] + s0[3]);
         part[wid * kRegPart + 64 + lane] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
-        if constexpr (MID) {                         // words 128 + (lane & 15)
-            // the lane group's four weights (not a broadcast: they differ between groups)
-            const double2 *eq = reinterpret_cast<const double2 *>(e + k0 + kq);
-            const double2 ea = eq[0], eb = eq[1];
-            double s2 = fma(ea.x, bE2[0], ea.y * bE2[1]) + fma(eb.x, bE2[2], eb.y * bE2[3]);
-            s2 = fold<32>(s2, s2);                   // + the other lane groups (estep_wide.h)
-            s2 = fold<16>(s2, s2);
+        if constexpr (MID) {
             if (lane < 16)
                 part[wid * kRegPart + 128 + lane] = s2;
         }
