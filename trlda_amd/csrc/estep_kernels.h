@@ -806,7 +806,7 @@ __device__ __forceinline__ double sum8_strided(const double *p)
 // words per wave, a third register block for the words 128..143 in the second orientation).
 // MODE 2: up to 192 words, the words past 128 as rows in LDS (register-lean exp(psi)).  The
 // host picks the variant per batch by its longest document: a launch lasts as long as its
-// longest document, and the variants cost 33 / 37 / 42 us on the bench's documents.
+// longest document, and the variants cost 33 / 36 / 42 us on the bench's documents.
 template <int MODE>
 __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelArgs a)
 {
