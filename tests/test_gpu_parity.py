@@ -680,6 +680,36 @@ def test_baseline_config_shapes(hip, oracle, K, V, B):
     assert abs(g.sum() - (total + B * K * .1)) < 1e-9 * total
 
 
+@pytest.mark.parametrize("lo,hi", [(-12, 2), (0, 12), (-8, 8)])
+def test_extreme_values(hip, oracle, lo, hi):
+    """lambda spread over many decades (exp E[log beta] down to underflow), tiny / integer
+    gamma0 (the exact branches of psi), counts up to 1e6, document lengths across the kernel
+    tiers.  Statistics below 1e-300 are left out: the device exp flushes denormals."""
+    from trlda_amd.documents import CSRDocuments
+    rng = np.random.RandomState(hi - lo)
+    K, V = 100, 500
+    ip, ids, cnts = [0], [], []
+    for n in [5, 40, 100, 128, 130, 144, 150, 192, 200, 1, 0, 64]:
+        ids += list(rng.permutation(V)[:n])
+        cnts += list(rng.randint(1, 1000000, size=n))
+        ip.append(ip[-1] + n)
+    ip, ids, cnts = np.array(ip, np.int32), np.array(ids, np.int32), np.array(cnts, np.int32)
+    B = len(ip) - 1
+    lam = np.asfortranarray(10.0 ** rng.uniform(lo, hi, (K, V)))
+    for g0 in (np.asfortranarray(rng.gamma(100, .01, (K, B))),
+               np.asfortranarray(10.0 ** rng.uniform(-10, 0, (K, B))),
+               np.asfortranarray(rng.randint(1, 11, (K, B)).astype(float))):
+        m = make_model(K, V, lam, alpha=.01)
+        g, s, it = m.update_variables(CSRDocuments(ip, ids, cnts), latents=g0, max_iter=30,
+                                      threshold=1e-3, return_iterations=True)
+        go, so, ito = oracle.estep(lam, .01, ip, ids, cnts, g0, 30, 1e-3)
+        assert np.isfinite(g).all() and np.isfinite(s).all()
+        assert relerr(g, go) < 1e-8
+        big = so > 1e-300
+        assert relerr(s[big], so[big]) < 1e-8
+        assert np.array_equal(it, ito)
+
+
 def test_converged_documents_stop_early(hip, oracle, sampler):
     """The data-dependent break (lda.cpp:202-203): iteration counts below max_iter, equal to
     the oracle's, per document."""
