@@ -256,7 +256,7 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
     }
     // gamma / alpha / exp(psi(gamma)) of topic tid                       lda.cpp:174
     const bool k_on = tid < K;
-    double gk = 1.0, ak = 0.0, ek = 0.0;
+    double gk = 1.5, ak = 0.0, ek = 0.0;          // (1.5: idle lanes must not take psi's integer branch)
     if (tid < KP) {
         if (k_on) {
             gk = a.gamma_in[(size_t)d * K + tid];
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
         const int nxt = cur ^ 1;
         if (wid < KS) {                              // tid < KP
             const double accs = sum8_strided<KP>(part + tid);
-            const double gnew = k_on ? fma(accs, ek, ak) : 1.0;
+            const double gnew = k_on ? fma(accs, ek, ak) : 1.5;
             const double diff = k_on ? fabs(gk - gnew) : 0.0;
             gk = gnew;
             const double enew = cfg::LEAN_PSI ? exp_digamma_minus_lean(gnew, 0.0) : exp_digamma(gnew);
