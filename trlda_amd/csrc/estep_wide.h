@@ -53,10 +53,11 @@ struct wide_cfg {
     static constexpr int KP = 64 * KS;               // padded topic count
 };
 
-// LDS carve (doubles): part[8][KP] | ebuf[2][KP] | misc[2][8] | rows[lds_rows][KP]
+// LDS carve (doubles): part[8][KP] | ebuf[2][KP] | misc[2][8] | cnt_tail[lds_rows] |
+// rows[lds_rows][KP]
 __host__ __device__ constexpr size_t wide_lds_doubles(int KS, int lds_rows)
 {
-    return (size_t)(kWideWaves + 2) * 64 * KS + 16 + (size_t)lds_rows * (64 * KS);
+    return (size_t)(kWideWaves + 2) * 64 * KS + 16 + (size_t)lds_rows * (64 * KS + 1);
 }
 
 // (fold<D>, the transposing butterfly step, lives in estep_kernels.h: the register kernel uses
@@ -209,7 +210,8 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
     double *part = lds;                              // 8 x KP
     double *ebuf = part + W * KP;                    // 2 x KP
     double *misc = ebuf + 2 * KP;                    // 2 x 8
-    double *rows = misc + 16;                        // lds_rows x KP
+    double *cnt_tail = misc + 16;                    // lds_rows: counts of the words in LDS rows
+    double *rows = cnt_tail + lds_rows;              // lds_rows x KP
 
     [[maybe_unused]] unsigned long long stamp_last = 0;
     TRLDA_STAMP_DECL;
@@ -274,6 +276,8 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
             const double v = rowp[min(lane + 64 * s, K - 1)];
             rows[(size_t)t * KP + lane + 64 * s] = kv[s] ? v : 0.0;
         }
+        if (lane == 0)
+            cnt_tail[t] = (double)cnts[n_reg + t];
     }
 #pragma unroll
     for (int i = 0; i < JW; ++i) {
@@ -293,9 +297,11 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
         double r[TCH][KS];
         const int my_u = fold_chunk_index<TCH>(lane);
         const int end = from_lds ? n_lds : n - n_reg;
+        // (the count comes from LDS for the words whose rows are there: a global load per chunk
+        // and iteration would sit in front of the weight)
         double my_cnt = 0.0;
         if (t0 + my_u < end)
-            my_cnt = (double)cnts[n_reg + t0 + my_u];
+            my_cnt = from_lds ? cnt_tail[t0 + my_u] : (double)cnts[n_reg + t0 + my_u];
         if (from_lds) {
 #pragma unroll
             for (int u = 0; u < TCH; ++u) {

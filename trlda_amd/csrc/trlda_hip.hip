@@ -386,7 +386,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
             }
             // LDS rows for the words past the registers, as many as the longest document needs
             const size_t fixed = wide_lds_doubles(KS, 0) * sizeof(double);
-            const int fit = (int)(((size_t)kLdsBytes - fixed) / ((size_t)(64 * KS) * sizeof(double)));
+            const int fit = (int)(((size_t)kLdsBytes - fixed) / ((size_t)(64 * KS + 1) * sizeof(double)));
             const int lds_rows = std::max(0, std::min(fit, b->max_n - kWideWaves * jw));
             const size_t lds_bytes = wide_lds_doubles(KS, lds_rows) * sizeof(double);
             a.n_cap = 0;
