@@ -64,6 +64,12 @@ int trlda_device_count(void);             /* number of HIP devices, 0 if none */
 /* trlda.seed(): srand(seed).  python/src/module.cpp:332-342 */
 void trlda_seed(unsigned int seed);
 
+/* The state of that stream (33 words), so that the ranks of a data-parallel job can adopt
+ * rank 0's: the reference has one process and one stream (src/lda.cpp:71, :135); replicas that
+ * draw "the same" gamma0 must share it. */
+void trlda_rng_get_state(uint32_t *state33);
+void trlda_rng_set_state(const uint32_t *state33);
+
 /* sampleGamma(m, n, k): -sum_{i<k} log|U_i|, U = -1 + 2*rand()/RAND_MAX, k passes over
  * an m x n column-major matrix, libc rand() consumed in exactly the reference's order.
  * src/utils.cpp:224-231, Eigen/src/Core/MathFunctions.h:439-446.  Host memory. */
@@ -234,6 +240,8 @@ int trlda_model_copy_lambda(trlda_model *model, double *dst_dev);
  *   gamma_out  optional host K x B: gamma of the last E-step
  * Single GPU.  The multi-GPU composition (E-step -> RCCL all-reduce of sstats ->
  * blend) is done by the host mirror from the three calls above.
+ * Returns without waiting for the device unless gamma_out is given (every getter
+ * synchronises): the host's draw of the next gamma0 overlaps this call's kernels.
  */
 int trlda_model_online_update(trlda_model *model, const trlda_batch *batch,
                               int num_documents, double eta,
@@ -259,6 +267,53 @@ int trlda_model_batch_update(trlda_model *model, const trlda_batch *batch, doubl
 int trlda_model_cumulative_update(trlda_model *model, const trlda_batch *batch, int max_epochs,
                                   int max_iter_inference, int update_lambda, double threshold,
                                   double *gamma_out);
+
+/* ---- update loop: what stays on the device between its steps ----------------------------
+ *
+ * Inside one OnlineLDA update lambda' and rho are fixed and a word outside the mini-batch has
+ * zero statistics (src/lda.cpp:169), so every M-step of the trust-region loop
+ * (src/onlinelda.cpp:99-100) gives it the same value -- the one the initial step of :85-86
+ * gives it too.  The update entry points above therefore write those words once per call and
+ * run the loop on the batch's active words only, with the statistics (src/lda.cpp:207-217), the
+ * M-step and the row sums the next E-step needs (src/lda.cpp:172) in ONE kernel per iteration.
+ * The switches below exist for tests and before/after measurements; results do not depend on
+ * them beyond summation order. */
+/* fused = 0: separate statistics and M-step kernels over all V words (K > 512 always does) */
+int trlda_model_set_fused_update(trlda_model *model, int fused);
+/* carry = 0: every E-step adds up the rows of lambda again (src/lda.cpp:172 as written) */
+int trlda_model_set_carry_rowsums(trlda_model *model, int carry);
+/* keep = 1: the update entry points also leave the sufficient statistics of their last E-step
+ * and the complete lambda' on the device (what src/onlinelda.cpp:167-175 reads); costs two
+ * K x V writes per call. */
+int trlda_model_set_keep_sstats(trlda_model *model, int keep);
+/* bytes this model has copied to host memory so far (tests assert that the empirical-Bayes
+ * steps move O(K), not O(K V)) */
+int64_t trlda_model_d2h_bytes(const trlda_model *model);
+
+/* LDA::updateVariables(documents, parameters) from a fresh random gamma (src/lda.cpp:119-138)
+ * with gamma and the statistics left on the device: what src/onlinelda.cpp:118-120 and
+ * src/batchlda.cpp:66-68 do before an alpha step when update_lambda is off. */
+int trlda_model_estep_resident(trlda_model *model, const trlda_batch *batch, int max_iter,
+                               double threshold);
+
+/* out_host[k] = sum_d psi(gamma_dk) - psi(sum_k gamma_dk): the data term of the alpha gradient,
+ * src/onlinelda.cpp:123-128, src/batchlda.cpp:72-74, src/cumulativelda.cpp:82-84.
+ *   gamma_dev  K x B device array, or NULL: gamma of the model's last update / resident E-step */
+int trlda_model_eb_gamma_stats(trlda_model *model, int B, const double *gamma_dev,
+                               double *out_host /* K */);
+
+/* *sum_psi_lambda = sum_kw psi(lambda_kw); rowsums_host[k] = sum_w lambda_kw (the host applies
+ * psi to those K numbers): the data terms of the eta gradient, src/onlinelda.cpp:152-154,
+ * src/batchlda.cpp:152. */
+int trlda_model_eb_lambda_stats(trlda_model *model, double *sum_psi_lambda,
+                                double *rowsums_host /* K */);
+
+/* Adaptive learning rate, src/onlinelda.cpp:167-172, after an update made with keep_sstats on:
+ * lambdaUpdate = (eta + scale * sstats) - lambda'; the model's running average
+ * mAdaGradient = (1 - 1/tau) mAdaGradient + 1/tau lambdaUpdate (K x V, device, zero at first);
+ * returns |lambdaUpdate|^2 and |mAdaGradient|^2.  eta: the value the update used. */
+int trlda_model_adaptive_stats(trlda_model *model, double eta, double scale, double tau,
+                               double *sq_norm_update, double *sq_norm_gradient);
 
 /* ---- test hook ----------------------------------------------------------- */
 

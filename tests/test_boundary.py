@@ -284,6 +284,45 @@ def test_parallel_gamma_draw_is_the_serial_stream(hip_lib, monkeypatch):
             assert np.array_equal(a, a1) and np.array_equal(b, b1), (m, n, k, threads)
 
 
+def test_jump_cache_eviction_keeps_the_stream(tmp_path):
+    """More distinct K x B shapes than the jump-matrix cache holds (it evicts above 64 entries;
+    a draw holds three powers at once and hands them to worker threads): run in a child with
+    MALLOC_PERTURB_ so that any freed-and-reused cache node would change the numbers.  Every
+    threaded draw, and the stream state after it, must equal the single-thread walk."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, %r)
+from trlda_amd import _ffi
+L = _ffi.lib()
+def run(threads):
+    os.environ["TRLDA_SAMPLE_THREADS"] = str(threads)
+    L.trlda_seed(77)
+    out = []
+    for i in range(120):
+        m, n = 3 + (i %% 7), 11 + 3 * i          # 120 distinct totals -> ~360 distinct powers
+        a = np.empty((m, n), order="F")
+        L.trlda_sample_gamma(m, n, 5, a)
+        out.append(a)
+    tail = np.empty((4, 4), order="F")
+    L.trlda_sample_gamma(4, 4, 2, tail)
+    out.append(tail)
+    return out
+ref = run(1)
+for t in (7, 3):
+    got = run(t)
+    for i, (a, b) in enumerate(zip(got, ref)):
+        assert np.array_equal(a, b), (t, i, float(np.abs(a - b).max()))
+print("ok")
+''' % ROOT
+    env = dict(os.environ, MALLOC_PERTURB_="165")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="no fork() from a process on a GPU box")
 def test_gamma_draw_survives_fork(hip_lib):
     """The draw's host threads are persistent; a child of fork() has none of them and must

@@ -77,7 +77,8 @@ def _free_port():
 
 
 CASES = [dict(max_iter_tr=2, init_gamma=True, rho=-1.), dict(max_iter_tr=0, init_gamma=True, rho=.2),
-         dict(max_iter_tr=3, init_gamma=False, rho=-1.)]
+         dict(max_iter_tr=3, init_gamma=False, rho=-1.),
+         dict(max_iter_tr=2, init_gamma=True, rho=-1., presharded=True)]
 K, V, D, B = 6, 120, 500, 23
 
 
@@ -91,14 +92,27 @@ def _worker(rank, world, port, outdir):
         from trlda_amd.documents import CSRDocuments
         from trlda_amd.utils.synthetic import make_corpus
         for c, case in enumerate(CASES):
-            trlda_amd.seed(500 + c)                       # same stream on every rank
+            case = dict(case)
+            presharded = case.pop("presharded", False)
+            # only rank 0's seed counts: the constructor hands its lambda AND its generator
+            # state to the other ranks (the library seeds itself from the clock otherwise)
+            trlda_amd.seed(500 + c if rank == 0 else 9000 + 10 * c + rank)
             model = ShardedOnlineLDA(V, K, D, alpha=.1, eta=.3, engine=OracleEngine(V, K))
             assert model.world == world and model.rank == rank
+            assert model.replicas_agree()
             rhos = []
             for i in range(2):
                 docs = CSRDocuments(*make_corpus(B, V, seed=40 + i, mean_unique=25))
-                rhos.append(model.update_parameters(docs, max_iter_inference=20, **case))
+                if presharded:                            # every rank brings its own documents
+                    cuts = docs.shard_cuts(world)
+                    lo, hi = int(cuts[rank]), int(cuts[rank + 1])
+                    rhos.append(model.update_parameters(docs.slice(lo, hi), max_iter_inference=20,
+                                                        presharded=True, total_docs=B,
+                                                        doc_range=(lo, hi), **case))
+                else:
+                    rhos.append(model.update_parameters(docs, max_iter_inference=20, **case))
             assert model.update_parameters([]) == 1.0 and model.update_count == 2
+            assert model.replicas_agree()
             # lambda must be replicated: identical on every rank
             lam = torch.from_numpy(np.ascontiguousarray(model.lambdas))
             gathered = [torch.empty_like(lam) for _ in range(world)]
@@ -119,6 +133,7 @@ def test_two_rank_update_matches_single_process(tmp_path, oracle, hip_lib):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     for c, case in enumerate(CASES):
+        case = {k: v for k, v in case.items() if k != "presharded"}
         got = np.load(os.path.join(str(tmp_path), "case%d.npz" % c))
         # single-process trajectory from the same libc stream (ctor draws lambda, then gammas)
         oracle.seed(500 + c)

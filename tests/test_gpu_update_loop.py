@@ -1,0 +1,336 @@
+"""The update loops end to end on the GPU (reference src/onlinelda.cpp:53-111,
+src/batchlda.cpp:43-61, src/cumulativelda.cpp:49-72) at BASELINE.json's big configurations,
+against the pinned CPU oracle composed step by step, plus the equivalences between the fused
+device path (statistics + M-step + next row sums in one kernel, active words only) and the plain
+launch sequence, size-independent invariants at the full per-GPU batch sizes, and the
+empirical-Bayes reductions staying on the device.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import TIGHT_RTOL, HipSampler, relerr, seeded_gamma
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip(hip_lib):
+    from trlda_amd import _ffi
+    assert _ffi.device_count() >= 1, "GPU tests need a visible MI355X"
+    return hip_lib
+
+
+@pytest.fixture(scope="module")
+def sampler(hip):
+    return HipSampler(hip)
+
+
+def corpus(B, V, seed, mean_unique=100):
+    from trlda_amd.documents import CSRDocuments
+    from trlda_amd.utils.synthetic import make_corpus
+    return CSRDocuments(*make_corpus(B, V, seed=seed, mean_unique=mean_unique))
+
+
+def random_lambda(K, V, seed):
+    # (the libc-stream sampler would need K * V * 100 draws: 5e9 at K = 500, V = 100 000)
+    rng = np.random.RandomState(seed)
+    return np.asfortranarray(rng.gamma(100., .01, (K, V)))
+
+
+def online_model(K, V, lam, D, alpha=.1, eta=.3):
+    """An OnlineLDA holding `lam` without paying for the constructor's K * V * 100 draws."""
+    from trlda_amd.models import OnlineLDA
+    m = OnlineLDA.__new__(OnlineLDA)
+    m._num_documents = int(D)
+    m._update_count = 0
+    m._ada_tau = 1000.
+    m._ada_rho = 1. / m._ada_tau
+    m._ada_sq_norm = 1.
+    m._setup(V, K, alpha, eta, None, _lambda=lam)
+    return m
+
+
+def batch_model(K, V, lam, alpha=.1, eta=.3):
+    from trlda_amd.models import BatchLDA
+    m = BatchLDA.__new__(BatchLDA)
+    m._setup(V, K, alpha, eta, None, _lambda=lam)
+    return m
+
+
+def oracle_online_update(orc, lam, alpha, eta, D, docs, g0, count, max_iter_tr, max_iter_inference,
+                         kappa=.7, tau=100., nthreads=8):
+    """onlinelda.cpp:53-111 composed from the oracle's pieces (its E-step on `nthreads`, which
+    equals its serial one bit for bit); init_gamma=True, so g0 is the only draw."""
+    B = len(docs)
+    rho = float(np.power(tau + count, -kappa))
+    lam_prime = lam
+    g = g0
+    if max_iter_tr > 0:
+        lam = orc.tr_init(lam_prime, docs.indptr, docs.ids, docs.cnts, D, rho, eta)
+        for _ in range(max_iter_tr):
+            g, s, _it = orc.estep(lam, alpha, docs.indptr, docs.ids, docs.cnts, g,
+                                  max_iter_inference, 1e-3, nthreads=nthreads)
+            lam = orc.mstep_blend(lam_prime, s, rho, eta, float(D) / B)
+    else:
+        g, s, _it = orc.estep(lam, alpha, docs.indptr, docs.ids, docs.cnts, g, max_iter_inference,
+                              1e-3, nthreads=nthreads)
+        lam = orc.mstep_blend(lam_prime, s, rho, eta, float(D) / B)
+    return rho, lam, g
+
+
+# --------------------------------------------------------------------------------------------
+# BASELINE.json config 5: OnlineLDA K=500, V=100 000, max_iter_tr=10
+# --------------------------------------------------------------------------------------------
+def test_config5_online_update_trust_region(hip, oracle, sampler):
+    import trlda_amd
+    K, V, B, D = 500, 100000, 256, 1000000
+    lam0 = random_lambda(K, V, 5)
+    m = online_model(K, V, lam0, D)
+    lam = lam0
+    for call, seed in enumerate((31, 32)):           # the 2nd call starts from carried row sums
+        docs = corpus(B, V, seed=500 + call)
+        trlda_amd.seed(seed)
+        rho = m.update_parameters(docs, max_iter_tr=10, max_iter_inference=20)
+        g0 = seeded_gamma(sampler, seed, K, B)
+        rho_o, lam, _g = oracle_online_update(oracle, lam, .1, .3, D, docs, g0, call, 10, 20)
+        assert rho == rho_o
+        got = m.lambdas
+        assert relerr(got, lam) < TIGHT_RTOL, (call, relerr(got, lam))
+    assert m.update_count == 2
+
+
+def test_config5_single_step_and_plain_sequence(hip, oracle, sampler):
+    """max_iter_tr=0 (onlinelda.cpp:103-109: the in-place M-step on the active words plus the
+    decay of the others), and the plain launch sequence (fused update and carried row sums off)
+    on the same inputs: both equal the oracle, and each other to rounding."""
+    import trlda_amd
+    K, V, B, D = 500, 100000, 128, 500000
+    lam0 = random_lambda(K, V, 6)
+    docs = [corpus(B, V, seed=600 + i) for i in range(2)]
+    results = []
+    for fused in (1, 0):
+        m = online_model(K, V, lam0, D)
+        hip.trlda_model_set_fused_update(m._handle, fused)
+        hip.trlda_model_set_carry_rowsums(m._handle, fused)
+        for i, (tr, seed) in enumerate(((0, 41), (2, 42))):
+            trlda_amd.seed(seed)
+            m.update_parameters(docs[i], max_iter_tr=tr, max_iter_inference=20)
+        results.append(m.lambdas)
+        m.close()
+    lam = lam0
+    for i, (tr, seed) in enumerate(((0, 41), (2, 42))):
+        g0 = seeded_gamma(sampler, seed, K, B)
+        _r, lam, _g = oracle_online_update(oracle, lam, .1, .3, D, docs[i], g0, i, tr, 20)
+    assert relerr(results[0], lam) < TIGHT_RTOL
+    assert relerr(results[1], lam) < TIGHT_RTOL
+    assert relerr(results[0], results[1]) < 1e-12
+
+
+# --------------------------------------------------------------------------------------------
+# BASELINE.json config 4: BatchLDA K=200, V=50 000, max_iter_inference=100 (its default)
+# --------------------------------------------------------------------------------------------
+def test_config4_batch_update(hip, oracle, sampler):
+    import trlda_amd
+    K, V, B = 200, 50000, 512
+    lam0 = random_lambda(K, V, 4)
+    docs = corpus(B, V, seed=400)
+    m = batch_model(K, V, lam0)
+    trlda_amd.seed(51)
+    m.update_parameters(docs, max_epochs=2, max_iter_inference=100)
+    sampler.seed(51)
+    lam = lam0
+    for _epoch in range(2):                          # batchlda.cpp:48-61
+        g0 = sampler.sample_gamma(K, B, 100) / 100.
+        _g, s, _it = oracle.estep(lam, .1, docs.indptr, docs.ids, docs.cnts, g0, 100, 1e-3, nthreads=8)
+        lam = .3 + s
+    got = m.lambdas
+    assert relerr(got, lam) < TIGHT_RTOL, relerr(got, lam)
+    untouched = np.setdiff1d(np.arange(V), docs.ids)
+    assert np.all(got[:, untouched] == .3)           # lambda = eta where the batch has no word
+
+
+# --------------------------------------------------------------------------------------------
+# full per-GPU batch sizes: size-independent properties (SURVEY.md a17 carried through the M-step)
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K,V,B,tr", [(500, 100000, 512, 10), (500, 100000, 4096, 2),
+                                      (100, 7000, 1600, 10)])
+def test_online_update_mass_balance_full_batch(hip, K, V, B, tr):
+    """sum(sstats) = sum(counts) (a17), so after any number of trust-region M-steps
+    sum(lambda) = (1-rho) sum(lambda') + rho (K V eta + D/B sum(counts)); and the words outside
+    the batch hold exactly (1-rho) lambda' + rho eta."""
+    import trlda_amd
+    D = 1000000
+    lam0 = random_lambda(K, V, K + B)
+    docs = corpus(B, V, seed=B)
+    m = online_model(K, V, lam0, D)
+    trlda_amd.seed(7)
+    rho = m.update_parameters(docs, max_iter_tr=tr, max_iter_inference=20)
+    got = m.lambdas
+    total = float(docs.cnts.sum())
+    want = (1. - rho) * lam0.sum() + rho * (K * V * .3 + D / float(B) * total)
+    assert abs(got.sum() - want) < 1e-9 * want
+    untouched = np.setdiff1d(np.arange(V), docs.ids)
+    if len(untouched):
+        assert relerr(got[:, untouched], (1. - rho) * lam0[:, untouched] + rho * .3) < 1e-14
+    assert np.isfinite(got).all() and (got > 0).all()
+
+
+def test_batch_update_mass_balance_full_batch(hip):
+    """BatchLDA at config 4's per-GPU batch: sum(lambda) = K V eta + sum(counts)."""
+    import trlda_amd
+    K, V, B = 200, 50000, 12500
+    lam0 = random_lambda(K, V, 44)
+    docs = corpus(B, V, seed=44)
+    m = batch_model(K, V, lam0)
+    trlda_amd.seed(8)
+    m.update_parameters(docs, max_epochs=1, max_iter_inference=100)
+    got = m.lambdas
+    total = float(docs.cnts.sum())
+    want = K * V * .3 + total
+    assert abs(got.sum() - want) < 1e-9 * want
+
+
+# --------------------------------------------------------------------------------------------
+# fused device path == plain launch sequence, small tables and odd shapes
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K,V,B", [(100, 7000, 200), (7, 900, 33), (333, 13000, 40),
+                                   (129, 40000, 64), (512, 9000, 24)])
+def test_fused_update_equals_plain_sequence(hip, oracle, sampler, K, V, B):
+    """Every update loop through both device paths: OnlineLDA with and without the trust region
+    (twice, so that the second call runs on carried row sums), BatchLDA, CumulativeLDA.  K odd
+    (8-byte streaming accesses), K = 512 (four topic blocks), V not a multiple of anything."""
+    import trlda_amd
+    from trlda_amd.models import BatchLDA, CumulativeLDA
+    D = 20000
+    lam0 = random_lambda(K, V, K)
+    docs = [corpus(B, V, seed=K + i, mean_unique=min(60, V // 4)) for i in range(3)]
+    out = {}
+    for fused in (1, 0):
+        m = online_model(K, V, lam0, D)
+        hip.trlda_model_set_fused_update(m._handle, fused)
+        hip.trlda_model_set_carry_rowsums(m._handle, fused)
+        trlda_amd.seed(61)
+        m.update_parameters(docs[0], max_iter_tr=3, max_iter_inference=20)
+        m.update_parameters(docs[1], max_iter_tr=0, max_iter_inference=20)
+        m.update_parameters(docs[2], max_iter_tr=2, max_iter_inference=20, init_gamma=False)
+        out["online", fused] = m.lambdas
+        m.close()
+        trlda_amd.seed(62)
+        b = BatchLDA(num_words=V, num_topics=K) if K * V < 2000000 else batch_model(K, V, lam0)
+        hip.trlda_model_set_fused_update(b._handle, fused)
+        hip.trlda_model_set_carry_rowsums(b._handle, fused)
+        trlda_amd.seed(63)
+        b.update_parameters(docs[0], max_epochs=3, max_iter_inference=30)
+        out["batch", fused] = b.lambdas
+        b.close()
+        if K * V < 2000000:
+            trlda_amd.seed(64)
+            c = CumulativeLDA(num_words=V, num_topics=K)
+            hip.trlda_model_set_fused_update(c._handle, fused)
+            hip.trlda_model_set_carry_rowsums(c._handle, fused)
+            c.update_parameters(docs[0], max_epochs=2, max_iter_inference=30)
+            c.update_parameters(docs[1], max_epochs=1, max_iter_inference=30)
+            out["cumulative", fused] = c.lambdas
+            c.close()
+    for kind in ("online", "batch", "cumulative"):
+        if (kind, 1) in out:
+            assert relerr(out[kind, 1], out[kind, 0]) < 1e-11, (kind, relerr(out[kind, 1], out[kind, 0]))
+    # and the fused online trajectory against the oracle
+    lam = lam0
+    sampler.seed(61)
+    for i, tr in enumerate((3, 0, 2)):
+        rho = float(np.power(100. + i, -.7))
+        lam_prime = lam
+        if tr > 0:
+            lam = oracle.tr_init(lam_prime, docs[i].indptr, docs[i].ids, docs[i].cnts, D, rho, .3)
+        g = None
+        for j in range(max(tr, 1)):
+            if g is None or i == 2:                  # init_gamma=False on the third call
+                g = sampler.sample_gamma(K, B, 100) / 100.
+            g, s, _it = oracle.estep(lam, .1, docs[i].indptr, docs[i].ids, docs[i].cnts, g, 20, 1e-3,
+                                     nthreads=8)
+            lam = oracle.mstep_blend(lam_prime, s, rho, .3, float(D) / B)
+    assert relerr(out["online", 1], lam) < TIGHT_RTOL
+
+
+def test_tiny_row_sums_do_not_take_the_fused_preamble(hip, oracle):
+    """Row sums below ~1.4e-3 make exp(-psi(row sum)) overflow, which the fused small-table
+    preamble would multiply into an underflowed exp(psi(lambda)): the host keeps a lower bound of
+    the row sums and uses the two-kernel preamble there (the reference's single exponential)."""
+    K, V, B = 16, 40, 12
+    rng = np.random.RandomState(3)
+    lam = np.asfortranarray(rng.uniform(1e-6, 3e-6, (K, V)))        # row sums ~8e-5
+    lam[3, :] = rng.uniform(.5, 1.5, V)                             # one ordinary topic
+    docs = corpus(B, V, seed=9, mean_unique=10)
+    g0 = np.asfortranarray(rng.gamma(100., .01, (K, B)))
+    m = online_model(K, V, lam, 100, alpha=.1, eta=1e-6)
+    g, s = m.update_variables(docs, latents=g0, max_iter=20)
+    assert hip.trlda_model_last_preamble_fused(m._handle) == 0
+    go, so, _ = oracle.estep(lam, .1, docs.indptr, docs.ids, docs.cnts, g0, 20, 1e-3)
+    assert np.isfinite(g).all() and np.isfinite(s).all()
+    assert relerr(g, go) < 1e-8
+    big = so > 1e-290
+    assert relerr(s[big], so[big]) < 1e-8
+    # an ordinary lambda on the same model takes the fused preamble again
+    m.lambdas = random_lambda(K, V, 1)
+    m.update_variables(docs, latents=g0, max_iter=5)
+    assert hip.trlda_model_last_preamble_fused(m._handle) == 1
+    # ... and stays on it through updates (the bound follows the M-step)
+    m.update_parameters(docs, max_iter_tr=2)
+    m.update_variables(docs, latents=g0, max_iter=5)
+    assert hip.trlda_model_last_preamble_fused(m._handle) == 1
+
+
+# --------------------------------------------------------------------------------------------
+# empirical Bayes / adaptive rate: K-sized traffic only
+# --------------------------------------------------------------------------------------------
+def test_empirical_bayes_moves_only_k_sized_results(hip):
+    import trlda_amd
+    K, V, B, D = 100, 7000, 200, 100000
+    m = online_model(K, V, random_lambda(K, V, 2), D)
+    docs = m.upload(corpus(B, V, seed=21))
+    trlda_amd.seed(5)
+    before = hip.trlda_model_d2h_bytes(m._handle)
+    for _ in range(3):
+        m.update_parameters(docs, max_iter_tr=2, update_alpha=True, update_eta=True, adaptive=True)
+    m.update_parameters(docs, max_iter_tr=0, update_lambda=False, update_alpha=True, update_eta=True)
+    moved = hip.trlda_model_d2h_bytes(m._handle) - before
+    assert moved < 4 * (3 * K * 8 + 3 * 4096 * 8 + 2048 * 8), moved     # << K * V * 8 = 5.6 MB
+    assert moved < K * V * 8 // 20
+    assert np.isfinite(m.alpha).all() and m.eta > 0
+
+
+def test_device_eb_statistics_match_numpy(hip):
+    """The three reductions against NumPy on downloaded copies (K = 200: two topics per thread
+    in the gamma kernel; B not a multiple of the chunk)."""
+    import trlda_amd
+    from trlda_amd import _special
+    K, V, B, D = 200, 3000, 77, 5000
+    lam0 = random_lambda(K, V, 12)
+    m = online_model(K, V, lam0, D)
+    docs = m.upload(corpus(B, V, seed=22, mean_unique=50))
+    hip.trlda_model_set_keep_sstats(m._handle, 1)
+    trlda_amd.seed(9)
+    gamma = np.empty((K, B), order="F")
+    count, rho_out = C.c_int(0), C.c_double(0.)
+    from trlda_amd import _ffi
+    _ffi.check(hip.trlda_model_online_update(m._handle, docs.handle, D, .3, 2, 20, .7, 100., -1., 1, 1,
+                                             0.001, C.byref(count), C.byref(rho_out),
+                                             gamma.ctypes.data))
+    want = (_special.digamma(gamma) - _special.digamma(gamma.sum(axis=0))[None, :]).sum(axis=1)
+    assert relerr(m._psi_gamma_diff_device(B), want) < 1e-11
+    lam = m.lambdas
+    total, rowsums = m._lambda_psi_stats_device()
+    assert relerr(rowsums, lam.sum(axis=1)) < 1e-13
+    assert abs(total - _special.digamma(lam).sum()) < 1e-11 * abs(total)
+    sstats = np.empty((K, V), order="F")
+    _ffi.check(hip.trlda_model_get_sstats(m._handle, sstats))
+    upd = (.3 + D / float(B) * sstats) - lam0
+    u2, g2 = C.c_double(0.), C.c_double(0.)
+    _ffi.check(hip.trlda_model_adaptive_stats(m._handle, .3, D / float(B), 1000., C.byref(u2),
+                                              C.byref(g2)))
+    assert abs(u2.value - (upd * upd).sum()) < 1e-11 * u2.value
+    grad = upd / 1000.
+    assert abs(g2.value - (grad * grad).sum()) < 1e-11 * g2.value

@@ -26,6 +26,8 @@ _SIGNATURES = {
     "trlda_version": (C.c_int, []),
     "trlda_device_count": (C.c_int, []),
     "trlda_seed": (None, [C.c_uint]),
+    "trlda_rng_get_state": (None, [np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")]),
+    "trlda_rng_set_state": (None, [np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")]),
     "trlda_sample_gamma": (None, [C.c_int, C.c_int, C.c_int, f64p]),
     "trlda_sample_gamma_init": (None, [C.c_int, C.c_int, f64p]),
     "trlda_estep": (C.c_int, [C.c_int, C.c_int, C.c_int, i32p, i32p, i32p, f64p, f64p, f64p, f64p,
@@ -74,6 +76,15 @@ _SIGNATURES = {
                                                 vp]),
     "trlda_model_lower_bound": (C.c_int, [vp, vp, f64p, C.c_double, C.c_double, C.c_int, C.c_double,
                                 C.POINTER(C.c_double)]),
+    "trlda_model_set_fused_update": (C.c_int, [vp, C.c_int]),
+    "trlda_model_set_carry_rowsums": (C.c_int, [vp, C.c_int]),
+    "trlda_model_set_keep_sstats": (C.c_int, [vp, C.c_int]),
+    "trlda_model_d2h_bytes": (C.c_int64, [vp]),
+    "trlda_model_estep_resident": (C.c_int, [vp, vp, C.c_int, C.c_double]),
+    "trlda_model_eb_gamma_stats": (C.c_int, [vp, C.c_int, vp, f64p]),
+    "trlda_model_eb_lambda_stats": (C.c_int, [vp, C.POINTER(C.c_double), f64p]),
+    "trlda_model_adaptive_stats": (C.c_int, [vp, C.c_double, C.c_double, C.c_double,
+                                            C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "trlda_debug_fold16": (C.c_int, [C.c_int, vp, vp, vp, vp]),
     "trlda_model_set_doc_kernel": (C.c_int, [vp, C.c_int]),
     "trlda_model_last_doc_kernel": (C.c_char_p, [vp]),

@@ -1155,8 +1155,8 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
 // The entries of a word are stored in document order, so the additions happen in
 // the order of the reference's serial loop (lda.cpp:207-213) and the result is
 // bitwise reproducible.  Words without entries get 0 (lda.cpp:169).
-// Optionally fuses the M-step blend (onlinelda.cpp:99-100):
-//   lambda_out = (1-rho) lambda' + rho (eta + scale * sstats)
+// sstats_words_kernel writes the statistics only; sstats_update_kernel (4c, below) also applies
+// the M-step and collects the row sums of the lambda it writes.
 // ---------------------------------------------------------------------------
 // acc[h] += sum_{q in [q0, q1)} tw_word[q] * epg[kbase + 64 h + lane, wdoc[q]], h < NH topic
 // halves; q0, q1 are wave-uniform.  Per pass of 16 entries: lane u fetches (document,
@@ -1280,15 +1280,165 @@ __global__ __launch_bounds__(T) void sstats_words_kernel(
     }
 }
 
-// 4b. Atomic mode finish: sstats *= eeb (lda.cpp:217).
-template <int T>
-__global__ __launch_bounds__(T) void finish_kernel(size_t total, const double *__restrict__ eeb,
-                                                   double *__restrict__ sstats)
+// ---------------------------------------------------------------------------
+// 4c. Statistics, M-step and the next E-step's row sums in ONE pass over the words (K <= 512).
+//
+//   s[k, w]      = eeb[k, w] * sum_{q in word w} tw_word[q] * epg[k, wdoc[q]]    lda.cpp:207-217
+//   lambda[k, w] = omr * lambda'[k, w] + rho * (eta + scale * s[k, w])
+//       OnlineLDA  onlinelda.cpp:99-100, :108-109   omr = 1 - rho, scale = D / B
+//       BatchLDA   batchlda.cpp:60                  no lambda' term, rho = 1, scale = 1
+//       Cumulative cumulativelda.cpp:70             omr = 1, rho = 1, eta = 0, scale = 1
+//   partial[block][k] = sum over the block's words of lambda[k, w]                lda.cpp:172
+//
+// The same per-word ordered sums as sstats_words_kernel (bitwise the same s), but the words
+// come from a list -- all V, or only the batch's active words: inside a trust-region loop the
+// inactive ones do not change (stream_kernels.h) -- and a wave walks its share of the list
+// (positions wave * G + block, then every W * G further on) keeping the row sums of what it
+// writes in registers.  One kernel boundary later rowsum_combine_wave_kernel adds the block
+// partials (in block order) to the row sums of the inactive words: the next E-step starts
+// without reading lambda at all.  lambda' may be lambda itself (in-place update): an element
+// is read and written by the same thread.
+// ---------------------------------------------------------------------------
+struct UpdateOut {
+    double *sstats;               // K x V, or nullptr
+    double *lambda;               // K x V, or nullptr: no M-step
+    const double *lambda_prime;   // K x V, or nullptr: lambda = rho * (eta + scale * s)
+    double omr, rho, eta, scale;
+    double *partial;              // gridDim.x x K, or nullptr
+};
+
+__device__ __forceinline__ double update_one(const UpdateOut &o, size_t i, double s)
 {
-    const size_t stride = (size_t)gridDim.x * T;
-    for (size_t i = (size_t)blockIdx.x * T + threadIdx.x; i < total; i += stride)
-        sstats[i] *= eeb[i];
+    if (o.sstats)
+        o.sstats[i] = s;
+    double lam = 0.0;
+    if (o.lambda) {
+        const double hat = o.eta + o.scale * s;
+        lam = o.lambda_prime ? o.omr * o.lambda_prime[i] + o.rho * hat : o.rho * hat;
+        o.lambda[i] = lam;
+    }
+    return lam;
 }
+
+template <int T, int NKB>
+__global__ __launch_bounds__(T) void sstats_update_kernel(
+    int K, int N, int G_short, int n_long, const int32_t *__restrict__ list,
+    const int32_t *__restrict__ wptr, const int32_t *__restrict__ wdoc,
+    const int32_t *__restrict__ long_words, const double *__restrict__ tw_word,
+    const double *__restrict__ epg, const double *__restrict__ eeb, UpdateOut o)
+{
+    constexpr int W = T / kWave;
+    extern __shared__ double wpart[];                // W x K
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+
+    if ((int)blockIdx.x < G_short) {
+        double rs[NKB][2];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+            rs[kb][0] = rs[kb][1] = 0.0;
+        for (int p = wid * G_short + (int)blockIdx.x; p < N; p += W * G_short) {
+            const int w = __builtin_amdgcn_readfirstlane(list ? list[p] : p);
+            const int q0 = __builtin_amdgcn_readfirstlane(wptr[w]);
+            const int len = __builtin_amdgcn_readfirstlane(wptr[w + 1]) - q0;
+            if (len > kLongWord)
+                continue;                            // left to the blocks below
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                if (kb * 2 * kWave < K) {            // wave-uniform
+                    double acc[2] = {0.0, 0.0};
+                    if (len > 0)
+                        word_segment_sum<2>(q0, q0 + len, K, kb * 2 * kWave, wdoc, tw_word, epg, acc);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int k = kb * 2 * kWave + 64 * h + lane;
+                        if (k < K) {
+                            const size_t i = (size_t)w * K + k;
+                            // lda.cpp:169: words the batch does not touch are 0 (eeb is not read)
+                            const double s = len > 0 ? acc[h] * eeb[i] : 0.0;
+                            rs[kb][h] += update_one(o, i, s);
+                        }
+                    }
+                }
+            }
+        }
+        if (o.partial) {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int k = kb * 2 * kWave + 64 * h + lane;
+                    if (k < K)
+                        wpart[wid * K + k] = rs[kb][h];
+                }
+            __syncthreads();
+            for (int k = threadIdx.x; k < K; k += T) {
+                double sum = wpart[k];
+                for (int c = 1; c < W; ++c)
+                    sum += wpart[c * K + k];
+                o.partial[(size_t)blockIdx.x * K + k] = sum;
+            }
+        }
+        return;
+    }
+
+    // ---- long lists: the remaining blocks walk long_words, one word per pass, the entries
+    // split into W contiguous chunks whose sums are combined in chunk order
+    const int G_long = (int)gridDim.x - G_short;
+    double rsl[(512 + T - 1) / T];                   // row sums of thread k = tid (+ T ..)
+#pragma unroll
+    for (int c = 0; c < (512 + T - 1) / T; ++c)
+        rsl[c] = 0.0;
+    for (int lw = (int)blockIdx.x - G_short; lw < n_long; lw += G_long) {
+        const int w = long_words[lw];
+        const int base = __builtin_amdgcn_readfirstlane(wptr[w]);
+        const int L = __builtin_amdgcn_readfirstlane(wptr[w + 1]) - base;
+        const int chunk = (L + W - 1) / W;
+        const int c0 = __builtin_amdgcn_readfirstlane(min(L, wid * chunk));
+        const int c1 = __builtin_amdgcn_readfirstlane(min(L, c0 + chunk));
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (kb * 2 * kWave < K) {
+                double acc[2] = {0.0, 0.0};
+                word_segment_sum<2>(base + c0, base + c1, K, kb * 2 * kWave, wdoc, tw_word, epg, acc);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int k = kb * 2 * kWave + 64 * h + lane;
+                    if (k < K)
+                        wpart[wid * K + k] = acc[h];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < (512 + T - 1) / T; ++c) {
+            const int k = threadIdx.x + c * T;
+            if (k < K) {
+                double pv[W];
+#pragma unroll
+                for (int q = 0; q < W; ++q)
+                    pv[q] = wpart[q * K + k];
+                double acc = pv[0];
+#pragma unroll
+                for (int q = 1; q < W; ++q)
+                    acc += pv[q];
+                const size_t i = (size_t)w * K + k;
+                rsl[c] += update_one(o, i, acc * eeb[i]);
+            }
+        }
+        __syncthreads();
+    }
+    if (o.partial) {
+#pragma unroll
+        for (int c = 0; c < (512 + T - 1) / T; ++c) {
+            const int k = threadIdx.x + c * T;
+            if (k < K)
+                o.partial[(size_t)blockIdx.x * K + k] = rsl[c];
+        }
+    }
+}
+
+// 4b. Atomic mode finish: sstats *= eeb (lda.cpp:217): FinishOp in stream_kernels.h.
 
 // psi[i] = psi(x[i]); epsi[i] = exp(psi(x[i])) as the document kernels compute it (no
 // logarithm); epsi_lean[i] = the register-lean schedule of the same value; eminus[i] =
@@ -1311,33 +1461,6 @@ __global__ void digamma_table_kernel(int n, double c, const double *__restrict__
 // ---------------------------------------------------------------------------
 // M-step kernels.
 // ---------------------------------------------------------------------------
-
-// lambda = (1-rho) lambda' + rho (eta + scale * sstats)     onlinelda.cpp:99-100
-template <int T>
-__global__ __launch_bounds__(T) void blend_kernel(size_t total, double rho, double eta,
-                                                  double scale,
-                                                  const double *__restrict__ lambda_prime,
-                                                  const double *__restrict__ sstats,
-                                                  double *__restrict__ lambda)
-{
-    const size_t stride = (size_t)gridDim.x * T;
-    for (size_t i = (size_t)blockIdx.x * T + threadIdx.x; i < total; i += stride) {
-        const double hat = eta + scale * sstats[i];
-        lambda[i] = (1. - rho) * lambda_prime[i] + rho * hat;
-    }
-}
-
-// lambda = lambda' + sstats                                     cumulativelda.cpp:70
-template <int T>
-__global__ __launch_bounds__(T) void accumulate_kernel(size_t total,
-                                                       const double *__restrict__ lambda_prime,
-                                                       const double *__restrict__ sstats,
-                                                       double *__restrict__ lambda)
-{
-    const size_t stride = (size_t)gridDim.x * T;
-    for (size_t i = (size_t)blockIdx.x * T + threadIdx.x; i < total; i += stride)
-        lambda[i] = lambda_prime[i] + sstats[i];
-}
 
 // wordcounts[w] += cnt (integers in fp64: exact, order-free)   onlinelda.cpp:79-82
 template <int T>

@@ -27,8 +27,20 @@
 #include "estep_kernels.h"
 #include "estep_wide.h"
 #include "elbo_kernels.h"
+#include "stream_kernels.h"
+#include "eb_kernels.h"
 
 namespace {
+
+// frees a temporary device allocation on every path out of a function
+struct DevTemp {
+    void *p = nullptr;
+    ~DevTemp()
+    {
+        if (p)
+            (void)hipFree(p);
+    }
+};
 
 thread_local std::string g_error;
 
@@ -53,7 +65,10 @@ constexpr int kLdsBytes = 160 * 1024;   // LDS per workgroup on gfx950
 unsigned long long *g_stamp_buf = nullptr;
 #endif
 constexpr int kDenseThreads = 256;
-constexpr int kMaxRowsumBlocks = 1025;   // 1024 blocks on large tables + the combined row
+constexpr int kMaxRowsumBlocks = 1025;   // rows of trlda_model::partial (block partials of row sums)
+constexpr int kUpdShortBlocks = 1024;    // sstats_update_kernel: blocks walking the short lists
+constexpr int kUpdLongBlocks = 256;      //                       blocks walking the long lists
+constexpr double kFusedRowsumFloor = 2e-3;   // psi(2e-3) = -500.6: exp(-psi(row sum)) stays finite
 
 template <typename T>
 int dev_alloc(T **p, size_t count)
@@ -62,6 +77,22 @@ int dev_alloc(T **p, size_t count)
     if (count == 0)
         count = 1;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T)));
+    return TRLDA_OK;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel and size, not per launch
+int ensure_dynamic_lds(const void *func, size_t bytes)
+{
+    static std::mutex mu;
+    static std::map<const void *, size_t> granted;
+    if (bytes <= 48 * 1024)
+        return TRLDA_OK;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = granted.find(func);
+    if (it != granted.end() && it->second >= bytes)
+        return TRLDA_OK;
+    HIP_TRY(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    granted[func] = bytes;
     return TRLDA_OK;
 }
 
@@ -81,6 +112,14 @@ int use_device(int device)
 }  // namespace
 
 struct trlda_batch {
+    // Every array below lives in ONE device allocation (`blob`), filled by ONE host-to-device
+    // copy from pinned memory on the upload stream; `ready` marks the end of that copy and
+    // `done` the last kernel that read the batch (recorded by every entry point that uses it),
+    // so that creating, using and recycling batches never waits for the device.
+    void *blob = nullptr;
+    size_t blob_bytes = 0;
+    hipEvent_t ready = nullptr, done = nullptr;
+    bool used = false;
     int device = 0;
     int V = 0, B = 0, max_n = 0;
     int64_t nnz = 0;
@@ -91,6 +130,7 @@ struct trlda_batch {
     int32_t *wdoc = nullptr;    // document of each word-major entry
     int32_t *active = nullptr;  // ids of the words that occur in the batch (ascending)
     int n_active = 0;
+    uint8_t *active_flag = nullptr;   // V bytes: 1 for the words in `active`
     int32_t *long_words = nullptr;   // words with more than kLongWord entries
     int n_long = 0;
     // per document, in `order`: (document, length, CSR offset, 0) and its first kRegMaxN word
@@ -115,12 +155,35 @@ struct trlda_model {
     double *lambda = nullptr, *alpha = nullptr;
     double *eeb = nullptr, *psi_sum = nullptr, *partial = nullptr;
     unsigned int *counter = nullptr;
+    // Row sums carried from the kernels that wrote lambda: rs_full[k] = sum_w lambda[k, w]
+    // (lda.cpp:172) is valid while rs_valid, and the next E-step skips its row-sum pass.
+    // rs_static: the part over the words outside the current update's mini-batch.
+    double *rs_full = nullptr, *rs_static = nullptr, *upd_partial = nullptr;
+    bool rs_valid = false;
+    bool carry_rowsums = true;          // trlda_model_set_carry_rowsums (tests, comparisons)
+    bool fused_update = true;           // trlda_model_set_fused_update: statistics + M-step in one pass
+    bool keep_sstats = false;           // updates also leave the statistics (and all of lambda') behind
+    // A lower bound on every row sum of lambda, kept on the host: the fused preamble forms
+    // exp(-psi(row sum)), which overflows below 1.4e-3 (estep_kernels.h, 2b)
+    double rs_floor = 0.0;
+    int64_t d2h_bytes = 0;              // bytes copied to the host through this model (tests)
+    bool lambda_exposed = false;        // trlda_model_lambda_dev was handed out: never trust rs_*
     // per-batch workspaces, grown on demand
-    size_t cap_docs = 0, cap_nnz = 0;
+    size_t cap_docs = 0, cap_tw_csr = 0, cap_tw_word = 0;
     double *epg = nullptr, *tw_csr = nullptr, *tw_word = nullptr;
     // update_parameters workspaces
     double *lambda_prime = nullptr, *sstats = nullptr, *gamma = nullptr, *wordcounts = nullptr;
-    size_t cap_gamma = 0;
+    size_t cap_gamma = 0, cap_lambda_prime = 0, cap_sstats = 0, cap_wordcounts = 0;
+    double *stage[2] = {nullptr, nullptr};      // pinned host buffers for gamma0 draws
+    size_t cap_stage[2] = {0, 0};
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    int stage_next = 0;
+    // adaptive learning rate: running average of the updates (onlinelda.cpp:170), K x V
+    double *ada_gradient = nullptr;
+    double *reduce_out = nullptr;               // small buffer for block results of reductions
+    size_t cap_reduce = 0;
+    int32_t *iters = nullptr;                   // per-document iteration counts (estep_host)
+    size_t cap_iters = 0;
     // timing: five events per E-step from a pool, resolved lazily (no host sync per step)
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;   // all events ever created
@@ -131,54 +194,145 @@ struct trlda_model {
 
 namespace {
 
-int ensure_batch_workspace(trlda_model *m, const trlda_batch *b)
+// Per-device upload machinery: a non-blocking stream, two pinned staging buffers and a small
+// cache of device allocations.  hipMalloc / hipFree cost tens of microseconds and hipFree waits
+// for the whole device; a mini-batch lives for one update call.
+struct UploadContext {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    struct Stage {
+        void *host = nullptr;
+        size_t cap = 0;
+        hipEvent_t ev = nullptr;
+    } stage[2];
+    int next = 0;
+    struct Blob {
+        void *ptr;
+        size_t bytes;
+        hipEvent_t done;      // last reader of the previous owner (may be null)
+    };
+    std::vector<Blob> cache;
+    size_t cached_bytes = 0;
+    std::vector<hipEvent_t> events;   // spare events
+};
+
+UploadContext &upload_context(int device)
 {
-    if ((size_t)b->B > m->cap_docs) {
-        if (m->epg)
-            HIP_TRY(hipFree(m->epg));
-        int rc = dev_alloc(&m->epg, (size_t)b->B * m->K);
-        if (rc)
-            return rc;
-        m->cap_docs = (size_t)b->B;
+    static std::mutex mu;
+    static std::map<std::pair<pid_t, int>, UploadContext *> all;   // never destroyed (see host_pool)
+    std::lock_guard<std::mutex> lock(mu);
+    auto key = std::make_pair(getpid(), device);
+    auto it = all.find(key);
+    if (it == all.end())
+        it = all.emplace(key, new UploadContext()).first;
+    return *it->second;
+}
+
+constexpr size_t kBlobCacheMax = 8;
+constexpr size_t kBlobCacheBytes = (size_t)1 << 30;
+
+int take_event(UploadContext &u, hipEvent_t *ev)
+{
+    if (!u.events.empty()) {
+        *ev = u.events.back();
+        u.events.pop_back();
+        return TRLDA_OK;
     }
-    if ((size_t)b->nnz > m->cap_nnz) {
-        if (m->tw_csr)
-            HIP_TRY(hipFree(m->tw_csr));
-        if (m->tw_word)
-            HIP_TRY(hipFree(m->tw_word));
-        int rc = dev_alloc(&m->tw_csr, (size_t)b->nnz);
-        if (rc)
-            return rc;
-        rc = dev_alloc(&m->tw_word, (size_t)b->nnz);
-        if (rc)
-            return rc;
-        m->cap_nnz = (size_t)b->nnz;
+    HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    return TRLDA_OK;
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// every reader of a batch: wait for its upload, and leave a mark behind
+int batch_begin(trlda_model *m, const trlda_batch *b)
+{
+    if (b && b->ready)
+        HIP_TRY(hipStreamWaitEvent(m->stream, b->ready, 0));
+    return TRLDA_OK;
+}
+int batch_end(trlda_model *m, const trlda_batch *b)
+{
+    if (b && b->done) {
+        HIP_TRY(hipEventRecord(b->done, m->stream));
+        const_cast<trlda_batch *>(b)->used = true;
     }
     return TRLDA_OK;
+}
+
+// grow-only device buffer: on failure the pointer is null AND the capacity is 0, so a later,
+// smaller request allocates again instead of launching on a null pointer
+template <typename T>
+int grow(T **p, size_t *cap, size_t count)
+{
+    if (count <= *cap && *p)
+        return TRLDA_OK;
+    if (*p)
+        (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    int rc = dev_alloc(p, count);
+    if (rc)
+        return rc;
+    *cap = count;
+    return TRLDA_OK;
+}
+
+int ensure_batch_workspace(trlda_model *m, const trlda_batch *b)
+{
+    int rc = grow(&m->epg, &m->cap_docs, (size_t)std::max(b->B, 1) * m->K);
+    if (!rc) rc = grow(&m->tw_csr, &m->cap_tw_csr, (size_t)std::max<int64_t>(b->nnz, 1));
+    if (!rc) rc = grow(&m->tw_word, &m->cap_tw_word, (size_t)std::max<int64_t>(b->nnz, 1));
+    return rc;
 }
 
 int ensure_update_workspace(trlda_model *m, int B)
 {
     size_t KV = (size_t)m->K * m->V;
-    if (!m->lambda_prime) {
-        int rc = dev_alloc(&m->lambda_prime, KV);
-        if (rc)
-            return rc;
-        rc = dev_alloc(&m->sstats, KV);
-        if (rc)
-            return rc;
-        rc = dev_alloc(&m->wordcounts, (size_t)m->V);
-        if (rc)
-            return rc;
+    int rc = grow(&m->lambda_prime, &m->cap_lambda_prime, KV);
+    if (!rc) rc = grow(&m->sstats, &m->cap_sstats, KV);
+    if (!rc) rc = grow(&m->wordcounts, &m->cap_wordcounts, (size_t)m->V);
+    if (!rc) rc = grow(&m->gamma, &m->cap_gamma, (size_t)std::max(B, 1) * m->K);
+    return rc;
+}
+
+// pinned staging for the gamma0 draws (two slots: the host may draw the next one while the
+// previous upload is still in flight)
+int ensure_gamma_staging(trlda_model *m, size_t count)
+{
+    for (int i = 0; i < 2; ++i) {
+        if (count > m->cap_stage[i] || !m->stage[i]) {
+            if (m->stage[i]) {
+                (void)hipEventSynchronize(m->stage_ev[i]);
+                (void)hipHostFree(m->stage[i]);
+            }
+            m->stage[i] = nullptr;
+            m->cap_stage[i] = 0;
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&m->stage[i]),
+                                  std::max<size_t>(count, 1) * sizeof(double), hipHostMallocDefault));
+            m->cap_stage[i] = count;
+            if (!m->stage_ev[i])
+                HIP_TRY(hipEventCreateWithFlags(&m->stage_ev[i], hipEventDisableTiming));
+        }
     }
-    if ((size_t)B * m->K > m->cap_gamma) {
-        if (m->gamma)
-            HIP_TRY(hipFree(m->gamma));
-        int rc = dev_alloc(&m->gamma, (size_t)B * m->K);
-        if (rc)
-            return rc;
-        m->cap_gamma = (size_t)B * m->K;
-    }
+    return TRLDA_OK;
+}
+
+// gamma = sampleGamma(K, B, 100) / 100 from the host stream (lda.cpp:135), uploaded without
+// blocking: the draw of the next call can overlap the kernels of this one
+int fresh_gamma_device(trlda_model *m, int B)
+{
+    const size_t count = (size_t)m->K * B;
+    int rc = ensure_gamma_staging(m, count);
+    if (rc)
+        return rc;
+    const int slot = m->stage_next;
+    m->stage_next ^= 1;
+    HIP_TRY(hipEventSynchronize(m->stage_ev[slot]));   // the slot's previous upload is done
+    trlda_sample_gamma_init(m->K, B, m->stage[slot]);
+    HIP_TRY(hipMemcpyAsync(m->gamma, m->stage[slot], count * sizeof(double), hipMemcpyHostToDevice,
+                           m->stream));
+    HIP_TRY(hipEventRecord(m->stage_ev[slot], m->stream));
     return TRLDA_OK;
 }
 
@@ -219,8 +373,9 @@ template <int T>
 int launch_docs(trlda_model *m, const trlda::DocKernelArgs &args, int B, size_t lds_bytes)
 {
     auto kern = trlda::estep_docs_kernel<T>;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_bytes);
+    if (rc)
+        return rc;
     hipLaunchKernelGGL(kern, dim3(B), dim3(T), lds_bytes, m->stream, args);
     HIP_TRY(hipGetLastError());
     return TRLDA_OK;
@@ -234,8 +389,95 @@ size_t docs_lds_bytes(int K, int Kp, int n_cap, int T)
     return doubles * sizeof(double);
 }
 
-// The E-step launch sequence on the model's stream (no synchronisation).
-int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double *sstats_dev,
+// What the statistics stage of an E-step leaves behind.
+struct EstepOut {
+    trlda::UpdateOut upd;       // sstats and / or the M-step (estep_kernels.h, 4c)
+    bool active_only = false;   // walk the batch's active words only (fused path)
+    int partial_rows = 0;       // out: rows written to upd.partial
+    EstepOut() { upd = trlda::UpdateOut{nullptr, nullptr, nullptr, 0., 0., 0., 0., nullptr}; }
+    explicit EstepOut(double *sstats) : EstepOut() { upd.sstats = sstats; }
+};
+
+// statistics + M-step + row sums in one kernel: K <= 512, segmented mode
+bool fused_update_available(const trlda_model *m)
+{
+    return m->fused_update && m->K <= trlda::kWideMaxK && m->sstats_mode == TRLDA_SSTATS_SEGMENTED;
+}
+
+// the column-slot streaming kernels (stream_kernels.h) cover K <= 512
+bool stream_available(const trlda_model *m) { return m->K <= trlda::kWideMaxK; }
+
+int combine_rowsums(trlda_model *m, const double *partial, int G, const double *base, double *out)
+{
+    constexpr int T = 256;
+    hipLaunchKernelGGL(trlda::rowsum_combine_wave_kernel<T>, dim3((m->K + T / 64 - 1) / (T / 64)),
+                       dim3(T), 0, m->stream, m->K, G, partial, base, out);
+    HIP_TRY(hipGetLastError());
+    return TRLDA_OK;
+}
+
+template <int VEC>
+int launch_rowsum_stream(trlda_model *m, const trlda::StreamGeom &g, double *partial)
+{
+    constexpr int T = trlda::kStreamThreads;
+    const size_t lds = (size_t)g.cpb * m->K * sizeof(double);
+    hipLaunchKernelGGL((trlda::rowsum_stream_kernel<T, VEC>), dim3(g.G), dim3(T), lds, m->stream,
+                       m->K, m->V, g.P, g.cpb, m->lambda, partial);
+    HIP_TRY(hipGetLastError());
+    return TRLDA_OK;
+}
+
+// rs_full = row sums of lambda, from scratch (lda.cpp:172)
+int rowsums_from_scratch(trlda_model *m)
+{
+    const trlda::StreamGeom g = trlda::stream_geometry(m->K, m->V);
+    int rc = g.vec == 2 ? launch_rowsum_stream<2>(m, g, m->partial)
+                        : launch_rowsum_stream<1>(m, g, m->partial);
+    if (rc)
+        return rc;
+    return combine_rowsums(m, m->partial, g.G, nullptr, m->rs_full);
+}
+
+template <int T, int NKB>
+int launch_sstats_update(trlda_model *m, const trlda_batch *b, EstepOut &out)
+{
+    constexpr int W = T / trlda::kWave;
+    const int K = m->K;
+    const int N = out.active_only ? b->n_active : m->V;
+    const int G_short = std::max(1, std::min(kUpdShortBlocks, (N + W - 1) / W));
+    const int G_long = std::min(kUpdLongBlocks, b->n_long);
+    const size_t lds = (size_t)W * K * sizeof(double);
+    auto kern = trlda::sstats_update_kernel<T, NKB>;
+    int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+    if (rc)
+        return rc;
+    hipLaunchKernelGGL(kern, dim3(G_short + G_long), dim3(T), lds, m->stream, K, N, G_short,
+                       b->n_long, out.active_only ? b->active : nullptr, b->wptr, b->wdoc,
+                       b->long_words, m->tw_word, m->epg, m->eeb, out.upd);
+    HIP_TRY(hipGetLastError());
+    out.partial_rows = G_short + G_long;
+    return TRLDA_OK;
+}
+
+int sstats_update_device(trlda_model *m, const trlda_batch *b, EstepOut &out)
+{
+    const int NKB = (m->K + 127) / 128;
+    if (m->K >= 256) {
+        switch (NKB) {
+        case 2: return launch_sstats_update<512, 2>(m, b, out);
+        case 3: return launch_sstats_update<512, 3>(m, b, out);
+        default: return launch_sstats_update<512, 4>(m, b, out);
+        }
+    }
+    // one wavefront per word; 16 words per workgroup for small K, 8 from K = 256 on
+    // (measured: 7.1 vs 7.4 us at K = 100, 170 vs 145 us at K = 500)
+    return NKB == 1 ? launch_sstats_update<1024, 1>(m, b, out)
+                    : launch_sstats_update<1024, 2>(m, b, out);
+}
+
+// The E-step launch sequence on the model's stream (no synchronisation).  `out` says what the
+// statistics stage writes; an M-step in it (out.upd.lambda) needs fused_update_available().
+int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepOut &out,
                  int max_iter, double threshold, int32_t *iters_dev,
                  const double *gamma_in_dev = nullptr)
 {
@@ -247,29 +489,44 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
     if (b->device != m->device)
         return fail(TRLDA_ERR_ARG, "batch and model live on different devices");
     int rc = ensure_batch_workspace(m, b);
+    if (!rc)
+        rc = batch_begin(m, b);
     if (rc)
         return rc;
     const bool atomic = m->sstats_mode == TRLDA_SSTATS_ATOMIC;
+    if (out.upd.lambda && !fused_update_available(m))
+        return fail(TRLDA_ERR_ARG, "internal: fused M-step requested where it is not available");
+    double *sstats_dev = out.upd.sstats;
     if (m->timing && (rc = stamp(m)))
         return rc;
 
-    // 1. row sums of lambda, per block of words (lda.cpp:172).  Small tables: 64 blocks whose
-    // partials every eeb block adds up itself (saves a launch).  Large ones (tens of MB and
-    // more): up to 1024 blocks to fill HBM, then one small kernel combines the partials.
+    // 1. row sums of lambda (lda.cpp:172) -- unless the kernel that wrote lambda left them
+    // behind (rs_valid).  Small tables: 64 blocks whose partials the consumers add up
+    // themselves (saves a launch).  Large ones: the streaming kernel, then one small kernel
+    // combines the block partials.
     const bool big = KV >= ((size_t)1 << 22);
+    const bool trust = !m->lambda_exposed;
+    const bool carried = trust && m->rs_valid && m->carry_rowsums;
     int G = std::min(big ? kMaxRowsumBlocks - 1 : trlda::kRowsumBlocks, std::max(1, V / 32));
     const double *partial_in = m->partial;
     // Small table and every document in the register-resident kernel's range: kernels 1 and
     // 2 become one launch and the topic factors exp(-psiSum) are applied by the document
-    // kernel (estep_kernels.h, 2b)
+    // kernel (estep_kernels.h, 2b) -- as long as no row sum can be so small that exp(-psi(sum))
+    // overflows (rs_floor: a bound the host keeps through every update)
     const bool fused = !big && B > 0 && m->doc_threads == 0 && m->doc_kernel == TRLDA_DOCS_AUTO &&
-                       !m->split_preamble && K <= trlda::kRegMaxK && b->max_n <= trlda::kRegMaxN;
+                       !m->split_preamble && K <= trlda::kRegMaxK && b->max_n <= trlda::kRegMaxN &&
+                       trust && m->rs_floor >= kFusedRowsumFloor;
     m->last_preamble_fused = fused;
     if (fused) {
         constexpr int TP = 512;
-        G = std::min(trlda::kRowsumBlocks, std::max(1, V / 32));
-        int wpb = (V + G - 1) / G;
-        G = (V + wpb - 1) / wpb;
+        int wpb = 0;
+        if (carried) {
+            G = 0;                                   // no row-sum workgroups: all of them fill
+        } else {
+            G = std::min(trlda::kRowsumBlocks, std::max(1, V / 32));
+            wpb = (V + G - 1) / G;
+            G = (V + wpb - 1) / wpb;
+        }
         const bool dense = m->dense_preamble;
         const size_t total = dense ? KV : (size_t)K * (size_t)b->n_active;
         // G workgroups add up the row sums, the others fill exp(psi(lambda)): 256 in all, one
@@ -278,10 +535,23 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
         hipLaunchKernelGGL(preamble_fused_kernel<TP>, dim3(GP), dim3(TP), 0, m->stream, K, V, G, wpb,
                            total, m->lambda, m->partial, m->eeb, dense ? nullptr : b->active);
         HIP_TRY(hipGetLastError());
+        if (carried) {
+            partial_in = m->rs_full;
+            G = 1;
+        }
         if (m->timing && ((rc = stamp(m)) || (rc = stamp(m))))
             return rc;
     } else {
-    {
+    if (carried) {
+        partial_in = m->rs_full;
+        G = 1;
+    } else if (big && stream_available(m)) {
+        rc = rowsums_from_scratch(m);
+        if (rc)
+            return rc;
+        partial_in = m->rs_full;
+        G = 1;
+    } else {
         int wpb = (V + G - 1) / G;
         G = (V + wpb - 1) / wpb;
         hipLaunchKernelGGL(rowsum_partial_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads), 0,
@@ -309,9 +579,9 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
         size_t blocks = (total + TE - 1) / TE;
         int GE = (int)std::max<size_t>(1, std::min<size_t>(blocks, 256));
         size_t lds = (size_t)K * 9 * sizeof(double);
-        if (lds > 48 * 1024)
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(exp_elog_beta_kernel<TE>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        rc = ensure_dynamic_lds(reinterpret_cast<const void *>(exp_elog_beta_kernel<TE>), lds);
+        if (rc)
+            return rc;
         hipLaunchKernelGGL(exp_elog_beta_kernel<TE>, dim3(GE), dim3(TE), lds, m->stream, K, total, G,
                            m->lambda, partial_in, m->psi_sum, m->eeb,
                            dense ? nullptr : b->active);
@@ -322,8 +592,11 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
     }
 
     // 3. per-document fixed point (lda.cpp:174-204)
-    if (atomic)
+    if (atomic) {
+        if (!sstats_dev)
+            return fail(TRLDA_ERR_ARG, "internal: atomic statistics need an sstats buffer");
         HIP_TRY(hipMemsetAsync(sstats_dev, 0, KV * sizeof(double), m->stream));  // lda.cpp:169
+    }
     if (B > 0) {
         DocKernelArgs a;
         a.K = K; a.B = B;
@@ -346,7 +619,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
         a.wrank = b->wrank; a.tw_word = m->tw_word;
         a.sstats_acc = atomic ? sstats_dev : nullptr;
         a.max_iter = max_iter; a.threshold = threshold; a.iters_out = iters_dev;
-        a.partial = fused ? m->partial : nullptr;
+        a.partial = fused ? partial_in : nullptr;
         a.G = G;
         a.scale_out = fused ? m->psi_sum : nullptr;
         const int Kp = K | 1;
@@ -395,9 +668,8 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
 #define TRLDA_LAUNCH_WIDE(KSV)                                                             \
     do {                                                                                   \
         auto kern = estep_docs_wide_kernel<KSV>;                                           \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                  \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,            \
-                                    (int)lds_bytes));                                      \
+        if ((rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_bytes)))     \
+            return rc;                                                                     \
         hipLaunchKernelGGL(kern, dim3(n_wide), dim3(kWideThreads), lds_bytes, m->stream, a, \
                            lds_rows);                                                      \
     } while (0)
@@ -453,9 +725,8 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
             auto kern = longest <= 128                    ? estep_docs_reg_kernel<0>
                         : longest <= 144 && n_reg <= 256 ? estep_docs_reg_kernel<1>
                                                           : estep_docs_reg_kernel<2>;
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)kRegLdsBytes));
+            if ((rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), kRegLdsBytes)))
+                return rc;
             a.order = b->order + (B - n_reg);
             a.pad_meta = b->pad_meta + (size_t)(B - n_reg) * 4;
             a.pad_ids = b->pad_ids + (size_t)(B - n_reg) * kRegMaxN;
@@ -466,25 +737,29 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
     if (m->timing && (rc = stamp(m)))
         return rc;
 
-    // 4. sufficient statistics (lda.cpp:207-217)
+    // 4. sufficient statistics (lda.cpp:207-217), with the M-step and the next row sums where
+    // the caller asked for them
     if (atomic) {
-        size_t blocks = (KV + kDenseThreads - 1) / kDenseThreads;
-        int G = (int)std::min<size_t>(blocks, 256 * 8);
-        hipLaunchKernelGGL(finish_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads), 0, m->stream,
-                           KV, m->eeb, sstats_dev);
+        size_t blocks = (KV / 2 + kDenseThreads * 4 - 1) / (kDenseThreads * 4);
+        int GF = (int)std::max<size_t>(1, std::min<size_t>(blocks, 256 * 8));
+        hipLaunchKernelGGL((elementwise_stream_kernel<kDenseThreads, FinishOp>), dim3(GF),
+                           dim3(kDenseThreads), 0, m->stream, KV, FinishOp{m->eeb, sstats_dev});
+    } else if (fused_update_available(m)) {
+        rc = sstats_update_device(m, b, out);
+        if (rc)
+            return rc;
     } else {
+        if (!sstats_dev)
+            return fail(TRLDA_ERR_ARG, "internal: the statistics need an sstats buffer");
         // one wavefront per word; 16 words per workgroup for small K, 8 from K = 256 on
-        // (measured: 7.1 vs 7.4 us at K = 100, 170 vs 145 us at K = 500)
 #define TRLDA_LAUNCH_SSTATS(TS)                                                            \
     do {                                                                                   \
         constexpr int wpb = TS / kWave;                                                    \
         const int G_short = (V + wpb - 1) / wpb;                                           \
         size_t lds = (size_t)wpb * K * sizeof(double);                                     \
         auto kern = sstats_words_kernel<TS>;                                               \
-        if (lds > 48 * 1024)                                                               \
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),              \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize,        \
-                                        (int)lds));                                        \
+        if ((rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)))           \
+            return rc;                                                                     \
         hipLaunchKernelGGL(kern, dim3(G_short + b->n_long), dim3(TS), lds, m->stream, K, V, \
                            G_short, b->wptr, b->wdoc, b->long_words, m->tw_word, m->epg,   \
                            m->eeb, sstats_dev);                                            \
@@ -500,23 +775,43 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double
     // event records cost on an otherwise idle stream position (which = 4)
     if (m->timing && ((rc = stamp(m)) || (rc = stamp(m))))
         return rc;
+    return batch_end(m, b);
+}
+
+// sstats-only form (the E-step entry points)
+int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, double *sstats_dev,
+                 int max_iter, double threshold, int32_t *iters_dev,
+                 const double *gamma_in_dev = nullptr)
+{
+    EstepOut out(sstats_dev);
+    return estep_device(m, b, gamma_dev, out, max_iter, threshold, iters_dev, gamma_in_dev);
+}
+
+template <class Op>
+int launch_elementwise(trlda_model *m, size_t total, const Op &op)
+{
+    size_t blocks = (total / 2 + kDenseThreads * 4 - 1) / (kDenseThreads * 4);
+    int G = (int)std::max<size_t>(1, std::min<size_t>(blocks, 256 * 8));
+    hipLaunchKernelGGL((trlda::elementwise_stream_kernel<kDenseThreads, Op>), dim3(G),
+                       dim3(kDenseThreads), 0, m->stream, total, op);
+    HIP_TRY(hipGetLastError());
     return TRLDA_OK;
 }
 
 int blend_device(trlda_model *m, const double *lambda_prime, const double *sstats, double rho,
                  double eta, double scale)
 {
-    size_t KV = (size_t)m->K * m->V;
-    size_t blocks = (KV + kDenseThreads - 1) / kDenseThreads;
-    int G = (int)std::min<size_t>(blocks, 256 * 8);
-    hipLaunchKernelGGL(trlda::blend_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads), 0,
-                       m->stream, KV, rho, eta, scale, lambda_prime, sstats, m->lambda);
-    HIP_TRY(hipGetLastError());
-    return TRLDA_OK;
+    m->rs_valid = false;
+    m->rs_floor = rho * m->V * eta;     // (1 - rho) lambda' >= 0 whatever lambda' is
+    return launch_elementwise(m, (size_t)m->K * m->V,
+                              trlda::BlendOp{rho, eta, scale, lambda_prime, sstats, m->lambda});
 }
 
 int wordcounts_device(trlda_model *m, const trlda_batch *b, double *wc)
 {
+    int rcb = batch_begin(m, b);
+    if (rcb)
+        return rcb;
     HIP_TRY(hipMemsetAsync(wc, 0, (size_t)m->V * sizeof(double), m->stream));
     if (b->nnz > 0) {
         size_t blocks = ((size_t)b->nnz + kDenseThreads - 1) / kDenseThreads;
@@ -525,12 +820,52 @@ int wordcounts_device(trlda_model *m, const trlda_batch *b, double *wc)
                            m->stream, b->nnz, b->ids, b->cnts, wc);
         HIP_TRY(hipGetLastError());
     }
+    return batch_end(m, b);
+}
+
+// The streaming pass over the words of lambda outside the batch (stream_kernels.h):
+// block partials of the row sums go to m->partial rows [0, G) (inactive words) and
+// [kStreamMaxBlocks, kStreamMaxBlocks + G) (active words, ACT_TRINIT only).
+template <int ACT, bool SAVE_ALL>
+int launch_inactive_update(trlda_model *m, double a, double b, double rho, double eta, double coef,
+                           const uint8_t *flags, const double *wc, const double *src,
+                           double *lambda_prime, int *G_out)
+{
+    constexpr int T = trlda::kStreamThreads;
+    const trlda::StreamGeom g = trlda::stream_geometry(m->K, m->V);
+    const size_t lds = (size_t)g.cpb * m->K * sizeof(double);
+    double *ps = m->partial, *pa = m->partial + (size_t)trlda::kStreamMaxBlocks * m->K;
+    if (g.vec == 2)
+        hipLaunchKernelGGL((trlda::inactive_update_stream_kernel<T, 2, ACT, SAVE_ALL>), dim3(g.G),
+                           dim3(T), lds, m->stream, m->K, m->V, g.P, g.cpb, a, b, rho, eta, coef,
+                           flags, wc, src, m->lambda, lambda_prime, ps, pa);
+    else
+        hipLaunchKernelGGL((trlda::inactive_update_stream_kernel<T, 1, ACT, SAVE_ALL>), dim3(g.G),
+                           dim3(T), lds, m->stream, m->K, m->V, g.P, g.cpb, a, b, rho, eta, coef,
+                           flags, wc, src, m->lambda, lambda_prime, ps, pa);
+    HIP_TRY(hipGetLastError());
+    *G_out = g.G;
     return TRLDA_OK;
 }
 
+// lambda = (1 - rho) lambda' (+row) rho (eta + coef * wordcounts), lambda' a separate buffer
+// (onlinelda.cpp:85-86); leaves the row sums of the new lambda behind
 int tr_init_wc_device(trlda_model *m, const double *wc, const double *lambda_prime, double rho,
                       double eta, double coef)
 {
+    m->rs_valid = false;
+    m->rs_floor = rho * m->V * eta;
+    if (stream_available(m)) {
+        int G = 0;
+        int rc = launch_inactive_update<trlda::ACT_TRINIT, false>(m, 0., 0., rho, eta, coef, nullptr,
+                                                                  wc, lambda_prime, nullptr, &G);
+        if (!rc)
+            rc = combine_rowsums(m, m->partial + (size_t)trlda::kStreamMaxBlocks * m->K, G, nullptr,
+                                 m->rs_full);
+        if (!rc)
+            m->rs_valid = true;
+        return rc;
+    }
     size_t KV = (size_t)m->K * m->V;
     size_t blocks = (KV + kDenseThreads - 1) / kDenseThreads;
     int G = (int)std::min<size_t>(blocks, 256 * 8);
@@ -552,6 +887,26 @@ int tr_init_device(trlda_model *m, const trlda_batch *b, const double *lambda_pr
     // static_cast<double>(D) / B / K, evaluated in the reference's order (onlinelda.cpp:86)
     double coef = (double)num_documents / (double)b->B / (double)m->K;
     return tr_init_wc_device(m, m->wordcounts, lambda_prime, rho, eta, coef);
+}
+
+// lambda was replaced from host memory: the carried row sums are void, and the smallest row
+// sum (what decides whether the fused preamble is safe) is taken from the host copy.  Only
+// small tables can use the fused preamble; for the others 0 ("unknown") is as good.
+void note_host_lambda(trlda_model *m, const double *host_lambda)
+{
+    m->rs_valid = false;
+    m->rs_floor = 0.0;
+    const size_t K = (size_t)m->K, V = (size_t)m->V;
+    if (K * V >= ((size_t)1 << 22) || m->K > trlda::kRegMaxK)
+        return;
+    std::vector<double> sum(K, 0.0);
+    for (size_t w = 0; w < V; ++w)
+        for (size_t k = 0; k < K; ++k)
+            sum[k] += host_lambda[w * K + k];
+    double lo = sum[0];
+    for (size_t k = 1; k < K; ++k)
+        lo = std::min(lo, sum[k]);
+    m->rs_floor = lo > 0.0 ? 0.999 * lo : 0.0;   // NaN compares false -> 0
 }
 
 int check_model(const trlda_model *m)
@@ -658,7 +1013,9 @@ void jump_multiply(const JumpMatrix &x, const JumpMatrix &y, JumpMatrix &out)
     }
 }
 
-const JumpMatrix &jump_power(uint64_t n)
+// Returned BY VALUE (3.8 kB): the cache below evicts, and a caller holds several powers at once
+// and hands them to worker threads -- a reference into the map would dangle after an eviction.
+JumpMatrix jump_power(uint64_t n)
 {
     static std::mutex mu;
     static std::map<uint64_t, JumpMatrix> cache;
@@ -683,7 +1040,8 @@ const JumpMatrix &jump_power(uint64_t n)
     }
     if (cache.size() > 64)
         cache.clear();
-    return cache.emplace(n, result).first->second;
+    cache.emplace(n, result);
+    return result;
 }
 
 // window (oldest first) <-> the circular buffer of GlibcRandom
@@ -824,6 +1182,21 @@ void trlda_seed(unsigned int seed)
     g_rng.seed(seed);
 }
 
+// the generator's whole state: 31 words, then the two indices
+void trlda_rng_get_state(uint32_t *state33)
+{
+    std::memcpy(state33, g_rng.x, sizeof(g_rng.x));
+    state33[31] = (uint32_t)g_rng.f;
+    state33[32] = (uint32_t)g_rng.b;
+}
+
+void trlda_rng_set_state(const uint32_t *state33)
+{
+    std::memcpy(g_rng.x, state33, sizeof(g_rng.x));
+    g_rng.f = (int)(state33[31] % 31u);
+    g_rng.b = (int)(state33[32] % 31u);
+}
+
 void trlda_sample_gamma(int m, int n, int k, double *out)
 {
     const int64_t total = (int64_t)m * n;
@@ -855,9 +1228,9 @@ void trlda_sample_gamma(int m, int n, int k, double *out)
     const int64_t len = (total + T - 1) / T;
     T = (total + len - 1) / len;
     const int64_t last_len = total - (T - 1) * len;
-    const JumpMatrix &hop = jump_power((uint64_t)len);                     // thread t -> t + 1
-    const JumpMatrix &skip = jump_power((uint64_t)(total - len));          // pass p -> p + 1
-    const JumpMatrix &skip_last = jump_power((uint64_t)(total - last_len));
+    const JumpMatrix hop = jump_power((uint64_t)len);                      // thread t -> t + 1
+    const JumpMatrix skip = jump_power((uint64_t)(total - len));           // pass p -> p + 1
+    const JumpMatrix skip_last = jump_power((uint64_t)(total - last_len));
     std::vector<GlibcRandom> start((size_t)T);
     {
         uint32_t w[31];
@@ -979,80 +1352,165 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     if (rc)
         return rc;
 
-    // word-major index: stable counting sort of the CSR positions by word id
-    std::vector<int32_t> wptr((size_t)V + 1, 0), wrank((size_t)std::max<int64_t>(nnz, 1)),
-        wdoc((size_t)std::max<int64_t>(nnz, 1)), order((size_t)std::max(B, 1));
+    // word-major segment offsets first: they give the number of active and long words, i.e.
+    // the layout of the allocation
+    std::vector<int32_t> wptr((size_t)V + 1, 0);
     for (int64_t i = 0; i < nnz; ++i)
         ++wptr[(size_t)ids[i] + 1];
-    for (int w = 0; w < V; ++w)
+    int n_active = 0, n_long = 0;
+    for (int w = 0; w < V; ++w) {
+        const int len = wptr[(size_t)w + 1];
+        n_active += len > 0;
+        n_long += len > trlda::kLongWord;
         wptr[(size_t)w + 1] += wptr[(size_t)w];
+    }
+
+    // layout (bytes, 256-aligned sections)
+    size_t off = 0;
+    auto section = [&](size_t bytes) {
+        const size_t at = off;
+        off = align256(off + std::max<size_t>(bytes, 4));
+        return at;
+    };
+    const size_t nz = (size_t)nnz, Bz = (size_t)B;
+    const size_t o_indptr = section((Bz + 1) * 4), o_ids = section(nz * 4), o_cnts = section(nz * 4),
+                 o_order = section(Bz * 4), o_wrank = section(nz * 4),
+                 o_wptr = section(((size_t)V + 1) * 4), o_wdoc = section(nz * 4),
+                 o_meta = section(Bz * 16), o_pids = section(Bz * trlda::kRegMaxN * 4),
+                 o_active = section((size_t)n_active * 4), o_long = section((size_t)n_long * 4),
+                 o_flag = section((size_t)V);
+    const size_t total = off;
+
+    UploadContext &u = upload_context(device);
+    std::lock_guard<std::mutex> lock(u.mu);
+    if (!u.stream)
+        HIP_TRY(hipStreamCreateWithFlags(&u.stream, hipStreamNonBlocking));
+    UploadContext::Stage &st = u.stage[u.next];
+    u.next ^= 1;
+    if (st.ev)
+        HIP_TRY(hipEventSynchronize(st.ev));         // the slot's previous upload has left
+    if (st.cap < total) {
+        if (st.host)
+            (void)hipHostFree(st.host);
+        st.host = nullptr;
+        st.cap = 0;
+        const size_t want = std::max<size_t>(total + total / 2, (size_t)1 << 20);
+        HIP_TRY(hipHostMalloc(&st.host, want, hipHostMallocDefault));
+        st.cap = want;
+    }
+    if (!st.ev)
+        HIP_TRY(hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
+    char *h = static_cast<char *>(st.host);
+    auto I = [&](size_t o) { return reinterpret_cast<int32_t *>(h + o); };
+
+    std::memcpy(I(o_indptr), indptr, (Bz + 1) * 4);
+    if (nz) {
+        std::memcpy(I(o_ids), ids, nz * 4);
+        std::memcpy(I(o_cnts), cnts, nz * 4);
+    }
+    std::memcpy(I(o_wptr), wptr.data(), ((size_t)V + 1) * 4);
+    // stable counting sort of the CSR positions by word id
     {
+        int32_t *wrank = I(o_wrank), *wdoc = I(o_wdoc);
         std::vector<int32_t> cursor(wptr.begin(), wptr.end() - 1);
         for (int d = 0; d < B; ++d)
             for (int32_t p = indptr[d]; p < indptr[d + 1]; ++p) {
-                int32_t q = cursor[(size_t)ids[p]]++;
-                wrank[(size_t)p] = q;
-                wdoc[(size_t)q] = d;
+                const int32_t q = cursor[(size_t)ids[p]]++;
+                wrank[p] = q;
+                wdoc[q] = d;
             }
     }
-    std::iota(order.begin(), order.begin() + B, 0);
-    std::stable_sort(order.begin(), order.begin() + B, [&](int32_t x, int32_t y) {
+    int32_t *order = I(o_order);
+    std::iota(order, order + B, 0);
+    std::stable_sort(order, order + B, [&](int32_t x, int32_t y) {
         return indptr[x + 1] - indptr[x] > indptr[y + 1] - indptr[y];
     });
 
     trlda_batch *b = new trlda_batch();
     b->device = device; b->V = V; b->B = B; b->nnz = nnz; b->max_n = max_n;
-    b->sorted_len.resize((size_t)B);
-    for (int i = 0; i < B; ++i)
-        b->sorted_len[(size_t)i] = indptr[order[(size_t)i] + 1] - indptr[order[(size_t)i]];
-    auto up = [&](int32_t **dst, const int32_t *src, size_t count) -> int {
-        int r = dev_alloc(dst, count);
-        if (r)
-            return r;
-        if (count)
-            HIP_TRY(hipMemcpy(*dst, src, count * sizeof(int32_t), hipMemcpyHostToDevice));
-        return TRLDA_OK;
-    };
-    rc = up(&b->indptr, indptr, (size_t)B + 1);
-    if (!rc) rc = up(&b->ids, ids, (size_t)nnz);
-    if (!rc) rc = up(&b->cnts, cnts, (size_t)nnz);
-    if (!rc) rc = up(&b->order, order.data(), (size_t)B);
-    if (!rc) rc = up(&b->wrank, wrank.data(), (size_t)nnz);
-    if (!rc) rc = up(&b->wptr, wptr.data(), (size_t)V + 1);
-    if (!rc) rc = up(&b->wdoc, wdoc.data(), (size_t)nnz);
+    b->n_active = n_active; b->n_long = n_long;
+    b->sorted_len.resize(Bz);
     {
-        std::vector<int32_t> meta((size_t)std::max(B, 1) * 4, 0),
-            pids((size_t)std::max(B, 1) * trlda::kRegMaxN, 0);
+        int32_t *meta = I(o_meta), *pids = I(o_pids);
         for (int i = 0; i < B; ++i) {
-            const int d = order[(size_t)i], p0 = indptr[d], n = indptr[d + 1] - p0;
+            const int d = order[i], p0 = indptr[d], n = indptr[d + 1] - p0;
+            b->sorted_len[(size_t)i] = n;
             meta[(size_t)i * 4] = d;
             meta[(size_t)i * 4 + 1] = n;
             meta[(size_t)i * 4 + 2] = p0;
+            meta[(size_t)i * 4 + 3] = 0;
             // words past the document repeat its last id (rows that exist; masked by length)
-            for (int j = 0; j < trlda::kRegMaxN; ++j)
-                pids[(size_t)i * trlda::kRegMaxN + j] = n > 0 ? ids[p0 + std::min(j, n - 1)] : 0;
+            int32_t *row = pids + (size_t)i * trlda::kRegMaxN;
+            const int m0 = std::min(n, trlda::kRegMaxN);
+            for (int j = 0; j < m0; ++j)
+                row[j] = ids[p0 + j];
+            const int32_t fill = n > 0 ? ids[p0 + std::min(n, trlda::kRegMaxN) - 1] : 0;
+            for (int j = m0; j < trlda::kRegMaxN; ++j)
+                row[j] = fill;
         }
-        if (!rc) rc = up(&b->pad_meta, meta.data(), (size_t)B * 4);
-        if (!rc) rc = up(&b->pad_ids, pids.data(), (size_t)B * trlda::kRegMaxN);
     }
     {
-        std::vector<int32_t> active;
-        for (int w = 0; w < V; ++w)
-            if (wptr[(size_t)w + 1] > wptr[(size_t)w])
-                active.push_back(w);
-        b->n_active = (int)active.size();
-        if (!rc) rc = up(&b->active, active.data(), active.size());
-        std::vector<int32_t> longw;
-        for (int w : active)
-            if (wptr[(size_t)w + 1] - wptr[(size_t)w] > trlda::kLongWord)
-                longw.push_back(w);
-        b->n_long = (int)longw.size();
-        if (!rc) rc = up(&b->long_words, longw.data(), longw.size());
+        int32_t *active = I(o_active), *longw = I(o_long);
+        uint8_t *flag = reinterpret_cast<uint8_t *>(h + o_flag);
+        int na = 0, nl = 0;
+        for (int w = 0; w < V; ++w) {
+            const int len = wptr[(size_t)w + 1] - wptr[(size_t)w];
+            flag[w] = len > 0;
+            if (len > 0)
+                active[na++] = w;
+            if (len > trlda::kLongWord)
+                longw[nl++] = w;
+        }
     }
-    if (rc) {
-        trlda_batch_destroy(b);
-        return rc;
+
+    // a device allocation: from the cache when one fits, else new
+    UploadContext::Blob blob{nullptr, 0, nullptr};
+    for (size_t i = 0; i < u.cache.size(); ++i)
+        if (u.cache[i].bytes >= total && u.cache[i].bytes <= 4 * total + ((size_t)1 << 20)) {
+            blob = u.cache[i];
+            u.cached_bytes -= blob.bytes;
+            u.cache.erase(u.cache.begin() + (long)i);
+            break;
+        }
+    if (!blob.ptr) {
+        size_t want = (size_t)1 << 16;
+        while (want < total)
+            want <<= 1;
+        hipError_t e = hipMalloc(&blob.ptr, want);
+        if (e != hipSuccess) {
+            delete b;
+            return fail(TRLDA_ERR_HIP, std::string("hipMalloc (batch): ") + hipGetErrorString(e));
+        }
+        blob.bytes = want;
     }
+    b->blob = blob.ptr;
+    b->blob_bytes = blob.bytes;
+    hipError_t err = hipSuccess;
+    if (blob.done) {                                 // the previous owner's last reader
+        err = hipStreamWaitEvent(u.stream, blob.done, 0);
+        u.events.push_back(blob.done);
+    }
+    if (err == hipSuccess)
+        err = hipMemcpyAsync(b->blob, st.host, total, hipMemcpyHostToDevice, u.stream);
+    if (err == hipSuccess)
+        err = hipEventRecord(st.ev, u.stream);
+    if (err == hipSuccess && take_event(u, &b->ready) == TRLDA_OK && take_event(u, &b->done) == TRLDA_OK)
+        err = hipEventRecord(b->ready, u.stream);
+    else if (err == hipSuccess)
+        err = hipErrorOutOfMemory;
+    if (err != hipSuccess) {
+        (void)hipStreamSynchronize(u.stream);
+        (void)hipFree(b->blob);
+        delete b;
+        return fail(TRLDA_ERR_HIP, std::string("batch upload: ") + hipGetErrorString(err));
+    }
+    char *dv = static_cast<char *>(b->blob);
+    auto D = [&](size_t o) { return reinterpret_cast<int32_t *>(dv + o); };
+    b->indptr = D(o_indptr); b->ids = D(o_ids); b->cnts = D(o_cnts); b->order = D(o_order);
+    b->wrank = D(o_wrank); b->wptr = D(o_wptr); b->wdoc = D(o_wdoc);
+    b->pad_meta = D(o_meta); b->pad_ids = D(o_pids);
+    b->active = D(o_active); b->long_words = D(o_long);
+    b->active_flag = reinterpret_cast<uint8_t *>(dv + o_flag);
     *out = b;
     return TRLDA_OK;
 }
@@ -1061,11 +1519,23 @@ int trlda_batch_destroy(trlda_batch *b)
 {
     if (!b)
         return TRLDA_OK;
-    if (hipSetDevice(b->device) == hipSuccess) {
-        (void)hipFree(b->indptr); (void)hipFree(b->ids); (void)hipFree(b->cnts); (void)hipFree(b->order);
-        (void)hipFree(b->wrank); (void)hipFree(b->wptr); (void)hipFree(b->wdoc);
-        (void)hipFree(b->active); (void)hipFree(b->long_words);
-        (void)hipFree(b->pad_meta); (void)hipFree(b->pad_ids);
+    if (b->blob && hipSetDevice(b->device) == hipSuccess) {
+        UploadContext &u = upload_context(b->device);
+        std::lock_guard<std::mutex> lock(u.mu);
+        // recycle: whoever takes the allocation next waits (on the upload stream) for this
+        // batch's last reader; a batch nobody read is guarded by its own upload
+        hipEvent_t guard = b->used ? b->done : b->ready;
+        hipEvent_t spare = b->used ? b->ready : b->done;
+        if (spare)
+            u.events.push_back(spare);
+        if (u.cache.size() < kBlobCacheMax && u.cached_bytes + b->blob_bytes <= kBlobCacheBytes) {
+            u.cache.push_back(UploadContext::Blob{b->blob, b->blob_bytes, guard});
+            u.cached_bytes += b->blob_bytes;
+        } else {
+            (void)hipFree(b->blob);                  // waits for the device: nothing reads it after
+            if (guard)
+                u.events.push_back(guard);
+        }
     }
     delete b;
     return TRLDA_OK;
@@ -1096,14 +1566,18 @@ int trlda_model_create(trlda_model **out, int device, int K, int V)
     if (!rc) rc = dev_alloc(&m->psi_sum, 3 * (size_t)K);   // psi(row sums), the row sums, exp(-psi)
     if (!rc) rc = dev_alloc(&m->partial, (size_t)kMaxRowsumBlocks * K);
     if (!rc) rc = dev_alloc(&m->counter, 1);
+    if (!rc) rc = dev_alloc(&m->rs_full, (size_t)K);
+    if (!rc) rc = dev_alloc(&m->rs_static, (size_t)K);
+    if (!rc) rc = dev_alloc(&m->upd_partial, (size_t)(kUpdShortBlocks + kUpdLongBlocks) * K);
+    // columns of words no batch has touched yet are never read for their value, but the
+    // atomic-mode finish multiplies them by 0: keep them finite
+    if (!rc && (hipMemset(m->counter, 0, sizeof(unsigned int)) != hipSuccess ||
+                hipMemset(m->eeb, 0, KV * sizeof(double)) != hipSuccess))
+        rc = fail(TRLDA_ERR_HIP, "hipMemset failed");
     if (rc) {
         trlda_model_destroy(m);
         return rc;
     }
-    HIP_TRY(hipMemset(m->counter, 0, sizeof(unsigned int)));
-    // columns of words no batch has touched yet are never read for their value, but the
-    // atomic-mode finish multiplies them by 0: keep them finite
-    HIP_TRY(hipMemset(m->eeb, 0, KV * sizeof(double)));
     *out = m;
     return TRLDA_OK;
 }
@@ -1117,7 +1591,15 @@ int trlda_model_destroy(trlda_model *m)
         (void)hipFree(m->lambda); (void)hipFree(m->alpha); (void)hipFree(m->eeb); (void)hipFree(m->psi_sum);
         (void)hipFree(m->partial); (void)hipFree(m->counter); (void)hipFree(m->epg); (void)hipFree(m->tw_csr);
         (void)hipFree(m->tw_word); (void)hipFree(m->lambda_prime); (void)hipFree(m->sstats); (void)hipFree(m->gamma);
-        (void)hipFree(m->wordcounts);
+        (void)hipFree(m->wordcounts); (void)hipFree(m->rs_full); (void)hipFree(m->rs_static);
+        (void)hipFree(m->upd_partial); (void)hipFree(m->ada_gradient); (void)hipFree(m->reduce_out);
+        (void)hipFree(m->iters);
+        for (int i = 0; i < 2; ++i) {
+            if (m->stage[i])
+                (void)hipHostFree(m->stage[i]);
+            if (m->stage_ev[i])
+                (void)hipEventDestroy(m->stage_ev[i]);
+        }
         for (auto &e : m->ev_pool)
             (void)hipEventDestroy(e);
 
@@ -1205,6 +1687,7 @@ int trlda_model_set_lambda(trlda_model *m, const double *host_lambda)
         return fail(TRLDA_ERR_ARG, "lambda is NULL");
     HIP_TRY(hipMemcpyAsync(m->lambda, host_lambda, (size_t)m->K * m->V * sizeof(double),
                            hipMemcpyHostToDevice, m->stream));
+    note_host_lambda(m, host_lambda);     // while the copy runs
     HIP_TRY(hipStreamSynchronize(m->stream));
     return TRLDA_OK;
 }
@@ -1218,6 +1701,7 @@ int trlda_model_get_lambda(trlda_model *m, double *host_lambda)
         return fail(TRLDA_ERR_ARG, "lambda is NULL");
     HIP_TRY(hipMemcpyAsync(host_lambda, m->lambda, (size_t)m->K * m->V * sizeof(double),
                            hipMemcpyDeviceToHost, m->stream));
+    m->d2h_bytes += (int64_t)((size_t)m->K * m->V * sizeof(double));
     HIP_TRY(hipStreamSynchronize(m->stream));
     return TRLDA_OK;
 }
@@ -1238,7 +1722,16 @@ int trlda_model_set_alpha(trlda_model *m, const double *host_alpha)
     return TRLDA_OK;
 }
 
-void *trlda_model_lambda_dev(trlda_model *m) { return m ? m->lambda : nullptr; }
+void *trlda_model_lambda_dev(trlda_model *m)
+{
+    if (!m)
+        return nullptr;
+    // whoever holds this pointer may write lambda: nothing is known about its row sums any more
+    m->rs_valid = false;
+    m->rs_floor = 0.0;
+    m->lambda_exposed = true;
+    return m->lambda;
+}
 
 int trlda_model_get_sstats(trlda_model *m, double *host_sstats)
 {
@@ -1251,6 +1744,7 @@ int trlda_model_get_sstats(trlda_model *m, double *host_sstats)
         return fail(TRLDA_ERR_ARG, "no E-step has run through this model's own workspace yet");
     HIP_TRY(hipMemcpyAsync(host_sstats, m->sstats, (size_t)m->K * m->V * sizeof(double),
                            hipMemcpyDeviceToHost, m->stream));
+    m->d2h_bytes += (int64_t)((size_t)m->K * m->V * sizeof(double));
     HIP_TRY(hipStreamSynchronize(m->stream));
     return TRLDA_OK;
 }
@@ -1293,9 +1787,10 @@ int trlda_model_estep_host(trlda_model *m, const trlda_batch *b, double *gamma, 
     const size_t sbytes = (size_t)m->K * m->V * sizeof(double);
     int32_t *iters_dev = nullptr;
     if (iters_out) {
-        rc = dev_alloc(&iters_dev, (size_t)b->B);
+        rc = grow(&m->iters, &m->cap_iters, (size_t)std::max(b->B, 1));
         if (rc)
             return rc;
+        iters_dev = m->iters;
     }
     if (gbytes)
         HIP_TRY(hipMemcpyAsync(m->gamma, gamma, gbytes, hipMemcpyHostToDevice, m->stream));
@@ -1308,9 +1803,8 @@ int trlda_model_estep_host(trlda_model *m, const trlda_batch *b, double *gamma, 
             HIP_TRY(hipMemcpyAsync(iters_out, iters_dev, (size_t)b->B * sizeof(int32_t),
                                    hipMemcpyDeviceToHost, m->stream));
         HIP_TRY(hipStreamSynchronize(m->stream));
+        m->d2h_bytes += (int64_t)(gbytes + sbytes);
     }
-    if (iters_dev)
-        (void)hipFree(iters_dev);
     return rc;
 }
 
@@ -1336,16 +1830,17 @@ int trlda_model_lower_bound(trlda_model *m, const trlda_batch *b, double *gamma,
     if (rc)
         return rc;
     const int G = (int)std::min<size_t>((KV + kDenseThreads - 1) / kDenseThreads, 1024);
-    double *out = nullptr;
-    rc = dev_alloc(&out, 2 * (size_t)G + 2 * (size_t)B);
+    rc = grow(&m->reduce_out, &m->cap_reduce, 2 * (size_t)G + 2 * (size_t)B);
     if (rc)
         return rc;
+    double *out = m->reduce_out;
     hipLaunchKernelGGL(trlda::elbo_dense_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads), 0,
                        m->stream, K, KV, eta, factor, m->lambda, m->psi_sum, m->sstats, out);
     const size_t lds = ((size_t)K + 4 * (kDenseThreads / trlda::kWave)) * sizeof(double);
     hipLaunchKernelGGL(trlda::elbo_docs_kernel<kDenseThreads>, dim3(B), dim3(kDenseThreads), lds,
                        m->stream, K, b->indptr, b->ids, b->cnts, m->lambda, m->psi_sum, m->alpha,
                        m->gamma, out + 2 * (size_t)G);
+    (void)batch_end(m, b);
     std::vector<double> h(2 * (size_t)G + 2 * (size_t)B), lam_sum((size_t)K), alpha_h((size_t)K);
     hipError_t e1 = hipMemcpyAsync(h.data(), out, h.size() * sizeof(double), hipMemcpyDeviceToHost,
                                    m->stream);
@@ -1353,7 +1848,6 @@ int trlda_model_lower_bound(trlda_model *m, const trlda_batch *b, double *gamma,
     hipError_t e3 = hipMemcpyAsync(alpha_h.data(), m->alpha, (size_t)K * sizeof(double),
                                    hipMemcpyDeviceToHost, m->stream);
     hipError_t e4 = hipStreamSynchronize(m->stream);
-    (void)hipFree(out);
     HIP_TRY(e1); HIP_TRY(e2); HIP_TRY(e3); HIP_TRY(e4);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(lam_sum.data(), m->psi_sum + K, (size_t)K * sizeof(double),
@@ -1437,6 +1931,122 @@ int trlda_model_copy_lambda(trlda_model *m, double *dst_dev)
     return TRLDA_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// rs_full = rs_static (or nothing) + the block partials the statistics kernel left behind
+int finish_rowsums(trlda_model *m, const EstepOut &out, const double *base, double floor)
+{
+    int rc = combine_rowsums(m, out.upd.partial, out.partial_rows, base, m->rs_full);
+    if (rc)
+        return rc;
+    m->rs_valid = true;
+    m->rs_floor = floor;
+    return TRLDA_OK;
+}
+
+// rs_full for the E-step that follows, when nothing carried it here (big tables only: the
+// small-table preamble adds up lambda itself)
+int ensure_rowsums(trlda_model *m)
+{
+    if ((m->rs_valid && m->carry_rowsums && !m->lambda_exposed) || !stream_available(m))
+        return TRLDA_OK;
+    if ((size_t)m->K * m->V < ((size_t)1 << 22))
+        return TRLDA_OK;
+    int rc = rowsums_from_scratch(m);
+    if (!rc)
+        m->rs_valid = true;      // lambda has not changed since: they ARE its row sums
+    return rc;
+}
+
+// OnlineLDA::updateParameters' lambda path with the statistics, the M-step and the next row
+// sums in one kernel per trust-region iteration, restricted to the batch's active words
+// (sstats_update_kernel; stream_kernels.h for the words outside the batch).
+int online_update_fused(trlda_model *m, const trlda_batch *b, int num_documents, double eta,
+                        int max_iter_tr, int max_iter_inference, double rho, int init_gamma,
+                        double threshold)
+{
+    const int K = m->K, V = m->V, B = b->B;
+    const size_t KV = (size_t)K * V;
+    const double scale = (double)num_documents / (double)B;
+    const double floor_after = (1. - rho) * m->rs_floor + rho * V * eta;   // sstats >= 0
+    const bool keep = m->keep_sstats;     // adaptive rate: whole lambda' and the statistics stay
+    int rc = TRLDA_OK, G = 0;
+
+    EstepOut out;
+    out.upd.omr = 1. - rho; out.upd.rho = rho; out.upd.eta = eta; out.upd.scale = scale;
+    out.upd.lambda = m->lambda;
+    out.upd.partial = m->upd_partial;
+
+    if (max_iter_tr > 0) {
+        // onlinelda.cpp:79-86 for the active words, the final value for all the others
+        rc = wordcounts_device(m, b, m->wordcounts);
+        const double coef = (double)num_documents / (double)B / (double)K;   // onlinelda.cpp:86
+        if (!rc)
+            rc = keep ? launch_inactive_update<trlda::ACT_TRINIT, true>(
+                            m, 1. - rho, rho * eta, rho, eta, coef, b->active_flag, m->wordcounts,
+                            m->lambda, m->lambda_prime, &G)
+                      : launch_inactive_update<trlda::ACT_TRINIT, false>(
+                            m, 1. - rho, rho * eta, rho, eta, coef, b->active_flag, m->wordcounts,
+                            m->lambda, m->lambda_prime, &G);
+        if (!rc) rc = combine_rowsums(m, m->partial, G, nullptr, m->rs_static);
+        if (!rc) rc = combine_rowsums(m, m->partial + (size_t)trlda::kStreamMaxBlocks * K, G,
+                                      m->rs_static, m->rs_full);
+        if (rc)
+            return rc;
+        m->rs_valid = true;
+        m->rs_floor = floor_after;         // the initial step obeys the same bound
+        out.upd.lambda_prime = m->lambda_prime;
+        for (int i = 0; !rc && i < max_iter_tr; ++i) {       // onlinelda.cpp:89-101
+            if (!(i > 0 && init_gamma))
+                rc = fresh_gamma_device(m, B);               // lda.cpp:135
+            const bool last = i + 1 == max_iter_tr;
+            out.active_only = !(keep && last);
+            out.upd.sstats = (keep && last) ? m->sstats : nullptr;
+            if (!rc)
+                rc = estep_device(m, b, m->gamma, out, max_iter_inference, threshold, nullptr);
+            if (!rc)
+                rc = finish_rowsums(m, out, out.active_only ? m->rs_static : nullptr, floor_after);
+        }
+        return rc;
+    }
+
+    // onlinelda.cpp:103-109: one E-step on the old lambda, then the M-step in place
+    rc = fresh_gamma_device(m, B);
+    if (!rc) rc = ensure_rowsums(m);
+    if (rc)
+        return rc;
+    if (keep) {
+        HIP_TRY(hipMemcpyAsync(m->lambda_prime, m->lambda, KV * sizeof(double),
+                               hipMemcpyDeviceToDevice, m->stream));
+        out.active_only = false;
+        out.upd.sstats = m->sstats;
+        out.upd.lambda_prime = m->lambda_prime;
+        rc = estep_device(m, b, m->gamma, out, max_iter_inference, threshold, nullptr);
+        if (!rc) rc = finish_rowsums(m, out, nullptr, floor_after);
+        return rc;
+    }
+    out.active_only = true;
+    out.upd.lambda_prime = m->lambda;                        // in place
+    rc = estep_device(m, b, m->gamma, out, max_iter_inference, threshold, nullptr);
+    // the words outside the batch: lambda = (1 - rho) lambda + rho eta.  After the E-step: its
+    // row-sum stage (small tables) reads all of lambda.
+    if (!rc)
+        rc = launch_inactive_update<trlda::ACT_KEEP, false>(m, 1. - rho, rho * eta, rho, eta, 0.,
+                                                            b->active_flag, nullptr, m->lambda,
+                                                            nullptr, &G);
+    if (!rc) rc = batch_end(m, b);                           // the pass above read its flags
+    m->rs_valid = false;
+    if (!rc) rc = combine_rowsums(m, m->partial, G, nullptr, m->rs_static);
+    if (!rc) rc = finish_rowsums(m, out, m->rs_static, floor_after);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
 int trlda_model_online_update(trlda_model *m, const trlda_batch *b, int num_documents, double eta,
                               int max_iter_tr, int max_iter_inference, double kappa, double tau,
                               double rho, int init_gamma, int update_lambda, double threshold,
@@ -1447,6 +2057,8 @@ int trlda_model_online_update(trlda_model *m, const trlda_batch *b, int num_docu
         return rc;
     if (!b || !update_count || !rho_out)
         return fail(TRLDA_ERR_ARG, "NULL batch / update_count / rho_out");
+    if (b->V != m->V)
+        return fail(TRLDA_ERR_SHAPE, "batch was created for a different vocabulary size");
     if (b->B == 0) {                                         // onlinelda.cpp:54-56
         *rho_out = 1.0;
         return TRLDA_OK;
@@ -1462,43 +2074,44 @@ int trlda_model_online_update(trlda_model *m, const trlda_batch *b, int num_docu
         const int K = m->K, B = b->B;
         const size_t KV = (size_t)K * m->V;
         const size_t gbytes = (size_t)K * B * sizeof(double);
-        std::vector<double> gamma0((size_t)K * B);
         const double scale = (double)num_documents / (double)B;
 
-        HIP_TRY(hipMemcpyAsync(m->lambda_prime, m->lambda, KV * sizeof(double),
-                               hipMemcpyDeviceToDevice, m->stream));
-        auto fresh_gamma = [&]() -> int {                    // lda.cpp:135
-            trlda_sample_gamma_init(K, B, gamma0.data());
-            // gamma0 is reused by the next draw: finish the upload before returning
-            HIP_TRY(hipMemcpyAsync(m->gamma, gamma0.data(), gbytes, hipMemcpyHostToDevice,
-                                   m->stream));
-            HIP_TRY(hipStreamSynchronize(m->stream));
-            return TRLDA_OK;
-        };
-        if (max_iter_tr > 0) {
-            rc = tr_init_device(m, b, m->lambda_prime, rho, eta, num_documents);
-            for (int i = 0; !rc && i < max_iter_tr; ++i) {   // onlinelda.cpp:89-101
-                if (!(i > 0 && init_gamma))
-                    rc = fresh_gamma();
+        if (fused_update_available(m) && stream_available(m)) {
+            rc = online_update_fused(m, b, num_documents, eta, max_iter_tr, max_iter_inference, rho,
+                                     init_gamma, threshold);
+        } else {
+            // the plain sequence: lambda' = lambda; E-step -> statistics -> blend
+            HIP_TRY(hipMemcpyAsync(m->lambda_prime, m->lambda, KV * sizeof(double),
+                                   hipMemcpyDeviceToDevice, m->stream));
+            if (max_iter_tr > 0) {
+                rc = tr_init_device(m, b, m->lambda_prime, rho, eta, num_documents);
+                for (int i = 0; !rc && i < max_iter_tr; ++i) {   // onlinelda.cpp:89-101
+                    if (!(i > 0 && init_gamma))
+                        rc = fresh_gamma_device(m, B);
+                    if (!rc)
+                        rc = estep_device(m, b, m->gamma, m->sstats, max_iter_inference, threshold,
+                                          nullptr);
+                    if (!rc)
+                        rc = blend_device(m, m->lambda_prime, m->sstats, rho, eta, scale);
+                }
+            } else {                                             // onlinelda.cpp:103-109
+                rc = fresh_gamma_device(m, B);
                 if (!rc)
                     rc = estep_device(m, b, m->gamma, m->sstats, max_iter_inference, threshold,
                                       nullptr);
                 if (!rc)
                     rc = blend_device(m, m->lambda_prime, m->sstats, rho, eta, scale);
             }
-        } else {                                             // onlinelda.cpp:103-109
-            rc = fresh_gamma();
-            if (!rc)
-                rc = estep_device(m, b, m->gamma, m->sstats, max_iter_inference, threshold,
-                                  nullptr);
-            if (!rc)
-                rc = blend_device(m, m->lambda_prime, m->sstats, rho, eta, scale);
         }
         if (rc)
             return rc;
-        if (gamma_out)
+        if (gamma_out) {
             HIP_TRY(hipMemcpyAsync(gamma_out, m->gamma, gbytes, hipMemcpyDeviceToHost, m->stream));
-        HIP_TRY(hipStreamSynchronize(m->stream));
+            m->d2h_bytes += (int64_t)gbytes;
+            HIP_TRY(hipStreamSynchronize(m->stream));
+        }
+        // no synchronisation otherwise: the kernels of this call run while the host draws the
+        // next call's gamma0; every getter synchronises the stream it copies on
     }
     ++*update_count;                                         // onlinelda.cpp:177
     return TRLDA_OK;
@@ -1513,30 +2126,64 @@ int trlda_model_batch_update(trlda_model *m, const trlda_batch *b, double eta, i
         return rc;
     if (!b)
         return fail(TRLDA_ERR_ARG, "NULL batch");
+    if (b->V != m->V)
+        return fail(TRLDA_ERR_SHAPE, "batch was created for a different vocabulary size");
     if (b->B == 0)                                           // batchlda.cpp:44-46
         return TRLDA_OK;
     rc = ensure_update_workspace(m, b->B);
     if (rc)
         return rc;
     const int K = m->K, B = b->B;
+    const size_t KV = (size_t)K * m->V;
     const size_t gbytes = (size_t)K * B * sizeof(double);
-    std::vector<double> gamma0((size_t)K * B);
+    const bool fused = fused_update_available(m) && stream_available(m);
+    bool first = true;
     for (int epoch = 0; epoch < max_epochs; ++epoch) {       // batchlda.cpp:48-61
         if (!update_lambda)
             continue;
-        trlda_sample_gamma_init(K, B, gamma0.data());
-        HIP_TRY(hipMemcpyAsync(m->gamma, gamma0.data(), gbytes, hipMemcpyHostToDevice, m->stream));
-        HIP_TRY(hipStreamSynchronize(m->stream));
-        rc = estep_device(m, b, m->gamma, m->sstats, max_iter_inference, threshold, nullptr);
+        rc = fresh_gamma_device(m, B);
         if (rc)
             return rc;
-        // lambda = eta + sstats  ==  blend with rho = 1, scale = 1 (lambda' term is * 0)
-        rc = blend_device(m, m->lambda, m->sstats, 1.0, eta, 1.0);
+        if (fused) {
+            // lambda = eta + sstats (batchlda.cpp:60): the statistics kernel writes it for the
+            // batch's words; the others are eta, written once per call
+            rc = ensure_rowsums(m);
+            EstepOut out;
+            out.upd.omr = 0.; out.upd.rho = 1.; out.upd.eta = eta; out.upd.scale = 1.;
+            out.upd.lambda = m->lambda;
+            out.upd.lambda_prime = nullptr;
+            out.upd.partial = m->upd_partial;
+            out.upd.sstats = m->keep_sstats ? m->sstats : nullptr;
+            out.active_only = !m->keep_sstats;
+            if (!rc)
+                rc = estep_device(m, b, m->gamma, out, max_iter_inference, threshold, nullptr);
+            if (!rc && first && out.active_only) {
+                int G = 0;
+                rc = launch_inactive_update<trlda::ACT_KEEP, false>(m, 0., eta, 1., eta, 0.,
+                                                                    b->active_flag, nullptr,
+                                                                    m->lambda, nullptr, &G);
+                if (!rc) rc = batch_end(m, b);
+                m->rs_valid = false;
+                if (!rc) rc = combine_rowsums(m, m->partial, G, nullptr, m->rs_static);
+            }
+            if (!rc)
+                rc = finish_rowsums(m, out, out.active_only ? m->rs_static : nullptr, m->V * eta);
+            first = false;
+        } else {
+            rc = estep_device(m, b, m->gamma, m->sstats, max_iter_inference, threshold, nullptr);
+            if (!rc) {
+                m->rs_valid = false;
+                m->rs_floor = m->V * eta;
+                rc = launch_elementwise(m, KV, trlda::SetOp{eta, m->sstats, m->lambda});
+            }
+        }
         if (rc)
             return rc;
     }
-    if (gamma_out && update_lambda && max_epochs > 0)
+    if (gamma_out && update_lambda && max_epochs > 0) {
         HIP_TRY(hipMemcpyAsync(gamma_out, m->gamma, gbytes, hipMemcpyDeviceToHost, m->stream));
+        m->d2h_bytes += (int64_t)gbytes;
+    }
     HIP_TRY(hipStreamSynchronize(m->stream));
     return TRLDA_OK;
 }
@@ -1550,6 +2197,8 @@ int trlda_model_cumulative_update(trlda_model *m, const trlda_batch *b, int max_
         return rc;
     if (!b)
         return fail(TRLDA_ERR_ARG, "NULL batch");
+    if (b->V != m->V)
+        return fail(TRLDA_ERR_SHAPE, "batch was created for a different vocabulary size");
     if (b->B == 0)                                           // cumulativelda.cpp:50-52
         return TRLDA_OK;
     rc = ensure_update_workspace(m, b->B);
@@ -1561,35 +2210,223 @@ int trlda_model_cumulative_update(trlda_model *m, const trlda_batch *b, int max_
     // lambdaPrime = mLambda; mLambda = sampleGamma(K, V, 100) / 100   cumulativelda.cpp:57-60
     HIP_TRY(hipMemcpyAsync(m->lambda_prime, m->lambda, KV * sizeof(double),
                            hipMemcpyDeviceToDevice, m->stream));
+    const double floor_prime = m->rs_floor;
     {
         std::vector<double> lam0(KV);
         trlda_sample_gamma_init(K, m->V, lam0.data());
         HIP_TRY(hipMemcpyAsync(m->lambda, lam0.data(), KV * sizeof(double), hipMemcpyHostToDevice,
                                m->stream));
+        note_host_lambda(m, lam0.data());
         HIP_TRY(hipStreamSynchronize(m->stream));
     }
-    std::vector<double> gamma0((size_t)K * B);
+    const bool fused = fused_update_available(m) && stream_available(m);
     bool ran = false;
     if (update_lambda) {
         for (int epoch = 0; epoch < max_epochs; ++epoch) {    // cumulativelda.cpp:62-71
-            trlda_sample_gamma_init(K, B, gamma0.data());
-            HIP_TRY(hipMemcpyAsync(m->gamma, gamma0.data(), gbytes, hipMemcpyHostToDevice,
-                                   m->stream));
-            HIP_TRY(hipStreamSynchronize(m->stream));
-            rc = estep_device(m, b, m->gamma, m->sstats, max_iter_inference, threshold, nullptr);
+            rc = fresh_gamma_device(m, B);
             if (rc)
                 return rc;
-            size_t blocks = (KV + kDenseThreads - 1) / kDenseThreads;
-            int G = (int)std::min<size_t>(blocks, 256 * 8);
-            hipLaunchKernelGGL(trlda::accumulate_kernel<kDenseThreads>, dim3(G), dim3(kDenseThreads),
-                               0, m->stream, KV, m->lambda_prime, m->sstats, m->lambda);
-            HIP_TRY(hipGetLastError());
+            if (fused) {
+                // lambda = lambda' + sstats for every word (cumulativelda.cpp:70)
+                rc = ensure_rowsums(m);
+                EstepOut out;
+                out.upd.omr = 1.; out.upd.rho = 1.; out.upd.eta = 0.; out.upd.scale = 1.;
+                out.upd.lambda = m->lambda;
+                out.upd.lambda_prime = m->lambda_prime;
+                out.upd.partial = m->upd_partial;
+                out.upd.sstats = m->keep_sstats ? m->sstats : nullptr;
+                out.active_only = false;
+                if (!rc)
+                    rc = estep_device(m, b, m->gamma, out, max_iter_inference, threshold, nullptr);
+                if (!rc)
+                    rc = finish_rowsums(m, out, nullptr, floor_prime);
+            } else {
+                rc = estep_device(m, b, m->gamma, m->sstats, max_iter_inference, threshold, nullptr);
+                if (!rc) {
+                    m->rs_valid = false;
+                    m->rs_floor = floor_prime;
+                    rc = launch_elementwise(
+                        m, KV, trlda::AccumulateOp{m->lambda_prime, m->sstats, m->lambda});
+                }
+            }
+            if (rc)
+                return rc;
             ran = true;
         }
     }
-    if (gamma_out && ran)
+    if (gamma_out && ran) {
         HIP_TRY(hipMemcpyAsync(gamma_out, m->gamma, gbytes, hipMemcpyDeviceToHost, m->stream));
+        m->d2h_bytes += (int64_t)gbytes;
+    }
     HIP_TRY(hipStreamSynchronize(m->stream));
+    return TRLDA_OK;
+}
+
+// ---- empirical Bayes / adaptive rate: device reductions, K-sized results ------------------
+
+int trlda_model_set_keep_sstats(trlda_model *m, int keep)
+{
+    if (!m)
+        return fail(TRLDA_ERR_ARG, "model is NULL");
+    m->keep_sstats = keep != 0;
+    return TRLDA_OK;
+}
+
+int trlda_model_set_carry_rowsums(trlda_model *m, int carry)
+{
+    if (!m)
+        return fail(TRLDA_ERR_ARG, "model is NULL");
+    m->carry_rowsums = carry != 0;
+    return TRLDA_OK;
+}
+
+int trlda_model_set_fused_update(trlda_model *m, int fused)
+{
+    if (!m)
+        return fail(TRLDA_ERR_ARG, "model is NULL");
+    m->fused_update = fused != 0;
+    m->rs_valid = false;
+    return TRLDA_OK;
+}
+
+int64_t trlda_model_d2h_bytes(const trlda_model *m) { return m ? m->d2h_bytes : 0; }
+
+int trlda_model_estep_resident(trlda_model *m, const trlda_batch *b, int max_iter, double threshold)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!b)
+        return fail(TRLDA_ERR_ARG, "NULL batch");
+    if (b->B == 0)
+        return TRLDA_OK;
+    rc = ensure_update_workspace(m, b->B);
+    if (!rc) rc = fresh_gamma_device(m, b->B);               // lda.cpp:135
+    if (!rc) rc = estep_device(m, b, m->gamma, m->sstats, max_iter, threshold, nullptr);
+    return rc;
+}
+
+int trlda_model_eb_gamma_stats(trlda_model *m, int B, const double *gamma_dev, double *out_host)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (B <= 0 || !out_host)
+        return fail(TRLDA_ERR_ARG, "bad eb_gamma_stats arguments");
+    const double *gamma = gamma_dev ? gamma_dev : m->gamma;
+    if (!gamma || (!gamma_dev && (size_t)B * m->K > m->cap_gamma))
+        return fail(TRLDA_ERR_ARG, "no gamma of that size is resident in the model");
+    const int K = m->K;
+    const int chunks = (B + trlda::kEbDocsPerBlock - 1) / trlda::kEbDocsPerBlock;
+    rc = grow(&m->reduce_out, &m->cap_reduce, (size_t)(chunks + 1) * K);
+    if (rc)
+        return rc;
+    constexpr int T = 256;
+    const size_t lds = ((size_t)K + T / trlda::kWave + 1) * sizeof(double);
+    auto kern = trlda::eb_gamma_kernel<T>;
+    if ((rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)))
+        return rc;
+    hipLaunchKernelGGL(kern, dim3(chunks), dim3(T), lds, m->stream, K, B, gamma, m->reduce_out);
+    HIP_TRY(hipGetLastError());
+    double *sum = m->reduce_out + (size_t)chunks * K;
+    rc = combine_rowsums(m, m->reduce_out, chunks, nullptr, sum);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(out_host, sum, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, m->stream));
+    m->d2h_bytes += (int64_t)K * sizeof(double);
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return TRLDA_OK;
+}
+
+int trlda_model_eb_lambda_stats(trlda_model *m, double *sum_psi_lambda, double *rowsums_host)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!sum_psi_lambda || !rowsums_host)
+        return fail(TRLDA_ERR_ARG, "bad eb_lambda_stats arguments");
+    const int K = m->K;
+    const size_t KV = (size_t)K * m->V;
+    constexpr int T = 256;
+    const int G = (int)std::max<size_t>(1, std::min<size_t>((KV + 4 * T - 1) / (4 * T), 2048));
+    rc = grow(&m->reduce_out, &m->cap_reduce, (size_t)G + (size_t)K);
+    if (rc)
+        return rc;
+    hipLaunchKernelGGL(trlda::eb_lambda_kernel<T>, dim3(G), dim3(T), 0, m->stream, KV, m->lambda,
+                       m->reduce_out);
+    HIP_TRY(hipGetLastError());
+    // the row sums: carried by the kernel that wrote lambda, else added up now
+    const double *rs = m->rs_full;
+    if (!(m->rs_valid && m->carry_rowsums && !m->lambda_exposed)) {
+        if (stream_available(m)) {
+            rc = rowsums_from_scratch(m);
+            if (rc)
+                return rc;
+            if (!m->lambda_exposed)
+                m->rs_valid = true;
+        } else {
+            int GR = std::min(kMaxRowsumBlocks - 1, std::max(1, m->V / 32));
+            int wpb = (m->V + GR - 1) / GR;
+            GR = (m->V + wpb - 1) / wpb;
+            hipLaunchKernelGGL(trlda::rowsum_partial_kernel<kDenseThreads>, dim3(GR),
+                               dim3(kDenseThreads), 0, m->stream, K, m->V, wpb, m->lambda, m->partial);
+            HIP_TRY(hipGetLastError());
+            rc = combine_rowsums(m, m->partial, GR, nullptr, m->rs_full);
+            if (rc)
+                return rc;
+        }
+    }
+    std::vector<double> blocks((size_t)G);
+    HIP_TRY(hipMemcpyAsync(blocks.data(), m->reduce_out, (size_t)G * sizeof(double),
+                           hipMemcpyDeviceToHost, m->stream));
+    HIP_TRY(hipMemcpyAsync(rowsums_host, rs, (size_t)K * sizeof(double), hipMemcpyDeviceToHost,
+                           m->stream));
+    m->d2h_bytes += (int64_t)((size_t)G + K) * sizeof(double);
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    double total = 0.0;
+    for (int g = 0; g < G; ++g)
+        total += blocks[(size_t)g];
+    *sum_psi_lambda = total;
+    return TRLDA_OK;
+}
+
+int trlda_model_adaptive_stats(trlda_model *m, double eta, double scale, double tau,
+                               double *sq_norm_update, double *sq_norm_gradient)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!sq_norm_update || !sq_norm_gradient)
+        return fail(TRLDA_ERR_ARG, "bad adaptive_stats arguments");
+    if (!m->keep_sstats || !m->sstats || !m->lambda_prime)
+        return fail(TRLDA_ERR_ARG, "adaptive_stats needs an update made with keep_sstats on");
+    const size_t KV = (size_t)m->K * m->V;
+    if (!m->ada_gradient) {
+        rc = dev_alloc(&m->ada_gradient, KV);                // mAdaGradient starts at zero
+        if (rc)
+            return rc;
+        HIP_TRY(hipMemsetAsync(m->ada_gradient, 0, KV * sizeof(double), m->stream));
+    }
+    constexpr int T = 256;
+    const int G = (int)std::max<size_t>(1, std::min<size_t>((KV + 4 * T - 1) / (4 * T), 2048));
+    rc = grow(&m->reduce_out, &m->cap_reduce, 2 * (size_t)G);
+    if (rc)
+        return rc;
+    hipLaunchKernelGGL(trlda::adaptive_kernel<T>, dim3(G), dim3(T), 0, m->stream, KV, eta, scale, tau,
+                       m->sstats, m->lambda_prime, m->ada_gradient, m->reduce_out);
+    HIP_TRY(hipGetLastError());
+    std::vector<double> blocks(2 * (size_t)G);
+    HIP_TRY(hipMemcpyAsync(blocks.data(), m->reduce_out, blocks.size() * sizeof(double),
+                           hipMemcpyDeviceToHost, m->stream));
+    m->d2h_bytes += (int64_t)(blocks.size() * sizeof(double));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    double u2 = 0.0, g2 = 0.0;
+    for (int g = 0; g < G; ++g) {
+        u2 += blocks[2 * (size_t)g];
+        g2 += blocks[2 * (size_t)g + 1];
+    }
+    *sq_norm_update = u2;
+    *sq_norm_gradient = g2;
     return TRLDA_OK;
 }
 
@@ -1685,6 +2522,8 @@ int trlda_debug_digamma(int device, int n, double c, const double *x, double *ps
     rc = dev_alloc(&d, (size_t)n * 5);
     if (rc)
         return rc;
+    DevTemp guard;
+    guard.p = d;
     const size_t bytes = (size_t)n * sizeof(double);
     HIP_TRY(hipMemcpy(d, x, bytes, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(trlda::digamma_table_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, n,
@@ -1694,7 +2533,6 @@ int trlda_debug_digamma(int device, int n, double c, const double *x, double *ps
     HIP_TRY(hipMemcpy(epsi, d + 2 * (size_t)n, bytes, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(epsi_lean, d + 3 * (size_t)n, bytes, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(eminus, d + 4 * (size_t)n, bytes, hipMemcpyDeviceToHost));
-    HIP_TRY(hipFree(d));
     return TRLDA_OK;
 }
 
@@ -1709,6 +2547,8 @@ int trlda_debug_fold16(int device, const double *in, double *out16, double *out4
     rc = dev_alloc(&d, 64 * 16 + 3 * 64);
     if (rc)
         return rc;
+    DevTemp guard;
+    guard.p = d;
     HIP_TRY(hipMemcpy(d, in, 64 * 16 * sizeof(double), hipMemcpyHostToDevice));
     double *o = d + 64 * 16;
     hipLaunchKernelGGL(trlda::debug_fold16_kernel, dim3(1), dim3(64), 0, nullptr, d, o, o + 64,
@@ -1717,7 +2557,6 @@ int trlda_debug_fold16(int device, const double *in, double *out16, double *out4
     HIP_TRY(hipMemcpy(out16, o, 64 * sizeof(double), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out4, o + 64, 64 * sizeof(double), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(out2, o + 128, 64 * sizeof(double), hipMemcpyDeviceToHost));
-    HIP_TRY(hipFree(d));
     return TRLDA_OK;
 }
 

@@ -125,10 +125,20 @@ class ShardedOnlineLDA(object):
             engine = HipEngine(self._V, K, _default_device() if device is None else device)
         self.engine = engine
         engine.set_alpha(alpha_vec)
-        # lambda = sampleGamma(K, V, 100) / 100 (lda.cpp:71): every rank draws the same
-        # stream (same srand seed on every rank), so lambda starts replicated.
+        # lambda = sampleGamma(K, V, 100) / 100 (lda.cpp:71), drawn on every rank (so that a
+        # rank's stream is where the single-process run's would be) -- and then rank 0's lambda
+        # AND rank 0's generator state are broadcast: the library seeds itself from the clock at
+        # load time (module.cpp:356-359), so without `trlda_amd.seed(s)` on every rank the
+        # replicas would start from different lambdas and draw different "replicated" gamma0s,
+        # and never agree.
         lam = np.empty((K, self._V), dtype=np.float64, order="F")
         _ffi.lib().trlda_sample_gamma_init(K, self._V, lam)
+        if self.world > 1:
+            lam = self._broadcast_host(lam)
+            state = np.zeros(33, dtype=np.uint32)
+            _ffi.lib().trlda_rng_get_state(state)
+            state = self._broadcast_host(state)
+            _ffi.lib().trlda_rng_set_state(state)
         engine.set_lambda(lam)
 
     num_topics = property(lambda self: self._K)
@@ -149,6 +159,39 @@ class ShardedOnlineLDA(object):
         self.engine.set_lambda(arr)
 
     # -- helpers -----------------------------------------------------------------------
+    def _broadcast_host(self, array):
+        """Rank 0's copy of a host array on every rank (through the group's backend: RCCL moves
+        device memory, gloo host memory)."""
+        import torch
+        flat = np.ascontiguousarray(array).reshape(-1)
+        signed = flat.view(np.int32) if flat.dtype == np.uint32 else flat
+        t = torch.from_numpy(signed.copy())
+        backend = self.dist.get_backend(self.group)
+        if backend == "nccl":
+            t = t.to(self.engine.device)
+        self.dist.broadcast(t, src=self.dist.get_global_rank(self.group, 0) if self.group else 0,
+                            group=self.group)
+        out = t.cpu().numpy()
+        if flat.dtype == np.uint32:
+            out = out.view(np.uint32)
+        out = out.reshape(array.shape)
+        return np.asfortranarray(out) if array.ndim == 2 else out
+
+    def replicas_agree(self):
+        """True when every rank holds the same lambda (a checksum of it is compared across the
+        group): what the replicated M-step relies on."""
+        import torch
+        lam = self.engine.get_lambda()
+        digest = np.array([float(lam.sum()), float(np.abs(lam).max()), float(lam[:, ::7].sum())])
+        if self.world == 1:
+            return True
+        lo, hi = torch.from_numpy(digest.copy()), torch.from_numpy(digest.copy())
+        if self.dist.get_backend(self.group) == "nccl":
+            lo, hi = lo.to(self.engine.device), hi.to(self.engine.device)
+        self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN, group=self.group)
+        self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX, group=self.group)
+        return bool(torch.equal(lo.cpu(), hi.cpu()))
+
     def _all_reduce(self, tensor):
         if self.world > 1:
             self.dist.all_reduce(tensor, op=self.dist.ReduceOp.SUM, group=self.group)

@@ -263,6 +263,27 @@ class LDA(Distribution):
                 batch.close()
         return bound.value
 
+    # -- device reductions for the empirical-Bayes steps (csrc/eb_kernels.h) ----------------
+    def _psi_gamma_diff_device(self, num_docs):
+        """sum_d (psi(gamma_dk) - psi(sum_k gamma_dk)) over the gamma the last update / resident
+        E-step left on the device (onlinelda.cpp:123-128, batchlda.cpp:72-74): K numbers."""
+        out = np.empty(self._K, dtype=np.float64)
+        _ffi.check(_ffi.lib().trlda_model_eb_gamma_stats(self._handle, int(num_docs), None, out))
+        return out
+
+    def _lambda_psi_stats_device(self):
+        """(sum_kw psi(lambda_kw), row sums of lambda): onlinelda.cpp:152-154, batchlda.cpp:152."""
+        total = C.c_double(0.)
+        rowsums = np.empty(self._K, dtype=np.float64)
+        _ffi.check(_ffi.lib().trlda_model_eb_lambda_stats(self._handle, C.byref(total), rowsums))
+        return total.value, rowsums
+
+    def _resident_estep(self, batch, max_iter, threshold=0.001):
+        """updateVariables(documents, parameters) from a fresh random gamma, results left on the
+        device (onlinelda.cpp:118-120)."""
+        _ffi.check(_ffi.lib().trlda_model_estep_resident(self._handle, batch.handle, int(max_iter),
+                                                         float(threshold)))
+
     # -- not on the accelerated path ----------------------------------------------
     def sample(self, num_documents, length):
         raise NotImplementedError("sample (lda.cpp:88-115) is outside the accelerated path.")
@@ -290,7 +311,6 @@ class OnlineLDA(LDA):
         self._ada_tau = 1000.
         self._ada_rho = 1. / self._ada_tau
         self._ada_sq_norm = 1.
-        self._ada_gradient = None
         self._setup(num_words, num_topics, alpha, eta, device)
 
     def _default_num_documents(self):
@@ -325,10 +345,10 @@ class OnlineLDA(LDA):
         """One online update; returns the learning rate used
         (onlineldainterface.cpp:204-256 -> onlinelda.cpp:53-179).
 
-        The lambda path (E-steps, trust-region loop, blend) runs on the GPU.  The
-        empirical-Bayes steps for alpha and eta and the adaptive learning rate
-        (onlinelda.cpp:116-175) are K- and scalar-sized Newton updates: they run on the host
-        from the device results (gamma of the last E-step, lambda, sstats)."""
+        The lambda path (E-steps, trust-region loop, M-steps) runs on the GPU, and so do the
+        sums over gamma, lambda and the statistics that the empirical-Bayes steps for alpha and
+        eta and the adaptive learning rate need (onlinelda.cpp:116-175, csrc/eb_kernels.h); the
+        host keeps the K- and scalar-sized Newton steps."""
         from .. import _special
         batch, owned = self._batch(docs)
         try:
@@ -340,28 +360,25 @@ class OnlineLDA(LDA):
             rho_arg = float(rho)
             if rho_arg < 0. and adaptive:
                 rho_arg = self._ada_rho                              # onlinelda.cpp:61-62
-            lam_prime = self.lambdas if (adaptive and update_lambda) else None
             eta_old = self._eta
-            gamma = None
-            if update_alpha and update_lambda:
-                gamma = np.empty((K, B), dtype=np.float64, order="F")
+            # the adaptive rate reads lambda' and the statistics after the update
+            # (onlinelda.cpp:167-175): the device keeps both
+            _ffi.check(L.trlda_model_set_keep_sstats(self._handle,
+                                                     int(bool(adaptive and update_lambda))))
             count = C.c_int(self._update_count)
             rho_out = C.c_double(0.)
             _ffi.check(L.trlda_model_online_update(
                 self._handle, batch.handle, self._num_documents, self._eta, int(max_iter_tr),
                 int(max_iter_inference), float(kappa), float(tau), rho_arg,
                 int(bool(init_gamma)), int(bool(update_lambda)), 0.001,  # lda.h:56: fixed
-                C.byref(count), C.byref(rho_out),
-                gamma.ctypes.data if gamma is not None else None))
+                C.byref(count), C.byref(rho_out), None))
             rho_used = rho_out.value
 
             if update_alpha:                                         # onlinelda.cpp:116-142
                 if not update_lambda:
-                    gamma, _ = self.update_variables(batch, max_iter=max_iter_inference)
-                psi_gamma = _special.digamma(gamma)
-                psi_gamma_sum = _special.digamma(gamma.sum(axis=0))
+                    self._resident_estep(batch, max_iter_inference)
                 alpha = self._alpha
-                g = (psi_gamma - psi_gamma_sum[None, :]).sum(axis=1) \
+                g = self._psi_gamma_diff_device(B) \
                     - B * (_special.digamma(alpha) - _special.digamma(alpha.sum()))
                 h = -float(B) * _special.trigamma(alpha)
                 z = B * _special.trigamma(alpha.sum())
@@ -371,24 +388,21 @@ class OnlineLDA(LDA):
                 self._alpha = alpha
 
             if update_eta:                                           # onlinelda.cpp:147-162
-                lam = self.lambdas
                 eta = self._eta
-                g = _special.digamma(lam).sum() - V * _special.digamma(lam.sum(axis=1)).sum() \
+                sum_psi, rowsums = self._lambda_psi_stats_device()
+                g = sum_psi - V * _special.digamma(rowsums).sum() \
                     - K * V * (_special.digamma(eta) - _special.digamma(V * eta))
                 h = K * V * (_special.trigamma(V * eta) - _special.trigamma(eta))
                 self._eta = max(float(eta - rho_used * g / h), min_eta)
 
             if update_lambda and adaptive:                           # onlinelda.cpp:167-175
-                sstats = np.empty((K, V), dtype=np.float64, order="F")
-                _ffi.check(L.trlda_model_get_sstats(self._handle, sstats))
-                lam_hat = eta_old + float(self._num_documents) / B * sstats
-                upd = lam_hat - lam_prime
-                if self._ada_gradient is None:
-                    self._ada_gradient = np.zeros((K, V), order="F")
                 t = self._ada_tau
-                self._ada_gradient = (1. - 1. / t) * self._ada_gradient + 1. / t * upd
-                self._ada_sq_norm = (1. - 1. / t) * self._ada_sq_norm + 1. / t * float((upd * upd).sum())
-                self._ada_rho = float((self._ada_gradient * self._ada_gradient).sum()) / self._ada_sq_norm
+                u2, g2 = C.c_double(0.), C.c_double(0.)
+                _ffi.check(L.trlda_model_adaptive_stats(
+                    self._handle, eta_old, float(self._num_documents) / B, t,
+                    C.byref(u2), C.byref(g2)))
+                self._ada_sq_norm = (1. - 1. / t) * self._ada_sq_norm + 1. / t * u2.value
+                self._ada_rho = g2.value / self._ada_sq_norm
                 self._ada_tau = t * (1. - self._ada_rho) + 1.
 
             self._update_count = count.value
@@ -462,8 +476,9 @@ class BatchLDA(LDA):
                           update_eta=False, min_alpha=1e-6, min_eta=1e-6,
                           emp_bayes_threshold=1e-8, verbosity=0):
         """batchldainterface.cpp:126-172 -> batchlda.cpp:43-208.  The E-steps and
-        lambda = eta + sstats run on the GPU; the alpha / eta line searches
-        (batchlda.cpp:66-205) are K- and scalar-sized and run on the host."""
+        lambda = eta + sstats run on the GPU, as do the sums over gamma and lambda behind the
+        alpha / eta line searches (batchlda.cpp:66-205); the searches themselves are K- and
+        scalar-sized and run on the host."""
         from .. import _special
         batch, owned = self._batch(docs)
         try:
@@ -477,22 +492,21 @@ class BatchLDA(LDA):
                     self._handle, batch.handle, self._eta, int(max_epochs),
                     int(max_iter_inference), int(bool(update_lambda)), 0.001, None))
                 return 1.
-            gamma = np.empty((K, B), dtype=np.float64, order="F")
             for _epoch in range(int(max_epochs)):                    # batchlda.cpp:48
                 if update_lambda:
                     _ffi.check(L.trlda_model_batch_update(
                         self._handle, batch.handle, self._eta, 1, int(max_iter_inference), 1,
-                        0.001, gamma.ctypes.data))
+                        0.001, None))
                 if update_alpha:                                     # batchlda.cpp:64-142
                     if not update_lambda:
-                        gamma, _ = self.update_variables(batch, max_iter=max_iter_inference)
-                    alpha = _alpha_line_search(self._alpha, _psi_gamma_diff(gamma), B,
+                        self._resident_estep(batch, max_iter_inference)
+                    alpha = _alpha_line_search(self._alpha, self._psi_gamma_diff_device(B), B,
                                                max_iter_alpha, min_alpha, emp_bayes_threshold)
                     _ffi.check(L.trlda_model_set_alpha(self._handle, np.ascontiguousarray(alpha)))
                     self._alpha = alpha
                 if update_eta:                                       # batchlda.cpp:147-205
-                    lam = self.lambdas
-                    c = _special.digamma(lam).sum() - V * _special.digamma(lam.sum(axis=1)).sum()
+                    sum_psi, rowsums = self._lambda_psi_stats_device()
+                    c = sum_psi - V * _special.digamma(rowsums).sum()
                     eta = self._eta
 
                     def bound(e):
@@ -561,9 +575,8 @@ class CumulativeLDA(LDA):
                 self._handle, batch.handle, int(max_epochs), int(max_iter_inference),
                 int(bool(update_lambda)), float(inference_threshold), None))
             if update_alpha:                                         # cumulativelda.cpp:76-150
-                gamma, _ = self.update_variables(batch, max_iter=max_iter_inference,
-                                                 threshold=inference_threshold)
-                self._psi_gamma_diff = self._psi_gamma_diff + _psi_gamma_diff(gamma)
+                self._resident_estep(batch, max_iter_inference, inference_threshold)
+                self._psi_gamma_diff = self._psi_gamma_diff + self._psi_gamma_diff_device(B)
                 self._num_documents += B
                 alpha = _alpha_line_search(self._alpha, self._psi_gamma_diff, self._num_documents,
                                            max_iter_alpha, min_alpha, emp_bayes_threshold)
