@@ -110,6 +110,24 @@ int trlda_tr_init(int K, int V, int B, int num_documents, double rho, double eta
                   const int32_t *indptr, const int32_t *ids, const int32_t *cnts,
                   const double *lambda_prime, double *lambda_out, int device);
 
+/* ---- text corpora (host side) ---------------------------------------------------------
+ *
+ * The reference's corpus files (python/utils/load_documents.py:6-69): one document per line,
+ * "<n> id:cnt id:cnt ...", the leading <n> ignored like line.split()[1:] does.  The file is
+ * mapped and parsed by the library's host threads straight into CSR -- the form
+ * trlda_batch_create takes: batch b of documents [d0, d1) is
+ * indptr = offsets[d0 .. d1] - offsets[d0], ids + offsets[d0], cnts + offsets[d0].
+ * Tokens that are not [+-]digits:[+-]digits within int32, and files with bare carriage
+ * returns, fail with TRLDA_ERR_VALUE / TRLDA_ERR_ARG and a line number in trlda_last_error(). */
+typedef struct trlda_docs trlda_docs;
+int trlda_docs_from_text(const char *path, trlda_docs **out);
+int64_t trlda_docs_num_docs(const trlda_docs *docs);
+int64_t trlda_docs_nnz(const trlda_docs *docs);
+const int64_t *trlda_docs_offsets(const trlda_docs *docs);   /* num_docs + 1 */
+const int32_t *trlda_docs_ids(const trlda_docs *docs);       /* nnz */
+const int32_t *trlda_docs_cnts(const trlda_docs *docs);      /* nnz */
+int trlda_docs_destroy(trlda_docs *docs);
+
 /* ---- device memory helpers (so a host program needs no HIP headers) ---- */
 
 int trlda_dev_alloc(int device, size_t bytes, void **dev_out);

@@ -813,7 +813,9 @@ def test_sharded_model_single_rank_matches_online_lda(hip):
     b = ShardedOnlineLDA(V, K, D, device=0)
     rb = [b.update_parameters(d, max_iter_tr=3) for d in docs]
     assert ra == rb and b.update_count == 2
-    assert np.array_equal(a.lambdas, b.lambdas)
+    # (the model fuses the M-step into the statistics kernel, the composition path blends in a
+    # kernel of its own: equal to rounding, not bit for bit)
+    assert relerr(a.lambdas, b.lambdas) < 1e-10
 
 
 def test_sharded_model_through_rccl_world_1(hip, tmp_path):

@@ -36,6 +36,13 @@ _SIGNATURES = {
                                     f64p, f64p, C.c_int]),
     "trlda_tr_init": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, i32p,
                                 i32p, i32p, f64p, f64p, C.c_int]),
+    "trlda_docs_from_text": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+    "trlda_docs_num_docs": (C.c_int64, [vp]),
+    "trlda_docs_nnz": (C.c_int64, [vp]),
+    "trlda_docs_offsets": (C.POINTER(C.c_int64), [vp]),
+    "trlda_docs_ids": (C.POINTER(C.c_int32), [vp]),
+    "trlda_docs_cnts": (C.POINTER(C.c_int32), [vp]),
+    "trlda_docs_destroy": (C.c_int, [vp]),
     "trlda_dev_alloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(vp)]),
     "trlda_dev_free": (C.c_int, [C.c_int, vp]),
     "trlda_dev_upload": (C.c_int, [C.c_int, vp, vp, C.c_size_t]),

@@ -24,6 +24,28 @@ def _hipcc():
     raise RuntimeError("hipcc not found (need ROCm >= 7.0)")
 
 
+def fastdocs_path():
+    import sysconfig
+    return os.path.join(_PKG, "_fastdocs" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_fastdocs(force=False, verbose=False):
+    """Compile csrc/fastdocs.c (CPython extension: list-of-tuples <-> CSR) with the C compiler."""
+    import sysconfig
+    out, src = fastdocs_path(), os.path.join(_CSRC, "fastdocs.c")
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src):
+        return out
+    cc = os.environ.get("CC") or shutil.which("gcc") or shutil.which("cc")
+    if not cc:
+        raise RuntimeError("no C compiler for trlda_amd._fastdocs")
+    cmd = [cc, "-O2", "-fPIC", "-shared", "-Wall", "-I" + sysconfig.get_paths()["include"],
+           "-o", out, src]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return out
+
+
 def is_stale():
     if not os.path.exists(LIB_PATH):
         return True
@@ -34,6 +56,7 @@ def is_stale():
 
 def build(force=False, verbose=False):
     """Compile the HIP kernels + C ABI into trlda_amd/libtrlda_hip.so."""
+    build_fastdocs(force=force, verbose=verbose)
     if not force and not is_stale():
         return LIB_PATH
     cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH] + [os.path.join(_CSRC, s) for s in SOURCES]

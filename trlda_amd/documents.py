@@ -11,6 +11,11 @@ import numpy as np
 
 from . import _ffi
 
+try:                                                 # built by trlda_amd.build next to the .so
+    from . import _fastdocs
+except ImportError:                                  # host-side format conversion only: the
+    _fastdocs = None                                 # Python path below does the same job
+
 
 class CSRDocuments(object):
     """A batch already in CSR form: ``indptr[B+1]``, ``ids[nnz]``, ``cnts[nnz]`` (int32).
@@ -57,9 +62,16 @@ class CSRDocuments(object):
         return self.slice(int(cuts[rank]), int(cuts[rank + 1]))
 
     def to_list(self):
-        ip, ids, cnts = self.indptr, self.ids, self.cnts
-        return [[(int(ids[i]), int(cnts[i])) for i in range(ip[d], ip[d + 1])]
-                for d in range(len(self))]
+        return csr_to_lists(self)
+
+
+def csr_to_lists(csr):
+    """CSR -> the reference's list of lists of ``(id, count)`` tuples."""
+    if _fastdocs is not None:
+        return _fastdocs.tuples(np.ascontiguousarray(csr.indptr), np.ascontiguousarray(csr.ids),
+                                np.ascontiguousarray(csr.cnts))
+    ip, ids, cnts = csr.indptr, csr.ids.tolist(), csr.cnts.tolist()
+    return [list(zip(ids[ip[d]:ip[d + 1]], cnts[ip[d]:ip[d + 1]])) for d in range(len(csr))]
 
 
 _INT_TYPES = {int, bool, np.int8, np.int16, np.int32, np.int64, np.uint8, np.uint16, np.uint32,
@@ -74,6 +86,14 @@ def as_csr(docs):
         return docs.csr
     if not isinstance(docs, list):
         raise TypeError("Documents must be stored in a list.")
+    if _fastdocs is not None:
+        # one pass in C (csrc/fastdocs.c); None when something is not a list / 2-tuple of ints,
+        # which the Python path below then reports with PyList_ToDocuments' exceptions
+        flat = _fastdocs.flatten(docs)
+        if flat is not None:
+            return CSRDocuments(np.frombuffer(flat[0], dtype=np.int32),
+                                np.frombuffer(flat[1], dtype=np.int32),
+                                np.frombuffer(flat[2], dtype=np.int32))
     lengths = np.empty(len(docs), dtype=np.int64)
     for i, doc in enumerate(docs):
         if not isinstance(doc, list):
