@@ -13,7 +13,8 @@ beta] preamble, per-document gamma fixed point, sufficient statistics -- and, fo
 RCCL all-reduce of the K x V statistics (the path's one exchange step).  Inputs (lambda,
 CSR batches and their word-major index, gamma0) are resident in HBM before the timed region;
 nothing is cached across steps (lambda's preamble is recomputed every step, as in the
-reference).  Weak scaling: 200 documents per GPU per step.
+reference).  Weak scaling by default: 200 documents per GPU per step; `--global-batch 1600`
+splits a fixed 1600-document step over the GPUs instead (BASELINE.json configs[2], "strong").
 
 Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel
 (estep_docs_kernel) from HIP events on the launch stream; `cpu_baseline` is the reference's
@@ -33,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+FP64_PEAK_TFLOPS = 78.6        # fp64 vector: half the 157.3 TF fp32 vector peak of the same guide
 KERNEL_NAMES = ["rowsum_partial_kernel", "exp_elog_beta_kernel", "estep_docs_kernel",
                 "sstats_words_kernel"]
 
@@ -58,7 +60,16 @@ def parse():
                     help="exp E[log beta] for all V words (reference behaviour) instead of the "
                          "batch's active words")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity-only", action="store_true",
+                    help="keep the parity leg (GPU against the oracle on the first timed batch) but "
+                         "skip timing the CPU baseline")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: this many documents per step in all, split over the "
+                         "GPUs (BASELINE.json configs[2]: 1600); default 0 = weak scaling, "
+                         "--batch documents per GPU")
+    ap.add_argument("--no-update-rates", action="store_true",
+                    help="skip the secondary update_parameters figures (N = 1 only)")
     return ap.parse_args()
 
 
@@ -111,7 +122,15 @@ def main():
             dist.init_process_group("nccl", device_id=device)
     collective = world > 1 or force_dist
 
-    K, V, B = args.topics, args.words, args.batch
+    K, V = args.topics, args.words
+    strong = args.global_batch > 0
+    if strong:
+        # documents [rank * B, (rank + 1) * B) of each global mini-batch: equal counts (the
+        # synthetic documents are i.i.d., so the shares of nnz are equal to within a percent)
+        if args.global_batch % world:
+            raise SystemExit("--global-batch must be a multiple of the number of GPUs")
+        args.batch = args.global_batch // world
+    B = args.batch
     KV = K * V
 
     # ---- inputs, resident in HBM before the timed region ---------------------------------
@@ -142,6 +161,12 @@ def main():
     gamma = torch.empty(B * K, dtype=torch.float64, device=device)
     sstats = torch.empty(KV, dtype=torch.float64, device=device)
     iters_dev = torch.zeros(B, dtype=torch.int32, device=device)
+    # N > 1: the M-step (onlinelda.cpp:99-100) closes the dependency chain E-step -> all-reduce
+    # -> lambda -> next E-step, so the collective cannot hide behind the next step's kernels.
+    # lambda' stays the initial lambda and rho is small: lambda moves, the workload does not drift.
+    lam_prime = torch.from_numpy(np.ascontiguousarray(lam.ravel(order="F"))).to(device) \
+        if collective else None
+    RHO, ETA, D_TOTAL = 0.01, 0.3, 1000000
 
     def step(i, want_iters=False):
         j = i % args.num_batches
@@ -152,6 +177,8 @@ def main():
                                           iters_dev.data_ptr() if want_iters else None))
         if collective:
             dist.all_reduce(sstats)                   # RCCL over xGMI: K x V fp64 sum
+            _ffi.check(L.trlda_model_blend(model, lam_prime.data_ptr(), sstats.data_ptr(), RHO, ETA,
+                                           D_TOTAL / float(B * world)))
 
     def fence():
         if collective:
@@ -196,9 +223,20 @@ def main():
     kernel_us = [max(u - event_us, 0.0) if u > 0.5 * event_pair_us else 0.0 for u in kernel_us]
     _ffi.check(L.trlda_model_set_timing(model, 0))
 
-    step(0, want_iters=True)
-    fence()
-    mean_iters = float(iters_dev.float().mean().item())
+    # executed iterations per document, every batch: mean, and the fp64 work of the document
+    # kernel, sum_d I_d (4 K n_d + c_psi K) with c_psi = 140 fp64 operations per exp(psi)
+    # (csrc/psi.h; SURVEY.md 8d's secondary figure) plus the first phinorm (2 K n_d)
+    C_PSI = 140.
+    doc_flops, iter_sum = [], 0.
+    for j in range(args.num_batches):
+        step(j, want_iters=True)
+        fence()
+        it = iters_dev.cpu().numpy().astype(np.float64)
+        n_d = np.diff(csrs[j].indptr).astype(np.float64)
+        doc_flops.append(float((it * (4. * K * n_d + C_PSI * K) + 2. * K * n_d + C_PSI * K).sum()))
+        iter_sum += float(it.mean())
+    mean_iters = iter_sum / args.num_batches
+    doc_flops = float(np.mean(doc_flops))
 
     if rank != 0:
         dist.destroy_process_group()
@@ -209,7 +247,7 @@ def main():
     estep_bytes, docs_bytes = float(np.mean(all_e)), float(np.mean(all_d))
     docs_us = kernel_us[2]
     achieved = docs_bytes / (docs_us * 1e-6) / 1e9 if docs_us > 0 else 0.0
-    traffic = None
+    traffic, traffic_src = None, None
     # the document stage under the name rocprofv3 lists it by (profiles/*_kernel_stats.csv)
     doc_kernel = (L.trlda_model_last_doc_kernel(model) or b"estep_docs_kernel").decode()
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -219,12 +257,16 @@ def main():
             # measured for the default workload only
             if tj.get("kernel", "").endswith(doc_kernel) and (K, V, args.batch) == (100, 7000, 200):
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_src = {k: tj.get(k) for k in ("measured_at_commit", "fetch_size_kb",
+                                                      "write_size_kb") if k in tj}
         except (OSError, ValueError):
             traffic = None
     kernel_names = list(KERNEL_NAMES)
     kernel_names[2] = doc_kernel
     if args.sstats_mode == "atomic":
-        kernel_names[3] = "finish_kernel"
+        kernel_names[3] = "elementwise_stream_kernel<FinishOp>"
+    elif K <= 512:
+        kernel_names[3] = "sstats_update_kernel"
     kernel_pairs = list(zip(kernel_names, kernel_us))
     if L.trlda_model_last_preamble_fused(model):      # kernels 1 and 2 ran as one launch
         kernel_pairs = [("preamble_fused_kernel", kernel_us[0])] + kernel_pairs[2:]
@@ -232,12 +274,21 @@ def main():
         "bound": "hbm", "kernel": "trlda::" + doc_kernel,
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "traffic_source": traffic_src,
         "algorithmic_bytes_per_launch": docs_bytes,
         "avg_launch_us": round(docs_us, 2),
         "method": "HIP events on the launch stream around every launch in a replay of the timed "
                   "steps, minus the events' own share (replay time over timed time, per launch)",
         "event_share_us": round(event_us, 2), "empty_event_pair_us": round(event_pair_us, 2),
         "kernels_us": {n: round(u, 2) for n, u in kernel_pairs},
+        # HBM is not what bounds this kernel (its traffic is below the algorithmic bytes): the same
+        # launch against the fp64 vector peak (MI355X_MICROARCH.md: 157.3 TF fp32 vector, fp64 at
+        # half of it)
+        "fp64": {"flops_per_launch": doc_flops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "achieved": round(doc_flops / (docs_us * 1e-6) / 1e12, 3) if docs_us > 0 else 0.0,
+                 "frac": round(doc_flops / (docs_us * 1e-6) / 1e12 / FP64_PEAK_TFLOPS, 5)
+                 if docs_us > 0 else 0.0,
+                 "model": "sum_d I_d (4 K n_d + 140 K) + 2 K n_d + 140 K"},
         "estep": {   # the whole path against SURVEY.md 8(d)'s bytes_alg
             "algorithmic_bytes_per_step": estep_bytes,
             "achieved": round(estep_bytes * args.steps / elapsed / 1e9, 2),
@@ -246,13 +297,15 @@ def main():
 
     # ---- parity + CPU baseline (rank 0, N = 1 only): the checker, timed beside the GPU ----
     cpu_baseline, parity = None, None
+    if collective:
+        _ffi.check(L.trlda_model_set_lambda(model, lam))      # the parity leg wants lambda0 back
     if world == 1 and not args.no_cpu_baseline:
         from oracle import pyoracle                   # test infrastructure: checker + baseline
         orc = pyoracle.Oracle()
         c = csrs[0]
         g0 = np.asfortranarray(gamma0s[0].cpu().numpy().T)
         go, so, ito = orc.estep(lam, .1, c.indptr, c.ids, c.cnts, g0, args.max_iter,
-                                args.threshold)
+                                args.threshold, nthreads=min(8, os.cpu_count() or 1))
         step(0, want_iters=True)
         fence()
         gg = np.asfortranarray(gamma.cpu().numpy().reshape(B, K).T)
@@ -274,52 +327,80 @@ def main():
                 if dt >= budget or n >= 400:
                     return n, dt
 
-        ncores = os.cpu_count() or 1
-        if pyoracle.Reference.available():
-            ref = pyoracle.Reference()
-            rm = ref.online(V, K, 1000000, alpha=.1, eta=.3)
-            rm.lambdas = lam
-            n1, t1 = time_cpu(lambda cc, g: rm.estep(cc.indptr, cc.ids, cc.cnts, g, args.max_iter,
-                                                     args.threshold), args.cpu_seconds)
-            kind = "reference"
-        else:
-            n1, t1 = time_cpu(lambda cc, g: orc.estep(lam, .1, cc.indptr, cc.ids, cc.cnts, g,
-                                                      args.max_iter, args.threshold),
-                              args.cpu_seconds)
-            kind = "port"
-        # doc-parallel port: a 200-document batch does not feed hundreds of threads; take the
-        # best of a few thread counts (each a short sample)
-        best = None
-        for nthr in sorted({t for t in (8, 16, 32, 64, ncores) if t <= ncores}):
-            nm, tm = time_cpu(lambda cc, g: orc.estep(lam, .1, cc.indptr, cc.ids, cc.cnts, g,
-                                                      args.max_iter, args.threshold,
-                                                      nthreads=nthr), args.cpu_seconds / 8)
-            if best is None or nm / tm > best[0] / best[1]:
-                best = (nm, tm, nthr)
-        nm, tm, best_threads = best
-        cpu_baseline = {
-            "value": round(n1 * B / t1, 1), "unit": "docs/s", "cores": 1, "kind": kind,
-            "sample": "%d E-step calls over the bench's own %d-document mini-batches "
-                      "(%.1f s), single thread" % (n1, B, t1),
-            "all_cores": {"value": round(nm * B / tm, 1), "cores": best_threads,
-                          "cores_available": ncores, "kind": "port",
-                          "note": "oracle/cpu_ref.c doc-parallel variant, best of 8..%d threads; "
-                                  "the reference's own OpenMP path is slower than its single "
-                                  "thread (BASELINE.md)" % ncores},
-            "gpu_over_cpu_1thread": round(docs_per_s / (n1 * B / t1), 1),
-        }
-        try:
-            cpu_baseline["cpu_model"] = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo")
-                                         if l.startswith("model name")][0]
-        except Exception:
-            pass
+        if not args.parity_only:
+            ncores = os.cpu_count() or 1
+            if pyoracle.Reference.available():
+                ref = pyoracle.Reference()
+                rm = ref.online(V, K, 1000000, alpha=.1, eta=.3)
+                rm.lambdas = lam
+                n1, t1 = time_cpu(lambda cc, g: rm.estep(cc.indptr, cc.ids, cc.cnts, g, args.max_iter,
+                                                         args.threshold), args.cpu_seconds)
+                kind = "reference"
+            else:
+                n1, t1 = time_cpu(lambda cc, g: orc.estep(lam, .1, cc.indptr, cc.ids, cc.cnts, g,
+                                                          args.max_iter, args.threshold),
+                                  args.cpu_seconds)
+                kind = "port"
+            # doc-parallel port: a 200-document batch does not feed hundreds of threads; take the
+            # best of a few thread counts (each a short sample)
+            best = None
+            for nthr in sorted({t for t in (8, 16, 32, 64, ncores) if t <= ncores}):
+                nm, tm = time_cpu(lambda cc, g: orc.estep(lam, .1, cc.indptr, cc.ids, cc.cnts, g,
+                                                          args.max_iter, args.threshold,
+                                                          nthreads=nthr), args.cpu_seconds / 8)
+                if best is None or nm / tm > best[0] / best[1]:
+                    best = (nm, tm, nthr)
+            nm, tm, best_threads = best
+            cpu_baseline = {
+                "value": round(n1 * B / t1, 1), "unit": "docs/s", "cores": 1, "kind": kind,
+                "sample": "%d E-step calls over the bench's own %d-document mini-batches "
+                          "(%.1f s), single thread" % (n1, B, t1),
+                "all_cores": {"value": round(nm * B / tm, 1), "cores": best_threads,
+                              "cores_available": ncores, "kind": "port",
+                              "note": "oracle/cpu_ref.c doc-parallel variant, best of 8..%d threads; "
+                                      "the reference's own OpenMP path is slower than its single "
+                                      "thread (BASELINE.md)" % ncores},
+                "gpu_over_cpu_1thread": round(docs_per_s / (n1 * B / t1), 1),
+            }
+            try:
+                cpu_baseline["cpu_model"] = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo")
+                                             if l.startswith("model name")][0]
+            except Exception:
+                pass
+
+    # ---- secondary: whole update_parameters calls through the Python surface (N = 1) --------
+    update_rates = None
+    if world == 1 and not args.no_update_rates:
+        from trlda_amd.models import OnlineLDA
+        om = OnlineLDA.__new__(OnlineLDA)
+        om._num_documents, om._update_count = 1000000, 0
+        om._ada_tau, om._ada_rho, om._ada_sq_norm = 1000., 1e-3, 1.
+        om._setup(V, K, .1, .3, local_rank, _lambda=lam)
+        resident = om.upload(csrs[0])
+        as_list = csrs[0].to_list()
+        update_rates = {"unit": "docs/s", "note": "update_parameters(docs, max_iter_inference=%d) "
+                        "end to end from Python, host-side gamma0 draw (sampleGamma, lda.cpp:135) "
+                        "included; never `value`" % args.max_iter}
+        for label, docs_in in (("device_batch", resident), ("list_of_tuples", as_list)):
+            for tr in (0, 10):
+                n_calls = 30 if label == "device_batch" else 10
+                om.update_parameters(docs_in, max_iter_tr=tr, max_iter_inference=args.max_iter)
+                _ffi.check(L.trlda_model_synchronize(om._handle))
+                t_u = time.perf_counter()
+                for _ in range(n_calls):
+                    om.update_parameters(docs_in, max_iter_tr=tr, max_iter_inference=args.max_iter)
+                _ffi.check(L.trlda_model_synchronize(om._handle))
+                dt_u = (time.perf_counter() - t_u) / n_calls
+                update_rates["%s_tr%d" % (label, tr)] = {"docs_per_s": round(B / dt_u, 1),
+                                                        "ms_per_call": round(1e3 * dt_u, 4)}
+        om.close()
 
     out = {
         "metric": "E-step docs/sec (mini-batch) at K=100, V=7000",
         "value": round(docs_per_s, 1), "unit": "docs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 5),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "OnlineLDA E-step (LDA::updateVariablesVI) K=%d V=%d batch=%d "
                                "docs/GPU, max_iter_inference=%d, threshold=%g, %s vocabulary, "
@@ -334,10 +415,13 @@ def main():
                    "active words of the batch (mean %d of %d)" % (
                        int(np.mean([len(np.unique(c.ids)) for c in csrs])), V),
                    "parallelism": "dp%d" % world,
-                   "exchange": "RCCL all-reduce of K x V fp64 sstats" if collective else "none"},
+                   "exchange": "RCCL all-reduce of K x V fp64 sstats, then the M-step "
+                               "(onlinelda.cpp:99-100) that the next step's E-step reads"
+                   if collective else "none"},
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
         "parity": parity,
+        "update_parameters": update_rates,
     }
     if collective:
         dist.destroy_process_group()

@@ -286,6 +286,30 @@ int trlda_model_cumulative_update(trlda_model *model, const trlda_batch *batch, 
                                   int max_iter_inference, int update_lambda, double threshold,
                                   double *gamma_out);
 
+/* ---- multi-GPU: documents shard across ranks, one RCCL all-reduce per E-step ---------------
+ *
+ * One process per GPU, lambda replicated, each rank holds a contiguous range of the
+ * mini-batch's documents.  Documents are independent given lambda (src/lda.cpp:176-214 touches
+ * only column i of gamma and ADDS into sstats), so the path's one exchange is the sum of the
+ * K x V statistics where the reference has its omp-critical reduction (src/lda.cpp:211-217),
+ * plus the V word counts of src/onlinelda.cpp:79-82.  `rccl_comm` is the host program's
+ * ncclComm_t (from ncclCommInitRank), passed as an opaque pointer; ncclAllReduce is resolved
+ * at run time from the process or librccl.so, and runs on the model's stream. */
+/* sstats_dev[K x V] <- sum over ranks */
+int trlda_model_allreduce_sstats(trlda_model *model, void *rccl_comm, double *sstats_dev);
+/* OnlineLDA::updateParameters (src/onlinelda.cpp:53-111, 177-179) over the ranks of rccl_comm:
+ *   shard       this rank's documents [doc_lo, doc_lo + trlda_batch_num_docs(shard)) of a
+ *               mini-batch of total_docs
+ * gamma0 is drawn for the whole mini-batch from the host stream on every rank (trlda_seed /
+ * trlda_rng_set_state keep the ranks' streams equal) and this rank's columns are kept, so an
+ * N-rank run reproduces the one-rank trajectory up to the summation order of the all-reduce.
+ * Every rank applies the identical M-step: lambda stays replicated without a broadcast. */
+int trlda_model_online_update_multi(trlda_model *model, const trlda_batch *shard, void *rccl_comm,
+                                    int total_docs, int doc_lo, int num_documents, double eta,
+                                    int max_iter_tr, int max_iter_inference, double kappa,
+                                    double tau, double rho, int init_gamma, double threshold,
+                                    int *update_count, double *rho_out);
+
 /* ---- update loop: what stays on the device between its steps ----------------------------
  *
  * Inside one OnlineLDA update lambda' and rho are fixed and a word outside the mini-batch has

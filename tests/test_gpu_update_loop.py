@@ -334,3 +334,65 @@ def test_device_eb_statistics_match_numpy(hip):
     assert abs(u2.value - (upd * upd).sum()) < 1e-11 * u2.value
     grad = upd / 1000.
     assert abs(g2.value - (grad * grad).sum()) < 1e-11 * g2.value
+
+
+# --------------------------------------------------------------------------------------------
+# multi-GPU composition in C over a real RCCL communicator (world size 1 on this box)
+# --------------------------------------------------------------------------------------------
+def test_online_update_multi_over_rccl_world_1(hip, tmp_path):
+    """trlda_model_online_update_multi with an ncclComm_t made by ncclCommInitRank (one rank):
+    E-step -> ncclAllReduce of the statistics on the model's stream -> M-step, no Python in
+    between; equals the single-GPU update.  In a child process: the communicator stays there."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_c_abi.py"
+    script.write_text('''
+import ctypes as C, os, sys
+sys.path.insert(0, %r)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import numpy as np
+import torch                                   # brings librccl.so into the process
+import trlda_amd
+from trlda_amd import _ffi
+from trlda_amd.documents import CSRDocuments
+from trlda_amd.models import OnlineLDA
+from trlda_amd.utils.synthetic import make_corpus
+rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+class UniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+uid, comm = UniqueId(), C.c_void_p()
+torch.cuda.set_device(0)
+assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+L = _ffi.lib()
+K, V, D, B = 24, 900, 5000, 60
+docs = [CSRDocuments(*make_corpus(B, V, seed=70 + i, mean_unique=40)) for i in range(2)]
+trlda_amd.seed(4)
+a = OnlineLDA(num_words=V, num_topics=K, num_documents=D)
+ra = [a.update_parameters(d, max_iter_tr=tr) for d, tr in zip(docs, (3, 0))]
+trlda_amd.seed(4)
+b = OnlineLDA(num_words=V, num_topics=K, num_documents=D)
+count, rho, rb = C.c_int(0), C.c_double(0.), []
+for d, tr in zip(docs, (3, 0)):
+    batch = b.upload(d)
+    _ffi.check(L.trlda_model_online_update_multi(b._handle, batch.handle, comm, B, 0, D, .3, tr, 20,
+                                                 .7, 100., -1., 1, 0.001, C.byref(count), C.byref(rho)))
+    rb.append(rho.value)
+assert ra == rb and count.value == 2, (ra, rb, count.value)
+err = float(np.max(np.abs(a.lambdas - b.lambdas) / a.lambdas))
+assert err < 1e-10, err
+# the bare all-reduce: world 1 leaves the buffer unchanged
+buf = torch.arange(K * V, dtype=torch.float64, device="cuda")
+_ffi.check(L.trlda_model_allreduce_sstats(b._handle, comm, C.c_void_p(buf.data_ptr())))
+_ffi.check(L.trlda_model_synchronize(b._handle))
+assert torch.equal(buf.cpu(), torch.arange(K * V, dtype=torch.float64))
+rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+rccl.ncclCommDestroy(comm)
+print("RCCL-C-ABI-OK")
+''' % root)
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900)
+    assert "RCCL-C-ABI-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -1,0 +1,95 @@
+"""Whole-call time of update_parameters (the update loops end to end, inputs resident as a
+DeviceBatch) at BASELINE.json's configurations: the fused device path against the plain launch
+sequence, with and without the host-side gamma0 draw.
+
+    python tools/update_rate.py [--configs small,c5a,c5b,c4] [--package trlda_amd]
+
+Run on the GPU box from the repo root.  `--package` lets the same script time another tree
+(e.g. an export of an earlier round under _r01/) for before/after figures.
+"""
+import argparse
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CONFIGS = {
+    # name: (K, V, B, kind, calls)
+    "small": (100, 7000, 200, "online", 40),
+    "c3": (100, 7000, 1600, "online", 20),
+    "c5a": (500, 100000, 512, "online", 6),
+    "c5b": (500, 100000, 4096, "online", 3),
+    "c4": (200, 50000, 12500, "batch", 2),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="small,c5a,c5b,c4")
+    ap.add_argument("--root", default=ROOT, help="tree to import trlda_amd from")
+    ap.add_argument("--modes", default="fused,plain")
+    args = ap.parse_args()
+    sys.path.insert(0, args.root)
+    pkg = importlib.import_module("trlda_amd")
+    from trlda_amd import _ffi
+    from trlda_amd.documents import CSRDocuments
+    from trlda_amd.models import BatchLDA, OnlineLDA
+    from trlda_amd.utils.synthetic import make_corpus
+    L = _ffi.lib()
+    print("tree:", os.path.dirname(pkg.__file__))
+    has_switch = hasattr(L, "trlda_model_set_fused_update")
+
+    def sync(m):
+        _ffi.check(L.trlda_model_synchronize(m._handle))
+
+    for name in args.configs.split(","):
+        K, V, B, kind, calls = CONFIGS[name]
+        rng = np.random.RandomState(1)
+        lam = np.asfortranarray(rng.gamma(100., .01, (K, V)))
+        docs = CSRDocuments(*make_corpus(B, V, seed=20150706 + K, mean_unique=100))
+        # time of the host-side gamma0 draw alone (sampleGamma(K, B, 100) / 100, lda.cpp:135)
+        g = np.empty((K, B), order="F")
+        L.trlda_sample_gamma_init(K, B, g)
+        t = time.perf_counter()
+        for _ in range(3):
+            L.trlda_sample_gamma_init(K, B, g)
+        draw_ms = (time.perf_counter() - t) / 3 * 1e3
+        for mode in args.modes.split(","):
+            if mode == "plain" and not has_switch:
+                continue
+            cls = OnlineLDA if kind == "online" else BatchLDA
+            m = cls.__new__(cls)
+            if kind == "online":
+                m._num_documents, m._update_count = 1000000, 0
+                m._ada_tau, m._ada_rho, m._ada_sq_norm = 1000., 1e-3, 1.
+                m._ada_gradient = None
+            m._setup(V, K, .1, .3, None, _lambda=lam)
+            if has_switch:
+                L.trlda_model_set_fused_update(m._handle, int(mode == "fused"))
+                L.trlda_model_set_carry_rowsums(m._handle, int(mode == "fused"))
+            batch = m.upload(docs)
+            variants = [("max_iter_tr=10", dict(max_iter_tr=10, max_iter_inference=20)),
+                        ("max_iter_tr=0", dict(max_iter_tr=0, max_iter_inference=20))] \
+                if kind == "online" else \
+                [("1 epoch, max_iter_inference=100", dict(max_epochs=1, max_iter_inference=100)),
+                 ("1 epoch, max_iter_inference=20", dict(max_epochs=1, max_iter_inference=20))]
+            for label, kw in variants:
+                m.update_parameters(batch, **kw)          # warm-up (allocations, code objects)
+                sync(m)
+                t = time.perf_counter()
+                for _ in range(calls):
+                    m.update_parameters(batch, **kw)
+                sync(m)
+                dt = (time.perf_counter() - t) / calls
+                print("%-5s K=%d V=%d B=%d %-6s %-32s %9.3f ms/call  %10.0f docs/s  "
+                      "(gamma0 draw on the host: %.3f ms/call)"
+                      % (name, K, V, B, mode, label, dt * 1e3, B / dt, draw_ms))
+            m.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -83,6 +83,11 @@ _SIGNATURES = {
                                                 vp]),
     "trlda_model_lower_bound": (C.c_int, [vp, vp, f64p, C.c_double, C.c_double, C.c_int, C.c_double,
                                 C.POINTER(C.c_double)]),
+    "trlda_model_allreduce_sstats": (C.c_int, [vp, vp, vp]),
+    "trlda_model_online_update_multi": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double,
+                                                  C.c_int, C.c_int, C.c_double, C.c_double,
+                                                  C.c_double, C.c_int, C.c_double,
+                                                  C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "trlda_model_set_fused_update": (C.c_int, [vp, C.c_int]),
     "trlda_model_set_carry_rowsums": (C.c_int, [vp, C.c_int]),
     "trlda_model_set_keep_sstats": (C.c_int, [vp, C.c_int]),
@@ -108,6 +113,35 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own HIP / HSA runtime (torch/lib/libamdhip64.so, soname
+    libamdhip64.so.7 -- the soname libtrlda_hip.so asks for).  A process must hold ONE runtime: if
+    /opt/rocm's copy is loaded first, torch later loads its own beside it and finds no GPU.  So
+    when a torch with a bundled runtime is installed, that copy is loaded first (without
+    importing torch) and libtrlda_hip.so binds to it -- the same result as `import torch` before
+    `import trlda_amd`.  TRLDA_NO_TORCH_RUNTIME=1 skips this."""
+    if os.environ.get("TRLDA_NO_TORCH_RUNTIME") == "1":
+        return
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if not spec or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def lib():
     """Load (once) and return the ctypes handle; raises if the .so was not built."""
     global _lib
@@ -116,6 +150,7 @@ def lib():
             raise RuntimeError(
                 "trlda_amd: %s not found -- build it with `python -m trlda_amd.build` "
                 "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+        _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (restype, argtypes) in _SIGNATURES.items():
             fn = getattr(L, name)

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(T) void exp_elog_beta_kernel(
     const size_t astep = stride / (size_t)K;
     for (; i < total; i += stride) {
         const size_t idx = active ? (size_t)active[a] * K + k : i;
-        eeb[idx] = exp_digamma_minus(lambda[idx], psi_sum[k]);
+        eeb[idx] = exp_digamma_minus<false>(lambda[idx], psi_sum[k]);
         k += kstep;
         a += astep;
         if (k >= K) {
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
             const double gk = gamma0_d[tid];
             gbuf[tid] = gk;
             alpha_l[tid] = a.alpha[tid];
-            e0 = exp_digamma(gk);
+            e0 = exp_digamma_chain(gk);
         }
         ebuf[144 + tid] = 0.0;                       // zero beyond K, in both buffers
         if (!a.partial || tid >= K)
@@ -1097,7 +1097,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
             const double ek = e_old[kk], ak = alpha_l[kk];
             const double acc = sum8_strided<kRegPart>(part + kk);
             const double gnew = acc * ek + ak;
-            const double enew = (MODE == 2 ? exp_digamma_minus_lean(gnew, 0.0) : exp_digamma(gnew)) * c_psi;
+            const double enew = (MODE == 2 ? exp_digamma_minus_lean(gnew, 0.0) : exp_digamma_chain(gnew)) * c_psi;
             if (psi_on) {
                 g_new[k_psi] = gnew;
                 e_new[k_psi] = enew;
@@ -1438,11 +1438,215 @@ __global__ __launch_bounds__(T) void sstats_update_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// 4d. The same kernel for even K: every lane owns two ADJACENT topics, so that a row of
+// exp(psi(gamma)) is gathered with one 16-byte load per lane (8-byte gathers reach about 0.6 of
+// the 16-byte rate on gfx950) and a pass over a word's entry list serves 256 topics instead of
+// 128 -- half as many walks of the list at K = 500.  Same sums in the same order per topic:
+// bitwise the same statistics as 4c.
+// ---------------------------------------------------------------------------
+template <int NH>
+__device__ __forceinline__ void word_segment_sum2(int q0, int q1, int K, int kbase,
+                                                  const int32_t *__restrict__ wdoc,
+                                                  const double *__restrict__ tw_word,
+                                                  const double *__restrict__ epg, double2 *acc)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    int kk[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+        kk[h] = min(kbase + 128 * h + 2 * lane, K - 2);   // lanes past K gather the last pair, unused
+    for (int q = q0; q < q1; q += 16) {
+        const int cnt = min(16, q1 - q);
+        const bool mine = lane < cnt;
+        const int dl = mine ? wdoc[q + lane] : 0;
+        const double tl = mine ? tw_word[q + lane] : 0.0;
+        const int tlo = __double2loint(tl), thi = __double2hiint(tl);
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+            if (4 * grp < cnt) {                     // wave-uniform
+                double2 ev[4][NH];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const size_t row = (size_t)__builtin_amdgcn_readlane(dl, 4 * grp + u) * K;
+#pragma unroll
+                    for (int h = 0; h < NH; ++h)
+                        ev[u][h] = *reinterpret_cast<const double2 *>(epg + row + kk[h]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double tu =
+                        __hiloint2double(__builtin_amdgcn_readlane(thi, 4 * grp + u),
+                                         __builtin_amdgcn_readlane(tlo, 4 * grp + u));
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) {
+                        acc[h].x = fma(tu, ev[u][h].x, acc[h].x);
+                        acc[h].y = fma(tu, ev[u][h].y, acc[h].y);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// the pair (i, i + 1) of one word: statistics, M-step, returns the two lambdas written
+__device__ __forceinline__ double2 update_pair(const UpdateOut &o, size_t i, double2 s)
+{
+    if (o.sstats)
+        *reinterpret_cast<double2 *>(o.sstats + i) = s;
+    double2 lam = make_double2(0.0, 0.0);
+    if (o.lambda) {
+        const double hx = o.eta + o.scale * s.x, hy = o.eta + o.scale * s.y;
+        if (o.lambda_prime) {
+            const double2 lp = *reinterpret_cast<const double2 *>(o.lambda_prime + i);
+            lam.x = o.omr * lp.x + o.rho * hx;
+            lam.y = o.omr * lp.y + o.rho * hy;
+        } else {
+            lam.x = o.rho * hx;
+            lam.y = o.rho * hy;
+        }
+        *reinterpret_cast<double2 *>(o.lambda + i) = lam;
+    }
+    return lam;
+}
+
+template <int T, int NKB, int NH>                    // NKB = ceil(K / (128 NH)), K even
+__global__ __launch_bounds__(T) void sstats_update2_kernel(
+    int K, int N, int G_short, int n_long, const int32_t *__restrict__ list,
+    const int32_t *__restrict__ wptr, const int32_t *__restrict__ wdoc,
+    const int32_t *__restrict__ long_words, const double *__restrict__ tw_word,
+    const double *__restrict__ epg, const double *__restrict__ eeb, UpdateOut o)
+{
+    constexpr int W = T / kWave;
+    constexpr int BW = 128 * NH;                     // topics per pass over a word's list
+    extern __shared__ __attribute__((aligned(16))) double wpart2[];   // W x K
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+
+    if ((int)blockIdx.x < G_short) {
+        double2 rs[NKB][NH];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int h = 0; h < NH; ++h)
+                rs[kb][h] = make_double2(0.0, 0.0);
+        for (int p = wid * G_short + (int)blockIdx.x; p < N; p += W * G_short) {
+            const int w = __builtin_amdgcn_readfirstlane(list ? list[p] : p);
+            const int q0 = __builtin_amdgcn_readfirstlane(wptr[w]);
+            const int len = __builtin_amdgcn_readfirstlane(wptr[w + 1]) - q0;
+            if (len > kLongWord)
+                continue;                            // left to the blocks below
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                if (kb * BW < K) {            // wave-uniform
+                    double2 acc[NH];
+#pragma unroll
+                    for (int h = 0; h < NH; ++h)
+                        acc[h] = make_double2(0.0, 0.0);
+                    if (len > 0)
+                        word_segment_sum2<NH>(q0, q0 + len, K, kb * BW, wdoc, tw_word, epg, acc);
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) {
+                        const int k = kb * BW + 128 * h + 2 * lane;
+                        if (k < K) {
+                            const size_t i = (size_t)w * K + k;
+                            double2 s = make_double2(0.0, 0.0);   // lda.cpp:169
+                            if (len > 0) {
+                                const double2 e2 = *reinterpret_cast<const double2 *>(eeb + i);
+                                s = make_double2(acc[h].x * e2.x, acc[h].y * e2.y);
+                            }
+                            const double2 lam = update_pair(o, i, s);
+                            rs[kb][h].x += lam.x;
+                            rs[kb][h].y += lam.y;
+                        }
+                    }
+                }
+            }
+        }
+        if (o.partial) {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const int k = kb * BW + 128 * h + 2 * lane;
+                    if (k < K)
+                        *reinterpret_cast<double2 *>(wpart2 + wid * K + k) = rs[kb][h];
+                }
+            __syncthreads();
+            for (int k = threadIdx.x; k < K; k += T) {
+                double sum = wpart2[k];
+                for (int c = 1; c < W; ++c)
+                    sum += wpart2[c * K + k];
+                o.partial[(size_t)blockIdx.x * K + k] = sum;
+            }
+        }
+        return;
+    }
+
+    // ---- long lists, as in 4c
+    const int G_long = (int)gridDim.x - G_short;
+    double rsl[(512 + T - 1) / T];
+#pragma unroll
+    for (int c = 0; c < (512 + T - 1) / T; ++c)
+        rsl[c] = 0.0;
+    for (int lw = (int)blockIdx.x - G_short; lw < n_long; lw += G_long) {
+        const int w = long_words[lw];
+        const int base = __builtin_amdgcn_readfirstlane(wptr[w]);
+        const int L = __builtin_amdgcn_readfirstlane(wptr[w + 1]) - base;
+        const int chunk = (L + W - 1) / W;
+        const int c0 = __builtin_amdgcn_readfirstlane(min(L, wid * chunk));
+        const int c1 = __builtin_amdgcn_readfirstlane(min(L, c0 + chunk));
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            if (kb * BW < K) {
+                double2 acc[NH];
+#pragma unroll
+                    for (int h = 0; h < NH; ++h)
+                        acc[h] = make_double2(0.0, 0.0);
+                word_segment_sum2<NH>(base + c0, base + c1, K, kb * BW, wdoc, tw_word, epg, acc);
+#pragma unroll
+                for (int h = 0; h < NH; ++h) {
+                    const int k = kb * BW + 128 * h + 2 * lane;
+                    if (k < K)
+                        *reinterpret_cast<double2 *>(wpart2 + wid * K + k) = acc[h];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < (512 + T - 1) / T; ++c) {
+            const int k = threadIdx.x + c * T;
+            if (k < K) {
+                double pv[W];
+#pragma unroll
+                for (int q = 0; q < W; ++q)
+                    pv[q] = wpart2[q * K + k];
+                double acc = pv[0];
+#pragma unroll
+                for (int q = 1; q < W; ++q)
+                    acc += pv[q];
+                const size_t i = (size_t)w * K + k;
+                rsl[c] += update_one(o, i, acc * eeb[i]);
+            }
+        }
+        __syncthreads();
+    }
+    if (o.partial) {
+#pragma unroll
+        for (int c = 0; c < (512 + T - 1) / T; ++c) {
+            const int k = threadIdx.x + c * T;
+            if (k < K)
+                o.partial[(size_t)blockIdx.x * K + k] = rsl[c];
+        }
+    }
+}
+
 // 4b. Atomic mode finish: sstats *= eeb (lda.cpp:217): FinishOp in stream_kernels.h.
 
-// psi[i] = psi(x[i]); epsi[i] = exp(psi(x[i])) as the document kernels compute it (no
-// logarithm); epsi_lean[i] = the register-lean schedule of the same value; eminus[i] =
-// exp(psi(x[i]) - c): test hook for the device special functions
+// psi[i] = psi(x[i]); epsi[i] = exp(psi(x[i])) as the register-resident document kernel
+// computes it (no logarithm, short-chain exponential); epsi_lean[i] = the register-lean schedule
+// with the library exponential (the other kernels' value); eminus[i] = exp(psi(x[i]) - c): test
+// hook for the device special functions
 // (tests/test_gpu_parity.py::test_device_digamma_table).
 __global__ void digamma_table_kernel(int n, double c, const double *__restrict__ x,
                                      double *__restrict__ psi, double *__restrict__ epsi,
@@ -1453,9 +1657,9 @@ __global__ void digamma_table_kernel(int n, double c, const double *__restrict__
         return;
     const double v = x[i];
     psi[i] = digamma(v);
-    epsi[i] = exp_digamma(v);
+    epsi[i] = exp_digamma_chain(v);
     epsi_lean[i] = exp_digamma_minus_lean(v, 0.0);
-    eminus[i] = exp_digamma_minus(v, c);
+    eminus[i] = exp_digamma_minus<false>(v, c);
 }
 
 // ---------------------------------------------------------------------------

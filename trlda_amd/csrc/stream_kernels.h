@@ -66,6 +66,20 @@ __device__ __forceinline__ typename vec_t<VEC>::type vload(const double *p)
 {
     return *reinterpret_cast<const typename vec_t<VEC>::type *>(p);
 }
+// the same load with the non-temporal hint: for bytes that are read once and must not push
+// re-used lines (exp E[log beta], exp(psi(gamma))) out of L2 / the Infinity Cache
+template <int VEC>
+__device__ __forceinline__ typename vec_t<VEC>::type vload_nt(const double *p)
+{
+    if constexpr (VEC == 2) {
+        double2 r;
+        r.x = __builtin_nontemporal_load(p);
+        r.y = __builtin_nontemporal_load(p + 1);
+        return r;
+    } else {
+        return __builtin_nontemporal_load(p);
+    }
+}
 template <int VEC>
 __device__ __forceinline__ void vstore(double *p, typename vec_t<VEC>::type v)
 {
@@ -106,13 +120,12 @@ __device__ __forceinline__ void stream_block_partial(int K, int P, int cpb, int 
 // ---------------------------------------------------------------------------
 // Row sums of lambda (lda.cpp:172): partial[block][k] = sum over the block's columns.
 // ---------------------------------------------------------------------------
-template <int T, int VEC>
+template <int T, int VEC, int U = kStreamUnroll, bool NT = true>
 __global__ __launch_bounds__(T) void rowsum_stream_kernel(int K, int V, int P, int cpb,
                                                           const double *__restrict__ lambda,
                                                           double *__restrict__ partial)
 {
     extern __shared__ double scratch[];
-    constexpr int U = kStreamUnroll;
     using V_t = typename vec_t<VEC>::type;
     const int slot = threadIdx.x / P, kp = threadIdx.x - slot * P;
     const int m = gridDim.x * cpb;
@@ -126,7 +139,8 @@ __global__ __launch_bounds__(T) void rowsum_stream_kernel(int K, int V, int P, i
             V_t x[U];
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                x[u] = vload<VEC>(base + (size_t)min(col + u * m, V - 1) * K);
+                x[u] = NT ? vload_nt<VEC>(base + (size_t)min(col + u * m, V - 1) * K)
+                          : vload<VEC>(base + (size_t)min(col + u * m, V - 1) * K);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const bool on = col + u * m < V;
@@ -235,7 +249,7 @@ __global__ __launch_bounds__(T) void inactive_update_stream_kernel(
                 for (int v = 0; v < VEC; ++v)
                     vset(x[u], v, 0.0);
                 if (fl[u] ? read_active : read_inactive)
-                    x[u] = vload<VEC>(src + (size_t)c * K + off);
+                    x[u] = vload_nt<VEC>(src + (size_t)c * K + off);   // read once
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {

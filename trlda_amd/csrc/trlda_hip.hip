@@ -20,6 +20,7 @@
 #include <numeric>
 #include <string>
 #include <thread>
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -172,6 +173,7 @@ struct trlda_model {
     double rs_floor = 0.0;
     int64_t d2h_bytes = 0;              // bytes copied to the host through this model (tests)
     bool lambda_exposed = false;        // trlda_model_lambda_dev was handed out: never trust rs_*
+    bool pair_gathers = true;           // statistics kernel with two topics per lane (even K > 128)
     // per-batch workspaces, grown on demand
     size_t cap_docs = 0, cap_tw_csr = 0, cap_tw_word = 0;
     double *epg = nullptr, *tw_csr = nullptr, *tw_word = nullptr;
@@ -442,7 +444,19 @@ int rowsums_from_scratch(trlda_model *m)
     return combine_rowsums(m, m->partial, g.G, nullptr, m->rs_full);
 }
 
-template <int T, int NKB>
+using sstats_update_fn = void (*)(int, int, int, int, const int32_t *, const int32_t *, const int32_t *,
+                                  const int32_t *, const double *, const double *, const double *,
+                                  trlda::UpdateOut);
+template <int T, int NKB, int NH>
+sstats_update_fn sstats_update_entry()
+{
+    if constexpr (NH == 0)
+        return trlda::sstats_update_kernel<T, NKB>;
+    else
+        return trlda::sstats_update2_kernel<T, NKB, NH>;
+}
+
+template <int T, int NKB, int NH>                    // NH = 0: one topic per lane (any K)
 int launch_sstats_update(trlda_model *m, const trlda_batch *b, EstepOut &out)
 {
     constexpr int W = T / trlda::kWave;
@@ -451,7 +465,7 @@ int launch_sstats_update(trlda_model *m, const trlda_batch *b, EstepOut &out)
     const int G_short = std::max(1, std::min(kUpdShortBlocks, (N + W - 1) / W));
     const int G_long = std::min(kUpdLongBlocks, b->n_long);
     const size_t lds = (size_t)W * K * sizeof(double);
-    auto kern = trlda::sstats_update_kernel<T, NKB>;
+    auto kern = sstats_update_entry<T, NKB, NH>();
     int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (rc)
         return rc;
@@ -465,18 +479,28 @@ int launch_sstats_update(trlda_model *m, const trlda_batch *b, EstepOut &out)
 
 int sstats_update_device(trlda_model *m, const trlda_batch *b, EstepOut &out)
 {
-    const int NKB = (m->K + 127) / 128;
-    if (m->K >= 256) {
-        switch (NKB) {
-        case 2: return launch_sstats_update<512, 2>(m, b, out);
-        case 3: return launch_sstats_update<512, 3>(m, b, out);
-        default: return launch_sstats_update<512, 4>(m, b, out);
-        }
-    }
+    const int K = m->K;
     // one wavefront per word; 16 words per workgroup for small K, 8 from K = 256 on
     // (measured: 7.1 vs 7.4 us at K = 100, 170 vs 145 us at K = 500)
-    return NKB == 1 ? launch_sstats_update<1024, 1>(m, b, out)
-                    : launch_sstats_update<1024, 2>(m, b, out);
+    if (K % 2 == 0 && m->pair_gathers) {
+        // a lane owns two adjacent topics: 16-byte gathers, 256 topics per pass over a list
+        if (K <= 128)
+            return launch_sstats_update<1024, 1, 1>(m, b, out);
+        if (K < 256)
+            return launch_sstats_update<1024, 1, 2>(m, b, out);
+        return K <= 256 ? launch_sstats_update<512, 1, 2>(m, b, out)
+                        : launch_sstats_update<512, 2, 2>(m, b, out);
+    }
+    const int NKB = (K + 127) / 128;
+    if (K >= 256) {
+        switch (NKB) {
+        case 2: return launch_sstats_update<512, 2, 0>(m, b, out);
+        case 3: return launch_sstats_update<512, 3, 0>(m, b, out);
+        default: return launch_sstats_update<512, 4, 0>(m, b, out);
+        }
+    }
+    return NKB == 1 ? launch_sstats_update<1024, 1, 0>(m, b, out)
+                    : launch_sstats_update<1024, 2, 0>(m, b, out);
 }
 
 // The E-step launch sequence on the model's stream (no synchronisation).  `out` says what the
@@ -633,7 +657,8 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         //                    orientations (estep_docs_reg_kernel)
         //   [0, B - n_reg)   everything else
         int n_reg = 0;
-        if (m->doc_threads == 0 && K <= kRegMaxK && m->doc_kernel != TRLDA_DOCS_WIDE)
+        if (m->doc_threads == 0 && K <= kRegMaxK && m->doc_kernel != TRLDA_DOCS_WIDE &&
+            m->doc_kernel != TRLDA_DOCS_GENERAL)
             while (n_reg < B && b->sorted_len[(size_t)(B - 1 - n_reg)] <= kRegMaxN)
                 ++n_reg;
 
@@ -726,14 +751,14 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
             // (With more documents than CUs it is throughput that counts, and there <2> wins over
             // <1>: it only charges the long documents for their tail.)
             const int longest = b->sorted_len[(size_t)(B - n_reg)];
+            a.order = b->order + (B - n_reg);
+            a.pad_meta = b->pad_meta + (size_t)(B - n_reg) * 4;
+            a.pad_ids = b->pad_ids + (size_t)(B - n_reg) * kRegMaxN;
             auto kern = longest <= 128                    ? estep_docs_reg_kernel<0>
                         : longest <= 144 && n_reg <= 256 ? estep_docs_reg_kernel<1>
                                                           : estep_docs_reg_kernel<2>;
             if ((rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), kRegLdsBytes)))
                 return rc;
-            a.order = b->order + (B - n_reg);
-            a.pad_meta = b->pad_meta + (size_t)(B - n_reg) * 4;
-            a.pad_ids = b->pad_ids + (size_t)(B - n_reg) * kRegMaxN;
             hipLaunchKernelGGL(kern, dim3(n_reg), dim3(kRegThreads), kRegLdsBytes, m->stream, a);
             HIP_TRY(hipGetLastError());
         }
@@ -1563,6 +1588,13 @@ int trlda_model_create(trlda_model **out, int device, int K, int V)
         return rc;
     trlda_model *m = new trlda_model();
     m->device = device; m->K = K; m->V = V;
+    if (const char *env = std::getenv("TRLDA_PAIR_GATHERS"))   // measurements
+        m->pair_gathers = std::atoi(env) != 0;
+    if (const char *env = std::getenv("TRLDA_DOC_KERNEL")) {   // measurements: force a document kernel
+        const std::string v(env);
+        m->doc_kernel = v == "wide" ? TRLDA_DOCS_WIDE : v == "general" ? TRLDA_DOCS_GENERAL
+                                                                       : TRLDA_DOCS_AUTO;
+    }
     size_t KV = (size_t)K * V;
     rc = dev_alloc(&m->lambda, KV);
     if (!rc) rc = dev_alloc(&m->eeb, KV);
@@ -1657,7 +1689,7 @@ int trlda_model_set_doc_kernel(trlda_model *m, int kind)
     if (!m)
         return fail(TRLDA_ERR_ARG, "null model");
     if (kind != TRLDA_DOCS_AUTO && kind != TRLDA_DOCS_GENERAL && kind != TRLDA_DOCS_WIDE)
-        return fail(TRLDA_ERR_ARG, "doc_kernel must be TRLDA_DOCS_AUTO, _LDS or _WIDE");
+        return fail(TRLDA_ERR_ARG, "doc_kernel must be TRLDA_DOCS_AUTO, _GENERAL or _WIDE");
     m->doc_kernel = kind;
     return TRLDA_OK;
 }
@@ -2263,6 +2295,131 @@ int trlda_model_cumulative_update(trlda_model *m, const trlda_batch *b, int max_
         m->d2h_bytes += (int64_t)gbytes;
     }
     HIP_TRY(hipStreamSynchronize(m->stream));
+    return TRLDA_OK;
+}
+
+// ---- multi-GPU composition over RCCL, no Python in between --------------------------------
+//
+// One process per GPU; documents shard across ranks, lambda is replicated.  The only exchange
+// of the path is the sum of the K x V statistics where the reference has its `omp critical`
+// reduction (src/lda.cpp:211-217) -- one ncclAllReduce on the model's stream -- plus one sum of
+// V word counts for the trust-region initial step (src/onlinelda.cpp:79-82).  The host program
+// owns the communicator (ncclCommInitRank) and hands it over as an opaque pointer; RCCL is
+// looked up at run time in the process (the host already links it) or as librccl.so, so this
+// library carries no link-time dependency on it.
+} // extern "C"
+
+namespace {
+
+using nccl_allreduce_fn = int (*)(const void *, void *, size_t, int, int, void *, hipStream_t);
+constexpr int kNcclFloat64 = 8, kNcclSum = 0;       // ncclDataType_t / ncclRedOp_t (nccl.h)
+
+nccl_allreduce_fn rccl_allreduce()
+{
+    static nccl_allreduce_fn fn = [] {
+        void *sym = dlsym(RTLD_DEFAULT, "ncclAllReduce");
+        if (!sym) {
+            const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+            for (const char *name : names) {
+                if (void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
+                    sym = dlsym(h, "ncclAllReduce");
+                    if (sym)
+                        break;
+                }
+            }
+        }
+        return reinterpret_cast<nccl_allreduce_fn>(sym);
+    }();
+    return fn;
+}
+
+int allreduce_f64(trlda_model *m, void *comm, double *buf, size_t count)
+{
+    if (!comm)
+        return fail(TRLDA_ERR_ARG, "RCCL communicator is NULL");
+    nccl_allreduce_fn fn = rccl_allreduce();
+    if (!fn)
+        return fail(TRLDA_ERR_ARG, "ncclAllReduce not found: load RCCL (librccl.so) into the process");
+    const int rc = fn(buf, buf, count, kNcclFloat64, kNcclSum, comm, m->stream);
+    if (rc != 0)
+        return fail(TRLDA_ERR_HIP, "ncclAllReduce failed with ncclResult_t " + std::to_string(rc));
+    return TRLDA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int trlda_model_allreduce_sstats(trlda_model *m, void *rccl_comm, double *sstats_dev)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!sstats_dev)
+        return fail(TRLDA_ERR_ARG, "sstats is NULL");
+    return allreduce_f64(m, rccl_comm, sstats_dev, (size_t)m->K * m->V);
+}
+
+int trlda_model_online_update_multi(trlda_model *m, const trlda_batch *shard, void *rccl_comm,
+                                    int total_docs, int doc_lo, int num_documents, double eta,
+                                    int max_iter_tr, int max_iter_inference, double kappa, double tau,
+                                    double rho, int init_gamma, double threshold, int *update_count,
+                                    double *rho_out)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!shard || !update_count || !rho_out)
+        return fail(TRLDA_ERR_ARG, "NULL shard / update_count / rho_out");
+    if (shard->V != m->V)
+        return fail(TRLDA_ERR_SHAPE, "batch was created for a different vocabulary size");
+    const int K = m->K, Bl = shard->B, B = total_docs;
+    if (B < 0 || doc_lo < 0 || doc_lo + Bl > B)
+        return fail(TRLDA_ERR_ARG, "shard [doc_lo, doc_lo + its size) must lie inside [0, total_docs)");
+    if (B == 0) {                                            // onlinelda.cpp:54-56
+        *rho_out = 1.0;
+        return TRLDA_OK;
+    }
+    if (rho < 0.)                                            // onlinelda.cpp:59-66
+        rho = std::pow(tau + (double)*update_count, -kappa);
+    *rho_out = rho;
+    rc = ensure_update_workspace(m, Bl);
+    if (rc)
+        return rc;
+    const size_t KV = (size_t)K * m->V;
+    const double scale = (double)num_documents / (double)B;
+    // gamma0 of the whole mini-batch from the (shared) host stream, this rank's columns kept:
+    // every rank consumes the stream exactly as the single-process run does (lda.cpp:135)
+    std::vector<double> full;
+    auto fresh_gamma = [&]() -> int {
+        full.resize((size_t)K * B);
+        trlda_sample_gamma_init(K, B, full.data());
+        if (Bl > 0) {
+            HIP_TRY(hipMemcpyAsync(m->gamma, full.data() + (size_t)K * doc_lo,
+                                   (size_t)K * Bl * sizeof(double), hipMemcpyHostToDevice, m->stream));
+            HIP_TRY(hipStreamSynchronize(m->stream));        // `full` is reused by the next draw
+        }
+        return TRLDA_OK;
+    };
+    HIP_TRY(hipMemcpyAsync(m->lambda_prime, m->lambda, KV * sizeof(double), hipMemcpyDeviceToDevice,
+                           m->stream));                      // lambdaPrime = mLambda  (:68)
+    const int steps = max_iter_tr > 0 ? max_iter_tr : 1;
+    if (max_iter_tr > 0) {                                   // onlinelda.cpp:79-86
+        rc = wordcounts_device(m, shard, m->wordcounts);
+        if (!rc) rc = allreduce_f64(m, rccl_comm, m->wordcounts, (size_t)m->V);
+        const double coef = (double)num_documents / (double)B / (double)K;
+        if (!rc) rc = tr_init_wc_device(m, m->wordcounts, m->lambda_prime, rho, eta, coef);
+    }
+    for (int i = 0; !rc && i < steps; ++i) {                 // onlinelda.cpp:89-101 / :103-109
+        if (!(i > 0 && init_gamma))
+            rc = fresh_gamma();
+        if (!rc) rc = estep_device(m, shard, m->gamma, m->sstats, max_iter_inference, threshold, nullptr);
+        if (!rc) rc = allreduce_f64(m, rccl_comm, m->sstats, KV);    // lda.cpp:211-217 across ranks
+        if (!rc) rc = blend_device(m, m->lambda_prime, m->sstats, rho, eta, scale);
+    }
+    if (rc)
+        return rc;
+    ++*update_count;                                         // onlinelda.cpp:177
     return TRLDA_OK;
 }
 
