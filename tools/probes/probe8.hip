@@ -6,6 +6,32 @@
 #include "../../trlda_amd/csrc/psi.h"
 using namespace trlda;
 
+// the Estrin-scheme exponential that was tried in the psi stage (four dependent steps after the
+// argument reduction instead of Horner's eleven) -- kept here, where it was measured
+__device__ __forceinline__ double exp_short_chain(double x)
+{
+    const double n = rint(x * 1.44269504088896338700e+00);
+    double r = fma(n, -6.93147180369123816490e-01, x);
+    r = fma(n, -1.90821492927058770002e-10, r);
+    const double r2 = r * r;
+    const double p01 = r + 1.0, p23 = fma(r, 1.0 / 6.0, 0.5), p45 = fma(r, 1.0 / 120.0, 1.0 / 24.0);
+    const double p67 = fma(r, 1.0 / 5040.0, 1.0 / 720.0), p89 = fma(r, 1.0 / 362880.0, 1.0 / 40320.0);
+    const double pab = fma(r, 1.0 / 39916800.0, 1.0 / 3628800.0);
+    const double pcd = fma(r, 1.0 / 6227020800.0, 1.0 / 479001600.0);
+    const double r4 = r2 * r2;
+    const double q0 = fma(p23, r2, p01), q1 = fma(p67, r2, p45), q2 = fma(pab, r2, p89);
+    const double r8 = r4 * r4;
+    return ldexp(fma(fma(pcd, r4, q2), r8, fma(q1, r4, q0)), (int)n);
+}
+__device__ __forceinline__ double exp_digamma_chain(double x)
+{
+    double pi[5];
+    for (int i = 0; i < 5; ++i) pi[i] = rcp_pair(x + (double)(2 * i));
+    const double s = x + 10.0, w = ((pi[0] + pi[1]) + (pi[2] + pi[3])) + pi[4], r = rcp_pos<true>(s);
+    const double z = r * r, y = z * psi_series(z);
+    return s * exp_short_chain(-(((0.5 * r) + y) + w));
+}
+
 template <int WHICH>
 __global__ void chain(double *out, unsigned long long *cyc, double x0, int n)
 {

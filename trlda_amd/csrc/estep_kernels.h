@@ -191,7 +191,7 @@ __global__ __launch_bounds__(T) void exp_elog_beta_kernel(
     const size_t astep = stride / (size_t)K;
     for (; i < total; i += stride) {
         const size_t idx = active ? (size_t)active[a] * K + k : i;
-        eeb[idx] = exp_digamma_minus<false>(lambda[idx], psi_sum[k]);
+        eeb[idx] = exp_digamma_minus(lambda[idx], psi_sum[k]);
         k += kstep;
         a += astep;
         if (k >= K) {
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
             const double gk = gamma0_d[tid];
             gbuf[tid] = gk;
             alpha_l[tid] = a.alpha[tid];
-            e0 = exp_digamma_chain(gk);
+            e0 = exp_digamma(gk);
         }
         ebuf[144 + tid] = 0.0;                       // zero beyond K, in both buffers
         if (!a.partial || tid >= K)
@@ -1097,7 +1097,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
             const double ek = e_old[kk], ak = alpha_l[kk];
             const double acc = sum8_strided<kRegPart>(part + kk);
             const double gnew = acc * ek + ak;
-            const double enew = (MODE == 2 ? exp_digamma_minus_lean(gnew, 0.0) : exp_digamma_chain(gnew)) * c_psi;
+            const double enew = (MODE == 2 ? exp_digamma_minus_lean(gnew, 0.0) : exp_digamma(gnew)) * c_psi;
             if (psi_on) {
                 g_new[k_psi] = gnew;
                 e_new[k_psi] = enew;
@@ -1643,10 +1643,9 @@ __global__ __launch_bounds__(T) void sstats_update2_kernel(
 
 // 4b. Atomic mode finish: sstats *= eeb (lda.cpp:217): FinishOp in stream_kernels.h.
 
-// psi[i] = psi(x[i]); epsi[i] = exp(psi(x[i])) as the register-resident document kernel
-// computes it (no logarithm, short-chain exponential); epsi_lean[i] = the register-lean schedule
-// with the library exponential (the other kernels' value); eminus[i] = exp(psi(x[i]) - c): test
-// hook for the device special functions
+// psi[i] = psi(x[i]); epsi[i] = exp(psi(x[i])) as the document kernels compute it (no
+// logarithm); epsi_lean[i] = the register-lean schedule of the same value; eminus[i] =
+// exp(psi(x[i]) - c): test hook for the device special functions
 // (tests/test_gpu_parity.py::test_device_digamma_table).
 __global__ void digamma_table_kernel(int n, double c, const double *__restrict__ x,
                                      double *__restrict__ psi, double *__restrict__ epsi,
@@ -1657,9 +1656,9 @@ __global__ void digamma_table_kernel(int n, double c, const double *__restrict__
         return;
     const double v = x[i];
     psi[i] = digamma(v);
-    epsi[i] = exp_digamma_chain(v);
+    epsi[i] = exp_digamma(v);
     epsi_lean[i] = exp_digamma_minus_lean(v, 0.0);
-    eminus[i] = exp_digamma_minus<false>(v, c);
+    eminus[i] = exp_digamma_minus(v, c);
 }
 
 // ---------------------------------------------------------------------------

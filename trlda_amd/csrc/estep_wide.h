@@ -264,7 +264,7 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
             gk = a.gamma_in[(size_t)d * K + tid];
             ak = a.alpha[tid];
         }
-        const double e0 = cfg::LEAN_PSI ? exp_digamma_minus_lean(gk, 0.0) : exp_digamma_chain(gk);
+        const double e0 = cfg::LEAN_PSI ? exp_digamma_minus_lean(gk, 0.0) : exp_digamma(gk);
         ek = k_on ? e0 : 0.0;
         ebuf[tid] = ek;                              // zero beyond K
     }
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
             const double gnew = k_on ? fma(accs, ek, ak) : 1.5;
             const double diff = k_on ? fabs(gk - gnew) : 0.0;
             gk = gnew;
-            const double enew = cfg::LEAN_PSI ? exp_digamma_minus_lean(gnew, 0.0) : exp_digamma_chain(gnew);
+            const double enew = cfg::LEAN_PSI ? exp_digamma_minus_lean(gnew, 0.0) : exp_digamma(gnew);
             ek = k_on ? enew : 0.0;
             ebuf[nxt * KP + tid] = ek;
             const double dsum = wave_sum_dpp(diff);

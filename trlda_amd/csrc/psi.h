@@ -169,39 +169,6 @@ __device__ __forceinline__ double rcp_pair(double a)
     return fma(2.0, a, 1.0) * rcp_pos<true>(fma(a, a, a));
 }
 
-// exp(x) with a short dependency chain, for x <= 700 (results below the normal range go to
-// denormals / zero like the library's).  The library exp evaluates its polynomial by Horner's
-// rule: eleven DEPENDENT fused multiply-adds, ~37 cycles each on gfx950 for a wave that has
-// the SIMD to itself.  Here: the same argument reduction (x = n ln2 + r, |r| <= ln2 / 2), then
-// the Taylor polynomial through r^13 (next term < 4e-18) by Estrin's scheme -- powers r^2, r^4,
-// r^8 beside pairwise and quadwise partial sums -- four dependent steps instead of eleven, at
-// the price of six more (independent) instructions.  Within 2 ulp of the library's value.  For
-// the document kernel's exp(psi(gamma)) stage, which is one latency-bound chain per iteration;
-// kernels bound by instruction issue keep the library exp.
-__device__ __forceinline__ double exp_short_chain(double x)
-{
-    const double n = rint(x * 1.44269504088896338700e+00);
-    double r = fma(n, -6.93147180369123816490e-01, x);
-    r = fma(n, -1.90821492927058770002e-10, r);
-    const double r2 = r * r;
-    const double p01 = r + 1.0;
-    const double p23 = fma(r, 1.0 / 6.0, 0.5);
-    const double p45 = fma(r, 1.0 / 120.0, 1.0 / 24.0);
-    const double p67 = fma(r, 1.0 / 5040.0, 1.0 / 720.0);
-    const double p89 = fma(r, 1.0 / 362880.0, 1.0 / 40320.0);
-    const double pab = fma(r, 1.0 / 39916800.0, 1.0 / 3628800.0);
-    const double pcd = fma(r, 1.0 / 6227020800.0, 1.0 / 479001600.0);
-    const double r4 = r2 * r2;
-    const double q0 = fma(p23, r2, p01);
-    const double q1 = fma(p67, r2, p45);
-    const double q2 = fma(pab, r2, p89);
-    const double r8 = r4 * r4;
-    const double s0 = fma(q1, r4, q0);
-    const double s1 = fma(pcd, r4, q2);
-    return ldexp(fma(s1, r8, s0), (int)n);
-}
-
-template <bool SHORT_CHAIN = false>
 __device__ __forceinline__ double exp_psi_regular(double x, double c)
 {
     double pi[5];
@@ -216,24 +183,20 @@ __device__ __forceinline__ double exp_psi_regular(double x, double c)
         const double z = r * r;
         y = z * psi_series(z);
     }
-    const double t = -(((0.5 * r) + y) + w) - c;
-    return s * (SHORT_CHAIN ? exp_short_chain(t) : exp(t));
+    return s * exp(-(((0.5 * r) + y) + w) - c);
 }
 
-template <bool SHORT_CHAIN = false>
 __device__ __forceinline__ double exp_digamma_minus(double x, double c)
 {
     // the regular value is computed unconditionally so that the (rare-branch) test runs
     // beside the main dependency chain instead of in front of it
-    const double v = exp_psi_regular<SHORT_CHAIN>(x, c);
+    const double v = exp_psi_regular(x, c);
     if (__builtin_expect(!(x > 1e-290 && x < 1e150) || (x <= 10.0 && x == floor(x)), 0))
         return exp(digamma(x) - c);
     return v;
 }
 
-__device__ __forceinline__ double exp_digamma(double x) { return exp_digamma_minus<false>(x, 0.0); }
-// the same value to 2 ulp with the short-chain exponential: latency-bound callers
-__device__ __forceinline__ double exp_digamma_chain(double x) { return exp_digamma_minus<true>(x, 0.0); }
+__device__ __forceinline__ double exp_digamma(double x) { return exp_digamma_minus(x, 0.0); }
 
 // The same value, bit for bit, scheduled for few live registers instead of for latency: the
 // pairs of reciprocals are formed two at a time (same summation tree) with scheduling
