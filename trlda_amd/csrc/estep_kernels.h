@@ -218,14 +218,48 @@ template <int T>
 __global__ __launch_bounds__(T) void preamble_fused_kernel(
     int K, int V, int G, int wpb, size_t total, const double *__restrict__ lambda,
     double *__restrict__ partial /* G x K */, double *__restrict__ u,
-    const int32_t *__restrict__ active /* word ids or nullptr */)
+    const int32_t *__restrict__ active /* word ids or nullptr */, int GC,
+    const double *__restrict__ carry_rows /* carry_n x K */, int carry_n,
+    const double *__restrict__ carry_base /* K or nullptr */, double *__restrict__ carry_out /* GC x K */)
 {
     __shared__ double red[T];
     const int tid = threadIdx.x;
+    // Row sums carried over from the kernel that wrote lambda, still in carry_n block partials
+    // (sstats_update_kernel, or the streaming pass of the initial step): the first GC workgroups
+    // add up a contiguous range of the rows each -- four threads per topic, eight loads in
+    // flight, parts combined in order; workgroup 0 adds the share of the words outside the
+    // batch -- and the document workgroups finish the sum over the GC rows (topic_scale_*).
+    if ((int)blockIdx.x < GC) {                      // block-uniform
+        const int per = (carry_n + GC - 1) / GC;
+        const int r0 = min(carry_n, (int)blockIdx.x * per), r1 = min(carry_n, r0 + per);
+        const int k = tid % 128, part = tid / 128;   // K <= 128, T = 512: four parts
+        double acc[2] = {0.0, 0.0};
+        if (k < K) {
+            for (int r = r0 + part; r < r1; r += 4 * 8) {
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    v[q] = carry_rows[(size_t)min(r + 4 * q, carry_n - 1) * K + k];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    acc[q & 1] += (r + 4 * q < r1) ? v[q] : 0.0;
+            }
+        }
+        red[tid] = acc[0] + acc[1];
+        __syncthreads();
+        if (tid < K) {
+            double sum = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
+            if (blockIdx.x == 0 && carry_base)
+                sum += carry_base[tid];
+            carry_out[(size_t)blockIdx.x * K + tid] = sum;
+        }
+        return;
+    }
+    const int lead = GC + G;
     // row sums: the first G workgroups, words [b * wpb, (b + 1) * wpb) each (K <= T here),
     // as rowsum_partial_kernel
-    if ((int)blockIdx.x < G) {                       // block-uniform
-        const int w0 = blockIdx.x * wpb;
+    if ((int)blockIdx.x < lead) {                    // block-uniform
+        const int w0 = ((int)blockIdx.x - GC) * wpb;
         const int w1 = min(V, w0 + wpb);
         const int slots = T / K;
         const int slot = tid / K;
@@ -248,7 +282,7 @@ __global__ __launch_bounds__(T) void preamble_fused_kernel(
             double sum = red[tid];
             for (int sl = 1; sl < slots; ++sl)
                 sum += red[sl * K + tid];
-            partial[(size_t)blockIdx.x * K + tid] = sum;
+            partial[(size_t)((int)blockIdx.x - GC) * K + tid] = sum;
         }
         return;
     }
@@ -256,8 +290,8 @@ __global__ __launch_bounds__(T) void preamble_fused_kernel(
     // flat index i = a * K + k of (active word a, topic k), two elements per pass so that
     // their loads overlap
     // (total < 2^22 here: 32-bit index arithmetic, a 64-bit division costs as much as psi)
-    const unsigned stride = (gridDim.x - G) * T, tot = (unsigned)total, Ku = (unsigned)K;
-    for (unsigned i = (blockIdx.x - G) * T + tid; i < tot; i += 2 * stride) {
+    const unsigned stride = (gridDim.x - lead) * T, tot = (unsigned)total, Ku = (unsigned)K;
+    for (unsigned i = (blockIdx.x - lead) * T + tid; i < tot; i += 2 * stride) {
         const unsigned i2 = i + stride;
         const bool two = i2 < tot;
         const unsigned j2 = two ? i2 : i;

@@ -71,6 +71,7 @@ unsigned long long *g_stamp_buf = nullptr;
 #endif
 constexpr int kDenseThreads = 256;
 constexpr int kMaxRowsumBlocks = 1025;   // rows of trlda_model::partial (block partials of row sums)
+constexpr int kCarryBlocks = 8;          // preamble_fused_kernel: workgroups adding up carried partials
 constexpr int kUpdShortBlocks = 1024;    // sstats_update_kernel: blocks walking the short lists
 constexpr int kUpdLongBlocks = 256;      //                       blocks walking the long lists
 constexpr double kFusedRowsumFloor = 2e-3;   // psi(2e-3) = -500.6: exp(-psi(row sum)) stays finite
@@ -165,6 +166,14 @@ struct trlda_model {
     // rs_static: the part over the words outside the current update's mini-batch.
     double *rs_full = nullptr, *rs_static = nullptr, *upd_partial = nullptr;
     bool rs_valid = false;
+    // ... or they are still in pieces: block partials `carry_rows` (carry_n rows of K) plus
+    // `carry_base` (K, or null).  Small tables add them up inside the next preamble launch
+    // (preamble_fused_kernel's combine workgroups, 8 rows into carry_out); anything else
+    // resolves them with rowsum_combine_wave_kernel first.
+    bool carry_pending = false;
+    const double *carry_rows = nullptr, *carry_base = nullptr;
+    int carry_n = 0;
+    double *carry_out = nullptr;        // kCarryBlocks x K
     bool carry_rowsums = true;          // trlda_model_set_carry_rowsums (tests, comparisons)
     bool fused_update = true;           // trlda_model_set_fused_update: statistics + M-step in one pass
     bool keep_sstats = false;           // updates also leave the statistics (and all of lambda') behind
@@ -422,6 +431,31 @@ int combine_rowsums(trlda_model *m, const double *partial, int G, const double *
     return TRLDA_OK;
 }
 
+void invalidate_rowsums(trlda_model *m)
+{
+    m->rs_valid = false;
+    m->carry_pending = false;
+}
+
+// carried row sums still in pieces -> rs_full
+int resolve_carry(trlda_model *m)
+{
+    if (!m->carry_pending)
+        return TRLDA_OK;
+    int rc = combine_rowsums(m, m->carry_rows, m->carry_n, m->carry_base, m->rs_full);
+    if (rc)
+        return rc;
+    m->carry_pending = false;
+    m->rs_valid = true;
+    return TRLDA_OK;
+}
+
+// something knows the row sums of the current lambda (and may be believed)
+bool rowsums_carried(const trlda_model *m)
+{
+    return !m->lambda_exposed && m->carry_rowsums && (m->rs_valid || m->carry_pending);
+}
+
 template <int VEC>
 int launch_rowsum_stream(trlda_model *m, const trlda::StreamGeom &g, double *partial)
 {
@@ -534,7 +568,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
     // combines the block partials.
     const bool big = KV >= ((size_t)1 << 22);
     const bool trust = !m->lambda_exposed;
-    const bool carried = trust && m->rs_valid && m->carry_rowsums;
+    const bool carried = rowsums_carried(m);
     int G = std::min(big ? kMaxRowsumBlocks - 1 : trlda::kRowsumBlocks, std::max(1, V / 32));
     const double *partial_in = m->partial;
     // Small table and every document in the register-resident kernel's range: kernels 1 and
@@ -545,10 +579,20 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                        !m->split_preamble && K <= trlda::kRegMaxK && b->max_n <= trlda::kRegMaxN &&
                        trust && m->rs_floor >= kFusedRowsumFloor;
     m->last_preamble_fused = fused;
+    if (!fused && carried && (rc = resolve_carry(m)))   // everything else wants one row of sums
+        return rc;
     if (fused) {
         constexpr int TP = 512;
-        int wpb = 0;
-        if (carried) {
+        int wpb = 0, GC = 0;
+        const double *carry_rows = nullptr, *carry_base = nullptr;
+        int carry_n = 0;
+        if (carried && m->carry_pending && (m->carry_n > trlda::kRowsumBlocks || m->carry_base)) {
+            // block partials left by the statistics kernel: kCarryBlocks workgroups of this
+            // launch add them up (with the inactive words' share) into carry_out
+            G = 0;
+            GC = kCarryBlocks;
+            carry_rows = m->carry_rows; carry_base = m->carry_base; carry_n = m->carry_n;
+        } else if (carried) {
             G = 0;                                   // no row-sum workgroups: all of them fill
         } else {
             G = std::min(trlda::kRowsumBlocks, std::max(1, V / 32));
@@ -559,18 +603,28 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         const size_t total = dense ? KV : (size_t)K * (size_t)b->n_active;
         // G workgroups add up the row sums, the others fill exp(psi(lambda)): 256 in all, one
         // per CU (a 1024-thread workgroup of this kernel fills a CU's registers)
-        const int GP = G + (int)std::max<size_t>(1, std::min<size_t>((total + TP - 1) / TP, (size_t)(256 * (1024 / TP) - G)));
+        const int lead = G + GC;
+        const int GP = lead + (int)std::max<size_t>(1, std::min<size_t>((total + TP - 1) / TP, (size_t)(256 * (1024 / TP) - lead)));
         hipLaunchKernelGGL(preamble_fused_kernel<TP>, dim3(GP), dim3(TP), 0, m->stream, K, V, G, wpb,
-                           total, m->lambda, m->partial, m->eeb, dense ? nullptr : b->active);
+                           total, m->lambda, m->partial, m->eeb, dense ? nullptr : b->active, GC,
+                           carry_rows, carry_n, carry_base, m->carry_out);
         HIP_TRY(hipGetLastError());
-        if (carried) {
+        if (GC > 0) {
+            partial_in = m->carry_out;
+            G = kCarryBlocks;
+            // lambda has not changed: its row sums are now these eight rows
+            m->carry_rows = m->carry_out; m->carry_n = kCarryBlocks; m->carry_base = nullptr;
+        } else if (carried && m->carry_pending) {
+            partial_in = m->carry_rows;              // few enough rows for the document kernel
+            G = m->carry_n;
+        } else if (carried) {
             partial_in = m->rs_full;
             G = 1;
         }
         if (m->timing && ((rc = stamp(m)) || (rc = stamp(m))))
             return rc;
     } else {
-    if (carried) {
+    if (carried) {                                   // (resolved above)
         partial_in = m->rs_full;
         G = 1;
     } else if (big && stream_available(m)) {
@@ -830,7 +884,7 @@ int launch_elementwise(trlda_model *m, size_t total, const Op &op)
 int blend_device(trlda_model *m, const double *lambda_prime, const double *sstats, double rho,
                  double eta, double scale)
 {
-    m->rs_valid = false;
+    invalidate_rowsums(m);
     m->rs_floor = rho * m->V * eta;     // (1 - rho) lambda' >= 0 whatever lambda' is
     return launch_elementwise(m, (size_t)m->K * m->V,
                               trlda::BlendOp{rho, eta, scale, lambda_prime, sstats, m->lambda});
@@ -882,7 +936,7 @@ int launch_inactive_update(trlda_model *m, double a, double b, double rho, doubl
 int tr_init_wc_device(trlda_model *m, const double *wc, const double *lambda_prime, double rho,
                       double eta, double coef)
 {
-    m->rs_valid = false;
+    invalidate_rowsums(m);
     m->rs_floor = rho * m->V * eta;
     if (stream_available(m)) {
         int G = 0;
@@ -923,7 +977,7 @@ int tr_init_device(trlda_model *m, const trlda_batch *b, const double *lambda_pr
 // small tables can use the fused preamble; for the others 0 ("unknown") is as good.
 void note_host_lambda(trlda_model *m, const double *host_lambda)
 {
-    m->rs_valid = false;
+    invalidate_rowsums(m);
     m->rs_floor = 0.0;
     const size_t K = (size_t)m->K, V = (size_t)m->V;
     if (K * V >= ((size_t)1 << 22) || m->K > trlda::kRegMaxK)
@@ -1044,7 +1098,8 @@ void jump_multiply(const JumpMatrix &x, const JumpMatrix &y, JumpMatrix &out)
 
 // Returned BY VALUE (3.8 kB): the cache below evicts, and a caller holds several powers at once
 // and hands them to worker threads -- a reference into the map would dangle after an eviction.
-JumpMatrix jump_power(uint64_t n)
+// `half`: A^(n/2) when the caller has it (n even): one squaring instead of the whole ladder.
+JumpMatrix jump_power(uint64_t n, const JumpMatrix *half = nullptr)
 {
     static std::mutex mu;
     static std::map<uint64_t, JumpMatrix> cache;
@@ -1053,6 +1108,13 @@ JumpMatrix jump_power(uint64_t n)
     if (it != cache.end())
         return it->second;
     JumpMatrix base, result, tmp;
+    if (half && n % 2 == 0) {
+        jump_multiply(*half, *half, result);
+        if (cache.size() > 2048)
+            cache.clear();
+        cache.emplace(n, result);
+        return result;
+    }
     std::memset(base.a, 0, sizeof(base.a));
     for (int i = 0; i < 30; ++i)
         base.a[i][i + 1] = 1;                        // shift
@@ -1067,7 +1129,7 @@ JumpMatrix jump_power(uint64_t n)
         jump_multiply(base, base, tmp);
         base = tmp;
     }
-    if (cache.size() > 64)
+    if (cache.size() > 2048)                         // 8 MB
         cache.clear();
     cache.emplace(n, result);
     return result;
@@ -1237,6 +1299,8 @@ void trlda_sample_gamma(int m, int n, int k, double *out)
     // (utils.cpp:224-231).  Small requests: one thread, straight through the stream.
     unsigned int hw = std::thread::hardware_concurrency();
     // (the threads are persistent, host_pool(): their number is bounded by the work per thread)
+    // (more than 64 threads were measured on the 256-hardware-thread GPU box and lost: 1.0 ms
+    // against 0.8 ms for K x B = 100 x 200, 100 against 56 ms for 500 x 4096)
     int64_t T = std::max<int64_t>(1, std::min<int64_t>({(int64_t)hw, (int64_t)64, total / 256}));
     if (total * k < (1 << 17))
         T = 1;
@@ -1260,18 +1324,25 @@ void trlda_sample_gamma(int m, int n, int k, double *out)
     const JumpMatrix hop = jump_power((uint64_t)len);                      // thread t -> t + 1
     const JumpMatrix skip = jump_power((uint64_t)(total - len));           // pass p -> p + 1
     const JumpMatrix skip_last = jump_power((uint64_t)(total - last_len));
-    std::vector<GlibcRandom> start((size_t)T);
-    {
-        uint32_t w[31];
-        rng_to_window(g_rng, w);
-        for (int64_t t = 0; t < T; ++t) {
-            window_to_rng(w, start[(size_t)t]);
-            jump_apply(hop, w);
-        }
-    }
+    // thread t starts hop^t into the stream: every thread applies the powers hop^(2^b) of the
+    // set bits of t itself (a handful of 31 x 31 products) instead of the caller walking all T
+    std::vector<JumpMatrix> hop_pow;
+    for (int64_t span = 1; span < T; span <<= 1)
+        hop_pow.push_back(span == 1 ? hop
+                                    : jump_power((uint64_t)len * (uint64_t)span, &hop_pow.back()));
+    uint32_t w0[31];
+    rng_to_window(g_rng, w0);
     GlibcRandom final_state;
     auto work = [&](int64_t t) {
-        GlibcRandom g = start[(size_t)t];
+        GlibcRandom g;
+        {
+            uint32_t w[31];
+            std::memcpy(w, w0, sizeof(w));
+            for (size_t b = 0; b < hop_pow.size(); ++b)
+                if ((t >> b) & 1)
+                    jump_apply(hop_pow[b], w);
+            window_to_rng(w, g);
+        }
         const int64_t lo = t * len, hi = std::min<int64_t>(total, lo + len);
         const JumpMatrix &sk = (t == T - 1) ? skip_last : skip;
         for (int p = 0; p < k; ++p) {
@@ -1605,6 +1676,7 @@ int trlda_model_create(trlda_model **out, int device, int K, int V)
     if (!rc) rc = dev_alloc(&m->rs_full, (size_t)K);
     if (!rc) rc = dev_alloc(&m->rs_static, (size_t)K);
     if (!rc) rc = dev_alloc(&m->upd_partial, (size_t)(kUpdShortBlocks + kUpdLongBlocks) * K);
+    if (!rc) rc = dev_alloc(&m->carry_out, (size_t)kCarryBlocks * K);
     // columns of words no batch has touched yet are never read for their value, but the
     // atomic-mode finish multiplies them by 0: keep them finite
     if (!rc && (hipMemset(m->counter, 0, sizeof(unsigned int)) != hipSuccess ||
@@ -1629,6 +1701,7 @@ int trlda_model_destroy(trlda_model *m)
         (void)hipFree(m->tw_word); (void)hipFree(m->lambda_prime); (void)hipFree(m->sstats); (void)hipFree(m->gamma);
         (void)hipFree(m->wordcounts); (void)hipFree(m->rs_full); (void)hipFree(m->rs_static);
         (void)hipFree(m->upd_partial); (void)hipFree(m->ada_gradient); (void)hipFree(m->reduce_out);
+        (void)hipFree(m->carry_out);
         (void)hipFree(m->iters);
         for (int i = 0; i < 2; ++i) {
             if (m->stage[i])
@@ -1763,7 +1836,7 @@ void *trlda_model_lambda_dev(trlda_model *m)
     if (!m)
         return nullptr;
     // whoever holds this pointer may write lambda: nothing is known about its row sums any more
-    m->rs_valid = false;
+    invalidate_rowsums(m);
     m->rs_floor = 0.0;
     m->lambda_exposed = true;
     return m->lambda;
@@ -1972,21 +2045,36 @@ int trlda_model_copy_lambda(trlda_model *m, double *dst_dev)
 namespace {
 
 // rs_full = rs_static (or nothing) + the block partials the statistics kernel left behind
-int finish_rowsums(trlda_model *m, const EstepOut &out, const double *base, double floor)
+// the row sums of the lambda just written: `n` rows of block partials (+ base)
+int carry_rowsums_from(trlda_model *m, const double *rows, int n, const double *base, double floor)
 {
-    int rc = combine_rowsums(m, out.upd.partial, out.partial_rows, base, m->rs_full);
+    invalidate_rowsums(m);
+    m->rs_floor = floor;
+    if ((size_t)m->K * m->V < ((size_t)1 << 22) && m->K <= trlda::kRegMaxK) {
+        // small table: the next preamble launch adds the pieces up itself (no launch of its own)
+        m->carry_pending = true;
+        m->carry_rows = rows;
+        m->carry_n = n;
+        m->carry_base = base;
+        return TRLDA_OK;
+    }
+    int rc = combine_rowsums(m, rows, n, base, m->rs_full);
     if (rc)
         return rc;
     m->rs_valid = true;
-    m->rs_floor = floor;
     return TRLDA_OK;
+}
+
+int finish_rowsums(trlda_model *m, const EstepOut &out, const double *base, double floor)
+{
+    return carry_rowsums_from(m, out.upd.partial, out.partial_rows, base, floor);
 }
 
 // rs_full for the E-step that follows, when nothing carried it here (big tables only: the
 // small-table preamble adds up lambda itself)
 int ensure_rowsums(trlda_model *m)
 {
-    if ((m->rs_valid && m->carry_rowsums && !m->lambda_exposed) || !stream_available(m))
+    if (rowsums_carried(m) || !stream_available(m))
         return TRLDA_OK;
     if ((size_t)m->K * m->V < ((size_t)1 << 22))
         return TRLDA_OK;
@@ -2027,12 +2115,11 @@ int online_update_fused(trlda_model *m, const trlda_batch *b, int num_documents,
                             m, 1. - rho, rho * eta, rho, eta, coef, b->active_flag, m->wordcounts,
                             m->lambda, m->lambda_prime, &G);
         if (!rc) rc = combine_rowsums(m, m->partial, G, nullptr, m->rs_static);
-        if (!rc) rc = combine_rowsums(m, m->partial + (size_t)trlda::kStreamMaxBlocks * K, G,
-                                      m->rs_static, m->rs_full);
+        // (the initial step obeys the same bound on the row sums as the M-steps)
+        if (!rc) rc = carry_rowsums_from(m, m->partial + (size_t)trlda::kStreamMaxBlocks * K, G,
+                                         m->rs_static, floor_after);
         if (rc)
             return rc;
-        m->rs_valid = true;
-        m->rs_floor = floor_after;         // the initial step obeys the same bound
         out.upd.lambda_prime = m->lambda_prime;
         for (int i = 0; !rc && i < max_iter_tr; ++i) {       // onlinelda.cpp:89-101
             if (!(i > 0 && init_gamma))
@@ -2073,7 +2160,7 @@ int online_update_fused(trlda_model *m, const trlda_batch *b, int num_documents,
                                                             b->active_flag, nullptr, m->lambda,
                                                             nullptr, &G);
     if (!rc) rc = batch_end(m, b);                           // the pass above read its flags
-    m->rs_valid = false;
+    invalidate_rowsums(m);
     if (!rc) rc = combine_rowsums(m, m->partial, G, nullptr, m->rs_static);
     if (!rc) rc = finish_rowsums(m, out, m->rs_static, floor_after);
     return rc;
@@ -2199,7 +2286,7 @@ int trlda_model_batch_update(trlda_model *m, const trlda_batch *b, double eta, i
                                                                     b->active_flag, nullptr,
                                                                     m->lambda, nullptr, &G);
                 if (!rc) rc = batch_end(m, b);
-                m->rs_valid = false;
+                invalidate_rowsums(m);
                 if (!rc) rc = combine_rowsums(m, m->partial, G, nullptr, m->rs_static);
             }
             if (!rc)
@@ -2208,7 +2295,7 @@ int trlda_model_batch_update(trlda_model *m, const trlda_batch *b, double eta, i
         } else {
             rc = estep_device(m, b, m->gamma, m->sstats, max_iter_inference, threshold, nullptr);
             if (!rc) {
-                m->rs_valid = false;
+                invalidate_rowsums(m);
                 m->rs_floor = m->V * eta;
                 rc = launch_elementwise(m, KV, trlda::SetOp{eta, m->sstats, m->lambda});
             }
@@ -2279,7 +2366,7 @@ int trlda_model_cumulative_update(trlda_model *m, const trlda_batch *b, int max_
             } else {
                 rc = estep_device(m, b, m->gamma, m->sstats, max_iter_inference, threshold, nullptr);
                 if (!rc) {
-                    m->rs_valid = false;
+                    invalidate_rowsums(m);
                     m->rs_floor = floor_prime;
                     rc = launch_elementwise(
                         m, KV, trlda::AccumulateOp{m->lambda_prime, m->sstats, m->lambda});
@@ -2446,7 +2533,7 @@ int trlda_model_set_fused_update(trlda_model *m, int fused)
     if (!m)
         return fail(TRLDA_ERR_ARG, "model is NULL");
     m->fused_update = fused != 0;
-    m->rs_valid = false;
+    invalidate_rowsums(m);
     return TRLDA_OK;
 }
 
@@ -2518,7 +2605,11 @@ int trlda_model_eb_lambda_stats(trlda_model *m, double *sum_psi_lambda, double *
     HIP_TRY(hipGetLastError());
     // the row sums: carried by the kernel that wrote lambda, else added up now
     const double *rs = m->rs_full;
-    if (!(m->rs_valid && m->carry_rowsums && !m->lambda_exposed)) {
+    if (rowsums_carried(m)) {
+        rc = resolve_carry(m);
+        if (rc)
+            return rc;
+    } else {
         if (stream_available(m)) {
             rc = rowsums_from_scratch(m);
             if (rc)
