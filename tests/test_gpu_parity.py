@@ -315,20 +315,43 @@ def test_lower_bound_golden(hip, oracle):
         m2.lower_bound(csr(f, "2"), inference_method="gibbs")
 
 
-def test_reference_readme_example(hip, tmp_path):
-    """README.md:36-59 of the reference, verbatim but for the package name and sizes."""
-    from trlda_amd.models import OnlineLDA
-    from trlda_amd.utils import load_documents
+def test_reference_readme_example(hip, tmp_path, monkeypatch):
+    """The example of the reference's README.md:36-59 through the reference's own import path
+    (`trlda`, served by trlda_amd): same imports, same constructor and update_parameters
+    keywords, `data_train.dat` in the working directory, batches of 200, ten epochs."""
     from trlda_amd.utils.synthetic import csr_to_docs, make_corpus
-    path = tmp_path / "data_train.dat"
-    docs = csr_to_docs(*make_corpus(120, 700, seed=3, mean_unique=30))
-    path.write_text("".join("%d %s\n" % (len(d), " ".join("%d:%d" % t for t in d)) for d in docs))
-    model = OnlineLDA(num_words=700, num_topics=10, num_documents=120, alpha=.1, eta=.2)
-    for epoch in range(2):
-        for documents in load_documents(str(path), 50):
-            model.update_parameters(docs=documents, max_iter_tr=3, max_iter_inference=20, kappa=.7,
-                                    tau=100., update_alpha=True, update_eta=True)
-    assert model.update_count == 6 and np.isfinite(model.lambdas).all()
+    docs = csr_to_docs(*make_corpus(500, 7000, seed=3, mean_unique=60))
+    (tmp_path / "data_train.dat").write_text(
+        "".join("%d %s\n" % (len(d), " ".join("%d:%d" % t for t in d)) for d in docs))
+    monkeypatch.chdir(tmp_path)
+
+    from trlda.models import OnlineLDA
+    from trlda.utils import load_documents
+
+    # create model
+    model = OnlineLDA(
+        num_words=7000,
+        num_topics=100,
+        num_documents=1000000,
+        alpha=.1,
+        eta=.2)
+
+    # train model for 10 epochs with a batch size of 200
+    for epoch in range(10):
+        for documents in load_documents('data_train.dat', 200):
+            model.update_parameters(
+                docs=documents,
+                max_iter_tr=10,
+                max_iter_inference=20,
+                kappa=.7,
+                tau=100.,
+                update_alpha=True,
+                update_eta=True)
+
+    import trlda
+    assert trlda.models.OnlineLDA is OnlineLDA and callable(trlda.seed)
+    assert model.update_count == 10 * 3          # 500 lines: two full batches and the rest
+    assert np.isfinite(model.lambdas).all() and (model.lambdas > 0).all()
     assert (model.alpha > 0).all() and model.eta > 0
 
 

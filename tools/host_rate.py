@@ -1,33 +1,95 @@
-"""PCIe-inclusive rate of the host-pointer entry point (gamma0 up, gamma + sstats down per call)."""
-import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""Host-side and PCIe-inclusive rates around the path (never `value`): document ingestion (list
+of tuples -> CSR -> device batch; text corpus -> CSR), the host-pointer E-step, whole
+update_parameters calls, and the reference's README example loop.
+
+    python tools/host_rate.py [--root TREE]      (GPU box, repo root; --root times another tree)
+"""
+import argparse
+import os
+import sys
+import tempfile
+import time
+
 import numpy as np
-from trlda_amd import _ffi
-from trlda_amd.models import OnlineLDA
-from trlda_amd.documents import CSRDocuments
-from trlda_amd.utils.synthetic import make_corpus
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ap = argparse.ArgumentParser()
+ap.add_argument("--root", default=ROOT)
+args = ap.parse_args()
+sys.path.insert(0, args.root)
+import trlda_amd                                     # noqa: E402
+from trlda_amd import _ffi                           # noqa: E402
+from trlda_amd.documents import CSRDocuments, DeviceBatch, as_csr   # noqa: E402
+from trlda_amd.models import OnlineLDA               # noqa: E402
+from trlda_amd.utils import load_documents           # noqa: E402
+from trlda_amd.utils.synthetic import make_corpus    # noqa: E402
+
+print("tree:", os.path.dirname(trlda_amd.__file__))
 L = _ffi.lib()
 K, V, B = 100, 7000, 200
 docs = CSRDocuments(*make_corpus(B, V, seed=20150707, mean_unique=100))
+lst = docs.to_list()
+
+
+def rate(label, fn, n, unit_docs=B):
+    fn()
+    t = time.perf_counter()
+    for _ in range(n):
+        fn()
+    dt = (time.perf_counter() - t) / n
+    print("%-58s %9.1f us/call -> %10.0f docs/s" % (label, dt * 1e6, unit_docs / dt))
+    return dt
+
+
+# ---- ingestion ---------------------------------------------------------------------------
+rate("list of tuples -> CSR (as_csr)", lambda: as_csr(lst), 50)
+rate("list of tuples -> device batch (DeviceBatch)", lambda: DeviceBatch(lst, V, 0).close(), 50)
+rate("CSR -> device batch", lambda: DeviceBatch(docs, V, 0).close(), 50)
+big = CSRDocuments(*make_corpus(20000, V, seed=1, mean_unique=100))
+with tempfile.TemporaryDirectory() as tmp:
+    path = os.path.join(tmp, "corpus.dat")
+    with open(path, "w") as f:
+        for d in big.to_list():
+            f.write("%d %s\n" % (len(d), " ".join("%d:%d" % t for t in d)))
+    size = os.path.getsize(path) / 1e6
+    try:
+        from trlda_amd.utils import load_documents_csr
+        rate("text (%.0f MB, 20k docs) -> CSR batches of 200" % size,
+             lambda: sum(len(b) for b in load_documents_csr(path, 200)), 5, unit_docs=20000)
+    except (ImportError, TypeError):
+        pass
+    rate("text -> lists of tuples, batches of 200 (load_documents)",
+         lambda: sum(len(b) for b in load_documents(path, 200)), 2, unit_docs=20000)
+
+# ---- the host-pointer E-step and whole updates ------------------------------------------------
 L.trlda_seed(1)
 m = OnlineLDA(V, K, 1000000)
-g0 = np.empty((K, B), order="F"); L.trlda_sample_gamma_init(K, B, g0)
+g0 = np.empty((K, B), order="F")
+L.trlda_sample_gamma_init(K, B, g0)
 batch = m.upload(docs)
-for _ in range(5): m.update_variables(batch, latents=g0, max_iter=20)
-n = 200; t = time.perf_counter()
-for _ in range(n): m.update_variables(batch, latents=g0, max_iter=20)
-dt = (time.perf_counter() - t) / n
-print("host-pointer do_e_step, device-resident batch: %.1f us/call -> %.0f docs/s" % (dt * 1e6, B / dt))
-lst = docs.to_list()
-t = time.perf_counter()
-for _ in range(20): m.update_variables(lst, latents=g0, max_iter=20)
-dt2 = (time.perf_counter() - t) / 20
-print("host-pointer do_e_step, list-of-tuples docs:   %.1f us/call -> %.0f docs/s" % (dt2 * 1e6, B / dt2))
-t = time.perf_counter()
-for _ in range(20): m.update_parameters(batch, max_iter_tr=10, max_iter_inference=20)
-dt3 = (time.perf_counter() - t) / 20
-print("update_parameters(max_iter_tr=10):              %.1f us/call -> %.0f docs/s (includes the host-side libc-rand gamma draw)" % (dt3 * 1e6, B / dt3))
-t = time.perf_counter()
-for _ in range(20): m.update_parameters(batch, max_iter_tr=0, max_iter_inference=20)
-dt4 = (time.perf_counter() - t) / 20
-print("update_parameters(max_iter_tr=0):               %.1f us/call -> %.0f docs/s" % (dt4 * 1e6, B / dt4))
+rate("do_e_step, device-resident batch (gamma0 up, gamma + sstats down)",
+     lambda: m.update_variables(batch, latents=g0, max_iter=20), 100)
+rate("do_e_step, list-of-tuples docs", lambda: m.update_variables(lst, latents=g0, max_iter=20), 20)
+for tr in (10, 0):
+    for label, d in (("device batch", batch), ("list of tuples", lst)):
+        def call(d=d, tr=tr):
+            m.update_parameters(d, max_iter_tr=tr, max_iter_inference=20)
+        dt = rate("update_parameters(max_iter_tr=%d), %s" % (tr, label), call, 30)
+L.trlda_model_synchronize(m._handle) if hasattr(L, "trlda_model_synchronize") else None
+
+# ---- the reference's README example (README.md:36-59) on a 1000-document file, one epoch ------
+with tempfile.TemporaryDirectory() as tmp:
+    path = os.path.join(tmp, "data_train.dat")
+    small = CSRDocuments(*make_corpus(1000, V, seed=5, mean_unique=100))
+    with open(path, "w") as f:
+        for d in small.to_list():
+            f.write("%d %s\n" % (len(d), " ".join("%d:%d" % t for t in d)))
+    model = OnlineLDA(num_words=7000, num_topics=100, num_documents=1000000, alpha=.1, eta=.2)
+
+    def epoch():
+        for documents in load_documents(path, 200):
+            model.update_parameters(docs=documents, max_iter_tr=10, max_iter_inference=20, kappa=.7,
+                                    tau=100., update_alpha=True, update_eta=True)
+        model.lambdas                                    # the getter synchronises
+    rate("README example, one epoch over 1000 documents (update_alpha, update_eta)", epoch, 3,
+         unit_docs=1000)

@@ -1,21 +1,35 @@
 #!/bin/bash
-# Run on the GPU box from the repo root:  tools/make_profiles.sh <round-tag>
-# Produces under gpurun_out/:
-#   <tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the default bench command
-#   <tag>_pmc_fetch.txt / <tag>_pmc_write.txt   FETCH_SIZE / WRITE_SIZE per kernel (separate passes)
-#   <tag>_bench.json         the bench line of the profiled run
-#   <tag>_configs.txt        tools/sweep_configs.sh: the other BASELINE.json configurations
-#   <tag>_host_rates.txt     tools/host_rate.py: PCIe-inclusive entry points
-tag=${1:-r01}
+# Run on the GPU box from the repo root:  tools/make_profiles.sh <round-tag> <commit>
+# Produces under gpurun_out/ (copy what is to be judged into profiles/):
+#   <tag>_kernel_stats.csv       rocprofv3 --kernel-trace --stats of the default bench command
+#   <tag>_pmc_fetch.txt / _write.txt / _sq.txt   PMC passes (separate runs, kernel-trace only)
+#   <tag>_traffic.json           tools/make_traffic.py from the two passes, stamped with <commit>
+#   <tag>_bench.json             the un-profiled default bench line
+#   <tag>_k500_*                 the same three for the E-step at K = 500, V = 100 000, B = 512
+#   <tag>_configs.txt            tools/sweep_configs.sh: the other BASELINE.json configurations, with parity
+#   <tag>_host_rates.txt         tools/host_rate.py: ingestion and PCIe-inclusive entry points
+#   <tag>_update_rates.txt       tools/update_rate.py: whole update_parameters calls
+#   <tag>_<cfg>_update_kernel_stats.csv   tools/prof_update.sh: kernels of the update loops
+tag=${1:-r02}; commit=${2:-unknown}
 export TMPDIR=/tmp
 tools/prof_stats.sh ${tag} --steps 200 --warmup 20 > /dev/null
 tools/prof_pmc.sh ${tag}_fetch "FETCH_SIZE" --steps 50 --warmup 5 > gpurun_out/${tag}_pmc_fetch.txt
 tools/prof_pmc.sh ${tag}_write "WRITE_SIZE" --steps 50 --warmup 5 > gpurun_out/${tag}_pmc_write.txt
 tools/prof_pmc.sh ${tag}_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY" --steps 50 --warmup 5 > gpurun_out/${tag}_pmc_sq.txt
-python3 bench.py --steps 200 --warmup 20 > gpurun_out/${tag}_bench_full.json 2> gpurun_out/${tag}_bench_full.err
-# the other BASELINE.json configurations (not bench lines: docs/s + per-kernel us for DESIGN.md)
+python3 tools/make_traffic.py gpurun_out/${tag}_pmc_fetch.txt gpurun_out/${tag}_pmc_write.txt estep_docs_reg_kernel ${commit} > gpurun_out/${tag}_traffic.json
+K500="--topics 500 --words 100000 --batch 512 --steps 20 --warmup 3"
+tools/prof_stats.sh ${tag}_k500 $K500 > /dev/null
+tools/prof_pmc.sh ${tag}_k500_fetch "FETCH_SIZE" $K500 > gpurun_out/${tag}_k500_pmc_fetch.txt
+tools/prof_pmc.sh ${tag}_k500_write "WRITE_SIZE" $K500 > gpurun_out/${tag}_k500_pmc_write.txt
+python3 bench.py --steps 200 --warmup 20 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 bash tools/sweep_configs.sh > gpurun_out/${tag}_configs.txt 2>&1
 python3 tools/host_rate.py > gpurun_out/${tag}_host_rates.txt 2>&1
-cat gpurun_out/${tag}_kernel_stats.csv | cut -c1-160 | head -8
+python3 tools/update_rate.py --configs small,c3,c5a,c5b,c4 > gpurun_out/${tag}_update_rates.txt 2>&1
+for cfg in small c5a c5b c4; do
+  tools/prof_update.sh ${tag}_${cfg}_fused $cfg fused > /dev/null 2>&1
+done
+tools/prof_update.sh ${tag}_c5a_plain c5a plain > /dev/null 2>&1
+python3 tools/allreduce_cost.py 2>/dev/null | grep "K=" > gpurun_out/${tag}_allreduce_world1.txt
+cut -c1-160 gpurun_out/${tag}_kernel_stats.csv | head -8
 cat gpurun_out/${tag}_pmc_fetch.txt gpurun_out/${tag}_pmc_write.txt
-tail -1 gpurun_out/${tag}_bench_full.json
+tail -1 gpurun_out/${tag}_bench.json | cut -c1-600

