@@ -328,6 +328,16 @@ int trlda_model_set_carry_rowsums(trlda_model *model, int carry);
  * and the complete lambda' on the device (what src/onlinelda.cpp:167-175 reads); costs two
  * K x V writes per call. */
 int trlda_model_set_keep_sstats(trlda_model *model, int keep);
+/* gamma0 of the update entry points (sampleGamma(K, B, 100) / 100, src/lda.cpp:135) is drawn ON
+ * THE DEVICE from the host's libc stream -- the same integers in the same order, hence the same
+ * uniforms; the device logarithm may differ from glibc's in the last bit (about 1e-16 relative
+ * in gamma0) -- and the host stream is advanced by the same number of draws.  host = 1: draw on
+ * the host instead, bit for bit the reference's values (K * B * 100 glibc logarithms per call). */
+int trlda_model_set_host_gamma_draw(trlda_model *model, int host);
+/* out_dev[rows x cols] = sampleGamma(rows, cols, passes) / divisor (src/utils.cpp:224-231) on
+ * the device, as above (divisor 1 for the bare sum). */
+int trlda_model_sample_gamma(trlda_model *model, int rows, int cols, int passes, double divisor,
+                             double *out_dev);
 /* bytes this model has copied to host memory so far (tests assert that the empirical-Bayes
  * steps move O(K), not O(K V)) */
 int64_t trlda_model_d2h_bytes(const trlda_model *model);

@@ -396,3 +396,53 @@ print("RCCL-C-ABI-OK")
 ''' % root)
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900)
     assert "RCCL-C-ABI-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+# --------------------------------------------------------------------------------------------
+# sampleGamma on the device, from the host's libc stream
+# --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,cols,passes", [(100, 200, 100), (7, 3, 100), (13, 77, 31), (1, 5, 4),
+                                              (500, 999, 100), (64, 4, 1)])
+def test_device_gamma_draw_is_the_libc_stream(hip, rows, cols, passes):
+    """rng_kernels.h against the host draw (tests/test_boundary.py pins THAT one bit for bit
+    against the reference): the same integers in the same order, so only the logarithm's last
+    bit can differ; and the host generator ends up exactly where the host draw leaves it."""
+    import trlda_amd
+    from trlda_amd import _ffi
+    m = online_model(4, 16, random_lambda(4, 16, 1), 10)
+    dev = _ffi.vp()
+    n = rows * cols
+    _ffi.check(hip.trlda_dev_alloc(0, n * 8, C.byref(dev)))
+    got = np.empty((rows, cols), order="F")
+    for seed in (42, 7):
+        trlda_amd.seed(seed)
+        want = np.empty((rows, cols), order="F")
+        hip.trlda_sample_gamma(rows, cols, passes, want)
+        after_host = np.empty((3, 3), order="F")
+        hip.trlda_sample_gamma(3, 3, 2, after_host)
+        trlda_amd.seed(seed)
+        _ffi.check(hip.trlda_model_sample_gamma(m._handle, rows, cols, passes, 1., dev))
+        _ffi.check(hip.trlda_model_synchronize(m._handle))
+        _ffi.check(hip.trlda_dev_download(0, got.ctypes.data, dev, n * 8))
+        after_dev = np.empty((3, 3), order="F")
+        hip.trlda_sample_gamma(3, 3, 2, after_dev)
+        assert relerr(got, want) < 2e-15, relerr(got, want)
+        assert np.array_equal(after_dev, after_host)
+    hip.trlda_dev_free(0, dev)
+
+
+def test_host_gamma_draw_switch_gives_the_same_update(hip):
+    import trlda_amd
+    K, V, B, D = 50, 2000, 70, 10000
+    lam0 = random_lambda(K, V, 3)
+    docs = corpus(B, V, seed=33, mean_unique=50)
+    out = []
+    for host in (0, 1):
+        m = online_model(K, V, lam0, D)
+        hip.trlda_model_set_host_gamma_draw(m._handle, host)
+        trlda_amd.seed(17)
+        m.update_parameters(docs, max_iter_tr=2, init_gamma=False)
+        m.update_parameters(docs, max_iter_tr=0)
+        out.append(m.lambdas)
+        m.close()
+    assert relerr(out[0], out[1]) < 1e-11

@@ -1,0 +1,118 @@
+// rng_kernels.h -- sampleGamma (reference src/utils.cpp:224-231) on the device, from the SAME
+// libc rand() stream the reference consumes.
+//
+// The reference draws lambda0 and every default gamma0 as -sum_{p<100} log|u_{p,i}| / 100 with
+// u = -1 + 2 rand() / RAND_MAX, the (p * total + i)-th draw of glibc's TYPE_3 generator
+// s_n = s_{n-31} + s_{n-3} (mod 2^32), output s_n >> 1 (see the host version in trlda_hip.hip).
+// That is K * B * 100 draws and logarithms per update call -- 2 * 10^6 at K = 100, B = 200,
+// 2 * 10^8 at K = 500, B = 4096 -- which the host's threads cannot produce as fast as the GPU
+// consumes them.  The generator is linear: a window of 31 consecutive values advances N draws by
+// a 31 x 31 matrix over Z / 2^32.  So the stream is cut into segments of kRngSegment draws:
+//
+//   window_level_kernel   the window at the start of every segment, W_s = A^(s L) W_0, built
+//                         radix 16: W_(d 16^l + r) = M[l][d] W_r, one matrix-vector product per
+//                         segment (M[l][d] = A^(d 16^l L): 15 matrices per level, computed once
+//                         on the host)
+//   draw_log_kernel       one thread per segment walks its L draws (window in LDS, a rotating
+//                         index) and stores log|u| of every draw -- the same integers, hence
+//                         the same u, as the host stream; the device logarithm may differ from
+//                         glibc's in the last bit
+//   gamma_sum_kernel      out[i] -= log|u_{p,i}| for p = 0, 1, .. in pass order (the host's
+//                         order of subtractions), and the final division by 100
+//
+// Results equal the host draw to ~1e-16 relative per term; the generator state after the call
+// is the host stream's, exactly (the host advances it by the same number of draws).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace trlda {
+
+constexpr int kRngSegment = 256;      // draws per thread
+constexpr int kRngLevels = 8;         // 16^8 segments: more than any table needs
+constexpr int kRngThreads = 256;
+
+// windows are stored word-major: win[j * S + s], j < 31
+template <int T>
+__global__ __launch_bounds__(T) void window_level_kernel(long long S, long long lo, long long hi,
+                                                         long long unit /* 16^level */,
+                                                         const uint32_t *__restrict__ mats /* 15 x 31 x 31 */,
+                                                         uint32_t *__restrict__ win)
+{
+    const long long s = lo + (long long)blockIdx.x * T + threadIdx.x;
+    if (s >= hi)
+        return;
+    const int d = (int)(s / unit);                   // 1 .. 15
+    const long long r = s - (long long)d * unit;
+    const uint32_t *M = mats + (size_t)(d - 1) * 961;
+    uint32_t w[31];
+#pragma unroll
+    for (int j = 0; j < 31; ++j)
+        w[j] = win[(size_t)j * S + r];
+#pragma unroll 1
+    for (int i = 0; i < 31; ++i) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int j = 0; j < 31; ++j)
+            acc += M[i * 31 + j] * w[j];
+        win[(size_t)i * S + s] = acc;
+    }
+}
+
+// positions [pos_lo, pos_hi) of the stream (a whole number of passes); vbuf[pos - pos_lo] = log|u|
+template <int T>
+__global__ __launch_bounds__(T) void draw_log_kernel(long long S, long long seg_lo, long long seg_hi,
+                                                     long long pos_lo, long long pos_hi,
+                                                     const uint32_t *__restrict__ win,
+                                                     double *__restrict__ vbuf)
+{
+    __shared__ uint32_t x[31 * T];
+    const long long s = seg_lo + (long long)blockIdx.x * T + threadIdx.x;
+    if (s >= seg_hi)
+        return;
+    const long long first = s * kRngSegment;
+    if (first >= pos_hi || first + kRngSegment <= pos_lo)
+        return;
+#pragma unroll
+    for (int j = 0; j < 31; ++j)
+        x[j * T + threadIdx.x] = win[(size_t)j * S + s];
+    int f = 0, b = 28;
+    for (int q = 0; q < kRngSegment; ++q) {
+        const uint32_t v = x[f * T + threadIdx.x] + x[b * T + threadIdx.x];
+        x[f * T + threadIdx.x] = v;
+        f = f == 30 ? 0 : f + 1;
+        b = b == 30 ? 0 : b + 1;
+        const long long pos = first + q;
+        if (pos >= pos_lo && pos < pos_hi) {
+            const double u = -1.0 + 2.0 * (double)(v >> 1) / (double)2147483647;
+            vbuf[pos - pos_lo] = log(fabs(u));
+        }
+    }
+}
+
+// passes [p0, p1) of `total` elements each: out[i] = (first ? 0 : out[i]) - sum_p vbuf[p][i],
+// subtracted in pass order; the last group divides by `divisor` (1 for none)
+template <int T>
+__global__ __launch_bounds__(T) void gamma_sum_kernel(long long total, int passes, int first, double divisor,
+                                                      const double *__restrict__ vbuf,
+                                                      double *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * T + threadIdx.x;
+    if (i >= total)
+        return;
+    double acc = first ? 0.0 : out[i];
+    int p = 0;
+    for (; p + 4 <= passes; p += 4) {
+        const double v0 = vbuf[(size_t)p * total + i], v1 = vbuf[(size_t)(p + 1) * total + i],
+                     v2 = vbuf[(size_t)(p + 2) * total + i], v3 = vbuf[(size_t)(p + 3) * total + i];
+        acc -= v0;
+        acc -= v1;
+        acc -= v2;
+        acc -= v3;
+    }
+    for (; p < passes; ++p)
+        acc -= vbuf[(size_t)p * total + i];
+    out[i] = divisor != 1.0 ? acc / divisor : acc;
+}
+
+}  // namespace trlda

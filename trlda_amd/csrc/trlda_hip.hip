@@ -34,6 +34,7 @@
 #include "elbo_kernels.h"
 #include "stream_kernels.h"
 #include "eb_kernels.h"
+#include "rng_kernels.h"
 
 namespace {
 
@@ -199,6 +200,12 @@ struct trlda_model {
     size_t cap_reduce = 0;
     int32_t *iters = nullptr;                   // per-document iteration counts (estep_host)
     size_t cap_iters = 0;
+    // device-side sampleGamma (rng_kernels.h): segment windows, log|u| of a group of passes
+    bool host_gamma_draw = false;               // true: the bit-exact host draw (glibc log)
+    uint32_t *rng_win = nullptr;
+    size_t cap_rng_win = 0;
+    double *rng_vbuf = nullptr;
+    size_t cap_rng_vbuf = 0;
     // timing: five events per E-step from a pool, resolved lazily (no host sync per step)
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;   // all events ever created
@@ -333,10 +340,18 @@ int ensure_gamma_staging(trlda_model *m, size_t count)
     return TRLDA_OK;
 }
 
-// gamma = sampleGamma(K, B, 100) / 100 from the host stream (lda.cpp:135), uploaded without
-// blocking: the draw of the next call can overlap the kernels of this one
+// out_dev[total] = sampleGamma(total, 1, passes) / divisor on the device, from the host's libc
+// stream, which is advanced by passes * total draws (defined below, after the generator)
+int sample_gamma_on_device(trlda_model *m, long long total, int passes, double divisor, double *out_dev);
+
+// gamma = sampleGamma(K, B, 100) / 100 (lda.cpp:135).  Default: drawn on the device from the same
+// integer stream (rng_kernels.h).  host_gamma_draw: on the host (glibc's logarithm, bit for bit
+// the reference's values), uploaded without blocking so that the draw of the next call can
+// overlap the kernels of this one.
 int fresh_gamma_device(trlda_model *m, int B)
 {
+    if (!m->host_gamma_draw)
+        return sample_gamma_on_device(m, (long long)m->K * B, 100, 100., m->gamma);
     const size_t count = (size_t)m->K * B;
     int rc = ensure_gamma_staging(m, count);
     if (rc)
@@ -1374,6 +1389,112 @@ void trlda_sample_gamma_init(int m, int n, double *out)
         out[i] /= 100.;
 }
 
+} // extern "C"
+
+namespace {
+
+// M[l][d - 1] = A^(d 16^l L), l < kRngLevels, d = 1 .. 15 (31 x 31 words each), computed once
+const std::vector<uint32_t> &rng_level_matrices()
+{
+    static std::vector<uint32_t> mats;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        mats.resize((size_t)trlda::kRngLevels * 15 * 961);
+        JumpMatrix one = jump_power((uint64_t)trlda::kRngSegment), cur, tmp;
+        for (int l = 0; l < trlda::kRngLevels; ++l) {
+            cur = one;
+            for (int d = 1; d <= 15; ++d) {
+                std::memcpy(mats.data() + ((size_t)l * 15 + (d - 1)) * 961, cur.a, sizeof(cur.a));
+                jump_multiply(cur, one, tmp);        // A^((d + 1) 16^l L)
+                cur = tmp;
+            }
+            one = cur;                               // A^(16^(l + 1) L)
+        }
+    });
+    return mats;
+}
+
+struct RngSeedWindow {
+    uint32_t w[31];
+};
+
+__global__ void window_seed_kernel(long long S, RngSeedWindow w0, uint32_t *win)
+{
+    if (threadIdx.x < 31)
+        win[(size_t)threadIdx.x * S] = w0.w[threadIdx.x];
+}
+
+// the matrices live on the device once per (process, device)
+int rng_device_matrices(int device, const uint32_t **out)
+{
+    static std::mutex mu;
+    static std::map<std::pair<pid_t, int>, uint32_t *> all;
+    std::lock_guard<std::mutex> lock(mu);
+    auto key = std::make_pair(getpid(), device);
+    auto it = all.find(key);
+    if (it == all.end()) {
+        const std::vector<uint32_t> &h = rng_level_matrices();
+        uint32_t *d = nullptr;
+        int rc = dev_alloc(&d, h.size());
+        if (rc)
+            return rc;
+        HIP_TRY(hipMemcpy(d, h.data(), h.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        it = all.emplace(key, d).first;
+    }
+    *out = it->second;
+    return TRLDA_OK;
+}
+
+int sample_gamma_on_device(trlda_model *m, long long total, int passes, double divisor, double *out_dev)
+{
+    if (total <= 0)
+        return TRLDA_OK;
+    constexpr int L = trlda::kRngSegment, T = trlda::kRngThreads;
+    const long long draws = total * passes;
+    const long long S = (draws + L - 1) / L;
+    const uint32_t *mats = nullptr;
+    int rc = rng_device_matrices(m->device, &mats);
+    if (!rc) rc = grow(&m->rng_win, &m->cap_rng_win, (size_t)31 * (size_t)S);
+    // log|u| of a group of passes: at most ~1 GB at a time
+    const long long group = std::max<long long>(1, std::min<long long>(passes, ((long long)1 << 27) / total));
+    if (!rc) rc = grow(&m->rng_vbuf, &m->cap_rng_vbuf, (size_t)group * (size_t)total);
+    if (rc)
+        return rc;
+    RngSeedWindow w0;
+    rng_to_window(g_rng, w0.w);
+    hipLaunchKernelGGL(window_seed_kernel, dim3(1), dim3(64), 0, m->stream, S, w0, m->rng_win);
+    long long unit = 1;
+    for (int l = 0; l < trlda::kRngLevels && unit < S; ++l, unit *= 16) {
+        const long long lo = unit, hi = std::min<long long>(S, unit * 16);
+        hipLaunchKernelGGL(trlda::window_level_kernel<T>, dim3((unsigned)((hi - lo + T - 1) / T)), dim3(T),
+                           0, m->stream, S, lo, hi, unit, mats + (size_t)l * 15 * 961, m->rng_win);
+    }
+    if (unit < S)
+        return fail(TRLDA_ERR_ARG, "sampleGamma request too large for the device generator");
+    for (long long p0 = 0; p0 < passes; p0 += group) {
+        const long long p1 = std::min<long long>(passes, p0 + group);
+        const long long pos_lo = p0 * total, pos_hi = p1 * total;
+        const long long seg_lo = pos_lo / L, seg_hi = (pos_hi + L - 1) / L;
+        hipLaunchKernelGGL(trlda::draw_log_kernel<T>, dim3((unsigned)((seg_hi - seg_lo + T - 1) / T)),
+                           dim3(T), 0, m->stream, S, seg_lo, std::min(S, seg_hi), pos_lo, pos_hi,
+                           m->rng_win, m->rng_vbuf);
+        hipLaunchKernelGGL(trlda::gamma_sum_kernel<T>, dim3((unsigned)((total + T - 1) / T)), dim3(T), 0,
+                           m->stream, total, (int)(p1 - p0), p0 == 0 ? 1 : 0,
+                           p1 == passes ? divisor : 1.0, m->rng_vbuf, out_dev);
+    }
+    HIP_TRY(hipGetLastError());
+    // the host stream moves on by the same number of draws
+    uint32_t w[31];
+    rng_to_window(g_rng, w);
+    jump_apply(jump_power((uint64_t)draws), w);
+    window_to_rng(w, g_rng);
+    return TRLDA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
 // ---- device memory helpers ----------------------------------------------------
 
 int trlda_dev_alloc(int device, size_t bytes, void **dev_out)
@@ -1702,7 +1823,7 @@ int trlda_model_destroy(trlda_model *m)
         (void)hipFree(m->wordcounts); (void)hipFree(m->rs_full); (void)hipFree(m->rs_static);
         (void)hipFree(m->upd_partial); (void)hipFree(m->ada_gradient); (void)hipFree(m->reduce_out);
         (void)hipFree(m->carry_out);
-        (void)hipFree(m->iters);
+        (void)hipFree(m->iters); (void)hipFree(m->rng_win); (void)hipFree(m->rng_vbuf);
         for (int i = 0; i < 2; ++i) {
             if (m->stage[i])
                 (void)hipHostFree(m->stage[i]);
@@ -2334,13 +2455,36 @@ int trlda_model_cumulative_update(trlda_model *m, const trlda_batch *b, int max_
     HIP_TRY(hipMemcpyAsync(m->lambda_prime, m->lambda, KV * sizeof(double),
                            hipMemcpyDeviceToDevice, m->stream));
     const double floor_prime = m->rs_floor;
-    {
+    if (m->host_gamma_draw) {
         std::vector<double> lam0(KV);
         trlda_sample_gamma_init(K, m->V, lam0.data());
         HIP_TRY(hipMemcpyAsync(m->lambda, lam0.data(), KV * sizeof(double), hipMemcpyHostToDevice,
                                m->stream));
         note_host_lambda(m, lam0.data());
         HIP_TRY(hipStreamSynchronize(m->stream));
+    } else {
+        invalidate_rowsums(m);
+        m->rs_floor = 0.0;
+        rc = sample_gamma_on_device(m, (long long)KV, 100, 100., m->lambda);
+        if (!rc && stream_available(m)) {
+            // its row sums: carried to the first E-step, and their minimum decides whether the
+            // fused small-table preamble is safe (K numbers come back)
+            rc = rowsums_from_scratch(m);
+            std::vector<double> rs((size_t)K);
+            if (!rc) {
+                HIP_TRY(hipMemcpyAsync(rs.data(), m->rs_full, (size_t)K * sizeof(double),
+                                       hipMemcpyDeviceToHost, m->stream));
+                HIP_TRY(hipStreamSynchronize(m->stream));
+                m->d2h_bytes += (int64_t)K * sizeof(double);
+                double lo = rs[0];
+                for (int k = 1; k < K; ++k)
+                    lo = std::min(lo, rs[(size_t)k]);
+                m->rs_floor = lo > 0.0 ? 0.999 * lo : 0.0;
+                m->rs_valid = true;
+            }
+        }
+        if (rc)
+            return rc;
     }
     const bool fused = fused_update_available(m) && stream_available(m);
     bool ran = false;
@@ -2538,6 +2682,25 @@ int trlda_model_set_fused_update(trlda_model *m, int fused)
 }
 
 int64_t trlda_model_d2h_bytes(const trlda_model *m) { return m ? m->d2h_bytes : 0; }
+
+int trlda_model_set_host_gamma_draw(trlda_model *m, int host)
+{
+    if (!m)
+        return fail(TRLDA_ERR_ARG, "model is NULL");
+    m->host_gamma_draw = host != 0;
+    return TRLDA_OK;
+}
+
+int trlda_model_sample_gamma(trlda_model *m, int rows, int cols, int passes, double divisor,
+                             double *out_dev)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (rows < 0 || cols < 0 || passes < 0 || !out_dev || divisor == 0.)
+        return fail(TRLDA_ERR_ARG, "bad sample_gamma arguments");
+    return sample_gamma_on_device(m, (long long)rows * cols, passes, divisor, out_dev);
+}
 
 int trlda_model_estep_resident(trlda_model *m, const trlda_batch *b, int max_iter, double threshold)
 {
