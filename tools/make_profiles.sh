@@ -25,6 +25,13 @@ python3 bench.py --steps 200 --warmup 20 > gpurun_out/${tag}_bench.json 2> gpuru
 bash tools/sweep_configs.sh > gpurun_out/${tag}_configs.txt 2>&1
 python3 tools/host_rate.py > gpurun_out/${tag}_host_rates.txt 2>&1
 python3 tools/update_rate.py --configs small,c3,c5a,c5b,c4 > gpurun_out/${tag}_update_rates.txt 2>&1
+python3 tools/update_rate.py --configs small,c5a,c5b,c4 --modes fused --host-draw > gpurun_out/${tag}_update_rates_host_draw.txt 2>&1
+TRLDA_BENCH_FORCE_DIST=1 python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-update-rates 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_forced_dist_world1.json
+TRLDA_BENCH_FORCE_DIST=1 python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-update-rates --global-batch 1600 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_forced_dist_world1_b1600.json
+if [ -d _r01 ]; then
+  python3 tools/update_rate.py --root _r01 --configs small,c5a,c5b,c4 --modes fused > gpurun_out/r01_update_rates.txt 2>&1
+  python3 tools/host_rate.py --root _r01 > gpurun_out/r01_host_rates_rerun.txt 2>&1
+fi
 for cfg in small c5a c5b c4; do
   tools/prof_update.sh ${tag}_${cfg}_fused $cfg fused > /dev/null 2>&1
 done
