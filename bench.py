@@ -295,6 +295,34 @@ def main():
             "frac": round(estep_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5)},
     }
 
+    # ---- secondary: whole update_parameters calls through the Python surface (N = 1) --------
+    update_rates = None
+    if world == 1 and not args.no_update_rates:
+        from trlda_amd.models import OnlineLDA
+        om = OnlineLDA.__new__(OnlineLDA)
+        om._num_documents, om._update_count = 1000000, 0
+        om._ada_tau, om._ada_rho, om._ada_sq_norm = 1000., 1e-3, 1.
+        om._setup(V, K, .1, .3, local_rank, _lambda=lam)
+        resident = om.upload(csrs[0])
+        as_list = csrs[0].to_list()
+        update_rates = {"unit": "docs/s", "note": "update_parameters(docs, max_iter_inference=%d) "
+                        "end to end from Python (gamma0 drawn per call, lda.cpp:135; the list form "
+                        "includes flattening and upload); measured before the CPU baseline's "
+                        "threads start; never `value`" % args.max_iter}
+        for label, docs_in in (("device_batch", resident), ("list_of_tuples", as_list)):
+            for tr in (0, 10):
+                n_calls = 30 if label == "device_batch" else 10
+                om.update_parameters(docs_in, max_iter_tr=tr, max_iter_inference=args.max_iter)
+                _ffi.check(L.trlda_model_synchronize(om._handle))
+                t_u = time.perf_counter()
+                for _ in range(n_calls):
+                    om.update_parameters(docs_in, max_iter_tr=tr, max_iter_inference=args.max_iter)
+                _ffi.check(L.trlda_model_synchronize(om._handle))
+                dt_u = (time.perf_counter() - t_u) / n_calls
+                update_rates["%s_tr%d" % (label, tr)] = {"docs_per_s": round(B / dt_u, 1),
+                                                        "ms_per_call": round(1e3 * dt_u, 4)}
+        om.close()
+
     # ---- parity + CPU baseline (rank 0, N = 1 only): the checker, timed beside the GPU ----
     cpu_baseline, parity = None, None
     if collective:
@@ -367,33 +395,6 @@ def main():
                                              if l.startswith("model name")][0]
             except Exception:
                 pass
-
-    # ---- secondary: whole update_parameters calls through the Python surface (N = 1) --------
-    update_rates = None
-    if world == 1 and not args.no_update_rates:
-        from trlda_amd.models import OnlineLDA
-        om = OnlineLDA.__new__(OnlineLDA)
-        om._num_documents, om._update_count = 1000000, 0
-        om._ada_tau, om._ada_rho, om._ada_sq_norm = 1000., 1e-3, 1.
-        om._setup(V, K, .1, .3, local_rank, _lambda=lam)
-        resident = om.upload(csrs[0])
-        as_list = csrs[0].to_list()
-        update_rates = {"unit": "docs/s", "note": "update_parameters(docs, max_iter_inference=%d) "
-                        "end to end from Python, host-side gamma0 draw (sampleGamma, lda.cpp:135) "
-                        "included; never `value`" % args.max_iter}
-        for label, docs_in in (("device_batch", resident), ("list_of_tuples", as_list)):
-            for tr in (0, 10):
-                n_calls = 30 if label == "device_batch" else 10
-                om.update_parameters(docs_in, max_iter_tr=tr, max_iter_inference=args.max_iter)
-                _ffi.check(L.trlda_model_synchronize(om._handle))
-                t_u = time.perf_counter()
-                for _ in range(n_calls):
-                    om.update_parameters(docs_in, max_iter_tr=tr, max_iter_inference=args.max_iter)
-                _ffi.check(L.trlda_model_synchronize(om._handle))
-                dt_u = (time.perf_counter() - t_u) / n_calls
-                update_rates["%s_tr%d" % (label, tr)] = {"docs_per_s": round(B / dt_u, 1),
-                                                        "ms_per_call": round(1e3 * dt_u, 4)}
-        om.close()
 
     out = {
         "metric": "E-step docs/sec (mini-batch) at K=100, V=7000",

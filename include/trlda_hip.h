@@ -338,6 +338,11 @@ int trlda_model_set_host_gamma_draw(trlda_model *model, int host);
  * the device, as above (divisor 1 for the bare sum). */
 int trlda_model_sample_gamma(trlda_model *model, int rows, int cols, int passes, double divisor,
                              double *out_dev);
+/* The columns [col_lo, col_hi) of that matrix only (out_dev: rows x (col_hi - col_lo)); the
+ * stream still advances by rows * cols * passes draws.  A data-parallel rank draws its own
+ * documents' gamma0 out of the mini-batch's matrix this way, in step with the other ranks. */
+int trlda_model_sample_gamma_cols(trlda_model *model, int rows, int cols, int col_lo, int col_hi,
+                                  int passes, double divisor, double *out_dev);
 /* bytes this model has copied to host memory so far (tests assert that the empirical-Bayes
  * steps move O(K), not O(K V)) */
 int64_t trlda_model_d2h_bytes(const trlda_model *model);

@@ -446,3 +446,33 @@ def test_host_gamma_draw_switch_gives_the_same_update(hip):
         out.append(m.lambdas)
         m.close()
     assert relerr(out[0], out[1]) < 1e-11
+
+
+def test_device_gamma_draw_of_a_column_range(hip):
+    """A data-parallel rank draws only its own documents' columns of the mini-batch's gamma0 and
+    stays in step with the stream: the columns equal the host matrix's, the generator ends where
+    the full draw ends."""
+    import trlda_amd
+    from trlda_amd import _ffi
+    K, B = 37, 53
+    m = online_model(4, 16, random_lambda(4, 16, 1), 10)
+    trlda_amd.seed(99)
+    want = np.empty((K, B), order="F")
+    hip.trlda_sample_gamma_init(K, B, want)
+    after_host = np.empty((2, 2), order="F")
+    hip.trlda_sample_gamma(2, 2, 3, after_host)
+    for lo, hi in ((0, B), (0, 7), (7, 30), (30, B), (11, 11)):
+        trlda_amd.seed(99)
+        n = max(hi - lo, 1) * K
+        dev = _ffi.vp()
+        _ffi.check(hip.trlda_dev_alloc(0, n * 8, C.byref(dev)))
+        _ffi.check(hip.trlda_model_sample_gamma_cols(m._handle, K, B, lo, hi, 100, 100., dev))
+        _ffi.check(hip.trlda_model_synchronize(m._handle))
+        got = np.empty((K, max(hi - lo, 1)), order="F")
+        _ffi.check(hip.trlda_dev_download(0, got.ctypes.data, dev, n * 8))
+        hip.trlda_dev_free(0, dev)
+        if hi > lo:
+            assert relerr(got[:, :hi - lo], want[:, lo:hi]) < 2e-15, (lo, hi)
+        after = np.empty((2, 2), order="F")
+        hip.trlda_sample_gamma(2, 2, 3, after)
+        assert np.array_equal(after, after_host), (lo, hi)

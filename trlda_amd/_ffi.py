@@ -94,6 +94,8 @@ _SIGNATURES = {
     "trlda_model_d2h_bytes": (C.c_int64, [vp]),
     "trlda_model_set_host_gamma_draw": (C.c_int, [vp, C.c_int]),
     "trlda_model_sample_gamma": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_double, vp]),
+    "trlda_model_sample_gamma_cols": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                C.c_double, vp]),
     "trlda_model_estep_resident": (C.c_int, [vp, vp, C.c_int, C.c_double]),
     "trlda_model_eb_gamma_stats": (C.c_int, [vp, C.c_int, vp, f64p]),
     "trlda_model_eb_lambda_stats": (C.c_int, [vp, C.POINTER(C.c_double), f64p]),

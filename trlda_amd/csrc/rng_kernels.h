@@ -59,10 +59,13 @@ __global__ __launch_bounds__(T) void window_level_kernel(long long S, long long 
     }
 }
 
-// positions [pos_lo, pos_hi) of the stream (a whole number of passes); vbuf[pos - pos_lo] = log|u|
+// positions [pos_lo, pos_hi) of the stream (a whole number of passes of `total` elements);
+// vbuf[pos - pos_lo] = log|u| for the elements [e_lo, e_hi) of every pass (a data-parallel rank
+// needs its own documents' columns only; segments that hold none of them do nothing)
 template <int T>
 __global__ __launch_bounds__(T) void draw_log_kernel(long long S, long long seg_lo, long long seg_hi,
-                                                     long long pos_lo, long long pos_hi,
+                                                     long long pos_lo, long long pos_hi, long long total,
+                                                     long long e_lo, long long e_hi,
                                                      const uint32_t *__restrict__ win,
                                                      double *__restrict__ vbuf)
 {
@@ -73,6 +76,14 @@ __global__ __launch_bounds__(T) void draw_log_kernel(long long S, long long seg_
     const long long first = s * kRngSegment;
     if (first >= pos_hi || first + kRngSegment <= pos_lo)
         return;
+    {
+        // elements covered by the segment (it may wrap into the next pass once: total >= 1)
+        const long long a = first % total, z = a + kRngSegment;   // [a, z) modulo total
+        const bool hit = z <= total ? (a < e_hi && z > e_lo)
+                                    : (a < e_hi || (z - total) > e_lo || kRngSegment >= total);
+        if (!hit)
+            return;
+    }
 #pragma unroll
     for (int j = 0; j < 31; ++j)
         x[j * T + threadIdx.x] = win[(size_t)j * S + s];
@@ -83,23 +94,27 @@ __global__ __launch_bounds__(T) void draw_log_kernel(long long S, long long seg_
         f = f == 30 ? 0 : f + 1;
         b = b == 30 ? 0 : b + 1;
         const long long pos = first + q;
-        if (pos >= pos_lo && pos < pos_hi) {
+        const long long el = pos % total;
+        if (pos >= pos_lo && pos < pos_hi && el >= e_lo && el < e_hi) {
             const double u = -1.0 + 2.0 * (double)(v >> 1) / (double)2147483647;
             vbuf[pos - pos_lo] = log(fabs(u));
         }
     }
 }
 
-// passes [p0, p1) of `total` elements each: out[i] = (first ? 0 : out[i]) - sum_p vbuf[p][i],
-// subtracted in pass order; the last group divides by `divisor` (1 for none)
+// passes [p0, p1) of `total` elements each, elements [e_lo, e_hi): out[i - e_lo] = (first ? 0 :
+// out[i - e_lo]) - sum_p vbuf[p][i], subtracted in pass order; the last group divides by
+// `divisor` (1 for none)
 template <int T>
-__global__ __launch_bounds__(T) void gamma_sum_kernel(long long total, int passes, int first, double divisor,
+__global__ __launch_bounds__(T) void gamma_sum_kernel(long long total, long long e_lo, long long e_hi,
+                                                      int passes, int first, double divisor,
                                                       const double *__restrict__ vbuf,
                                                       double *__restrict__ out)
 {
-    const long long i = (long long)blockIdx.x * T + threadIdx.x;
-    if (i >= total)
+    const long long i = e_lo + (long long)blockIdx.x * T + threadIdx.x;
+    if (i >= e_hi)
         return;
+    out += -e_lo;
     double acc = first ? 0.0 : out[i];
     int p = 0;
     for (; p + 4 <= passes; p += 4) {

@@ -342,7 +342,8 @@ int ensure_gamma_staging(trlda_model *m, size_t count)
 
 // out_dev[total] = sampleGamma(total, 1, passes) / divisor on the device, from the host's libc
 // stream, which is advanced by passes * total draws (defined below, after the generator)
-int sample_gamma_on_device(trlda_model *m, long long total, int passes, double divisor, double *out_dev);
+int sample_gamma_on_device(trlda_model *m, long long total, int passes, double divisor, double *out_dev,
+                           long long e_lo = 0, long long e_hi = -1);
 
 // gamma = sampleGamma(K, B, 100) / 100 (lda.cpp:135).  Default: drawn on the device from the same
 // integer stream (rng_kernels.h).  host_gamma_draw: on the host (glibc's logarithm, bit for bit
@@ -1445,10 +1446,15 @@ int rng_device_matrices(int device, const uint32_t **out)
     return TRLDA_OK;
 }
 
-int sample_gamma_on_device(trlda_model *m, long long total, int passes, double divisor, double *out_dev)
+// elements [e_lo, e_hi) only (out_dev compact, e_hi - e_lo values); e_hi < 0: all of them.  The
+// stream always advances by passes * total draws.
+int sample_gamma_on_device(trlda_model *m, long long total, int passes, double divisor, double *out_dev,
+                           long long e_lo, long long e_hi)
 {
     if (total <= 0)
         return TRLDA_OK;
+    if (e_hi < 0)
+        e_hi = total;
     constexpr int L = trlda::kRngSegment, T = trlda::kRngThreads;
     const long long draws = total * passes;
     const long long S = (draws + L - 1) / L;
@@ -1476,11 +1482,13 @@ int sample_gamma_on_device(trlda_model *m, long long total, int passes, double d
         const long long pos_lo = p0 * total, pos_hi = p1 * total;
         const long long seg_lo = pos_lo / L, seg_hi = (pos_hi + L - 1) / L;
         hipLaunchKernelGGL(trlda::draw_log_kernel<T>, dim3((unsigned)((seg_hi - seg_lo + T - 1) / T)),
-                           dim3(T), 0, m->stream, S, seg_lo, std::min(S, seg_hi), pos_lo, pos_hi,
-                           m->rng_win, m->rng_vbuf);
-        hipLaunchKernelGGL(trlda::gamma_sum_kernel<T>, dim3((unsigned)((total + T - 1) / T)), dim3(T), 0,
-                           m->stream, total, (int)(p1 - p0), p0 == 0 ? 1 : 0,
-                           p1 == passes ? divisor : 1.0, m->rng_vbuf, out_dev);
+                           dim3(T), 0, m->stream, S, seg_lo, std::min(S, seg_hi), pos_lo, pos_hi, total,
+                           e_lo, e_hi, m->rng_win, m->rng_vbuf);
+        if (e_hi > e_lo)
+            hipLaunchKernelGGL(trlda::gamma_sum_kernel<T>,
+                               dim3((unsigned)((e_hi - e_lo + T - 1) / T)), dim3(T), 0, m->stream, total,
+                               e_lo, e_hi, (int)(p1 - p0), p0 == 0 ? 1 : 0,
+                               p1 == passes ? divisor : 1.0, m->rng_vbuf, out_dev);
     }
     HIP_TRY(hipGetLastError());
     // the host stream moves on by the same number of draws
@@ -1685,10 +1693,20 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     }
 
     // a device allocation: from the cache when one fits, else new
+    // (one whose last reader has finished, if there is one: an upload into an allocation that
+    // the previous call's kernels still read would have to wait for them; with two or three
+    // allocations in rotation the upload of call n + 1 runs under the kernels of call n)
     UploadContext::Blob blob{nullptr, 0, nullptr};
-    for (size_t i = 0; i < u.cache.size(); ++i)
-        if (u.cache[i].bytes >= total && u.cache[i].bytes <= 4 * total + ((size_t)1 << 20)) {
-            blob = u.cache[i];
+    for (int pass = 0; pass < 2 && !blob.ptr; ++pass)
+        for (size_t i = 0; i < u.cache.size(); ++i) {
+            const UploadContext::Blob &c = u.cache[i];
+            if (c.bytes < total || c.bytes > 4 * total + ((size_t)1 << 20))
+                continue;
+            if (pass == 0 && c.done && hipEventQuery(c.done) != hipSuccess)
+                continue;
+            if (pass == 1 && u.cache.size() < kBlobCacheMax / 2)
+                break;                               // rather a new allocation than a wait
+            blob = c;
             u.cached_bytes -= blob.bytes;
             u.cache.erase(u.cache.begin() + (long)i);
             break;
@@ -2623,6 +2641,9 @@ int trlda_model_online_update_multi(trlda_model *m, const trlda_batch *shard, vo
     // every rank consumes the stream exactly as the single-process run does (lda.cpp:135)
     std::vector<double> full;
     auto fresh_gamma = [&]() -> int {
+        if (!m->host_gamma_draw)                             // this rank's columns, on the device
+            return sample_gamma_on_device(m, (long long)K * B, 100, 100., m->gamma,
+                                          (long long)K * doc_lo, (long long)K * (doc_lo + Bl));
         full.resize((size_t)K * B);
         trlda_sample_gamma_init(K, B, full.data());
         if (Bl > 0) {
@@ -2694,12 +2715,20 @@ int trlda_model_set_host_gamma_draw(trlda_model *m, int host)
 int trlda_model_sample_gamma(trlda_model *m, int rows, int cols, int passes, double divisor,
                              double *out_dev)
 {
+    return trlda_model_sample_gamma_cols(m, rows, cols, 0, cols, passes, divisor, out_dev);
+}
+
+int trlda_model_sample_gamma_cols(trlda_model *m, int rows, int cols, int col_lo, int col_hi,
+                                  int passes, double divisor, double *out_dev)
+{
     int rc = check_model(m);
     if (rc)
         return rc;
-    if (rows < 0 || cols < 0 || passes < 0 || !out_dev || divisor == 0.)
+    if (rows < 0 || cols < 0 || passes < 0 || !out_dev || divisor == 0. || col_lo < 0 ||
+        col_hi < col_lo || col_hi > cols)
         return fail(TRLDA_ERR_ARG, "bad sample_gamma arguments");
-    return sample_gamma_on_device(m, (long long)rows * cols, passes, divisor, out_dev);
+    return sample_gamma_on_device(m, (long long)rows * cols, passes, divisor, out_dev,
+                                  (long long)rows * col_lo, (long long)rows * col_hi);
 }
 
 int trlda_model_estep_resident(trlda_model *m, const trlda_batch *b, int max_iter, double threshold)

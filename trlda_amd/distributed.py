@@ -95,6 +95,16 @@ class HipEngine(object):
     def gamma_host(self):
         return np.asfortranarray(self.gamma.cpu().numpy().T)
 
+    def draw_gamma(self, total_docs, lo, hi):
+        """gamma0 = columns [lo, hi) of sampleGamma(K, total_docs, 100) / 100 (lda.cpp:135), drawn
+        on the device from the host's libc stream (csrc/rng_kernels.h); the stream advances by
+        the whole matrix, so every rank stays in step."""
+        self.gamma = self.torch.empty(max(hi - lo, 1) * self.K, dtype=self.torch.float64,
+                                      device=self.device)
+        _ffi.check(self.lib.trlda_model_sample_gamma_cols(self.handle, self.K, int(total_docs),
+                                                          int(lo), int(hi), 100, 100.,
+                                                          self.gamma.data_ptr()))
+
 
 class ShardedOnlineLDA(object):
     """OnlineLDA whose ``update_parameters`` runs data-parallel over a process group.
@@ -242,7 +252,14 @@ class ShardedOnlineLDA(object):
                     eng.tr_init(wc, rho, self._eta, coef)
                 for i in range(n_steps):
                     fresh = not (i > 0 and init_gamma)           # onlinelda.cpp:91-95
-                    g0 = self._fresh_gamma(B, lo, hi) if fresh else None
+                    g0 = None
+                    if fresh and hasattr(eng, "draw_gamma"):     # on the device, same stream
+                        if self.gamma_init == "replicated":
+                            eng.draw_gamma(B, lo, hi)
+                        else:
+                            eng.draw_gamma(hi - lo, 0, hi - lo)
+                    elif fresh:
+                        g0 = self._fresh_gamma(B, lo, hi)
                     sstats = eng.estep(batch, g0, max_iter_inference, threshold)
                     sstats = self._all_reduce(sstats)
                     eng.blend(sstats, rho, self._eta, scale)     # onlinelda.cpp:99-100
