@@ -21,7 +21,11 @@
  *     addresses on the model's device (hipMalloc'ed by trlda_dev_alloc or by
  *     anyone else, e.g. a torch tensor's data_ptr()).
  *   - functions taking a trlda_model enqueue work on the model's stream and
- *     return without synchronising unless they copy to host memory.
+ *     return without synchronising unless they copy to host memory.  That stream is a
+ *     non-blocking stream of the model's own until trlda_model_set_stream hands it
+ *     another one: it does NOT order itself against the legacy null stream, so device
+ *     buffers a caller fills or reads on a stream of its own must either be complete
+ *     (trlda_model_synchronize / trlda_dev_synchronize) or that stream be the model's.
  *
  * There is NO CPU fallback behind this header: with no usable GPU every compute
  * entry point returns TRLDA_ERR_NO_DEVICE.

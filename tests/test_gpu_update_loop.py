@@ -387,6 +387,7 @@ err = float(np.max(np.abs(a.lambdas - b.lambdas) / a.lambdas))
 assert err < 1e-10, err
 # the bare all-reduce: world 1 leaves the buffer unchanged
 buf = torch.arange(K * V, dtype=torch.float64, device="cuda")
+torch.cuda.synchronize()                       # the model runs on a stream of its own
 _ffi.check(L.trlda_model_allreduce_sstats(b._handle, comm, C.c_void_p(buf.data_ptr())))
 _ffi.check(L.trlda_model_synchronize(b._handle))
 assert torch.equal(buf.cpu(), torch.arange(K * V, dtype=torch.float64))

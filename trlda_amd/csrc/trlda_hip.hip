@@ -151,7 +151,10 @@ struct trlda_batch {
 struct trlda_model {
     int device = 0;
     int K = 0, V = 0;
-    hipStream_t stream = nullptr;
+    // A stream of the model's own (non-blocking): waits on other streams' events -- a batch's
+    // upload -- then stay on the device; on the legacy null stream the runtime resolves them on
+    // the host, which serialises the host behind the GPU.  trlda_model_set_stream replaces it.
+    hipStream_t stream = nullptr, own_stream = nullptr;
     int sstats_mode = TRLDA_SSTATS_SEGMENTED;
     int doc_threads = 0;
     int doc_kernel = 0;    // TRLDA_DOCS_*
@@ -1812,6 +1815,11 @@ int trlda_model_create(trlda_model **out, int device, int K, int V)
     if (!rc) rc = dev_alloc(&m->psi_sum, 3 * (size_t)K);   // psi(row sums), the row sums, exp(-psi)
     if (!rc) rc = dev_alloc(&m->partial, (size_t)kMaxRowsumBlocks * K);
     if (!rc) rc = dev_alloc(&m->counter, 1);
+    if (!rc && !std::getenv("TRLDA_NULL_STREAM")) {
+        if (hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess)
+            rc = fail(TRLDA_ERR_HIP, "hipStreamCreateWithFlags failed");
+        m->stream = m->own_stream;
+    }
     if (!rc) rc = dev_alloc(&m->rs_full, (size_t)K);
     if (!rc) rc = dev_alloc(&m->rs_static, (size_t)K);
     if (!rc) rc = dev_alloc(&m->upd_partial, (size_t)(kUpdShortBlocks + kUpdLongBlocks) * K);
@@ -1819,8 +1827,9 @@ int trlda_model_create(trlda_model **out, int device, int K, int V)
     // columns of words no batch has touched yet are never read for their value, but the
     // atomic-mode finish multiplies them by 0: keep them finite
     if (!rc && (hipMemset(m->counter, 0, sizeof(unsigned int)) != hipSuccess ||
-                hipMemset(m->eeb, 0, KV * sizeof(double)) != hipSuccess))
-        rc = fail(TRLDA_ERR_HIP, "hipMemset failed");
+                hipMemset(m->eeb, 0, KV * sizeof(double)) != hipSuccess ||
+                hipStreamSynchronize(nullptr) != hipSuccess))    // (the model's stream does not
+        rc = fail(TRLDA_ERR_HIP, "hipMemset failed");            //  wait for the null stream)
     if (rc) {
         trlda_model_destroy(m);
         return rc;
@@ -1850,6 +1859,8 @@ int trlda_model_destroy(trlda_model *m)
         }
         for (auto &e : m->ev_pool)
             (void)hipEventDestroy(e);
+        if (m->own_stream)
+            (void)hipStreamDestroy(m->own_stream);
 
     }
     delete m;
