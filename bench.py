@@ -68,6 +68,9 @@ def parse():
                     help="strong scaling: this many documents per step in all, split over the "
                          "GPUs (BASELINE.json configs[2]: 1600); default 0 = weak scaling, "
                          "--batch documents per GPU")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="every step launches its own preamble kernel instead of having it prepared "
+                         "by extra workgroups of the previous step's document-kernel launch")
     ap.add_argument("--no-update-rates", action="store_true",
                     help="skip the secondary update_parameters figures (N = 1 only)")
     return ap.parse_args()
@@ -168,13 +171,21 @@ def main():
         if collective else None
     RHO, ETA, D_TOTAL = 0.01, 0.3, 1000000
 
+    prefetch = not collective and not args.no_prefetch
+
     def step(i, want_iters=False):
         j = i % args.num_batches
-        # gamma0 is read-only input, gamma the output (lda.cpp:168 copies, we do not)
-        _ffi.check(L.trlda_model_estep_io(model, batches[j].handle, gamma0s[j].data_ptr(),
-                                          gamma.data_ptr(), sstats.data_ptr(), args.max_iter,
-                                          args.threshold,
-                                          iters_dev.data_ptr() if want_iters else None))
+        # gamma0 is read-only input, gamma the output (lda.cpp:168 copies, we do not).  The batch
+        # of the next step is announced: its preamble (row sums + exp(psi(lambda)) on ITS words,
+        # recomputed for every step) is prepared by extra workgroups of this step's document-kernel
+        # launch, on the CUs a 200-document batch leaves idle -- one launch fewer per step,
+        # nothing skipped, nothing shared between steps.  N > 1: the M-step changes lambda every
+        # step, so there is nothing to prepare ahead.
+        nxt = batches[(i + 1) % args.num_batches].handle if prefetch else None
+        _ffi.check(L.trlda_model_estep_io_next(model, batches[j].handle, nxt, gamma0s[j].data_ptr(),
+                                               gamma.data_ptr(), sstats.data_ptr(), args.max_iter,
+                                               args.threshold,
+                                               iters_dev.data_ptr() if want_iters else None))
         if collective:
             dist.all_reduce(sstats)                   # RCCL over xGMI: K x V fp64 sum
             _ffi.check(L.trlda_model_blend(model, lam_prime.data_ptr(), sstats.data_ptr(), RHO, ETA,
@@ -270,6 +281,10 @@ def main():
     kernel_pairs = list(zip(kernel_names, kernel_us))
     if L.trlda_model_last_preamble_fused(model):      # kernels 1 and 2 ran as one launch
         kernel_pairs = [("preamble_fused_kernel", kernel_us[0])] + kernel_pairs[2:]
+        if prefetch:
+            # ... or as workgroups [n_docs, ..) of the previous step's document-kernel launch
+            kernel_pairs = [(doc_kernel + " (documents of this step + preamble workgroups for "
+                             "the next step's batch)", kernel_us[2])] + kernel_pairs[2:]
     roofline = {
         "bound": "hbm", "kernel": "trlda::" + doc_kernel,
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -415,6 +430,9 @@ def main():
                    "exp_elog_beta": "all V words" if args.dense_preamble else
                    "active words of the batch (mean %d of %d)" % (
                        int(np.mean([len(np.unique(c.ids)) for c in csrs])), V),
+                   "preamble": ("prepared by extra workgroups of the previous step's document-kernel "
+                                "launch (trlda_model_estep_io_next)" if prefetch else
+                                "a kernel launch of its own every step"),
                    "parallelism": "dp%d" % world,
                    "exchange": "RCCL all-reduce of K x V fp64 sstats, then the M-step "
                                "(onlinelda.cpp:99-100) that the next step's E-step reads"

@@ -213,6 +213,20 @@ int trlda_model_estep_io(trlda_model *model, const trlda_batch *batch,
                          const double *gamma0_dev, double *gamma_dev, double *sstats_dev,
                          int max_iter, double threshold, int32_t *iters_dev);
 
+/* The same, with the batch of the NEXT E-step announced.  Consecutive E-steps on an unchanged
+ * lambda are independent of each other, and the document kernel of a 200-document batch leaves
+ * 56 of the 256 CUs idle: extra workgroups of this call's document-kernel launch then prepare
+ * `next`'s preamble (src/lda.cpp:172-173: row sums, exp(psi(lambda)) on its words) in alternate
+ * buffers, and the call that later runs `next` starts with its document kernel.  Nothing is
+ * skipped or shared between batches; a wrong or stale announcement (another batch comes, lambda
+ * is written in between) just costs the wasted preparation.  Small tables (K <= 128, documents
+ * of at most 192 words); elsewhere `next` is ignored.  trlda_model_set_prefetch(model, 0) makes
+ * every call prepare its own preamble in a launch of its own. */
+int trlda_model_estep_io_next(trlda_model *model, const trlda_batch *batch, const trlda_batch *next,
+                              const double *gamma0_dev, double *gamma_dev, double *sstats_dev,
+                              int max_iter, double threshold, int32_t *iters_dev);
+int trlda_model_set_prefetch(trlda_model *model, int enabled);
+
 /* Host-pointer convenience around trlda_model_estep (uploads gamma0, downloads
  * gamma / sstats / iters, synchronises). */
 int trlda_model_estep_host(trlda_model *model, const trlda_batch *batch,

@@ -477,3 +477,82 @@ def test_device_gamma_draw_of_a_column_range(hip):
         after = np.empty((2, 2), order="F")
         hip.trlda_sample_gamma(2, 2, 3, after)
         assert np.array_equal(after, after_host), (lo, hi)
+
+
+# --------------------------------------------------------------------------------------------
+# the next batch's preamble as extra workgroups of this call's document-kernel launch
+# --------------------------------------------------------------------------------------------
+def test_announced_next_batch_changes_nothing(hip, oracle):
+    """trlda_model_estep_io_next over a stream of batches -- right announcements, wrong ones, a
+    batch announced and then destroyed, lambda replaced and updated in between, long documents
+    that leave the register tier -- against the same calls without announcements: bitwise the
+    same gamma, statistics and iteration counts; and against the oracle."""
+    import trlda_amd
+    from trlda_amd import _ffi
+    from trlda_amd.documents import CSRDocuments
+    from trlda_amd.utils.synthetic import make_corpus
+    K, V, B, D = 100, 7000, 200, 100000
+    lams = [random_lambda(K, V, 80), random_lambda(K, V, 81)]
+    csrs = [corpus(B, V, seed=800 + i) for i in range(4)]
+    csrs.append(CSRDocuments(*make_corpus(40, V, seed=9, mean_unique=400)))    # beyond 192 words
+    rng = np.random.RandomState(8)
+    g0s = [np.asfortranarray(rng.gamma(100., .01, (K, len(c)))) for c in csrs]
+
+    def run(announce):
+        trlda_amd.seed(5)                                # the update below draws its gamma0
+        m = online_model(K, V, lams[0], D)
+        dev = [m.upload(c) for c in csrs]
+        bufs = []
+        for c, g in zip(csrs, g0s):
+            ptrs = [_ffi.vp() for _ in range(4)]
+            n = K * len(c)
+            for p, nbytes in zip(ptrs, (n * 8, n * 8, K * V * 8, len(c) * 4)):
+                _ffi.check(hip.trlda_dev_alloc(0, nbytes, C.byref(p)))
+            _ffi.check(hip.trlda_dev_upload(0, ptrs[0], g.ctypes.data, n * 8))
+            bufs.append(ptrs)
+        out = []
+
+        def estep(i, nxt):
+            g0d, gd, sd, itd = bufs[i]
+            _ffi.check(hip.trlda_model_estep_io_next(
+                m._handle, dev[i].handle, dev[nxt].handle if (announce and nxt is not None) else None,
+                g0d, gd, sd, 20, 1e-3, itd))
+            _ffi.check(hip.trlda_model_synchronize(m._handle))
+            g = np.empty((K, len(csrs[i])), order="F")
+            s = np.empty((K, V), order="F")
+            it = np.empty(len(csrs[i]), dtype=np.int32)
+            _ffi.check(hip.trlda_dev_download(0, g.ctypes.data, gd, g.nbytes))
+            _ffi.check(hip.trlda_dev_download(0, s.ctypes.data, sd, s.nbytes))
+            _ffi.check(hip.trlda_dev_download(0, it.ctypes.data, itd, it.nbytes))
+            out.append((g, s, it))
+
+        for i, nxt in ((0, 1), (1, 2), (2, 0), (0, 3), (1, 1), (1, 4), (4, 0), (0, None)):
+            estep(i, nxt)                                # (0, 3) then batch 1: a wrong announcement
+        m.lambdas = lams[1]
+        estep(2, 3)
+        estep(3, 0)
+        m.update_parameters(dev[1], max_iter_tr=2)       # lambda written after batch 0 was announced
+        estep(0, 2)
+        estep(2, 1)
+        tmp = m.upload(csrs[3])                          # announce a batch, destroy it, run another
+        g0d, gd, sd, itd = bufs[1]
+        _ffi.check(hip.trlda_model_estep_io_next(m._handle, dev[1].handle,
+                                                 tmp.handle if announce else None, g0d, gd, sd, 20, 1e-3, itd))
+        tmp.close()
+        estep(3, None)
+        out.append((m.lambdas, np.zeros(1), np.zeros(1)))
+        for ptrs in bufs:
+            for p in ptrs:
+                hip.trlda_dev_free(0, p)
+        m.close()
+        return out
+
+    with_next, without = run(True), run(False)
+    for n, (a, b) in enumerate(zip(with_next, without)):
+        for q, (x, y) in enumerate(zip(a, b)):
+            assert np.array_equal(x, y), (n, q, float(np.max(np.abs(x - y))))
+    go, so, ito = oracle.estep(lams[0], .1, csrs[1].indptr, csrs[1].ids, csrs[1].cnts, g0s[1], 20, 1e-3,
+                               nthreads=8)
+    g, s, it = with_next[1]                              # batch 1, prepared under batch 0's launch
+    assert relerr(g, go) < TIGHT_RTOL and np.array_equal(it, ito)
+    assert relerr(s[so > 0], so[so > 0]) < TIGHT_RTOL

@@ -67,6 +67,8 @@ _SIGNATURES = {
     "trlda_model_get_sstats": (C.c_int, [vp, f64p]),
     "trlda_model_estep": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_double, vp]),
     "trlda_model_estep_io": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_double, vp]),
+    "trlda_model_estep_io_next": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_double, vp]),
+    "trlda_model_set_prefetch": (C.c_int, [vp, C.c_int]),
     "trlda_model_estep_host": (C.c_int, [vp, vp, f64p, f64p, C.c_int, C.c_double, vp]),
     "trlda_model_blend": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, C.c_double]),
     "trlda_model_tr_init": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, C.c_int]),

@@ -214,24 +214,26 @@ __global__ __launch_bounds__(T) void exp_elog_beta_kernel(
 // Both kernels this replaces spend most of their few microseconds on launch and on waiting
 // for the row sums.  Against the one-exponential form the results move by a few ulp.
 // ---------------------------------------------------------------------------
+// (vb, nb: this workgroup's index and the number of workgroups doing this job -- the kernel's
+// own grid, or the extra workgroups of a document-kernel launch that prepare the NEXT batch's
+// preamble, estep_docs_reg_kernel; red: T doubles of LDS)
 template <int T>
-__global__ __launch_bounds__(T) void preamble_fused_kernel(
-    int K, int V, int G, int wpb, size_t total, const double *__restrict__ lambda,
-    double *__restrict__ partial /* G x K */, double *__restrict__ u,
-    const int32_t *__restrict__ active /* word ids or nullptr */, int GC,
+__device__ __forceinline__ void preamble_fused_body(
+    int vb, int nb, double *red, int K, int V, int G, int wpb, size_t total,
+    const double *__restrict__ lambda, double *__restrict__ partial /* G x K */,
+    double *__restrict__ u, const int32_t *__restrict__ active /* word ids or nullptr */, int GC,
     const double *__restrict__ carry_rows /* carry_n x K */, int carry_n,
     const double *__restrict__ carry_base /* K or nullptr */, double *__restrict__ carry_out /* GC x K */)
 {
-    __shared__ double red[T];
     const int tid = threadIdx.x;
     // Row sums carried over from the kernel that wrote lambda, still in carry_n block partials
     // (sstats_update_kernel, or the streaming pass of the initial step): the first GC workgroups
     // add up a contiguous range of the rows each -- four threads per topic, eight loads in
     // flight, parts combined in order; workgroup 0 adds the share of the words outside the
     // batch -- and the document workgroups finish the sum over the GC rows (topic_scale_*).
-    if ((int)blockIdx.x < GC) {                      // block-uniform
+    if (vb < GC) {                      // block-uniform
         const int per = (carry_n + GC - 1) / GC;
-        const int r0 = min(carry_n, (int)blockIdx.x * per), r1 = min(carry_n, r0 + per);
+        const int r0 = min(carry_n, vb * per), r1 = min(carry_n, r0 + per);
         const int k = tid % 128, part = tid / 128;   // K <= 128, T = 512: four parts
         double acc[2] = {0.0, 0.0};
         if (k < K) {
@@ -249,17 +251,17 @@ __global__ __launch_bounds__(T) void preamble_fused_kernel(
         __syncthreads();
         if (tid < K) {
             double sum = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
-            if (blockIdx.x == 0 && carry_base)
+            if (vb == 0 && carry_base)
                 sum += carry_base[tid];
-            carry_out[(size_t)blockIdx.x * K + tid] = sum;
+            carry_out[(size_t)vb * K + tid] = sum;
         }
         return;
     }
     const int lead = GC + G;
     // row sums: the first G workgroups, words [b * wpb, (b + 1) * wpb) each (K <= T here),
     // as rowsum_partial_kernel
-    if ((int)blockIdx.x < lead) {                    // block-uniform
-        const int w0 = ((int)blockIdx.x - GC) * wpb;
+    if (vb < lead) {                    // block-uniform
+        const int w0 = (vb - GC) * wpb;
         const int w1 = min(V, w0 + wpb);
         const int slots = T / K;
         const int slot = tid / K;
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(T) void preamble_fused_kernel(
             double sum = red[tid];
             for (int sl = 1; sl < slots; ++sl)
                 sum += red[sl * K + tid];
-            partial[(size_t)((int)blockIdx.x - GC) * K + tid] = sum;
+            partial[(size_t)(vb - GC) * K + tid] = sum;
         }
         return;
     }
@@ -290,8 +292,8 @@ __global__ __launch_bounds__(T) void preamble_fused_kernel(
     // flat index i = a * K + k of (active word a, topic k), two elements per pass so that
     // their loads overlap
     // (total < 2^22 here: 32-bit index arithmetic, a 64-bit division costs as much as psi)
-    const unsigned stride = (gridDim.x - lead) * T, tot = (unsigned)total, Ku = (unsigned)K;
-    for (unsigned i = (blockIdx.x - lead) * T + tid; i < tot; i += 2 * stride) {
+    const unsigned stride = (nb - lead) * T, tot = (unsigned)total, Ku = (unsigned)K;
+    for (unsigned i = (vb - lead) * T + tid; i < tot; i += 2 * stride) {
         const unsigned i2 = i + stride;
         const bool two = i2 < tot;
         const unsigned j2 = two ? i2 : i;
@@ -304,6 +306,18 @@ __global__ __launch_bounds__(T) void preamble_fused_kernel(
         if (two)
             u[idx2] = u2;
     }
+}
+
+template <int T>
+__global__ __launch_bounds__(T) void preamble_fused_kernel(
+    int K, int V, int G, int wpb, size_t total, const double *__restrict__ lambda,
+    double *__restrict__ partial, double *__restrict__ u, const int32_t *__restrict__ active, int GC,
+    const double *__restrict__ carry_rows, int carry_n, const double *__restrict__ carry_base,
+    double *__restrict__ carry_out)
+{
+    __shared__ double red[T];
+    preamble_fused_body<T>((int)blockIdx.x, (int)gridDim.x, red, K, V, G, wpb, total, lambda, partial, u,
+                           active, GC, carry_rows, carry_n, carry_base, carry_out);
 }
 
 // c[k] = exp(-psi(sum_b partial[b][k])), k < K <= 128, G <= 64 block partials, formed by a
@@ -841,10 +855,32 @@ __device__ __forceinline__ double sum8_strided(const double *p)
 // MODE 2: up to 192 words, the words past 128 as rows in LDS (register-lean exp(psi)).  The
 // host picks the variant per batch by its longest document: a launch lasts as long as its
 // longest document, and the variants cost 33 / 36 / 42 us on the bench's documents.
+// The preamble of the NEXT batch as extra workgroups of this launch: a 200-document batch leaves
+// 56 of the 256 CUs idle for the 35 us the document workgroups run, and consecutive E-steps on an
+// unchanged lambda are independent of each other -- so the workgroups past the documents fill
+// exp(psi(lambda)) and the row-sum partials for the batch that the host announced as the next
+// one, into the model's alternate buffers; that batch's E-step then starts with its document
+// kernel.  Everything stays on one stream: no cross-stream hand-off (which was measured and lost).
+struct PreArgs {
+    int n_docs;               // workgroups [0, n_docs) are documents
+    int nb;                   // workgroups [n_docs, n_docs + nb) do the preamble; 0 = none
+    int K, V, G, wpb;
+    size_t total;
+    const double *lambda;
+    double *partial, *u;
+    const int32_t *active;
+};
+
 template <int MODE>
-__global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelArgs a)
+__global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelArgs a, PreArgs pre)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    if ((int)blockIdx.x >= pre.n_docs) {             // block-uniform
+        preamble_fused_body<kRegThreads>((int)blockIdx.x - pre.n_docs, pre.nb, lds, pre.K, pre.V, pre.G,
+                                         pre.wpb, pre.total, pre.lambda, pre.partial, pre.u, pre.active,
+                                         0, nullptr, 0, nullptr, nullptr);
+        return;
+    }
     constexpr bool TAIL = MODE == 2, MID = MODE == 1;
     constexpr int JC = MID ? 18 : 16;                // words per wave: wave w owns [JC w, JC w + JC)
     constexpr int NREG = 8 * JC;                     // words held in registers

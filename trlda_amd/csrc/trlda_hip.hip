@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -127,6 +128,7 @@ struct trlda_batch {
     size_t blob_bytes = 0;
     hipEvent_t ready = nullptr, done = nullptr;
     bool used = false;
+    uint64_t id = 0;            // unique per batch (an address can be reused by a later batch)
     int device = 0;
     int V = 0, B = 0, max_n = 0;
     int64_t nnz = 0;
@@ -155,6 +157,18 @@ struct trlda_model {
     // upload -- then stay on the device; on the legacy null stream the runtime resolves them on
     // the host, which serialises the host behind the GPU.  trlda_model_set_stream replaces it.
     hipStream_t stream = nullptr, own_stream = nullptr;
+    // The preamble of the batch announced as the next one, prepared by extra workgroups of this
+    // call's document-kernel launch (estep_kernels.h, PreArgs) in alternating buffers; valid for
+    // that batch while lambda has not been written (lambda_version).
+    uint64_t lambda_version = 1;
+    double *eeb_pp[2] = {nullptr, nullptr}, *partial_pp[2] = {nullptr, nullptr};
+    struct {
+        bool valid = false;
+        uint64_t batch_id = 0, version = 0;
+        int buf = 0, G = 0;
+        bool dense = false;
+    } prefetch;
+    double *eeb_cur = nullptr;          // the exp E[log beta] buffer of the E-step in flight
     int sstats_mode = TRLDA_SSTATS_SEGMENTED;
     int doc_threads = 0;
     int doc_kernel = 0;    // TRLDA_DOCS_*
@@ -187,6 +201,7 @@ struct trlda_model {
     int64_t d2h_bytes = 0;              // bytes copied to the host through this model (tests)
     bool lambda_exposed = false;        // trlda_model_lambda_dev was handed out: never trust rs_*
     bool pair_gathers = true;           // statistics kernel with two topics per lane (even K > 128)
+    bool prefetch_next = true;          // trlda_model_set_prefetch: honour "next batch" announcements
     // per-batch workspaces, grown on demand
     size_t cap_docs = 0, cap_tw_csr = 0, cap_tw_word = 0;
     double *epg = nullptr, *tw_csr = nullptr, *tw_word = nullptr;
@@ -450,10 +465,11 @@ int combine_rowsums(trlda_model *m, const double *partial, int G, const double *
     return TRLDA_OK;
 }
 
-void invalidate_rowsums(trlda_model *m)
+void invalidate_rowsums(trlda_model *m)               // called wherever lambda is (about to be) written
 {
     m->rs_valid = false;
     m->carry_pending = false;
+    ++m->lambda_version;
 }
 
 // carried row sums still in pieces -> rs_full
@@ -524,7 +540,7 @@ int launch_sstats_update(trlda_model *m, const trlda_batch *b, EstepOut &out)
         return rc;
     hipLaunchKernelGGL(kern, dim3(G_short + G_long), dim3(T), lds, m->stream, K, N, G_short,
                        b->n_long, out.active_only ? b->active : nullptr, b->wptr, b->wdoc,
-                       b->long_words, m->tw_word, m->epg, m->eeb, out.upd);
+                       b->long_words, m->tw_word, m->epg, m->eeb_cur, out.upd);
     HIP_TRY(hipGetLastError());
     out.partial_rows = G_short + G_long;
     return TRLDA_OK;
@@ -560,7 +576,7 @@ int sstats_update_device(trlda_model *m, const trlda_batch *b, EstepOut &out)
 // statistics stage writes; an M-step in it (out.upd.lambda) needs fused_update_available().
 int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepOut &out,
                  int max_iter, double threshold, int32_t *iters_dev,
-                 const double *gamma_in_dev = nullptr)
+                 const double *gamma_in_dev = nullptr, const trlda_batch *next = nullptr)
 {
     using namespace trlda;
     const int K = m->K, V = m->V, B = b->B;
@@ -600,7 +616,22 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
     m->last_preamble_fused = fused;
     if (!fused && carried && (rc = resolve_carry(m)))   // everything else wants one row of sums
         return rc;
-    if (fused) {
+    m->eeb_cur = m->eeb;
+    // this batch's preamble may have been prepared under the previous call's document kernel
+    const bool prefetched = fused && !carried && m->prefetch.valid && m->prefetch.batch_id == b->id &&
+                            m->prefetch.version == m->lambda_version &&
+                            m->prefetch.dense == m->dense_preamble;
+    int cur_buf = -1;
+    if (prefetched) {
+        cur_buf = m->prefetch.buf;
+        m->eeb_cur = m->eeb_pp[cur_buf];
+        partial_in = m->partial_pp[cur_buf];
+        G = m->prefetch.G;
+        if (m->timing && ((rc = stamp(m)) || (rc = stamp(m))))
+            return rc;
+    }
+    m->prefetch.valid = false;
+    if (fused && !prefetched) {
         constexpr int TP = 512;
         int wpb = 0, GC = 0;
         const double *carry_rows = nullptr, *carry_base = nullptr;
@@ -625,7 +656,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         const int lead = G + GC;
         const int GP = lead + (int)std::max<size_t>(1, std::min<size_t>((total + TP - 1) / TP, (size_t)(256 * (1024 / TP) - lead)));
         hipLaunchKernelGGL(preamble_fused_kernel<TP>, dim3(GP), dim3(TP), 0, m->stream, K, V, G, wpb,
-                           total, m->lambda, m->partial, m->eeb, dense ? nullptr : b->active, GC,
+                           total, m->lambda, m->partial, m->eeb_cur, dense ? nullptr : b->active, GC,
                            carry_rows, carry_n, carry_base, m->carry_out);
         HIP_TRY(hipGetLastError());
         if (GC > 0) {
@@ -642,7 +673,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         }
         if (m->timing && ((rc = stamp(m)) || (rc = stamp(m))))
             return rc;
-    } else {
+    } else if (!fused) {
     if (carried) {                                   // (resolved above)
         partial_in = m->rs_full;
         G = 1;
@@ -684,7 +715,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         if (rc)
             return rc;
         hipLaunchKernelGGL(exp_elog_beta_kernel<TE>, dim3(GE), dim3(TE), lds, m->stream, K, total, G,
-                           m->lambda, partial_in, m->psi_sum, m->eeb,
+                           m->lambda, partial_in, m->psi_sum, m->eeb_cur,
                            dense ? nullptr : b->active);
         HIP_TRY(hipGetLastError());
     }
@@ -714,7 +745,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         }
 #endif
         a.indptr = b->indptr; a.ids = b->ids; a.cnts = b->cnts;
-        a.eeb = m->eeb; a.alpha = m->alpha;
+        a.eeb = m->eeb_cur; a.alpha = m->alpha;
         a.gamma = gamma_dev; a.gamma_in = gamma_in_dev ? gamma_in_dev : gamma_dev;
         a.epg = m->epg; a.tw_csr = m->tw_csr;
         a.wrank = b->wrank; a.tw_word = m->tw_word;
@@ -832,7 +863,53 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                                                           : estep_docs_reg_kernel<2>;
             if ((rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), kRegLdsBytes)))
                 return rc;
-            hipLaunchKernelGGL(kern, dim3(n_reg), dim3(kRegThreads), kRegLdsBytes, m->stream, a);
+            // the next batch's preamble as extra workgroups of this launch (PreArgs): when the
+            // caller announced it, it fits the same path, and lambda is not about to change
+            PreArgs pre{};
+            pre.n_docs = n_reg;
+            if (next && fused && n_reg == B && !out.upd.lambda && !atomic && next->V == V &&
+                next->device == m->device && next->B > 0 && next->max_n <= kRegMaxN &&
+                !m->lambda_exposed && m->prefetch_next) {
+                if (!m->eeb_pp[0]) {
+                    for (int i = 0; i < 2 && !rc; ++i) {
+                        rc = dev_alloc(&m->eeb_pp[i], KV);
+                        if (!rc) rc = dev_alloc(&m->partial_pp[i], (size_t)kRowsumBlocks * K);
+                        if (!rc && hipMemsetAsync(m->eeb_pp[i], 0, KV * sizeof(double), m->stream) != hipSuccess)
+                            rc = fail(TRLDA_ERR_HIP, "hipMemsetAsync failed");
+                    }
+                    if (rc)
+                        return rc;
+                }
+                if ((rc = batch_begin(m, next)))
+                    return rc;
+                const int nbuf = cur_buf == 0 ? 1 : 0;
+                const bool dense = m->dense_preamble;
+                pre.K = K; pre.V = V;
+                pre.G = std::min(kRowsumBlocks, std::max(1, V / 32));
+                pre.wpb = (V + pre.G - 1) / pre.G;
+                pre.G = (V + pre.wpb - 1) / pre.wpb;
+                pre.total = dense ? KV : (size_t)K * (size_t)next->n_active;
+                // ~8 elements per thread: at K = 100, B = 200 about 100 fill workgroups beside the 64
+                // that add up the rows -- three rounds on the 56 CUs the documents leave free.
+                // (Letting them start a few microseconds late, so as not to disturb the documents'
+                // staging, was measured: every s_sleep step made the launch longer.)
+                const size_t per = (size_t)kRegThreads * 8;
+                pre.nb = pre.G + (int)std::max<size_t>(1, std::min<size_t>((pre.total + per - 1) / per, 448));
+                pre.lambda = m->lambda;
+                pre.partial = m->partial_pp[nbuf];
+                pre.u = m->eeb_pp[nbuf];
+                pre.active = dense ? nullptr : next->active;
+                m->prefetch.valid = true;
+                m->prefetch.batch_id = next->id;
+                m->prefetch.version = m->lambda_version;
+                m->prefetch.buf = nbuf;
+                m->prefetch.G = pre.G;
+                m->prefetch.dense = dense;
+            }
+            hipLaunchKernelGGL(kern, dim3(n_reg + pre.nb), dim3(kRegThreads), kRegLdsBytes, m->stream, a,
+                               pre);
+            if (pre.nb > 0 && (rc = batch_end(m, next)))
+                return rc;
             HIP_TRY(hipGetLastError());
         }
     }
@@ -845,7 +922,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         size_t blocks = (KV / 2 + kDenseThreads * 4 - 1) / (kDenseThreads * 4);
         int GF = (int)std::max<size_t>(1, std::min<size_t>(blocks, 256 * 8));
         hipLaunchKernelGGL((elementwise_stream_kernel<kDenseThreads, FinishOp>), dim3(GF),
-                           dim3(kDenseThreads), 0, m->stream, KV, FinishOp{m->eeb, sstats_dev});
+                           dim3(kDenseThreads), 0, m->stream, KV, FinishOp{m->eeb_cur, sstats_dev});
     } else if (fused_update_available(m)) {
         rc = sstats_update_device(m, b, out);
         if (rc)
@@ -864,7 +941,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
             return rc;                                                                     \
         hipLaunchKernelGGL(kern, dim3(G_short + b->n_long), dim3(TS), lds, m->stream, K, V, \
                            G_short, b->wptr, b->wdoc, b->long_words, m->tw_word, m->epg,   \
-                           m->eeb, sstats_dev);                                            \
+                           m->eeb_cur, sstats_dev);                                        \
     } while (0)
         if (K >= 256)
             TRLDA_LAUNCH_SSTATS(512);
@@ -1659,6 +1736,10 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     });
 
     trlda_batch *b = new trlda_batch();
+    {
+        static std::atomic<uint64_t> next_id{1};
+        b->id = next_id.fetch_add(1);
+    }
     b->device = device; b->V = V; b->B = B; b->nnz = nnz; b->max_n = max_n;
     b->n_active = n_active; b->n_long = n_long;
     b->sorted_len.resize(Bz);
@@ -1859,6 +1940,9 @@ int trlda_model_destroy(trlda_model *m)
         }
         for (auto &e : m->ev_pool)
             (void)hipEventDestroy(e);
+        for (int i = 0; i < 2; ++i) {
+            (void)hipFree(m->eeb_pp[i]); (void)hipFree(m->partial_pp[i]);
+        }
         if (m->own_stream)
             (void)hipStreamDestroy(m->own_stream);
 
@@ -2029,6 +2113,28 @@ int trlda_model_estep_io(trlda_model *m, const trlda_batch *b, const double *gam
     if (!b || !sstats_dev || (b->B > 0 && (!gamma_dev || !gamma0_dev)))
         return fail(TRLDA_ERR_ARG, "NULL batch / gamma / sstats");
     return estep_device(m, b, gamma_dev, sstats_dev, max_iter, threshold, iters_dev, gamma0_dev);
+}
+
+int trlda_model_estep_io_next(trlda_model *m, const trlda_batch *b, const trlda_batch *next,
+                              const double *gamma0_dev, double *gamma_dev, double *sstats_dev,
+                              int max_iter, double threshold, int32_t *iters_dev)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!b || !sstats_dev || (b->B > 0 && (!gamma_dev || !gamma0_dev)))
+        return fail(TRLDA_ERR_ARG, "NULL batch / gamma / sstats");
+    EstepOut out(sstats_dev);
+    return estep_device(m, b, gamma_dev, out, max_iter, threshold, iters_dev, gamma0_dev, next);
+}
+
+int trlda_model_set_prefetch(trlda_model *m, int enabled)
+{
+    if (!m)
+        return fail(TRLDA_ERR_ARG, "model is NULL");
+    m->prefetch_next = enabled != 0;
+    m->prefetch.valid = false;
+    return TRLDA_OK;
 }
 
 int trlda_model_estep_host(trlda_model *m, const trlda_batch *b, double *gamma, double *sstats,
