@@ -16,6 +16,11 @@ nothing is cached across steps (lambda's preamble is recomputed every step, as i
 reference).  Weak scaling by default: 200 documents per GPU per step; `--global-batch 1600`
 splits a fixed 1600-document step over the GPUs instead (BASELINE.json configs[2], "strong").
 
+N = 1: every step announces the batch of the next step (trlda_model_estep_io_next), whose preamble
+is then prepared by extra workgroups of this step's document-kernel launch, on the CUs that a
+200-document batch leaves idle: one launch fewer per step, every step's preamble still computed
+from lambda for its own words (`--no-prefetch`: a launch of its own).
+
 Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel
 (estep_docs_kernel) from HIP events on the launch stream; `cpu_baseline` is the reference's
 own C++ core (oracle/_ref, kind "reference") or, when that was not built, the plain-C port
@@ -257,6 +262,13 @@ def main():
     all_e, all_d = zip(*[algorithmic_bytes(K, V, c.indptr)[:2] for c in csrs])
     estep_bytes, docs_bytes = float(np.mean(all_e)), float(np.mean(all_d))
     docs_us = kernel_us[2]
+    # with the next batch announced, the document-kernel launch also carries that batch's
+    # preamble: 8 K V (row sums: lambda read once) + 16 K n_active (lambda in, exp(psi) out)
+    pre_bytes = 0.0
+    if prefetch and L.trlda_model_last_preamble_fused(model):
+        pre_bytes = float(np.mean([8. * K * V + 16. * K * len(np.unique(c.ids)) for c in csrs]))
+    docs_only_bytes = docs_bytes
+    docs_bytes = docs_bytes + pre_bytes
     achieved = docs_bytes / (docs_us * 1e-6) / 1e9 if docs_us > 0 else 0.0
     traffic, traffic_src = None, None
     # the document stage under the name rocprofv3 lists it by (profiles/*_kernel_stats.csv)
@@ -291,6 +303,7 @@ def main():
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
         "traffic_source": traffic_src,
         "algorithmic_bytes_per_launch": docs_bytes,
+        "algorithmic_bytes_split": {"documents": docs_only_bytes, "next_batch_preamble": pre_bytes},
         "avg_launch_us": round(docs_us, 2),
         "method": "HIP events on the launch stream around every launch in a replay of the timed "
                   "steps, minus the events' own share (replay time over timed time, per launch)",
