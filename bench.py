@@ -130,6 +130,37 @@ def main():
             dist.init_process_group("nccl", device_id=device)
     collective = world > 1 or force_dist
 
+    # The exchange through the C ABI: a communicator of our own (ncclCommInitRank on the id that
+    # rank 0 broadcasts), handed to trlda_model_allreduce_sstats, which enqueues ncclAllReduce on
+    # the model's stream -- the same collective as torch.distributed.all_reduce without ~9 us of
+    # framework per call (profiles/r02_allreduce_world1.txt).  Checked against torch's result
+    # once; any failure falls back to torch.distributed.
+    rccl_comm = None
+    if collective and os.environ.get("TRLDA_BENCH_TORCH_ALLREDUCE") != "1":
+        try:
+            rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
+            class UniqueId(C.Structure):
+                _fields_ = [("internal", C.c_char * 128)]
+
+            rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+            rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+            uid = UniqueId()
+            if rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
+                raise RuntimeError("ncclGetUniqueId failed")
+            raw = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone().to(device)
+            dist.broadcast(raw, src=0)
+            C.memmove(C.byref(uid), bytes(raw.cpu().numpy().tobytes()), 128)
+            comm = C.c_void_p()
+            if rccl.ncclCommInitRank(C.byref(comm), world, uid, rank) != 0:
+                raise RuntimeError("ncclCommInitRank failed")
+            rccl_comm = comm
+        except Exception as exc:                      # noqa: BLE001
+            if rank == 0:
+                print("bench: own RCCL communicator unavailable (%s); using torch.distributed" % exc,
+                      file=sys.stderr)
+            rccl_comm = None
+
     K, V = args.topics, args.words
     strong = args.global_batch > 0
     if strong:
@@ -155,6 +186,18 @@ def main():
     _ffi.check(L.trlda_model_set_doc_threads(model, args.doc_threads))
     _ffi.check(L.trlda_model_set_dense_preamble(model, int(args.dense_preamble)))
     _ffi.check(L.trlda_model_set_split_preamble(model, int(args.split_preamble)))
+
+    if rccl_comm is not None:                         # one check against torch's collective
+        probe = torch.ones(KV, dtype=torch.float64, device=device) * (rank + 1)
+        want = probe.clone()
+        dist.all_reduce(want)
+        rc = L.trlda_model_allreduce_sstats(model, rccl_comm, C.c_void_p(probe.data_ptr()))
+        torch.cuda.synchronize()
+        ok = torch.tensor([int(rc == 0 and bool(torch.equal(probe, want)))], device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) != 1:
+            rccl_comm = None                          # every rank falls back together
+        del probe, want
 
     batches, csrs, gamma0s = [], [], []
     for i in range(args.num_batches):
@@ -191,8 +234,10 @@ def main():
                                                gamma.data_ptr(), sstats.data_ptr(), args.max_iter,
                                                args.threshold,
                                                iters_dev.data_ptr() if want_iters else None))
-        if collective:
-            dist.all_reduce(sstats)                   # RCCL over xGMI: K x V fp64 sum
+        if collective and rccl_comm is not None:      # RCCL over xGMI: K x V fp64 sum
+            _ffi.check(L.trlda_model_allreduce_sstats(model, rccl_comm, C.c_void_p(sstats.data_ptr())))
+        elif collective:
+            dist.all_reduce(sstats)
             _ffi.check(L.trlda_model_blend(model, lam_prime.data_ptr(), sstats.data_ptr(), RHO, ETA,
                                            D_TOTAL / float(B * world)))
 
@@ -447,6 +492,8 @@ def main():
                                 "launch (trlda_model_estep_io_next)" if prefetch else
                                 "a kernel launch of its own every step"),
                    "parallelism": "dp%d" % world,
+                   "exchange_via": ("trlda_model_allreduce_sstats (own ncclComm_t)" if rccl_comm is not None
+                                    else "torch.distributed.all_reduce") if collective else None,
                    "exchange": "RCCL all-reduce of K x V fp64 sstats, then the M-step "
                                "(onlinelda.cpp:99-100) that the next step's E-step reads"
                    if collective else "none"},

@@ -26,9 +26,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "psi.h"
+
 namespace trlda {
 
-constexpr int kRngSegment = 256;      // draws per thread
+// draws per thread: 256 for large requests, 64 for small ones (a thread's draws are serial --
+// ~130 instructions each at ~8.6 cycles for a wave that has little company -- so a request of
+// 2 * 10^6 draws wants 31 000 threads, not 7 800)
+constexpr int kRngSegment = 256;
+constexpr int kRngSegmentSmall = 64;
+constexpr long long kRngSmallDraws = (long long)1 << 25;
 constexpr int kRngLevels = 8;         // 16^8 segments: more than any table needs
 constexpr int kRngThreads = 256;
 
@@ -62,7 +69,7 @@ __global__ __launch_bounds__(T) void window_level_kernel(long long S, long long 
 // positions [pos_lo, pos_hi) of the stream (a whole number of passes of `total` elements);
 // vbuf[pos - pos_lo] = log|u| for the elements [e_lo, e_hi) of every pass (a data-parallel rank
 // needs its own documents' columns only; segments that hold none of them do nothing)
-template <int T>
+template <int T, int L>
 __global__ __launch_bounds__(T) void draw_log_kernel(long long S, long long seg_lo, long long seg_hi,
                                                      long long pos_lo, long long pos_hi, long long total,
                                                      long long e_lo, long long e_hi,
@@ -73,14 +80,14 @@ __global__ __launch_bounds__(T) void draw_log_kernel(long long S, long long seg_
     const long long s = seg_lo + (long long)blockIdx.x * T + threadIdx.x;
     if (s >= seg_hi)
         return;
-    const long long first = s * kRngSegment;
-    if (first >= pos_hi || first + kRngSegment <= pos_lo)
+    const long long first = s * L;
+    if (first >= pos_hi || first + L <= pos_lo)
         return;
     {
         // elements covered by the segment (it may wrap into the next pass once: total >= 1)
-        const long long a = first % total, z = a + kRngSegment;   // [a, z) modulo total
+        const long long a = first % total, z = a + L;             // [a, z) modulo total
         const bool hit = z <= total ? (a < e_hi && z > e_lo)
-                                    : (a < e_hi || (z - total) > e_lo || kRngSegment >= total);
+                                    : (a < e_hi || (z - total) > e_lo || L >= total);
         if (!hit)
             return;
     }
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(T) void draw_log_kernel(long long S, long long seg_
     for (int j = 0; j < 31; ++j)
         x[j * T + threadIdx.x] = win[(size_t)j * S + s];
     int f = 0, b = 28;
-    for (int q = 0; q < kRngSegment; ++q) {
+    for (int q = 0; q < L; ++q) {
         const uint32_t v = x[f * T + threadIdx.x] + x[b * T + threadIdx.x];
         x[f * T + threadIdx.x] = v;
         f = f == 30 ? 0 : f + 1;
@@ -96,8 +103,11 @@ __global__ __launch_bounds__(T) void draw_log_kernel(long long S, long long seg_
         const long long pos = first + q;
         const long long el = pos % total;
         if (pos >= pos_lo && pos < pos_hi && el >= e_lo && el < e_hi) {
+            // the host's expression, operation for operation (an IEEE division: the same u)
             const double u = -1.0 + 2.0 * (double)(v >> 1) / (double)2147483647;
-            vbuf[pos - pos_lo] = log(fabs(u));
+            // |u| is a normal number in [4.6e-10, 1]: the short logarithm of psi.h (within an ulp
+            // of the library's, a third of its instructions)
+            vbuf[pos - pos_lo] = log_normal(fabs(u));
         }
     }
 }

@@ -21,6 +21,7 @@
 #include <numeric>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -1475,24 +1476,27 @@ void trlda_sample_gamma_init(int m, int n, double *out)
 namespace {
 
 // M[l][d - 1] = A^(d 16^l L), l < kRngLevels, d = 1 .. 15 (31 x 31 words each), computed once
-const std::vector<uint32_t> &rng_level_matrices()
+// per segment length L
+const std::vector<uint32_t> &rng_level_matrices(int L)
 {
-    static std::vector<uint32_t> mats;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        mats.resize((size_t)trlda::kRngLevels * 15 * 961);
-        JumpMatrix one = jump_power((uint64_t)trlda::kRngSegment), cur, tmp;
-        for (int l = 0; l < trlda::kRngLevels; ++l) {
-            cur = one;
-            for (int d = 1; d <= 15; ++d) {
-                std::memcpy(mats.data() + ((size_t)l * 15 + (d - 1)) * 961, cur.a, sizeof(cur.a));
-                jump_multiply(cur, one, tmp);        // A^((d + 1) 16^l L)
-                cur = tmp;
-            }
-            one = cur;                               // A^(16^(l + 1) L)
+    static std::mutex mu;
+    static std::map<int, std::vector<uint32_t>> all;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = all.find(L);
+    if (it != all.end())
+        return it->second;
+    std::vector<uint32_t> mats((size_t)trlda::kRngLevels * 15 * 961);
+    JumpMatrix one = jump_power((uint64_t)L), cur, tmp;
+    for (int l = 0; l < trlda::kRngLevels; ++l) {
+        cur = one;
+        for (int d = 1; d <= 15; ++d) {
+            std::memcpy(mats.data() + ((size_t)l * 15 + (d - 1)) * 961, cur.a, sizeof(cur.a));
+            jump_multiply(cur, one, tmp);            // A^((d + 1) 16^l L)
+            cur = tmp;
         }
-    });
-    return mats;
+        one = cur;                                   // A^(16^(l + 1) L)
+    }
+    return all.emplace(L, std::move(mats)).first->second;
 }
 
 struct RngSeedWindow {
@@ -1505,16 +1509,16 @@ __global__ void window_seed_kernel(long long S, RngSeedWindow w0, uint32_t *win)
         win[(size_t)threadIdx.x * S] = w0.w[threadIdx.x];
 }
 
-// the matrices live on the device once per (process, device)
-int rng_device_matrices(int device, const uint32_t **out)
+// the matrices live on the device once per (process, device, segment length)
+int rng_device_matrices(int device, int L, const uint32_t **out)
 {
     static std::mutex mu;
-    static std::map<std::pair<pid_t, int>, uint32_t *> all;
+    static std::map<std::tuple<pid_t, int, int>, uint32_t *> all;
     std::lock_guard<std::mutex> lock(mu);
-    auto key = std::make_pair(getpid(), device);
+    auto key = std::make_tuple(getpid(), device, L);
     auto it = all.find(key);
     if (it == all.end()) {
-        const std::vector<uint32_t> &h = rng_level_matrices();
+        const std::vector<uint32_t> &h = rng_level_matrices(L);
         uint32_t *d = nullptr;
         int rc = dev_alloc(&d, h.size());
         if (rc)
@@ -1535,11 +1539,12 @@ int sample_gamma_on_device(trlda_model *m, long long total, int passes, double d
         return TRLDA_OK;
     if (e_hi < 0)
         e_hi = total;
-    constexpr int L = trlda::kRngSegment, T = trlda::kRngThreads;
+    constexpr int T = trlda::kRngThreads;
     const long long draws = total * passes;
+    const int L = draws < trlda::kRngSmallDraws ? trlda::kRngSegmentSmall : trlda::kRngSegment;
     const long long S = (draws + L - 1) / L;
     const uint32_t *mats = nullptr;
-    int rc = rng_device_matrices(m->device, &mats);
+    int rc = rng_device_matrices(m->device, L, &mats);
     if (!rc) rc = grow(&m->rng_win, &m->cap_rng_win, (size_t)31 * (size_t)S);
     // log|u| of a group of passes: at most ~1 GB at a time
     const long long group = std::max<long long>(1, std::min<long long>(passes, ((long long)1 << 27) / total));
@@ -1561,9 +1566,15 @@ int sample_gamma_on_device(trlda_model *m, long long total, int passes, double d
         const long long p1 = std::min<long long>(passes, p0 + group);
         const long long pos_lo = p0 * total, pos_hi = p1 * total;
         const long long seg_lo = pos_lo / L, seg_hi = (pos_hi + L - 1) / L;
-        hipLaunchKernelGGL(trlda::draw_log_kernel<T>, dim3((unsigned)((seg_hi - seg_lo + T - 1) / T)),
-                           dim3(T), 0, m->stream, S, seg_lo, std::min(S, seg_hi), pos_lo, pos_hi, total,
-                           e_lo, e_hi, m->rng_win, m->rng_vbuf);
+        const dim3 dgrid((unsigned)((seg_hi - seg_lo + T - 1) / T));
+        if (L == trlda::kRngSegment)
+            hipLaunchKernelGGL((trlda::draw_log_kernel<T, trlda::kRngSegment>), dgrid, dim3(T), 0,
+                               m->stream, S, seg_lo, std::min(S, seg_hi), pos_lo, pos_hi, total, e_lo,
+                               e_hi, m->rng_win, m->rng_vbuf);
+        else
+            hipLaunchKernelGGL((trlda::draw_log_kernel<T, trlda::kRngSegmentSmall>), dgrid, dim3(T), 0,
+                               m->stream, S, seg_lo, std::min(S, seg_hi), pos_lo, pos_hi, total, e_lo,
+                               e_hi, m->rng_win, m->rng_vbuf);
         if (e_hi > e_lo)
             hipLaunchKernelGGL(trlda::gamma_sum_kernel<T>,
                                dim3((unsigned)((e_hi - e_lo + T - 1) / T)), dim3(T), 0, m->stream, total,
