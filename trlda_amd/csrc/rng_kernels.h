@@ -39,7 +39,13 @@ constexpr long long kRngSmallDraws = (long long)1 << 25;
 constexpr int kRngLevels = 8;         // 16^8 segments: more than any table needs
 constexpr int kRngThreads = 256;
 
-// windows are stored word-major: win[j * S + s], j < 31
+// windows are stored word-major: win[j * S + s], j < 31.  Two forms of one level:
+//   window_level_kernel       one thread per window (961 serial multiply-adds: fine when there
+//                             are hundreds of thousands of windows to keep the chip busy)
+//   window_level_coop_kernel  one window per 32 lanes, lane i < 31 forms word i of M w (31
+//                             multiply-adds): a few hundred cycles of latency per level, for
+//                             requests with few windows (8.2 against 14.3 us per level at 31 000
+//                             windows; 98 against 35 us at 800 000)
 template <int T>
 __global__ __launch_bounds__(T) void window_level_kernel(long long S, long long lo, long long hi,
                                                          long long unit /* 16^level */,
@@ -66,9 +72,32 @@ __global__ __launch_bounds__(T) void window_level_kernel(long long S, long long 
     }
 }
 
+template <int T>
+__global__ __launch_bounds__(T) void window_level_coop_kernel(long long S, long long lo, long long hi,
+                                                              long long unit,
+                                                              const uint32_t *__restrict__ mats,
+                                                              uint32_t *__restrict__ win)
+{
+    const long long s = lo + ((long long)blockIdx.x * T + threadIdx.x) / 32;
+    const int i = threadIdx.x & 31;
+    if (s >= hi || i >= 31)
+        return;
+    const int d = (int)(s / unit);
+    const long long r = s - (long long)d * unit;
+    const uint32_t *M = mats + (size_t)(d - 1) * 961 + (size_t)i * 31;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < 31; ++j)
+        acc += M[j] * win[(size_t)j * S + r];
+    win[(size_t)i * S + s] = acc;
+}
+
 // positions [pos_lo, pos_hi) of the stream (a whole number of passes of `total` elements);
-// vbuf[pos - pos_lo] = log|u| for the elements [e_lo, e_hi) of every pass (a data-parallel rank
-// needs its own documents' columns only; segments that hold none of them do nothing)
+// vbuf[pos - pos_lo] = log|u|.  A data-parallel rank needs the elements [e_lo, e_hi) of every
+// pass only (its own documents' columns): segments that hold none of them do nothing (the
+// others write all of their draws: vbuf is scratch).  A thread's draws are consecutive
+// positions, so a wave's stores would be 64 separate 8-byte writes 8 L bytes apart: eight
+// draws at a time go through an LDS tile and leave as 64-byte runs, eight per store instruction.
 template <int T, int L>
 __global__ __launch_bounds__(T) void draw_log_kernel(long long S, long long seg_lo, long long seg_hi,
                                                      long long pos_lo, long long pos_hi, long long total,
@@ -77,37 +106,50 @@ __global__ __launch_bounds__(T) void draw_log_kernel(long long S, long long seg_
                                                      double *__restrict__ vbuf)
 {
     __shared__ uint32_t x[31 * T];
+    __shared__ double tile[T * 9];                   // per thread 8 values, rows padded to 9
+    const int lane = threadIdx.x & 63;
     const long long s = seg_lo + (long long)blockIdx.x * T + threadIdx.x;
-    if (s >= seg_hi)
-        return;
+    const long long s_wave = s - lane;               // segment of the wave's lane 0
+    bool on = s < seg_hi;
     const long long first = s * L;
-    if (first >= pos_hi || first + L <= pos_lo)
-        return;
-    {
+    on = on && first < pos_hi && first + L > pos_lo;
+    if (on) {
         // elements covered by the segment (it may wrap into the next pass once: total >= 1)
         const long long a = first % total, z = a + L;             // [a, z) modulo total
-        const bool hit = z <= total ? (a < e_hi && z > e_lo)
-                                    : (a < e_hi || (z - total) > e_lo || L >= total);
-        if (!hit)
-            return;
+        on = z <= total ? (a < e_hi && z > e_lo)
+                        : (a < e_hi || (z - total) > e_lo || L >= total);
     }
+    const unsigned long long onmask = __ballot(on);
+    if (onmask == 0)                                 // the whole wave has nothing to do
+        return;
 #pragma unroll
     for (int j = 0; j < 31; ++j)
-        x[j * T + threadIdx.x] = win[(size_t)j * S + s];
+        x[j * T + threadIdx.x] = on ? win[(size_t)j * S + s] : 0u;
+    double *mine = tile + (size_t)threadIdx.x * 9;
+    const double *wave_tile = tile + (size_t)(threadIdx.x - lane) * 9;
     int f = 0, b = 28;
-    for (int q = 0; q < L; ++q) {
-        const uint32_t v = x[f * T + threadIdx.x] + x[b * T + threadIdx.x];
-        x[f * T + threadIdx.x] = v;
-        f = f == 30 ? 0 : f + 1;
-        b = b == 30 ? 0 : b + 1;
-        const long long pos = first + q;
-        const long long el = pos % total;
-        if (pos >= pos_lo && pos < pos_hi && el >= e_lo && el < e_hi) {
-            // the host's expression, operation for operation (an IEEE division: the same u)
-            const double u = -1.0 + 2.0 * (double)(v >> 1) / (double)2147483647;
+    for (int q0 = 0; q0 < L; q0 += 8) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint32_t v = x[f * T + threadIdx.x] + x[b * T + threadIdx.x];
+            x[f * T + threadIdx.x] = v;
+            f = f == 30 ? 0 : f + 1;
+            b = b == 30 ? 0 : b + 1;
+            // the host's expression, operation for operation (an IEEE division: the same u);
             // |u| is a normal number in [4.6e-10, 1]: the short logarithm of psi.h (within an ulp
             // of the library's, a third of its instructions)
-            vbuf[pos - pos_lo] = log_normal(fabs(u));
+            const double u = -1.0 + 2.0 * (double)(v >> 1) / (double)2147483647;
+            mine[q] = log_normal(fabs(u));
+        }
+        // (LDS traffic of one wave is in order: no barrier between the writes and these reads)
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int src = 8 * g + (lane >> 3);     // which thread's run, which of its 8 values
+            const int o = lane & 7;
+            const long long pos = (s_wave + src) * L + q0 + o;
+            const bool src_on = (onmask >> src) & 1;
+            if (src_on && pos >= pos_lo && pos < pos_hi)
+                vbuf[pos - pos_lo] = wave_tile[src * 9 + o];
         }
     }
 }

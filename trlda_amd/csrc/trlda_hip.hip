@@ -1557,8 +1557,14 @@ int sample_gamma_on_device(trlda_model *m, long long total, int passes, double d
     long long unit = 1;
     for (int l = 0; l < trlda::kRngLevels && unit < S; ++l, unit *= 16) {
         const long long lo = unit, hi = std::min<long long>(S, unit * 16);
-        hipLaunchKernelGGL(trlda::window_level_kernel<T>, dim3((unsigned)((hi - lo + T - 1) / T)), dim3(T),
-                           0, m->stream, S, lo, hi, unit, mats + (size_t)l * 15 * 961, m->rng_win);
+        if (S < 200000)
+            hipLaunchKernelGGL(trlda::window_level_coop_kernel<T>,
+                               dim3((unsigned)(((hi - lo) * 32 + T - 1) / T)), dim3(T), 0, m->stream, S,
+                               lo, hi, unit, mats + (size_t)l * 15 * 961, m->rng_win);
+        else
+            hipLaunchKernelGGL(trlda::window_level_kernel<T>, dim3((unsigned)((hi - lo + T - 1) / T)),
+                               dim3(T), 0, m->stream, S, lo, hi, unit, mats + (size_t)l * 15 * 961,
+                               m->rng_win);
     }
     if (unit < S)
         return fail(TRLDA_ERR_ARG, "sampleGamma request too large for the device generator");
