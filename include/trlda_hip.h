@@ -328,6 +328,56 @@ int trlda_model_online_update_multi(trlda_model *model, const trlda_batch *shard
                                     double tau, double rho, int init_gamma, double threshold,
                                     int *update_count, double *rho_out);
 
+/* ---- multi-GPU with FACTOR exchange: an all-gather of 8 (K + n_d) bytes per document --------
+ *
+ * The same reduction point (src/lda.cpp:211-217), without moving K x V numbers.  lambda is
+ * replicated, and sstats[k, w] = expElogbeta[k, w] * sum_{(d, w)} (cnt_dw / phinorm_dw) *
+ * expElogtheta[d, k] (src/lda.cpp:207-217): a rank only has to publish, per document, the K
+ * numbers expElogtheta[d, :] and one weight per (document, word) entry.  Every rank holds the
+ * WHOLE mini-batch (`batch`: word lists, counts -- a few hundred kB) and iterates the documents
+ * [doc_cuts[rank], doc_cuts[rank + 1]) of it (`shard`, a batch made of exactly those
+ * documents); one ncclAllGather of equal slots follows the document stage, and every rank forms
+ * the statistics of the whole mini-batch with the single-GPU kernel -- which adds the entries of
+ * a word in document order, the reference's serial order.  Every rank performs the same
+ * additions in the same order on the same numbers: the replicas of lambda stay bitwise equal
+ * without a broadcast, and they equal the one-GPU result for the whole mini-batch up to the
+ * rounding of the document-kernel variant a shard selects (~1e-15; bitwise when the shards and
+ * the whole mini-batch select the same variant) -- no dependence on the rank count through an
+ * order of summation.  The fused M-step with carried row sums applies unchanged.  Bytes received per rank and E-step: (world - 1) * slot * 8, slot ~
+ * max_r(docs_r) * K + max_r(nnz_r): 2.1 MB at K = 100, 8 x 200 documents (the K x V all-reduce
+ * moves 9.8 MB per rank); 17 MB at K = 500, 8 x 512 documents (700 MB).  Not the better choice
+ * when documents outnumber words (BatchLDA on 8 x 12 500 documents, V = 50 000): compare
+ * world * slot with 2 * K * V.
+ *
+ * `rccl_comm` as above (ncclAllGather, in place, on the model's stream); world = 1 needs none.
+ * A host with a transport of its own installs trlda_model_set_allgather instead: the hook is
+ * called with this rank's slot (`send` = recv + rank * count), the buffer of world * count
+ * doubles and the model's hipStream_t, and must leave every rank's slot in `recv` in stream
+ * order; a non-zero return fails the call. */
+typedef int (*trlda_allgather_fn)(void *ctx, const void *send_dev, void *recv_dev,
+                                  size_t count_f64, void *hip_stream);
+int trlda_model_set_allgather(trlda_model *model, trlda_allgather_fn fn, void *ctx);
+/* OnlineLDA::updateParameters (src/onlinelda.cpp:53-111, 177-179) over `world` ranks: the
+ * arguments of trlda_model_online_update, which it equals for world = 1.  gamma0 is this rank's
+ * columns of the whole mini-batch's draw (the stream advances by all of it on every rank). */
+int trlda_model_online_update_dp(trlda_model *model, const trlda_batch *batch,
+                                 const trlda_batch *shard, void *rccl_comm, int rank, int world,
+                                 const int32_t *doc_cuts /* world + 1 */, int num_documents,
+                                 double eta, int max_iter_tr, int max_iter_inference, double kappa,
+                                 double tau, double rho, int init_gamma, double threshold,
+                                 int *update_count, double *rho_out);
+/* One E-step (src/lda.cpp:160-220) over `world` ranks: gamma0_dev / gamma_dev hold this rank's
+ * K x docs_r columns (gamma0_dev NULL: in place); sstats_dev (K x V, may be NULL with mstep)
+ * receives the statistics of the whole mini-batch; iters_dev this rank's iteration counts or
+ * NULL.  mstep != 0: the statistics kernel also writes lambda = (1 - rho) lambda' + rho (eta +
+ * scale * sstats) for every word (src/onlinelda.cpp:99-100; lambda_prime_dev NULL: lambda'
+ * is the current lambda) and leaves the row sums of the new lambda for the next E-step. */
+int trlda_model_estep_dp(trlda_model *model, const trlda_batch *batch, const trlda_batch *shard,
+                         void *rccl_comm, int rank, int world, const int32_t *doc_cuts,
+                         const double *gamma0_dev, double *gamma_dev, double *sstats_dev,
+                         int max_iter, double threshold, int32_t *iters_dev, int mstep,
+                         const double *lambda_prime_dev, double rho, double eta, double scale);
+
 /* ---- update loop: what stays on the device between its steps ----------------------------
  *
  * Inside one OnlineLDA update lambda' and rho are fixed and a word outside the mini-batch has

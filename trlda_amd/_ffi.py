@@ -90,6 +90,14 @@ _SIGNATURES = {
                                                   C.c_int, C.c_int, C.c_double, C.c_double,
                                                   C.c_double, C.c_int, C.c_double,
                                                   C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "trlda_model_set_allgather": (C.c_int, [vp, vp, vp]),
+    "trlda_model_online_update_dp": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int,
+                                               C.POINTER(C.c_int32), C.c_int, C.c_double, C.c_int,
+                                               C.c_int, C.c_double, C.c_double, C.c_double, C.c_int,
+                                               C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "trlda_model_estep_dp": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(C.c_int32), vp, vp,
+                                       vp, C.c_int, C.c_double, vp, C.c_int, vp, C.c_double,
+                                       C.c_double, C.c_double]),
     "trlda_model_set_fused_update": (C.c_int, [vp, C.c_int]),
     "trlda_model_set_carry_rowsums": (C.c_int, [vp, C.c_int]),
     "trlda_model_set_keep_sstats": (C.c_int, [vp, C.c_int]),

@@ -12,7 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 LIB_PATH = os.path.join(_PKG, "libtrlda_hip.so")
 SOURCES = ["trlda_hip.hip"]
-HEADERS = ["estep_kernels.h", "estep_wide.h", "elbo_kernels.h", "stream_kernels.h", "eb_kernels.h", "psi.h", os.path.join("..", "..", "include", "trlda_hip.h")]
+HEADERS = ["estep_kernels.h", "estep_wide.h", "elbo_kernels.h", "stream_kernels.h", "eb_kernels.h", "rng_kernels.h", "dp_kernels.h", "psi.h", os.path.join("..", "..", "include", "trlda_hip.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
                "-munsafe-fp-atomics", "-Wall"]
 

@@ -1,0 +1,76 @@
+// dp_kernels.h -- data-parallel E-step with FACTOR exchange.
+//
+// The reference adds the K x V statistics of its threads under `omp critical`
+// (src/lda.cpp:211-217).  Across GPUs that sum is an all-reduce of K * V doubles per E-step:
+// 5.6 / 80 / 400 MB at BASELINE.json's table sizes, 2 (N-1)/N times that over every GPU's links.
+// But the statistics are a product of factors that are tiny next to the table,
+//
+//   sstats[k, w] = expElogbeta[k, w] * sum_{(d, w) in batch} (cnt_dw / phinorm_dw) expElogtheta[d, k]
+//
+// -- lambda (hence expElogbeta) is replicated, so a rank only has to tell the others the
+// K numbers expElogtheta[d, :] of each of its documents and one weight per (document, word)
+// entry: 8 (K + n_d) bytes per document instead of 8 K V per rank (0.3 MB instead of 5.6 MB per
+// rank at K = 100, 200 documents of ~90 words; 2.5 instead of 400 MB at K = 500, 512 documents).
+// Every rank then forms the statistics of the WHOLE mini-batch with the single-GPU kernel, which
+// adds a word's entries in document order -- the reference's serial order: every rank performs
+// the same additions on the same numbers, so the replicas stay bitwise equal and equal the
+// one-GPU result up to the rounding of the document-kernel variant a shard selects (an
+// all-reduce's order of additions depends on the rank count), and the fused M-step with carried
+// row sums (estep_kernels.h, 4c) applies unchanged.
+//
+// Layout of the gathered buffer, `world` equal slots (ncclAllGather wants equal counts):
+//
+//   slot r = [ expElogtheta of rank r's documents, rows of K | weights of its entries, CSR order | pad ]
+//            |<- tw_off = max_r(documents) * K doubles       ->|
+//   slot size = a multiple of K doubles, so that a document's row is slot-relative row index
+//
+// factor_unpack_kernel: one thread per entry p of the whole mini-batch (CSR position): which
+// document, which rank, where its weight lies in the gathered buffer; writes the weight to the
+// entry's place in word-major order (what the statistics kernel walks) and the row index of the
+// document's expElogtheta in the gathered buffer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace trlda {
+
+constexpr int kDpMaxWorld = 64;
+
+struct DpCuts {                      // document cut points of the mini-batch, by value
+    int32_t at[kDpMaxWorld + 1];
+};
+
+template <int T>
+__global__ __launch_bounds__(T) void factor_unpack_kernel(
+    int B, int64_t nnz, int world, const int32_t *__restrict__ indptr, const int32_t *__restrict__ wrank,
+    DpCuts cuts /* world + 1 document cut points */, size_t slot, int slot_rows,
+    size_t tw_off, const double *__restrict__ gathered, double *__restrict__ tw_word,
+    int32_t *__restrict__ wdoc_rows)
+{
+    __shared__ int32_t cut_l[kDpMaxWorld + 1];
+    for (int i = threadIdx.x; i <= world; i += T)
+        cut_l[i] = cuts.at[i];
+    __syncthreads();
+    for (int64_t p = (int64_t)blockIdx.x * T + threadIdx.x; p < nnz; p += (int64_t)gridDim.x * T) {
+        // document of entry p: the last d with indptr[d] <= p (empty documents share offsets)
+        int lo = 0, hi = B;                          // invariant: indptr[lo] <= p < indptr[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (indptr[mid] <= (int32_t)p)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const int d = lo;
+        int r = 0;
+        while (r + 1 < world && cut_l[r + 1] <= d)
+            ++r;
+        const int first = cut_l[r];
+        const size_t base = (size_t)r * slot;
+        const int q = wrank[p];
+        tw_word[q] = gathered[base + tw_off + (size_t)(p - indptr[first])];
+        wdoc_rows[q] = r * slot_rows + (d - first);
+    }
+}
+
+}  // namespace trlda

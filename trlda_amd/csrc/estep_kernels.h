@@ -432,7 +432,8 @@ struct DocKernelArgs {
     double *gamma;            // K x B out
     double *epg;              // K x B out: exp(psi(gamma)) of the returned gamma
     double *tw_csr;           // nnz: cnt/phinorm in CSR order (streaming-path scratch)
-    const int32_t *wrank;     // nnz: CSR position -> word-major rank (segmented mode)
+    const int32_t *wrank;     // nnz: CSR position -> word-major rank (segmented mode); NULL: the
+                              // weights stay in CSR order (data-parallel factor exchange)
     double *tw_word;          // nnz: cnt/phinorm in word-major order (segmented mode)
     double *sstats_acc;       // K x V atomic target (atomic mode) or nullptr
     int max_iter;
@@ -731,7 +732,7 @@ __global__ __launch_bounds__(T) void estep_docs_kernel(DocKernelArgs a)
         }
     } else {
         for (int j = tid; j < n; j += T)
-            a.tw_word[a.wrank[p0 + j]] = staged ? tw_l[j] : a.tw_csr[p0 + j];
+            a.tw_word[a.wrank ? a.wrank[p0 + j] : p0 + j] = staged ? tw_l[j] : a.tw_csr[p0 + j];
     }
 }
 
@@ -1213,7 +1214,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
         }
     } else {
         if (tid < n)
-            a.tw_word[a.wrank[p0 + tid]] = tw[tid];
+            a.tw_word[a.wrank ? a.wrank[p0 + tid] : p0 + tid] = tw[tid];
     }
     TRLDA_STAMP(6);
     TRLDA_STAMP_FLUSH;

@@ -493,11 +493,11 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
 #pragma unroll
             for (int g = 0; g < NH; ++g)
                 if (jv[g] >= 0)
-                    a.tw_word[a.wrank[p0 + jv[g]]] = twv[g];
+                    a.tw_word[a.wrank ? a.wrank[p0 + jv[g]] : p0 + jv[g]] = twv[g];
         }
         __syncthreads();                             // tw_csr of the tail words
         for (int j = n_reg + tid; j < n; j += kWideThreads)
-            a.tw_word[a.wrank[p0 + j]] = a.tw_csr[p0 + j];
+            a.tw_word[a.wrank ? a.wrank[p0 + j] : p0 + j] = a.tw_csr[p0 + j];
     }
     TRLDA_STAMP(7);
     TRLDA_STAMP_FLUSH;

@@ -37,6 +37,7 @@
 #include "stream_kernels.h"
 #include "eb_kernels.h"
 #include "rng_kernels.h"
+#include "dp_kernels.h"
 
 namespace {
 
@@ -149,6 +150,18 @@ struct trlda_batch {
     int32_t *pad_meta = nullptr;     // B x 4
     int32_t *pad_ids = nullptr;      // B x kRegMaxN
     std::vector<int32_t> sorted_len;   // host copy: document lengths in `order`
+    std::vector<int32_t> indptr_host;  // host copy of indptr (data-parallel slot geometry)
+};
+
+// A data-parallel call in flight (dp_kernels.h): the model holds the whole mini-batch `b`, iterates
+// the documents of `shard` = documents [cuts[rank], cuts[rank + 1]) of it, and exchanges factors.
+struct DpContext {
+    const trlda_batch *shard = nullptr;
+    int rank = 0, world = 1;
+    std::vector<int32_t> cuts;          // world + 1 document cut points of the whole mini-batch
+    void *comm = nullptr;               // ncclComm_t, unless the model has an all-gather hook
+    size_t slot = 0, tw_off = 0;        // doubles
+    int doc_lo() const { return cuts[(size_t)rank]; }
 };
 
 struct trlda_model {
@@ -205,6 +218,14 @@ struct trlda_model {
     bool prefetch_next = true;          // trlda_model_set_prefetch: honour "next batch" announcements
     // per-batch workspaces, grown on demand
     size_t cap_docs = 0, cap_tw_csr = 0, cap_tw_word = 0;
+    // Data-parallel factor exchange (DpContext below): the gathered factors of all ranks, the
+    // statistics kernel's row index into them, the shard cut points on the device
+    DpContext *dp = nullptr;            // set for the duration of a *_dp call
+    double *dp_gather = nullptr;
+    int32_t *dp_wdoc = nullptr;
+    size_t cap_dp_gather = 0, cap_dp_wdoc = 0;
+    int (*allgather_hook)(void *, const void *, void *, size_t, void *) = nullptr;
+    void *allgather_ctx = nullptr;
     double *epg = nullptr, *tw_csr = nullptr, *tw_word = nullptr;
     // update_parameters workspaces
     double *lambda_prime = nullptr, *sstats = nullptr, *gamma = nullptr, *wordcounts = nullptr;
@@ -370,6 +391,21 @@ int sample_gamma_on_device(trlda_model *m, long long total, int passes, double d
 // overlap the kernels of this one.
 int fresh_gamma_device(trlda_model *m, int B)
 {
+    if (m->dp) {
+        // this rank's columns of the whole mini-batch's matrix; the stream moves on by all of it,
+        // as in the single-process run (every rank draws from the same state: lda.cpp:135)
+        const long long lo = (long long)m->K * m->dp->doc_lo(), n = (long long)m->K * m->dp->shard->B;
+        if (!m->host_gamma_draw)
+            return sample_gamma_on_device(m, (long long)m->K * B, 100, 100., m->gamma, lo, lo + n);
+        std::vector<double> full((size_t)m->K * B);
+        trlda_sample_gamma_init(m->K, B, full.data());
+        if (n > 0) {
+            HIP_TRY(hipMemcpyAsync(m->gamma, full.data() + lo, (size_t)n * sizeof(double),
+                                   hipMemcpyHostToDevice, m->stream));
+            HIP_TRY(hipStreamSynchronize(m->stream));        // `full` goes out of scope
+        }
+        return TRLDA_OK;
+    }
     if (!m->host_gamma_draw)
         return sample_gamma_on_device(m, (long long)m->K * B, 100, 100., m->gamma);
     const size_t count = (size_t)m->K * B;
@@ -539,9 +575,11 @@ int launch_sstats_update(trlda_model *m, const trlda_batch *b, EstepOut &out)
     int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (rc)
         return rc;
+    // (data-parallel: expElogtheta rows of all ranks in the gathered buffer, dp_kernels.h)
     hipLaunchKernelGGL(kern, dim3(G_short + G_long), dim3(T), lds, m->stream, K, N, G_short,
-                       b->n_long, out.active_only ? b->active : nullptr, b->wptr, b->wdoc,
-                       b->long_words, m->tw_word, m->epg, m->eeb_cur, out.upd);
+                       b->n_long, out.active_only ? b->active : nullptr, b->wptr,
+                       m->dp ? m->dp_wdoc : b->wdoc, b->long_words, m->tw_word,
+                       m->dp ? m->dp_gather : m->epg, m->eeb_cur, out.upd);
     HIP_TRY(hipGetLastError());
     out.partial_rows = G_short + G_long;
     return TRLDA_OK;
@@ -573,6 +611,90 @@ int sstats_update_device(trlda_model *m, const trlda_batch *b, EstepOut &out)
                     : launch_sstats_update<1024, 2, 0>(m, b, out);
 }
 
+// ---- data-parallel factor exchange (dp_kernels.h) -------------------------------------------
+using nccl_allgather_fn = int (*)(const void *, void *, size_t, int, void *, hipStream_t);
+constexpr int kNcclFloat64 = 8, kNcclSum = 0;       // ncclDataType_t / ncclRedOp_t (nccl.h)
+
+void *rccl_symbol(const char *name)
+{
+    void *sym = dlsym(RTLD_DEFAULT, name);
+    if (!sym) {
+        const char *libs[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char *lib : libs) {
+            if (void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL)) {
+                sym = dlsym(h, name);
+                if (sym)
+                    break;
+            }
+        }
+    }
+    return sym;
+}
+
+// slot geometry and buffers for a call on the whole mini-batch `b` cut at dp->cuts
+int dp_prepare(trlda_model *m, const trlda_batch *b, DpContext *dp)
+{
+    const int K = m->K, world = dp->world;
+    if (world < 1 || world > trlda::kDpMaxWorld || dp->rank < 0 || dp->rank >= world)
+        return fail(TRLDA_ERR_ARG, "rank / world out of range (world <= 64)");
+    if ((int)dp->cuts.size() != world + 1 || dp->cuts.front() != 0 || dp->cuts.back() != b->B)
+        return fail(TRLDA_ERR_ARG, "doc_cuts must run from 0 to the mini-batch size in world + 1 steps");
+    int max_docs = 0;
+    int64_t max_nnz = 0;
+    for (int r = 0; r < world; ++r) {
+        const int lo = dp->cuts[(size_t)r], hi = dp->cuts[(size_t)r + 1];
+        if (hi < lo)
+            return fail(TRLDA_ERR_ARG, "doc_cuts must be non-decreasing");
+        max_docs = std::max(max_docs, hi - lo);
+        max_nnz = std::max<int64_t>(max_nnz, b->indptr_host[(size_t)hi] - b->indptr_host[(size_t)lo]);
+    }
+    const trlda_batch *sh = dp->shard;
+    const int lo = dp->doc_lo(), hi = dp->cuts[(size_t)dp->rank + 1];
+    if (!sh || sh->B != hi - lo || sh->nnz != b->indptr_host[(size_t)hi] - b->indptr_host[(size_t)lo])
+        return fail(TRLDA_ERR_SHAPE, "the shard is not documents [doc_cuts[rank], doc_cuts[rank + 1]) of the mini-batch");
+    dp->tw_off = (size_t)max_docs * K;
+    dp->slot = (dp->tw_off + (size_t)max_nnz + (size_t)K - 1) / (size_t)K * (size_t)K;
+    if (dp->slot / (size_t)K * (size_t)world > (size_t)INT32_MAX)
+        return fail(TRLDA_ERR_ARG, "mini-batch too large for the factor exchange");
+    int rc = grow(&m->dp_gather, &m->cap_dp_gather, std::max<size_t>(dp->slot * (size_t)world, 1));
+    if (!rc) rc = grow(&m->dp_wdoc, &m->cap_dp_wdoc, (size_t)std::max<int64_t>(b->nnz, 1));
+    return rc;
+}
+
+// all ranks' factors -> every rank, then into the statistics kernel's order
+int dp_exchange(trlda_model *m, const trlda_batch *b)
+{
+    DpContext *dp = m->dp;
+    double *mine = m->dp_gather + (size_t)dp->rank * dp->slot;
+    if (m->allgather_hook) {
+        const int rc = m->allgather_hook(m->allgather_ctx, mine, m->dp_gather, dp->slot, m->stream);
+        if (rc != 0)
+            return fail(TRLDA_ERR_HIP, "the all-gather hook failed with " + std::to_string(rc));
+    } else if (dp->world > 1) {
+        if (!dp->comm)
+            return fail(TRLDA_ERR_ARG, "RCCL communicator is NULL");
+        static nccl_allgather_fn fn = reinterpret_cast<nccl_allgather_fn>(rccl_symbol("ncclAllGather"));
+        if (!fn)
+            return fail(TRLDA_ERR_ARG, "ncclAllGather not found: load RCCL (librccl.so) into the process");
+        const int rc = fn(mine, m->dp_gather, dp->slot, kNcclFloat64, dp->comm, m->stream);   // in place
+        if (rc != 0)
+            return fail(TRLDA_ERR_HIP, "ncclAllGather failed with ncclResult_t " + std::to_string(rc));
+    }
+    if (b->nnz > 0) {
+        constexpr int T = 256;
+        const int G = (int)std::min<int64_t>((b->nnz + T - 1) / T, 2048);
+        trlda::DpCuts cuts{};
+        for (int r = 0; r <= dp->world; ++r)
+            cuts.at[r] = dp->cuts[(size_t)r];
+        hipLaunchKernelGGL(trlda::factor_unpack_kernel<T>, dim3(G), dim3(T), 0, m->stream, b->B, b->nnz,
+                           dp->world, b->indptr, b->wrank, cuts, dp->slot,
+                           (int)(dp->slot / (size_t)m->K), dp->tw_off, m->dp_gather, m->tw_word,
+                           m->dp_wdoc);
+        HIP_TRY(hipGetLastError());
+    }
+    return TRLDA_OK;
+}
+
 // The E-step launch sequence on the model's stream (no synchronisation).  `out` says what the
 // statistics stage writes; an M-step in it (out.upd.lambda) needs fused_update_available().
 int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepOut &out,
@@ -580,18 +702,28 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                  const double *gamma_in_dev = nullptr, const trlda_batch *next = nullptr)
 {
     using namespace trlda;
-    const int K = m->K, V = m->V, B = b->B;
+    // data-parallel call: the preamble and the statistics cover the whole mini-batch `b`, the
+    // document stage this rank's shard `db` of it
+    DpContext *dp = m->dp;
+    const trlda_batch *db = dp ? dp->shard : b;
+    const int K = m->K, V = m->V, B = db->B;
     const size_t KV = (size_t)K * V;
-    if (b->V != V)
+    if (b->V != V || db->V != V)
         return fail(TRLDA_ERR_SHAPE, "batch was created for a different vocabulary size");
-    if (b->device != m->device)
+    if (b->device != m->device || db->device != m->device)
         return fail(TRLDA_ERR_ARG, "batch and model live on different devices");
     int rc = ensure_batch_workspace(m, b);
     if (!rc)
         rc = batch_begin(m, b);
+    if (!rc && dp)
+        rc = batch_begin(m, db);
     if (rc)
         return rc;
     const bool atomic = m->sstats_mode == TRLDA_SSTATS_ATOMIC;
+    if (dp && atomic)
+        return fail(TRLDA_ERR_ARG, "the factor exchange needs the segmented statistics mode");
+    if (dp)
+        next = nullptr;
     if (out.upd.lambda && !fused_update_available(m))
         return fail(TRLDA_ERR_ARG, "internal: fused M-step requested where it is not available");
     double *sstats_dev = out.upd.sstats;
@@ -612,7 +744,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
     // kernel (estep_kernels.h, 2b) -- as long as no row sum can be so small that exp(-psi(sum))
     // overflows (rs_floor: a bound the host keeps through every update)
     const bool fused = !big && B > 0 && m->doc_threads == 0 && m->doc_kernel == TRLDA_DOCS_AUTO &&
-                       !m->split_preamble && K <= trlda::kRegMaxK && b->max_n <= trlda::kRegMaxN &&
+                       !m->split_preamble && K <= trlda::kRegMaxK && db->max_n <= trlda::kRegMaxN &&
                        trust && m->rs_floor >= kFusedRowsumFloor;
     m->last_preamble_fused = fused;
     if (!fused && carried && (rc = resolve_carry(m)))   // everything else wants one row of sums
@@ -745,11 +877,18 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
             g_stamp_buf = stamp_buf;
         }
 #endif
-        a.indptr = b->indptr; a.ids = b->ids; a.cnts = b->cnts;
+        a.indptr = db->indptr; a.ids = db->ids; a.cnts = db->cnts;
         a.eeb = m->eeb_cur; a.alpha = m->alpha;
         a.gamma = gamma_dev; a.gamma_in = gamma_in_dev ? gamma_in_dev : gamma_dev;
         a.epg = m->epg; a.tw_csr = m->tw_csr;
-        a.wrank = b->wrank; a.tw_word = m->tw_word;
+        a.wrank = db->wrank; a.tw_word = m->tw_word;
+        if (dp) {
+            // straight into this rank's slot of the gathered buffer: expElogtheta rows, then the
+            // weights in CSR order
+            a.epg = m->dp_gather + (size_t)dp->rank * dp->slot;
+            a.tw_word = a.epg + dp->tw_off;
+            a.wrank = nullptr;
+        }
         a.sstats_acc = atomic ? sstats_dev : nullptr;
         a.max_iter = max_iter; a.threshold = threshold; a.iters_out = iters_dev;
         a.partial = fused ? partial_in : nullptr;
@@ -764,7 +903,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         int n_reg = 0;
         if (m->doc_threads == 0 && K <= kRegMaxK && m->doc_kernel != TRLDA_DOCS_WIDE &&
             m->doc_kernel != TRLDA_DOCS_GENERAL)
-            while (n_reg < B && b->sorted_len[(size_t)(B - 1 - n_reg)] <= kRegMaxN)
+            while (n_reg < B && db->sorted_len[(size_t)(B - 1 - n_reg)] <= kRegMaxN)
                 ++n_reg;
 
         // 128 < K <= 512, or K <= 128 with more than 192 words: registers in one orientation
@@ -794,11 +933,11 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
             // LDS rows for the words past the registers, as many as the longest document needs
             const size_t fixed = wide_lds_doubles(KS, 0) * sizeof(double);
             const int fit = (int)(((size_t)kLdsBytes - fixed) / ((size_t)(64 * KS + 1) * sizeof(double)));
-            const int lds_rows = std::max(0, std::min(fit, b->max_n - kWideWaves * jw));
+            const int lds_rows = std::max(0, std::min(fit, db->max_n - kWideWaves * jw));
             const size_t lds_bytes = wide_lds_doubles(KS, lds_rows) * sizeof(double);
             a.n_cap = 0;
             a.Kp = 64 * KS;
-            a.order = b->order;
+            a.order = db->order;
 #define TRLDA_LAUNCH_WIDE(KSV)                                                             \
     do {                                                                                   \
         auto kern = estep_docs_wide_kernel<KSV>;                                           \
@@ -826,14 +965,14 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                             ? 0
                             : (int)(((size_t)kLdsBytes - fixed) /
                                     ((size_t)(Kp + 2) * sizeof(double)));
-            int gen_cap = std::min(b->max_n, n_fit);
+            int gen_cap = std::min(db->max_n, n_fit);
             size_t lds_bytes = docs_lds_bytes(K, Kp, gen_cap, T);
             if (lds_bytes > (size_t)kLdsBytes)
                 return fail(TRLDA_ERR_ARG,
                             "num_topics too large for the document kernel's LDS layout");
             a.n_cap = gen_cap;
             a.Kp = Kp;
-            a.order = b->order;
+            a.order = db->order;
             switch (T) {
             case 64: rc = launch_docs<64>(m, a, n_stream, lds_bytes); break;
             case 128: rc = launch_docs<128>(m, a, n_stream, lds_bytes); break;
@@ -855,10 +994,10 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
             // fork/join costs more (~12 us) than it saves.
             // (With more documents than CUs it is throughput that counts, and there <2> wins over
             // <1>: it only charges the long documents for their tail.)
-            const int longest = b->sorted_len[(size_t)(B - n_reg)];
-            a.order = b->order + (B - n_reg);
-            a.pad_meta = b->pad_meta + (size_t)(B - n_reg) * 4;
-            a.pad_ids = b->pad_ids + (size_t)(B - n_reg) * kRegMaxN;
+            const int longest = db->sorted_len[(size_t)(B - n_reg)];
+            a.order = db->order + (B - n_reg);
+            a.pad_meta = db->pad_meta + (size_t)(B - n_reg) * 4;
+            a.pad_ids = db->pad_ids + (size_t)(B - n_reg) * kRegMaxN;
             auto kern = longest <= 128                    ? estep_docs_reg_kernel<0>
                         : longest <= 144 && n_reg <= 256 ? estep_docs_reg_kernel<1>
                                                           : estep_docs_reg_kernel<2>;
@@ -917,6 +1056,11 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
     if (m->timing && (rc = stamp(m)))
         return rc;
 
+    if (dp) {                                        // dp_kernels.h
+        if ((rc = batch_end(m, db)) || (rc = dp_exchange(m, b)))
+            return rc;
+    }
+
     // 4. sufficient statistics (lda.cpp:207-217), with the M-step and the next row sums where
     // the caller asked for them
     if (atomic) {
@@ -941,8 +1085,8 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         if ((rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)))           \
             return rc;                                                                     \
         hipLaunchKernelGGL(kern, dim3(G_short + b->n_long), dim3(TS), lds, m->stream, K, V, \
-                           G_short, b->wptr, b->wdoc, b->long_words, m->tw_word, m->epg,   \
-                           m->eeb_cur, sstats_dev);                                        \
+                           G_short, b->wptr, dp ? m->dp_wdoc : b->wdoc, b->long_words,     \
+                           m->tw_word, dp ? m->dp_gather : m->epg, m->eeb_cur, sstats_dev); \
     } while (0)
         if (K >= 256)
             TRLDA_LAUNCH_SSTATS(512);
@@ -1760,6 +1904,7 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     b->device = device; b->V = V; b->B = B; b->nnz = nnz; b->max_n = max_n;
     b->n_active = n_active; b->n_long = n_long;
     b->sorted_len.resize(Bz);
+    b->indptr_host.assign(indptr, indptr + Bz + 1);
     {
         int32_t *meta = I(o_meta), *pids = I(o_pids);
         for (int i = 0; i < B; ++i) {
@@ -1944,7 +2089,7 @@ int trlda_model_destroy(trlda_model *m)
         (void)hipStreamSynchronize(m->stream);
         (void)hipFree(m->lambda); (void)hipFree(m->alpha); (void)hipFree(m->eeb); (void)hipFree(m->psi_sum);
         (void)hipFree(m->partial); (void)hipFree(m->counter); (void)hipFree(m->epg); (void)hipFree(m->tw_csr);
-        (void)hipFree(m->tw_word); (void)hipFree(m->lambda_prime); (void)hipFree(m->sstats); (void)hipFree(m->gamma);
+        (void)hipFree(m->tw_word); (void)hipFree(m->dp_gather); (void)hipFree(m->dp_wdoc); (void)hipFree(m->lambda_prime); (void)hipFree(m->sstats); (void)hipFree(m->gamma);
         (void)hipFree(m->wordcounts); (void)hipFree(m->rs_full); (void)hipFree(m->rs_static);
         (void)hipFree(m->upd_partial); (void)hipFree(m->ada_gradient); (void)hipFree(m->reduce_out);
         (void)hipFree(m->carry_out);
@@ -2695,24 +2840,10 @@ int trlda_model_cumulative_update(trlda_model *m, const trlda_batch *b, int max_
 namespace {
 
 using nccl_allreduce_fn = int (*)(const void *, void *, size_t, int, int, void *, hipStream_t);
-constexpr int kNcclFloat64 = 8, kNcclSum = 0;       // ncclDataType_t / ncclRedOp_t (nccl.h)
 
 nccl_allreduce_fn rccl_allreduce()
 {
-    static nccl_allreduce_fn fn = [] {
-        void *sym = dlsym(RTLD_DEFAULT, "ncclAllReduce");
-        if (!sym) {
-            const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-            for (const char *name : names) {
-                if (void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) {
-                    sym = dlsym(h, "ncclAllReduce");
-                    if (sym)
-                        break;
-                }
-            }
-        }
-        return reinterpret_cast<nccl_allreduce_fn>(sym);
-    }();
+    static nccl_allreduce_fn fn = reinterpret_cast<nccl_allreduce_fn>(rccl_symbol("ncclAllReduce"));
     return fn;
 }
 
@@ -2807,6 +2938,104 @@ int trlda_model_online_update_multi(trlda_model *m, const trlda_batch *shard, vo
         return rc;
     ++*update_count;                                         // onlinelda.cpp:177
     return TRLDA_OK;
+}
+
+// ---- data parallelism with factor exchange (dp_kernels.h) ---------------------------------
+
+int trlda_model_set_allgather(trlda_model *m, trlda_allgather_fn fn, void *ctx)
+{
+    if (!m)
+        return fail(TRLDA_ERR_ARG, "model is NULL");
+    m->allgather_hook = fn;
+    m->allgather_ctx = ctx;
+    return TRLDA_OK;
+}
+
+} // extern "C"
+
+namespace {
+
+int dp_enter(trlda_model *m, DpContext &dp, const trlda_batch *batch, const trlda_batch *shard,
+             void *rccl_comm, int rank, int world, const int32_t *doc_cuts)
+{
+    if (!batch || !shard || !doc_cuts)
+        return fail(TRLDA_ERR_ARG, "NULL batch / shard / doc_cuts");
+    if (batch->V != m->V || shard->V != m->V)
+        return fail(TRLDA_ERR_SHAPE, "batch was created for a different vocabulary size");
+    if (world < 1 || world > trlda::kDpMaxWorld)
+        return fail(TRLDA_ERR_ARG, "world must lie in [1, 64]");
+    dp.shard = shard;
+    dp.rank = rank;
+    dp.world = world;
+    dp.comm = rccl_comm;
+    dp.cuts.assign(doc_cuts, doc_cuts + world + 1);
+    int rc = dp_prepare(m, batch, &dp);
+    if (!rc)
+        m->dp = &dp;
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int trlda_model_online_update_dp(trlda_model *m, const trlda_batch *batch, const trlda_batch *shard,
+                                 void *rccl_comm, int rank, int world, const int32_t *doc_cuts,
+                                 int num_documents, double eta, int max_iter_tr, int max_iter_inference,
+                                 double kappa, double tau, double rho, int init_gamma, double threshold,
+                                 int *update_count, double *rho_out)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    DpContext dp;
+    if ((rc = dp_enter(m, dp, batch, shard, rccl_comm, rank, world, doc_cuts)))
+        return rc;
+    // the single-GPU call on the whole mini-batch; its document stage runs on the shard and an
+    // exchange follows it (estep_device), everything else -- word counts, the initial step, the
+    // fused M-steps with carried row sums -- is replicated work on replicated data
+    rc = trlda_model_online_update(m, batch, num_documents, eta, max_iter_tr, max_iter_inference, kappa,
+                                   tau, rho, init_gamma, 1, threshold, update_count, rho_out, nullptr);
+    m->dp = nullptr;
+    return rc;
+}
+
+int trlda_model_estep_dp(trlda_model *m, const trlda_batch *batch, const trlda_batch *shard,
+                         void *rccl_comm, int rank, int world, const int32_t *doc_cuts,
+                         const double *gamma0_dev, double *gamma_dev, double *sstats_dev, int max_iter,
+                         double threshold, int32_t *iters_dev, int mstep,
+                         const double *lambda_prime_dev, double rho, double eta, double scale)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!gamma_dev)
+        return fail(TRLDA_ERR_ARG, "gamma is NULL");
+    if (!mstep && !sstats_dev)
+        return fail(TRLDA_ERR_ARG, "nothing to write: no sstats buffer and no M-step");
+    if (mstep && !fused_update_available(m))
+        return fail(TRLDA_ERR_ARG, "the fused M-step is not available for this model (K > 512 or switched off)");
+    DpContext dp;
+    if ((rc = dp_enter(m, dp, batch, shard, rccl_comm, rank, world, doc_cuts)))
+        return rc;
+    EstepOut out(sstats_dev);
+    if (mstep) {
+        // lambda = (1 - rho) lambda' + rho (eta + scale * sstats) for every word
+        // (onlinelda.cpp:99-100 / :107-108), in the statistics kernel
+        out.upd.omr = 1. - rho; out.upd.rho = rho; out.upd.eta = eta; out.upd.scale = scale;
+        out.upd.lambda = m->lambda;
+        out.upd.lambda_prime = lambda_prime_dev ? lambda_prime_dev : m->lambda;
+        out.upd.partial = m->upd_partial;
+        out.active_only = false;
+        rc = ensure_update_workspace(m, 1);
+        if (!rc) rc = ensure_rowsums(m);
+    }
+    if (!rc)
+        rc = estep_device(m, batch, gamma_dev, out, max_iter, threshold, iters_dev, gamma0_dev);
+    if (!rc && mstep)
+        rc = finish_rowsums(m, out, nullptr, rho * m->V * eta);
+    m->dp = nullptr;
+    return rc;
 }
 
 // ---- empirical Bayes / adaptive rate: device reductions, K-sized results ------------------
