@@ -73,6 +73,16 @@ def parse():
                     help="strong scaling: this many documents per step in all, split over the "
                          "GPUs (BASELINE.json configs[2]: 1600); default 0 = weak scaling, "
                          "--batch documents per GPU")
+    ap.add_argument("--exchange", choices=["auto", "factors", "sstats"], default="auto",
+                    help="N > 1: what crosses ranks per step -- 'factors': an all-gather of every "
+                         "document's expElogtheta row and per-entry weights (8 (K + n_d) bytes per "
+                         "document, trlda_model_estep_dp), each rank then forms the statistics of the "
+                         "whole mini-batch and the M-step in one kernel; 'sstats': the all-reduce of "
+                         "K x V statistics; 'auto': whichever moves fewer bytes")
+    ap.add_argument("--virtual-world", type=int, default=0,
+                    help="development aid for a one-GPU box: time what ONE rank of this many executes "
+                         "per step with --exchange factors (the other ranks' slots hold a copy of "
+                         "this rank's factors; no collective runs)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="every step launches its own preamble kernel instead of having it prepared "
                          "by extra workgroups of the previous step's document-kernel launch")
@@ -138,23 +148,8 @@ def main():
     rccl_comm = None
     if collective and os.environ.get("TRLDA_BENCH_TORCH_ALLREDUCE") != "1":
         try:
-            rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
-
-            class UniqueId(C.Structure):
-                _fields_ = [("internal", C.c_char * 128)]
-
-            rccl.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
-            rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
-            uid = UniqueId()
-            if rank == 0 and rccl.ncclGetUniqueId(C.byref(uid)) != 0:
-                raise RuntimeError("ncclGetUniqueId failed")
-            raw = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone().to(device)
-            dist.broadcast(raw, src=0)
-            C.memmove(C.byref(uid), bytes(raw.cpu().numpy().tobytes()), 128)
-            comm = C.c_void_p()
-            if rccl.ncclCommInitRank(C.byref(comm), world, uid, rank) != 0:
-                raise RuntimeError("ncclCommInitRank failed")
-            rccl_comm = comm
+            from trlda_amd import rccl
+            rccl_comm = rccl.own_communicator(dist, device)
         except Exception as exc:                      # noqa: BLE001
             if rank == 0:
                 print("bench: own RCCL communicator unavailable (%s); using torch.distributed" % exc,
@@ -199,13 +194,41 @@ def main():
             rccl_comm = None                          # every rank falls back together
         del probe, want
 
-    batches, csrs, gamma0s = [], [], []
+    # ---- what crosses ranks -------------------------------------------------
+    vworld = args.virtual_world if (args.virtual_world > 1 and world == 1) else 0
+    if vworld:
+        collective = True                            # the M-step inside the step, no prefetch
+    xworld = vworld or world                         # ranks the mini-batch is cut over
+    def rank_corpus(r, i):
+        seed = SEED_BASE + 1 + 1000 * r + i          # config index 1; distinct per rank
+        return CSRDocuments(*make_corpus(B, V, seed=seed, mean_unique=args.mean_unique,
+                                         zipf=not args.uniform))
+    exchange = "none"
+    if collective:
+        probe = rank_corpus(rank, 0)
+        slot = B * K + int(probe.indptr[-1]) * 11 // 10            # ~ max_r(docs) K + max_r(nnz)
+        factors_bytes, sstats_bytes = 8. * xworld * slot, 8. * 2. * KV
+        exchange = args.exchange if args.exchange != "auto" else \
+            ("factors" if factors_bytes < sstats_bytes else "sstats")
+        if vworld:
+            exchange = "factors"
+        if exchange == "factors" and world > 1 and rccl_comm is None:
+            exchange = "sstats"                      # ncclAllGather needs the communicator
+
+    batches, csrs, gamma0s, gbatches = [], [], [], []
+    cuts = (np.arange(xworld + 1) * B).astype(np.int32)
     for i in range(args.num_batches):
-        seed = SEED_BASE + 1 + 1000 * rank + i       # config index 1; distinct per rank
-        csr = CSRDocuments(*make_corpus(B, V, seed=seed, mean_unique=args.mean_unique,
-                                        zipf=not args.uniform))
+        csr = rank_corpus(rank, i)
         csrs.append(csr)
         batches.append(DeviceBatch(csr, V, local_rank))
+        if exchange == "factors":
+            # every rank holds the whole mini-batch (word lists only: a few hundred kB)
+            parts = [csr if r == rank else rank_corpus(r, i) for r in range(xworld)]
+            off = np.concatenate([[0], np.cumsum([int(p.indptr[-1]) for p in parts])])
+            whole = CSRDocuments(
+                np.concatenate([parts[0].indptr] + [p.indptr[1:] + off[r] for r, p in enumerate(parts) if r]),
+                np.concatenate([p.ids for p in parts]), np.concatenate([p.cnts for p in parts]))
+            gbatches.append(DeviceBatch(whole, V, local_rank))
         g0 = np.empty((K, B), order="F")
         L.trlda_sample_gamma_init(K, B, g0)
         gamma0s.append(torch.from_numpy(np.ascontiguousarray(g0.T)).to(device))
@@ -220,8 +243,26 @@ def main():
     RHO, ETA, D_TOTAL = 0.01, 0.3, 1000000
 
     prefetch = not collective and not args.no_prefetch
+    if vworld:
+        # no collective: the first call copies this rank's slot into the other ranks' (finite,
+        # plausible factors), later calls leave the buffer alone
+        HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+        filled = []
 
-    def step(i, want_iters=False):
+        def fill_once(ctx, send, recv, count, hip_stream):
+            if not filled:
+                filled.append(1)
+                torch.cuda.synchronize()
+                own = np.empty(int(count))
+                L.trlda_dev_download(local_rank, C.c_void_p(own.ctypes.data), C.c_void_p(send), own.nbytes)
+                for r in range(1, vworld):
+                    L.trlda_dev_upload(local_rank, C.c_void_p(recv + r * own.nbytes),
+                                       C.c_void_p(own.ctypes.data), own.nbytes)
+            return 0
+        virtual_hook = HOOK(fill_once)
+        _ffi.check(L.trlda_model_set_allgather(model, C.cast(virtual_hook, C.c_void_p), None))
+
+    def step(i, want_iters=False, plain=False):         # plain: the bare E-step (parity leg)
         j = i % args.num_batches
         # gamma0 is read-only input, gamma the output (lda.cpp:168 copies, we do not).  The batch
         # of the next step is announced: its preamble (row sums + exp(psi(lambda)) on ITS words,
@@ -229,20 +270,31 @@ def main():
         # launch, on the CUs a 200-document batch leaves idle -- one launch fewer per step,
         # nothing skipped, nothing shared between steps.  N > 1: the M-step changes lambda every
         # step, so there is nothing to prepare ahead.
+        if exchange == "factors" and not plain:
+            # documents of this rank -> all-gather of the factors -> statistics of the whole
+            # mini-batch + M-step (onlinelda.cpp:99-100) in one kernel, on every rank
+            _ffi.check(L.trlda_model_estep_dp(
+                model, gbatches[j].handle, batches[j].handle, rccl_comm, 0 if vworld else rank, xworld,
+                cuts.ctypes.data_as(C.POINTER(C.c_int32)), gamma0s[j].data_ptr(), gamma.data_ptr(),
+                None, args.max_iter, args.threshold, iters_dev.data_ptr() if want_iters else None, 1,
+                lam_prime.data_ptr(), RHO, ETA, D_TOTAL / float(B * xworld)))
+            return
         nxt = batches[(i + 1) % args.num_batches].handle if prefetch else None
         _ffi.check(L.trlda_model_estep_io_next(model, batches[j].handle, nxt, gamma0s[j].data_ptr(),
                                                gamma.data_ptr(), sstats.data_ptr(), args.max_iter,
                                                args.threshold,
                                                iters_dev.data_ptr() if want_iters else None))
-        if collective and rccl_comm is not None:      # RCCL over xGMI: K x V fp64 sum
-            _ffi.check(L.trlda_model_allreduce_sstats(model, rccl_comm, C.c_void_p(sstats.data_ptr())))
-        elif collective:
-            dist.all_reduce(sstats)
+        if collective and not plain:
+            if rccl_comm is not None:                 # RCCL over xGMI: K x V fp64 sum
+                _ffi.check(L.trlda_model_allreduce_sstats(model, rccl_comm,
+                                                          C.c_void_p(sstats.data_ptr())))
+            else:
+                dist.all_reduce(sstats)
             _ffi.check(L.trlda_model_blend(model, lam_prime.data_ptr(), sstats.data_ptr(), RHO, ETA,
                                            D_TOTAL / float(B * world)))
 
     def fence():
-        if collective:
+        if collective and not vworld:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -254,7 +306,7 @@ def main():
         step(i)
     fence()
     elapsed = time.perf_counter() - t0
-    if collective:
+    if collective and not vworld:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -407,7 +459,7 @@ def main():
         g0 = np.asfortranarray(gamma0s[0].cpu().numpy().T)
         go, so, ito = orc.estep(lam, .1, c.indptr, c.ids, c.cnts, g0, args.max_iter,
                                 args.threshold, nthreads=min(8, os.cpu_count() or 1))
-        step(0, want_iters=True)
+        step(0, want_iters=True, plain=True)
         fence()
         gg = np.asfortranarray(gamma.cpu().numpy().reshape(B, K).T)
         sg = sstats.cpu().numpy().reshape(K, V, order="F")
@@ -492,17 +544,24 @@ def main():
                                 "launch (trlda_model_estep_io_next)" if prefetch else
                                 "a kernel launch of its own every step"),
                    "parallelism": "dp%d" % world,
-                   "exchange_via": ("trlda_model_allreduce_sstats (own ncclComm_t)" if rccl_comm is not None
-                                    else "torch.distributed.all_reduce") if collective else None,
-                   "exchange": "RCCL all-reduce of K x V fp64 sstats, then the M-step "
-                               "(onlinelda.cpp:99-100) that the next step's E-step reads"
-                   if collective else "none"},
+                   "exchange_via": (("trlda_model_estep_dp (ncclAllGather on the model's stream)"
+                                     if exchange == "factors" else
+                                     "trlda_model_allreduce_sstats (own ncclComm_t)" if rccl_comm is not None
+                                     else "torch.distributed.all_reduce") if collective else None),
+                   "exchange": ("all-gather of the documents' factors (expElogtheta rows + entry weights, "
+                                "%.2f MB per rank and step); every rank forms the statistics of the whole "
+                                "%d-document mini-batch and the M-step (onlinelda.cpp:99-100) in one kernel"
+                                % (8e-6 * xworld * slot, B * xworld) if exchange == "factors" else
+                                "RCCL all-reduce of K x V fp64 sstats, then the M-step "
+                                "(onlinelda.cpp:99-100) that the next step's E-step reads")
+                   if collective else "none",
+                   "virtual_world": vworld or None},
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
         "parity": parity,
         "update_parameters": update_rates,
     }
-    if collective:
+    if collective and not vworld:
         dist.destroy_process_group()
     # RCCL prints its banner through C stdio, which is block-buffered on a pipe and would
     # otherwise come out at exit, after the JSON: drain it first

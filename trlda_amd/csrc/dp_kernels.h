@@ -24,10 +24,10 @@
 //            |<- tw_off = max_r(documents) * K doubles       ->|
 //   slot size = a multiple of K doubles, so that a document's row is slot-relative row index
 //
-// factor_unpack_kernel: one thread per entry p of the whole mini-batch (CSR position): which
-// document, which rank, where its weight lies in the gathered buffer; writes the weight to the
-// entry's place in word-major order (what the statistics kernel walks) and the row index of the
-// document's expElogtheta in the gathered buffer.
+// factor_unpack_kernel: one wavefront per document of the whole mini-batch: which rank, where its
+// weights lie in the gathered buffer; writes each weight to its entry's place in word-major
+// order (what the statistics kernel walks) and the row index of the document's expElogtheta in
+// the gathered buffer.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -47,29 +47,23 @@ __global__ __launch_bounds__(T) void factor_unpack_kernel(
     size_t tw_off, const double *__restrict__ gathered, double *__restrict__ tw_word,
     int32_t *__restrict__ wdoc_rows)
 {
-    __shared__ int32_t cut_l[kDpMaxWorld + 1];
-    for (int i = threadIdx.x; i <= world; i += T)
-        cut_l[i] = cuts.at[i];
-    __syncthreads();
-    for (int64_t p = (int64_t)blockIdx.x * T + threadIdx.x; p < nnz; p += (int64_t)gridDim.x * T) {
-        // document of entry p: the last d with indptr[d] <= p (empty documents share offsets)
-        int lo = 0, hi = B;                          // invariant: indptr[lo] <= p < indptr[hi]
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (indptr[mid] <= (int32_t)p)
-                lo = mid;
-            else
-                hi = mid;
-        }
-        const int d = lo;
-        int r = 0;
-        while (r + 1 < world && cut_l[r + 1] <= d)
-            ++r;
-        const int first = cut_l[r];
-        const size_t base = (size_t)r * slot;
+    // one wavefront per document: its rank and its place in the rank's slot are wave-uniform,
+    // its entries are consecutive in the slot (CSR order) and spread over the lanes
+    const int lane = threadIdx.x & 63;
+    const int d = (int)(((size_t)blockIdx.x * T + threadIdx.x) >> 6);
+    if (d >= B)
+        return;
+    int r = 0;
+    while (r + 1 < world && cuts.at[r + 1] <= d)     // (uniform: scalar loads of the argument)
+        ++r;
+    const int first = cuts.at[r];
+    const int p0 = indptr[d], p1 = indptr[d + 1], pf = indptr[first];
+    const double *src = gathered + (size_t)r * slot + tw_off - pf;
+    const int row = r * slot_rows + (d - first);
+    for (int p = p0 + lane; p < p1; p += 64) {
         const int q = wrank[p];
-        tw_word[q] = gathered[base + tw_off + (size_t)(p - indptr[first])];
-        wdoc_rows[q] = r * slot_rows + (d - first);
+        tw_word[q] = src[p];
+        wdoc_rows[q] = row;
     }
 }
 

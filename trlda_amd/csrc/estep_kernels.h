@@ -1114,6 +1114,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
     // e is kept as c_k exp(psi(gamma_k)) throughout (c = 1 without the fused preamble)
     const double c_psi = c_l[psi_on ? k_psi : 0];
 
+    const double thresholdK = a.threshold * (double)K;
     int it = 0;
     while (it < a.max_iter) {                        // lda.cpp:185-204
         // acc_k = sum_j tw_j beta[j][k]                               lda.cpp:189-193
@@ -1173,27 +1174,33 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
                 g_new[k_psi] = gnew;
                 e_new[k_psi] = enew;
             }
-        } else if (wid == W - 1) {
-            // mean |gamma - last| (lda.cpp:202): this otherwise idle wave recomputes gamma for
-            // two topics per lane from the same partial sums (bitwise the same value as the
-            // owners'), reduces with DPP and divides -- all underneath the exp(psi) chain
-            const int ka = k_lo ? lane : 0, kb2 = k_hi ? lane + 64 : 0;
+        } else if (wid >= W - 2) {
+            // mean |gamma - last| (lda.cpp:202): two otherwise idle waves (on SIMDs the exp(psi)
+            // waves do not use) recompute gamma for one topic per lane from the same partial
+            // sums (bitwise the same value as the owners'), reduce with DPP and leave the two
+            // halves of the sum -- all underneath the exp(psi) chain.  (One wave doing both
+            // halves was the longest wave of the stage once exp(psi) got shorter.)
+            const int kc = (wid - (W - 2)) * 64 + lane;
+            const bool on = kc < K;
+            const int ka = on ? kc : 0;
             const double ga = sum8_strided<kRegPart>(part + ka) * e_old[ka] + alpha_l[ka];
-            const double gb = sum8_strided<kRegPart>(part + kb2) * e_old[kb2] + alpha_l[kb2];
-            const double v = (k_lo ? fabs(g_old[ka] - ga) : 0.0) + (k_hi ? fabs(g_old[kb2] - gb) : 0.0);
-            const double mean = wave_sum_dpp(v) / (double)K;
+            const double v = on ? fabs(g_old[ka] - ga) : 0.0;
+            const double half = wave_sum_dpp(v);
             if (lane == 0)
-                misc[0] = mean;
+                misc[wid - (W - 2)] = half;
         }
         TRLDA_STAMP(7);
         __syncthreads();
         TRLDA_STAMP(4);
-        const double mean_change = misc[0];          // read now: off the loop-end critical path
+        // sum_k |gamma_k - last_k| (read now, used at the loop's end).  Every wave of this kernel
+        // is bound by its instruction count, so the mean's division is not taken here: the
+        // sum is compared with threshold * K instead
+        const double change_sum = misc[0] + misc[1];
 
         product_E(e_new);                            // ends with a barrier
         TRLDA_STAMP(5);
         ++it;
-        if (mean_change < a.threshold)               // lda.cpp:202-203
+        if (change_sum < thresholdK)                 // lda.cpp:202-203: mean < threshold
             break;
     }
     const double *g = gbuf + (it & 1) * 128, *e = ebuf + (it & 1) * 144;

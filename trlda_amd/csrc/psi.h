@@ -159,8 +159,6 @@ __device__ __forceinline__ double digamma(double x)
 // t = 1/(2s) + series + sum >= 0.  One exp instead of log + exp -- the log is the longest
 // dependency chain of psi -- and no cancellation between log(s) and t.  Both callers of the
 // reference's digamma on the hot path only ever want exp(psi(.)) (lda.cpp:173-174, :197).
-// The ten recurrence terms are taken in five pairs, one reciprocal each: the evaluation is
-// bound by instruction issue (about 140 fp64 instructions), and this is 20 fewer.
 //
 // 1/a + 1/(a + 1) = (2a + 1) / (a (a + 1)): one reciprocal for two terms of the recurrence
 // (a^2 must not overflow: callers keep a below 1e150).  A couple of ulp.
@@ -169,7 +167,47 @@ __device__ __forceinline__ double rcp_pair(double a)
     return fma(2.0, a, 1.0) * rcp_pos<true>(fma(a, a, a));
 }
 
+// The ten recurrence terms as ONE rational function: with P(x) = x (x+1) ... (x+9),
+//   sum_{i<10} 1/(x+i) = P'(x) / P(x).
+// For x > 0 every coefficient of P and P' (Stirling numbers of the first kind, exact in fp64)
+// and every Horner step is positive -- no cancellation: the quotient is within ~3 ulp of the
+// exact sum, like the five reciprocal pairs it replaces (rcp_pair, kept for the rare branch) --
+// and it is 23 instructions shorter: two Horner chains of nine fmas and ONE reciprocal,
+// 1 / (P s), which also yields 1/s = P / (P s).  The stage that evaluates this is bound by
+// the instruction count of a single wave (~8.6 cycles per fp64 instruction).
+// Needs x^11 finite: callers keep x below 1e25.
 __device__ __forceinline__ double exp_psi_regular(double x, double c)
+{
+    double q = x + 45.0;
+    q = fma(q, x, 870.0);
+    q = fma(q, x, 9450.0);
+    q = fma(q, x, 63273.0);
+    q = fma(q, x, 269325.0);
+    q = fma(q, x, 723680.0);
+    q = fma(q, x, 1172700.0);
+    q = fma(q, x, 1026576.0);
+    q = fma(q, x, 362880.0);
+    const double P = q * x;
+    double dP = fma(10.0, x, 405.0);
+    dP = fma(dP, x, 6960.0);
+    dP = fma(dP, x, 66150.0);
+    dP = fma(dP, x, 379638.0);
+    dP = fma(dP, x, 1346625.0);
+    dP = fma(dP, x, 2894720.0);
+    dP = fma(dP, x, 3518100.0);
+    dP = fma(dP, x, 2053152.0);
+    dP = fma(dP, x, 362880.0);
+    const double s = x + 10.0;
+    const double inv = rcp_pos<true>(P * s);
+    const double r = P * inv;                        // 1 / s
+    const double w = (dP * s) * inv;                 // P' / P
+    const double z = r * r;
+    const double y = z * psi_series(z);
+    return s * exp(-((fma(0.5, r, y)) + w) - c);
+}
+
+// the form with five reciprocal pairs: valid up to 1e150 (the rational form needs x^11 finite)
+__device__ __noinline__ double exp_psi_wide_range(double x, double c)
 {
     double pi[5];
 #pragma unroll
@@ -186,43 +224,31 @@ __device__ __forceinline__ double exp_psi_regular(double x, double c)
     return s * exp(-(((0.5 * r) + y) + w) - c);
 }
 
+// x <= 0, small integers, and everything outside (1e-290, 1e25)
+__device__ __noinline__ double exp_digamma_rare(double x, double c)
+{
+    if (x >= 1e25 && x < 1e150)
+        return exp_psi_wide_range(x, c);
+    return exp(digamma(x) - c);
+}
+
 __device__ __forceinline__ double exp_digamma_minus(double x, double c)
 {
     // the regular value is computed unconditionally so that the (rare-branch) test runs
     // beside the main dependency chain instead of in front of it
     const double v = exp_psi_regular(x, c);
-    if (__builtin_expect(!(x > 1e-290 && x < 1e150) || (x <= 10.0 && x == floor(x)), 0))
-        return exp(digamma(x) - c);
+    if (__builtin_expect(!(x > 1e-290 && x < 1e25) || (x <= 10.0 && x == floor(x)), 0))
+        return exp_digamma_rare(x, c);
     return v;
 }
 
 __device__ __forceinline__ double exp_digamma(double x) { return exp_digamma_minus(x, 0.0); }
 
-// The same value, bit for bit, scheduled for few live registers instead of for latency: the
-// pairs of reciprocals are formed two at a time (same summation tree) with scheduling
-// barriers in between, and the rare branch is a call.  For kernels that hold most of the
-// register file as data (estep_wide.h) and hide latency with the other waves instead.
-__device__ __noinline__ double exp_digamma_rare(double x, double c) { return exp(digamma(x) - c); }
-
+// (The rational form keeps few values alive -- two Horner accumulators -- so the kernels that hold
+// most of the register file as data, estep_wide.h, use the same function.)
 __device__ __forceinline__ double exp_digamma_minus_lean(double x, double c)
 {
-    const double wa = rcp_pair(x) + rcp_pair(x + 2.0);
-    __builtin_amdgcn_sched_barrier(0);
-    const double wb = rcp_pair(x + 4.0) + rcp_pair(x + 6.0);
-    __builtin_amdgcn_sched_barrier(0);
-    double w = wa + wb;
-    w += rcp_pair(x + 8.0);
-    const double s = x + 10.0;
-    const double r = rcp_pos<true>(s);
-    double y = 0.0;
-    if (s < 1.0e17) {
-        const double z = r * r;
-        y = z * psi_series(z);
-    }
-    const double v = s * exp(-(((0.5 * r) + y) + w) - c);
-    if (__builtin_expect(!(x > 1e-290 && x < 1e150) || (x <= 10.0 && x == floor(x)), 0))
-        return exp_digamma_rare(x, c);
-    return v;
+    return exp_digamma_minus(x, c);
 }
 
 }  // namespace trlda

@@ -16,6 +16,7 @@
 #include <condition_variable>
 #include <functional>
 #include <map>
+#include <set>
 #include <memory>
 #include <mutex>
 #include <numeric>
@@ -130,6 +131,12 @@ struct trlda_batch {
     size_t blob_bytes = 0;
     hipEvent_t ready = nullptr, done = nullptr;
     bool used = false;
+    // `done` is recorded when the batch is destroyed, on the stream that used it last (an event
+    // record per use costs a barrier packet per launch sequence); a batch that moves to another
+    // stream settles the first one on the spot
+    hipStream_t last_stream = nullptr;
+    bool last_owned = false;      // last_stream is a model's own stream (see live_own_streams)
+    bool ready_seen = false;      // the upload has been seen complete: no more waits
     uint64_t id = 0;            // unique per batch (an address can be reused by a later batch)
     int device = 0;
     int V = 0, B = 0, max_n = 0;
@@ -306,18 +313,58 @@ int take_event(UploadContext &u, hipEvent_t *ev)
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// the models' own streams that still exist (a destroyed model has synchronised its stream:
+// nothing of it can still be reading a batch)
+struct LiveStreams {
+    std::mutex mu;
+    std::set<hipStream_t> own;
+};
+LiveStreams &live_own_streams()
+{
+    static LiveStreams *all = new LiveStreams();     // never destroyed (see host_pool)
+    return *all;
+}
+
+// `done` <- everything the batch's last stream has been given so far
+void batch_settle(trlda_batch *b)
+{
+    if (!b->used || !b->done)
+        return;
+    if (b->last_owned && b->last_stream) {
+        LiveStreams &ls = live_own_streams();
+        std::lock_guard<std::mutex> lock(ls.mu);
+        if (!ls.own.count(b->last_stream))
+            return;                                  // stream gone, its work complete
+        (void)hipEventRecord(b->done, b->last_stream);
+        return;
+    }
+    (void)hipEventRecord(b->done, b->last_stream);   // the host's stream: alive by contract
+}
+
 // every reader of a batch: wait for its upload, and leave a mark behind
 int batch_begin(trlda_model *m, const trlda_batch *b)
 {
-    if (b && b->ready)
-        HIP_TRY(hipStreamWaitEvent(m->stream, b->ready, 0));
+    if (b && b->ready && !b->ready_seen) {
+        if (hipEventQuery(b->ready) == hipSuccess)
+            const_cast<trlda_batch *>(b)->ready_seen = true;
+        else
+            HIP_TRY(hipStreamWaitEvent(m->stream, b->ready, 0));
+    }
     return TRLDA_OK;
 }
 int batch_end(trlda_model *m, const trlda_batch *b)
 {
     if (b && b->done) {
-        HIP_TRY(hipEventRecord(b->done, m->stream));
-        const_cast<trlda_batch *>(b)->used = true;
+        trlda_batch *bb = const_cast<trlda_batch *>(b);
+        if (bb->used && bb->last_stream != m->stream) {
+            // second stream: it continues behind the first one's readers, so that one record
+            // on it (at destruction) covers both
+            batch_settle(bb);
+            HIP_TRY(hipStreamWaitEvent(m->stream, bb->done, 0));
+        }
+        bb->last_stream = m->stream;
+        bb->last_owned = m->stream == m->own_stream;
+        bb->used = true;
     }
     return TRLDA_OK;
 }
@@ -682,7 +729,7 @@ int dp_exchange(trlda_model *m, const trlda_batch *b)
     }
     if (b->nnz > 0) {
         constexpr int T = 256;
-        const int G = (int)std::min<int64_t>((b->nnz + T - 1) / T, 2048);
+        const int G = (b->B + T / 64 - 1) / (T / 64);
         trlda::DpCuts cuts{};
         for (int r = 0; r <= dp->world; ++r)
             cuts.at[r] = dp->cuts[(size_t)r];
@@ -2009,6 +2056,7 @@ int trlda_batch_destroy(trlda_batch *b)
         std::lock_guard<std::mutex> lock(u.mu);
         // recycle: whoever takes the allocation next waits (on the upload stream) for this
         // batch's last reader; a batch nobody read is guarded by its own upload
+        batch_settle(b);
         hipEvent_t guard = b->used ? b->done : b->ready;
         hipEvent_t spare = b->used ? b->ready : b->done;
         if (spare)
@@ -2062,6 +2110,11 @@ int trlda_model_create(trlda_model **out, int device, int K, int V)
         if (hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess)
             rc = fail(TRLDA_ERR_HIP, "hipStreamCreateWithFlags failed");
         m->stream = m->own_stream;
+        if (!rc) {
+            LiveStreams &ls = live_own_streams();
+            std::lock_guard<std::mutex> lock(ls.mu);
+            ls.own.insert(m->own_stream);
+        }
     }
     if (!rc) rc = dev_alloc(&m->rs_full, (size_t)K);
     if (!rc) rc = dev_alloc(&m->rs_static, (size_t)K);
@@ -2105,8 +2158,13 @@ int trlda_model_destroy(trlda_model *m)
         for (int i = 0; i < 2; ++i) {
             (void)hipFree(m->eeb_pp[i]); (void)hipFree(m->partial_pp[i]);
         }
-        if (m->own_stream)
+        if (m->own_stream) {
+            LiveStreams &ls = live_own_streams();
+            std::lock_guard<std::mutex> lock(ls.mu);
+            (void)hipStreamSynchronize(m->own_stream);
+            ls.own.erase(m->own_stream);
             (void)hipStreamDestroy(m->own_stream);
+        }
 
     }
     delete m;
