@@ -243,6 +243,40 @@ def main():
     RHO, ETA, D_TOTAL = 0.01, 0.3, 1000000
 
     prefetch = not collective and not args.no_prefetch
+    exchange_probe = None
+    if exchange == "factors" and not vworld and (world > 1 or force_dist):
+        # One check of the factor path against the trusted composition (E-step on the shard,
+        # torch.distributed's all-reduce of the K x V statistics) on the first mini-batch: every
+        # rank must see the whole mini-batch's statistics.  Any failure, on any rank, sends all
+        # ranks to the all-reduce path together.
+        ok = 0
+        try:
+            want = torch.empty(KV, dtype=torch.float64, device=device)
+            got = torch.empty(KV, dtype=torch.float64, device=device)
+            _ffi.check(L.trlda_model_estep_io(model, batches[0].handle, gamma0s[0].data_ptr(),
+                                              gamma.data_ptr(), want.data_ptr(), args.max_iter,
+                                              args.threshold, None))
+            torch.cuda.synchronize()
+            dist.all_reduce(want)
+            _ffi.check(L.trlda_model_estep_dp(
+                model, gbatches[0].handle, batches[0].handle, rccl_comm, rank, world,
+                cuts.ctypes.data_as(C.POINTER(C.c_int32)), gamma0s[0].data_ptr(), gamma.data_ptr(),
+                got.data_ptr(), args.max_iter, args.threshold, None, 0, None, 0., 0., 0.))
+            torch.cuda.synchronize()
+            scale_ = float(want.abs().max().item())
+            diff = float((got - want).abs().max().item())
+            ok = int(scale_ > 0 and diff <= 1e-9 * scale_)
+            exchange_probe = {"max_abs_diff_vs_allreduce": diff, "max_abs": scale_}
+            del want, got
+        except Exception as exc:                      # noqa: BLE001
+            exchange_probe = {"error": repr(exc)[:200]}
+        flag = torch.tensor([ok], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            exchange = "sstats"
+            if rank == 0:
+                print("bench: factor exchange failed its check (%s); using the all-reduce of sstats"
+                      % (exchange_probe,), file=sys.stderr)
     if vworld:
         # no collective: the first call copies this rank's slot into the other ranks' (finite,
         # plausible factors), later calls leave the buffer alone
@@ -555,6 +589,7 @@ def main():
                                 "RCCL all-reduce of K x V fp64 sstats, then the M-step "
                                 "(onlinelda.cpp:99-100) that the next step's E-step reads")
                    if collective else "none",
+                   "exchange_check": exchange_probe,
                    "virtual_world": vworld or None},
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,

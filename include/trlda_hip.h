@@ -390,6 +390,12 @@ int trlda_model_estep_dp(trlda_model *model, const trlda_batch *batch, const trl
  * them beyond summation order. */
 /* fused = 0: separate statistics and M-step kernels over all V words (K > 512 always does) */
 int trlda_model_set_fused_update(trlda_model *model, int fused);
+/* Small tables (K <= 128, K * V < 2^22): while a lambda element is in its registers the M-step
+ * kernel also writes exp(psi(.)) of it (src/lda.cpp:173's numerator) and combines the row sums
+ * (src/lda.cpp:172) into a few rows, so the next E-step on the same words starts with its
+ * document kernel: two launches per trust-region iteration instead of three.  enabled = 0: the
+ * next E-step launches its preamble kernel as before (default 1). */
+int trlda_model_set_next_preamble(trlda_model *model, int enabled);
 /* carry = 0: every E-step adds up the rows of lambda again (src/lda.cpp:172 as written) */
 int trlda_model_set_carry_rowsums(trlda_model *model, int carry);
 /* keep = 1: the update entry points also leave the sufficient statistics of their last E-step

@@ -166,3 +166,32 @@ def test_single_rank_without_process_group(oracle, hip_lib):
                                                         max_iter_tr=2)
     assert r == r2 and model.update_count == 1
     assert relerr(model.lambdas, lam) < 1e-12
+
+
+def test_exchange_choice_follows_the_bytes():
+    """ShardedOnlineLDA.use_factors: the factor exchange where world * (docs_r K + nnz_r) doubles
+    are fewer than the all-reduce's 2 K V (BASELINE.json configs 3 and 5), the all-reduce where
+    documents outnumber words (config 4), and never without an engine that implements it."""
+    from trlda_amd.distributed import ShardedOnlineLDA
+    from trlda_amd.documents import CSRDocuments
+
+    class Probe(ShardedOnlineLDA):
+        def __init__(self, K, V, world, capable, exchange="auto"):
+            self._K, self._V, self.world = K, V, world
+            self._factors_ok, self.exchange = capable, exchange
+
+    def even(B, n):
+        return CSRDocuments(np.arange(B + 1, dtype=np.int32) * n, np.zeros(B * n, dtype=np.int32),
+                            np.ones(B * n, dtype=np.int32))
+
+    def choice(K, V, B, n, world, **kw):
+        csr = even(B, n)
+        return Probe(K, V, world, True, **kw).use_factors(csr, csr.shard_cuts(world))
+
+    assert choice(100, 7000, 1600, 90, 8)            # config 3: 0.3 MB per rank against 5.6 MB
+    assert choice(500, 100000, 4096, 100, 8)         # config 5: 2.5 MB per rank against 400 MB
+    assert not choice(200, 50000, 100000, 100, 8)    # config 4: 240 MB gathered against 80 MB
+    assert choice(200, 50000, 100000, 100, 8, exchange="factors")
+    assert not choice(100, 7000, 1600, 90, 8, exchange="sstats")
+    csr = even(16, 5)
+    assert not Probe(10, 100, 2, False).use_factors(csr, csr.shard_cuts(2))

@@ -865,7 +865,7 @@ trlda_amd.seed(3)
 a = OnlineLDA(num_words=V, num_topics=K, num_documents=D)
 ra = [a.update_parameters(d, max_iter_tr=3) for d in docs]
 trlda_amd.seed(3)
-b = ShardedOnlineLDA(V, K, D, device=0)
+b = ShardedOnlineLDA(V, K, D, device=0, exchange="sstats")
 assert b.world == 1 and dist.is_initialized()
 b._all_reduce_calls = 0
 orig = b._all_reduce
@@ -878,6 +878,13 @@ rb = [b.update_parameters(d, max_iter_tr=3) for d in docs]
 assert ra == rb and b.update_count == 2
 assert b._all_reduce_calls == 2 * (1 + 3)      # word counts + one per trust-region E-step
 assert float(np.max(np.abs(a.lambdas - b.lambdas) / b.lambdas)) < 1e-10   # fused vs composed M-step
+# the factor exchange (the default where it moves fewer bytes): the single-GPU call, bit for bit
+trlda_amd.seed(3)
+c = ShardedOnlineLDA(V, K, D, device=0)
+assert c.use_factors(docs[0], docs[0].shard_cuts(1))
+rc = [c.update_parameters(d, max_iter_tr=3) for d in docs]
+assert rc == ra and c.update_count == 2
+assert np.array_equal(a.lambdas, c.lambdas)
 dist.destroy_process_group()
 print("RCCL1-OK")
 """ % ROOT_DIR)

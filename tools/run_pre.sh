@@ -1,12 +1,13 @@
 cd $GRAFT_REPO_ROOT
-python bench.py --parity-only --no-update-rates --steps 400 --warmup 50 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('pre', d['value'], d['ms_per_step'], list(d['roofline']['kernels_us'].values()), d['parity'])
-"
-python bench.py --parity-only --no-update-rates --steps 400 --warmup 50 --no-prefetch 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('nopre', d['value'], d['ms_per_step'], list(d['roofline']['kernels_us'].values()))
-"
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
+export TMPDIR=/tmp
+mkdir -p gpurun_out/np
+timeout 1500 python -m pytest tests/test_gpu_update_loop.py tests/test_gpu_dp.py -x -q -m gpu 2>&1 | tail -4
+python tools/update_rate.py --configs small,c3 --modes fused 2>&1 | grep -v amdgpu.ids
+rocprofv3 --kernel-trace --stats -d gpurun_out/np/prof_draw -o p --output-format csv -- python3 tools/update_rate.py --configs small --modes fused > gpurun_out/np/prof_draw.log 2>&1
+f=$(find gpurun_out/np/prof_draw -name "*kernel_stats.csv" | head -1)
+python - <<PY
+import csv
+rows=list(csv.DictReader(open("$f")))
+for r in rows[:12]:
+    print("%-70s calls %6s avg %9.1f ns total %10s" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]), r["TotalDurationNs"]))
+PY

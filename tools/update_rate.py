@@ -71,8 +71,12 @@ def main():
                 m._ada_gradient = None
             m._setup(V, K, .1, .3, None, _lambda=lam)
             if has_switch:
-                L.trlda_model_set_fused_update(m._handle, int(mode == "fused"))
-                L.trlda_model_set_carry_rowsums(m._handle, int(mode == "fused"))
+                L.trlda_model_set_fused_update(m._handle, int(mode != "plain"))
+                L.trlda_model_set_carry_rowsums(m._handle, int(mode != "plain"))
+            if mode == "fused_sep":        # fused M-step, but every E-step launches its preamble
+                if not hasattr(L, "trlda_model_set_next_preamble"):
+                    continue
+                L.trlda_model_set_next_preamble(m._handle, 0)
             if args.host_draw and hasattr(L, "trlda_model_set_host_gamma_draw"):
                 L.trlda_model_set_host_gamma_draw(m._handle, 1)
             batch = m.upload(docs)

@@ -99,6 +99,7 @@ _SIGNATURES = {
                                        vp, C.c_int, C.c_double, vp, C.c_int, vp, C.c_double,
                                        C.c_double, C.c_double]),
     "trlda_model_set_fused_update": (C.c_int, [vp, C.c_int]),
+    "trlda_model_set_next_preamble": (C.c_int, [vp, C.c_int]),
     "trlda_model_set_carry_rowsums": (C.c_int, [vp, C.c_int]),
     "trlda_model_set_keep_sstats": (C.c_int, [vp, C.c_int]),
     "trlda_model_d2h_bytes": (C.c_int64, [vp]),

@@ -1383,7 +1383,64 @@ struct UpdateOut {
     const double *lambda_prime;   // K x V, or nullptr: lambda = rho * (eta + scale * s)
     double omr, rho, eta, scale;
     double *partial;              // gridDim.x x K, or nullptr
+    // The next E-step's preamble, while lambda is in registers: u = exp(psi(lambda)) of every
+    // element written (may be the buffer `eeb` is read from: an element is read and replaced by
+    // the same thread), and the block partials of the row sums combined in groups of
+    // `group_size` consecutive blocks by the LAST block of each group to finish (a counter per
+    // group, reset by that block) -- few enough rows for the document kernel to add up itself
+    // (estep_kernels.h, topic_scale_*), in a fixed order whatever block comes last.
+    double *u_out;                // K x V, or nullptr
+    double *group_rows;           // ceil(gridDim.x / group_size) x K, or nullptr
+    const double *group_base;     // K, added into group 0 (the words outside the batch), or nullptr
+    unsigned int *group_counter;  // one per group, zero between launches
+    int group_size;
 };
+
+// Row k of a block's partial sums, for finish_partial_groups: stored and loaded with agent-scope
+// atomics (on gfx950: sc1 accesses, served by the memory side, coherent across the XCDs' L2s).
+// The ordering that makes the last block see every row is then a matter of the store having
+// been acknowledged before the block's counter increment is issued -- a workgroup-scope release
+// (s_waitcnt vmcnt(0)) -- instead of an agent-scope fence, whose L2 write-back of everything the
+// kernel has written so far (all of lambda) cost 300 us per launch when it was tried.
+__device__ __forceinline__ void store_partial(const UpdateOut &o, size_t idx, double v)
+{
+    if (o.group_rows)
+        __hip_atomic_store(o.partial + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        o.partial[idx] = v;
+}
+
+// the end of a block of the statistics kernels, after its row of o.partial has been written
+template <int T>
+__device__ __forceinline__ void finish_partial_groups(const UpdateOut &o, int K)
+{
+    if (!o.group_rows)                               // launch-uniform
+        return;
+    __shared__ int last_of_group;
+    const int rows = (int)gridDim.x;
+    const int g = (int)blockIdx.x / o.group_size;
+    const int r0 = g * o.group_size, r1 = min(rows, r0 + o.group_size);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this thread's row stores: acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int seen = __hip_atomic_fetch_add(&o.group_counter[g], 1u, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+        const int last = seen + 1u == (unsigned int)(r1 - r0);
+        if (last)                                    // for the next launch (stream order)
+            __hip_atomic_store(&o.group_counter[g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_of_group = last;
+    }
+    __syncthreads();
+    if (!last_of_group)
+        return;
+    for (int k = threadIdx.x; k < K; k += T) {
+        double sum = (g == 0 && o.group_base) ? o.group_base[k] : 0.0;
+        for (int r = r0; r < r1; ++r)
+            sum += __hip_atomic_load(o.partial + (size_t)r * K + k, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+        o.group_rows[(size_t)g * K + k] = sum;
+    }
+}
 
 __device__ __forceinline__ double update_one(const UpdateOut &o, size_t i, double s)
 {
@@ -1394,6 +1451,8 @@ __device__ __forceinline__ double update_one(const UpdateOut &o, size_t i, doubl
         const double hat = o.eta + o.scale * s;
         lam = o.lambda_prime ? o.omr * o.lambda_prime[i] + o.rho * hat : o.rho * hat;
         o.lambda[i] = lam;
+        if (o.u_out)
+            o.u_out[i] = exp_digamma(lam);
     }
     return lam;
 }
@@ -1403,7 +1462,7 @@ __global__ __launch_bounds__(T) void sstats_update_kernel(
     int K, int N, int G_short, int n_long, const int32_t *__restrict__ list,
     const int32_t *__restrict__ wptr, const int32_t *__restrict__ wdoc,
     const int32_t *__restrict__ long_words, const double *__restrict__ tw_word,
-    const double *__restrict__ epg, const double *__restrict__ eeb, UpdateOut o)
+    const double *__restrict__ epg, const double *eeb /* may be o.u_out */, UpdateOut o)
 {
     constexpr int W = T / kWave;
     extern __shared__ double wpart[];                // W x K
@@ -1454,8 +1513,9 @@ __global__ __launch_bounds__(T) void sstats_update_kernel(
                 double sum = wpart[k];
                 for (int c = 1; c < W; ++c)
                     sum += wpart[c * K + k];
-                o.partial[(size_t)blockIdx.x * K + k] = sum;
+                store_partial(o, (size_t)blockIdx.x * K + k, sum);
             }
+            finish_partial_groups<T>(o, K);
         }
         return;
     }
@@ -1511,8 +1571,9 @@ __global__ __launch_bounds__(T) void sstats_update_kernel(
         for (int c = 0; c < (512 + T - 1) / T; ++c) {
             const int k = threadIdx.x + c * T;
             if (k < K)
-                o.partial[(size_t)blockIdx.x * K + k] = rsl[c];
+                store_partial(o, (size_t)blockIdx.x * K + k, rsl[c]);
         }
+        finish_partial_groups<T>(o, K);
     }
 }
 
@@ -1584,6 +1645,8 @@ __device__ __forceinline__ double2 update_pair(const UpdateOut &o, size_t i, dou
             lam.y = o.rho * hy;
         }
         *reinterpret_cast<double2 *>(o.lambda + i) = lam;
+        if (o.u_out)
+            *reinterpret_cast<double2 *>(o.u_out + i) = make_double2(exp_digamma(lam.x), exp_digamma(lam.y));
     }
     return lam;
 }
@@ -1593,7 +1656,7 @@ __global__ __launch_bounds__(T) void sstats_update2_kernel(
     int K, int N, int G_short, int n_long, const int32_t *__restrict__ list,
     const int32_t *__restrict__ wptr, const int32_t *__restrict__ wdoc,
     const int32_t *__restrict__ long_words, const double *__restrict__ tw_word,
-    const double *__restrict__ epg, const double *__restrict__ eeb, UpdateOut o)
+    const double *__restrict__ epg, const double *eeb /* may be o.u_out */, UpdateOut o)
 {
     constexpr int W = T / kWave;
     constexpr int BW = 128 * NH;                     // topics per pass over a word's list
@@ -1655,8 +1718,9 @@ __global__ __launch_bounds__(T) void sstats_update2_kernel(
                 double sum = wpart2[k];
                 for (int c = 1; c < W; ++c)
                     sum += wpart2[c * K + k];
-                o.partial[(size_t)blockIdx.x * K + k] = sum;
+                store_partial(o, (size_t)blockIdx.x * K + k, sum);
             }
+            finish_partial_groups<T>(o, K);
         }
         return;
     }
@@ -1714,8 +1778,9 @@ __global__ __launch_bounds__(T) void sstats_update2_kernel(
         for (int c = 0; c < (512 + T - 1) / T; ++c) {
             const int k = threadIdx.x + c * T;
             if (k < K)
-                o.partial[(size_t)blockIdx.x * K + k] = rsl[c];
+                store_partial(o, (size_t)blockIdx.x * K + k, rsl[c]);
         }
+        finish_partial_groups<T>(o, K);
     }
 }
 

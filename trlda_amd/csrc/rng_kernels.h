@@ -10,9 +10,9 @@
 // a 31 x 31 matrix over Z / 2^32.  So the stream is cut into segments of kRngSegment draws:
 //
 //   window_level_kernel   the window at the start of every segment, W_s = A^(s L) W_0, built
-//                         radix 16: W_(d 16^l + r) = M[l][d] W_r, one matrix-vector product per
-//                         segment (M[l][d] = A^(d 16^l L): 15 matrices per level, computed once
-//                         on the host)
+//   / window_direct_kernel  radix 16: W_(d 16^l + r) = M[l][d] W_r, one matrix-vector product per
+//                         segment and level (M[l][d] = A^(d 16^l L): 15 matrices per level,
+//                         computed once on the host)
 //   draw_log_kernel       one thread per segment walks its L draws (window in LDS, a rotating
 //                         index) and stores log|u| of every draw -- the same integers, hence
 //                         the same u, as the host stream; the device logarithm may differ from
@@ -39,13 +39,12 @@ constexpr long long kRngSmallDraws = (long long)1 << 25;
 constexpr int kRngLevels = 8;         // 16^8 segments: more than any table needs
 constexpr int kRngThreads = 256;
 
-// windows are stored word-major: win[j * S + s], j < 31.  Two forms of one level:
-//   window_level_kernel       one thread per window (961 serial multiply-adds: fine when there
-//                             are hundreds of thousands of windows to keep the chip busy)
-//   window_level_coop_kernel  one window per 32 lanes, lane i < 31 forms word i of M w (31
-//                             multiply-adds): a few hundred cycles of latency per level, for
-//                             requests with few windows (8.2 against 14.3 us per level at 31 000
-//                             windows; 98 against 35 us at 800 000)
+// windows are stored word-major: win[j * S + s], j < 31.
+//   window_level_kernel   one level, one thread per window (961 serial multiply-adds: fine when
+//                         there are hundreds of thousands of windows to keep the chip busy)
+//   window_direct_kernel  every level in one launch, 32 lanes per window (below): for requests
+//                         with few windows, where the chain of launches was most of the time
+//                         (4 x 8.1 us of levels + 4.5 us of seeding at 31 000 windows)
 template <int T>
 __global__ __launch_bounds__(T) void window_level_kernel(long long S, long long lo, long long hi,
                                                          long long unit /* 16^level */,
@@ -72,24 +71,44 @@ __global__ __launch_bounds__(T) void window_level_kernel(long long S, long long 
     }
 }
 
+// All levels in one launch, for requests with few windows (a chain of small dependent launches
+// costs ~8 us each, whatever they do): 32 lanes form window s directly from the seed window,
+// W_s = prod_l M[l][digit_l(s)] W_0 (powers of one matrix: any order), the 31 words handed
+// around through an LDS line between the levels.
+struct RngSeedWindow {
+    uint32_t w[31];
+};
+
 template <int T>
-__global__ __launch_bounds__(T) void window_level_coop_kernel(long long S, long long lo, long long hi,
-                                                              long long unit,
-                                                              const uint32_t *__restrict__ mats,
-                                                              uint32_t *__restrict__ win)
+__global__ __launch_bounds__(T) void window_direct_kernel(long long S, int levels, RngSeedWindow w0,
+                                                          const uint32_t *__restrict__ mats_t,
+                                                          uint32_t *__restrict__ win)
 {
-    const long long s = lo + ((long long)blockIdx.x * T + threadIdx.x) / 32;
-    const int i = threadIdx.x & 31;
-    if (s >= hi || i >= 31)
-        return;
-    const int d = (int)(s / unit);
-    const long long r = s - (long long)d * unit;
-    const uint32_t *M = mats + (size_t)(d - 1) * 961 + (size_t)i * 31;
-    uint32_t acc = 0;
+    __shared__ uint32_t line[2][T];                  // per 32 lanes: the window's 31 words
+    const long long s = ((long long)blockIdx.x * T + threadIdx.x) / 32;
+    const int i = threadIdx.x & 31, base = threadIdx.x & ~31;
+    const int row = min(i, 30);
+    uint32_t w = w0.w[row];
+    long long rest = s;
+    int buf = 0;
+    for (int l = 0; l < levels; ++l) {               // (the same trip count in every thread)
+        const int d = (int)(rest & 15);
+        rest >>= 4;
+        line[buf][threadIdx.x] = w;
+        __syncthreads();
+        if (d != 0) {                                // uniform over the 32 lanes of a window
+            // (transposed matrices: the lanes of a window read consecutive words)
+            const uint32_t *Mt = mats_t + ((size_t)l * 15 + (size_t)(d - 1)) * 961 + row;
+            uint32_t acc = 0;
 #pragma unroll
-    for (int j = 0; j < 31; ++j)
-        acc += M[j] * win[(size_t)j * S + r];
-    win[(size_t)i * S + s] = acc;
+            for (int j = 0; j < 31; ++j)
+                acc += Mt[j * 31] * line[buf][base + j];
+            w = acc;
+        }
+        buf ^= 1;                                    // the next level writes the other line
+    }
+    if (s < S && i < 31)
+        win[(size_t)i * S + s] = w;
 }
 
 // positions [pos_lo, pos_hi) of the stream (a whole number of passes of `total` elements);
@@ -169,13 +188,14 @@ __global__ __launch_bounds__(T) void gamma_sum_kernel(long long total, long long
     out += -e_lo;
     double acc = first ? 0.0 : out[i];
     int p = 0;
-    for (; p + 4 <= passes; p += 4) {
-        const double v0 = vbuf[(size_t)p * total + i], v1 = vbuf[(size_t)(p + 1) * total + i],
-                     v2 = vbuf[(size_t)(p + 2) * total + i], v3 = vbuf[(size_t)(p + 3) * total + i];
-        acc -= v0;
-        acc -= v1;
-        acc -= v2;
-        acc -= v3;
+    for (; p + 20 <= passes; p += 20) {              // twenty loads in flight, subtracted in order
+        double v[20];
+#pragma unroll
+        for (int q = 0; q < 20; ++q)
+            v[q] = vbuf[(size_t)(p + q) * total + i];
+#pragma unroll
+        for (int q = 0; q < 20; ++q)
+            acc -= v[q];
     }
     for (; p < passes; ++p)
         acc -= vbuf[(size_t)p * total + i];

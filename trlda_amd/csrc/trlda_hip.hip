@@ -76,6 +76,7 @@ unsigned long long *g_stamp_buf = nullptr;
 #endif
 constexpr int kDenseThreads = 256;
 constexpr int kMaxRowsumBlocks = 1025;   // rows of trlda_model::partial (block partials of row sums)
+constexpr int kUpdGroups = 64;           // rows the document kernel adds up itself (topic_scale_load)
 constexpr int kCarryBlocks = 8;          // preamble_fused_kernel: workgroups adding up carried partials
 constexpr int kUpdShortBlocks = 1024;    // sstats_update_kernel: blocks walking the short lists
 constexpr int kUpdLongBlocks = 256;      //                       blocks walking the long lists
@@ -213,6 +214,16 @@ struct trlda_model {
     const double *carry_rows = nullptr, *carry_base = nullptr;
     int carry_n = 0;
     double *carry_out = nullptr;        // kCarryBlocks x K
+    // The preamble the last M-step kernel left behind (UpdateOut::u_out / group_rows): valid for
+    // lambda_version `version`, for every word (`all`) or the active words of batch `batch_id`
+    double *upd_groups = nullptr;       // kUpdGroups x K
+    unsigned int *group_counter = nullptr;
+    struct {
+        bool valid = false, all = false;
+        uint64_t version = 0, batch_id = 0;
+        int n = 0;
+    } next_pre;
+    bool emit_next_preamble = true;     // trlda_model_set_fused_update(.. & 2 == 0)
     bool carry_rowsums = true;          // trlda_model_set_carry_rowsums (tests, comparisons)
     bool fused_update = true;           // trlda_model_set_fused_update: statistics + M-step in one pass
     bool keep_sstats = false;           // updates also leave the statistics (and all of lambda') behind
@@ -527,7 +538,13 @@ struct EstepOut {
     trlda::UpdateOut upd;       // sstats and / or the M-step (estep_kernels.h, 4c)
     bool active_only = false;   // walk the batch's active words only (fused path)
     int partial_rows = 0;       // out: rows written to upd.partial
-    EstepOut() { upd = trlda::UpdateOut{nullptr, nullptr, nullptr, 0., 0., 0., 0., nullptr}; }
+    // in: the M-step may also leave the next E-step's preamble behind (exp(psi(lambda)) of the
+    // words it writes + the row sums in few rows; next_base = the share of the words it does
+    // not write, final at launch time, or nullptr).  out: it did, in `groups` rows
+    bool emit_next = false;
+    const double *next_base = nullptr;
+    int groups = 0;
+    EstepOut() { upd = trlda::UpdateOut{}; }
     explicit EstepOut(double *sstats) : EstepOut() { upd.sstats = sstats; }
 };
 
@@ -622,6 +639,21 @@ int launch_sstats_update(trlda_model *m, const trlda_batch *b, EstepOut &out)
     int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (rc)
         return rc;
+    out.groups = 0;
+    out.upd.u_out = nullptr;
+    out.upd.group_rows = nullptr;
+    out.upd.group_base = nullptr;
+    out.upd.group_counter = nullptr;
+    out.upd.group_size = 1;
+    if (out.emit_next && out.upd.lambda && out.upd.partial) {
+        const int rows = G_short + G_long;
+        out.upd.u_out = m->eeb;
+        out.upd.group_rows = m->upd_groups;
+        out.upd.group_base = out.next_base;
+        out.upd.group_counter = m->group_counter;
+        out.upd.group_size = (rows + kUpdGroups - 1) / kUpdGroups;
+        out.groups = (rows + out.upd.group_size - 1) / out.upd.group_size;
+    }
     // (data-parallel: expElogtheta rows of all ranks in the gathered buffer, dp_kernels.h)
     hipLaunchKernelGGL(kern, dim3(G_short + G_long), dim3(T), lds, m->stream, K, N, G_short,
                        b->n_long, out.active_only ? b->active : nullptr, b->wptr,
@@ -742,6 +774,21 @@ int dp_exchange(trlda_model *m, const trlda_batch *b)
     return TRLDA_OK;
 }
 
+// the small-table path: one launch for row sums + exp(psi(lambda)), topic factors applied by the
+// register-resident document kernel (estep_kernels.h, 2b) -- what a batch and a model must be like
+bool fused_preamble_possible(const trlda_model *m, const trlda_batch *docs)
+{
+    return (size_t)m->K * m->V < ((size_t)1 << 22) && docs->B > 0 && m->doc_threads == 0 &&
+           m->doc_kernel == TRLDA_DOCS_AUTO && !m->split_preamble && m->K <= trlda::kRegMaxK &&
+           docs->max_n <= trlda::kRegMaxN && !m->lambda_exposed;
+}
+
+// may the M-step kernel of an E-step on `docs` leave the next preamble behind?
+bool can_emit_next(const trlda_model *m, const trlda_batch *docs)
+{
+    return m->emit_next_preamble && m->carry_rowsums && fused_preamble_possible(m, docs);
+}
+
 // The E-step launch sequence on the model's stream (no synchronisation).  `out` says what the
 // statistics stage writes; an M-step in it (out.upd.lambda) needs fused_update_available().
 int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepOut &out,
@@ -790,14 +837,23 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
     // 2 become one launch and the topic factors exp(-psiSum) are applied by the document
     // kernel (estep_kernels.h, 2b) -- as long as no row sum can be so small that exp(-psi(sum))
     // overflows (rs_floor: a bound the host keeps through every update)
-    const bool fused = !big && B > 0 && m->doc_threads == 0 && m->doc_kernel == TRLDA_DOCS_AUTO &&
-                       !m->split_preamble && K <= trlda::kRegMaxK && db->max_n <= trlda::kRegMaxN &&
-                       trust && m->rs_floor >= kFusedRowsumFloor;
+    const bool fused = fused_preamble_possible(m, db) && trust && m->rs_floor >= kFusedRowsumFloor;
     m->last_preamble_fused = fused;
     if (!fused && carried && (rc = resolve_carry(m)))   // everything else wants one row of sums
         return rc;
     m->eeb_cur = m->eeb;
-    // this batch's preamble may have been prepared under the previous call's document kernel
+    // this batch's preamble may have been left behind by the kernel that wrote lambda (the
+    // M-step inside the statistics kernel: UpdateOut::u_out / group_rows) ...
+    const bool handed = fused && carried && m->carry_pending && m->next_pre.valid &&
+                        m->next_pre.version == m->lambda_version &&
+                        (m->next_pre.all || m->next_pre.batch_id == b->id);
+    if (handed) {
+        partial_in = m->upd_groups;
+        G = m->next_pre.n;
+        if (m->timing && ((rc = stamp(m)) || (rc = stamp(m))))
+            return rc;
+    }
+    // ... or prepared under the previous call's document kernel
     const bool prefetched = fused && !carried && m->prefetch.valid && m->prefetch.batch_id == b->id &&
                             m->prefetch.version == m->lambda_version &&
                             m->prefetch.dense == m->dense_preamble;
@@ -811,7 +867,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
             return rc;
     }
     m->prefetch.valid = false;
-    if (fused && !prefetched) {
+    if (fused && !prefetched && !handed) {
         constexpr int TP = 512;
         int wpb = 0, GC = 0;
         const double *carry_rows = nullptr, *carry_base = nullptr;
@@ -1690,9 +1746,7 @@ const std::vector<uint32_t> &rng_level_matrices(int L)
     return all.emplace(L, std::move(mats)).first->second;
 }
 
-struct RngSeedWindow {
-    uint32_t w[31];
-};
+using trlda::RngSeedWindow;
 
 __global__ void window_seed_kernel(long long S, RngSeedWindow w0, uint32_t *win)
 {
@@ -1709,7 +1763,15 @@ int rng_device_matrices(int device, int L, const uint32_t **out)
     auto key = std::make_tuple(getpid(), device, L);
     auto it = all.find(key);
     if (it == all.end()) {
-        const std::vector<uint32_t> &h = rng_level_matrices(L);
+        // row-major for window_level_kernel, then the transposes for window_direct_kernel (its 31
+        // lanes of a window read one column entry each: consecutive words)
+        std::vector<uint32_t> h = rng_level_matrices(L);
+        const size_t n = h.size();
+        h.resize(2 * n);
+        for (size_t mtx = 0; mtx < n / 961; ++mtx)
+            for (int i = 0; i < 31; ++i)
+                for (int j = 0; j < 31; ++j)
+                    h[n + mtx * 961 + (size_t)j * 31 + i] = h[mtx * 961 + (size_t)i * 31 + j];
         uint32_t *d = nullptr;
         int rc = dev_alloc(&d, h.size());
         if (rc)
@@ -1744,21 +1806,29 @@ int sample_gamma_on_device(trlda_model *m, long long total, int passes, double d
         return rc;
     RngSeedWindow w0;
     rng_to_window(g_rng, w0.w);
-    hipLaunchKernelGGL(window_seed_kernel, dim3(1), dim3(64), 0, m->stream, S, w0, m->rng_win);
     long long unit = 1;
-    for (int l = 0; l < trlda::kRngLevels && unit < S; ++l, unit *= 16) {
-        const long long lo = unit, hi = std::min<long long>(S, unit * 16);
-        if (S < 200000)
-            hipLaunchKernelGGL(trlda::window_level_coop_kernel<T>,
-                               dim3((unsigned)(((hi - lo) * 32 + T - 1) / T)), dim3(T), 0, m->stream, S,
-                               lo, hi, unit, mats + (size_t)l * 15 * 961, m->rng_win);
-        else
-            hipLaunchKernelGGL(trlda::window_level_kernel<T>, dim3((unsigned)((hi - lo + T - 1) / T)),
-                               dim3(T), 0, m->stream, S, lo, hi, unit, mats + (size_t)l * 15 * 961,
-                               m->rng_win);
+    int levels = 0;
+    while (levels < trlda::kRngLevels && unit < S) {
+        unit *= 16;
+        ++levels;
     }
     if (unit < S)
         return fail(TRLDA_ERR_ARG, "sampleGamma request too large for the device generator");
+    if (S < 200000) {
+        // few windows: every one straight from the seed window, one launch
+        hipLaunchKernelGGL(trlda::window_direct_kernel<T>, dim3((unsigned)((S * 32 + T - 1) / T)), dim3(T),
+                           0, m->stream, S, levels, w0, mats + (size_t)trlda::kRngLevels * 15 * 961,
+                           m->rng_win);
+    } else {
+        hipLaunchKernelGGL(window_seed_kernel, dim3(1), dim3(64), 0, m->stream, S, w0, m->rng_win);
+        unit = 1;
+        for (int l = 0; l < levels; ++l, unit *= 16) {
+            const long long lo = unit, hi = std::min<long long>(S, unit * 16);
+            hipLaunchKernelGGL(trlda::window_level_kernel<T>, dim3((unsigned)((hi - lo + T - 1) / T)),
+                               dim3(T), 0, m->stream, S, lo, hi, unit, mats + (size_t)l * 15 * 961,
+                               m->rng_win);
+        }
+    }
     for (long long p0 = 0; p0 < passes; p0 += group) {
         const long long p1 = std::min<long long>(passes, p0 + group);
         const long long pos_lo = p0 * total, pos_hi = p1 * total;
@@ -2120,6 +2190,14 @@ int trlda_model_create(trlda_model **out, int device, int K, int V)
     if (!rc) rc = dev_alloc(&m->rs_static, (size_t)K);
     if (!rc) rc = dev_alloc(&m->upd_partial, (size_t)(kUpdShortBlocks + kUpdLongBlocks) * K);
     if (!rc) rc = dev_alloc(&m->carry_out, (size_t)kCarryBlocks * K);
+    if (!rc) rc = dev_alloc(&m->upd_groups, (size_t)kUpdGroups * K);
+    if (!rc) {
+        void *p = nullptr;
+        if (hipMalloc(&p, kUpdGroups * sizeof(unsigned int)) != hipSuccess ||
+            hipMemset(p, 0, kUpdGroups * sizeof(unsigned int)) != hipSuccess)
+            rc = fail(TRLDA_ERR_HIP, "hipMalloc failed");
+        m->group_counter = static_cast<unsigned int *>(p);
+    }
     // columns of words no batch has touched yet are never read for their value, but the
     // atomic-mode finish multiplies them by 0: keep them finite
     if (!rc && (hipMemset(m->counter, 0, sizeof(unsigned int)) != hipSuccess ||
@@ -2145,7 +2223,7 @@ int trlda_model_destroy(trlda_model *m)
         (void)hipFree(m->tw_word); (void)hipFree(m->dp_gather); (void)hipFree(m->dp_wdoc); (void)hipFree(m->lambda_prime); (void)hipFree(m->sstats); (void)hipFree(m->gamma);
         (void)hipFree(m->wordcounts); (void)hipFree(m->rs_full); (void)hipFree(m->rs_static);
         (void)hipFree(m->upd_partial); (void)hipFree(m->ada_gradient); (void)hipFree(m->reduce_out);
-        (void)hipFree(m->carry_out);
+        (void)hipFree(m->carry_out); (void)hipFree(m->upd_groups); (void)hipFree(m->group_counter);
         (void)hipFree(m->iters); (void)hipFree(m->rng_win); (void)hipFree(m->rng_vbuf);
         for (int i = 0; i < 2; ++i) {
             if (m->stage[i])
@@ -2541,9 +2619,19 @@ int carry_rowsums_from(trlda_model *m, const double *rows, int n, const double *
     return TRLDA_OK;
 }
 
-int finish_rowsums(trlda_model *m, const EstepOut &out, const double *base, double floor)
+int finish_rowsums(trlda_model *m, const EstepOut &out, const double *base, double floor,
+                   const trlda_batch *b = nullptr)
 {
-    return carry_rowsums_from(m, out.upd.partial, out.partial_rows, base, floor);
+    int rc = carry_rowsums_from(m, out.upd.partial, out.partial_rows, base, floor);
+    // (carry_rowsums_from moved lambda_version on: what the kernel left behind belongs to the new one)
+    m->next_pre.valid = !rc && out.groups > 0 && b && base == out.next_base;
+    if (m->next_pre.valid) {
+        m->next_pre.all = !out.active_only;
+        m->next_pre.version = m->lambda_version;
+        m->next_pre.batch_id = b->id;
+        m->next_pre.n = out.groups;
+    }
+    return rc;
 }
 
 // rs_full for the E-step that follows, when nothing carried it here (big tables only: the
@@ -2603,10 +2691,15 @@ int online_update_fused(trlda_model *m, const trlda_batch *b, int num_documents,
             const bool last = i + 1 == max_iter_tr;
             out.active_only = !(keep && last);
             out.upd.sstats = (keep && last) ? m->sstats : nullptr;
+            // the next iteration's E-step runs on the same batch: its exp(psi(lambda)) and row
+            // sums come out of this iteration's M-step (after the last one only when every word
+            // was written: whatever batch comes next is covered)
+            out.next_base = out.active_only ? m->rs_static : nullptr;
+            out.emit_next = can_emit_next(m, m->dp ? m->dp->shard : b) && (!last || !out.active_only);
             if (!rc)
                 rc = estep_device(m, b, m->gamma, out, max_iter_inference, threshold, nullptr);
             if (!rc)
-                rc = finish_rowsums(m, out, out.active_only ? m->rs_static : nullptr, floor_after);
+                rc = finish_rowsums(m, out, out.next_base, floor_after, b);
         }
         return rc;
     }
@@ -2622,8 +2715,9 @@ int online_update_fused(trlda_model *m, const trlda_batch *b, int num_documents,
         out.active_only = false;
         out.upd.sstats = m->sstats;
         out.upd.lambda_prime = m->lambda_prime;
+        out.emit_next = can_emit_next(m, m->dp ? m->dp->shard : b);
         rc = estep_device(m, b, m->gamma, out, max_iter_inference, threshold, nullptr);
-        if (!rc) rc = finish_rowsums(m, out, nullptr, floor_after);
+        if (!rc) rc = finish_rowsums(m, out, nullptr, floor_after, b);
         return rc;
     }
     out.active_only = true;
@@ -2754,6 +2848,9 @@ int trlda_model_batch_update(trlda_model *m, const trlda_batch *b, double eta, i
             out.upd.partial = m->upd_partial;
             out.upd.sstats = m->keep_sstats ? m->sstats : nullptr;
             out.active_only = !m->keep_sstats;
+            // (first epoch: the share of the words outside the batch is not known yet)
+            out.next_base = out.active_only ? m->rs_static : nullptr;
+            out.emit_next = can_emit_next(m, b) && !(first && out.active_only) && epoch + 1 < max_epochs;
             if (!rc)
                 rc = estep_device(m, b, m->gamma, out, max_iter_inference, threshold, nullptr);
             if (!rc && first && out.active_only) {
@@ -2766,7 +2863,7 @@ int trlda_model_batch_update(trlda_model *m, const trlda_batch *b, double eta, i
                 if (!rc) rc = combine_rowsums(m, m->partial, G, nullptr, m->rs_static);
             }
             if (!rc)
-                rc = finish_rowsums(m, out, out.active_only ? m->rs_static : nullptr, m->V * eta);
+                rc = finish_rowsums(m, out, out.active_only ? m->rs_static : nullptr, m->V * eta, b);
             first = false;
         } else {
             rc = estep_device(m, b, m->gamma, m->sstats, max_iter_inference, threshold, nullptr);
@@ -2858,10 +2955,11 @@ int trlda_model_cumulative_update(trlda_model *m, const trlda_batch *b, int max_
                 out.upd.partial = m->upd_partial;
                 out.upd.sstats = m->keep_sstats ? m->sstats : nullptr;
                 out.active_only = false;
+                out.emit_next = can_emit_next(m, b);
                 if (!rc)
                     rc = estep_device(m, b, m->gamma, out, max_iter_inference, threshold, nullptr);
                 if (!rc)
-                    rc = finish_rowsums(m, out, nullptr, floor_prime);
+                    rc = finish_rowsums(m, out, nullptr, floor_prime, b);
             } else {
                 rc = estep_device(m, b, m->gamma, m->sstats, max_iter_inference, threshold, nullptr);
                 if (!rc) {
@@ -3085,13 +3183,14 @@ int trlda_model_estep_dp(trlda_model *m, const trlda_batch *batch, const trlda_b
         out.upd.lambda_prime = lambda_prime_dev ? lambda_prime_dev : m->lambda;
         out.upd.partial = m->upd_partial;
         out.active_only = false;
+        out.emit_next = can_emit_next(m, shard);
         rc = ensure_update_workspace(m, 1);
         if (!rc) rc = ensure_rowsums(m);
     }
     if (!rc)
         rc = estep_device(m, batch, gamma_dev, out, max_iter, threshold, iters_dev, gamma0_dev);
     if (!rc && mstep)
-        rc = finish_rowsums(m, out, nullptr, rho * m->V * eta);
+        rc = finish_rowsums(m, out, nullptr, rho * m->V * eta, batch);
     m->dp = nullptr;
     return rc;
 }
@@ -3111,6 +3210,15 @@ int trlda_model_set_carry_rowsums(trlda_model *m, int carry)
     if (!m)
         return fail(TRLDA_ERR_ARG, "model is NULL");
     m->carry_rowsums = carry != 0;
+    return TRLDA_OK;
+}
+
+int trlda_model_set_next_preamble(trlda_model *m, int enabled)
+{
+    if (!m)
+        return fail(TRLDA_ERR_ARG, "model is NULL");
+    m->emit_next_preamble = enabled != 0;
+    m->next_pre.valid = false;
     return TRLDA_OK;
 }
 

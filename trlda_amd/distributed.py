@@ -1,6 +1,13 @@
 """Data-parallel OnlineLDA over the GPUs of one node: one process per GPU,
 ``torch.distributed`` (backend "nccl" == RCCL over xGMI on ROCm).
 
+Two ways of meeting at the reference's reduction point (lda.cpp:211-217), chosen per call by the
+bytes they move (``exchange="auto"``): the all-reduce of the K x V statistics described below,
+and the FACTOR exchange of csrc/dp_kernels.h -- an all-gather of every document's expElogtheta
+row and per-entry weights (8 (K + n_d) bytes per document) after which every rank forms the
+whole mini-batch's statistics and the fused M-step itself, through
+``trlda_model_online_update_dp`` on a RCCL communicator of the process's own (``rccl.py``).
+
 Documents are independent given lambda (reference src/lda.cpp:176-214 touches only
 column i of gamma and *adds* into sstats), so a mini-batch is split into contiguous
 document ranges, one per rank.  lambda is replicated; every rank computes its own
@@ -46,6 +53,29 @@ class HipEngine(object):
         self.sstats = torch.empty(kv, dtype=torch.float64, device=self.device)
         self.wc = torch.empty(self.V, dtype=torch.float64, device=self.device)
         self.gamma = None
+        self.comm = None
+
+    def make_communicator(self, dist, group):
+        """A ncclComm_t of our own over the group's ranks (collective call); None if RCCL cannot
+        be reached that way."""
+        from . import rccl
+        try:
+            self.comm = rccl.own_communicator(dist, self.device, group)
+        except Exception:                             # noqa: BLE001 -- the all-reduce path remains
+            self.comm = None
+        return self.comm
+
+    def update_dp(self, batch, shard, cuts, rank, world, num_documents, eta, max_iter_tr,
+                  max_iter_inference, kappa, tau, rho, init_gamma, threshold, update_count):
+        """onlinelda.cpp:53-111 with the factor exchange; returns (rho, update_count)."""
+        cuts = np.ascontiguousarray(cuts, dtype=np.int32)
+        count, rho_out = C.c_int(int(update_count)), C.c_double(0.)
+        _ffi.check(self.lib.trlda_model_online_update_dp(
+            self.handle, batch.handle, shard.handle, self.comm, int(rank), int(world),
+            cuts.ctypes.data_as(C.POINTER(C.c_int32)), int(num_documents), float(eta),
+            int(max_iter_tr), int(max_iter_inference), float(kappa), float(tau), float(rho),
+            int(bool(init_gamma)), float(threshold), C.byref(count), C.byref(rho_out)))
+        return rho_out.value, count.value
 
     def close(self):
         if self.handle:
@@ -115,7 +145,7 @@ class ShardedOnlineLDA(object):
     """
 
     def __init__(self, num_words, num_topics, num_documents, alpha=.1, eta=.3, group=None,
-                 engine=None, device=None, gamma_init="replicated"):
+                 engine=None, device=None, gamma_init="replicated", exchange="auto"):
         import torch.distributed as dist
         from .models import _alpha_vector, _default_device
         self.dist = dist
@@ -130,6 +160,9 @@ class ShardedOnlineLDA(object):
         if gamma_init not in ("replicated", "local"):
             raise ValueError("gamma_init must be 'replicated' or 'local'")
         self.gamma_init = gamma_init
+        if exchange not in ("auto", "factors", "sstats"):
+            raise ValueError("exchange must be 'auto', 'factors' or 'sstats'")
+        self.exchange = exchange
         if engine is None:
             _ffi.require_gpu()
             engine = HipEngine(self._V, K, _default_device() if device is None else device)
@@ -150,6 +183,32 @@ class ShardedOnlineLDA(object):
             state = self._broadcast_host(state)
             _ffi.lib().trlda_rng_set_state(state)
         engine.set_lambda(lam)
+        # the factor exchange runs ncclAllGather on a communicator of our own
+        self._factors_ok = hasattr(engine, "update_dp") and gamma_init == "replicated"
+        if self._factors_ok and self.world > 1 and exchange != "sstats":
+            self._factors_ok = dist.get_backend(group) == "nccl" and \
+                engine.make_communicator(dist, group) is not None
+            self._factors_ok = self._all_ranks(self._factors_ok)
+
+    def _all_ranks(self, flag):
+        """True when `flag` holds on every rank"""
+        import torch
+        t = torch.tensor([int(bool(flag))])
+        if self.dist.get_backend(self.group) == "nccl":
+            t = t.to(self.engine.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t.item()))
+
+    def use_factors(self, csr, cuts):
+        """The factor exchange moves world * slot doubles per E-step, slot = max_r(docs_r) * K +
+        max_r(nnz_r); the all-reduce about 2 * K * V (reduce-scatter + all-gather)."""
+        if not self._factors_ok or self.exchange == "sstats":
+            return False
+        if self.exchange == "factors":
+            return True
+        docs = int(np.max(np.diff(cuts))) if len(cuts) > 1 else 0
+        nnz = int(np.max(np.diff(csr.indptr[cuts]))) if len(cuts) > 1 else 0
+        return self.world * (docs * self._K + nnz) < 2 * self._K * self._V
 
     num_topics = property(lambda self: self._K)
     num_words = property(lambda self: self._V)
@@ -239,6 +298,20 @@ class ShardedOnlineLDA(object):
             return 1.0                                           # onlinelda.cpp:54-56
         if rho < 0.:
             rho = float(np.power(tau + self.update_count, -kappa))   # onlinelda.cpp:59-66
+        if update_lambda and not presharded and self.use_factors(csr, cuts):
+            # every rank holds the whole mini-batch: documents of this rank -> all-gather of the
+            # factors -> statistics of the whole mini-batch + fused M-step on every rank
+            eng = self.engine
+            whole, mine = eng.upload(csr), eng.upload(shard)
+            try:
+                rho, self.update_count = eng.update_dp(
+                    whole, mine, cuts, self.rank, self.world, self.num_documents, self._eta,
+                    max_iter_tr, max_iter_inference, kappa, tau, rho, init_gamma, threshold,
+                    self.update_count)
+            finally:
+                whole.close()
+                mine.close()
+            return rho
         if update_lambda:
             eng = self.engine
             batch = eng.upload(shard)
