@@ -10,6 +10,9 @@
 #   <tag>_host_rates.txt         tools/host_rate.py: ingestion and PCIe-inclusive entry points
 #   <tag>_update_rates.txt       tools/update_rate.py: whole update_parameters calls
 #   <tag>_<cfg>_update_kernel_stats.csv   tools/prof_update.sh: kernels of the update loops
+#   <tag>_bench_forced_dist_world1_{factors,sstats}.json, <tag>_bench_virtual_world{2,4,8}.json,
+#   <tag>_virtual_world8_kernel_stats.csv   the data-parallel step
+#   <tag>_stamps_reg.txt         tools/stamps.sh: cycle shares inside the document kernel
 tag=${1:-r02}; commit=${2:-unknown}
 export TMPDIR=/tmp
 tools/prof_stats.sh ${tag} --steps 200 --warmup 20 > /dev/null
@@ -24,10 +27,20 @@ tools/prof_pmc.sh ${tag}_k500_write "WRITE_SIZE" $K500 > gpurun_out/${tag}_k500_
 python3 bench.py --steps 200 --warmup 20 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
 bash tools/sweep_configs.sh > gpurun_out/${tag}_configs.txt 2>&1
 python3 tools/host_rate.py > gpurun_out/${tag}_host_rates.txt 2>&1
-python3 tools/update_rate.py --configs small,c3,c5a,c5b,c4 > gpurun_out/${tag}_update_rates.txt 2>&1
+python3 tools/update_rate.py --configs small,c3,c5a,c5b,c4 --modes fused,fused_sep,plain > gpurun_out/${tag}_update_rates.txt 2>&1
 python3 tools/update_rate.py --configs small,c5a,c5b,c4 --modes fused --host-draw > gpurun_out/${tag}_update_rates_host_draw.txt 2>&1
-TRLDA_BENCH_FORCE_DIST=1 python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-update-rates 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_forced_dist_world1.json
+# the N > 1 code path on one GPU (1-rank process group), both exchanges; and what ONE rank of 2 / 4 / 8
+# executes per step with the factor exchange (--virtual-world: no collective runs)
+for ex in factors sstats; do
+  TRLDA_BENCH_FORCE_DIST=1 python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-update-rates --exchange $ex 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_forced_dist_world1_${ex}.json
+done
 TRLDA_BENCH_FORCE_DIST=1 python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-update-rates --global-batch 1600 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_forced_dist_world1_b1600.json
+for w in 2 4 8; do
+  python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-update-rates --virtual-world $w 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_virtual_world${w}.json
+done
+rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_virtual8_prof -o v8 --output-format csv -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-update-rates --virtual-world 8 > /dev/null 2>&1
+cp $(find gpurun_out/${tag}_virtual8_prof -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_virtual_world8_kernel_stats.csv
+bash tools/stamps.sh > gpurun_out/${tag}_stamps_reg.txt 2>&1
 if [ -d _r01 ]; then
   python3 tools/update_rate.py --root _r01 --configs small,c5a,c5b,c4 --modes fused > gpurun_out/r01_update_rates.txt 2>&1
   python3 tools/host_rate.py --root _r01 > gpurun_out/r01_host_rates_rerun.txt 2>&1
