@@ -24,10 +24,12 @@
 //            |<- tw_off = max_r(documents) * K doubles       ->|
 //   slot size = a multiple of K doubles, so that a document's row is slot-relative row index
 //
-// factor_unpack_kernel: one wavefront per document of the whole mini-batch: which rank, where its
-// weights lie in the gathered buffer; writes each weight to its entry's place in word-major
-// order (what the statistics kernel walks) and the row index of the document's expElogtheta in
-// the gathered buffer.
+// factor_index_kernel: once per (mini-batch, cut points) -- the mini-batch keeps the result --
+// one wavefront per document of the whole mini-batch: which rank, where its weights lie in the
+// gathered buffer.  For every entry in word-major order (what the statistics kernel walks): the
+// position of its weight in the gathered buffer and the row index of its document's
+// expElogtheta there.  The statistics kernel then reads the gathered buffer directly
+// (TwView, estep_kernels.h): per E-step the exchange is the all-gather and nothing else.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -41,11 +43,10 @@ struct DpCuts {                      // document cut points of the mini-batch, b
 };
 
 template <int T>
-__global__ __launch_bounds__(T) void factor_unpack_kernel(
-    int B, int64_t nnz, int world, const int32_t *__restrict__ indptr, const int32_t *__restrict__ wrank,
-    DpCuts cuts /* world + 1 document cut points */, size_t slot, int slot_rows,
-    size_t tw_off, const double *__restrict__ gathered, double *__restrict__ tw_word,
-    int32_t *__restrict__ wdoc_rows)
+__global__ __launch_bounds__(T) void factor_index_kernel(
+    int B, int world, const int32_t *__restrict__ indptr, const int32_t *__restrict__ wrank,
+    DpCuts cuts /* world + 1 document cut points */, size_t slot, int slot_rows, size_t tw_off,
+    int32_t *__restrict__ wsrc, int32_t *__restrict__ wrow)
 {
     // one wavefront per document: its rank and its place in the rank's slot are wave-uniform,
     // its entries are consecutive in the slot (CSR order) and spread over the lanes
@@ -58,12 +59,12 @@ __global__ __launch_bounds__(T) void factor_unpack_kernel(
         ++r;
     const int first = cuts.at[r];
     const int p0 = indptr[d], p1 = indptr[d + 1], pf = indptr[first];
-    const double *src = gathered + (size_t)r * slot + tw_off - pf;
+    const size_t src = (size_t)r * slot + tw_off - (size_t)pf;
     const int row = r * slot_rows + (d - first);
     for (int p = p0 + lane; p < p1; p += 64) {
         const int q = wrank[p];
-        tw_word[q] = src[p];
-        wdoc_rows[q] = row;
+        wsrc[q] = (int32_t)(src + (size_t)p);
+        wrow[q] = row;
     }
 }
 

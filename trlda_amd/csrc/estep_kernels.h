@@ -1236,6 +1236,15 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
 // sstats_words_kernel writes the statistics only; sstats_update_kernel (4c, below) also applies
 // the M-step and collects the row sums of the lambda it writes.
 // ---------------------------------------------------------------------------
+// The weights cnt / phinorm in word-major order: a plain array, or -- data-parallel factor
+// exchange, dp_kernels.h -- the gathered buffer of all ranks' weights (CSR order per rank)
+// seen through an index that is static per (mini-batch, shard cuts).
+struct TwView {
+    const double *v;
+    const int32_t *idx;       // or nullptr
+    __device__ __forceinline__ double operator[](int q) const { return idx ? v[idx[q]] : v[q]; }
+};
+
 // acc[h] += sum_{q in [q0, q1)} tw_word[q] * epg[kbase + 64 h + lane, wdoc[q]], h < NH topic
 // halves; q0, q1 are wave-uniform.  Per pass of 16 entries: lane u fetches (document,
 // weight) of entry u with one coalesced load each -- one memory latency for the whole list
@@ -1245,7 +1254,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
 template <int NH>
 __device__ __forceinline__ void word_segment_sum(int q0, int q1, int K, int kbase,
                                                  const int32_t *__restrict__ wdoc,
-                                                 const double *__restrict__ tw_word,
+                                                 TwView tw_word,
                                                  const double *__restrict__ epg, double *acc)
 {
     const int lane = threadIdx.x & (kWave - 1);
@@ -1289,7 +1298,7 @@ constexpr int kLongWord = 16;   // entries above which a word's list is split ov
 template <int T>
 __global__ __launch_bounds__(T) void sstats_words_kernel(
     int K, int V, int G_short, const int32_t *__restrict__ wptr, const int32_t *__restrict__ wdoc,
-    const int32_t *__restrict__ long_words, const double *__restrict__ tw_word,
+    const int32_t *__restrict__ long_words, TwView tw_word,
     const double *__restrict__ epg, const double *__restrict__ eeb, double *__restrict__ sstats)
 {
     constexpr int W = T / kWave;
@@ -1461,7 +1470,7 @@ template <int T, int NKB>
 __global__ __launch_bounds__(T) void sstats_update_kernel(
     int K, int N, int G_short, int n_long, const int32_t *__restrict__ list,
     const int32_t *__restrict__ wptr, const int32_t *__restrict__ wdoc,
-    const int32_t *__restrict__ long_words, const double *__restrict__ tw_word,
+    const int32_t *__restrict__ long_words, TwView tw_word,
     const double *__restrict__ epg, const double *eeb /* may be o.u_out */, UpdateOut o)
 {
     constexpr int W = T / kWave;
@@ -1587,7 +1596,7 @@ __global__ __launch_bounds__(T) void sstats_update_kernel(
 template <int NH>
 __device__ __forceinline__ void word_segment_sum2(int q0, int q1, int K, int kbase,
                                                   const int32_t *__restrict__ wdoc,
-                                                  const double *__restrict__ tw_word,
+                                                  TwView tw_word,
                                                   const double *__restrict__ epg, double2 *acc)
 {
     const int lane = threadIdx.x & (kWave - 1);
@@ -1655,7 +1664,7 @@ template <int T, int NKB, int NH>                    // NKB = ceil(K / (128 NH))
 __global__ __launch_bounds__(T) void sstats_update2_kernel(
     int K, int N, int G_short, int n_long, const int32_t *__restrict__ list,
     const int32_t *__restrict__ wptr, const int32_t *__restrict__ wdoc,
-    const int32_t *__restrict__ long_words, const double *__restrict__ tw_word,
+    const int32_t *__restrict__ long_words, TwView tw_word,
     const double *__restrict__ epg, const double *eeb /* may be o.u_out */, UpdateOut o)
 {
     constexpr int W = T / kWave;

@@ -159,6 +159,10 @@ struct trlda_batch {
     int32_t *pad_ids = nullptr;      // B x kRegMaxN
     std::vector<int32_t> sorted_len;   // host copy: document lengths in `order`
     std::vector<int32_t> indptr_host;  // host copy of indptr (data-parallel slot geometry)
+    // data-parallel factor exchange: where each word-major entry's weight and document row lie
+    // in the gathered buffer, for the cut points / geometry in dp_sig (built on first use)
+    int32_t *dp_wsrc = nullptr, *dp_wrow = nullptr;
+    std::vector<int64_t> dp_sig;
 };
 
 // A data-parallel call in flight (dp_kernels.h): the model holds the whole mini-batch `b`, iterates
@@ -240,8 +244,7 @@ struct trlda_model {
     // statistics kernel's row index into them, the shard cut points on the device
     DpContext *dp = nullptr;            // set for the duration of a *_dp call
     double *dp_gather = nullptr;
-    int32_t *dp_wdoc = nullptr;
-    size_t cap_dp_gather = 0, cap_dp_wdoc = 0;
+    size_t cap_dp_gather = 0;
     int (*allgather_hook)(void *, const void *, void *, size_t, void *) = nullptr;
     void *allgather_ctx = nullptr;
     double *epg = nullptr, *tw_csr = nullptr, *tw_word = nullptr;
@@ -615,7 +618,7 @@ int rowsums_from_scratch(trlda_model *m)
 }
 
 using sstats_update_fn = void (*)(int, int, int, int, const int32_t *, const int32_t *, const int32_t *,
-                                  const int32_t *, const double *, const double *, const double *,
+                                  const int32_t *, trlda::TwView, const double *, const double *,
                                   trlda::UpdateOut);
 template <int T, int NKB, int NH>
 sstats_update_fn sstats_update_entry()
@@ -657,7 +660,8 @@ int launch_sstats_update(trlda_model *m, const trlda_batch *b, EstepOut &out)
     // (data-parallel: expElogtheta rows of all ranks in the gathered buffer, dp_kernels.h)
     hipLaunchKernelGGL(kern, dim3(G_short + G_long), dim3(T), lds, m->stream, K, N, G_short,
                        b->n_long, out.active_only ? b->active : nullptr, b->wptr,
-                       m->dp ? m->dp_wdoc : b->wdoc, b->long_words, m->tw_word,
+                       m->dp ? b->dp_wrow : b->wdoc, b->long_words,
+                       m->dp ? trlda::TwView{m->dp_gather, b->dp_wsrc} : trlda::TwView{m->tw_word, nullptr},
                        m->dp ? m->dp_gather : m->epg, m->eeb_cur, out.upd);
     HIP_TRY(hipGetLastError());
     out.partial_rows = G_short + G_long;
@@ -735,13 +739,45 @@ int dp_prepare(trlda_model *m, const trlda_batch *b, DpContext *dp)
     dp->slot = (dp->tw_off + (size_t)max_nnz + (size_t)K - 1) / (size_t)K * (size_t)K;
     if (dp->slot / (size_t)K * (size_t)world > (size_t)INT32_MAX)
         return fail(TRLDA_ERR_ARG, "mini-batch too large for the factor exchange");
+    if (dp->slot * (size_t)world > (size_t)INT32_MAX)
+        return fail(TRLDA_ERR_ARG, "mini-batch too large for the factor exchange");
     int rc = grow(&m->dp_gather, &m->cap_dp_gather, std::max<size_t>(dp->slot * (size_t)world, 1));
-    if (!rc) rc = grow(&m->dp_wdoc, &m->cap_dp_wdoc, (size_t)std::max<int64_t>(b->nnz, 1));
-    return rc;
+    if (rc)
+        return rc;
+    // the static index of this (mini-batch, cut points): kept by the batch
+    std::vector<int64_t> sig;
+    sig.push_back(K);
+    sig.push_back((int64_t)dp->slot);
+    sig.push_back((int64_t)dp->tw_off);
+    for (int32_t c : dp->cuts)
+        sig.push_back(c);
+    trlda_batch *bb = const_cast<trlda_batch *>(b);
+    if (bb->dp_sig != sig && b->nnz > 0) {
+        if (!bb->dp_wsrc) {
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&bb->dp_wsrc), (size_t)b->nnz * sizeof(int32_t)));
+            if (hipMalloc(reinterpret_cast<void **>(&bb->dp_wrow), (size_t)b->nnz * sizeof(int32_t)) != hipSuccess) {
+                (void)hipFree(bb->dp_wsrc);
+                bb->dp_wsrc = nullptr;
+                return fail(TRLDA_ERR_HIP, "hipMalloc failed");
+            }
+        }
+        if ((rc = batch_begin(m, b)))
+            return rc;
+        constexpr int T = 256;
+        trlda::DpCuts cuts{};
+        for (int r = 0; r <= world; ++r)
+            cuts.at[r] = dp->cuts[(size_t)r];
+        hipLaunchKernelGGL(trlda::factor_index_kernel<T>, dim3((b->B + T / 64 - 1) / (T / 64)), dim3(T), 0,
+                           m->stream, b->B, world, b->indptr, b->wrank, cuts, dp->slot,
+                           (int)(dp->slot / (size_t)K), dp->tw_off, bb->dp_wsrc, bb->dp_wrow);
+        HIP_TRY(hipGetLastError());
+        bb->dp_sig = sig;
+    }
+    return TRLDA_OK;
 }
 
-// all ranks' factors -> every rank, then into the statistics kernel's order
-int dp_exchange(trlda_model *m, const trlda_batch *b)
+// all ranks' factors -> every rank (the statistics kernel reads them where they land)
+int dp_exchange(trlda_model *m, const trlda_batch *)
 {
     DpContext *dp = m->dp;
     double *mine = m->dp_gather + (size_t)dp->rank * dp->slot;
@@ -758,18 +794,6 @@ int dp_exchange(trlda_model *m, const trlda_batch *b)
         const int rc = fn(mine, m->dp_gather, dp->slot, kNcclFloat64, dp->comm, m->stream);   // in place
         if (rc != 0)
             return fail(TRLDA_ERR_HIP, "ncclAllGather failed with ncclResult_t " + std::to_string(rc));
-    }
-    if (b->nnz > 0) {
-        constexpr int T = 256;
-        const int G = (b->B + T / 64 - 1) / (T / 64);
-        trlda::DpCuts cuts{};
-        for (int r = 0; r <= dp->world; ++r)
-            cuts.at[r] = dp->cuts[(size_t)r];
-        hipLaunchKernelGGL(trlda::factor_unpack_kernel<T>, dim3(G), dim3(T), 0, m->stream, b->B, b->nnz,
-                           dp->world, b->indptr, b->wrank, cuts, dp->slot,
-                           (int)(dp->slot / (size_t)m->K), dp->tw_off, m->dp_gather, m->tw_word,
-                           m->dp_wdoc);
-        HIP_TRY(hipGetLastError());
     }
     return TRLDA_OK;
 }
@@ -1188,8 +1212,10 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         if ((rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)))           \
             return rc;                                                                     \
         hipLaunchKernelGGL(kern, dim3(G_short + b->n_long), dim3(TS), lds, m->stream, K, V, \
-                           G_short, b->wptr, dp ? m->dp_wdoc : b->wdoc, b->long_words,     \
-                           m->tw_word, dp ? m->dp_gather : m->epg, m->eeb_cur, sstats_dev); \
+                           G_short, b->wptr, dp ? b->dp_wrow : b->wdoc, b->long_words,     \
+                           dp ? trlda::TwView{m->dp_gather, b->dp_wsrc}                    \
+                              : trlda::TwView{m->tw_word, nullptr},                        \
+                           dp ? m->dp_gather : m->epg, m->eeb_cur, sstats_dev);            \
     } while (0)
         if (K >= 256)
             TRLDA_LAUNCH_SSTATS(512);
@@ -2121,6 +2147,10 @@ int trlda_batch_destroy(trlda_batch *b)
 {
     if (!b)
         return TRLDA_OK;
+    if (b->dp_wsrc && hipSetDevice(b->device) == hipSuccess) {
+        (void)hipFree(b->dp_wsrc);                   // (waits for the device)
+        (void)hipFree(b->dp_wrow);
+    }
     if (b->blob && hipSetDevice(b->device) == hipSuccess) {
         UploadContext &u = upload_context(b->device);
         std::lock_guard<std::mutex> lock(u.mu);
@@ -2220,7 +2250,7 @@ int trlda_model_destroy(trlda_model *m)
         (void)hipStreamSynchronize(m->stream);
         (void)hipFree(m->lambda); (void)hipFree(m->alpha); (void)hipFree(m->eeb); (void)hipFree(m->psi_sum);
         (void)hipFree(m->partial); (void)hipFree(m->counter); (void)hipFree(m->epg); (void)hipFree(m->tw_csr);
-        (void)hipFree(m->tw_word); (void)hipFree(m->dp_gather); (void)hipFree(m->dp_wdoc); (void)hipFree(m->lambda_prime); (void)hipFree(m->sstats); (void)hipFree(m->gamma);
+        (void)hipFree(m->tw_word); (void)hipFree(m->dp_gather); (void)hipFree(m->lambda_prime); (void)hipFree(m->sstats); (void)hipFree(m->gamma);
         (void)hipFree(m->wordcounts); (void)hipFree(m->rs_full); (void)hipFree(m->rs_static);
         (void)hipFree(m->upd_partial); (void)hipFree(m->ada_gradient); (void)hipFree(m->reduce_out);
         (void)hipFree(m->carry_out); (void)hipFree(m->upd_groups); (void)hipFree(m->group_counter);
