@@ -1451,6 +1451,7 @@ __device__ __forceinline__ void finish_partial_groups(const UpdateOut &o, int K)
     }
 }
 
+template <bool EMIT>
 __device__ __forceinline__ double update_one(const UpdateOut &o, size_t i, double s)
 {
     if (o.sstats)
@@ -1460,13 +1461,13 @@ __device__ __forceinline__ double update_one(const UpdateOut &o, size_t i, doubl
         const double hat = o.eta + o.scale * s;
         lam = o.lambda_prime ? o.omr * o.lambda_prime[i] + o.rho * hat : o.rho * hat;
         o.lambda[i] = lam;
-        if (o.u_out)
+        if (EMIT && o.u_out)
             o.u_out[i] = exp_digamma(lam);
     }
     return lam;
 }
 
-template <int T, int NKB>
+template <int T, int NKB, bool EMIT>                 // EMIT: also UpdateOut::u_out (K <= 128 only)
 __global__ __launch_bounds__(T) void sstats_update_kernel(
     int K, int N, int G_short, int n_long, const int32_t *__restrict__ list,
     const int32_t *__restrict__ wptr, const int32_t *__restrict__ wdoc,
@@ -1502,7 +1503,7 @@ __global__ __launch_bounds__(T) void sstats_update_kernel(
                             const size_t i = (size_t)w * K + k;
                             // lda.cpp:169: words the batch does not touch are 0 (eeb is not read)
                             const double s = len > 0 ? acc[h] * eeb[i] : 0.0;
-                            rs[kb][h] += update_one(o, i, s);
+                            rs[kb][h] += update_one<EMIT>(o, i, s);
                         }
                     }
                 }
@@ -1570,7 +1571,7 @@ __global__ __launch_bounds__(T) void sstats_update_kernel(
                 for (int q = 1; q < W; ++q)
                     acc += pv[q];
                 const size_t i = (size_t)w * K + k;
-                rsl[c] += update_one(o, i, acc * eeb[i]);
+                rsl[c] += update_one<EMIT>(o, i, acc * eeb[i]);
             }
         }
         __syncthreads();
@@ -1638,6 +1639,7 @@ __device__ __forceinline__ void word_segment_sum2(int q0, int q1, int K, int kba
 }
 
 // the pair (i, i + 1) of one word: statistics, M-step, returns the two lambdas written
+template <bool EMIT>
 __device__ __forceinline__ double2 update_pair(const UpdateOut &o, size_t i, double2 s)
 {
     if (o.sstats)
@@ -1654,13 +1656,13 @@ __device__ __forceinline__ double2 update_pair(const UpdateOut &o, size_t i, dou
             lam.y = o.rho * hy;
         }
         *reinterpret_cast<double2 *>(o.lambda + i) = lam;
-        if (o.u_out)
+        if (EMIT && o.u_out)
             *reinterpret_cast<double2 *>(o.u_out + i) = make_double2(exp_digamma(lam.x), exp_digamma(lam.y));
     }
     return lam;
 }
 
-template <int T, int NKB, int NH>                    // NKB = ceil(K / (128 NH)), K even
+template <int T, int NKB, int NH, bool EMIT>         // NKB = ceil(K / (128 NH)), K even
 __global__ __launch_bounds__(T) void sstats_update2_kernel(
     int K, int N, int G_short, int n_long, const int32_t *__restrict__ list,
     const int32_t *__restrict__ wptr, const int32_t *__restrict__ wdoc,
@@ -1705,7 +1707,7 @@ __global__ __launch_bounds__(T) void sstats_update2_kernel(
                                 const double2 e2 = *reinterpret_cast<const double2 *>(eeb + i);
                                 s = make_double2(acc[h].x * e2.x, acc[h].y * e2.y);
                             }
-                            const double2 lam = update_pair(o, i, s);
+                            const double2 lam = update_pair<EMIT>(o, i, s);
                             rs[kb][h].x += lam.x;
                             rs[kb][h].y += lam.y;
                         }
@@ -1777,7 +1779,7 @@ __global__ __launch_bounds__(T) void sstats_update2_kernel(
                 for (int q = 1; q < W; ++q)
                     acc += pv[q];
                 const size_t i = (size_t)w * K + k;
-                rsl[c] += update_one(o, i, acc * eeb[i]);
+                rsl[c] += update_one<EMIT>(o, i, acc * eeb[i]);
             }
         }
         __syncthreads();

@@ -620,13 +620,13 @@ int rowsums_from_scratch(trlda_model *m)
 using sstats_update_fn = void (*)(int, int, int, int, const int32_t *, const int32_t *, const int32_t *,
                                   const int32_t *, trlda::TwView, const double *, const double *,
                                   trlda::UpdateOut);
-template <int T, int NKB, int NH>
+template <int T, int NKB, int NH, bool EMIT>
 sstats_update_fn sstats_update_entry()
 {
     if constexpr (NH == 0)
-        return trlda::sstats_update_kernel<T, NKB>;
+        return trlda::sstats_update_kernel<T, NKB, EMIT>;
     else
-        return trlda::sstats_update2_kernel<T, NKB, NH>;
+        return trlda::sstats_update2_kernel<T, NKB, NH, EMIT>;
 }
 
 template <int T, int NKB, int NH>                    // NH = 0: one topic per lane (any K)
@@ -638,7 +638,14 @@ int launch_sstats_update(trlda_model *m, const trlda_batch *b, EstepOut &out)
     const int G_short = std::max(1, std::min(kUpdShortBlocks, (N + W - 1) / W));
     const int G_long = std::min(kUpdLongBlocks, b->n_long);
     const size_t lds = (size_t)W * K * sizeof(double);
-    auto kern = sstats_update_entry<T, NKB, NH>();
+    // (the instantiation that also writes exp(psi(lambda)) needs more registers: only where asked)
+    constexpr bool can_emit = NKB == 1 && NH <= 1;   // K <= 128
+    const bool emit = can_emit && out.emit_next && out.upd.lambda && out.upd.partial;
+    sstats_update_fn kern = sstats_update_entry<T, NKB, NH, false>();
+    if constexpr (can_emit) {
+        if (emit)
+            kern = sstats_update_entry<T, NKB, NH, true>();
+    }
     int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (rc)
         return rc;
@@ -648,7 +655,7 @@ int launch_sstats_update(trlda_model *m, const trlda_batch *b, EstepOut &out)
     out.upd.group_base = nullptr;
     out.upd.group_counter = nullptr;
     out.upd.group_size = 1;
-    if (out.emit_next && out.upd.lambda && out.upd.partial) {
+    if (emit) {
         const int rows = G_short + G_long;
         out.upd.u_out = m->eeb;
         out.upd.group_rows = m->upd_groups;
