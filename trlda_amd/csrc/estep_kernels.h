@@ -402,6 +402,9 @@ __device__ __forceinline__ double topic_scale_combine(int K, int k, const double
 // shipped library; the values go to a buffer nothing else reads.
 #ifdef TRLDA_STAMPS
 // segment sums stay in registers; one global write per segment at the very end
+#ifndef TRLDA_STAMP_THREAD
+#define TRLDA_STAMP_THREAD 0      // whose clock is reported (-DTRLDA_STAMP_THREAD=448: wave 7)
+#endif
 #define TRLDA_STAMP_DECL unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define TRLDA_STAMP(i)                                                        \
     do {                                                                      \
@@ -411,7 +414,7 @@ __device__ __forceinline__ double topic_scale_combine(int K, int k, const double
     } while (0)
 #define TRLDA_STAMP_FLUSH                                                     \
     do {                                                                      \
-        if (threadIdx.x == 0)                                                 \
+        if (threadIdx.x == TRLDA_STAMP_THREAD)                                \
             for (int q__ = 0; q__ < 8; ++q__)                                 \
                 a.stamps[blockIdx.x * 8 + q__] += stamp_acc[q__];             \
     } while (0)

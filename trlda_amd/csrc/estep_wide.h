@@ -352,7 +352,10 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
     double twv[NH];                                  // cnt / phinorm of word jv[g]
     int it = 0;
     int cur = 0;                                     // ebuf / misc buffer holding the current e
-    double mean_change = 0.0;
+    // sum_k |gamma_k - last_k| against threshold * K: the mean's division would sit in every
+    // wave's instruction stream (lda.cpp:202)
+    double change_sum = 0.0;
+    const double thresholdK = a.threshold * (double)K;
     for (;;) {
 #pragma unroll
         for (int s = 0; s < KS; ++s)
@@ -362,7 +365,7 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
 #pragma unroll
             for (int w = 0; w < (KS < W ? KS : W); ++w)
                 sum += misc[cur * 8 + w];
-            mean_change = sum / (double)K;
+            change_sum = sum;
         }
 #pragma unroll
         for (int u = 0; u < NSET; ++u)
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
         for (int t0 = n_lds + wid * TCH; n_reg + t0 < n; t0 += W * TCH)
             tail_chunk(t0, false);
         TRLDA_STAMP(2);
-        if (it >= a.max_iter || (it > 0 && mean_change < a.threshold))    // lda.cpp:185, :202-203
+        if (it >= a.max_iter || (it > 0 && change_sum < thresholdK))      // lda.cpp:185, :202-203
             break;
 
         // ---- acc_k = sum_j tw_j beta[j][k] over this wave's words        lda.cpp:189-193
