@@ -256,6 +256,18 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
         else
             jv[g] = -1;
     }
+    // Up to 256 topics the waves KS .. 2 KS - 1 have nothing to do while waves 0 .. KS - 1
+    // evaluate exp(psi): they mirror gamma of the topic tid - KP (recomputed from the same
+    // partial sums: bitwise the owner's value) and form sum |gamma - last| (lda.cpp:202) there,
+    // off the exp(psi) waves' instruction streams.
+    constexpr bool MIRROR = 2 * KS <= W;
+    const int km = tid - KP;                         // the mirrored topic
+    const bool m_on = MIRROR && km >= 0 && km < K;
+    double gm = 0.0, am = 0.0;
+    if (m_on) {
+        gm = a.gamma_in[(size_t)d * K + km];
+        am = a.alpha[km];
+    }
     // gamma / alpha / exp(psi(gamma)) of topic tid                       lda.cpp:174
     const bool k_on = tid < K;
     double gk = 1.5, ak = 0.0, ek = 0.0;          // (1.5: idle lanes must not take psi's integer branch)
@@ -446,14 +458,23 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
         if (wid < KS) {                              // tid < KP
             const double accs = sum8_strided<KP>(part + tid);
             const double gnew = k_on ? fma(accs, ek, ak) : 1.5;
-            const double diff = k_on ? fabs(gk - gnew) : 0.0;
+            [[maybe_unused]] const double diff = k_on ? fabs(gk - gnew) : 0.0;
             gk = gnew;
             const double enew = cfg::LEAN_PSI ? exp_digamma_minus_lean(gnew, 0.0) : exp_digamma(gnew);
             ek = k_on ? enew : 0.0;
             ebuf[nxt * KP + tid] = ek;
-            const double dsum = wave_sum_dpp(diff);
+            if constexpr (!MIRROR) {
+                const double dsum = wave_sum_dpp(diff);
+                if (lane == 0)
+                    misc[nxt * 8 + wid] = dsum;
+            }
+        } else if (MIRROR && wid < 2 * KS) {
+            const int kc = m_on ? km : 0;
+            const double gnew = fma(sum8_strided<KP>(part + kc), ebuf[cur * KP + kc], am);
+            const double dsum = wave_sum_dpp(m_on ? fabs(gm - gnew) : 0.0);
+            gm = gnew;
             if (lane == 0)
-                misc[nxt * 8 + wid] = dsum;
+                misc[nxt * 8 + (wid - KS)] = dsum;
         }
         TRLDA_STAMP(5);
         __syncthreads();
