@@ -160,6 +160,10 @@ int trlda_batch_max_doc_len(const trlda_batch *batch);
  * trlda_sample_gamma_init (as src/lda.cpp:71 does) and uploads it. */
 int trlda_model_create(trlda_model **out, int device, int K, int V);
 int trlda_model_destroy(trlda_model *model);
+/* Kernels of this model run on the host's stream from now on (default: a non-blocking stream of
+ * the model's own).  The stream must outlive every trlda_batch that was used on it: a batch
+ * records the event that guards its memory once, when it is destroyed, on the stream that used
+ * it last. */
 int trlda_model_set_stream(trlda_model *model, void *hip_stream /* hipStream_t */);
 int trlda_model_set_sstats_mode(trlda_model *model, int mode);
 /* exp E[log beta] (src/lda.cpp:173) is computed for the words that occur in the batch (the

@@ -239,6 +239,7 @@ def test_dp_argument_checks(hip):
             100, .3, 0, 5, .7, 100., -1., 1, 1e-3, C.byref(m.count), C.byref(rho))
 
     assert call([0, 4, 9], 0, 2, shard) != 0           # cuts do not end at the batch size
+    assert call([0, 1000, 10], 0, 2, shard) != 0       # a cut point beyond the batch
     assert call([0, 5, 10], 0, 2, shard) != 0          # shard is not documents [0, 5)
     assert call([0, 4, 10], 2, 2, shard) != 0          # rank outside the world
     assert call([0, 4, 10], 0, 2, shard) != 0          # two ranks, no communicator, no hook

@@ -733,8 +733,8 @@ int dp_prepare(trlda_model *m, const trlda_batch *b, DpContext *dp)
     int64_t max_nnz = 0;
     for (int r = 0; r < world; ++r) {
         const int lo = dp->cuts[(size_t)r], hi = dp->cuts[(size_t)r + 1];
-        if (hi < lo)
-            return fail(TRLDA_ERR_ARG, "doc_cuts must be non-decreasing");
+        if (lo < 0 || hi < lo || hi > b->B)
+            return fail(TRLDA_ERR_ARG, "doc_cuts must be non-decreasing and lie in [0, mini-batch size]");
         max_docs = std::max(max_docs, hi - lo);
         max_nnz = std::max<int64_t>(max_nnz, b->indptr_host[(size_t)hi] - b->indptr_host[(size_t)lo]);
     }
