@@ -257,7 +257,9 @@ __device__ __forceinline__ void preamble_fused_body(
     const double *__restrict__ lambda, double *__restrict__ partial /* G x K */,
     double *__restrict__ u, const int32_t *__restrict__ active /* word ids or nullptr */, int GC,
     const double *__restrict__ carry_rows /* carry_n x K */, int carry_n,
-    const double *__restrict__ carry_base /* K or nullptr */, double *__restrict__ carry_out /* GC x K */)
+    const double *__restrict__ carry_base /* K or nullptr */, double *__restrict__ carry_out /* GC x K */,
+    double *__restrict__ c_out = nullptr /* 3 K: psi(row sums), row sums, exp(-psi) */,
+    unsigned int *c_counter = nullptr, double *c_scratch = nullptr /* 8 K doubles of LDS */)
 {
     const int tid = threadIdx.x;
     // Row sums carried over from the kernel that wrote lambda, still in carry_n block partials
@@ -318,7 +320,65 @@ __device__ __forceinline__ void preamble_fused_body(
             double sum = red[tid];
             for (int sl = 1; sl < slots; ++sl)
                 sum += red[sl * K + tid];
-            partial[(size_t)(vb - GC) * K + tid] = sum;
+            if (c_out)                               // (read by another workgroup of this launch)
+                __hip_atomic_store(partial + (size_t)(vb - GC) * K + tid, sum, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            else
+                partial[(size_t)(vb - GC) * K + tid] = sum;
+        }
+        // The topic factors c_k = exp(-psi(row sum_k)), finished HERE when nobody is waiting for
+        // this launch's end (the preamble of the NEXT batch, riding on a document launch): the
+        // last row-sum workgroup to finish adds up the G rows -- in topic_scale_*'s order, so
+        // that the factors are bitwise those every document workgroup would form -- and the
+        // documents of the next launch load K numbers instead of summing 64 rows and evaluating
+        // psi and exp between two of their barriers (~1500 cycles of every document's latency).
+        // Visibility of the rows as in finish_partial_groups: sc1 stores / loads, a workgroup
+        // release before the counter, no agent-scope fence.
+        if (c_out) {                                 // launch-uniform
+            __shared__ int last_rows;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned int seen = __hip_atomic_fetch_add(c_counter, 1u, __ATOMIC_RELAXED,
+                                                                 __HIP_MEMORY_SCOPE_AGENT);
+                const int last = seen + 1u == (unsigned int)G;
+                if (last)
+                    __hip_atomic_store(c_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last_rows = last;
+            }
+            __syncthreads();
+            if (last_rows) {
+                const int per = (G + 7) / 8;         // topic_scale_load / _partials, sc1 loads
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int t = tid + h * T;
+                    if (t < 8 * K) {
+                        const int k = t % K, b0 = (t / K) * per, b1 = min(G, b0 + per);
+                        double v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            v[q] = __hip_atomic_load(partial + (size_t)min(b0 + q, G - 1) * K + k,
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        double acc[2] = {0.0, 0.0};
+#pragma unroll
+                        for (int q = 0; q < 8; ++q)
+                            acc[q & 1] += (b0 + q < b1) ? v[q] : 0.0;
+                        c_scratch[t] = acc[0] + acc[1];
+                    }
+                }
+                __syncthreads();
+                if (tid < K) {                       // topic_scale_combine
+                    double w[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        w[q] = c_scratch[q * K + tid];
+                    const double rs = ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
+                    const double ps = digamma(rs);
+                    c_out[tid] = ps;
+                    c_out[K + tid] = rs;
+                    c_out[2 * K + tid] = exp(-ps);
+                }
+            }
         }
         return;
     }
@@ -469,6 +529,8 @@ struct DocKernelArgs {
     double *gamma;            // K x B out
     double *epg;              // K x B out: exp(psi(gamma)) of the returned gamma
     double *tw_csr;           // nnz: cnt/phinorm in CSR order (streaming-path scratch)
+    const double *scale_in;   // 3 K finished topic factors (psi, row sums, c) or NULL: form them
+                              // from `partial` (fused preamble)
     const int32_t *wrank;     // nnz: CSR position -> word-major rank (segmented mode); NULL: the
                               // weights stay in CSR order (data-parallel factor exchange)
     double *tw_word;          // nnz: cnt/phinorm in word-major order (segmented mode)
@@ -907,6 +969,8 @@ struct PreArgs {
     const double *lambda;
     double *partial, *u;
     const int32_t *active;
+    double *c_out;            // 3 K: the finished topic factors of that batch's preamble
+    unsigned int *c_counter;
 };
 
 template <int MODE>
@@ -916,7 +980,8 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
     if ((int)blockIdx.x >= pre.n_docs) {             // block-uniform
         preamble_fused_body<kRegThreads>((int)blockIdx.x - pre.n_docs, pre.nb, lds, pre.K, pre.V, pre.G,
                                          pre.wpb, pre.total, pre.lambda, pre.partial, pre.u, pre.active,
-                                         0, nullptr, 0, nullptr, nullptr);
+                                         0, nullptr, 0, nullptr, nullptr, pre.c_out, pre.c_counter,
+                                         lds + kRegThreads);
         return;
     }
     constexpr bool TAIL = MODE == 2, MID = MODE == 1;
@@ -931,7 +996,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
     // fused preamble: the block partials of the row sums are fetched first -- they depend on
     // nothing -- and consumed once the row loads below are in flight
     double pv[2][8];
-    if (a.partial)                                   // launch-uniform
+    if (a.partial && !a.scale_in)                    // launch-uniform
         topic_scale_load<T>(K, a.G, a.partial, pv);
 
     // One load gives (document, length, CSR offset); the word ids sit at an address that
@@ -942,6 +1007,22 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
     const int myid = pids[wid * JC + min(lane, JC - 1)];   // word wid * JC + i of the document
     const int d = meta.x, n = meta.y, p0 = meta.z;
     const int32_t *__restrict__ cnts = a.cnts + p0;
+    // gamma0 / alpha of topic tid: requested BEFORE the 32 row loads below -- loads return in
+    // order, so a request behind them could not be consumed (exp(psi(gamma0)), ~700 cycles on the
+    // two waves that own the topics) until every row had landed
+    double gk0 = 1.5, ak0 = 0.0, ck0 = 1.0;
+    if (tid < K) {
+        gk0 = a.gamma_in[(size_t)d * K + tid];
+        ak0 = a.alpha[tid];
+        if (a.scale_in) {                            // finished by the launch that prepared them
+            ck0 = a.scale_in[2 * K + tid];
+            if (blockIdx.x == 0 && a.scale_out) {
+                a.scale_out[tid] = a.scale_in[tid];
+                a.scale_out[K + tid] = a.scale_in[K + tid];
+                a.scale_out[2 * K + tid] = ck0;
+            }
+        }
+    }
 
     double *gbuf = lds;               // 2 x 128
     double *alpha_l = gbuf + 256;     // 128
@@ -983,20 +1064,18 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
     }
 
     double *gamma_d = a.gamma + (size_t)d * K;
-    const double *gamma0_d = a.gamma_in + (size_t)d * K;
     double e0 = 0.0;                                 // thread k < K: exp(psi(gamma0_k))
     if (tid < 144) {                                 // lda.cpp:174
         if (tid < K) {
-            const double gk = gamma0_d[tid];
-            gbuf[tid] = gk;
-            alpha_l[tid] = a.alpha[tid];
-            e0 = exp_digamma(gk);
+            gbuf[tid] = gk0;
+            alpha_l[tid] = ak0;
+            e0 = exp_digamma(gk0);
         }
         ebuf[144 + tid] = 0.0;                       // zero beyond K, in both buffers
         if (!a.partial || tid >= K)
             ebuf[tid] = e0;
     }
-    if (a.partial)                                   // launch-uniform; `part` is idle until
+    if (a.partial && !a.scale_in)                    // launch-uniform; `part` is idle until
         topic_scale_partials<T>(K, a.G, pv, part);   // the first product
     for (int j = tid; j < 208; j += T) {
         tw[j] = 0.0;
@@ -1024,7 +1103,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
     if (tid < K) {
         double ck = 1.0;
         if (a.partial) {                             // launch-uniform
-            ck = topic_scale_combine(K, tid, part, a.scale_out);
+            ck = a.scale_in ? ck0 : topic_scale_combine(K, tid, part, a.scale_out);
             ebuf[tid] = e0 * ck;
         }
         c_l[tid] = ck;

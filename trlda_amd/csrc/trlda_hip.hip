@@ -188,6 +188,7 @@ struct trlda_model {
     // that batch while lambda has not been written (lambda_version).
     uint64_t lambda_version = 1;
     double *eeb_pp[2] = {nullptr, nullptr}, *partial_pp[2] = {nullptr, nullptr};
+    double *scale_pp[2] = {nullptr, nullptr};   // 3 K each: the finished topic factors (PreArgs::c_out)
     struct {
         bool valid = false;
         uint64_t batch_id = 0, version = 0;
@@ -1026,6 +1027,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         a.sstats_acc = atomic ? sstats_dev : nullptr;
         a.max_iter = max_iter; a.threshold = threshold; a.iters_out = iters_dev;
         a.partial = fused ? partial_in : nullptr;
+        a.scale_in = prefetched ? m->scale_pp[cur_buf] : nullptr;
         a.G = G;
         a.scale_out = fused ? m->psi_sum : nullptr;
         const int Kp = K | 1;
@@ -1148,6 +1150,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                     for (int i = 0; i < 2 && !rc; ++i) {
                         rc = dev_alloc(&m->eeb_pp[i], KV);
                         if (!rc) rc = dev_alloc(&m->partial_pp[i], (size_t)kRowsumBlocks * K);
+                        if (!rc) rc = dev_alloc(&m->scale_pp[i], 3 * (size_t)K);
                         if (!rc && hipMemsetAsync(m->eeb_pp[i], 0, KV * sizeof(double), m->stream) != hipSuccess)
                             rc = fail(TRLDA_ERR_HIP, "hipMemsetAsync failed");
                     }
@@ -1173,6 +1176,8 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                 pre.partial = m->partial_pp[nbuf];
                 pre.u = m->eeb_pp[nbuf];
                 pre.active = dense ? nullptr : next->active;
+                pre.c_out = m->scale_pp[nbuf];
+                pre.c_counter = m->group_counter + kUpdGroups;
                 m->prefetch.valid = true;
                 m->prefetch.batch_id = next->id;
                 m->prefetch.version = m->lambda_version;
@@ -2230,8 +2235,9 @@ int trlda_model_create(trlda_model **out, int device, int K, int V)
     if (!rc) rc = dev_alloc(&m->upd_groups, (size_t)kUpdGroups * K);
     if (!rc) {
         void *p = nullptr;
-        if (hipMalloc(&p, kUpdGroups * sizeof(unsigned int)) != hipSuccess ||
-            hipMemset(p, 0, kUpdGroups * sizeof(unsigned int)) != hipSuccess)
+        // (+1: the row-sum workgroups' counter of a prefetched preamble)
+        if (hipMalloc(&p, (kUpdGroups + 1) * sizeof(unsigned int)) != hipSuccess ||
+            hipMemset(p, 0, (kUpdGroups + 1) * sizeof(unsigned int)) != hipSuccess)
             rc = fail(TRLDA_ERR_HIP, "hipMalloc failed");
         m->group_counter = static_cast<unsigned int *>(p);
     }
@@ -2271,7 +2277,7 @@ int trlda_model_destroy(trlda_model *m)
         for (auto &e : m->ev_pool)
             (void)hipEventDestroy(e);
         for (int i = 0; i < 2; ++i) {
-            (void)hipFree(m->eeb_pp[i]); (void)hipFree(m->partial_pp[i]);
+            (void)hipFree(m->eeb_pp[i]); (void)hipFree(m->partial_pp[i]); (void)hipFree(m->scale_pp[i]);
         }
         if (m->own_stream) {
             LiveStreams &ls = live_own_streams();
