@@ -229,6 +229,23 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
     for (int s = 0; s < KS; ++s)
         kv[s] = lane + 64 * s < K;
 
+    // gamma0 / alpha (and the mirrored pair) are requested BEFORE the JW x KS row loads: loads
+    // return in order, so behind the rows exp(psi(gamma0)) could not start until all had landed
+    constexpr bool MIRROR = 2 * KS <= W;
+    const int km = tid - KP;                         // the mirrored topic (below)
+    const bool m_on = MIRROR && km >= 0 && km < K;
+    const bool k_on = tid < K;
+    double gk = 1.5, ak = 0.0;                       // (1.5: idle lanes must not take psi's integer branch)
+    double gm = 0.0, am = 0.0;
+    if (k_on) {
+        gk = a.gamma_in[(size_t)d * K + tid];
+        ak = a.alpha[tid];
+    }
+    if (m_on) {
+        gm = a.gamma_in[(size_t)d * K + km];
+        am = a.alpha[km];
+    }
+
     // ---- the slice (lda.cpp:179-181): JW x KS coalesced loads per lane, all independent.
     // Word ids: one vector load (lane i -> slot i of this wave), handed out with v_readlane.
     double beta[JW][KS];
@@ -260,22 +277,10 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
     // evaluate exp(psi): they mirror gamma of the topic tid - KP (recomputed from the same
     // partial sums: bitwise the owner's value) and form sum |gamma - last| (lda.cpp:202) there,
     // off the exp(psi) waves' instruction streams.
-    constexpr bool MIRROR = 2 * KS <= W;
-    const int km = tid - KP;                         // the mirrored topic
-    const bool m_on = MIRROR && km >= 0 && km < K;
-    double gm = 0.0, am = 0.0;
-    if (m_on) {
-        gm = a.gamma_in[(size_t)d * K + km];
-        am = a.alpha[km];
-    }
+    // (MIRROR, gm / am: loaded above, ahead of the rows)
     // gamma / alpha / exp(psi(gamma)) of topic tid                       lda.cpp:174
-    const bool k_on = tid < K;
-    double gk = 1.5, ak = 0.0, ek = 0.0;          // (1.5: idle lanes must not take psi's integer branch)
+    double ek = 0.0;
     if (tid < KP) {
-        if (k_on) {
-            gk = a.gamma_in[(size_t)d * K + tid];
-            ak = a.alpha[tid];
-        }
         const double e0 = cfg::LEAN_PSI ? exp_digamma_minus_lean(gk, 0.0) : exp_digamma(gk);
         ek = k_on ? e0 : 0.0;
         ebuf[tid] = ek;                              // zero beyond K
