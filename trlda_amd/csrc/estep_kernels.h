@@ -1755,8 +1755,10 @@ __device__ __forceinline__ void word_segment_sum2(int q0, int q1, int K, int kba
 }
 
 // the pair (i, i + 1) of one word: statistics, M-step, returns the two lambdas written
+// (lp: lambda'[i], fetched by the caller ahead of the word's gathers -- loads return in order,
+// and a request made here, behind them, would be one more memory latency per word)
 template <bool EMIT>
-__device__ __forceinline__ double2 update_pair(const UpdateOut &o, size_t i, double2 s)
+__device__ __forceinline__ double2 update_pair(const UpdateOut &o, size_t i, double2 s, double2 lp)
 {
     if (o.sstats)
         *reinterpret_cast<double2 *>(o.sstats + i) = s;
@@ -1764,7 +1766,6 @@ __device__ __forceinline__ double2 update_pair(const UpdateOut &o, size_t i, dou
     if (o.lambda) {
         const double hx = o.eta + o.scale * s.x, hy = o.eta + o.scale * s.y;
         if (o.lambda_prime) {
-            const double2 lp = *reinterpret_cast<const double2 *>(o.lambda_prime + i);
             lam.x = o.omr * lp.x + o.rho * hx;
             lam.y = o.omr * lp.y + o.rho * hy;
         } else {
@@ -1807,10 +1808,20 @@ __global__ __launch_bounds__(T) void sstats_update2_kernel(
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
                 if (kb * BW < K) {            // wave-uniform
-                    double2 acc[NH];
+                    double2 acc[NH], e2[NH], lp[NH];
+                    // exp E[log beta] and lambda' of this word's elements: requested before the
+                    // gathers (clamped, unconditional), consumed after them
 #pragma unroll
-                    for (int h = 0; h < NH; ++h)
+                    for (int h = 0; h < NH; ++h) {
                         acc[h] = make_double2(0.0, 0.0);
+                        const size_t ic = (size_t)w * K + min(kb * BW + 128 * h + 2 * lane, K - 2);
+                        // (a word without entries has zero statistics: its exp E[log beta] is
+                        // neither defined -- only the batch's words are filled -- nor read)
+                        e2[h] = len > 0 ? *reinterpret_cast<const double2 *>(eeb + ic)
+                                        : make_double2(0.0, 0.0);
+                        lp[h] = o.lambda_prime ? *reinterpret_cast<const double2 *>(o.lambda_prime + ic)
+                                               : make_double2(0.0, 0.0);
+                    }
                     if (len > 0)
                         word_segment_sum2<NH>(q0, q0 + len, K, kb * BW, wdoc, tw_word, epg, acc);
 #pragma unroll
@@ -1819,11 +1830,9 @@ __global__ __launch_bounds__(T) void sstats_update2_kernel(
                         if (k < K) {
                             const size_t i = (size_t)w * K + k;
                             double2 s = make_double2(0.0, 0.0);   // lda.cpp:169
-                            if (len > 0) {
-                                const double2 e2 = *reinterpret_cast<const double2 *>(eeb + i);
-                                s = make_double2(acc[h].x * e2.x, acc[h].y * e2.y);
-                            }
-                            const double2 lam = update_pair<EMIT>(o, i, s);
+                            if (len > 0)
+                                s = make_double2(acc[h].x * e2[h].x, acc[h].y * e2[h].y);
+                            const double2 lam = update_pair<EMIT>(o, i, s, lp[h]);
                             rs[kb][h].x += lam.x;
                             rs[kb][h].y += lam.y;
                         }
