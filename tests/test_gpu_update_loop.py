@@ -556,3 +556,44 @@ def test_announced_next_batch_changes_nothing(hip, oracle):
     g, s, it = with_next[1]                              # batch 1, prepared under batch 0's launch
     assert relerr(g, go) < TIGHT_RTOL and np.array_equal(it, ito)
     assert relerr(s[so > 0], so[so > 0]) < TIGHT_RTOL
+
+
+def test_next_preamble_from_the_m_step_changes_nothing_but_rounding(hip):
+    """Small tables: the M-step kernel leaves exp(psi(lambda)) and grouped row sums for the next
+    E-step (two launches per trust-region iteration); with trlda_model_set_next_preamble(0) every
+    E-step launches its preamble.  Same exp(psi) values, row sums added in a different (fixed)
+    order: lambda agrees to rounding, for OnlineLDA with the trust region, BatchLDA epochs and
+    CumulativeLDA epochs; and repeating a run reproduces it bit for bit."""
+    import trlda_amd
+    from trlda_amd.models import BatchLDA, CumulativeLDA
+    K, V, B, D = 100, 5000, 150, 40000
+    lam0 = random_lambda(K, V, 77)
+    docs = [corpus(B, V, seed=900 + i, mean_unique=80) for i in range(2)]
+
+    def run(emit):
+        out = []
+        m = online_model(K, V, lam0, D)
+        hip.trlda_model_set_next_preamble(m._handle, emit)
+        trlda_amd.seed(71)
+        m.update_parameters(docs[0], max_iter_tr=5, max_iter_inference=20)
+        m.update_parameters(docs[1], max_iter_tr=4, max_iter_inference=20, init_gamma=False)
+        out.append(m.lambdas)
+        m.close()
+        b = batch_model(K, V, lam0)
+        hip.trlda_model_set_next_preamble(b._handle, emit)
+        trlda_amd.seed(72)
+        b.update_parameters(docs[0], max_epochs=4, max_iter_inference=25)
+        out.append(b.lambdas)
+        b.close()
+        trlda_amd.seed(73)
+        c = CumulativeLDA(num_words=V, num_topics=K)
+        hip.trlda_model_set_next_preamble(c._handle, emit)
+        c.update_parameters(docs[0], max_epochs=3, max_iter_inference=25)
+        out.append(c.lambdas)
+        c.close()
+        return out
+
+    on, off, again = run(1), run(0), run(1)
+    for a, b, c in zip(on, off, again):
+        assert relerr(a, b) < 1e-12, relerr(a, b)
+        assert np.array_equal(a, c)
