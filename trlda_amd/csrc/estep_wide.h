@@ -47,7 +47,9 @@ struct wide_cfg {
     // waves share a SIMD and the register-lean version is as fast and leaves room for data
     static constexpr bool LEAN_PSI = KS > 4;
 #endif
-    static constexpr int NH = (JW + 7) / 8;          // groups of 8 register slots (one fold each)
+    // groups of 16 register slots, one transposing fold each (57 instructions for 16 sums:
+    // 3.6 per word; groups of 8 cost 6.5 per word -- 87 against 57 instructions at JW = 12)
+    static constexpr int NH = (JW + 15) / 16;
     static constexpr int NSET = KS >= 8 ? 1 : KS >= 4 ? 2 : KS >= 2 ? 4 : 8;   // >= 8 fma chains
     static constexpr int TCH = KS <= 4 ? 4 : 2;      // words of a tail chunk (TCH * KS <= 16)
     static constexpr int KP = 64 * KS;               // padded topic count
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
     int jv[NH];
 #pragma unroll
     for (int g = 0; g < NH; ++g) {
-        const int i = 8 * g + fold8_index(lane);
+        const int i = 16 * g + fold16_index(lane);
         jv[g] = i * W + wid;
         cntv[g] = 0.0;
         if (i < JW && jv[g] < n_reg)
@@ -394,14 +396,14 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
 #pragma unroll
         for (int g = 0; g < NH; ++g) {
             twv[g] = 0.0;
-            if (8 * g < JE) {                        // wave-uniform: the group has words
-                double sv[8];
+            if (16 * g < JE) {                       // wave-uniform: the group has words
+                double sv[16];
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
+                for (int c = 0; c < 4; ++c) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u)
                         sv[4 * c + u] = 0.0;
-                    const int i0 = 8 * g + 4 * c;
+                    const int i0 = 16 * g + 4 * c;
                     if (i0 < JW && i0 < JE) {
 #pragma unroll
                         for (int s = 0; s < KS; ++s)
@@ -412,7 +414,8 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
                                                         sv[4 * c + u]);
                     }
                 }
-                const double tot = (8 * g + 8 <= JW) ? fold8<8>(sv) : fold8<((JW & 7) ? (JW & 7) : 8)>(sv);
+                const double tot = (16 * g + 16 <= JW) ? fold16<16>(sv)
+                                                       : fold16<((JW & 15) ? (JW & 15) : 16)>(sv);
                 twv[g] = cntv[g] * rcp_pos<true>(tot + 1e-100);
             }
         }
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
                 for (int u = 0; u < 4; ++u) {
                     const int i = 4 * c + u;
                     if (i < JW) {
-                        const double twi = readlane_f64(twv[i / 8], fold8_lane(i & 7));
+                        const double twi = readlane_f64(twv[i / 16], fold16_lane(i & 15));
 #pragma unroll
                         for (int s = 0; s < KS; ++s)
                             acc[i % NSET][s] = fma(twi, beta[i < JW ? i : 0][s], acc[i % NSET][s]);
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
         __syncthreads();                             // tw_csr of the tail words
 #pragma unroll
         for (int i = 0; i < JW; ++i) {
-            const double twi = readlane_f64(twv[i / 8], fold8_lane(i & 7));
+            const double twi = readlane_f64(twv[i / 16], fold16_lane(i & 15));
             const int j = i * W + wid;
             if (j < n_reg) {
                 double *col = a.sstats_acc + (size_t)ids[j] * K;
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
                     unsafeAtomicAdd(&col[lane + 64 * s], twj * e[s]);
         }
     } else {
-        if ((lane & 7) == 0) {
+        if ((lane & 3) == 0) {                       // (a fold's result sits in all four lanes of a quad)
 #pragma unroll
             for (int g = 0; g < NH; ++g)
                 if (jv[g] >= 0)
