@@ -182,6 +182,12 @@ def main():
     _ffi.check(L.trlda_model_set_dense_preamble(model, int(args.dense_preamble)))
     _ffi.check(L.trlda_model_set_split_preamble(model, int(args.split_preamble)))
 
+    if collective:
+        # every rank has the communicator, or none uses it (a rank on its own in a collective hangs)
+        have = torch.tensor([int(rccl_comm is not None)], device=device)
+        dist.all_reduce(have, op=dist.ReduceOp.MIN)
+        if int(have.item()) != 1:
+            rccl_comm = None
     if rccl_comm is not None:                         # one check against torch's collective
         probe = torch.ones(KV, dtype=torch.float64, device=device) * (rank + 1)
         want = probe.clone()

@@ -31,12 +31,17 @@ def own_communicator(dist, device, group=None):
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     lib = _librccl()
     uid = _UniqueId()
+    # (a failure on rank 0 travels with the id: no rank is left waiting in the broadcast)
+    good = 1
     if rank == 0 and lib.ncclGetUniqueId(C.byref(uid)) != 0:
-        raise RuntimeError("ncclGetUniqueId failed")
-    raw = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone().to(device)
+        good = 0
+    raw = torch.frombuffer(bytearray(bytes(uid) + bytes([good])), dtype=torch.uint8).clone().to(device)
     src = dist.get_global_rank(group, 0) if group is not None else 0
     dist.broadcast(raw, src=src, group=group)
-    C.memmove(C.byref(uid), bytes(raw.cpu().numpy().tobytes()), 128)
+    host = raw.cpu().numpy().tobytes()
+    if host[128] != 1:
+        raise RuntimeError("ncclGetUniqueId failed on rank 0")
+    C.memmove(C.byref(uid), host[:128], 128)
     comm = C.c_void_p()
     if lib.ncclCommInitRank(C.byref(comm), world, uid, rank) != 0:
         raise RuntimeError("ncclCommInitRank failed")
