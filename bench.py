@@ -211,8 +211,8 @@ def main():
                                          zipf=not args.uniform))
     exchange = "none"
     if collective:
-        probe = rank_corpus(rank, 0)
-        slot = B * K + int(probe.indptr[-1]) * 11 // 10            # ~ max_r(docs) K + max_r(nnz)
+        # ~ max_r(docs) K + max_r(nnz), from the arguments only: the same choice on every rank
+        slot = B * K + int(B * args.mean_unique * 1.2)
         factors_bytes, sstats_bytes = 8. * xworld * slot, 8. * 2. * KV
         exchange = args.exchange if args.exchange != "auto" else \
             ("factors" if factors_bytes < sstats_bytes else "sstats")
