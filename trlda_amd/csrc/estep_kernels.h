@@ -956,7 +956,7 @@ __device__ __forceinline__ double sum8_strided(const double *p)
 // host picks the variant per batch by its longest document: a launch lasts as long as its
 // longest document, and the variants cost 33 / 36 / 42 us on the bench's documents.
 // The preamble of the NEXT batch as extra workgroups of this launch: a 200-document batch leaves
-// 56 of the 256 CUs idle for the 35 us the document workgroups run, and consecutive E-steps on an
+// 56 of the 256 CUs idle for the ~31 us the document workgroups run, and consecutive E-steps on an
 // unchanged lambda are independent of each other -- so the workgroups past the documents fill
 // exp(psi(lambda)) and the row-sum partials for the batch that the host announced as the next
 // one, into the model's alternate buffers; that batch's E-step then starts with its document
