@@ -597,3 +597,26 @@ def test_next_preamble_from_the_m_step_changes_nothing_but_rounding(hip):
     for a, b, c in zip(on, off, again):
         assert relerr(a, b) < 1e-12, relerr(a, b)
         assert np.array_equal(a, c)
+
+
+def test_word_count_sums_beyond_32_bits(hip, oracle, sampler):
+    """The trust-region initial step (onlinelda.cpp:79-86) takes the words' count sums from the
+    batch (formed on the host, int32); a sum that does not fit 32 bits sends the call to the
+    device's own sums.  Both against the oracle."""
+    import trlda_amd
+    from trlda_amd.documents import CSRDocuments
+    K, V, D = 16, 200, 5000
+    lam0 = random_lambda(K, V, 88)
+    for big in (1000, 2000000000):                   # 3 x 2e9 for word 7: 6e9 > 2^31
+        indptr = np.array([0, 3, 5, 8], dtype=np.int32)
+        ids = np.array([7, 11, 150, 7, 60, 7, 11, 199], dtype=np.int32)
+        cnts = np.array([big, 2, 1, big, 3, big, 1, 4], dtype=np.int32)
+        docs = CSRDocuments(indptr, ids, cnts)
+        m = online_model(K, V, lam0, D)
+        trlda_amd.seed(91)
+        rho = m.update_parameters(docs, max_iter_tr=2, max_iter_inference=20)
+        g0 = seeded_gamma(sampler, 91, K, 3)
+        rho_o, lam, _g = oracle_online_update(oracle, lam0, .1, .3, D, docs, g0, 0, 2, 20)
+        assert rho == rho_o
+        assert relerr(m.lambdas, lam) < 1e-8, (big, relerr(m.lambdas, lam))
+        m.close()

@@ -216,6 +216,7 @@ template <int T, int VEC, int ACT, bool SAVE_ALL>
 __global__ __launch_bounds__(T) void inactive_update_stream_kernel(
     int K, int V, int P, int cpb, double a, double b, double rho, double eta, double coef,
     const uint8_t *__restrict__ active_flag, const double *__restrict__ wordcounts,
+    const int32_t *__restrict__ wordcounts_i32 /* or nullptr: the doubles */,
     const double *src, double *lambda, double *lambda_prime, double *__restrict__ part_static,
     double *__restrict__ part_active)
 {
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(T) void inactive_update_stream_kernel(
             for (int u = 0; u < U; ++u) {
                 const int c = min(col + u * m, V - 1);
                 fl[u] = active_flag ? active_flag[c] != 0 : true;
-                wc[u] = ACT == ACT_TRINIT ? wordcounts[c] : 0.0;
+                wc[u] = ACT != ACT_TRINIT ? 0.0 : wordcounts_i32 ? (double)wordcounts_i32[c] : wordcounts[c];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {

@@ -163,6 +163,10 @@ struct trlda_batch {
     // in the gathered buffer, for the cut points / geometry in dp_sig (built on first use)
     int32_t *dp_wsrc = nullptr, *dp_wrow = nullptr;
     std::vector<int64_t> dp_sig;
+    // sum of the counts per word (onlinelda.cpp:79-82), formed on the host while the batch is
+    // indexed; valid unless a sum does not fit 32 bits (then the device adds them up)
+    int32_t *wc32 = nullptr;
+    bool wc32_ok = false;
 };
 
 // A data-parallel call in flight (dp_kernels.h): the model holds the whole mini-batch `b`, iterates
@@ -1294,7 +1298,7 @@ int wordcounts_device(trlda_model *m, const trlda_batch *b, double *wc)
 template <int ACT, bool SAVE_ALL>
 int launch_inactive_update(trlda_model *m, double a, double b, double rho, double eta, double coef,
                            const uint8_t *flags, const double *wc, const double *src,
-                           double *lambda_prime, int *G_out)
+                           double *lambda_prime, int *G_out, const int32_t *wc32 = nullptr)
 {
     constexpr int T = trlda::kStreamThreads;
     const trlda::StreamGeom g = trlda::stream_geometry(m->K, m->V);
@@ -1303,11 +1307,11 @@ int launch_inactive_update(trlda_model *m, double a, double b, double rho, doubl
     if (g.vec == 2)
         hipLaunchKernelGGL((trlda::inactive_update_stream_kernel<T, 2, ACT, SAVE_ALL>), dim3(g.G),
                            dim3(T), lds, m->stream, m->K, m->V, g.P, g.cpb, a, b, rho, eta, coef,
-                           flags, wc, src, m->lambda, lambda_prime, ps, pa);
+                           flags, wc, wc32, src, m->lambda, lambda_prime, ps, pa);
     else
         hipLaunchKernelGGL((trlda::inactive_update_stream_kernel<T, 1, ACT, SAVE_ALL>), dim3(g.G),
                            dim3(T), lds, m->stream, m->K, m->V, g.P, g.cpb, a, b, rho, eta, coef,
-                           flags, wc, src, m->lambda, lambda_prime, ps, pa);
+                           flags, wc, wc32, src, m->lambda, lambda_prime, ps, pa);
     HIP_TRY(hipGetLastError());
     *G_out = g.G;
     return TRLDA_OK;
@@ -2003,7 +2007,7 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
                  o_wptr = section(((size_t)V + 1) * 4), o_wdoc = section(nz * 4),
                  o_meta = section(Bz * 16), o_pids = section(Bz * trlda::kRegMaxN * 4),
                  o_active = section((size_t)n_active * 4), o_long = section((size_t)n_long * 4),
-                 o_flag = section((size_t)V);
+                 o_flag = section((size_t)V), o_wc32 = section((size_t)V * 4);
     const size_t total = off;
 
     UploadContext &u = upload_context(device);
@@ -2034,16 +2038,23 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
         std::memcpy(I(o_cnts), cnts, nz * 4);
     }
     std::memcpy(I(o_wptr), wptr.data(), ((size_t)V + 1) * 4);
-    // stable counting sort of the CSR positions by word id
+    // stable counting sort of the CSR positions by word id, and the words' count sums
+    bool wc32_ok = true;
     {
-        int32_t *wrank = I(o_wrank), *wdoc = I(o_wdoc);
+        int32_t *wrank = I(o_wrank), *wdoc = I(o_wdoc), *wc32 = I(o_wc32);
         std::vector<int32_t> cursor(wptr.begin(), wptr.end() - 1);
+        std::vector<int64_t> wsum((size_t)V, 0);
         for (int d = 0; d < B; ++d)
             for (int32_t p = indptr[d]; p < indptr[d + 1]; ++p) {
                 const int32_t q = cursor[(size_t)ids[p]]++;
                 wrank[p] = q;
                 wdoc[q] = d;
+                wsum[(size_t)ids[p]] += cnts[p];
             }
+        for (int w = 0; w < V; ++w) {
+            wc32_ok = wc32_ok && wsum[(size_t)w] >= INT32_MIN && wsum[(size_t)w] <= INT32_MAX;
+            wc32[w] = (int32_t)wsum[(size_t)w];
+        }
     }
     int32_t *order = I(o_order);
     std::iota(order, order + B, 0);
@@ -2151,6 +2162,8 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     b->pad_meta = D(o_meta); b->pad_ids = D(o_pids);
     b->active = D(o_active); b->long_words = D(o_long);
     b->active_flag = reinterpret_cast<uint8_t *>(dv + o_flag);
+    b->wc32 = D(o_wc32);
+    b->wc32_ok = wc32_ok;
     *out = b;
     return TRLDA_OK;
 }
@@ -2712,15 +2725,17 @@ int online_update_fused(trlda_model *m, const trlda_batch *b, int num_documents,
 
     if (max_iter_tr > 0) {
         // onlinelda.cpp:79-86 for the active words, the final value for all the others
-        rc = wordcounts_device(m, b, m->wordcounts);
+        // (the words' count sums came with the batch, unless one of them overflows 32 bits)
+        const int32_t *wc32 = b->wc32_ok ? b->wc32 : nullptr;
+        rc = wc32 ? batch_begin(m, b) : wordcounts_device(m, b, m->wordcounts);
         const double coef = (double)num_documents / (double)B / (double)K;   // onlinelda.cpp:86
         if (!rc)
             rc = keep ? launch_inactive_update<trlda::ACT_TRINIT, true>(
                             m, 1. - rho, rho * eta, rho, eta, coef, b->active_flag, m->wordcounts,
-                            m->lambda, m->lambda_prime, &G)
+                            m->lambda, m->lambda_prime, &G, wc32)
                       : launch_inactive_update<trlda::ACT_TRINIT, false>(
                             m, 1. - rho, rho * eta, rho, eta, coef, b->active_flag, m->wordcounts,
-                            m->lambda, m->lambda_prime, &G);
+                            m->lambda, m->lambda_prime, &G, wc32);
         if (!rc) rc = combine_rowsums(m, m->partial, G, nullptr, m->rs_static);
         // (the initial step obeys the same bound on the row sums as the M-steps)
         if (!rc) rc = carry_rowsums_from(m, m->partial + (size_t)trlda::kStreamMaxBlocks * K, G,
