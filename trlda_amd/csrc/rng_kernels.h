@@ -36,6 +36,8 @@ namespace trlda {
 constexpr int kRngSegment = 256;
 constexpr int kRngSegmentSmall = 64;
 constexpr long long kRngSmallDraws = (long long)1 << 25;
+constexpr int kRngSegmentTiny = 32;   // a mini-batch of 200 documents at K = 100: 2 * 10^6 draws
+constexpr long long kRngTinyDraws = (long long)1 << 22;
 constexpr int kRngLevels = 8;         // 16^8 segments: more than any table needs
 constexpr int kRngThreads = 256;
 
@@ -80,7 +82,9 @@ struct RngSeedWindow {
 };
 
 template <int T>
-__global__ __launch_bounds__(T) void window_direct_kernel(long long S, int levels, RngSeedWindow w0,
+__global__ __launch_bounds__(T) void window_direct_kernel(long long S /* stride of win */,
+                                                          long long S0 /* windows [0, S0) */, int levels,
+                                                          RngSeedWindow w0,
                                                           const uint32_t *__restrict__ mats_t,
                                                           uint32_t *__restrict__ win)
 {
@@ -107,8 +111,32 @@ __global__ __launch_bounds__(T) void window_direct_kernel(long long S, int level
         }
         buf ^= 1;                                    // the next level writes the other line
     }
-    if (s < S && i < 31)
+    if (s < S0 && i < 31)
         win[(size_t)i * S + s] = w;
+}
+
+// One level, 32 lanes per window, transposed matrices: W_s = M[level][s / unit] W_(s mod unit)
+// for s in [lo, hi) -- ONE matrix-vector product per window, where the direct form spends one
+// per level.  Requests with a few ten thousand windows take the first three levels (4096 windows)
+// directly and the rest level by level: two or three launches instead of one with 4x the work.
+template <int T>
+__global__ __launch_bounds__(T) void window_level_coop_kernel(long long S, long long lo, long long hi,
+                                                              long long unit,
+                                                              const uint32_t *__restrict__ mats_t,
+                                                              uint32_t *__restrict__ win)
+{
+    const long long s = lo + ((long long)blockIdx.x * T + threadIdx.x) / 32;
+    const int i = threadIdx.x & 31;
+    if (s >= hi || i >= 31)
+        return;
+    const int d = (int)(s / unit);                   // 1 .. 15
+    const long long r = s - (long long)d * unit;
+    const uint32_t *Mt = mats_t + (size_t)(d - 1) * 961 + i;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < 31; ++j)
+        acc += Mt[j * 31] * win[(size_t)j * S + r];
+    win[(size_t)i * S + s] = acc;
 }
 
 // positions [pos_lo, pos_hi) of the stream (a whole number of passes of `total` elements);

@@ -1836,7 +1836,9 @@ int sample_gamma_on_device(trlda_model *m, long long total, int passes, double d
         e_hi = total;
     constexpr int T = trlda::kRngThreads;
     const long long draws = total * passes;
-    const int L = draws < trlda::kRngSmallDraws ? trlda::kRngSegmentSmall : trlda::kRngSegment;
+    const int L = draws < trlda::kRngTinyDraws    ? trlda::kRngSegmentTiny
+                  : draws < trlda::kRngSmallDraws ? trlda::kRngSegmentSmall
+                                                  : trlda::kRngSegment;
     const long long S = (draws + L - 1) / L;
     const uint32_t *mats = nullptr;
     int rc = rng_device_matrices(m->device, L, &mats);
@@ -1857,10 +1859,20 @@ int sample_gamma_on_device(trlda_model *m, long long total, int passes, double d
     if (unit < S)
         return fail(TRLDA_ERR_ARG, "sampleGamma request too large for the device generator");
     if (S < 200000) {
-        // few windows: every one straight from the seed window, one launch
-        hipLaunchKernelGGL(trlda::window_direct_kernel<T>, dim3((unsigned)((S * 32 + T - 1) / T)), dim3(T),
-                           0, m->stream, S, levels, w0, mats + (size_t)trlda::kRngLevels * 15 * 961,
-                           m->rng_win);
+        // few windows: the first three levels (4096 windows) straight from the seed window in one
+        // launch, the levels above with one matrix-vector product per window each
+        const uint32_t *mats_t = mats + (size_t)trlda::kRngLevels * 15 * 961;
+        const int direct = std::min(levels, 3);
+        const long long S0 = std::min<long long>(S, 4096);
+        hipLaunchKernelGGL(trlda::window_direct_kernel<T>, dim3((unsigned)((S0 * 32 + T - 1) / T)), dim3(T),
+                           0, m->stream, S, S0, direct, w0, mats_t, m->rng_win);
+        unit = 4096;
+        for (int l = direct; l < levels; ++l, unit *= 16) {
+            const long long lo = unit, hi = std::min<long long>(S, unit * 16);
+            hipLaunchKernelGGL(trlda::window_level_coop_kernel<T>,
+                               dim3((unsigned)(((hi - lo) * 32 + T - 1) / T)), dim3(T), 0, m->stream, S,
+                               lo, hi, unit, mats_t + (size_t)l * 15 * 961, m->rng_win);
+        }
     } else {
         hipLaunchKernelGGL(window_seed_kernel, dim3(1), dim3(64), 0, m->stream, S, w0, m->rng_win);
         unit = 1;
@@ -1878,6 +1890,10 @@ int sample_gamma_on_device(trlda_model *m, long long total, int passes, double d
         const dim3 dgrid((unsigned)((seg_hi - seg_lo + T - 1) / T));
         if (L == trlda::kRngSegment)
             hipLaunchKernelGGL((trlda::draw_log_kernel<T, trlda::kRngSegment>), dgrid, dim3(T), 0,
+                               m->stream, S, seg_lo, std::min(S, seg_hi), pos_lo, pos_hi, total, e_lo,
+                               e_hi, m->rng_win, m->rng_vbuf);
+        else if (L == trlda::kRngSegmentTiny)
+            hipLaunchKernelGGL((trlda::draw_log_kernel<T, trlda::kRngSegmentTiny>), dgrid, dim3(T), 0,
                                m->stream, S, seg_lo, std::min(S, seg_hi), pos_lo, pos_hi, total, e_lo,
                                e_hi, m->rng_win, m->rng_vbuf);
         else
