@@ -88,6 +88,14 @@ def parse():
                          "by extra workgroups of the previous step's document-kernel launch")
     ap.add_argument("--no-update-rates", action="store_true",
                     help="skip the secondary update_parameters figures (N = 1 only)")
+    ap.add_argument("--repeats", type=int, default=7,
+                    help="the timed region (--steps steps) is run this many times back to back; "
+                         "the median is reported, min / max beside it")
+    ap.add_argument("--launch-timeout", type=float, default=1500.,
+                    help="`--gpus N` without a launcher starts the N ranks itself; seconds after "
+                         "which it ends them and fails")
+    ap.add_argument("--dry-run-launch", action="store_true",
+                    help="exercise the rank launch only (no torch, no GPU): CPU test of the path")
     return ap.parse_args()
 
 
@@ -104,18 +112,127 @@ def algorithmic_bytes(K, V, indptr):
     return estep, docs_kernel, B
 
 
+def launch_ranks(n, argv, timeout_s):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes ourselves.
+
+    The parent never touches the GPU (torch is not even imported here): the ranks are CHILD
+    processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment -- what
+    torch.distributed.run would give them -- and rank 0's JSON line is relayed as the parent's
+    one line of stdout.  Any rank failing, or the deadline passing, ends every rank (each child
+    leads a process group of its own, killed by exact pid) and the parent exits non-zero
+    without a JSON line."""
+    import signal
+    import socket
+    import subprocess
+    import tempfile
+    assert "torch" not in sys.modules, "the launching parent must stay off the GPU runtime"
+    with socket.socket() as s:                        # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs, outs = [], []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   TRLDA_BENCH_PARENT_HAD_TORCH=str(int("torch" in sys.modules)))
+        out = tempfile.TemporaryFile(mode="w+")
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=out, stderr=None, start_new_session=True))
+
+    def end_all():
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGTERM)
+                except OSError:
+                    pass
+        t_end = time.time() + 5.
+        for p in procs:
+            try:
+                p.wait(max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                p.wait()
+
+    deadline = time.time() + timeout_s
+    failed = None
+    try:
+        while failed is None and any(p.poll() is None for p in procs):
+            for r, p in enumerate(procs):
+                if p.poll() not in (None, 0):
+                    failed = "rank %d exited with status %d" % (r, p.returncode)
+                    break
+            if failed is None and time.time() > deadline:
+                failed = "no result after %.0f s (--launch-timeout)" % timeout_s
+            if failed is None:
+                time.sleep(0.05)
+        for r, p in enumerate(procs):
+            if failed is None and p.poll() not in (None, 0):
+                failed = "rank %d exited with status %d" % (r, p.returncode)
+    finally:
+        end_all()
+    lines = []
+    for r, out in enumerate(outs):
+        out.seek(0)
+        text = out.read()
+        out.close()
+        if r == 0:
+            lines = [l for l in text.splitlines() if l.strip()]
+        elif text.strip():
+            sys.stderr.write(text)                   # other ranks' stdout is not the result
+    result = None
+    for l in lines:
+        try:
+            j = json.loads(l)
+        except ValueError:
+            j = None
+        if isinstance(j, dict) and "metric" in j:
+            result = l
+        else:
+            sys.stderr.write(l + "\n")
+    if failed is None and result is None:
+        failed = "rank 0 printed no result line"
+    if failed is not None:
+        sys.stderr.write("bench.py --gpus %d: %s; all ranks ended, no result\n" % (n, failed))
+        return 1
+    print(result, flush=True)
+    return 0
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: be the launcher (child processes, before any GPU call)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], args.launch_timeout))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run "
-                             "--nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
+    if args.dry_run_launch:
+        # CPU check of the launch path (tests/test_bench_launch.py): no torch, no GPU
+        if os.environ.get("TRLDA_BENCH_DRY_FAIL_RANK") == str(rank):
+            sys.exit(7)
+        if os.environ.get("TRLDA_BENCH_DRY_HANG_RANK") == str(rank):
+            time.sleep(3600)
+        mark = os.environ.get("TRLDA_BENCH_DRY_DIR")
+        if mark:
+            with open(os.path.join(mark, "rank%d" % rank), "w") as f:
+                f.write("%d %d %s %s\n" % (rank, world, os.environ.get("MASTER_ADDR"),
+                                          os.environ.get("TRLDA_BENCH_PARENT_HAD_TORCH")))
+        if rank == 0:
+            print(json.dumps({"metric": "dry run of the rank launch", "n_gpus": world,
+                              "torch_in_rank": "torch" in sys.modules}), flush=True)
+        return
 
     import torch
+    if torch.cuda.device_count() < world:             # (counting does not initialise the GPU)
+        sys.stderr.write("bench.py: %d GPUs requested, %d visible on this node\n"
+                         % (world, torch.cuda.device_count()))
+        sys.exit(3)
     import torch.distributed as dist
     from trlda_amd import _ffi, build
     from trlda_amd.documents import CSRDocuments, DeviceBatch
@@ -155,6 +272,11 @@ def main():
                 print("bench: own RCCL communicator unavailable (%s); using torch.distributed" % exc,
                       file=sys.stderr)
             rccl_comm = None
+
+    rccl_ranks = None
+    if rccl_comm is not None:
+        from trlda_amd import rccl
+        rccl_ranks = rccl.comm_count(rccl_comm)       # what RCCL itself says, not WORLD_SIZE
 
     K, V = args.topics, args.words
     strong = args.global_batch > 0
@@ -302,8 +424,20 @@ def main():
         virtual_hook = HOOK(fill_once)
         _ffi.check(L.trlda_model_set_allgather(model, C.cast(virtual_hook, C.c_void_p), None))
 
-    def step(i, want_iters=False, plain=False):         # plain: the bare E-step (parity leg)
+    cuts_solo = np.array([0, B], dtype=np.int32)
+    use_prefetch = [prefetch]
+
+    def step(i, want_iters=False, plain=False, solo=False):
+        # plain: the bare E-step (parity leg).  solo: the N > 1 step without its exchange -- this
+        # rank's documents, the same kernels, the M-step -- run by one rank on its own
         j = i % args.num_batches
+        if solo and exchange == "factors":
+            _ffi.check(L.trlda_model_estep_dp(
+                model, batches[j].handle, batches[j].handle, None, 0, 1,
+                cuts_solo.ctypes.data_as(C.POINTER(C.c_int32)), gamma0s[j].data_ptr(), gamma.data_ptr(),
+                None, args.max_iter, args.threshold, None, 1, lam_prime.data_ptr(), RHO, ETA,
+                D_TOTAL / float(B)))
+            return
         # gamma0 is read-only input, gamma the output (lda.cpp:168 copies, we do not).  The batch
         # of the next step is announced: its preamble (row sums + exp(psi(lambda)) on ITS words,
         # recomputed for every step) is prepared by extra workgroups of this step's document-kernel
@@ -319,38 +453,92 @@ def main():
                 None, args.max_iter, args.threshold, iters_dev.data_ptr() if want_iters else None, 1,
                 lam_prime.data_ptr(), RHO, ETA, D_TOTAL / float(B * xworld)))
             return
-        nxt = batches[(i + 1) % args.num_batches].handle if prefetch else None
+        nxt = batches[(i + 1) % args.num_batches].handle if use_prefetch[0] else None
         _ffi.check(L.trlda_model_estep_io_next(model, batches[j].handle, nxt, gamma0s[j].data_ptr(),
                                                gamma.data_ptr(), sstats.data_ptr(), args.max_iter,
                                                args.threshold,
                                                iters_dev.data_ptr() if want_iters else None))
         if collective and not plain:
-            if rccl_comm is not None:                 # RCCL over xGMI: K x V fp64 sum
+            if solo:
+                pass                                  # the sum over one rank
+            elif rccl_comm is not None:               # RCCL over xGMI: K x V fp64 sum
                 _ffi.check(L.trlda_model_allreduce_sstats(model, rccl_comm,
                                                           C.c_void_p(sstats.data_ptr())))
             else:
                 dist.all_reduce(sstats)
             _ffi.check(L.trlda_model_blend(model, lam_prime.data_ptr(), sstats.data_ptr(), RHO, ETA,
-                                           D_TOTAL / float(B * world)))
+                                           D_TOTAL / float(B * (1 if solo else world))))
 
     def fence():
         if collective and not vworld:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(**kw):
+        """EXACTLY args.steps steps between two fences; the maximum over ranks."""
+        fence()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, **kw)
+        fence()
+        dt = time.perf_counter() - t0
+        if collective and not vworld:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
     for i in range(args.warmup):
         step(i)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if collective and not vworld:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # the timed region, `--repeats` times back to back: the median is the result (20 steps of
+    # 40 us are under a millisecond -- one scheduling hiccup moves a single sample by 10 %)
+    samples = sorted(timed() for _ in range(max(1, args.repeats)))
+    elapsed = samples[len(samples) // 2]
     docs_per_s = world * B * args.steps / elapsed
+    repeats = {"n": len(samples), "value": "median",
+               "ms_per_step_min": round(1e3 * samples[0] / args.steps, 5),
+               "ms_per_step_max": round(1e3 * samples[-1] / args.steps, 5)}
+
+    # N = 1: the same steps with every preamble in a launch of its own (what a caller gets who
+    # does not announce its next batch, e.g. OnlineLDA.do_e_step)
+    value_no_prefetch = None
+    if prefetch:
+        use_prefetch[0] = False
+        for i in range(min(args.warmup, 5)):
+            step(i)
+        s_np = sorted(timed() for _ in range(max(1, args.repeats)))
+        value_no_prefetch = {"value": round(B * args.steps / s_np[len(s_np) // 2], 1), "unit": "docs/s",
+                             "ms_per_step": round(1e3 * s_np[len(s_np) // 2] / args.steps, 5)}
+        use_prefetch[0] = True
+        for i in range(2):
+            step(i)
+
+    # N > 1: the identical step (documents -> statistics -> M-step, no prefetch) WITHOUT the
+    # exchange, timed on rank 0 alone while the other ranks wait: the like-for-like one-GPU
+    # figure that the N-GPU value is to be divided by
+    same_step_n1 = None
+    if collective and not vworld:
+        dist.barrier()
+        if rank == 0:
+            for i in range(min(args.warmup, 5)):
+                step(i, solo=True)
+            s_solo = []
+            for _ in range(max(1, args.repeats)):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(args.steps):
+                    step(i, solo=True)
+                torch.cuda.synchronize()
+                s_solo.append(time.perf_counter() - t0)
+            s_solo.sort()
+            same_step_n1 = {"value": round(B * args.steps / s_solo[len(s_solo) // 2], 1),
+                            "unit": "docs/s", "n_gpus": 1,
+                            "ms_per_step": round(1e3 * s_solo[len(s_solo) // 2] / args.steps, 5),
+                            "what": "rank 0 alone, same kernels and M-step, no exchange"}
+        dist.barrier()
+        for i in range(2):                            # every rank back on the common lambda
+            _ffi.check(L.trlda_model_set_lambda(model, lam))
+            break
 
     # ---- per-kernel durations: HIP events on the launch stream, same steps replayed -------
     _ffi.check(L.trlda_model_set_timing(model, 1))
@@ -599,6 +787,10 @@ def main():
                    if collective else "none",
                    "exchange_check": exchange_probe,
                    "virtual_world": vworld or None},
+        "repeats": repeats,
+        "value_no_prefetch": value_no_prefetch,
+        "rccl_ranks": rccl_ranks,
+        "same_step_n1": same_step_n1,
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
         "parity": parity,

@@ -332,6 +332,29 @@ int trlda_model_online_update_multi(trlda_model *model, const trlda_batch *shard
                                     double tau, double rho, int init_gamma, double threshold,
                                     int *update_count, double *rho_out);
 
+/* BatchLDA::updateParameters, lambda path (src/batchlda.cpp:43-61), over the ranks of rccl_comm:
+ * max_epochs x { this rank's documents from a fresh random gamma -- its columns of the whole
+ * batch's draw, as above; ONE all-reduce of the K x V statistics (src/lda.cpp:211-217 across
+ * ranks); lambda = eta + sstats on every rank (src/batchlda.cpp:60) }.  BASELINE config 4: 100 000
+ * documents over 8 ranks, 80 MB per all-reduce.  gamma of the shard's documents stays on the
+ * device for trlda_model_eb_gamma_stats_multi. */
+int trlda_model_batch_update_multi(trlda_model *model, const trlda_batch *shard, void *rccl_comm,
+                                   int total_docs, int doc_lo, double eta, int max_epochs,
+                                   int max_iter_inference, int update_lambda, double threshold);
+/* buf_dev[count] <- sum over ranks (fp64), on the model's stream: the K-vector reduction of
+ * src/onlinelda.cpp:128 and any other sum a host composes across ranks */
+int trlda_model_allreduce(trlda_model *model, void *rccl_comm, double *buf_dev, size_t count);
+/* trlda_model_estep_resident for this rank's documents of a sharded mini-batch (gamma0 = its
+ * columns of the whole mini-batch's draw; no exchange, the statistics are not used) */
+int trlda_model_estep_resident_shard(trlda_model *model, const trlda_batch *shard, int total_docs,
+                                     int doc_lo, int max_iter, double threshold);
+/* trlda_model_eb_gamma_stats summed over the ranks' documents: out_host[k] = sum over ALL
+ * documents of psi(gamma_dk) - psi(sum_k gamma_dk) (src/onlinelda.cpp:123-128,
+ * src/batchlda.cpp:72-74); B = this rank's document count (0 allowed: the rank still takes part
+ * in the all-reduce of K doubles).  rccl_comm NULL: this rank's sums only. */
+int trlda_model_eb_gamma_stats_multi(trlda_model *model, void *rccl_comm, int B,
+                                     const double *gamma_dev, double *out_host /* K */);
+
 /* ---- multi-GPU with FACTOR exchange: an all-gather of 8 (K + n_d) bytes per document --------
  *
  * The same reduction point (src/lda.cpp:211-217), without moving K x V numbers.  lambda is
@@ -370,6 +393,14 @@ int trlda_model_online_update_dp(trlda_model *model, const trlda_batch *batch,
                                  double eta, int max_iter_tr, int max_iter_inference, double kappa,
                                  double tau, double rho, int init_gamma, double threshold,
                                  int *update_count, double *rho_out);
+/* BatchLDA::updateParameters (src/batchlda.cpp:43-61) with the factor exchange: the arguments of
+ * trlda_model_batch_update, which it equals for world = 1.  Pays where the words outnumber the
+ * documents' factors (world * slot < 2 K V); BASELINE config 4 is the opposite case
+ * (trlda_model_batch_update_multi). */
+int trlda_model_batch_update_dp(trlda_model *model, const trlda_batch *batch,
+                                const trlda_batch *shard, void *rccl_comm, int rank, int world,
+                                const int32_t *doc_cuts /* world + 1 */, double eta, int max_epochs,
+                                int max_iter_inference, int update_lambda, double threshold);
 /* One E-step (src/lda.cpp:160-220) over `world` ranks: gamma0_dev / gamma_dev hold this rank's
  * K x docs_r columns (gamma0_dev NULL: in place); sstats_dev (K x V, may be NULL with mstep)
  * receives the statistics of the whole mini-batch; iters_dev this rank's iteration counts or
@@ -449,6 +480,12 @@ int trlda_model_eb_lambda_stats(trlda_model *model, double *sum_psi_lambda,
  * returns |lambdaUpdate|^2 and |mAdaGradient|^2.  eta: the value the update used. */
 int trlda_model_adaptive_stats(trlda_model *model, double eta, double scale, double tau,
                                double *sq_norm_update, double *sq_norm_gradient);
+
+/* The same with the statistics and lambda' given as device arrays (K x V each): for a host that
+ * composes the data-parallel update itself (E-step -> all-reduce -> blend) and holds both. */
+int trlda_model_adaptive_stats_dev(trlda_model *model, const double *sstats_dev,
+                                   const double *lambda_prime_dev, double eta, double scale,
+                                   double tau, double *sq_norm_update, double *sq_norm_gradient);
 
 /* ---- test hook ----------------------------------------------------------- */
 

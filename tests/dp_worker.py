@@ -104,7 +104,8 @@ def main():
     count = C.c_int(0)
     for call, spec in enumerate(cfg["calls"]):
         csr = CSRDocuments(*make_corpus(spec["B"], V, seed=spec["corpus_seed"],
-                                        mean_unique=spec.get("mean_unique", 60)))
+                                        mean_unique=spec.get("mean_unique", 60),
+                                        lengths=spec.get("lengths")))
         cuts = np.asarray(spec["cuts"], dtype=np.int32) if "cuts" in spec \
             else csr.shard_cuts(world).astype(np.int32)
         lo, hi = int(cuts[rank]), int(cuts[rank + 1])
@@ -119,6 +120,11 @@ def main():
                 spec["max_iter_tr"], spec["max_iter_inference"], .7, 100., -1., 1, 1e-3,
                 C.byref(count), C.byref(rho)))
             out["rho%d" % call] = np.array([rho.value])
+        elif spec["kind"] == "batch":                       # BatchLDA epochs, batchlda.cpp:43-61
+            L.trlda_seed(spec["seed"])
+            _ffi.check(L.trlda_model_batch_update_dp(
+                model, batch.handle, shard.handle, None, rank, world, cuts_p, cfg["eta"],
+                spec["max_epochs"], spec["max_iter_inference"], 1, 1e-3))
         else:                                               # one E-step from a given gamma0
             g0 = np.load(spec["gamma0"])                    # K x B, column-major file
             mine = np.ascontiguousarray(g0[:, lo:hi].T)     # docs_r x K == K x docs_r col-major

@@ -65,7 +65,28 @@ class OracleEngine(object):
 
     def blend(self, sstats, rho, eta, scale):
         s = sstats.numpy().reshape(self.K, self.V, order="F")
+        self.last_sstats = s.copy(order="F")
         self.lam = self.o.mstep_blend(self.lam_prime, s, rho, eta, scale)
+
+    # -- empirical Bayes / adaptive rate: this rank's sums, plain NumPy + SciPy ---------------
+    def psi_gamma_diff(self, num_local):
+        from scipy.special import digamma
+        if num_local == 0:
+            return np.zeros(self.K), False
+        g = self.gamma
+        return (digamma(g) - digamma(g.sum(axis=0))[None, :]).sum(axis=1), False
+
+    def lambda_psi_stats(self):
+        from scipy.special import digamma
+        return float(digamma(self.lam).sum()), self.lam.sum(axis=1)
+
+    def adaptive_stats(self, eta, scale, tau, internal):
+        assert not internal
+        upd = (eta + scale * self.last_sstats) - self.lam_prime
+        if not hasattr(self, "ada"):
+            self.ada = np.zeros_like(upd)
+        self.ada = (1. - 1. / tau) * self.ada + 1. / tau * upd
+        return float((upd * upd).sum()), float((self.ada * self.ada).sum())
 
 
 def _free_port():
@@ -124,6 +145,107 @@ def _worker(rank, world, port, outdir):
                          rhos=np.array(rhos))
     finally:
         dist.destroy_process_group()
+
+
+def _kwargs(arr):
+    import ast
+    return {str(k): ast.literal_eval(str(v)) for k, v in arr}
+
+
+def _golden_worker(rank, world, port, outdir):
+    """The empirical-Bayes / adaptive-rate trajectories of the COMPILED REFERENCE (golden f8:
+    OnlineLDA, f9: BatchLDA) replayed by the sharded models over two gloo ranks."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import trlda_amd
+        from helpers import golden
+        from trlda_amd.distributed import ShardedBatchLDA, ShardedOnlineLDA
+        from trlda_amd.documents import CSRDocuments
+        f = golden("f8_empirical_bayes")
+        K8, V8, D8 = int(f["K"]), int(f["V"]), int(f["D"])
+        res = {}
+        for case in range(int(f["num_cases"])):
+            kw = _kwargs(f["c%d_kwargs" % case])
+            trlda_amd.seed(3000 + case if rank == 0 else 77 + rank)
+            m = ShardedOnlineLDA(V8, K8, D8, alpha=np.linspace(.05, .4, K8), eta=.25,
+                                 engine=OracleEngine(V8, K8))
+            for i in range(4):
+                docs = CSRDocuments(f["indptr%d" % i], f["ids%d" % i], f["cnts%d" % i])
+                args = dict(max_iter_tr=2, max_iter_inference=20, kappa=.7, tau=10., rho=-1.)
+                args.update(kw)
+                if case % 2:                                  # odd cases: every rank its own shard
+                    cuts = docs.shard_cuts(world)
+                    lo, hi = int(cuts[rank]), int(cuts[rank + 1])
+                    r = m.update_parameters(docs.slice(lo, hi), presharded=True, total_docs=len(docs),
+                                            doc_range=(lo, hi), **args)
+                else:
+                    r = m.update_parameters(docs, **args)
+                assert m.replicas_agree()
+                res["on%d_%d" % (case, i)] = np.concatenate(
+                    [[r, m.eta], m.alpha.ravel(), m.lambdas.ravel(order="F")])
+            assert m.update_count == 4
+        f = golden("f9_batch_empirical_bayes")
+        K9, V9 = int(f["K"]), int(f["V"])
+        docs = CSRDocuments(f["indptr"], f["ids"], f["cnts"])
+        for case in range(int(f["num_cases"])):
+            kw = _kwargs(f["c%d_kwargs" % case])
+            trlda_amd.seed(4000 + case if rank == 0 else 99 + rank)
+            m = ShardedBatchLDA(V9, K9, alpha=np.linspace(.1, .6, K9), eta=.2,
+                                engine=OracleEngine(V9, K9))
+            args = dict(max_epochs=3, max_iter_inference=50)
+            args.update(kw)
+            assert m.update_parameters(docs, **args) == 1.
+            assert m.replicas_agree()
+            res["ba%d" % case] = np.concatenate([[m.eta], m.alpha.ravel(), m.lambdas.ravel(order="F")])
+        # plain BatchLDA epochs (no empirical Bayes), every rank its own shard
+        trlda_amd.seed(4100 if rank == 0 else 5)
+        m = ShardedBatchLDA(V9, K9, alpha=.2, eta=.2, engine=OracleEngine(V9, K9))
+        cuts = docs.shard_cuts(world)
+        lo, hi = int(cuts[rank]), int(cuts[rank + 1])
+        m.update_parameters(docs.slice(lo, hi), max_epochs=2, max_iter_inference=30, presharded=True,
+                            total_docs=len(docs), doc_range=(lo, hi))
+        assert m.replicas_agree() and m.update_parameters([]) == 1.
+        res["plain"] = m.lambdas.ravel(order="F")
+        if rank == 0:
+            np.savez(os.path.join(outdir, "golden_replay.npz"), **res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_empirical_bayes_and_batch_lda_match_the_reference(tmp_path, oracle, hip_lib):
+    """ShardedOnlineLDA with update_alpha / update_eta / adaptive and ShardedBatchLDA with its line
+    searches, two gloo ranks: alpha, eta, lambda and rho after every call equal the compiled
+    reference's single-process trajectories (golden f8 / f9; onlinelda.cpp:116-175,
+    batchlda.cpp:43-205)."""
+    from helpers import golden, relerr
+    world = 2
+    mp.spawn(_golden_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = np.load(os.path.join(str(tmp_path), "golden_replay.npz"))
+    f = golden("f8_empirical_bayes")
+    K8 = int(f["K"])
+    for case in range(int(f["num_cases"])):
+        for i in range(4):
+            g = got["on%d_%d" % (case, i)]
+            assert abs(g[0] - f["c%d_rhos" % case][i]) <= 1e-9 * abs(g[0]), (case, i)
+            assert abs(g[1] - float(f["c%d_eta%d" % (case, i + 1)])) < 1e-8 * g[1], (case, i)
+            assert relerr(g[2:2 + K8], f["c%d_alpha%d" % (case, i + 1)].ravel()) < 1e-8, (case, i)
+            assert relerr(g[2 + K8:], f["c%d_lambda%d" % (case, i + 1)].ravel(order="F")) < 1e-8, (case, i)
+    f = golden("f9_batch_empirical_bayes")
+    K9, V9 = int(f["K"]), int(f["V"])
+    for case in range(int(f["num_cases"])):
+        g = got["ba%d" % case]
+        assert abs(g[0] - float(f["c%d_eta" % case])) < 1e-7 * g[0], case
+        assert relerr(g[1:1 + K9], f["c%d_alpha" % case].ravel()) < 1e-7, case
+        assert relerr(g[1 + K9:], f["c%d_lambda" % case].ravel(order="F")) < 1e-7, case
+    # the plain epochs against the oracle's BatchLDA from the same stream
+    oracle.seed(4100)
+    lam = oracle.sample_gamma(K9, V9, 100) / 100.
+    _, lam, _ = oracle.batch_update_parameters(lam, .2, .2, f["indptr"], f["ids"], f["cnts"],
+                                               max_epochs=2, max_iter_inference=30)
+    assert relerr(got["plain"], lam.ravel(order="F")) < 1e-11
 
 
 @pytest.mark.timeout(300)

@@ -32,10 +32,10 @@ def hip(hip_lib):
     return hip_lib
 
 
-def corpus(B, V, seed, mean_unique=60):
+def corpus(B, V, seed, mean_unique=60, lengths=None):
     from trlda_amd.documents import CSRDocuments
     from trlda_amd.utils.synthetic import make_corpus
-    return CSRDocuments(*make_corpus(B, V, seed=seed, mean_unique=mean_unique))
+    return CSRDocuments(*make_corpus(B, V, seed=seed, mean_unique=mean_unique, lengths=lengths))
 
 
 def random_lambda(K, V, seed):
@@ -83,6 +83,14 @@ class Single(object):
         self.ffi.check(self.L.trlda_model_synchronize(self.h))
         b.close()
         return rho.value
+
+    def batch_update(self, csr, eta, seed, max_epochs, max_iter_inference):
+        from trlda_amd.documents import DeviceBatch
+        b = DeviceBatch(csr, self.V, 0)
+        self.L.trlda_seed(seed)
+        self.ffi.check(self.L.trlda_model_batch_update(self.h, b.handle, eta, max_epochs,
+                                                       max_iter_inference, 1, 1e-3, None))
+        b.close()
 
     def lambdas(self):
         lam = np.empty((self.K, self.V), order="F")
@@ -193,6 +201,66 @@ def test_online_update_dp_large_table_and_plain_sequence(hip, tmp_path):
             lam_one = one.lambdas()
             one.close()
         assert relerr(res[0]["lambda"], lam_one) < 1e-11, (plain, relerr(res[0]["lambda"], lam_one))
+
+
+def test_long_document_in_one_shard_and_an_empty_shard(hip, oracle, tmp_path):
+    """The ranks must agree on what the gathered factors mean whatever their own shards hold
+    (ADVICE r2): one shard with a 300-word document (beyond the register kernel), one EMPTY shard,
+    one ordinary shard -- every rank's statistics and lambda bitwise equal, the mass balance
+    holds, and the results equal the one-GPU call's and the oracle's."""
+    from trlda_amd import _ffi
+    K, V, B, D, world = 100, 3000, 60, 8000, 3
+    lengths = [40 + (7 * i) % 50 for i in range(B)]
+    lengths[3] = 300                                        # in shard 0
+    cuts = [0, 25, 25, B]                                   # rank 1 holds nothing
+    csr = corpus(B, V, seed=861, lengths=lengths)
+    lam = random_lambda(K, V, 37)
+    g0 = np.asfortranarray(np.random.RandomState(5).gamma(100., .01, (K, B)))
+    np.save(str(tmp_path / "g0.npy"), g0)
+    specs = [dict(kind="estep", B=B, corpus_seed=861, lengths=lengths, cuts=cuts,
+                  gamma0=str(tmp_path / "g0.npy"), max_iter=20),
+             dict(kind="update", B=B, corpus_seed=861, lengths=lengths, cuts=cuts, seed=11,
+                  max_iter_tr=2, max_iter_inference=20)]
+    cfg = dict(K=K, V=V, D=D, alpha=.1, eta=.3, lambda_seed=37,
+               max_count=(35 * K + int(csr.indptr[-1]) + K), calls=specs)
+    res = run_ranks(tmp_path, cfg, world)
+    g_ref, s_ref, it_ref = oracle.estep(lam, np.full(K, .1), csr.indptr, csr.ids, csr.cnts, g0, 20,
+                                        1e-3, nthreads=8)
+    assert res[1]["gamma0"].shape[1] == 0
+    gamma = np.concatenate([r["gamma0"] for r in res], axis=1)
+    assert np.array_equal(np.concatenate([r["iters0"] for r in res]), it_ref)
+    assert relerr(gamma, g_ref) < TIGHT_RTOL
+    for r in res:
+        assert np.array_equal(r["sstats0"], res[0]["sstats0"])
+        assert np.array_equal(r["lambda"], res[0]["lambda"])
+    assert relerr(res[0]["sstats0"], s_ref, floor=1e-12) < TIGHT_RTOL
+    assert abs(res[0]["sstats0"].sum() - csr.cnts.sum()) < 1e-8 * csr.cnts.sum()
+    one = Single(hip, K, V, lam, .1)
+    rho = one.update(csr, D, .3, 11, 2, 20)
+    assert float(res[0]["rho1"][0]) == rho
+    assert relerr(res[0]["lambda"], one.lambdas()) < 1e-12
+    one.close()
+
+
+@pytest.mark.parametrize("K,V", [(100, 4000), (200, 9000)])
+def test_batch_update_dp_processes(hip, tmp_path, K, V):
+    """BatchLDA::updateParameters (batchlda.cpp:43-61), two epochs over two ranks with the factor
+    exchange: lambda bitwise equal across ranks and equal to the one-GPU model's."""
+    B = 80
+    specs = [dict(kind="batch", B=B, corpus_seed=871, seed=21, max_epochs=2, max_iter_inference=30)]
+    csrs = [corpus(B, V, seed=871)]
+    cfg = dict(K=K, V=V, D=0, alpha=.1, eta=.3, lambda_seed=41, max_count=slot_bound(csrs, K, 2),
+               calls=specs)
+    res = run_ranks(tmp_path, cfg, 2)
+    one = Single(hip, K, V, random_lambda(K, V, 41), .1)
+    one.batch_update(csrs[0], .3, 21, 2, 30)
+    lam_one = one.lambdas()
+    one.close()
+    assert np.array_equal(res[0]["lambda"], res[1]["lambda"])
+    assert int(res[0]["exchanges"][0]) == 2
+    assert relerr(res[0]["lambda"], lam_one) < 1e-12
+    # lambda = eta + sstats: the mass balance of the last epoch
+    assert abs(lam_one.sum() - (.3 * K * V + csrs[0].cnts.sum())) < 1e-9 * lam_one.sum()
 
 
 def test_world_one_is_the_single_gpu_call(hip):

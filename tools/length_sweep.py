@@ -1,0 +1,83 @@
+"""How long one E-step takes as a function of the documents' lengths: the cliffs between the
+document-kernel variants (estep_kernels.h 3c, estep_wide.h).
+
+    python tools/length_sweep.py [--topics 100 --words 7000 --batch 200]
+
+Two series, both on B-document batches at max_iter 20, threshold 0 (fixed work):
+  all   every document has exactly n unique words
+  one   B - 1 documents of 100 words and ONE of n words (a launch lasts as long as its longest
+        document: what a single long document costs the batch)
+Run on the GPU box from the repo root.
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--topics", type=int, default=100)
+    ap.add_argument("--words", type=int, default=7000)
+    ap.add_argument("--batch", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--lengths", default="32,64,100,128,129,144,145,160,192,193,224,256,320,400,600")
+    ap.add_argument("--series", default="all,one")
+    args = ap.parse_args()
+    import torch
+    from trlda_amd import _ffi
+    from trlda_amd.documents import CSRDocuments, DeviceBatch
+    from trlda_amd.utils.synthetic import make_corpus
+    L = _ffi.lib()
+    _ffi.require_gpu()
+    K, V, B = args.topics, args.words, args.batch
+    dev = torch.device("cuda", 0)
+    L.trlda_seed(1)
+    lam = np.empty((K, V), order="F")
+    L.trlda_sample_gamma_init(K, V, lam)
+    model = _ffi.vp()
+    _ffi.check(L.trlda_model_create(C.byref(model), 0, K, V))
+    _ffi.check(L.trlda_model_set_stream(model, _ffi.vp(torch.cuda.current_stream(dev).cuda_stream)))
+    _ffi.check(L.trlda_model_set_lambda(model, lam))
+    _ffi.check(L.trlda_model_set_alpha(model, np.full(K, .1)))
+    g0 = np.empty((K, B), order="F")
+    L.trlda_sample_gamma_init(K, B, g0)
+    gamma0 = torch.from_numpy(np.ascontiguousarray(g0.T)).to(dev)
+    gamma = torch.empty(B * K, dtype=torch.float64, device=dev)
+    sstats = torch.empty(K * V, dtype=torch.float64, device=dev)
+    print("K=%d V=%d B=%d, %d steps per point; us per E-step (documents kernel name)" % (K, V, B, args.steps))
+    for series in args.series.split(","):
+        for n in [int(x) for x in args.lengths.split(",")]:
+            if n > V:
+                continue
+            lens = np.full(B, n) if series == "all" else np.concatenate([[n], np.full(B - 1, 100)])
+            batches = [DeviceBatch(CSRDocuments(*make_corpus(B, V, seed=100 * n + i, lengths=lens)), V, 0)
+                       for i in range(4)]
+
+            def step(i):
+                _ffi.check(L.trlda_model_estep_io_next(
+                    model, batches[i % 4].handle, batches[(i + 1) % 4].handle, gamma0.data_ptr(),
+                    gamma.data_ptr(), sstats.data_ptr(), 20, 0., None))
+            for i in range(10):
+                step(i)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for i in range(args.steps):
+                step(i)
+            torch.cuda.synchronize()
+            us = (time.perf_counter() - t) / args.steps * 1e6
+            print("%-4s n=%4d  %8.1f us  %s  fused_preamble=%d" % (
+                series, n, us, L.trlda_model_last_doc_kernel(model).decode(),
+                L.trlda_model_last_preamble_fused(model)), flush=True)
+            for b in batches:
+                b.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -11,8 +11,10 @@ from trlda_amd.utils.synthetic import make_corpus
 L = _ffi.lib()
 L.trlda_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
 K, V, B = (int(os.environ.get(k, d)) for k, d in (("STAMPS_K", "100"), ("STAMPS_V", "7000"), ("STAMPS_B", "200")))
-WIDE = int(os.environ.get("STAMPS_WIDE", "0")) or K > 128
-indptr, ids, cnts = make_corpus(B, V, seed=20150707, mean_unique=int(os.environ.get("STAMPS_MEAN", "95")))
+WIDE = int(os.environ.get("STAMPS_WIDE", "0")) or K > 128 or int(os.environ.get("STAMPS_LEN", "0")) > 192
+LEN = int(os.environ.get("STAMPS_LEN", "0"))         # every document exactly this long
+indptr, ids, cnts = make_corpus(B, V, seed=20150707, mean_unique=int(os.environ.get("STAMPS_MEAN", "95")),
+                                lengths=np.full(B, LEN) if LEN else None)
 print("max doc length", np.diff(indptr).max())
 L.trlda_seed(1)
 m = OnlineLDA(V, K, 1000000)

@@ -109,9 +109,18 @@ _SIGNATURES = {
                                                 C.c_double, vp]),
     "trlda_model_estep_resident": (C.c_int, [vp, vp, C.c_int, C.c_double]),
     "trlda_model_eb_gamma_stats": (C.c_int, [vp, C.c_int, vp, f64p]),
+    "trlda_model_eb_gamma_stats_multi": (C.c_int, [vp, vp, C.c_int, vp, f64p]),
+    "trlda_model_batch_update_multi": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_double, C.c_int,
+                                                 C.c_int, C.c_int, C.c_double]),
+    "trlda_model_batch_update_dp": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(C.c_int32),
+                                              C.c_double, C.c_int, C.c_int, C.c_int, C.c_double]),
+    "trlda_model_allreduce": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "trlda_model_estep_resident_shard": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double]),
     "trlda_model_eb_lambda_stats": (C.c_int, [vp, C.POINTER(C.c_double), f64p]),
     "trlda_model_adaptive_stats": (C.c_int, [vp, C.c_double, C.c_double, C.c_double,
                                             C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "trlda_model_adaptive_stats_dev": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, C.c_double,
+                                                C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "trlda_debug_fold16": (C.c_int, [C.c_int, vp, vp, vp, vp]),
     "trlda_model_set_doc_kernel": (C.c_int, [vp, C.c_int]),
     "trlda_model_last_doc_kernel": (C.c_char_p, [vp]),

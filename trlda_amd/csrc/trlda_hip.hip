@@ -873,7 +873,10 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
     // 2 become one launch and the topic factors exp(-psiSum) are applied by the document
     // kernel (estep_kernels.h, 2b) -- as long as no row sum can be so small that exp(-psi(sum))
     // overflows (rs_floor: a bound the host keeps through every update)
-    const bool fused = fused_preamble_possible(m, db) && trust && m->rs_floor >= kFusedRowsumFloor;
+    // (data-parallel: a property of the WHOLE mini-batch, which every rank holds -- the ranks must
+    // agree on what the gathered factors mean: with the fused preamble a rank publishes c_k
+    // expElogtheta and keeps exp(psi(lambda)) unnormalised, without it plain expElogtheta)
+    const bool fused = fused_preamble_possible(m, b) && trust && m->rs_floor >= kFusedRowsumFloor;
     m->last_preamble_fused = fused;
     if (!fused && carried && (rc = resolve_carry(m)))   // everything else wants one row of sums
         return rc;
@@ -2769,7 +2772,7 @@ int online_update_fused(trlda_model *m, const trlda_batch *b, int num_documents,
             // sums come out of this iteration's M-step (after the last one only when every word
             // was written: whatever batch comes next is covered)
             out.next_base = out.active_only ? m->rs_static : nullptr;
-            out.emit_next = can_emit_next(m, m->dp ? m->dp->shard : b) && (!last || !out.active_only);
+            out.emit_next = can_emit_next(m, b) && (!last || !out.active_only);
             if (!rc)
                 rc = estep_device(m, b, m->gamma, out, max_iter_inference, threshold, nullptr);
             if (!rc)
@@ -2789,7 +2792,7 @@ int online_update_fused(trlda_model *m, const trlda_batch *b, int num_documents,
         out.active_only = false;
         out.upd.sstats = m->sstats;
         out.upd.lambda_prime = m->lambda_prime;
-        out.emit_next = can_emit_next(m, m->dp ? m->dp->shard : b);
+        out.emit_next = can_emit_next(m, b);
         rc = estep_device(m, b, m->gamma, out, max_iter_inference, threshold, nullptr);
         if (!rc) rc = finish_rowsums(m, out, nullptr, floor_after, b);
         return rc;
@@ -3090,6 +3093,36 @@ int allreduce_f64(trlda_model *m, void *comm, double *buf, size_t count)
     return TRLDA_OK;
 }
 
+// m->gamma = columns [doc_lo, doc_lo + Bl) of sampleGamma(K, B, 100) / 100 for a mini-batch of B
+// documents (lda.cpp:135): gamma0 of the whole mini-batch from the (shared) host stream, this
+// rank's columns kept -- every rank consumes the stream exactly as the single-process run does
+int fresh_gamma_columns(trlda_model *m, int B, int doc_lo, int Bl, std::vector<double> &full)
+{
+    const int K = m->K;
+    if (!m->host_gamma_draw)                                 // this rank's columns, on the device
+        return sample_gamma_on_device(m, (long long)K * B, 100, 100., m->gamma,
+                                      (long long)K * doc_lo, (long long)K * (doc_lo + Bl));
+    full.resize((size_t)K * B);
+    trlda_sample_gamma_init(K, B, full.data());
+    if (Bl > 0) {
+        HIP_TRY(hipMemcpyAsync(m->gamma, full.data() + (size_t)K * doc_lo,
+                               (size_t)K * Bl * sizeof(double), hipMemcpyHostToDevice, m->stream));
+        HIP_TRY(hipStreamSynchronize(m->stream));            // `full` is reused by the next draw
+    }
+    return TRLDA_OK;
+}
+
+int check_shard_range(const trlda_model *m, const trlda_batch *shard, int total_docs, int doc_lo)
+{
+    if (!shard)
+        return fail(TRLDA_ERR_ARG, "NULL shard");
+    if (shard->V != m->V)
+        return fail(TRLDA_ERR_SHAPE, "batch was created for a different vocabulary size");
+    if (total_docs < 0 || doc_lo < 0 || doc_lo + shard->B > total_docs)
+        return fail(TRLDA_ERR_ARG, "shard [doc_lo, doc_lo + its size) must lie inside [0, total_docs)");
+    return TRLDA_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -3113,13 +3146,11 @@ int trlda_model_online_update_multi(trlda_model *m, const trlda_batch *shard, vo
     int rc = check_model(m);
     if (rc)
         return rc;
-    if (!shard || !update_count || !rho_out)
-        return fail(TRLDA_ERR_ARG, "NULL shard / update_count / rho_out");
-    if (shard->V != m->V)
-        return fail(TRLDA_ERR_SHAPE, "batch was created for a different vocabulary size");
+    if (!update_count || !rho_out)
+        return fail(TRLDA_ERR_ARG, "NULL update_count / rho_out");
+    if ((rc = check_shard_range(m, shard, total_docs, doc_lo)))
+        return rc;
     const int K = m->K, Bl = shard->B, B = total_docs;
-    if (B < 0 || doc_lo < 0 || doc_lo + Bl > B)
-        return fail(TRLDA_ERR_ARG, "shard [doc_lo, doc_lo + its size) must lie inside [0, total_docs)");
     if (B == 0) {                                            // onlinelda.cpp:54-56
         *rho_out = 1.0;
         return TRLDA_OK;
@@ -3132,22 +3163,8 @@ int trlda_model_online_update_multi(trlda_model *m, const trlda_batch *shard, vo
         return rc;
     const size_t KV = (size_t)K * m->V;
     const double scale = (double)num_documents / (double)B;
-    // gamma0 of the whole mini-batch from the (shared) host stream, this rank's columns kept:
-    // every rank consumes the stream exactly as the single-process run does (lda.cpp:135)
     std::vector<double> full;
-    auto fresh_gamma = [&]() -> int {
-        if (!m->host_gamma_draw)                             // this rank's columns, on the device
-            return sample_gamma_on_device(m, (long long)K * B, 100, 100., m->gamma,
-                                          (long long)K * doc_lo, (long long)K * (doc_lo + Bl));
-        full.resize((size_t)K * B);
-        trlda_sample_gamma_init(K, B, full.data());
-        if (Bl > 0) {
-            HIP_TRY(hipMemcpyAsync(m->gamma, full.data() + (size_t)K * doc_lo,
-                                   (size_t)K * Bl * sizeof(double), hipMemcpyHostToDevice, m->stream));
-            HIP_TRY(hipStreamSynchronize(m->stream));        // `full` is reused by the next draw
-        }
-        return TRLDA_OK;
-    };
+    auto fresh_gamma = [&]() -> int { return fresh_gamma_columns(m, B, doc_lo, Bl, full); };
     HIP_TRY(hipMemcpyAsync(m->lambda_prime, m->lambda, KV * sizeof(double), hipMemcpyDeviceToDevice,
                            m->stream));                      // lambdaPrime = mLambda  (:68)
     const int steps = max_iter_tr > 0 ? max_iter_tr : 1;
@@ -3168,6 +3185,73 @@ int trlda_model_online_update_multi(trlda_model *m, const trlda_batch *shard, vo
         return rc;
     ++*update_count;                                         // onlinelda.cpp:177
     return TRLDA_OK;
+}
+
+int trlda_model_allreduce(trlda_model *m, void *rccl_comm, double *buf_dev, size_t count)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!buf_dev && count)
+        return fail(TRLDA_ERR_ARG, "buffer is NULL");
+    return count ? allreduce_f64(m, rccl_comm, buf_dev, count) : TRLDA_OK;
+}
+
+// BatchLDA::updateParameters' lambda path (src/batchlda.cpp:43-61) over the ranks of rccl_comm:
+// per epoch, this rank's documents from a fresh gamma, ONE all-reduce of the K x V statistics
+// (src/lda.cpp:211-217 across ranks), lambda = eta + sstats on every rank.
+int trlda_model_batch_update_multi(trlda_model *m, const trlda_batch *shard, void *rccl_comm,
+                                   int total_docs, int doc_lo, double eta, int max_epochs,
+                                   int max_iter_inference, int update_lambda, double threshold)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if ((rc = check_shard_range(m, shard, total_docs, doc_lo)))
+        return rc;
+    if (total_docs == 0)                                     // batchlda.cpp:44-46
+        return TRLDA_OK;
+    rc = ensure_update_workspace(m, shard->B);
+    if (rc)
+        return rc;
+    const size_t KV = (size_t)m->K * m->V;
+    std::vector<double> full;
+    for (int epoch = 0; !rc && update_lambda && epoch < max_epochs; ++epoch) {   // batchlda.cpp:48-61
+        rc = fresh_gamma_columns(m, total_docs, doc_lo, shard->B, full);
+        if (!rc) rc = estep_device(m, shard, m->gamma, m->sstats, max_iter_inference, threshold, nullptr);
+        if (!rc) rc = allreduce_f64(m, rccl_comm, m->sstats, KV);
+        if (!rc) {
+            invalidate_rowsums(m);
+            m->rs_floor = m->V * eta;
+            rc = launch_elementwise(m, KV, trlda::SetOp{eta, m->sstats, m->lambda});   // :60
+        }
+    }
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return TRLDA_OK;
+}
+
+// LDA::updateVariables(documents, parameters) from a fresh random gamma (src/lda.cpp:119-138) for
+// this rank's documents of a sharded mini-batch, gamma left on the device: what
+// src/onlinelda.cpp:118-120 / src/batchlda.cpp:66-68 do before an alpha step when update_lambda
+// is off.  No exchange: the statistics are not used.
+int trlda_model_estep_resident_shard(trlda_model *m, const trlda_batch *shard, int total_docs,
+                                     int doc_lo, int max_iter, double threshold)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if ((rc = check_shard_range(m, shard, total_docs, doc_lo)))
+        return rc;
+    if (total_docs == 0)
+        return TRLDA_OK;
+    rc = ensure_update_workspace(m, shard->B);
+    std::vector<double> full;
+    if (!rc) rc = fresh_gamma_columns(m, total_docs, doc_lo, shard->B, full);
+    if (!rc && shard->B > 0)
+        rc = estep_device(m, shard, m->gamma, m->sstats, max_iter, threshold, nullptr);
+    return rc;
 }
 
 // ---- data parallelism with factor exchange (dp_kernels.h) ---------------------------------
@@ -3230,6 +3314,24 @@ int trlda_model_online_update_dp(trlda_model *m, const trlda_batch *batch, const
     return rc;
 }
 
+int trlda_model_batch_update_dp(trlda_model *m, const trlda_batch *batch, const trlda_batch *shard,
+                                void *rccl_comm, int rank, int world, const int32_t *doc_cuts,
+                                double eta, int max_epochs, int max_iter_inference, int update_lambda,
+                                double threshold)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    DpContext dp;
+    if ((rc = dp_enter(m, dp, batch, shard, rccl_comm, rank, world, doc_cuts)))
+        return rc;
+    // the single-GPU call on the whole mini-batch, its document stage on the shard
+    rc = trlda_model_batch_update(m, batch, eta, max_epochs, max_iter_inference, update_lambda,
+                                  threshold, nullptr);
+    m->dp = nullptr;
+    return rc;
+}
+
 int trlda_model_estep_dp(trlda_model *m, const trlda_batch *batch, const trlda_batch *shard,
                          void *rccl_comm, int rank, int world, const int32_t *doc_cuts,
                          const double *gamma0_dev, double *gamma_dev, double *sstats_dev, int max_iter,
@@ -3257,7 +3359,7 @@ int trlda_model_estep_dp(trlda_model *m, const trlda_batch *batch, const trlda_b
         out.upd.lambda_prime = lambda_prime_dev ? lambda_prime_dev : m->lambda;
         out.upd.partial = m->upd_partial;
         out.active_only = false;
-        out.emit_next = can_emit_next(m, shard);
+        out.emit_next = can_emit_next(m, batch);
         rc = ensure_update_workspace(m, 1);
         if (!rc) rc = ensure_rowsums(m);
     }
@@ -3351,11 +3453,34 @@ int trlda_model_estep_resident(trlda_model *m, const trlda_batch *b, int max_ite
 
 int trlda_model_eb_gamma_stats(trlda_model *m, int B, const double *gamma_dev, double *out_host)
 {
+    if (B <= 0)
+        return fail(TRLDA_ERR_ARG, "bad eb_gamma_stats arguments");
+    return trlda_model_eb_gamma_stats_multi(m, nullptr, B, gamma_dev, out_host);
+}
+
+// the same sums over the documents of every rank: this rank's K numbers (zeros for a rank
+// without documents), one all-reduce of K doubles (src/onlinelda.cpp:128 across ranks)
+int trlda_model_eb_gamma_stats_multi(trlda_model *m, void *rccl_comm, int B, const double *gamma_dev,
+                                     double *out_host)
+{
     int rc = check_model(m);
     if (rc)
         return rc;
-    if (B <= 0 || !out_host)
+    if (B < 0 || !out_host)
         return fail(TRLDA_ERR_ARG, "bad eb_gamma_stats arguments");
+    if (B == 0) {
+        rc = grow(&m->reduce_out, &m->cap_reduce, (size_t)m->K);
+        if (rc)
+            return rc;
+        HIP_TRY(hipMemsetAsync(m->reduce_out, 0, (size_t)m->K * sizeof(double), m->stream));
+        if (rccl_comm && (rc = allreduce_f64(m, rccl_comm, m->reduce_out, (size_t)m->K)))
+            return rc;
+        HIP_TRY(hipMemcpyAsync(out_host, m->reduce_out, (size_t)m->K * sizeof(double),
+                               hipMemcpyDeviceToHost, m->stream));
+        m->d2h_bytes += (int64_t)m->K * sizeof(double);
+        HIP_TRY(hipStreamSynchronize(m->stream));
+        return TRLDA_OK;
+    }
     const double *gamma = gamma_dev ? gamma_dev : m->gamma;
     if (!gamma || (!gamma_dev && (size_t)B * m->K > m->cap_gamma))
         return fail(TRLDA_ERR_ARG, "no gamma of that size is resident in the model");
@@ -3373,6 +3498,8 @@ int trlda_model_eb_gamma_stats(trlda_model *m, int B, const double *gamma_dev, d
     HIP_TRY(hipGetLastError());
     double *sum = m->reduce_out + (size_t)chunks * K;
     rc = combine_rowsums(m, m->reduce_out, chunks, nullptr, sum);
+    if (!rc && rccl_comm)
+        rc = allreduce_f64(m, rccl_comm, sum, (size_t)K);
     if (rc)
         return rc;
     HIP_TRY(hipMemcpyAsync(out_host, sum, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, m->stream));
@@ -3447,6 +3574,19 @@ int trlda_model_adaptive_stats(trlda_model *m, double eta, double scale, double 
         return fail(TRLDA_ERR_ARG, "bad adaptive_stats arguments");
     if (!m->keep_sstats || !m->sstats || !m->lambda_prime)
         return fail(TRLDA_ERR_ARG, "adaptive_stats needs an update made with keep_sstats on");
+    return trlda_model_adaptive_stats_dev(m, m->sstats, m->lambda_prime, eta, scale, tau, sq_norm_update,
+                                          sq_norm_gradient);
+}
+
+int trlda_model_adaptive_stats_dev(trlda_model *m, const double *sstats_dev,
+                                   const double *lambda_prime_dev, double eta, double scale, double tau,
+                                   double *sq_norm_update, double *sq_norm_gradient)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!sq_norm_update || !sq_norm_gradient || !sstats_dev || !lambda_prime_dev)
+        return fail(TRLDA_ERR_ARG, "bad adaptive_stats arguments");
     const size_t KV = (size_t)m->K * m->V;
     if (!m->ada_gradient) {
         rc = dev_alloc(&m->ada_gradient, KV);                // mAdaGradient starts at zero
@@ -3460,7 +3600,7 @@ int trlda_model_adaptive_stats(trlda_model *m, double eta, double scale, double 
     if (rc)
         return rc;
     hipLaunchKernelGGL(trlda::adaptive_kernel<T>, dim3(G), dim3(T), 0, m->stream, KV, eta, scale, tau,
-                       m->sstats, m->lambda_prime, m->ada_gradient, m->reduce_out);
+                       sstats_dev, lambda_prime_dev, m->ada_gradient, m->reduce_out);
     HIP_TRY(hipGetLastError());
     std::vector<double> blocks(2 * (size_t)G);
     HIP_TRY(hipMemcpyAsync(blocks.data(), m->reduce_out, blocks.size() * sizeof(double),

@@ -355,7 +355,6 @@ class OnlineLDA(LDA):
         sums over gamma, lambda and the statistics that the empirical-Bayes steps for alpha and
         eta and the adaptive learning rate need (onlinelda.cpp:116-175, csrc/eb_kernels.h); the
         host keeps the K- and scalar-sized Newton steps."""
-        from .. import _special
         batch, owned = self._batch(docs)
         try:
             B = len(batch)
@@ -383,23 +382,14 @@ class OnlineLDA(LDA):
             if update_alpha:                                         # onlinelda.cpp:116-142
                 if not update_lambda:
                     self._resident_estep(batch, max_iter_inference)
-                alpha = self._alpha
-                g = self._psi_gamma_diff_device(B) \
-                    - B * (_special.digamma(alpha) - _special.digamma(alpha.sum()))
-                h = -float(B) * _special.trigamma(alpha)
-                z = B * _special.trigamma(alpha.sum())
-                c = (g / h).sum() / (1. / z + (1. / h).sum())
-                alpha = np.maximum(alpha - rho_used * (g - c) / h, min_alpha)
+                alpha = _online_alpha_step(self._alpha, self._psi_gamma_diff_device(B), B,
+                                           rho_used, min_alpha)
                 _ffi.check(L.trlda_model_set_alpha(self._handle, np.ascontiguousarray(alpha)))
                 self._alpha = alpha
 
             if update_eta:                                           # onlinelda.cpp:147-162
-                eta = self._eta
                 sum_psi, rowsums = self._lambda_psi_stats_device()
-                g = sum_psi - V * _special.digamma(rowsums).sum() \
-                    - K * V * (_special.digamma(eta) - _special.digamma(V * eta))
-                h = K * V * (_special.trigamma(V * eta) - _special.trigamma(eta))
-                self._eta = max(float(eta - rho_used * g / h), min_eta)
+                self._eta = _online_eta_step(self._eta, sum_psi, rowsums, K, V, rho_used, min_eta)
 
             if update_lambda and adaptive:                           # onlinelda.cpp:167-175
                 t = self._ada_tau
@@ -426,6 +416,57 @@ class OnlineLDA(LDA):
         lam, count = state
         self.lambdas = lam
         self.update_count = count
+
+
+def _online_alpha_step(alpha, psi_gamma_diff, num_docs, rho, min_alpha):
+    """One natural-gradient step on alpha, onlinelda.cpp:123-142; psi_gamma_diff[k] = sum over the
+    mini-batch's documents of psi(gamma_dk) - psi(sum_k gamma_dk)."""
+    from .. import _special
+    B = num_docs
+    g = psi_gamma_diff - B * (_special.digamma(alpha) - _special.digamma(alpha.sum()))
+    h = -float(B) * _special.trigamma(alpha)
+    z = B * _special.trigamma(alpha.sum())
+    c = (g / h).sum() / (1. / z + (1. / h).sum())
+    return np.maximum(alpha - rho * (g - c) / h, min_alpha)
+
+
+def _online_eta_step(eta, sum_psi_lambda, rowsums, K, V, rho, min_eta):
+    """One Newton step on eta, onlinelda.cpp:147-162."""
+    from .. import _special
+    g = sum_psi_lambda - V * _special.digamma(rowsums).sum() \
+        - K * V * (_special.digamma(eta) - _special.digamma(V * eta))
+    h = K * V * (_special.trigamma(V * eta) - _special.trigamma(eta))
+    return max(float(eta - rho * g / h), min_eta)
+
+
+def _eta_line_search(eta, sum_psi_lambda, rowsums, K, V, max_iter_eta, min_eta, threshold):
+    """Newton steps on eta with a step-halving line search on the lower bound,
+    batchlda.cpp:147-205."""
+    from .. import _special
+    c = sum_psi_lambda - V * _special.digamma(rowsums).sum()
+
+    def bound(e):
+        return (e - 1) * c + K * float(_lngamma(V * e)) - K * V * float(_lngamma(e))
+    Lb = bound(eta)
+    Lprime = Lb
+    for _i in range(int(max_iter_eta)):
+        g = c - K * V * (_special.digamma(eta) - _special.digamma(V * eta))
+        h = K * V * (_special.trigamma(V * eta) - _special.trigamma(eta))
+        rho = .5
+        for _j in range(20):
+            cand = float(eta - rho * g / h)
+            if cand < min_eta:
+                rho /= 2.
+                continue
+            Lprime = bound(cand)
+            if Lb <= Lprime:
+                eta = cand
+                break
+            rho /= 2.
+        if Lprime - Lb < threshold:
+            break
+        Lb = Lprime
+    return float(eta)
 
 
 def _lngamma(x):
@@ -485,7 +526,6 @@ class BatchLDA(LDA):
         lambda = eta + sstats run on the GPU, as do the sums over gamma and lambda behind the
         alpha / eta line searches (batchlda.cpp:66-205); the searches themselves are K- and
         scalar-sized and run on the host."""
-        from .. import _special
         batch, owned = self._batch(docs)
         try:
             B = len(batch)
@@ -512,31 +552,8 @@ class BatchLDA(LDA):
                     self._alpha = alpha
                 if update_eta:                                       # batchlda.cpp:147-205
                     sum_psi, rowsums = self._lambda_psi_stats_device()
-                    c = sum_psi - V * _special.digamma(rowsums).sum()
-                    eta = self._eta
-
-                    def bound(e):
-                        return (e - 1) * c + K * float(_lngamma(V * e)) - K * V * float(_lngamma(e))
-                    Lb = bound(eta)
-                    Lprime = Lb
-                    for _i in range(int(max_iter_eta)):
-                        g = c - K * V * (_special.digamma(eta) - _special.digamma(V * eta))
-                        h = K * V * (_special.trigamma(V * eta) - _special.trigamma(eta))
-                        rho = .5
-                        for _j in range(20):
-                            cand = float(eta - rho * g / h)
-                            if cand < min_eta:
-                                rho /= 2.
-                                continue
-                            Lprime = bound(cand)
-                            if Lb <= Lprime:
-                                eta = cand
-                                break
-                            rho /= 2.
-                        if Lprime - Lb < emp_bayes_threshold:
-                            break
-                        Lb = Lprime
-                    self._eta = float(eta)
+                    self._eta = _eta_line_search(self._eta, sum_psi, rowsums, K, V, max_iter_eta,
+                                                 min_eta, emp_bayes_threshold)
         finally:
             if owned:
                 batch.close()

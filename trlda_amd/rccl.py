@@ -14,14 +14,21 @@ class _UniqueId(C.Structure):
     _fields_ = [("internal", C.c_char * 128)]
 
 
+_LIB = None
+
+
 def _librccl():
-    import torch
-    path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-    lib = C.CDLL(path if os.path.exists(path) else "librccl.so", mode=C.RTLD_GLOBAL)
-    lib.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
-    lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
-    lib.ncclCommDestroy.argtypes = [C.c_void_p]
-    return lib
+    global _LIB
+    if _LIB is None:                                  # one handle per process
+        import torch
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        lib = C.CDLL(path if os.path.exists(path) else "librccl.so", mode=C.RTLD_GLOBAL)
+        lib.ncclGetUniqueId.argtypes = [C.POINTER(_UniqueId)]
+        lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _UniqueId, C.c_int]
+        lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        lib.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        _LIB = lib
+    return _LIB
 
 
 def own_communicator(dist, device, group=None):
@@ -46,6 +53,14 @@ def own_communicator(dist, device, group=None):
     if lib.ncclCommInitRank(C.byref(comm), world, uid, rank) != 0:
         raise RuntimeError("ncclCommInitRank failed")
     return comm
+
+
+def comm_count(comm):
+    """Number of ranks RCCL itself reports for the communicator (ncclCommCount); -1 on failure."""
+    n = C.c_int(-1)
+    if not comm or _librccl().ncclCommCount(comm, C.byref(n)) != 0:
+        return -1
+    return n.value
 
 
 def destroy(comm):

@@ -20,12 +20,29 @@ def word_popularity(V, zipf=True, exponent=1.07):
     return p / p.sum()
 
 
+def lognormal_lengths(num_docs, seed, median=100, sigma=0.32, longest=600, p_long=0.004):
+    """Heavy-tailed document lengths: log-normal around `median` (sigma 0.32: about 2 % of the
+    documents have more than 192 unique words) and, with probability p_long, a document of
+    `longest` / 2 .. `longest` words -- real corpora hold such documents, and the reference's own
+    test_speed uses up to 600 (onlinelda_test.py:204-246)."""
+    rng = np.random.Generator(np.random.PCG64(seed + 7919))
+    n = np.rint(np.exp(np.log(median) + sigma * rng.standard_normal(num_docs)))
+    long_one = rng.random(num_docs) < p_long
+    n = np.where(long_one, rng.integers(longest // 2, longest + 1, size=num_docs), n)
+    return np.clip(n, 1, longest).astype(np.int64)
+
+
 def make_corpus(num_docs, V, seed=SEED_BASE, mean_unique=100, zipf=True, count_rate=0.6,
-                chunk=2048):
-    """-> (indptr[num_docs+1], ids[nnz], cnts[nnz]) int32 CSR."""
+                chunk=2048, lengths=None):
+    """-> (indptr[num_docs+1], ids[nnz], cnts[nnz]) int32 CSR.  `lengths`: the documents'
+    numbers of unique words (default: 1 + Poisson(mean_unique - 1))."""
     rng = np.random.Generator(np.random.PCG64(seed))
     logp = np.log(word_popularity(V, zipf))
     n = np.clip(1 + rng.poisson(mean_unique - 1, size=num_docs), 1, V).astype(np.int64)
+    if lengths is not None:
+        n = np.clip(np.asarray(lengths, dtype=np.int64), 0, V)
+        if n.shape != (num_docs,):
+            raise ValueError("lengths must have one entry per document")
     indptr = np.zeros(num_docs + 1, dtype=np.int64)
     np.cumsum(n, out=indptr[1:])
     ids = np.empty(indptr[-1], dtype=np.int32)
@@ -34,7 +51,7 @@ def make_corpus(num_docs, V, seed=SEED_BASE, mean_unique=100, zipf=True, count_r
     for lo in range(0, num_docs, chunk):
         hi = min(lo + chunk, num_docs)
         keys = logp[None, :] + rng.gumbel(size=(hi - lo, V))
-        kmax = int(n[lo:hi].max())
+        kmax = max(int(n[lo:hi].max()), 1)
         top = np.argpartition(-keys, min(kmax, V - 1), axis=1)[:, :kmax] if kmax < V else \
             np.argsort(-keys, axis=1)
         # order the kmax candidates by key so the first n_d are the true top-n_d
