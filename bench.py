@@ -88,6 +88,10 @@ def parse():
                          "by extra workgroups of the previous step's document-kernel launch")
     ap.add_argument("--no-update-rates", action="store_true",
                     help="skip the secondary update_parameters figures (N = 1 only)")
+    ap.add_argument("--batch-lda", action="store_true",
+                    help="N > 1: close every step with BatchLDA's M-step, lambda = eta + sstats "
+                         "(batchlda.cpp:60; BASELINE.json configs[3] with --topics 200 --words 50000 "
+                         "--batch 12500 --max-iter 100), instead of OnlineLDA's blend with rho = 0.01")
     ap.add_argument("--repeats", type=int, default=7,
                     help="the timed region (--steps steps) is run this many times back to back; "
                          "the median is reported, min / max beside it")
@@ -369,6 +373,10 @@ def main():
     lam_prime = torch.from_numpy(np.ascontiguousarray(lam.ravel(order="F"))).to(device) \
         if collective else None
     RHO, ETA, D_TOTAL = 0.01, 0.3, 1000000
+    if args.batch_lda:
+        # BatchLDA's M-step (batchlda.cpp:60): lambda = eta + sstats -- rho = 1, no D / B scaling;
+        # the steps are then consecutive epochs-on-a-mini-batch of a real BatchLDA run
+        RHO, D_TOTAL = 1.0, None
 
     prefetch = not collective and not args.no_prefetch
     exchange_probe = None
@@ -436,7 +444,7 @@ def main():
                 model, batches[j].handle, batches[j].handle, None, 0, 1,
                 cuts_solo.ctypes.data_as(C.POINTER(C.c_int32)), gamma0s[j].data_ptr(), gamma.data_ptr(),
                 None, args.max_iter, args.threshold, None, 1, lam_prime.data_ptr(), RHO, ETA,
-                D_TOTAL / float(B)))
+                D_TOTAL / float(B) if D_TOTAL else 1.))
             return
         # gamma0 is read-only input, gamma the output (lda.cpp:168 copies, we do not).  The batch
         # of the next step is announced: its preamble (row sums + exp(psi(lambda)) on ITS words,
@@ -451,7 +459,7 @@ def main():
                 model, gbatches[j].handle, batches[j].handle, rccl_comm, 0 if vworld else rank, xworld,
                 cuts.ctypes.data_as(C.POINTER(C.c_int32)), gamma0s[j].data_ptr(), gamma.data_ptr(),
                 None, args.max_iter, args.threshold, iters_dev.data_ptr() if want_iters else None, 1,
-                lam_prime.data_ptr(), RHO, ETA, D_TOTAL / float(B * xworld)))
+                lam_prime.data_ptr(), RHO, ETA, D_TOTAL / float(B * xworld) if D_TOTAL else 1.))
             return
         nxt = batches[(i + 1) % args.num_batches].handle if use_prefetch[0] else None
         _ffi.check(L.trlda_model_estep_io_next(model, batches[j].handle, nxt, gamma0s[j].data_ptr(),
@@ -467,7 +475,7 @@ def main():
             else:
                 dist.all_reduce(sstats)
             _ffi.check(L.trlda_model_blend(model, lam_prime.data_ptr(), sstats.data_ptr(), RHO, ETA,
-                                           D_TOTAL / float(B * (1 if solo else world))))
+                                           D_TOTAL / float(B * (1 if solo else world)) if D_TOTAL else 1.))
 
     def fence():
         if collective and not vworld:
@@ -783,7 +791,8 @@ def main():
                                 "%d-document mini-batch and the M-step (onlinelda.cpp:99-100) in one kernel"
                                 % (8e-6 * xworld * slot, B * xworld) if exchange == "factors" else
                                 "RCCL all-reduce of K x V fp64 sstats, then the M-step "
-                                "(onlinelda.cpp:99-100) that the next step's E-step reads")
+                                "(%s) that the next step's E-step reads"
+                                % ("batchlda.cpp:60" if args.batch_lda else "onlinelda.cpp:99-100"))
                    if collective else "none",
                    "exchange_check": exchange_probe,
                    "virtual_world": vworld or None},

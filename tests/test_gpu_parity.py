@@ -482,13 +482,16 @@ def test_full_size_document_permutation(hip, bench_case):
 @pytest.mark.parametrize("K", [100, 128, 7])
 def test_document_length_boundaries(hip, oracle, sampler, K):
     """Documents right at the limits of the document kernels' tiers: 128 words (all in
-    registers), 129..192 (register part + LDS tail), 193 and up (single-orientation kernel), all
-    in one batch; once more with everything forced through the general kernel."""
+    registers), 129..144 (18 words per wave), 145..192 (register part + LDS tail), 193 and up
+    (single orientation: registers, then LDS rows -- 400 words -- then rows streamed from L2 --
+    700 and 1300 words), all in ONE batch and one launch, with the fused preamble's topic factors
+    applied by every variant; once more with everything forced through the general kernel."""
     from trlda_amd.documents import CSRDocuments
     V = 3000
     rng = np.random.RandomState(K)
     lam = seeded_lambda(sampler, 31, K, V)
-    lens = [1, 2, 63, 64, 65, 127, 128, 129, 130, 137, 143, 144, 145, 150, 191, 192, 193, 250]
+    lens = [1, 2, 63, 64, 65, 127, 128, 129, 130, 137, 143, 144, 145, 150, 191, 192, 193, 250, 400,
+            700, 1300]
     docs, ip = [], [0]
     for n in lens:
         ids = rng.permutation(V)[:n]
@@ -505,6 +508,9 @@ def test_document_length_boundaries(hip, oracle, sampler, K):
         for (it, thr) in [(0, 0.), (1, 0.), (25, 1e-3)]:
             g, s, iters = m.update_variables(CSRDocuments(ip, ids, cnts), latents=g0, max_iter=it,
                                              threshold=thr, return_iterations=True)
+            if kind == 0:
+                assert hip.trlda_model_last_doc_kernel(m._handle) == b"estep_docs_tiered_kernel"
+                assert hip.trlda_model_last_preamble_fused(m._handle) == 1
             go, so, ito = oracle.estep(lam, .1, ip, ids, cnts, g0, it, thr)
             per_doc = np.max(np.abs(g - go) / np.abs(go), axis=0)
             assert per_doc.max() < TIGHT_RTOL, list(zip(lens, per_doc))
@@ -540,7 +546,8 @@ def test_register_kernel_144_word_variant(hip, oracle, sampler, K, longest):
             hip.trlda_model_set_split_preamble(m._handle, split)
             g, s, iters = m.update_variables(CSRDocuments(ip, ids, cnts), latents=g0, max_iter=25,
                                              threshold=1e-3, return_iterations=True)
-            assert hip.trlda_model_last_doc_kernel(m._handle) == b"estep_docs_reg_kernel"
+            # (one launch whose workgroups take the variant their own document needs)
+            assert hip.trlda_model_last_doc_kernel(m._handle) == b"estep_docs_tiered_kernel"
             per_doc = np.max(np.abs(g - go) / np.abs(go), axis=0)
             assert per_doc.max() < TIGHT_RTOL, list(zip(lens, per_doc))
             check_sstats(s, so, rtol=TIGHT_RTOL if mode == 0 else 1e-8)
@@ -639,7 +646,8 @@ def test_fused_preamble_agrees_with_the_two_kernel_one(hip, oracle, sampler, mod
     """Small tables run row sums + exp(psi(lambda)) as one launch and fold exp(-psiSum) into
     exp(psi(gamma)) in the document kernel (estep_kernels.h 2b): same gamma / sstats /
     iteration counts as the two-kernel preamble (a few ulp apart) and as the oracle; a batch
-    with a long document falls back to the two kernels by itself."""
+    with a long document keeps the fused preamble (every variant of the document launch applies
+    the topic factors)."""
     from trlda_amd.documents import CSRDocuments
     from trlda_amd.utils.synthetic import make_corpus
     K, V, B = 100, 1500, 60
@@ -670,12 +678,21 @@ def test_fused_preamble_agrees_with_the_two_kernel_one(hip, oracle, sampler, mod
     trlda_amd.seed(9)
     lb_split = m.lower_bound(docs)
     assert abs(lb_fused - lb_split) < 1e-11 * abs(lb_split)
-    # one document of 300 words: not the register kernel's batch any more
-    hip.trlda_model_set_split_preamble(m._handle, 0)
+    # one document of 300 words: beyond the register variants, still one launch with the fused
+    # preamble -- and the two-kernel form agrees
     ip2 = np.array([0, 300], np.int32)
     ids2 = np.arange(300, dtype=np.int32)
-    m.update_variables(CSRDocuments(ip2, ids2, np.ones(300, np.int32)), max_iter=3)
-    assert hip.trlda_model_last_preamble_fused(m._handle) == 0
+    long_doc = CSRDocuments(ip2, ids2, np.ones(300, np.int32))
+    g0l = seeded_gamma(sampler, 53, K, 1)
+    res = {}
+    for split in (0, 1):
+        hip.trlda_model_set_split_preamble(m._handle, split)
+        res[split] = m.update_variables(long_doc, latents=g0l, max_iter=30, return_iterations=True)
+        assert hip.trlda_model_last_preamble_fused(m._handle) == 1 - split
+    assert relerr(res[0][0], res[1][0]) < 1e-10 and np.array_equal(res[0][2], res[1][2])
+    gl, sl, itl = oracle.estep(lam, .1, ip2, ids2, np.ones(300, np.int32), g0l, 30, 1e-3)
+    assert relerr(res[0][0], gl) < TIGHT_RTOL and np.array_equal(res[0][2], itl)
+    check_sstats(res[0][1], sl, rtol=TIGHT_RTOL if mode == 0 else 1e-8)
 
 
 @pytest.mark.parametrize("K,V,B", [(200, 50000, 48), (500, 100000, 40)])

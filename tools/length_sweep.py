@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--lengths", default="32,64,100,128,129,144,145,160,192,193,224,256,320,400,600")
     ap.add_argument("--series", default="all,one")
+    ap.add_argument("--wide", action="store_true", help="force the single-orientation kernel")
     args = ap.parse_args()
     import torch
     from trlda_amd import _ffi
@@ -46,6 +47,8 @@ def main():
     _ffi.check(L.trlda_model_set_stream(model, _ffi.vp(torch.cuda.current_stream(dev).cuda_stream)))
     _ffi.check(L.trlda_model_set_lambda(model, lam))
     _ffi.check(L.trlda_model_set_alpha(model, np.full(K, .1)))
+    if args.wide:
+        _ffi.check(L.trlda_model_set_doc_kernel(model, 2))
     g0 = np.empty((K, B), order="F")
     L.trlda_sample_gamma_init(K, B, g0)
     gamma0 = torch.from_numpy(np.ascontiguousarray(g0.T)).to(dev)

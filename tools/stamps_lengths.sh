@@ -1,2 +1,6 @@
-cd trlda_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -DTRLDA_STAMPS -DTRLDA_STAMP_THREAD=0 -o ../libtrlda_hip_stamps.so trlda_hip.hip && cd ../..
-for n in 128 144 160 192 193 256 400; do echo "== n=$n"; STAMPS_LEN=$n python tools/stamps.py; done
+#!/bin/bash
+# per-stage cycle shares of the document kernels for batches of equal-length documents (GPU box)
+# usage: tools/stamps_lengths.sh "128 144 160 192 193 256 400"
+cd "$(dirname "$0")/.." || exit 1
+(cd trlda_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -DTRLDA_STAMPS -DTRLDA_STAMP_THREAD=${STAMP_THREAD:-0} -o ../libtrlda_hip_stamps.so trlda_hip.hip) || exit 1
+for n in ${1:-128 144 160 192 193 256 400}; do echo "== n=$n"; STAMPS_LEN=$n python tools/stamps.py; done

@@ -19,6 +19,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "psi.h"
 
 namespace trlda {
@@ -973,17 +975,21 @@ struct PreArgs {
     unsigned int *c_counter;
 };
 
-template <int MODE>
-__global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelArgs a, PreArgs pre)
+// the preamble workgroups of a document-kernel launch (blockIdx.x >= pre.n_docs)
+__device__ __forceinline__ void docs_launch_preamble(const PreArgs &pre, double *lds)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    if ((int)blockIdx.x >= pre.n_docs) {             // block-uniform
-        preamble_fused_body<kRegThreads>((int)blockIdx.x - pre.n_docs, pre.nb, lds, pre.K, pre.V, pre.G,
-                                         pre.wpb, pre.total, pre.lambda, pre.partial, pre.u, pre.active,
-                                         0, nullptr, 0, nullptr, nullptr, pre.c_out, pre.c_counter,
-                                         lds + kRegThreads);
-        return;
-    }
+    preamble_fused_body<kRegThreads>((int)blockIdx.x - pre.n_docs, pre.nb, lds, pre.K, pre.V, pre.G,
+                                     pre.wpb, pre.total, pre.lambda, pre.partial, pre.u, pre.active,
+                                     0, nullptr, 0, nullptr, nullptr, pre.c_out, pre.c_counter,
+                                     lds + kRegThreads);
+}
+
+// One document = one workgroup: the body of estep_docs_reg_kernel<MODE>, also instantiated by
+// the tiered kernel of estep_wide.h, where every workgroup takes the variant its own document
+// needs.  The document is the one of a.pad_meta[blockIdx.x].
+template <int MODE>
+__device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, double *lds)
+{
     constexpr bool TAIL = MODE == 2, MID = MODE == 1;
     constexpr int JC = MID ? 18 : 16;                // words per wave: wave w owns [JC w, JC w + JC)
     constexpr int NREG = 8 * JC;                     // words held in registers
@@ -1181,40 +1187,97 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
             s2 = fold<32>(s2, s2);                   // + the other lane groups
             s2 = fold<16>(s2, s2);
         }
-        double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
+        if constexpr (TAIL) {
+            double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
+            // (MODE 2 requests the first half of the tail word's row ahead of these products: below)
+            double tvA[8];
+            if constexpr (TAIL) {
+                if (nt > 0) {                            // block-uniform
+                    const double *trow = tbuf + min(lane, 8 * TC - 1) * kRegStride + min(k0, K - 1);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            s0[(2 * i) & 3] = fma(ew[i].x, bE0[2 * i], s0[(2 * i) & 3]);
-            s1[(2 * i) & 3] = fma(ew[i].x, bE1[2 * i], s1[(2 * i) & 3]);
-            s0[(2 * i + 1) & 3] = fma(ew[i].y, bE0[2 * i + 1], s0[(2 * i + 1) & 3]);
-            s1[(2 * i + 1) & 3] = fma(ew[i].y, bE1[2 * i + 1], s1[(2 * i + 1) & 3]);
-        }
-        part[wid * kRegPart + lane] = (s0[0] + s0[1]) + (s0[2] + s0[3]);
-        part[wid * kRegPart + 64 + lane] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
-        if constexpr (MID) {
-            if (lane < 16)
-                part[wid * kRegPart + 128 + lane] = s2;
-        }
-        if (nt > 0) {                                // tail word 128 + lane from LDS
-            const double *rowp = tbuf + min(lane, 8 * TC - 1) * kRegStride + min(k0, K - 1);
-            double s2[4] = {0.0, 0.0, 0.0, 0.0};     // four chains
-#pragma unroll
-            for (int hb = 0; hb < 2; ++hb) {         // two halves of eight: fewer live registers
-                double tv[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int c = 8 * hb + i;
-                    const bool colv = c < KC && k0 + c < K;   // wave-uniform, as for bE0 / bE1
-                    const double v = rowp[colv ? c : 0];
-                    tv[i] = colv ? v : 0.0;
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    s2[(2 * i) & 3] = fma(ew[4 * hb + i].x, tv[2 * i], s2[(2 * i) & 3]);
-                    s2[(2 * i + 1) & 3] = fma(ew[4 * hb + i].y, tv[2 * i + 1], s2[(2 * i + 1) & 3]);
+                    for (int i = 0; i < 8; ++i) {
+                        const bool colv = i < KC && k0 + i < K;  // wave-uniform, as for bE0 / bE1
+                        const double v = trow[colv ? i : 0];
+                        tvA[i] = colv ? v : 0.0;
+                    }
                 }
             }
-            part[wid * kRegPart + 128 + lane] = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                s0[(2 * i) & 3] = fma(ew[i].x, bE0[2 * i], s0[(2 * i) & 3]);
+                s1[(2 * i) & 3] = fma(ew[i].x, bE1[2 * i], s1[(2 * i) & 3]);
+                s0[(2 * i + 1) & 3] = fma(ew[i].y, bE0[2 * i + 1], s0[(2 * i + 1) & 3]);
+                s1[(2 * i + 1) & 3] = fma(ew[i].y, bE1[2 * i + 1], s1[(2 * i + 1) & 3]);
+            }
+            part[wid * kRegPart + lane] = (s0[0] + s0[1]) + (s0[2] + s0[3]);
+            part[wid * kRegPart + 64 + lane] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
+            if constexpr (MID) {
+                if (lane < 16)
+                    part[wid * kRegPart + 128 + lane] = s2;
+            }
+            if constexpr (TAIL) {
+                if (nt > 0) {
+                    // tail word 128 + lane: the second half of its row, requested before the first
+                    // half's multiply-adds -- no LDS round trip is waited for with nothing else to do
+                    const double *trow = tbuf + min(lane, 8 * TC - 1) * kRegStride + min(k0, K - 1);
+                    double tvB[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int c = 8 + i;
+                        const bool colv = c < KC && k0 + c < K;
+                        const double v = trow[colv ? c : 0];
+                        tvB[i] = colv ? v : 0.0;
+                    }
+                    double t2[4] = {0.0, 0.0, 0.0, 0.0}; // four chains
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        t2[(2 * i) & 3] = fma(ew[i].x, tvA[2 * i], t2[(2 * i) & 3]);
+                        t2[(2 * i + 1) & 3] = fma(ew[i].y, tvA[2 * i + 1], t2[(2 * i + 1) & 3]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        t2[(2 * i) & 3] = fma(ew[4 + i].x, tvB[2 * i], t2[(2 * i) & 3]);
+                        t2[(2 * i + 1) & 3] = fma(ew[4 + i].y, tvB[2 * i + 1], t2[(2 * i + 1) & 3]);
+                    }
+                    part[wid * kRegPart + 128 + lane] = (t2[0] + t2[1]) + (t2[2] + t2[3]);
+                }
+            }
+        } else {
+            double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                s0[(2 * i) & 3] = fma(ew[i].x, bE0[2 * i], s0[(2 * i) & 3]);
+                s1[(2 * i) & 3] = fma(ew[i].x, bE1[2 * i], s1[(2 * i) & 3]);
+                s0[(2 * i + 1) & 3] = fma(ew[i].y, bE0[2 * i + 1], s0[(2 * i + 1) & 3]);
+                s1[(2 * i + 1) & 3] = fma(ew[i].y, bE1[2 * i + 1], s1[(2 * i + 1) & 3]);
+            }
+            part[wid * kRegPart + lane] = (s0[0] + s0[1]) + (s0[2] + s0[3]);
+            part[wid * kRegPart + 64 + lane] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
+            if constexpr (MID) {
+                if (lane < 16)
+                    part[wid * kRegPart + 128 + lane] = s2;
+            }
+            if (nt > 0) {                                // tail word 128 + lane from LDS
+                const double *rowp = tbuf + min(lane, 8 * TC - 1) * kRegStride + min(k0, K - 1);
+                double s2[4] = {0.0, 0.0, 0.0, 0.0};     // four chains
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {         // two halves of eight: fewer live registers
+                    double tv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int c = 8 * hb + i;
+                        const bool colv = c < KC && k0 + c < K;   // wave-uniform, as for bE0 / bE1
+                        const double v = rowp[colv ? c : 0];
+                        tv[i] = colv ? v : 0.0;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        s2[(2 * i) & 3] = fma(ew[4 * hb + i].x, tv[2 * i], s2[(2 * i) & 3]);
+                        s2[(2 * i + 1) & 3] = fma(ew[4 * hb + i].y, tv[2 * i + 1], s2[(2 * i + 1) & 3]);
+                    }
+                }
+                part[wid * kRegPart + 128 + lane] = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+            }
         }
         __syncthreads();
         if (tid < 128 || tid < n)                    // 0 beyond n (cnt is 0 there)
@@ -1248,25 +1311,40 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
                 a0[(2 * i + 1) & 3] = fma(tv[i].y, bB0[2 * i + 1], a0[(2 * i + 1) & 3]);
                 a1[(2 * i + 1) & 3] = fma(tv[i].y, bB1[2 * i + 1], a1[(2 * i + 1) & 3]);
             }
+            if constexpr (TAIL) {
             if (nt > 0) {                            // tail rows of this wave, from LDS
-                // rows wid * TC + r, r < TC <= 8, two at a time: a document a little over 128
-                // words (the usual long one) has TC = 1 or 2 and pays for one pair only
+                // rows wid * TC + r, r < TC <= 8.  All loads of a group of rows are issued before
+                // its first multiply-add (a wave-uniform branch around every pair made the
+                // compiler wait for each pair's LDS round trip in turn: 165 cycles per row);
+                // a document a little over 128 words (the usual long one) has TC <= 2 and takes
+                // the short group.  Rows past TC are clamped and weighted 0.
                 const double *rowp = tbuf + (wid * TC) * kRegStride + lane;
                 const double *twp = tw + 128 + wid * TC;
+                auto tail_rows = [&](auto NR, int r0) {      // rows r0 .. r0 + R - 1
+                    constexpr int R = decltype(NR)::value;
+                    double lo[R], hi[R], w[R];
 #pragma unroll
-                for (int pr = 0; pr < 4; ++pr) {
-                    if (2 * pr < TC) {               // wave-uniform
-                        const int r1 = (2 * pr + 1 < TC) ? 2 * pr + 1 : 2 * pr;
-                        const double lo0 = rowp[2 * pr * kRegStride], hi0 = rowp[2 * pr * kRegStride + 64];
-                        const double lo1 = rowp[r1 * kRegStride], hi1 = rowp[r1 * kRegStride + 64];
-                        const double w0 = twp[2 * pr];
-                        const double w1 = (2 * pr + 1 < TC) ? twp[r1] : 0.0;
-                        a0[0] = fma(w0, lo0, a0[0]);
-                        a1[0] = fma(w0, hi0, a1[0]);
-                        a0[1] = fma(w1, lo1, a0[1]);
-                        a1[1] = fma(w1, hi1, a1[1]);
+                    for (int r = 0; r < R; ++r) {
+                        const int rr = r0 + r < TC ? r0 + r : TC - 1;
+                        lo[r] = rowp[rr * kRegStride];
+                        hi[r] = rowp[rr * kRegStride + 64];
+                        w[r] = twp[rr];
                     }
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const double wr = r0 + r < TC ? w[r] : 0.0;
+                        a0[r & 3] = fma(wr, lo[r], a0[r & 3]);
+                        a1[r & 3] = fma(wr, hi[r], a1[r & 3]);
+                    }
+                };
+                if (TC <= 2) {
+                    tail_rows(std::integral_constant<int, 2>{}, 0);
+                } else {
+                    tail_rows(std::integral_constant<int, 4>{}, 0);
+                    if (TC > 4)
+                        tail_rows(std::integral_constant<int, 4>{}, 4);
                 }
+            }
             }
             part[wid * kRegPart + lane] = (a0[0] + a0[1]) + (a0[2] + a0[3]);
             part[wid * kRegPart + 64 + lane] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
@@ -1341,6 +1419,17 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
     }
     TRLDA_STAMP(6);
     TRLDA_STAMP_FLUSH;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelArgs a, PreArgs pre)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if ((int)blockIdx.x >= pre.n_docs) {             // block-uniform
+        docs_launch_preamble(pre, lds);
+        return;
+    }
+    estep_docs_reg_body<MODE>(a, lds);
 }
 
 // ---------------------------------------------------------------------------

@@ -51,7 +51,17 @@ struct wide_cfg {
     // 3.6 per word; groups of 8 cost 6.5 per word -- 87 against 57 instructions at JW = 12)
     static constexpr int NH = (JW + 15) / 16;
     static constexpr int NSET = KS >= 8 ? 1 : KS >= 4 ? 2 : KS >= 2 ? 4 : 8;   // >= 8 fma chains
-    static constexpr int TCH = KS <= 4 ? 4 : 2;      // words of a tail chunk (TCH * KS <= 16)
+    // words of a tail group (one read of their rows serves phinorm and the update of acc; ONE
+    // transposing fold per group): TG * KS doubles in flight per lane
+#ifdef TRLDA_WIDE_TG
+    static constexpr int TCH = TRLDA_WIDE_TG;
+#else
+    // (16 per group at K <= 128 with 16 register words per wave was measured: a group costs
+    // ~2000 cycles, LDS-bandwidth- and issue-bound like the register words, ~15 cycles per word
+    // and workgroup either way -- but a document one word over the registers pays for a whole
+    // group: 67 against 57 us at 145..192 words, 263 against 292 us at 600.  Small groups stay.)
+    static constexpr int TCH = KS <= 4 ? 4 : 2;
+#endif
     static constexpr int KP = 64 * KS;               // padded topic count
 };
 
@@ -163,6 +173,33 @@ __host__ __device__ constexpr int fold_chunk_lane(int idx)
     return N == 4 ? (((idx & 1) << 5) | ((idx & 2) << 3)) : ((idx & 1) << 5);
 }
 
+// One fold for a group of N = 16, 8, 4 or 2 values; lane l receives the total of value
+// fold_group_index<N>(l), found in every lane fold_group_lane<N>(i) + {0..3}.
+template <int N>
+__device__ __forceinline__ double fold_group(const double (&v)[N])
+{
+    if constexpr (N == 16)
+        return fold16<16>(v);
+    else if constexpr (N == 8)
+        return fold8<8>(v);
+    else
+        return fold_chunk<N>(v);
+}
+template <int N>
+__device__ __forceinline__ int fold_group_index(int lane)
+{
+    if constexpr (N == 16)
+        return fold16_index(lane);
+    else if constexpr (N == 8)
+        return fold8_index(lane);
+    else
+        return fold_chunk_index<N>(lane);
+}
+template <int N>
+__host__ __device__ constexpr int fold_group_lane(int idx)
+{
+    return N == 16 ? fold16_lane(idx) : N == 8 ? fold8_lane(idx) : fold_chunk_lane<N>(idx);
+}
 __device__ __forceinline__ double readlane_f64(double v, int lane)
 {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
@@ -191,21 +228,29 @@ __global__ void debug_fold16_kernel(const double *in, double *out, double *out4,
 // words; their rows sit in LDS (the first lds_rows of them) or are streamed from eeb (L2) in
 // every iteration -- one read of a row serves its phinorm and its update of acc.
 // ---------------------------------------------------------------------------
-template <int KS>
-__global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernelArgs a, int lds_rows)
+// Document d (n words, CSR offset p0) on this workgroup.  FACTORS: the fused preamble's topic
+// factors (K <= 128: a.partial / a.scale_in, estep_kernels.h 2b) are formed and folded into
+// exp(psi(gamma)) as the register kernel does -- bitwise the same factors, so that documents of
+// both kernels can share a launch and a statistics pass.
+template <int KS, bool FACTORS>
+__device__ __forceinline__ void estep_docs_wide_body(const DocKernelArgs &a, int lds_rows, double *lds,
+                                                     int d, int p0, int n)
 {
     using cfg = wide_cfg<KS>;
     constexpr int JW = cfg::JW, NH = cfg::NH, NSET = cfg::NSET, TCH = cfg::TCH, KP = cfg::KP;
     constexpr int W = kWideWaves;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wid = __builtin_amdgcn_readfirstlane(tid / kWave);
 
-    const int d = a.order[blockIdx.x];
     const int K = a.K;
-    const int p0 = a.indptr[d];
-    const int n = a.indptr[d + 1] - p0;
+    // fused preamble: the block partials of the row sums are fetched first (they depend on
+    // nothing) and consumed once the row loads below are in flight
+    [[maybe_unused]] double pv[2][8];
+    if constexpr (FACTORS) {
+        if (a.partial && !a.scale_in)                // launch-uniform
+            topic_scale_load<kWideThreads>(K, a.G, a.partial, pv);
+    }
     const int32_t *__restrict__ ids = a.ids + p0;
     const int32_t *__restrict__ cnts = a.cnts + p0;
 
@@ -239,9 +284,20 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
     const bool k_on = tid < K;
     double gk = 1.5, ak = 0.0;                       // (1.5: idle lanes must not take psi's integer branch)
     double gm = 0.0, am = 0.0;
+    [[maybe_unused]] double ck = 1.0;                // topic factor exp(-psiSum_k) (FACTORS) or 1
     if (k_on) {
         gk = a.gamma_in[(size_t)d * K + tid];
         ak = a.alpha[tid];
+        if constexpr (FACTORS) {
+            if (a.scale_in) {                        // finished by the launch that prepared them
+                ck = a.scale_in[2 * K + tid];
+                if (blockIdx.x == 0 && a.scale_out) {
+                    a.scale_out[tid] = a.scale_in[tid];
+                    a.scale_out[K + tid] = a.scale_in[K + tid];
+                    a.scale_out[2 * K + tid] = ck;
+                }
+            }
+        }
     }
     if (m_on) {
         gm = a.gamma_in[(size_t)d * K + km];
@@ -287,6 +343,10 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
         ek = k_on ? e0 : 0.0;
         ebuf[tid] = ek;                              // zero beyond K
     }
+    if constexpr (FACTORS) {
+        if (a.partial && !a.scale_in)                // `part` is idle until the first product
+            topic_scale_partials<kWideThreads>(K, a.G, pv, part);
+    }
     // rows of the first tail words, zero beyond K
     for (int t = wid; t < n_lds; t += W) {
         const double *rowp = a.eeb + (size_t)ids[n_reg + t] * K;
@@ -306,6 +366,19 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
             beta[i][s] = (row && kv[s]) ? beta[i][s] : 0.0;
     }
     __syncthreads();
+    if constexpr (FACTORS) {
+        if (a.partial) {                             // launch-uniform
+            // e is kept as c_k exp(psi(gamma_k)) throughout: phinorm and gamma come out the same
+            // with u = exp(psi(lambda)) in place of exp E[log beta] (estep_kernels.h 2b)
+            if (k_on) {
+                if (!a.scale_in)
+                    ck = topic_scale_combine(K, tid, part, a.scale_out);
+                ek *= ck;
+                ebuf[tid] = ek;
+            }
+            __syncthreads();                         // `part` is free again, e complete
+        }
+    }
     TRLDA_STAMP(0);
 
     double e[KS];
@@ -314,7 +387,7 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
     // document's tail length for streamed rows) contribute zero.
     auto tail_chunk = [&](int t0, bool from_lds) {
         double r[TCH][KS];
-        const int my_u = fold_chunk_index<TCH>(lane);
+        const int my_u = fold_group_index<TCH>(lane);
         const int end = from_lds ? n_lds : n - n_reg;
         // (the count comes from LDS for the words whose rows are there: a global load per chunk
         // and iteration would sit in front of the weight)
@@ -356,12 +429,13 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
             }
             sv[u] = d0 + d1;
         }
-        const double tw = my_cnt * rcp_pos<true>(fold_chunk<TCH>(sv) + 1e-100);
-        if ((lane & (TCH == 4 ? 15 : 31)) == 0 && t0 + my_u < end)    // one lane per word
+        const double tw = my_cnt * rcp_pos<true>(fold_group<TCH>(sv) + 1e-100);
+        // one lane per word (a word's result sits in 64 / TCH lanes: the first of them stores)
+        if (lane == fold_group_lane<TCH>(my_u) && t0 + my_u < end)
             a.tw_csr[p0 + n_reg + t0 + my_u] = tw;
 #pragma unroll
         for (int u = 0; u < TCH; ++u) {
-            const double twu = readlane_f64(tw, fold_chunk_lane<TCH>(u));
+            const double twu = readlane_f64(tw, fold_group_lane<TCH>(u));
 #pragma unroll
             for (int s = 0; s < KS; ++s)
                 acc[u % NSET][s] = fma(twu, r[u][s], acc[u % NSET][s]);
@@ -421,6 +495,10 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
         }
         TRLDA_STAMP(1);
         // ---- tail words: phinorm, weight and update of acc from one read of the row
+        // (dealt from wave 0 up: of the two waves that share a SIMD the older one runs at its
+        // lone-wave speed and waits for the younger at the barrier -- the slack a document a few
+        // words over the registers spends here; dealing from wave 7 down was measured: 63.8
+        // against 60.6 us per step with one 193-word document in the batch)
         for (int t0 = wid * TCH; t0 < n_lds; t0 += W * TCH)
             tail_chunk(t0, true);
         for (int t0 = n_lds + wid * TCH; n_reg + t0 < n; t0 += W * TCH)
@@ -468,7 +546,9 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
             const double gnew = k_on ? fma(accs, ek, ak) : 1.5;
             [[maybe_unused]] const double diff = k_on ? fabs(gk - gnew) : 0.0;
             gk = gnew;
-            const double enew = cfg::LEAN_PSI ? exp_digamma_minus_lean(gnew, 0.0) : exp_digamma(gnew);
+            double enew = cfg::LEAN_PSI ? exp_digamma_minus_lean(gnew, 0.0) : exp_digamma(gnew);
+            if constexpr (FACTORS)
+                enew *= ck;
             ek = k_on ? enew : 0.0;
             ebuf[nxt * KP + tid] = ek;
             if constexpr (!MIRROR) {
@@ -533,6 +613,57 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
     }
     TRLDA_STAMP(7);
     TRLDA_STAMP_FLUSH;
+}
+
+template <int KS>
+__global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernelArgs a, int lds_rows)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int d = a.order[blockIdx.x];
+    const int p0 = a.indptr[d];
+    estep_docs_wide_body<KS, false>(a, lds_rows, lds, d, p0, a.indptr[d + 1] - p0);
+}
+
+// ---------------------------------------------------------------------------
+// K <= 128: ONE launch for a batch whose documents differ in length -- every workgroup takes the
+// variant its own document needs (block-uniform branch; all variants want the same 512 threads
+// and ~250 registers):
+//   up to 128 words   both orientations in registers               (estep_docs_reg_body<0>)
+//   up to 144         the same with 18 words per wave              (<1>)
+//   up to 192         words past 128 as LDS rows                   (<2>)
+//   beyond            one orientation, words past the registers in LDS / streamed from L2
+//                     (estep_docs_wide_body, with the fused preamble's topic factors)
+// Documents are ordered by decreasing length, so the long ones start first; the launch lasts as
+// long as its slowest document.  Workgroups past pre.n_docs prepare the next batch's preamble as
+// in estep_docs_reg_kernel.  (A launch per variant, one behind the other, made a batch with one
+// 193-word document 2.5 times slower than without it: profiles/r03_length_sweep_before.txt.)
+// ---------------------------------------------------------------------------
+#ifndef TRLDA_TIER2_MAX
+#define TRLDA_TIER2_MAX 144
+#endif
+constexpr int kTier2MaxN = TRLDA_TIER2_MAX;   // longest document of the <2> variant (144: none)
+
+template <int KS>
+__global__ __launch_bounds__(kRegThreads) void estep_docs_tiered_kernel(DocKernelArgs a, PreArgs pre,
+                                                                         int lds_rows)
+{
+    static_assert(kRegThreads == kWideThreads, "one workgroup shape for every tier");
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if ((int)blockIdx.x >= pre.n_docs) {             // block-uniform
+        docs_launch_preamble(pre, lds);
+        return;
+    }
+    const int n = a.pad_meta[4 * blockIdx.x + 1];    // (document, length, CSR offset, 0)
+    if (n <= 128) {
+        estep_docs_reg_body<0>(a, lds);
+    } else if (n <= 144) {
+        estep_docs_reg_body<1>(a, lds);
+    } else if (kTier2MaxN > 144 && n <= kTier2MaxN) {
+        estep_docs_reg_body<2>(a, lds);
+    } else {
+        const int4 meta = reinterpret_cast<const int4 *>(a.pad_meta)[blockIdx.x];
+        estep_docs_wide_body<KS, true>(a, lds_rows, lds, meta.x, meta.z, meta.y);
+    }
 }
 
 }  // namespace trlda

@@ -814,9 +814,11 @@ int dp_exchange(trlda_model *m, const trlda_batch *)
 // register-resident document kernel (estep_kernels.h, 2b) -- what a batch and a model must be like
 bool fused_preamble_possible(const trlda_model *m, const trlda_batch *docs)
 {
+    // (whatever the documents' lengths: every variant of the K <= 128 document launch applies
+    // the topic factors, estep_docs_tiered_kernel)
     return (size_t)m->K * m->V < ((size_t)1 << 22) && docs->B > 0 && m->doc_threads == 0 &&
            m->doc_kernel == TRLDA_DOCS_AUTO && !m->split_preamble && m->K <= trlda::kRegMaxK &&
-           docs->max_n <= trlda::kRegMaxN && !m->lambda_exposed;
+           !m->lambda_exposed;
 }
 
 // may the M-step kernel of an E-step on `docs` leave the next preamble behind?
@@ -1039,15 +1041,12 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         a.scale_out = fused ? m->psi_sum : nullptr;
         const int Kp = K | 1;
 
-        // Documents are ordered by decreasing length and split into two runs:
-        //   [B - n_reg, B)   K <= 128 and at most 192 words: slice in registers, both
-        //                    orientations (estep_docs_reg_kernel)
-        //   [0, B - n_reg)   everything else
+        // K <= 128: ONE launch for all documents, ordered by decreasing length -- the register
+        // kernel when none has more than 128 words, else the tiered kernel, whose workgroups
+        // take the variant their own document needs (estep_wide.h).  Everything else: below.
         int n_reg = 0;
-        if (m->doc_threads == 0 && K <= kRegMaxK && m->doc_kernel != TRLDA_DOCS_WIDE &&
-            m->doc_kernel != TRLDA_DOCS_GENERAL)
-            while (n_reg < B && db->sorted_len[(size_t)(B - 1 - n_reg)] <= kRegMaxN)
-                ++n_reg;
+        if (m->doc_threads == 0 && K <= kRegMaxK && m->doc_kernel == TRLDA_DOCS_AUTO)
+            n_reg = B;
 
         // 128 < K <= 512, or K <= 128 with more than 192 words: registers in one orientation
         // (estep_wide.h); it takes every document the register tier does not.  Beyond 512
@@ -1058,7 +1057,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         if (B - n_reg >= n_reg)
             m->last_doc_kernel = wide ? "estep_docs_wide_kernel" : "estep_docs_kernel";
         else
-            m->last_doc_kernel = "estep_docs_reg_kernel";
+            m->last_doc_kernel = db->max_n <= 128 ? "estep_docs_reg_kernel" : "estep_docs_tiered_kernel";
         if (wide && B - n_reg > 0) {
             const int n_wide = B - n_reg;
             const int KS = (K + kWave - 1) / kWave;
@@ -1130,29 +1129,37 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         if (n_reg > 0) {
             a.n_cap = 0;
             a.Kp = K;
-            // One launch; the variant follows the longest document of the tier (it comes first):
-            // up to 128 words, up to 144 (all in registers still), up to 192 (LDS tail).  A
-            // launch lasts as long as its longest document and the variants cost 33 / 36 / 42 us
-            // at K = 100.  Running two variants on two streams was measured and lost: the event
-            // fork/join costs more (~12 us) than it saves.
-            // (With more documents than CUs it is throughput that counts, and there <2> wins over
-            // <1>: it only charges the long documents for their tail.)
-            const int longest = db->sorted_len[(size_t)(B - n_reg)];
-            a.order = db->order + (B - n_reg);
-            a.pad_meta = db->pad_meta + (size_t)(B - n_reg) * 4;
-            a.pad_ids = db->pad_ids + (size_t)(B - n_reg) * kRegMaxN;
-            auto kern = longest <= 128                    ? estep_docs_reg_kernel<0>
-                        : longest <= 144 && n_reg <= 256 ? estep_docs_reg_kernel<1>
-                                                          : estep_docs_reg_kernel<2>;
-            if ((rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), kRegLdsBytes)))
+            // One launch.  No document over 128 words: the register kernel.  Else the tiered
+            // kernel: per workgroup up to 128 / 144 / 192 words in the register variants, beyond
+            // that one orientation with the words past the registers in LDS rows (as many as fit)
+            // or streamed from L2.  (Running two variants on two streams was measured and lost:
+            // the event fork/join costs ~12 us; one launch per variant one behind the other made
+            // a batch with a single 193-word document 2.5 times slower.)
+            a.order = db->order;
+            a.pad_meta = db->pad_meta;
+            a.pad_ids = db->pad_ids;
+            const bool tiered = db->max_n > 128;
+            const int KS = (K + kWave - 1) / kWave;              // 1 or 2
+            int lds_rows = 0;
+            size_t lds_bytes = kRegLdsBytes;
+            if (tiered && db->max_n > std::max(kTier2MaxN, 144)) {
+                const int jw = KS == 1 ? wide_cfg<1>::JW : wide_cfg<2>::JW;
+                const size_t fixed = wide_lds_doubles(KS, 0) * sizeof(double);
+                const int fit = (int)(((size_t)kLdsBytes - fixed) / ((size_t)(64 * KS + 1) * sizeof(double)));
+                lds_rows = std::max(0, std::min(fit, db->max_n - kWideWaves * jw));
+                lds_bytes = std::max(lds_bytes, wide_lds_doubles(KS, lds_rows) * sizeof(double));
+            }
+            const void *kern_ptr = !tiered ? reinterpret_cast<const void *>(estep_docs_reg_kernel<0>)
+                                   : KS == 1 ? reinterpret_cast<const void *>(estep_docs_tiered_kernel<1>)
+                                             : reinterpret_cast<const void *>(estep_docs_tiered_kernel<2>);
+            if ((rc = ensure_dynamic_lds(kern_ptr, lds_bytes)))
                 return rc;
             // the next batch's preamble as extra workgroups of this launch (PreArgs): when the
             // caller announced it, it fits the same path, and lambda is not about to change
             PreArgs pre{};
             pre.n_docs = n_reg;
             if (next && fused && n_reg == B && !out.upd.lambda && !atomic && next->V == V &&
-                next->device == m->device && next->B > 0 && next->max_n <= kRegMaxN &&
-                !m->lambda_exposed && m->prefetch_next) {
+                next->device == m->device && next->B > 0 && !m->lambda_exposed && m->prefetch_next) {
                 if (!m->eeb_pp[0]) {
                     for (int i = 0; i < 2 && !rc; ++i) {
                         rc = dev_alloc(&m->eeb_pp[i], KV);
@@ -1192,8 +1199,15 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                 m->prefetch.G = pre.G;
                 m->prefetch.dense = dense;
             }
-            hipLaunchKernelGGL(kern, dim3(n_reg + pre.nb), dim3(kRegThreads), kRegLdsBytes, m->stream, a,
-                               pre);
+            if (!tiered)
+                hipLaunchKernelGGL(estep_docs_reg_kernel<0>, dim3(n_reg + pre.nb), dim3(kRegThreads),
+                                   lds_bytes, m->stream, a, pre);
+            else if (KS == 1)
+                hipLaunchKernelGGL(estep_docs_tiered_kernel<1>, dim3(n_reg + pre.nb), dim3(kRegThreads),
+                                   lds_bytes, m->stream, a, pre, lds_rows);
+            else
+                hipLaunchKernelGGL(estep_docs_tiered_kernel<2>, dim3(n_reg + pre.nb), dim3(kRegThreads),
+                                   lds_bytes, m->stream, a, pre, lds_rows);
             if (pre.nb > 0 && (rc = batch_end(m, next)))
                 return rc;
             HIP_TRY(hipGetLastError());
