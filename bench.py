@@ -56,6 +56,10 @@ def parse():
     ap.add_argument("--threshold", type=float, default=1e-3)
     ap.add_argument("--mean-unique", type=int, default=100)
     ap.add_argument("--uniform", action="store_true", help="uniform instead of Zipf vocabulary")
+    ap.add_argument("--lengths", choices=["poisson", "lognormal"], default="poisson",
+                    help="unique words per document: 1 + Poisson(mean - 1) (SURVEY.md 8d, the "
+                         "headline) or heavy-tailed: log-normal around the mean, ~2 %% of the "
+                         "documents over 192 words, a few of 300..600 (utils/synthetic.py)")
     ap.add_argument("--num-batches", type=int, default=8, help="distinct mini-batches cycled")
     ap.add_argument("--sstats-mode", choices=["segmented", "atomic"], default="segmented")
     ap.add_argument("--doc-threads", type=int, default=0)
@@ -333,8 +337,12 @@ def main():
     xworld = vworld or world                         # ranks the mini-batch is cut over
     def rank_corpus(r, i):
         seed = SEED_BASE + 1 + 1000 * r + i          # config index 1; distinct per rank
+        lengths = None
+        if args.lengths == "lognormal":
+            from trlda_amd.utils.synthetic import lognormal_lengths
+            lengths = lognormal_lengths(B, seed, median=args.mean_unique, longest=min(600, V))
         return CSRDocuments(*make_corpus(B, V, seed=seed, mean_unique=args.mean_unique,
-                                         zipf=not args.uniform))
+                                         zipf=not args.uniform, lengths=lengths))
     exchange = "none"
     if collective:
         # ~ max_r(docs) K + max_r(nnz), from the arguments only: the same choice on every rank
@@ -768,9 +776,12 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "OnlineLDA E-step (LDA::updateVariablesVI) K=%d V=%d batch=%d "
                                "docs/GPU, max_iter_inference=%d, threshold=%g, %s vocabulary, "
-                               "~%d unique words/doc" % (K, V, B, args.max_iter, args.threshold,
-                                                         "uniform" if args.uniform else
-                                                         "Zipf-1.07", args.mean_unique),
+                               "~%d unique words/doc%s" % (K, V, B, args.max_iter, args.threshold,
+                                                           "uniform" if args.uniform else
+                                                           "Zipf-1.07", args.mean_unique,
+                                                           " (log-normal lengths, longest %d)"
+                                                           % max(int(np.diff(c.indptr).max()) for c in csrs)
+                                                           if args.lengths == "lognormal" else ""),
                    "num_topics": K, "num_words": V, "batch_per_gpu": B, "global_batch": B * world,
                    "max_iter_inference": args.max_iter, "threshold": args.threshold,
                    "mean_iterations_executed": round(mean_iters, 2),

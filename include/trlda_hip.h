@@ -191,6 +191,17 @@ const char *trlda_model_last_doc_kernel(const trlda_model *model);
 int trlda_model_set_split_preamble(trlda_model *model, int split);
 int trlda_model_last_preamble_fused(const trlda_model *model);
 int trlda_model_synchronize(trlda_model *model);
+/* K <= 128: a document of 193 .. 1024 words is iterated by ceil(n / 128) workgroups of the
+ * document launch, one segment of its words each, which exchange K partial sums per iteration
+ * through HBM (src/lda.cpp:189-193 is a sum over the document's words; every segment ends up with
+ * bitwise the same gamma) -- a launch lasts as long as its slowest document, and one CU takes
+ * ~270 us for 600 words where five take ~50.  enabled = 0: one workgroup per document whatever
+ * its length (default 1).  Should a segment ever give up waiting for its peers, the next
+ * trlda_model_synchronize / host-copying call fails with TRLDA_ERR_HIP. */
+int trlda_model_set_split_docs(trlda_model *model, int enabled);
+/* workgroups the model's last document launch used beyond one per document (0: nothing split;
+ * a batch whose launch would not end sooner with split documents stays unsplit) */
+int trlda_model_last_split_workgroups(const trlda_model *model);
 
 int trlda_model_set_lambda(trlda_model *model, const double *host_lambda /* K x V */);
 int trlda_model_get_lambda(trlda_model *model, double *host_lambda /* K x V */);

@@ -518,6 +518,68 @@ def test_document_length_boundaries(hip, oracle, sampler, K):
             assert np.array_equal(iters, ito)
 
 
+@pytest.mark.parametrize("K", [100, 128, 40])
+def test_documents_split_over_workgroups(hip, oracle, sampler, K):
+    """A document of 193 .. 2048 words is iterated by ceil(n / 128) workgroups that exchange K
+    partial sums per iteration (estep_docs_reg_body<0, true>): same gamma, statistics and
+    iteration counts as with one workgroup per document and as the oracle; lengths at the
+    segment boundaries (193, 256, 257, 384, 385, 1024, 1025, 2048), early exits (threshold 1e-3
+    over 60 iterations), both statistics modes; a batch that fills the chip with moderately long
+    documents, or whose longest document is beyond the split range anyway, stays unsplit."""
+    from trlda_amd.documents import CSRDocuments
+    from trlda_amd.utils.synthetic import make_corpus
+    V = 2600
+    rng = np.random.RandomState(3 * K)
+    lam = seeded_lambda(sampler, 71, K, V)
+    lens = [5, 100, 128, 144, 192, 193, 256, 257, 384, 385, 600, 1024, 1025, 2048]
+    ip = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ids = np.concatenate([rng.permutation(V)[:n] for n in lens]).astype(np.int32)
+    cnts = (1 + rng.randint(4, size=ip[-1])).astype(np.int32)
+    docs = CSRDocuments(ip, ids, cnts)
+    g0 = seeded_gamma(sampler, 72, K, len(lens))
+    m = make_model(K, V, lam)
+    go, so, ito = oracle.estep(lam, .1, ip, ids, cnts, g0, 60, 1e-3)
+    assert ito.min() < 60                          # some documents stop early
+    want_wgs = sum(-(-n // 128) - 1 for n in lens if 192 < n <= 2048)
+    for mode in (0, 1):
+        hip.trlda_model_set_sstats_mode(m._handle, mode)
+        res = {}
+        for split in (1, 0):
+            assert hip.trlda_model_set_split_docs(m._handle, split) == 0
+            res[split] = m.update_variables(docs, latents=g0, max_iter=60, threshold=1e-3,
+                                            return_iterations=True)
+            assert hip.trlda_model_last_split_workgroups(m._handle) == (want_wgs if split else 0)
+            assert hip.trlda_model_last_preamble_fused(m._handle) == 1
+        (g1, s1, i1), (g2, s2, i2) = res[1], res[0]
+        assert np.array_equal(i1, ito) and np.array_equal(i2, ito)
+        per_doc = np.max(np.abs(g1 - go) / np.abs(go), axis=0)
+        assert per_doc.max() < TIGHT_RTOL, list(zip(lens, per_doc))
+        assert relerr(g1, g2) < 1e-11
+        check_sstats(s1, so, rtol=TIGHT_RTOL if mode == 0 else 1e-8)
+    hip.trlda_model_set_sstats_mode(m._handle, 0)
+    hip.trlda_model_set_split_docs(m._handle, 1)
+    # run to run: bitwise (the segments add the published rows in a fixed order)
+    once = m.update_variables(docs, latents=g0, max_iter=60, threshold=1e-3)
+    again = m.update_variables(docs, latents=g0, max_iter=60, threshold=1e-3)
+    assert np.array_equal(again[0], once[0]) and np.array_equal(again[1], once[1])
+    assert np.array_equal(once[0], res[1][0])        # gamma does not depend on the statistics mode
+    # 300 documents of 200 words: 600 segments would take longer than 300 whole documents
+    full = CSRDocuments(*make_corpus(300, V, seed=5, lengths=np.full(300, 200)))
+    m.update_variables(full, max_iter=5)
+    assert hip.trlda_model_last_split_workgroups(m._handle) == 0
+    assert hip.trlda_model_last_doc_kernel(m._handle) == b"estep_docs_tiered_kernel"
+    # a 2049-word document (one workgroup, rows in LDS and streamed) sets the launch's length
+    ip3 = np.array([0, 2049, 2049 + 300], np.int32)
+    ids3 = np.concatenate([rng.permutation(V)[:2049], rng.permutation(V)[:300]]).astype(np.int32)
+    c3 = np.ones(len(ids3), np.int32)
+    g3 = seeded_gamma(sampler, 73, K, 2)
+    g, s_, it = m.update_variables(CSRDocuments(ip3, ids3, c3), latents=g3, max_iter=10,
+                                   return_iterations=True)
+    assert hip.trlda_model_last_split_workgroups(m._handle) == 0
+    go3, so3, ito3 = oracle.estep(lam, .1, ip3, ids3, c3, g3, 10, 1e-3)
+    assert relerr(g, go3) < TIGHT_RTOL and np.array_equal(it, ito3)
+
+
 @pytest.mark.parametrize("K", [100, 128, 7])
 @pytest.mark.parametrize("longest", [129, 137, 144])
 def test_register_kernel_144_word_variant(hip, oracle, sampler, K, longest):

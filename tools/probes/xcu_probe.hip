@@ -1,0 +1,129 @@
+// xcu_probe -- what an exchange of K doubles per iteration between C workgroups costs when it goes
+// through global memory (workgroups of one launch land on different XCDs round-robin, so nothing
+// short of agent-scope -- sc1 -- accesses is visible across them).
+//
+// Every iteration each workgroup publishes 128 doubles and needs the 128 doubles of every other
+// workgroup before it goes on (the shape of "one long document on several CUs": per-iteration
+// partial sums of acc_k).  Two protocols, slots indexed by iteration (never reused in a launch):
+//   A  data, then a per-workgroup flag (release), consumers poll the flags, then load the data
+//   B  no flag: the buffer starts as a NaN sentinel and consumers poll the data itself
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probes/xcu_probe.hip -o tools/probes/xcu_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+constexpr int K = 128, IT = 200;
+
+__device__ __forceinline__ void st_agent(double *p, double v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int PROTO>
+__global__ __launch_bounds__(512) void exchange(int C, int stride, double *buf /* IT x C x K */,
+                                                unsigned int *flags /* IT x C */, double *out,
+                                                unsigned long long *cyc, int *fail)
+{
+    // only every `stride`-th workgroup takes part (stride 8: all members on ONE XCD, if the
+    // dispatcher deals workgroups round-robin over the 8 XCDs; stride 1: members on C XCDs)
+    if (blockIdx.x % stride != 0 || (int)(blockIdx.x / stride) >= C)
+        return;
+    const int me = blockIdx.x / stride, tid = threadIdx.x;
+    double acc = me + 1.0;
+    __shared__ double sh[K];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < IT; ++it) {
+        double *slot = buf + ((size_t)it * C + me) * K;
+        if (tid < K)
+            st_agent(slot + tid, acc + tid * 1e-3 + it);          // never NaN
+        if (PROTO == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_s_waitcnt(0);                        // the stores have left
+            __syncthreads();
+            if (tid == 0)
+                __hip_atomic_store(flags + (size_t)it * C + me, 1u, __ATOMIC_RELEASE,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            if (tid < C) {                                        // lane c polls workgroup c's flag
+                int spins = 0;
+                while (__hip_atomic_load(flags + (size_t)it * C + tid, __ATOMIC_ACQUIRE,
+                                         __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                    if (++spins > (1 << 22)) { *fail = 1; break; }
+                }
+            }
+            __syncthreads();
+        }
+        // every thread k < K adds up column k over the C workgroups, in order
+        double sum = 0.0;
+        if (tid < K) {
+            for (int c = 0; c < C; ++c) {
+                const double *p = buf + ((size_t)it * C + c) * K + tid;
+                double v = ld_agent(p);
+                if (PROTO == 1) {
+                    int spins = 0;
+                    while (v != v) {                              // sentinel: not written yet
+                        if (++spins > (1 << 22)) { *fail = 1; break; }
+                        v = ld_agent(p);
+                    }
+                }
+                sum += v;
+            }
+            sh[tid] = sum;
+        }
+        __syncthreads();
+        acc = sh[(tid + it) % K] * 1e-3 + me;                     // the next round depends on this one
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (tid == 0) {
+        cyc[me] = t1 - t0;
+        out[me] = acc;
+    }
+}
+
+int main()
+{
+    double *buf, *out;
+    unsigned int *flags;
+    unsigned long long *cyc;
+    int *fail;
+    const int CMAX = 8;
+    hipMalloc(&buf, sizeof(double) * IT * CMAX * K);
+    hipMalloc(&flags, sizeof(unsigned) * IT * CMAX);
+    hipMalloc(&out, 8 * CMAX);
+    hipMalloc(&cyc, 8 * CMAX);
+    hipMalloc(&fail, 4);
+    for (int proto = 0; proto < 2; ++proto)
+        for (int stride : {1, 8})
+            for (int C : {1, 2, 3, 5, 8}) {
+                hipMemset(buf, 0xFF, sizeof(double) * IT * CMAX * K);   // NaN sentinel
+                hipMemset(flags, 0, sizeof(unsigned) * IT * CMAX);
+                hipMemset(fail, 0, 4);
+                hipEvent_t e0, e1;
+                hipEventCreate(&e0); hipEventCreate(&e1);
+                hipDeviceSynchronize();
+                hipEventRecord(e0, 0);
+                if (proto == 0)
+                    hipLaunchKernelGGL(exchange<0>, dim3(C * stride), dim3(512), 0, 0, C, stride, buf, flags, out, cyc, fail);
+                else
+                    hipLaunchKernelGGL(exchange<1>, dim3(C * stride), dim3(512), 0, 0, C, stride, buf, flags, out, cyc, fail);
+                hipEventRecord(e1, 0);
+                hipDeviceSynchronize();
+                float ms = 0.f;
+                hipEventElapsedTime(&ms, e0, e1);
+                unsigned long long h[CMAX];
+                int f = 0;
+                hipMemcpy(h, cyc, 8 * C, hipMemcpyDeviceToHost);
+                hipMemcpy(&f, fail, 4, hipMemcpyDeviceToHost);
+                unsigned long long worst = 0;
+                for (int c = 0; c < C; ++c)
+                    worst = h[c] > worst ? h[c] : worst;
+                printf("protocol %c  stride %d  C=%d workgroups: %6.0f s_memtime ticks, %6.0f ns per exchange "
+                       "(launch %.1f us)%s\n", proto ? 'B' : 'A', stride, C, (double)worst / IT,
+                       1e6 * ms / IT, 1e3 * ms, f ? "  [SPIN LIMIT HIT]" : "");
+            }
+    return 0;
+}

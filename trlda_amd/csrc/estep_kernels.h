@@ -547,6 +547,12 @@ struct DocKernelArgs {
     double *scale_out;        // 3K: psi(sum), sum, c (written by workgroup 0)
     // register kernel: per workgroup (document, length, CSR offset, 0) and kRegMaxN padded ids
     const int32_t *pad_meta, *pad_ids;
+    // split documents (estep_docs_reg_body<0, true>): meta_i4 = 2 int4 per workgroup, the second
+    // one (segment, segments, first exchange row of the document, document length); xbuf holds
+    // (max_iter + 1) x segments x K doubles per split document, NaN before the launch
+    int meta_i4;
+    double *xbuf;
+    int *xerr;                // set to 1 when an exchange gave up waiting (never in a sane run)
 };
 
 // sum_{i<count} a[i] * b[i * stride] with NA independent accumulators.  A dependent fp64
@@ -857,6 +863,9 @@ constexpr int kRegMaxK = 128;
 constexpr int kRegMaxN = 192;      // 128 words in registers + a tail of up to 64 in LDS
 constexpr int kRegStride = 129;    // LDS row stride of the transposition / tail buffer (odd)
 constexpr int kRegPart = 192;      // row length of the partial-sum arrays
+constexpr int kSplitMinN = 192;    // documents longer than this are split over several workgroups,
+constexpr int kSplitSegN = 128;    // ceil(n / 128) segments of at most 128 words each,
+constexpr int kSplitMaxSeg = 16;   // up to 16 of them (2048 words; longer documents: one workgroup)
 
 // g[2] | alpha | e[2] (+16 zero pad each) | tw (+16 zero pad) | cnt | part[8][192] | misc[8] |
 // buffer [128][129]: transposition scratch while the registers are filled, then the rows
@@ -987,9 +996,20 @@ __device__ __forceinline__ void docs_launch_preamble(const PreArgs &pre, double 
 // One document = one workgroup: the body of estep_docs_reg_kernel<MODE>, also instantiated by
 // the tiered kernel of estep_wide.h, where every workgroup takes the variant its own document
 // needs.  The document is the one of a.pad_meta[blockIdx.x].
-template <int MODE>
+// SPLIT: this workgroup holds ONE SEGMENT (at most 128 words) of a document that several
+// workgroups share.  Everything a word needs of the other words goes through gamma: every
+// iteration each segment publishes the K sums acc_k over its own words, all segments add up the
+// published rows in segment order (bitwise the same gamma and exp(psi(gamma)) everywhere, so the
+// same decision to stop), and go on with their own words.  The rows travel through global memory
+// with agent-scope (sc1) accesses -- workgroups of a launch sit on different XCDs -- into a
+// buffer with one row per (document, iteration, segment) that starts out as NaN: a row is there
+// when it is not NaN any more (tools/probes/xcu_probe: 0.6-0.9 us per exchange, against 2-3 with
+// a flag per row).  Segments of a document are consecutive workgroups at the front of the grid
+// (long documents first), so they are resident together.
+template <int MODE, bool SPLIT = false>
 __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, double *lds)
 {
+    static_assert(!SPLIT || MODE == 0, "segments hold at most 128 words");
     constexpr bool TAIL = MODE == 2, MID = MODE == 1;
     constexpr int JC = MID ? 18 : 16;                // words per wave: wave w owns [JC w, JC w + JC)
     constexpr int NREG = 8 * JC;                     // words held in registers
@@ -1008,7 +1028,10 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
     // One load gives (document, length, CSR offset); the word ids sit at an address that
     // depends on the workgroup index only, so they are fetched at the same time: two dependent
     // memory latencies (descriptor | ids -> rows) instead of four (order -> indptr -> ids -> rows)
-    const int4 meta = reinterpret_cast<const int4 *>(a.pad_meta)[blockIdx.x];
+    const int4 meta = reinterpret_cast<const int4 *>(a.pad_meta)[(size_t)blockIdx.x * a.meta_i4];
+    [[maybe_unused]] int4 seg = make_int4(0, 1, 0, 0);
+    if constexpr (SPLIT)
+        seg = reinterpret_cast<const int4 *>(a.pad_meta)[(size_t)blockIdx.x * a.meta_i4 + 1];
     const int32_t *__restrict__ pids = a.pad_ids + (size_t)blockIdx.x * kRegMaxN;
     const int myid = pids[wid * JC + min(lane, JC - 1)];   // word wid * JC + i of the document
     const int d = meta.x, n = meta.y, p0 = meta.z;
@@ -1361,14 +1384,64 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
         if (wid < 2) {
             const int kk = psi_on ? k_psi : 0;
             const double ek = e_old[kk], ak = alpha_l[kk];
-            const double acc = sum8_strided<kRegPart>(part + kk);
+            double acc = sum8_strided<kRegPart>(part + kk);
+            if constexpr (SPLIT) {
+                // this segment's row out, every segment's row in (segment order)
+                double *rows = a.xbuf + ((size_t)seg.z * (size_t)(a.max_iter + 1) +
+                                         (size_t)it * (size_t)seg.y) * (size_t)K;
+                if (psi_on)
+                    __hip_atomic_store(rows + (size_t)seg.x * K + k_psi, acc, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                // eight rows at a time: all their loads in flight, then again for those that
+                // were not there yet (a row is there when it is not NaN any more)
+                double total = 0.0;
+                for (int c0 = 0; c0 < seg.y; c0 += 8) {          // wave-uniform bounds
+                    double v[8];
+                    const int nc = min(8, seg.y - c0);
+                    unsigned need = (1u << nc) - 1u;             // rows not seen yet
+                    for (int spins = 0;; ++spins) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c)
+                            if (need >> c & 1u)
+                                v[c] = __hip_atomic_load(rows + (size_t)(c0 + c) * K + kk, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+                        unsigned still = 0u;
+#pragma unroll
+                        for (int c = 0; c < 8; ++c)
+                            if ((need >> c & 1u) && !(v[c] == v[c]))
+                                still |= 1u << c;
+                        need = still;
+                        if (!__any(need != 0u))                  // wave-uniform: every lane has every row
+                            break;
+                        if (spins > (1 << 21)) {                 // a peer never came: give up, loudly
+                            if (lane == 0)
+                                *a.xerr = 1;
+#pragma unroll
+                            for (int c = 0; c < 8; ++c)
+                                if (need >> c & 1u)
+                                    v[c] = 0.0;
+                            break;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)                  // segment order, on every segment
+                        if (c < nc)
+                            total += v[c];
+                }
+                acc = total;
+            }
             const double gnew = acc * ek + ak;
             const double enew = (MODE == 2 ? exp_digamma_minus_lean(gnew, 0.0) : exp_digamma(gnew)) * c_psi;
             if (psi_on) {
                 g_new[k_psi] = gnew;
                 e_new[k_psi] = enew;
             }
-        } else if (wid >= W - 2) {
+            if constexpr (SPLIT) {                               // sum |gamma - last| here too
+                const double half = wave_sum_dpp(psi_on ? fabs(g_old[kk] - gnew) : 0.0);
+                if (lane == 0)
+                    misc[wid] = half;
+            }
+        } else if (!SPLIT && wid >= W - 2) {
             // mean |gamma - last| (lda.cpp:202): two otherwise idle waves (on SIMDs the exp(psi)
             // waves do not use) recompute gamma for one topic per lane from the same partial
             // sums (bitwise the same value as the owners'), reduce with DPP and leave the two
@@ -1399,13 +1472,15 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
     }
     const double *g = gbuf + (it & 1) * 128, *e = ebuf + (it & 1) * 144;
 
-    // results
-    for (int k = tid; k < K; k += T) {
-        gamma_d[k] = g[k];
-        a.epg[(size_t)d * K + k] = e[k];
+    // results (a split document's gamma by its first segment; every segment holds the same)
+    if (!SPLIT || seg.x == 0) {
+        for (int k = tid; k < K; k += T) {
+            gamma_d[k] = g[k];
+            a.epg[(size_t)d * K + k] = e[k];
+        }
+        if (tid == 0 && a.iters_out)
+            a.iters_out[d] = it;
     }
-    if (tid == 0 && a.iters_out)
-        a.iters_out[d] = it;
     if (a.sstats_acc) {                              // lda.cpp:207-213, atomic form
         for (int j = wid; j < n; j += W) {
             const double c = tw[j];

@@ -630,9 +630,15 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
 // and ~250 registers):
 //   up to 128 words   both orientations in registers               (estep_docs_reg_body<0>)
 //   up to 144         the same with 18 words per wave              (<1>)
-//   up to 192         words past 128 as LDS rows                   (<2>)
-//   beyond            one orientation, words past the registers in LDS / streamed from L2
+//   up to 192         one orientation, all words in registers
 //                     (estep_docs_wide_body, with the fused preamble's topic factors)
+//   up to 1024        SPLIT over ceil(n / 128) workgroups that exchange K sums per iteration
+//                     (estep_docs_reg_body<0, true>): a 600-word document takes ~50 us on five
+//                     CUs instead of 270 on one
+//   beyond            one orientation, words past the registers in LDS / streamed from L2
+// (-DTRLDA_TIER2_MAX=192 brings back the variant with the words 129..192 as LDS rows read in
+// both orientations, <2>: measured equal at 145..160 words and slower at 176..192, 60.5 against
+// 57.2 us per step, profiles/r03_sweep_tier2_*.txt)
 // Documents are ordered by decreasing length, so the long ones start first; the launch lasts as
 // long as its slowest document.  Workgroups past pre.n_docs prepare the next batch's preamble as
 // in estep_docs_reg_kernel.  (A launch per variant, one behind the other, made a batch with one
@@ -653,15 +659,22 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_tiered_kernel(DocKerne
         docs_launch_preamble(pre, lds);
         return;
     }
-    const int n = a.pad_meta[4 * blockIdx.x + 1];    // (document, length, CSR offset, 0)
-    if (n <= 128) {
+    // (document, length, CSR offset, 0) [, (segment, segments, exchange row, document length)]
+    const int n = a.pad_meta[4 * (size_t)blockIdx.x * a.meta_i4 + 1];
+    if (a.meta_i4 == 2 && a.pad_meta[4 * ((size_t)blockIdx.x * 2 + 1) + 1] > 1) {
+        estep_docs_reg_body<0, true>(a, lds);        // one segment of a document split over CUs
+    } else if (n <= 128) {
         estep_docs_reg_body<0>(a, lds);
     } else if (n <= 144) {
         estep_docs_reg_body<1>(a, lds);
-    } else if (kTier2MaxN > 144 && n <= kTier2MaxN) {
-        estep_docs_reg_body<2>(a, lds);
     } else {
-        const int4 meta = reinterpret_cast<const int4 *>(a.pad_meta)[blockIdx.x];
+        if constexpr (kTier2MaxN > 144) {            // (the LDS-tail variant: off by default)
+            if (n <= kTier2MaxN) {
+                estep_docs_reg_body<2>(a, lds);
+                return;
+            }
+        }
+        const int4 meta = reinterpret_cast<const int4 *>(a.pad_meta)[(size_t)blockIdx.x * a.meta_i4];
         estep_docs_wide_body<KS, true>(a, lds_rows, lds, meta.x, meta.z, meta.y);
     }
 }

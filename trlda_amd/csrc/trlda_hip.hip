@@ -157,6 +157,14 @@ struct trlda_batch {
     // at an address that depends on its index only
     int32_t *pad_meta = nullptr;     // B x 4
     int32_t *pad_ids = nullptr;      // B x kRegMaxN
+    // the same per WORKGROUP when documents of more than kSplitMinN words are split into segments
+    // of at most kSplitSegN (estep_docs_reg_body<0, true>): (document, segment length, CSR offset
+    // of the segment, 0 | segment, segments, first exchange row of the document, document length)
+    // and the segment's ids; only for batches that hold such a document
+    int32_t *seg_meta = nullptr;     // n_wg x 8
+    int32_t *seg_ids = nullptr;      // n_wg x kRegMaxN
+    int n_wg = 0, n_xrows = 0;       // workgroups; exchange rows per iteration (sum of segments)
+    bool split_pays = false;         // the launch is expected to end sooner with split documents
     std::vector<int32_t> sorted_len;   // host copy: document lengths in `order`
     std::vector<int32_t> indptr_host;  // host copy of indptr (data-parallel slot geometry)
     // data-parallel factor exchange: where each word-major entry's weight and document row lie
@@ -253,6 +261,12 @@ struct trlda_model {
     int (*allgather_hook)(void *, const void *, void *, size_t, void *) = nullptr;
     void *allgather_ctx = nullptr;
     double *epg = nullptr, *tw_csr = nullptr, *tw_word = nullptr;
+    // split documents: the exchange rows of a launch (NaN before it), the give-up flag
+    double *xbuf = nullptr;
+    size_t cap_xbuf = 0;
+    int *xerr = nullptr;
+    bool split_docs = true;             // trlda_model_set_split_docs
+    int last_split_wgs = 0;             // workgroups of the last document launch beyond one per document
     // update_parameters workspaces
     double *lambda_prime = nullptr, *sstats = nullptr, *gamma = nullptr, *wordcounts = nullptr;
     size_t cap_gamma = 0, cap_lambda_prime = 0, cap_sstats = 0, cap_wordcounts = 0;
@@ -859,6 +873,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
     if (out.upd.lambda && !fused_update_available(m))
         return fail(TRLDA_ERR_ARG, "internal: fused M-step requested where it is not available");
     double *sstats_dev = out.upd.sstats;
+    m->last_split_wgs = 0;
     if (m->timing && (rc = stamp(m)))
         return rc;
 
@@ -1010,6 +1025,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         DocKernelArgs a;
         a.K = K; a.B = B;
         a.stamps = nullptr;
+        a.meta_i4 = 1; a.xbuf = nullptr; a.xerr = nullptr;
 #ifdef TRLDA_STAMPS
         {
             static unsigned long long *stamp_buf = nullptr;   // diagnostic build only
@@ -1140,9 +1156,37 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
             a.pad_ids = db->pad_ids;
             const bool tiered = db->max_n > 128;
             const int KS = (K + kWave - 1) / kWave;              // 1 or 2
+            // Documents of more than 192 words: split over several workgroups that exchange K
+            // sums per iteration (estep_docs_reg_body<0, true>) -- the batch brought the
+            // per-workgroup layout; one row of K doubles per (segment, iteration), NaN before
+            // the launch.  Not with an exchange buffer beyond 256 MB (max_iter in the thousands):
+            // those batches keep one workgroup per document.
+            int n_wgs = n_reg;                                   // document workgroups of the launch
+            const size_t xcount = (size_t)db->n_xrows * (size_t)(max_iter + 1) * (size_t)K;
+            if (tiered && m->split_docs && db->n_wg > 0 && db->split_pays && max_iter > 0 &&
+                xcount * sizeof(double) <= ((size_t)256 << 20)) {
+                if ((rc = grow(&m->xbuf, &m->cap_xbuf, xcount)))
+                    return rc;
+                if (!m->xerr) {
+                    if ((rc = dev_alloc(&m->xerr, 1)))
+                        return rc;
+                    HIP_TRY(hipMemsetAsync(m->xerr, 0, sizeof(int), m->stream));
+                }
+                HIP_TRY(hipMemsetAsync(m->xbuf, 0xFF, xcount * sizeof(double), m->stream));   // NaN
+                a.pad_meta = db->seg_meta;
+                a.pad_ids = db->seg_ids;
+                a.meta_i4 = 2;
+                a.xbuf = m->xbuf;
+                a.xerr = m->xerr;
+                n_wgs = db->n_wg;
+            }
+            const bool split = a.meta_i4 == 2;
+            m->last_split_wgs = n_wgs - n_reg;
             int lds_rows = 0;
             size_t lds_bytes = kRegLdsBytes;
-            if (tiered && db->max_n > std::max(kTier2MaxN, 144)) {
+            // (LDS rows only for what the single-orientation body cannot hold in registers:
+            // with split documents that is a document beyond the split range)
+            if (tiered && db->max_n > (split ? kSplitSegN * kSplitMaxSeg : std::max(kTier2MaxN, 144))) {
                 const int jw = KS == 1 ? wide_cfg<1>::JW : wide_cfg<2>::JW;
                 const size_t fixed = wide_lds_doubles(KS, 0) * sizeof(double);
                 const int fit = (int)(((size_t)kLdsBytes - fixed) / ((size_t)(64 * KS + 1) * sizeof(double)));
@@ -1157,7 +1201,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
             // the next batch's preamble as extra workgroups of this launch (PreArgs): when the
             // caller announced it, it fits the same path, and lambda is not about to change
             PreArgs pre{};
-            pre.n_docs = n_reg;
+            pre.n_docs = n_wgs;
             if (next && fused && n_reg == B && !out.upd.lambda && !atomic && next->V == V &&
                 next->device == m->device && next->B > 0 && !m->lambda_exposed && m->prefetch_next) {
                 if (!m->eeb_pp[0]) {
@@ -1200,13 +1244,13 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                 m->prefetch.dense = dense;
             }
             if (!tiered)
-                hipLaunchKernelGGL(estep_docs_reg_kernel<0>, dim3(n_reg + pre.nb), dim3(kRegThreads),
+                hipLaunchKernelGGL(estep_docs_reg_kernel<0>, dim3(n_wgs + pre.nb), dim3(kRegThreads),
                                    lds_bytes, m->stream, a, pre);
             else if (KS == 1)
-                hipLaunchKernelGGL(estep_docs_tiered_kernel<1>, dim3(n_reg + pre.nb), dim3(kRegThreads),
+                hipLaunchKernelGGL(estep_docs_tiered_kernel<1>, dim3(n_wgs + pre.nb), dim3(kRegThreads),
                                    lds_bytes, m->stream, a, pre, lds_rows);
             else
-                hipLaunchKernelGGL(estep_docs_tiered_kernel<2>, dim3(n_reg + pre.nb), dim3(kRegThreads),
+                hipLaunchKernelGGL(estep_docs_tiered_kernel<2>, dim3(n_wgs + pre.nb), dim3(kRegThreads),
                                    lds_bytes, m->stream, a, pre, lds_rows);
             if (pre.nb > 0 && (rc = batch_end(m, next)))
                 return rc;
@@ -1393,6 +1437,23 @@ void note_host_lambda(trlda_model *m, const double *host_lambda)
     for (size_t k = 1; k < K; ++k)
         lo = std::min(lo, sum[k]);
     m->rs_floor = lo > 0.0 ? 0.999 * lo : 0.0;   // NaN compares false -> 0
+}
+
+// after a synchronisation: did a segment of a split document give up waiting for its peers
+// (estep_docs_reg_body<0, true>)?  Results of that launch are void.
+int check_split_exchange(trlda_model *m)
+{
+    if (!m->xerr)
+        return TRLDA_OK;
+    int flag = 0;
+    HIP_TRY(hipMemcpy(&flag, m->xerr, sizeof(int), hipMemcpyDeviceToHost));
+    if (!flag)
+        return TRLDA_OK;
+    HIP_TRY(hipMemset(m->xerr, 0, sizeof(int)));
+    return fail(TRLDA_ERR_HIP, "a document split over several workgroups timed out waiting for one of "
+                               "its segments (or its statistics are NaN); the results of that call "
+                               "are void -- trlda_model_set_split_docs(model, 0) keeps every document "
+                               "on one workgroup");
 }
 
 int check_model(const trlda_model *m)
@@ -2027,6 +2088,22 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
         wptr[(size_t)w + 1] += wptr[(size_t)w];
     }
 
+    // documents of more than kSplitMinN words take several workgroups (segments)
+    auto segments_of = [](int n) {
+        if (n <= trlda::kSplitMinN)
+            return 1;
+        const int c = (n + trlda::kSplitSegN - 1) / trlda::kSplitSegN;
+        return c <= trlda::kSplitMaxSeg ? c : 1;
+    };
+    int n_wg = 0, n_xrows = 0;
+    for (int d = 0; d < B; ++d) {
+        const int c = segments_of(indptr[d + 1] - indptr[d]);
+        n_wg += c;
+        n_xrows += c > 1 ? c : 0;
+    }
+    if (n_xrows == 0)
+        n_wg = 0;                                    // no split document: no second layout
+
     // layout (bytes, 256-aligned sections)
     size_t off = 0;
     auto section = [&](size_t bytes) {
@@ -2039,6 +2116,7 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
                  o_order = section(Bz * 4), o_wrank = section(nz * 4),
                  o_wptr = section(((size_t)V + 1) * 4), o_wdoc = section(nz * 4),
                  o_meta = section(Bz * 16), o_pids = section(Bz * trlda::kRegMaxN * 4),
+                 o_smeta = section((size_t)n_wg * 32), o_spids = section((size_t)n_wg * trlda::kRegMaxN * 4),
                  o_active = section((size_t)n_active * 4), o_long = section((size_t)n_long * 4),
                  o_flag = section((size_t)V), o_wc32 = section((size_t)V * 4);
     const size_t total = off;
@@ -2123,6 +2201,53 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
                 row[j] = fill;
         }
     }
+    if (n_wg > 0) {
+        // Does splitting pay for THIS batch?  A launch lasts max(longest workgroup, all work /
+        // CUs).  Per iteration, in microseconds at K = 100 (profiles/r03_length_sweep*.txt; only
+        // the ratios matter): a document on one workgroup costs 1.0 + 0.0025 n up to 128 words,
+        // 1.5 up to 144, 0.013 n up to 192 and 2.5 + 0.025 (n - 192) beyond; a segment 2.6
+        // whatever its document's length -- 1.1 to 1.8 times the CU time of the unsplit form,
+        // which is why a batch of 400-word documents that fills the chip anyway stays unsplit,
+        // and a batch with a few long documents (or, like the reference's test_speed, very
+        // uneven ones) does not.
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+        double sum_u = 0., max_u = 0., sum_s = 0., max_s = 0.;
+        for (int i = 0; i < B; ++i) {
+            const int n = indptr[order[i] + 1] - indptr[order[i]];
+            const double cu = n <= 128 ? 1.0 + 0.0025 * n : n <= 144 ? 1.5 : n <= 192 ? 0.013 * n
+                                                                        : 2.5 + 0.025 * (n - 192);
+            const int c = segments_of(n);
+            sum_u += cu; max_u = std::max(max_u, cu);
+            sum_s += c > 1 ? 2.6 * c : cu; max_s = std::max(max_s, c > 1 ? 2.6 : cu);
+        }
+        b->split_pays = std::max(max_s, sum_s / cus) < 0.95 * std::max(max_u, sum_u / cus);
+        int32_t *meta = I(o_smeta), *pids = I(o_spids);
+        size_t w = 0;
+        int xrow = 0;
+        for (int i = 0; i < B; ++i) {
+            const int d = order[i], p0 = indptr[d], n = indptr[d + 1] - p0;
+            const int c = segments_of(n);
+            const int base = n / c, rem = n % c;
+            int start = 0;
+            for (int sgm = 0; sgm < c; ++sgm, ++w) {
+                const int len = base + (sgm < rem ? 1 : 0);
+                int32_t *mm = meta + w * 8;
+                mm[0] = d; mm[1] = len; mm[2] = p0 + start; mm[3] = 0;
+                mm[4] = sgm; mm[5] = c; mm[6] = c > 1 ? xrow : 0; mm[7] = n;
+                int32_t *row = pids + w * trlda::kRegMaxN;
+                const int m0 = std::min(len, trlda::kRegMaxN);
+                for (int j = 0; j < m0; ++j)
+                    row[j] = ids[p0 + start + j];
+                const int32_t fill = len > 0 ? ids[p0 + start + m0 - 1] : 0;
+                for (int j = m0; j < trlda::kRegMaxN; ++j)
+                    row[j] = fill;
+                start += len;
+            }
+            if (c > 1)
+                xrow += c;
+        }
+    }
     {
         int32_t *active = I(o_active), *longw = I(o_long);
         uint8_t *flag = reinterpret_cast<uint8_t *>(h + o_flag);
@@ -2193,6 +2318,8 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     b->indptr = D(o_indptr); b->ids = D(o_ids); b->cnts = D(o_cnts); b->order = D(o_order);
     b->wrank = D(o_wrank); b->wptr = D(o_wptr); b->wdoc = D(o_wdoc);
     b->pad_meta = D(o_meta); b->pad_ids = D(o_pids);
+    b->seg_meta = n_wg ? D(o_smeta) : nullptr; b->seg_ids = n_wg ? D(o_spids) : nullptr;
+    b->n_wg = n_wg; b->n_xrows = n_xrows;
     b->active = D(o_active); b->long_words = D(o_long);
     b->active_flag = reinterpret_cast<uint8_t *>(dv + o_flag);
     b->wc32 = D(o_wc32);
@@ -2308,6 +2435,7 @@ int trlda_model_destroy(trlda_model *m)
     if (hipSetDevice(m->device) == hipSuccess) {
         (void)hipStreamSynchronize(m->stream);
         (void)hipFree(m->lambda); (void)hipFree(m->alpha); (void)hipFree(m->eeb); (void)hipFree(m->psi_sum);
+        (void)hipFree(m->xbuf); (void)hipFree(m->xerr);
         (void)hipFree(m->partial); (void)hipFree(m->counter); (void)hipFree(m->epg); (void)hipFree(m->tw_csr);
         (void)hipFree(m->tw_word); (void)hipFree(m->dp_gather); (void)hipFree(m->lambda_prime); (void)hipFree(m->sstats); (void)hipFree(m->gamma);
         (void)hipFree(m->wordcounts); (void)hipFree(m->rs_full); (void)hipFree(m->rs_static);
@@ -2405,6 +2533,16 @@ int trlda_model_synchronize(trlda_model *m)
     if (rc)
         return rc;
     HIP_TRY(hipStreamSynchronize(m->stream));
+    return check_split_exchange(m);
+}
+
+int trlda_model_last_split_workgroups(const trlda_model *m) { return m ? m->last_split_wgs : 0; }
+
+int trlda_model_set_split_docs(trlda_model *m, int enabled)
+{
+    if (!m)
+        return fail(TRLDA_ERR_ARG, "model is NULL");
+    m->split_docs = enabled != 0;
     return TRLDA_OK;
 }
 
@@ -2433,7 +2571,7 @@ int trlda_model_get_lambda(trlda_model *m, double *host_lambda)
                            hipMemcpyDeviceToHost, m->stream));
     m->d2h_bytes += (int64_t)((size_t)m->K * m->V * sizeof(double));
     HIP_TRY(hipStreamSynchronize(m->stream));
-    return TRLDA_OK;
+    return check_split_exchange(m);
 }
 
 int trlda_model_set_alpha(trlda_model *m, const double *host_alpha)
@@ -2556,6 +2694,7 @@ int trlda_model_estep_host(trlda_model *m, const trlda_batch *b, double *gamma, 
                                    hipMemcpyDeviceToHost, m->stream));
         HIP_TRY(hipStreamSynchronize(m->stream));
         m->d2h_bytes += (int64_t)(gbytes + sbytes);
+        rc = check_split_exchange(m);
     }
     return rc;
 }
