@@ -125,6 +125,9 @@ int trlda_tr_init(int K, int V, int B, int num_documents, double rho, double eta
  * returns, fail with TRLDA_ERR_VALUE / TRLDA_ERR_ARG and a line number in trlda_last_error(). */
 typedef struct trlda_docs trlda_docs;
 int trlda_docs_from_text(const char *path, trlda_docs **out);
+/* the same for text already in memory (a window of a file that does not fit: the Python loader
+ * reads bounded chunks cut at line ends); `bytes` of `text`, the last line may lack its newline */
+int trlda_docs_from_buffer(const char *text, size_t bytes, trlda_docs **out);
 int64_t trlda_docs_num_docs(const trlda_docs *docs);
 int64_t trlda_docs_nnz(const trlda_docs *docs);
 const int64_t *trlda_docs_offsets(const trlda_docs *docs);   /* num_docs + 1 */
@@ -484,6 +487,34 @@ int trlda_model_eb_gamma_stats(trlda_model *model, int B, const double *gamma_de
  * src/batchlda.cpp:152. */
 int trlda_model_eb_lambda_stats(trlda_model *model, double *sum_psi_lambda,
                                 double *rowsums_host /* K */);
+
+/* ---- empirical Bayes: the K- and scalar-sized host steps (csrc/eb_steps.cpp) --------------- */
+
+/* alpha <- max(alpha - rho H^-1 g, min_alpha): one natural-gradient step, src/onlinelda.cpp:123-142;
+ * psi_gamma_diff[k] = sum over the mini-batch's documents of psi(gamma_dk) - psi(sum_k gamma_dk)
+ * (trlda_model_eb_gamma_stats), num_docs = the mini-batch's size.  Host memory, no GPU. */
+int trlda_eb_online_alpha_step(int K, const double *alpha, const double *psi_gamma_diff,
+                               double num_docs, double rho, double min_alpha, double *alpha_out);
+/* eta <- max(eta - rho g / h, min_eta): src/onlinelda.cpp:147-162 (sums from
+ * trlda_model_eb_lambda_stats) */
+double trlda_eb_online_eta_step(double eta, double sum_psi_lambda, const double *rowsums, int K,
+                                int V, double rho, double min_eta);
+/* Newton steps with a step-halving line search on the lower bound: src/batchlda.cpp:81-141 ==
+ * src/cumulativelda.cpp:90-150 (alpha), src/batchlda.cpp:147-205 (eta) */
+int trlda_eb_alpha_line_search(int K, const double *alpha, const double *psi_gamma_diff,
+                               double num_docs, int max_iter_alpha, double min_alpha,
+                               double threshold, double *alpha_out);
+double trlda_eb_eta_line_search(double eta, double sum_psi_lambda, const double *rowsums, int K,
+                                int V, int max_iter_eta, double min_eta, double threshold);
+/* Both online steps after an update, with ONE synchronisation: the device sums over the gamma
+ * the update left behind (B_local documents of this rank; summed over the ranks of rccl_comm
+ * when that is not NULL) and over lambda, the host steps above, the new alpha back on the
+ * device.  alpha_host (K) and *eta are read and updated; B_total = the mini-batch's size. */
+int trlda_model_online_eb(trlda_model *model, void *rccl_comm, int B_local, int B_total, double rho,
+                          int update_alpha, int update_eta, double min_alpha, double min_eta,
+                          double *alpha_host, double *eta);
+/* test hook: psi and psi' as eb_steps.cpp evaluates them */
+void trlda_debug_host_psi(int n, const double *x, double *psi_out, double *psi1_out);
 
 /* Adaptive learning rate, src/onlinelda.cpp:167-172, after an update made with keep_sstats on:
  * lambdaUpdate = (eta + scale * sstats) - lambda'; the model's running average

@@ -205,10 +205,21 @@ def test_alpha_argument_handling():
         _inference_method("map")
 
 
-def test_host_special_functions():
-    """trlda_amd._special (alpha / eta Newton steps) against the reference's psi table and its
-    polygamma known answers (utils_test.py:33-51)."""
-    from trlda_amd._special import digamma, trigamma
+def test_host_special_functions(hip_lib):
+    """psi and psi' of csrc/eb_steps.cpp (the host side of the alpha / eta Newton steps) against
+    the reference's psi table and its polygamma known answers (utils_test.py:33-51)."""
+    def both(x):
+        x = np.ascontiguousarray(np.atleast_1d(np.asarray(x, dtype=np.float64)))
+        p, p1 = np.empty_like(x), np.empty_like(x)
+        hip_lib.trlda_debug_host_psi(x.size, x, p, p1)
+        return p, p1
+
+    def digamma(x):
+        return both(x)[0]
+
+    def trigamma(x):
+        r = both(x)[1]
+        return r if np.ndim(x) else float(r[0])
     f = golden("f0_rng_psi")
     x, want = f["psi_x"], f["psi_y"]
     pos = (x > 0) & np.isfinite(want) & (x != np.floor(x))

@@ -70,7 +70,7 @@ def test_parser_threads_and_line_endings(tmp_path, hip_lib, monkeypatch):
     for ending, tail in (("\n", "\n"), ("\r\n", "\r\n"), ("\n", "")):
         path = tmp_path / "c.dat"
         path.write_bytes((ending.join(lines) + tail).encode())
-        want = _parse_python(str(path))
+        want = _parse_python(path.read_bytes().decode())
         for threads in (1, 2, 7, 64):
             monkeypatch.setenv("TRLDA_PARSE_THREADS", str(threads))
             got = parse_text(str(path))
@@ -80,6 +80,44 @@ def test_parser_threads_and_line_endings(tmp_path, hip_lib, monkeypatch):
     empty.write_text("")
     off, ids, cnts = parse_text(str(empty))
     assert list(off) == [0] and len(ids) == 0 and len(cnts) == 0
+
+
+def test_bounded_windows_lazy_batches_and_the_python_form(fixture, tmp_path, monkeypatch):
+    """The file is read in bounded windows cut at line ends (a corpus larger than memory must
+    stream, as it does in the reference): the same batches for any window size, nothing read
+    before the first next(); a batch indexes, iterates and compares like the reference's list of
+    lists of tuples while keeping its CSR arrays; without the built library the text still loads
+    (the reference's own Python steps)."""
+    from trlda_amd import _ffi
+    from trlda_amd.documents import DocumentList, as_csr
+    from trlda_amd.utils import load_documents, load_documents_csr
+    f, path = fixture
+    whole = load_documents(path)
+    assert isinstance(whole, DocumentList) and len(whole) == len(list(whole))
+    for chunk in (64, 1000, 1 << 16):
+        got = list(load_documents(path, 7, chunk_bytes=chunk))
+        want = list(load_documents(path, 7))
+        assert len(got) == len(want) and all(a == b for a, b in zip(got, want)), chunk
+        assert load_documents(path, chunk_bytes=chunk) == whole
+        a, b = load_documents_csr(path, chunk_bytes=chunk), as_csr(whole)
+        assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.ids, b.ids)
+    # list behaviour of a batch
+    batch = next(load_documents(path, 5))
+    assert batch._lists is None and as_csr(batch) is batch.csr          # no tuple built so far
+    first = batch[0]
+    assert isinstance(first, list) and (not first or isinstance(first[0], tuple))
+    assert batch == list(batch) and list(batch) == batch and not (batch != list(batch))
+    assert batch[1:3] == list(batch)[1:3] and batch[-1] == list(batch)[-1]
+    assert repr(batch) == repr(list(batch)) and batch + [[]] == list(batch) + [[]]
+    # lazy: a missing file raises at the first next(), as the reference's generator does
+    gen = load_documents(str(tmp_path / "missing.dat"), 5)
+    with pytest.raises(IOError):
+        next(gen)
+    # no library: the Python form gives the same documents
+    def missing():
+        raise RuntimeError("libtrlda_hip.so not built")
+    monkeypatch.setattr(_ffi, "lib", missing)
+    assert load_documents(path, chunk_bytes=1000) == whole
 
 
 def test_malformed_corpus_raises_like_the_reference(tmp_path, hip_lib):

@@ -5,7 +5,7 @@
 jws="$1"; shift
 cp trlda_amd/libtrlda_hip.so /tmp/libtrlda_hip.orig.so
 for jw in $jws; do
-  (cd trlda_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -pthread -munsafe-fp-atomics -DTRLDA_WIDE_JW=$jw -o ../libtrlda_hip.so trlda_hip.hip) || exit 1
+  (cd trlda_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -pthread -munsafe-fp-atomics -DTRLDA_WIDE_JW=$jw -o ../libtrlda_hip.so trlda_hip.hip host_common.cpp host_rng.cpp text_docs.cpp eb_steps.cpp) || exit 1
   echo "JW=$jw: $(tools/benchline.sh "$@")"
 done
 cp /tmp/libtrlda_hip.orig.so trlda_amd/libtrlda_hip.so

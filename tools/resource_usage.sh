@@ -3,7 +3,7 @@
 # of the kernels whose mangled names match $1 (default: the document kernels)
 cd "$(dirname "$0")/../trlda_amd/csrc" || exit 1
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -pthread -munsafe-fp-atomics -Wall \
-    -Rpass-analysis=kernel-resource-usage -o ../libtrlda_hip.so trlda_hip.hip 2> /tmp/trlda_res.txt || { grep -v "remark:" /tmp/trlda_res.txt | head -40; exit 1; }
+    -Rpass-analysis=kernel-resource-usage -o ../libtrlda_hip.so trlda_hip.hip host_common.cpp host_rng.cpp text_docs.cpp eb_steps.cpp 2> /tmp/trlda_res.txt || { grep -v "remark:" /tmp/trlda_res.txt | head -40; exit 1; }
 grep -v "remark:" /tmp/trlda_res.txt | grep -i "warning\|error" | head
 python3 - "${1:-estep_docs}" <<'PY'
 import re, sys

@@ -37,6 +37,7 @@ _SIGNATURES = {
     "trlda_tr_init": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, i32p,
                                 i32p, i32p, f64p, f64p, C.c_int]),
     "trlda_docs_from_text": (C.c_int, [C.c_char_p, C.POINTER(vp)]),
+    "trlda_docs_from_buffer": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(vp)]),
     "trlda_docs_num_docs": (C.c_int64, [vp]),
     "trlda_docs_nnz": (C.c_int64, [vp]),
     "trlda_docs_offsets": (C.POINTER(C.c_int64), [vp]),
@@ -119,6 +120,17 @@ _SIGNATURES = {
     "trlda_model_allreduce": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "trlda_model_estep_resident_shard": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double]),
     "trlda_model_eb_lambda_stats": (C.c_int, [vp, C.POINTER(C.c_double), f64p]),
+    "trlda_eb_online_alpha_step": (C.c_int, [C.c_int, f64p, f64p, C.c_double, C.c_double, C.c_double,
+                                             f64p]),
+    "trlda_eb_online_eta_step": (C.c_double, [C.c_double, C.c_double, f64p, C.c_int, C.c_int, C.c_double,
+                                              C.c_double]),
+    "trlda_eb_alpha_line_search": (C.c_int, [C.c_int, f64p, f64p, C.c_double, C.c_int, C.c_double,
+                                             C.c_double, f64p]),
+    "trlda_eb_eta_line_search": (C.c_double, [C.c_double, C.c_double, f64p, C.c_int, C.c_int, C.c_int,
+                                              C.c_double, C.c_double]),
+    "trlda_model_online_eb": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
+                                        C.c_double, C.c_double, f64p, C.POINTER(C.c_double)]),
+    "trlda_debug_host_psi": (None, [C.c_int, f64p, f64p, f64p]),
     "trlda_model_adaptive_stats": (C.c_int, [vp, C.c_double, C.c_double, C.c_double,
                                             C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "trlda_model_adaptive_stats_dev": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, C.c_double,

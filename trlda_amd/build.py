@@ -2,6 +2,7 @@
 
     python -m trlda_amd.build            # build if stale
     python -m trlda_amd.build --force
+    python -m trlda_amd.build --sanitize address|thread   # host-only code under ASan+UBSan / TSan
 """
 import os
 import shutil
@@ -11,8 +12,11 @@ import sys
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_PKG, "csrc")
 LIB_PATH = os.path.join(_PKG, "libtrlda_hip.so")
-SOURCES = ["trlda_hip.hip"]
-HEADERS = ["estep_kernels.h", "estep_wide.h", "elbo_kernels.h", "stream_kernels.h", "eb_kernels.h", "rng_kernels.h", "dp_kernels.h", "psi.h", os.path.join("..", "..", "include", "trlda_hip.h")]
+# the HIP translation unit (kernels, launch sequences, the C ABI over them) and the host-only
+# ones (no HIP: they also build with a plain C++ compiler under the sanitizers, `--sanitize`)
+SOURCES = ["trlda_hip.hip", "host_common.cpp", "host_rng.cpp", "text_docs.cpp", "eb_steps.cpp"]
+HOST_SOURCES = SOURCES[1:]
+HEADERS = ["host_common.h", "estep_kernels.h", "estep_wide.h", "elbo_kernels.h", "stream_kernels.h", "eb_kernels.h", "rng_kernels.h", "dp_kernels.h", "psi.h", os.path.join("..", "..", "include", "trlda_hip.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
                "-munsafe-fp-atomics", "-Wall"]
 
@@ -66,5 +70,32 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def build_sanitized(kind="address", verbose=False):
+    """The host-only translation units + tests/native/host_sanitize_main.cpp as ONE executable under
+    a sanitizer (plain g++: no HIP in these files): `address` = ASan + UBSan, `thread` = TSan.
+    GPU sanitizers are not available on this pool; this is the host side -- threads, mmap
+    parsing, the jump-ahead cache, the K-sized numerics.  Returns the executable's path."""
+    flags = {"address": ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"],
+             "thread": ["-fsanitize=thread"]}[kind]
+    cxx = os.environ.get("CXX") or shutil.which("g++") or shutil.which("c++")
+    if not cxx:
+        raise RuntimeError("no C++ compiler for the sanitizer build")
+    out_dir = os.path.join(os.path.dirname(_PKG), "build")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "host_sanitize_" + kind)
+    driver = os.path.join(os.path.dirname(_PKG), "tests", "native", "host_sanitize_main.cpp")
+    cmd = [cxx, "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-pthread", "-Wall"] + flags + \
+        ["-o", out, driver] + [os.path.join(_CSRC, f) for f in HOST_SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return out
+
+
 if __name__ == "__main__":
+    if "--sanitize" in sys.argv:
+        kind = sys.argv[sys.argv.index("--sanitize") + 1] if len(sys.argv) > sys.argv.index("--sanitize") + 1 \
+            else "address"
+        exe = build_sanitized(kind, verbose=True)
+        sys.exit(subprocess.run([exe] + (["threads"] if kind == "thread" else [])).returncode)
     print(build(force="--force" in sys.argv, verbose=True))

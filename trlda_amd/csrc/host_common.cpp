@@ -1,0 +1,115 @@
+// host_common.cpp -- error message and host thread pool of libtrlda_hip.so (host only; see
+// host_common.h).
+#include "host_common.h"
+
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <unistd.h>
+
+#include "../../include/trlda_hip.h"
+
+namespace trlda_host {
+
+namespace {
+thread_local std::string g_error;
+}
+
+int fail(int code, const std::string &msg)
+{
+    g_error = msg;
+    return code;
+}
+
+// A few persistent host threads for the gamma draw and the text parser: starting 20 threads
+// costs ~0.3 ms, as much as a draw itself.  One caller at a time (the Python surface holds the
+// GIL across the call, as the reference does; other callers queue on run_mu_).
+struct HostPool::Impl {
+    ~Impl()
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_)
+            t.join();
+    }
+    void run(int n, const std::function<void(int)> &job)
+    {
+        std::lock_guard<std::mutex> serial(run_mu_);
+        if (n <= 1) {
+            job(0);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            while ((int)workers_.size() < n - 1) {
+                const int id = (int)workers_.size() + 1;
+                workers_.emplace_back([this, id] { loop(id); });
+            }
+            job_ = &job;
+            active_ = n;
+            pending_ = n - 1;
+            ++generation_;
+        }
+        cv_.notify_all();
+        job(0);
+        std::unique_lock<std::mutex> lock(mu_);
+        done_.wait(lock, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+    void loop(int id)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int)> *job = nullptr;
+            {
+                std::unique_lock<std::mutex> lock(mu_);
+                cv_.wait(lock, [&] { return stop_ || generation_ != seen; });
+                if (stop_)
+                    return;
+                seen = generation_;
+                if (id < active_)
+                    job = job_;
+            }
+            if (job) {
+                (*job)(id);
+                std::lock_guard<std::mutex> lock(mu_);
+                if (--pending_ == 0)
+                    done_.notify_one();
+            }
+        }
+    }
+    std::mutex mu_, run_mu_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> workers_;
+    const std::function<void(int)> *job_ = nullptr;
+    uint64_t generation_ = 0;
+    int active_ = 0, pending_ = 0;
+    bool stop_ = false;
+};
+
+HostPool::HostPool() : impl_(new Impl()) {}
+HostPool::~HostPool() { delete impl_; }
+void HostPool::run(int n, const std::function<void(int)> &job) { impl_->run(n, job); }
+
+HostPool &host_pool()
+{
+    // On the heap and never destroyed: worker threads blocked on a condition variable must not
+    // be joined from a static destructor at exit, and a child of fork() has no workers at all
+    // -- it gets a pool of its own (the parent's object is left alone).
+    static HostPool *pool = nullptr;
+    static pid_t owner = 0;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!pool || owner != getpid()) {
+        pool = new HostPool();
+        owner = getpid();
+    }
+    return *pool;
+}
+
+}  // namespace trlda_host
+
+extern "C" const char *trlda_last_error(void) { return trlda_host::g_error.c_str(); }

@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "../../include/trlda_hip.h"
+#include "host_common.h"
 #include "estep_kernels.h"
 #include "estep_wide.h"
 #include "elbo_kernels.h"
@@ -52,13 +53,7 @@ struct DevTemp {
     }
 };
 
-thread_local std::string g_error;
-
-int fail(int code, const std::string &msg)
-{
-    g_error = msg;
-    return code;
-}
+using trlda_host::fail;                  // the thread-local message behind trlda_last_error()
 
 #define HIP_TRY(expr)                                                                   \
     do {                                                                                \
@@ -1468,8 +1463,6 @@ int check_model(const trlda_model *m)
 // ===========================================================================
 extern "C" {
 
-const char *trlda_last_error(void) { return g_error.c_str(); }
-
 int trlda_version(void) { return 100; }
 
 int trlda_device_count(void)
@@ -1480,391 +1473,9 @@ int trlda_device_count(void)
     return n;
 }
 
-// ---- host RNG ---------------------------------------------------------------
-//
-// The reference draws lambda0 and every default gamma0 from libc rand() through
-// Eigen::Random (src/utils.cpp:224-231, Eigen/src/Core/MathFunctions.h:439-446).  glibc's
-// rand() is the TYPE_3 additive-feedback generator of random_r.c (x[i] = x[i-3] + x[i-31],
-// output x >> 1) behind a lock that costs ~20 ns per call -- 2*10^6 calls per default gamma0 at
-// K=100, B=200.  The same recurrence is reproduced here without the lock (the stream is
-// checked against libc's in tests/test_boundary.py), and the logarithms -- glibc's own
-// log(), so the values stay bit-identical -- are taken by a few threads over disjoint
-// elements, each element accumulating its passes in order.
 } // extern "C"
 
 namespace {
-
-struct GlibcRandom {
-    uint32_t x[31];
-    int f = 3, b = 0;
-    void seed(unsigned int s)
-    {
-        // srandom_r, TYPE_3
-        int32_t word = s == 0 ? 1 : (int32_t)s;
-        x[0] = (uint32_t)word;
-        for (int i = 1; i < 31; ++i) {
-            const long hi = word / 127773, lo = word % 127773;
-            long w = 16807 * lo - 2836 * hi;
-            if (w < 0)
-                w += 2147483647;
-            word = (int32_t)w;
-            x[i] = (uint32_t)word;
-        }
-        f = 3;
-        b = 0;
-        for (int i = 0; i < 310; ++i)
-            (void)next();
-    }
-    inline uint32_t next()
-    {
-        x[f] += x[b];
-        const uint32_t out = x[f] >> 1;
-        if (++f == 31)
-            f = 0;
-        if (++b == 31)
-            b = 0;
-        return out;
-    }
-};
-
-// ---- jump-ahead for the generator above ---------------------------------------------
-// The unshifted sequence obeys s_n = s_{n-31} + s_{n-3} (mod 2^32): the window
-// W_n = (s_{n-31} .. s_{n-1}) advances by a 31 x 31 companion matrix A over Z / 2^32, and
-// A^N (square and multiply, cached per N) jumps N draws ahead.  sampleGamma's K*B*100 draws
-// are consumed pass by pass (utils.cpp:224-231); with the jumps every host thread produces
-// the draws of its own element range for all passes -- the same numbers in the same order of
-// additions as one serial stream, so seeded trajectories stay bit-identical.
-struct JumpMatrix {
-    uint32_t a[31][31];
-};
-
-void jump_identity(JumpMatrix &m)
-{
-    std::memset(m.a, 0, sizeof(m.a));
-    for (int i = 0; i < 31; ++i)
-        m.a[i][i] = 1;
-}
-
-void jump_multiply(const JumpMatrix &x, const JumpMatrix &y, JumpMatrix &out)
-{
-    for (int i = 0; i < 31; ++i) {
-        uint32_t row[31] = {0};
-        for (int k = 0; k < 31; ++k) {
-            const uint32_t xik = x.a[i][k];
-            if (xik == 0)
-                continue;
-            for (int j = 0; j < 31; ++j)
-                row[j] += xik * y.a[k][j];
-        }
-        std::memcpy(out.a[i], row, sizeof(row));
-    }
-}
-
-// Returned BY VALUE (3.8 kB): the cache below evicts, and a caller holds several powers at once
-// and hands them to worker threads -- a reference into the map would dangle after an eviction.
-// `half`: A^(n/2) when the caller has it (n even): one squaring instead of the whole ladder.
-JumpMatrix jump_power(uint64_t n, const JumpMatrix *half = nullptr)
-{
-    static std::mutex mu;
-    static std::map<uint64_t, JumpMatrix> cache;
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = cache.find(n);
-    if (it != cache.end())
-        return it->second;
-    JumpMatrix base, result, tmp;
-    if (half && n % 2 == 0) {
-        jump_multiply(*half, *half, result);
-        if (cache.size() > 2048)
-            cache.clear();
-        cache.emplace(n, result);
-        return result;
-    }
-    std::memset(base.a, 0, sizeof(base.a));
-    for (int i = 0; i < 30; ++i)
-        base.a[i][i + 1] = 1;                        // shift
-    base.a[30][0] = 1;                               // s_n = s_{n-31} + s_{n-3}
-    base.a[30][28] = 1;
-    jump_identity(result);
-    for (uint64_t e = n; e; e >>= 1) {
-        if (e & 1) {
-            jump_multiply(result, base, tmp);
-            result = tmp;
-        }
-        jump_multiply(base, base, tmp);
-        base = tmp;
-    }
-    if (cache.size() > 2048)                         // 8 MB
-        cache.clear();
-    cache.emplace(n, result);
-    return result;
-}
-
-// window (oldest first) <-> the circular buffer of GlibcRandom
-void rng_to_window(const GlibcRandom &g, uint32_t (&w)[31])
-{
-    for (int j = 0; j < 31; ++j)
-        w[j] = g.x[(g.f + j) % 31];
-}
-void window_to_rng(const uint32_t (&w)[31], GlibcRandom &g)
-{
-    g.f = 3;
-    g.b = 0;
-    for (int j = 0; j < 31; ++j)
-        g.x[(3 + j) % 31] = w[j];
-}
-void jump_apply(const JumpMatrix &m, uint32_t (&w)[31])
-{
-    uint32_t out[31];
-    for (int i = 0; i < 31; ++i) {
-        uint32_t acc = 0;
-        for (int j = 0; j < 31; ++j)
-            acc += m.a[i][j] * w[j];
-        out[i] = acc;
-    }
-    std::memcpy(w, out, sizeof(out));
-}
-
-GlibcRandom g_rng;
-
-// A few persistent host threads for the gamma draw: starting 20 threads costs ~0.3 ms, as
-// much as the draw itself.  run(n, job) executes job(0) on the caller and job(1..n-1) on the
-// workers and returns when all are done.  One caller at a time (the Python surface holds the
-// GIL across the call, as the reference does).
-class HostPool {
-public:
-    ~HostPool()
-    {
-        {
-            std::lock_guard<std::mutex> lock(mu_);
-            stop_ = true;
-        }
-        cv_.notify_all();
-        for (auto &t : workers_)
-            t.join();
-    }
-    void run(int n, const std::function<void(int)> &job)
-    {
-        std::lock_guard<std::mutex> serial(run_mu_);
-        if (n <= 1) {
-            job(0);
-            return;
-        }
-        {
-            std::lock_guard<std::mutex> lock(mu_);
-            while ((int)workers_.size() < n - 1) {
-                const int id = (int)workers_.size() + 1;
-                workers_.emplace_back([this, id] { loop(id); });
-            }
-            job_ = &job;
-            active_ = n;
-            pending_ = n - 1;
-            ++generation_;
-        }
-        cv_.notify_all();
-        job(0);
-        std::unique_lock<std::mutex> lock(mu_);
-        done_.wait(lock, [this] { return pending_ == 0; });
-        job_ = nullptr;
-    }
-
-private:
-    void loop(int id)
-    {
-        uint64_t seen = 0;
-        for (;;) {
-            const std::function<void(int)> *job = nullptr;
-            {
-                std::unique_lock<std::mutex> lock(mu_);
-                cv_.wait(lock, [&] { return stop_ || generation_ != seen; });
-                if (stop_)
-                    return;
-                seen = generation_;
-                if (id < active_)
-                    job = job_;
-            }
-            if (job) {
-                (*job)(id);
-                std::lock_guard<std::mutex> lock(mu_);
-                if (--pending_ == 0)
-                    done_.notify_one();
-            }
-        }
-    }
-    std::mutex mu_, run_mu_;
-    std::condition_variable cv_, done_;
-    std::vector<std::thread> workers_;
-    const std::function<void(int)> *job_ = nullptr;
-    uint64_t generation_ = 0;
-    int active_ = 0, pending_ = 0;
-    bool stop_ = false;
-};
-
-HostPool &host_pool()
-{
-    // On the heap and never destroyed: worker threads blocked on a condition variable must not
-    // be joined from a static destructor at exit, and a child of fork() has no workers at all
-    // -- it gets a pool of its own (the parent's object is left alone).
-    static HostPool *pool = nullptr;
-    static pid_t owner = 0;
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!pool || owner != getpid()) {
-        pool = new HostPool();
-        owner = getpid();
-    }
-    return *pool;
-}
-
-struct RngInit {
-    RngInit()
-    {
-        // module import seeds with the clock (python/src/module.cpp:356-359)
-        timespec t;
-        clock_gettime(CLOCK_REALTIME, &t);
-        const unsigned int s = (unsigned int)((t.tv_nsec / 1000) * t.tv_sec);
-        srand(s);
-        g_rng.seed(s);
-    }
-} g_rng_init;
-
-}  // namespace
-
-extern "C" {
-
-void trlda_seed(unsigned int seed)
-{
-    srand(seed);          // keep libc's own stream in step for anything else that uses it
-    g_rng.seed(seed);
-}
-
-// the generator's whole state: 31 words, then the two indices
-void trlda_rng_get_state(uint32_t *state33)
-{
-    std::memcpy(state33, g_rng.x, sizeof(g_rng.x));
-    state33[31] = (uint32_t)g_rng.f;
-    state33[32] = (uint32_t)g_rng.b;
-}
-
-void trlda_rng_set_state(const uint32_t *state33)
-{
-    std::memcpy(g_rng.x, state33, sizeof(g_rng.x));
-    g_rng.f = (int)(state33[31] % 31u);
-    g_rng.b = (int)(state33[32] % 31u);
-}
-
-void trlda_sample_gamma(int m, int n, int k, double *out)
-{
-    const int64_t total = (int64_t)m * n;
-    for (int64_t i = 0; i < total; ++i)
-        out[i] = 0.0;
-    if (total <= 0 || k <= 0)
-        return;
-    // out[i] = - sum_{p < k} log |u_{p, i}|, u_{p, i} the (p * total + i)-th draw of the stream
-    // (utils.cpp:224-231).  Small requests: one thread, straight through the stream.
-    unsigned int hw = std::thread::hardware_concurrency();
-    // (the threads are persistent, host_pool(): their number is bounded by the work per thread)
-    // (more than 64 threads were measured on the 256-hardware-thread GPU box and lost: 1.0 ms
-    // against 0.8 ms for K x B = 100 x 200, 100 against 56 ms for 500 x 4096)
-    int64_t T = std::max<int64_t>(1, std::min<int64_t>({(int64_t)hw, (int64_t)64, total / 256}));
-    if (total * k < (1 << 17))
-        T = 1;
-    if (const char *env = std::getenv("TRLDA_SAMPLE_THREADS"))   // tests: force a thread count
-        T = std::max<int64_t>(1, std::min<int64_t>(std::atoi(env), total));
-    if (T == 1) {
-        for (int p = 0; p < k; ++p)
-            for (int64_t i = 0; i < total; ++i) {
-                const double u = -1.0 + 2.0 * (double)g_rng.next() / (double)2147483647;
-                out[i] -= std::log(std::fabs(u));
-            }
-        return;
-    }
-    // Thread t owns the elements [t * len, min(total, (t + 1) * len)) in every pass: it starts
-    // lo_t draws into the stream and, after the draws of a pass, jumps over the other threads'
-    // share (total - its own length) to the next pass.  Per element the logs are added in pass
-    // order, exactly as the serial loop does.
-    const int64_t len = (total + T - 1) / T;
-    T = (total + len - 1) / len;
-    const int64_t last_len = total - (T - 1) * len;
-    const JumpMatrix hop = jump_power((uint64_t)len);                      // thread t -> t + 1
-    const JumpMatrix skip = jump_power((uint64_t)(total - len));           // pass p -> p + 1
-    const JumpMatrix skip_last = jump_power((uint64_t)(total - last_len));
-    // thread t starts hop^t into the stream: every thread applies the powers hop^(2^b) of the
-    // set bits of t itself (a handful of 31 x 31 products) instead of the caller walking all T
-    std::vector<JumpMatrix> hop_pow;
-    for (int64_t span = 1; span < T; span <<= 1)
-        hop_pow.push_back(span == 1 ? hop
-                                    : jump_power((uint64_t)len * (uint64_t)span, &hop_pow.back()));
-    uint32_t w0[31];
-    rng_to_window(g_rng, w0);
-    GlibcRandom final_state;
-    auto work = [&](int64_t t) {
-        GlibcRandom g;
-        {
-            uint32_t w[31];
-            std::memcpy(w, w0, sizeof(w));
-            for (size_t b = 0; b < hop_pow.size(); ++b)
-                if ((t >> b) & 1)
-                    jump_apply(hop_pow[b], w);
-            window_to_rng(w, g);
-        }
-        const int64_t lo = t * len, hi = std::min<int64_t>(total, lo + len);
-        const JumpMatrix &sk = (t == T - 1) ? skip_last : skip;
-        for (int p = 0; p < k; ++p) {
-            for (int64_t i = lo; i < hi; ++i) {
-                const double u = -1.0 + 2.0 * (double)g.next() / (double)2147483647;
-                out[i] -= std::log(std::fabs(u));
-            }
-            if (p + 1 < k || t == T - 1) {
-                if (p + 1 == k)
-                    break;                           // the last thread ends where the stream ends
-                uint32_t w[31];
-                rng_to_window(g, w);
-                jump_apply(sk, w);
-                window_to_rng(w, g);
-            }
-        }
-        if (t == T - 1)
-            final_state = g;
-    };
-    host_pool().run((int)T, [&](int t) { work(t); });
-    g_rng = final_state;
-}
-
-void trlda_sample_gamma_init(int m, int n, double *out)
-{
-    trlda_sample_gamma(m, n, 100, out);
-    const int64_t total = (int64_t)m * n;
-    for (int64_t i = 0; i < total; ++i)
-        out[i] /= 100.;
-}
-
-} // extern "C"
-
-namespace {
-
-// M[l][d - 1] = A^(d 16^l L), l < kRngLevels, d = 1 .. 15 (31 x 31 words each), computed once
-// per segment length L
-const std::vector<uint32_t> &rng_level_matrices(int L)
-{
-    static std::mutex mu;
-    static std::map<int, std::vector<uint32_t>> all;
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = all.find(L);
-    if (it != all.end())
-        return it->second;
-    std::vector<uint32_t> mats((size_t)trlda::kRngLevels * 15 * 961);
-    JumpMatrix one = jump_power((uint64_t)L), cur, tmp;
-    for (int l = 0; l < trlda::kRngLevels; ++l) {
-        cur = one;
-        for (int d = 1; d <= 15; ++d) {
-            std::memcpy(mats.data() + ((size_t)l * 15 + (d - 1)) * 961, cur.a, sizeof(cur.a));
-            jump_multiply(cur, one, tmp);            // A^((d + 1) 16^l L)
-            cur = tmp;
-        }
-        one = cur;                                   // A^(16^(l + 1) L)
-    }
-    return all.emplace(L, std::move(mats)).first->second;
-}
 
 using trlda::RngSeedWindow;
 
@@ -1885,7 +1496,7 @@ int rng_device_matrices(int device, int L, const uint32_t **out)
     if (it == all.end()) {
         // row-major for window_level_kernel, then the transposes for window_direct_kernel (its 31
         // lanes of a window read one column entry each: consecutive words)
-        std::vector<uint32_t> h = rng_level_matrices(L);
+        std::vector<uint32_t> h = trlda_host::rng_level_matrices(L, trlda::kRngLevels);
         const size_t n = h.size();
         h.resize(2 * n);
         for (size_t mtx = 0; mtx < n / 961; ++mtx)
@@ -1927,7 +1538,7 @@ int sample_gamma_on_device(trlda_model *m, long long total, int passes, double d
     if (rc)
         return rc;
     RngSeedWindow w0;
-    rng_to_window(g_rng, w0.w);
+    trlda_host::rng_current_window(w0.w);
     long long unit = 1;
     int levels = 0;
     while (levels < trlda::kRngLevels && unit < S) {
@@ -1986,10 +1597,7 @@ int sample_gamma_on_device(trlda_model *m, long long total, int passes, double d
     }
     HIP_TRY(hipGetLastError());
     // the host stream moves on by the same number of draws
-    uint32_t w[31];
-    rng_to_window(g_rng, w);
-    jump_apply(jump_power((uint64_t)draws), w);
-    window_to_rng(w, g_rng);
+    trlda_host::rng_advance((uint64_t)draws);
     return TRLDA_OK;
 }
 
@@ -3717,6 +3325,103 @@ int trlda_model_eb_lambda_stats(trlda_model *m, double *sum_psi_lambda, double *
     return TRLDA_OK;
 }
 
+// The empirical-Bayes steps of OnlineLDA::updateParameters (src/onlinelda.cpp:116-162) with ONE
+// trip to the host: the device sums over gamma (and over the ranks, when a communicator is
+// given) and over lambda are enqueued, K + G + K doubles come back in one synchronisation, the
+// K-sized Newton steps run here (eb_steps.cpp), the new alpha goes back to the device.
+int trlda_model_online_eb(trlda_model *m, void *rccl_comm, int B_local, int B_total, double rho,
+                          int update_alpha, int update_eta, double min_alpha, double min_eta,
+                          double *alpha_host, double *eta)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (B_local < 0 || B_total <= 0 || !alpha_host || !eta)
+        return fail(TRLDA_ERR_ARG, "bad online_eb arguments");
+    if (!update_alpha && !update_eta)
+        return TRLDA_OK;
+    const int K = m->K;
+    const size_t KV = (size_t)K * m->V;
+    constexpr int T = 256;
+    const int chunks = (std::max(B_local, 1) + trlda::kEbDocsPerBlock - 1) / trlda::kEbDocsPerBlock;
+    const int G = (int)std::max<size_t>(1, std::min<size_t>((KV + 4 * T - 1) / (4 * T), 2048));
+    // reduce_out: [gamma chunks | gamma sum (K)] [lambda blocks (G)]
+    const size_t off_sum = (size_t)chunks * K, off_lam = off_sum + (size_t)K;
+    rc = grow(&m->reduce_out, &m->cap_reduce, off_lam + (size_t)G);
+    if (rc)
+        return rc;
+    std::vector<double> host((size_t)K + (size_t)G + (size_t)K);
+    if (update_alpha) {
+        double *sum = m->reduce_out + off_sum;
+        if (B_local > 0) {
+            if ((size_t)B_local * K > m->cap_gamma || !m->gamma)
+                return fail(TRLDA_ERR_ARG, "no gamma of that size is resident in the model");
+            const size_t lds = ((size_t)K + T / trlda::kWave + 1) * sizeof(double);
+            auto kern = trlda::eb_gamma_kernel<T>;
+            if ((rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)))
+                return rc;
+            hipLaunchKernelGGL(kern, dim3(chunks), dim3(T), lds, m->stream, K, B_local, m->gamma,
+                               m->reduce_out);
+            HIP_TRY(hipGetLastError());
+            rc = combine_rowsums(m, m->reduce_out, chunks, nullptr, sum);
+        } else {
+            HIP_TRY(hipMemsetAsync(sum, 0, (size_t)K * sizeof(double), m->stream));
+        }
+        if (!rc && rccl_comm)
+            rc = allreduce_f64(m, rccl_comm, sum, (size_t)K);        // onlinelda.cpp:128 across ranks
+        if (rc)
+            return rc;
+        HIP_TRY(hipMemcpyAsync(host.data(), sum, (size_t)K * sizeof(double), hipMemcpyDeviceToHost,
+                               m->stream));
+        m->d2h_bytes += (int64_t)K * sizeof(double);
+    }
+    if (update_eta) {
+        hipLaunchKernelGGL(trlda::eb_lambda_kernel<T>, dim3(G), dim3(T), 0, m->stream, KV, m->lambda,
+                           m->reduce_out + off_lam);
+        HIP_TRY(hipGetLastError());
+        if (rowsums_carried(m)) {
+            rc = resolve_carry(m);
+        } else if (stream_available(m)) {
+            rc = rowsums_from_scratch(m);
+            if (!rc && !m->lambda_exposed)
+                m->rs_valid = true;
+        } else {
+            int GR = std::min(kMaxRowsumBlocks - 1, std::max(1, m->V / 32));
+            const int wpb = (m->V + GR - 1) / GR;
+            GR = (m->V + wpb - 1) / wpb;
+            hipLaunchKernelGGL(trlda::rowsum_partial_kernel<kDenseThreads>, dim3(GR), dim3(kDenseThreads), 0,
+                               m->stream, K, m->V, wpb, m->lambda, m->partial);
+            HIP_TRY(hipGetLastError());
+            rc = combine_rowsums(m, m->partial, GR, nullptr, m->rs_full);
+        }
+        if (rc)
+            return rc;
+        HIP_TRY(hipMemcpyAsync(host.data() + K, m->reduce_out + off_lam, (size_t)G * sizeof(double),
+                               hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipMemcpyAsync(host.data() + K + G, m->rs_full, (size_t)K * sizeof(double),
+                               hipMemcpyDeviceToHost, m->stream));
+        m->d2h_bytes += (int64_t)((size_t)G + K) * sizeof(double);
+    }
+    HIP_TRY(hipStreamSynchronize(m->stream));                        // the one trip
+    if (update_alpha) {
+        std::vector<double> next((size_t)K);
+        rc = trlda_eb_online_alpha_step(K, alpha_host, host.data(), (double)B_total, rho, min_alpha,
+                                        next.data());
+        if (rc)
+            return rc;
+        std::memcpy(alpha_host, next.data(), (size_t)K * sizeof(double));
+        HIP_TRY(hipMemcpyAsync(m->alpha, alpha_host, (size_t)K * sizeof(double), hipMemcpyHostToDevice,
+                               m->stream));
+    }
+    if (update_eta) {
+        double total = 0.0;
+        for (int g = 0; g < G; ++g)
+            total += host[(size_t)K + (size_t)g];
+        *eta = trlda_eb_online_eta_step(*eta, total, host.data() + K + G, K, m->V, rho, min_eta);
+    }
+    return TRLDA_OK;
+}
+
 int trlda_model_adaptive_stats(trlda_model *m, double eta, double scale, double tau,
                                double *sq_norm_update, double *sq_norm_gradient)
 {
@@ -3900,220 +3605,8 @@ int trlda_debug_fold16(int device, const double *in, double *out16, double *out4
     return TRLDA_OK;
 }
 
-// ---- text corpora -----------------------------------------------------------------
-//
-// The reference's corpus format (python/utils/load_documents.py:6-69): one document per line,
-// "<n> id:cnt id:cnt ..."; the loader does `for word in line.split()[1:]: wid, wct =
-// word.split(':')` and int() on both.  Here the file is mapped, cut into pieces at line ends
-// and parsed by the host threads straight into CSR.  Anything but [+-]digits:[+-]digits tokens
-// (or values outside int32) is reported with its line number; the Python mirror then re-reads
-// the file the slow way and raises what the reference would.
-} // extern "C"
-
-struct trlda_docs {
-    std::vector<int64_t> offsets;     // num_docs + 1
-    std::vector<int32_t> ids, cnts;
-};
-
-namespace {
-
-struct TextPiece {
-    // raw buffers sized for the worst case (a token "1:1 " is four bytes, a line one): filled
-    // through pointers, no per-token capacity checks
-    std::unique_ptr<int32_t[]> lens, ids, cnts;
-    size_t n_docs = 0, n_nz = 0;
-    int64_t bad_line = -1;            // line (within the piece) of the first malformed token
-    int64_t lines = 0;
-};
-
-// one [+-]digits run; returns false if malformed or outside int32
-inline bool parse_int(const char *&p, const char *end, int32_t *out)
-{
-    const char *q = p;
-    bool neg = false;
-    if (q < end && (*q == '+' || *q == '-')) {
-        neg = *q == '-';
-        ++q;
-    }
-    const char *d0 = q;
-    uint64_t v = 0;
-    while (q < end) {
-        const unsigned c = (unsigned)(*q - '0');
-        if (c > 9)
-            break;
-        v = v * 10 + c;
-        ++q;
-    }
-    const long nd = q - d0;
-    if (nd == 0 || nd > 10 || v > (uint64_t)INT32_MAX + (neg ? 1 : 0))
-        return false;
-    *out = neg ? (int32_t)(-(int64_t)v) : (int32_t)v;
-    p = q;
-    return true;
-}
-
-// lines of [p, end); the last one may lack its newline
-void parse_piece(const char *p, const char *end, TextPiece &out)
-{
-    const size_t bytes = (size_t)(end - p);
-    out.ids.reset(new int32_t[bytes / 4 + 2]);
-    out.cnts.reset(new int32_t[bytes / 4 + 2]);
-    out.lens.reset(new int32_t[bytes + 2]);
-    int32_t *ids = out.ids.get(), *cnts = out.cnts.get(), *lens = out.lens.get();
-    size_t nz = 0, nd = 0;
-    while (p < end) {
-        // the first token of the line (line.split()[0]): skipped whatever it is
-        while (p < end && *p != '\n' && (*p == ' ' || (*p >= '\t' && *p <= '\r')))
-            ++p;
-        while (p < end && !(*p == ' ' || (*p >= '\t' && *p <= '\r')))
-            ++p;
-        const size_t nz0 = nz;
-        for (;;) {
-            while (p < end && *p != '\n' && (*p == ' ' || (*p >= '\t' && *p <= '\r')))
-                ++p;
-            if (p >= end || *p == '\n')
-                break;
-            int32_t a, b;
-            if (!parse_int(p, end, &a) || p >= end || *p != ':' || (++p, !parse_int(p, end, &b)) ||
-                (p < end && !(*p == ' ' || (*p >= '\t' && *p <= '\r')))) {
-                out.bad_line = (int64_t)nd;
-                out.n_docs = nd;
-                out.n_nz = nz0;
-                out.lines = (int64_t)nd;
-                return;
-            }
-            ids[nz] = a;
-            cnts[nz] = b;
-            ++nz;
-        }
-        lens[nd++] = (int32_t)(nz - nz0);
-        if (p < end)
-            ++p;                                     // the newline
-    }
-    out.n_docs = nd;
-    out.n_nz = nz;
-    out.lines = (int64_t)nd;
-}
-
-}  // namespace
-
-extern "C" {
-
-int trlda_docs_from_text(const char *path, trlda_docs **out)
-{
-    if (!path || !out)
-        return fail(TRLDA_ERR_ARG, "path / out is NULL");
-    *out = nullptr;
-    const int fd = open(path, O_RDONLY);
-    if (fd < 0)
-        return fail(TRLDA_ERR_ARG, std::string("cannot open ") + path);
-    struct stat st;
-    if (fstat(fd, &st) != 0) {
-        close(fd);
-        return fail(TRLDA_ERR_ARG, std::string("cannot stat ") + path);
-    }
-    const size_t size = (size_t)st.st_size;
-    trlda_docs *docs = new trlda_docs();
-    docs->offsets.push_back(0);
-    if (size == 0) {
-        close(fd);
-        *out = docs;
-        return TRLDA_OK;
-    }
-    void *map = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
-    close(fd);
-    if (map == MAP_FAILED) {
-        delete docs;
-        return fail(TRLDA_ERR_ARG, std::string("cannot map ") + path);
-    }
-    (void)madvise(map, size, MADV_SEQUENTIAL);
-    const char *base = static_cast<const char *>(map), *end = base + size;
-    // a lone carriage return is a line end to Python's universal newlines, not to this parser
-    bool lone_cr = false;
-    for (const char *c = base; (c = static_cast<const char *>(std::memchr(c, '\r', (size_t)(end - c)))); ++c)
-        if (c + 1 >= end || c[1] != '\n') {
-            lone_cr = true;
-            break;
-        }
-    if (lone_cr) {
-        munmap(map, size);
-        delete docs;
-        return fail(TRLDA_ERR_ARG, "carriage returns without line feeds: not parsed here");
-    }
-    // pieces of about equal size, cut after a newline
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-    int T = (int)std::max<size_t>(1, std::min<size_t>({(size_t)hw, (size_t)64, size / ((size_t)1 << 20)}));
-    if (const char *env = std::getenv("TRLDA_PARSE_THREADS"))
-        T = std::max(1, std::min(std::atoi(env), 256));
-    std::vector<const char *> cut((size_t)T + 1, end);
-    cut[0] = base;
-    for (int t = 1; t < T; ++t) {
-        const char *guess = base + size / (size_t)T * (size_t)t;
-        if (guess < cut[(size_t)t - 1])
-            guess = cut[(size_t)t - 1];
-        const char *nl = static_cast<const char *>(std::memchr(guess, '\n', (size_t)(end - guess)));
-        cut[(size_t)t] = nl ? nl + 1 : end;
-    }
-    std::vector<TextPiece> pieces((size_t)T);
-    host_pool().run(T, [&](int t) { parse_piece(cut[(size_t)t], cut[(size_t)t + 1], pieces[(size_t)t]); });
-    int64_t line0 = 0;
-    for (int t = 0; t < T; ++t) {
-        if (pieces[(size_t)t].bad_line >= 0) {
-            const int64_t line = line0 + pieces[(size_t)t].bad_line + 1;
-            munmap(map, size);
-            delete docs;
-            return fail(TRLDA_ERR_VALUE, "line " + std::to_string(line) +
-                                             ": expected tokens of the form <int>:<int>");
-        }
-        line0 += pieces[(size_t)t].lines;
-    }
-    munmap(map, size);
-    size_t ndocs = 0, nnz = 0;
-    for (auto &pc : pieces) {
-        ndocs += pc.n_docs;
-        nnz += pc.n_nz;
-    }
-    docs->offsets.resize(ndocs + 1);
-    docs->ids.resize(nnz);
-    docs->cnts.resize(nnz);
-    std::vector<size_t> doc0((size_t)T), nz0((size_t)T);
-    {
-        size_t d = 0, z = 0;
-        for (int t = 0; t < T; ++t) {
-            doc0[(size_t)t] = d;
-            nz0[(size_t)t] = z;
-            d += pieces[(size_t)t].n_docs;
-            z += pieces[(size_t)t].n_nz;
-        }
-    }
-    host_pool().run(T, [&](int t) {
-        const TextPiece &pc = pieces[(size_t)t];
-        int64_t z = (int64_t)nz0[(size_t)t];
-        for (size_t i = 0; i < pc.n_docs; ++i) {
-            docs->offsets[doc0[(size_t)t] + i] = z;
-            z += pc.lens[i];
-        }
-        if (pc.n_nz) {
-            std::memcpy(docs->ids.data() + nz0[(size_t)t], pc.ids.get(), pc.n_nz * 4);
-            std::memcpy(docs->cnts.data() + nz0[(size_t)t], pc.cnts.get(), pc.n_nz * 4);
-        }
-    });
-    docs->offsets[ndocs] = (int64_t)nnz;
-    *out = docs;
-    return TRLDA_OK;
-}
-
-int64_t trlda_docs_num_docs(const trlda_docs *d) { return d ? (int64_t)d->offsets.size() - 1 : 0; }
-int64_t trlda_docs_nnz(const trlda_docs *d) { return d ? (int64_t)d->ids.size() : 0; }
-const int64_t *trlda_docs_offsets(const trlda_docs *d) { return d ? d->offsets.data() : nullptr; }
-const int32_t *trlda_docs_ids(const trlda_docs *d) { return d ? d->ids.data() : nullptr; }
-const int32_t *trlda_docs_cnts(const trlda_docs *d) { return d ? d->cnts.data() : nullptr; }
-
-int trlda_docs_destroy(trlda_docs *d)
-{
-    delete d;
-    return TRLDA_OK;
-}
+// (the text parser lives in text_docs.cpp, the generator in host_rng.cpp, the empirical-Bayes
+// Newton steps in eb_steps.cpp: host-only translation units, also built under the sanitizers)
 
 // ---- measurement ----------------------------------------------------------------
 

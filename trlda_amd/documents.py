@@ -65,6 +65,56 @@ class CSRDocuments(object):
         return csr_to_lists(self)
 
 
+class DocumentList(object):
+    """A batch in the reference's form -- it indexes, iterates, compares and prints like the list
+    of lists of ``(word id, count)`` tuples that ``load_documents`` returns -- that keeps its CSR
+    arrays: the tuples are built (all at once, in C) only when a document is looked at, and the
+    models take the arrays as they are (``as_csr``).  What the reference's README loop needs of
+    a batch is ``update_parameters(documents)``; everything else still works."""
+
+    __slots__ = ("csr", "_lists")
+
+    def __init__(self, csr):
+        self.csr = csr
+        self._lists = None
+
+    def to_list(self):
+        if self._lists is None:
+            self._lists = csr_to_lists(self.csr)
+        return self._lists
+
+    def __len__(self):
+        return len(self.csr)
+
+    def __getitem__(self, index):
+        return self.to_list()[index]
+
+    def __iter__(self):
+        return iter(self.to_list())
+
+    def __contains__(self, doc):
+        return doc in self.to_list()
+
+    def __eq__(self, other):
+        if isinstance(other, DocumentList):
+            other = other.to_list()
+        return self.to_list() == other
+
+    def __ne__(self, other):
+        return not self == other
+
+    __hash__ = None
+
+    def __add__(self, other):
+        return self.to_list() + list(other)
+
+    def __radd__(self, other):
+        return list(other) + self.to_list()
+
+    def __repr__(self):
+        return repr(self.to_list())
+
+
 def csr_to_lists(csr):
     """CSR -> the reference's list of lists of ``(id, count)`` tuples."""
     if _fastdocs is not None:
@@ -82,7 +132,7 @@ def as_csr(docs):
     """Validate ``docs`` exactly as PyList_ToDocuments does and flatten it to CSR."""
     if isinstance(docs, CSRDocuments):
         return docs
-    if isinstance(docs, DeviceBatch):
+    if isinstance(docs, (DeviceBatch, DocumentList)):
         return docs.csr
     if not isinstance(docs, list):
         raise TypeError("Documents must be stored in a list.")

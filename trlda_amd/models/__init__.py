@@ -361,7 +361,6 @@ class OnlineLDA(LDA):
             if B == 0:
                 return 1.0                                           # onlinelda.cpp:54-56
             L = _ffi.lib()
-            K, V = self._K, self._V
             rho_arg = float(rho)
             if rho_arg < 0. and adaptive:
                 rho_arg = self._ada_rho                              # onlinelda.cpp:61-62
@@ -379,17 +378,17 @@ class OnlineLDA(LDA):
                 C.byref(count), C.byref(rho_out), None))
             rho_used = rho_out.value
 
-            if update_alpha:                                         # onlinelda.cpp:116-142
-                if not update_lambda:
+            if update_alpha or update_eta:                           # onlinelda.cpp:116-162
+                if update_alpha and not update_lambda:
                     self._resident_estep(batch, max_iter_inference)
-                alpha = _online_alpha_step(self._alpha, self._psi_gamma_diff_device(B), B,
-                                           rho_used, min_alpha)
-                _ffi.check(L.trlda_model_set_alpha(self._handle, np.ascontiguousarray(alpha)))
-                self._alpha = alpha
-
-            if update_eta:                                           # onlinelda.cpp:147-162
-                sum_psi, rowsums = self._lambda_psi_stats_device()
-                self._eta = _online_eta_step(self._eta, sum_psi, rowsums, K, V, rho_used, min_eta)
+                # the device sums over gamma and lambda, one synchronisation, the K-sized Newton
+                # steps on the host, the new alpha back on the device
+                alpha = np.ascontiguousarray(self._alpha, dtype=np.float64).copy()
+                eta = C.c_double(self._eta)
+                _ffi.check(L.trlda_model_online_eb(
+                    self._handle, None, B, B, rho_used, int(bool(update_alpha)),
+                    int(bool(update_eta)), float(min_alpha), float(min_eta), alpha, C.byref(eta)))
+                self._alpha, self._eta = alpha, float(eta.value)
 
             if update_lambda and adaptive:                           # onlinelda.cpp:167-175
                 t = self._ada_tau
@@ -420,96 +419,40 @@ class OnlineLDA(LDA):
 
 def _online_alpha_step(alpha, psi_gamma_diff, num_docs, rho, min_alpha):
     """One natural-gradient step on alpha, onlinelda.cpp:123-142; psi_gamma_diff[k] = sum over the
-    mini-batch's documents of psi(gamma_dk) - psi(sum_k gamma_dk)."""
-    from .. import _special
-    B = num_docs
-    g = psi_gamma_diff - B * (_special.digamma(alpha) - _special.digamma(alpha.sum()))
-    h = -float(B) * _special.trigamma(alpha)
-    z = B * _special.trigamma(alpha.sum())
-    c = (g / h).sum() / (1. / z + (1. / h).sum())
-    return np.maximum(alpha - rho * (g - c) / h, min_alpha)
+    mini-batch's documents of psi(gamma_dk) - psi(sum_k gamma_dk).  K-sized host arithmetic in
+    the library (csrc/eb_steps.cpp)."""
+    alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+    out = np.empty_like(alpha)
+    _ffi.check(_ffi.lib().trlda_eb_online_alpha_step(
+        alpha.size, alpha, np.ascontiguousarray(psi_gamma_diff, dtype=np.float64), float(num_docs),
+        float(rho), float(min_alpha), out))
+    return out
 
 
 def _online_eta_step(eta, sum_psi_lambda, rowsums, K, V, rho, min_eta):
-    """One Newton step on eta, onlinelda.cpp:147-162."""
-    from .. import _special
-    g = sum_psi_lambda - V * _special.digamma(rowsums).sum() \
-        - K * V * (_special.digamma(eta) - _special.digamma(V * eta))
-    h = K * V * (_special.trigamma(V * eta) - _special.trigamma(eta))
-    return max(float(eta - rho * g / h), min_eta)
+    """One Newton step on eta, onlinelda.cpp:147-162 (csrc/eb_steps.cpp)."""
+    return float(_ffi.lib().trlda_eb_online_eta_step(
+        float(eta), float(sum_psi_lambda), np.ascontiguousarray(rowsums, dtype=np.float64), int(K),
+        int(V), float(rho), float(min_eta)))
 
 
 def _eta_line_search(eta, sum_psi_lambda, rowsums, K, V, max_iter_eta, min_eta, threshold):
     """Newton steps on eta with a step-halving line search on the lower bound,
-    batchlda.cpp:147-205."""
-    from .. import _special
-    c = sum_psi_lambda - V * _special.digamma(rowsums).sum()
-
-    def bound(e):
-        return (e - 1) * c + K * float(_lngamma(V * e)) - K * V * float(_lngamma(e))
-    Lb = bound(eta)
-    Lprime = Lb
-    for _i in range(int(max_iter_eta)):
-        g = c - K * V * (_special.digamma(eta) - _special.digamma(V * eta))
-        h = K * V * (_special.trigamma(V * eta) - _special.trigamma(eta))
-        rho = .5
-        for _j in range(20):
-            cand = float(eta - rho * g / h)
-            if cand < min_eta:
-                rho /= 2.
-                continue
-            Lprime = bound(cand)
-            if Lb <= Lprime:
-                eta = cand
-                break
-            rho /= 2.
-        if Lprime - Lb < threshold:
-            break
-        Lb = Lprime
-    return float(eta)
-
-
-def _lngamma(x):
-    """elementwise log Gamma (utils.cpp:75-91 -> libm lgamma)."""
-    import math
-    arr = np.asarray(x, dtype=np.float64)
-    return np.array([math.lgamma(v) for v in arr.ravel()]).reshape(arr.shape)
+    batchlda.cpp:147-205 (csrc/eb_steps.cpp)."""
+    return float(_ffi.lib().trlda_eb_eta_line_search(
+        float(eta), float(sum_psi_lambda), np.ascontiguousarray(rowsums, dtype=np.float64), int(K),
+        int(V), int(max_iter_eta), float(min_eta), float(threshold)))
 
 
 def _alpha_line_search(alpha, psi_gamma_diff, num_docs, max_iter_alpha, min_alpha, threshold):
     """Newton / natural-gradient steps on alpha with a step-halving line search on the lower
-    bound: batchlda.cpp:81-141 == cumulativelda.cpp:90-150."""
-    from .. import _special
-    L = num_docs * (_lngamma(alpha.sum()) - _lngamma(alpha).sum()) + \
-        (psi_gamma_diff * (alpha - 1.)).sum()
-    Lprime = L
-    for _ in range(int(max_iter_alpha)):
-        g = psi_gamma_diff - num_docs * (_special.digamma(alpha) - _special.digamma(alpha.sum()))
-        h = -float(num_docs) * _special.trigamma(alpha)
-        z = num_docs * _special.trigamma(alpha.sum())
-        c = (g / h).sum() / (1. / z + (1. / h).sum())
-        rho = .2
-        for _j in range(20):
-            cand = alpha - rho * (g - c) / h
-            if (cand < min_alpha).any():
-                rho /= 2.
-                continue
-            Lprime = num_docs * (_lngamma(cand.sum()) - _lngamma(cand).sum()) + \
-                (psi_gamma_diff * (cand - 1.)).sum()
-            if L <= Lprime:
-                alpha = cand
-                break
-            rho /= 2.
-        if Lprime - L < threshold:
-            break
-        L = Lprime
-    return alpha
-
-
-def _psi_gamma_diff(gamma):
-    """sum_d (psi(gamma_dk) - psi(sum_k gamma_dk)), batchlda.cpp:72-74."""
-    from .. import _special
-    return (_special.digamma(gamma) - _special.digamma(gamma.sum(axis=0))[None, :]).sum(axis=1)
+    bound: batchlda.cpp:81-141 == cumulativelda.cpp:90-150 (csrc/eb_steps.cpp)."""
+    alpha = np.ascontiguousarray(alpha, dtype=np.float64)
+    out = np.empty_like(alpha)
+    _ffi.check(_ffi.lib().trlda_eb_alpha_line_search(
+        alpha.size, alpha, np.ascontiguousarray(psi_gamma_diff, dtype=np.float64), float(num_docs),
+        int(max_iter_alpha), float(min_alpha), float(threshold), out))
+    return out
 
 
 class BatchLDA(LDA):
