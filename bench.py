@@ -77,12 +77,15 @@ def parse():
                     help="strong scaling: this many documents per step in all, split over the "
                          "GPUs (BASELINE.json configs[2]: 1600); default 0 = weak scaling, "
                          "--batch documents per GPU")
-    ap.add_argument("--exchange", choices=["auto", "factors", "sstats"], default="auto",
+    ap.add_argument("--exchange", choices=["auto", "factors", "sstats", "direct"], default="auto",
                     help="N > 1: what crosses ranks per step -- 'factors': an all-gather of every "
                          "document's expElogtheta row and per-entry weights (8 (K + n_d) bytes per "
                          "document, trlda_model_estep_dp), each rank then forms the statistics of the "
                          "whole mini-batch and the M-step in one kernel; 'sstats': the all-reduce of "
-                         "K x V statistics; 'auto': whichever moves fewer bytes")
+                         "K x V statistics; 'auto': whichever moves fewer bytes; 'direct': the "
+                         "factors, written straight into the peers' buffers through hipIpc-mapped "
+                         "pointers with a step counter instead of ncclAllGather "
+                         "(trlda_model_dp_direct_*)")
     ap.add_argument("--virtual-world", type=int, default=0,
                     help="development aid for a one-GPU box: time what ONE rank of this many executes "
                          "per step with --exchange factors (the other ranks' slots hold a copy of "
@@ -343,16 +346,32 @@ def main():
             lengths = lognormal_lengths(B, seed, median=args.mean_unique, longest=min(600, V))
         return CSRDocuments(*make_corpus(B, V, seed=seed, mean_unique=args.mean_unique,
                                          zipf=not args.uniform, lengths=lengths))
-    exchange = "none"
+    exchange, direct = "none", False
     if collective:
         # ~ max_r(docs) K + max_r(nnz), from the arguments only: the same choice on every rank
         slot = B * K + int(B * args.mean_unique * 1.2)
         factors_bytes, sstats_bytes = 8. * xworld * slot, 8. * 2. * KV
-        exchange = args.exchange if args.exchange != "auto" else \
-            ("factors" if factors_bytes < sstats_bytes else "sstats")
+        exchange = args.exchange if args.exchange not in ("auto", "direct") else \
+            ("factors" if factors_bytes < sstats_bytes or args.exchange == "direct" else "sstats")
         if vworld:
             exchange = "factors"
-        if exchange == "factors" and world > 1 and rccl_comm is None:
+        if args.exchange == "direct" and world > 1:
+            # every rank exports its region, the handles travel through the process group,
+            # every rank maps its peers' regions (all ranks together, or none)
+            mine = C.create_string_buffer(64)
+            ok = L.trlda_model_dp_direct_alloc(model, 2 * slot, world, mine) == 0
+            t = torch.frombuffer(bytearray(mine.raw + bytes([int(ok)])), dtype=torch.uint8).clone().to(device)
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(parts, t)
+            raw = [p_.cpu().numpy().tobytes() for p_ in parts]
+            ok = all(r_[64] == 1 for r_ in raw) and \
+                L.trlda_model_dp_direct_connect(model, rank, world, b"".join(r_[:64] for r_ in raw)) == 0
+            flag = torch.tensor([int(ok)], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            direct = int(flag.item()) == 1
+            if not direct:
+                L.trlda_model_dp_direct_close(model)
+        if exchange == "factors" and world > 1 and rccl_comm is None and not direct:
             exchange = "sstats"                      # ncclAllGather needs the communicator
 
     batches, csrs, gamma0s, gbatches = [], [], [], []
@@ -798,7 +817,9 @@ def main():
                                 "launch (trlda_model_estep_io_next)" if prefetch else
                                 "a kernel launch of its own every step"),
                    "parallelism": "dp%d" % world,
-                   "exchange_via": (("trlda_model_estep_dp (ncclAllGather on the model's stream)"
+                   "exchange_via": (("trlda_model_estep_dp (direct: peers' buffers through hipIpc, a step "
+                                     "counter per source)" if exchange == "factors" and direct else
+                                     "trlda_model_estep_dp (ncclAllGather on the model's stream)"
                                      if exchange == "factors" else
                                      "trlda_model_allreduce_sstats (own ncclComm_t)" if rccl_comm is not None
                                      else "torch.distributed.all_reduce") if collective else None),

@@ -398,6 +398,20 @@ int trlda_model_eb_gamma_stats_multi(trlda_model *model, void *rccl_comm, int B,
 typedef int (*trlda_allgather_fn)(void *ctx, const void *send_dev, void *recv_dev,
                                   size_t count_f64, void *hip_stream);
 int trlda_model_set_allgather(trlda_model *model, trlda_allgather_fn fn, void *ctx);
+/* A DIRECT exchange of the slots, behind this switch (the all-gather above stays the default):
+ * xGMI is point to point and a slot is a few hundred kB, so every rank writes its slot straight
+ * into its peers' gather buffers -- device memory the peers export through hipIpc -- and signals
+ * them with a step counter there; no collective launch sits on a step's critical path.
+ *   alloc    a region for slots of up to max_slot_f64 doubles (two buffers, alternating per E-step,
+ *            + the counters); handle_out receives the 64-byte hipIpcMemHandle_t to give to the peers
+ *   connect  handles = world x 64 bytes in rank order (this rank's own is ignored): maps the
+ *            peers' regions; the *_dp entry points then use the direct exchange for this world
+ *   close    unmaps and frees (also done by trlda_model_destroy)
+ * Every rank must make the same sequence of *_dp calls (they do: lambda is replicated).  A peer
+ * that never signals makes the next trlda_model_synchronize fail instead of hanging. */
+int trlda_model_dp_direct_alloc(trlda_model *model, size_t max_slot_f64, int world, void *handle_out);
+int trlda_model_dp_direct_connect(trlda_model *model, int rank, int world, const void *handles);
+int trlda_model_dp_direct_close(trlda_model *model);
 /* OnlineLDA::updateParameters (src/onlinelda.cpp:53-111, 177-179) over `world` ranks: the
  * arguments of trlda_model_online_update, which it equals for world = 1.  gamma0 is this rank's
  * columns of the whole mini-batch's draw (the stream advances by all of it on every rank). */

@@ -98,7 +98,20 @@ def main():
     transport = FileTransport(cfg["path"], rank, world, cfg["max_count"], L, dev)
     HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
     hook = HOOK(transport)
-    _ffi.check(L.trlda_model_set_allgather(model, C.cast(hook, C.c_void_p), None))
+    if cfg.get("direct"):
+        # the direct exchange: every rank exports its region (hipIpc), the 64-byte handles travel
+        # through files, every rank maps its peers' regions; no hook, no collective afterwards
+        mine = C.create_string_buffer(64)
+        _ffi.check(L.trlda_model_dp_direct_alloc(model, cfg["max_count"], world, mine))
+        with open(cfg["path"] + ".handle%d" % rank, "wb") as f:
+            f.write(mine.raw)
+        transport.barrier()
+        handles = b"".join(open(cfg["path"] + ".handle%d" % r, "rb").read() for r in range(world))
+        assert len(handles) == 64 * world
+        _ffi.check(L.trlda_model_dp_direct_connect(model, rank, world, handles))
+        transport.barrier()
+    else:
+        _ffi.check(L.trlda_model_set_allgather(model, C.cast(hook, C.c_void_p), None))
 
     out = {}
     count = C.c_int(0)
@@ -161,6 +174,8 @@ def main():
     out["exchanges"] = np.array([transport.calls, transport.bytes])
     out["update_count"] = np.array([count.value])
     np.savez(cfg["path"] + ".rank%d.npz" % rank, **out)
+    _ffi.check(L.trlda_model_synchronize(model))
+    transport.barrier()                    # nobody unmaps a region a peer may still write to
     L.trlda_model_destroy(model)
     print("DP-RANK-OK", rank)
 

@@ -39,10 +39,12 @@ def main():
             own = run.get("own_communicator", True)
             if run["model"] == "online":
                 m = ShardedOnlineLDA(V, K, D, alpha=run.get("alpha", .1), eta=.3, device=local,
-                                     exchange=run["exchange"], own_communicator=own)
+                                     exchange=run["exchange"], own_communicator=own,
+                                     direct_exchange=run.get("direct", False))
             else:
                 m = ShardedBatchLDA(V, K, alpha=run.get("alpha", .1), eta=.3, device=local,
-                                    exchange=run["exchange"], own_communicator=own)
+                                    exchange=run["exchange"], own_communicator=own,
+                                    direct_exchange=run.get("direct", False))
             assert m.world == world and m.rank == rank
             rhos, paths = [], []
             for call in run["calls"]:

@@ -203,6 +203,41 @@ def test_online_update_dp_large_table_and_plain_sequence(hip, tmp_path):
         assert relerr(res[0]["lambda"], lam_one) < 1e-11, (plain, relerr(res[0]["lambda"], lam_one))
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_direct_slot_exchange_processes(hip, oracle, tmp_path, world):
+    """The direct exchange (trlda_model_dp_direct_alloc / _connect): every rank writes its slot
+    into its peers' gather buffers through hipIpc-mapped pointers and signals them with a step
+    counter -- no all-gather hook, no collective.  Ranks as processes on the one GPU (IPC works
+    on the same device).  One E-step and two updateParameters calls (5 and 1 exchanges): every
+    rank's statistics and lambda bitwise equal, equal to the one-GPU results and the oracle's."""
+    K, V, D, B = 100, 4000, 20000, 75
+    csr = corpus(B, V, seed=881)
+    lam = random_lambda(K, V, 43)
+    g0 = np.asfortranarray(np.random.RandomState(6).gamma(100., .01, (K, B)))
+    np.save(str(tmp_path / "g0.npy"), g0)
+    specs = [dict(kind="estep", B=B, corpus_seed=881, gamma0=str(tmp_path / "g0.npy"), max_iter=20),
+             dict(kind="update", B=B, corpus_seed=881, seed=13, max_iter_tr=4, max_iter_inference=20),
+             dict(kind="update", B=60, corpus_seed=882, seed=14, max_iter_tr=0, max_iter_inference=20)]
+    csrs = [csr, csr, corpus(60, V, seed=882)]
+    cfg = dict(K=K, V=V, D=D, alpha=.1, eta=.3, lambda_seed=43, direct=True,
+               max_count=slot_bound(csrs, K, world) + 64, calls=specs)
+    res = run_ranks(tmp_path, cfg, world)
+    g_ref, s_ref, it_ref = oracle.estep(lam, np.full(K, .1), csr.indptr, csr.ids, csr.cnts, g0, 20,
+                                        1e-3, nthreads=8)
+    assert np.array_equal(np.concatenate([r["iters0"] for r in res]), it_ref)
+    assert relerr(np.concatenate([r["gamma0"] for r in res], axis=1), g_ref) < TIGHT_RTOL
+    for r in res:
+        assert np.array_equal(r["sstats0"], res[0]["sstats0"])
+        assert np.array_equal(r["lambda"], res[0]["lambda"])
+        assert int(r["exchanges"][0]) == 0                   # the hook transport never ran
+    assert relerr(res[0]["sstats0"], s_ref, floor=1e-12) < TIGHT_RTOL
+    one = Single(hip, K, V, lam, .1)
+    rhos = [one.update(csrs[1], D, .3, 13, 4, 20), one.update(csrs[2], D, .3, 14, 0, 20)]
+    assert [float(res[0]["rho1"][0]), float(res[0]["rho2"][0])] == rhos
+    assert relerr(res[0]["lambda"], one.lambdas()) < 1e-12
+    one.close()
+
+
 def test_long_document_in_one_shard_and_an_empty_shard(hip, oracle, tmp_path):
     """The ranks must agree on what the gathered factors mean whatever their own shards hold
     (ADVICE r2): one shard with a 300-word document (beyond the register kernel), one EMPTY shard,

@@ -50,7 +50,9 @@ def runs():
             dict(model="online", exchange="sstats", seed=32, alpha=.2, calls=ONLINE_CALLS),
             dict(model="batch", exchange="factors", seed=33, calls=BATCH_CALLS[:1]),
             dict(model="batch", exchange="sstats", seed=33, calls=BATCH_CALLS[:1]),
-            dict(model="batch", exchange="sstats", seed=34, calls=BATCH_CALLS)]
+            dict(model="batch", exchange="sstats", seed=34, calls=BATCH_CALLS),
+            # the direct slot exchange (hipIpc-mapped peer buffers, no collective per step)
+            dict(model="online", exchange="factors", seed=31, calls=long_calls[:2], direct=True)]
 
 
 @pytest.fixture(scope="module")
@@ -120,8 +122,10 @@ def check(got, want, world):
             assert int(got["run%d_rccl_ranks" % r][0]) == world, tag
         paths = [str(p) for p in got["run%d_paths" % r]]
         if run["exchange"] == "factors":
-            # (a presharded call cannot take the factor path: a rank only sees its shard)
-            assert all(p == "factors" for p, c in zip(paths, run["calls"]) if not c.get("presharded")), (tag, paths)
+            # (a presharded call cannot take the factor path: a rank only sees its shard; at one
+            # rank there is nothing to exchange, directly or otherwise)
+            want_path = "factors-direct" if run.get("direct") and world > 1 else "factors"
+            assert all(p == want_path for p, c in zip(paths, run["calls"]) if not c.get("presharded")), (tag, paths)
         if run["exchange"] == "sstats":
             assert all(p == ("allreduce" if own else "allreduce-composed") for p in paths), (tag, paths)
         if run["model"] == "online":
@@ -137,6 +141,7 @@ def check(got, want, world):
     assert relerr(got["run1_lambda"], got["run2_lambda"]) < 1e-11
     assert relerr(got["run3_lambda"], got["run4_lambda"]) < 1e-9
     assert relerr(got["run5_lambda"], got["run6_lambda"]) < 1e-11
+    assert np.array_equal(got["run8_lambda"], got["run0_lambda"])      # direct == all-gather, bitwise
 
 
 def test_rccl_world_one_exercises_the_same_entry_points(hip, tmp_path):

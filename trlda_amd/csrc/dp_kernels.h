@@ -68,4 +68,60 @@ __global__ __launch_bounds__(T) void factor_index_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------
+// DIRECT exchange of the factor slots (behind trlda_model_dp_direct_connect; RCCL's all-gather
+// stays the default): xGMI is point to point, and a slot is a few hundred kB -- so every rank
+// writes its slot straight into the gather buffers of its peers, which are mapped into this
+// process through hipIpc handles, and tells them so with a per-source step counter in their
+// buffer; no collective launch sits on the critical path of a step.
+//
+//   slot_push_kernel    this rank's slot -> every peer's buffer (same offset there), all peers
+//                       at once, 16-byte stores; the end of the kernel is its release
+//   slot_signal_wait_kernel   flags[rank] = step at every peer (system scope), then waits until
+//                       every peer has signalled the same step here; the statistics kernel that
+//                       follows in the stream starts with an acquire and reads the buffer
+// Two buffers alternate by step parity: when a rank pushes step s + 2 into the buffer of step s,
+// every peer has signalled s + 1, i.e. has finished the statistics of step s (stream order).
+// ---------------------------------------------------------------------------
+struct DpPeers {
+    double *buf[kDpMaxWorld];                // base of rank r's exchange region in THIS process
+    unsigned long long *flags[kDpMaxWorld];  // its kDpMaxWorld step counters
+};
+
+template <int T>
+__global__ __launch_bounds__(T) void slot_push_kernel(DpPeers peers, int rank, int world,
+                                                      size_t offset /* doubles: buffer parity + rank * slot */,
+                                                      size_t count /* doubles, even */)
+{
+    const double2 *__restrict__ src = reinterpret_cast<const double2 *>(peers.buf[rank] + offset);
+    const size_t n2 = count / 2;
+    // blockIdx.y = which peer (skipping this rank), blockIdx.x strides over the slot
+    int p = (int)blockIdx.y;
+    if (p >= rank)
+        ++p;
+    if (p >= world)
+        return;
+    double2 *__restrict__ dst = reinterpret_cast<double2 *>(peers.buf[p] + offset);
+    for (size_t i = (size_t)blockIdx.x * T + threadIdx.x; i < n2; i += (size_t)gridDim.x * T)
+        dst[i] = src[i];
+}
+
+__global__ void slot_signal_wait_kernel(DpPeers peers, int rank, int world, unsigned long long step,
+                                        int *give_up)
+{
+    const int p = threadIdx.x;
+    if (p < world && p != rank)
+        __hip_atomic_store(peers.flags[p] + rank, step, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (p < world && p != rank) {
+        long long spins = 0;
+        while (__hip_atomic_load(peers.flags[rank] + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < step) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1ll << 26)) {             // a peer never came: give up, loudly
+                *give_up = 1;
+                break;
+            }
+        }
+    }
+}
+
 }  // namespace trlda

@@ -251,10 +251,22 @@ struct trlda_model {
     // Data-parallel factor exchange (DpContext below): the gathered factors of all ranks, the
     // statistics kernel's row index into them, the shard cut points on the device
     DpContext *dp = nullptr;            // set for the duration of a *_dp call
-    double *dp_gather = nullptr;
+    double *dp_gather = nullptr;        // the buffer of the call in flight: one of the two below
+    double *dp_gather_own = nullptr, *dp_gather_direct = nullptr;
     size_t cap_dp_gather = 0;
     int (*allgather_hook)(void *, const void *, void *, size_t, void *) = nullptr;
     void *allgather_ctx = nullptr;
+    // direct exchange (dp_kernels.h): this process's region [2 x world x max_slot doubles |
+    // kDpMaxWorld step counters], exported through hipIpc; the peers' regions mapped here
+    struct {
+        void *region = nullptr;
+        size_t max_slot = 0;                // doubles per slot the region was sized for
+        int world = 0, rank = -1;
+        bool connected = false;
+        trlda::DpPeers peers{};
+        std::vector<void *> opened;         // hipIpcOpenMemHandle results to close
+        unsigned long long step = 0;
+    } direct;
     double *epg = nullptr, *tw_csr = nullptr, *tw_word = nullptr;
     // split documents: the exchange rows of a launch (NaN before it), the give-up flag
     double *xbuf = nullptr;
@@ -762,9 +774,22 @@ int dp_prepare(trlda_model *m, const trlda_batch *b, DpContext *dp)
         return fail(TRLDA_ERR_ARG, "mini-batch too large for the factor exchange");
     if (dp->slot * (size_t)world > (size_t)INT32_MAX)
         return fail(TRLDA_ERR_ARG, "mini-batch too large for the factor exchange");
-    int rc = grow(&m->dp_gather, &m->cap_dp_gather, std::max<size_t>(dp->slot * (size_t)world, 1));
-    if (rc)
-        return rc;
+    int rc = TRLDA_OK;
+    if (m->direct.connected && world > 1) {
+        // the gather buffer is this step's half of the exported region (peers write into it)
+        if (world != m->direct.world || dp->rank != m->direct.rank)
+            return fail(TRLDA_ERR_ARG, "rank / world differ from trlda_model_dp_direct_connect's");
+        if (dp->slot > m->direct.max_slot)
+            return fail(TRLDA_ERR_ARG, "mini-batch needs larger slots than the direct exchange region has "
+                                       "(trlda_model_dp_direct_alloc)");
+        m->dp_gather_direct = static_cast<double *>(m->direct.region);   // (the half: per E-step)
+    } else {
+        m->dp_gather_direct = nullptr;
+        rc = grow(&m->dp_gather_own, &m->cap_dp_gather, std::max<size_t>(dp->slot * (size_t)world, 1));
+        if (rc)
+            return rc;
+    }
+    m->dp_gather = m->dp_gather_direct ? m->dp_gather_direct : m->dp_gather_own;
     // the static index of this (mini-batch, cut points): kept by the batch
     std::vector<int64_t> sig;
     sig.push_back(K);
@@ -802,7 +827,25 @@ int dp_exchange(trlda_model *m, const trlda_batch *)
 {
     DpContext *dp = m->dp;
     double *mine = m->dp_gather + (size_t)dp->rank * dp->slot;
-    if (m->allgather_hook) {
+    if (m->dp_gather_direct && dp->world > 1) {
+        // direct: this rank's slot into every peer's buffer, then signal and wait (dp_kernels.h)
+        if (!m->xerr) {
+            int rc = dev_alloc(&m->xerr, 1);
+            if (rc)
+                return rc;
+            HIP_TRY(hipMemsetAsync(m->xerr, 0, sizeof(int), m->stream));
+        }
+        constexpr int T = 256;
+        const size_t offset = (size_t)(m->direct.step & 1ull) * (size_t)dp->world * m->direct.max_slot +
+                              (size_t)dp->rank * dp->slot;
+        const size_t count = (dp->slot + 1) & ~(size_t)1;
+        const unsigned gx = (unsigned)std::max<size_t>(1, std::min<size_t>((count / 2 + T - 1) / T, 32));
+        hipLaunchKernelGGL(trlda::slot_push_kernel<T>, dim3(gx, (unsigned)(dp->world - 1)), dim3(T), 0,
+                           m->stream, m->direct.peers, dp->rank, dp->world, offset, count);
+        hipLaunchKernelGGL(trlda::slot_signal_wait_kernel, dim3(1), dim3(trlda::kDpMaxWorld), 0, m->stream,
+                           m->direct.peers, dp->rank, dp->world, m->direct.step, m->xerr);
+        HIP_TRY(hipGetLastError());
+    } else if (m->allgather_hook) {
         const int rc = m->allgather_hook(m->allgather_ctx, mine, m->dp_gather, dp->slot, m->stream);
         if (rc != 0)
             return fail(TRLDA_ERR_HIP, "the all-gather hook failed with " + std::to_string(rc));
@@ -865,6 +908,12 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         return fail(TRLDA_ERR_ARG, "the factor exchange needs the segmented statistics mode");
     if (dp)
         next = nullptr;
+    if (dp && m->dp_gather_direct && dp->world > 1) {
+        // direct exchange: every E-step is a step of its own, in the other half of the region
+        ++m->direct.step;
+        m->dp_gather = m->dp_gather_direct +
+                       (size_t)(m->direct.step & 1ull) * (size_t)dp->world * m->direct.max_slot;
+    }
     if (out.upd.lambda && !fused_update_available(m))
         return fail(TRLDA_ERR_ARG, "internal: fused M-step requested where it is not available");
     double *sstats_dev = out.upd.sstats;
@@ -1445,10 +1494,11 @@ int check_split_exchange(trlda_model *m)
     if (!flag)
         return TRLDA_OK;
     HIP_TRY(hipMemset(m->xerr, 0, sizeof(int)));
-    return fail(TRLDA_ERR_HIP, "a document split over several workgroups timed out waiting for one of "
-                               "its segments (or its statistics are NaN); the results of that call "
-                               "are void -- trlda_model_set_split_docs(model, 0) keeps every document "
-                               "on one workgroup");
+    return fail(TRLDA_ERR_HIP, "an exchange gave up waiting: a document split over several workgroups "
+                               "for one of its segments (or its statistics are NaN; "
+                               "trlda_model_set_split_docs(model, 0) keeps every document on one "
+                               "workgroup), or the direct slot exchange for a peer's signal; the "
+                               "results of that call are void");
 }
 
 int check_model(const trlda_model *m)
@@ -2045,7 +2095,7 @@ int trlda_model_destroy(trlda_model *m)
         (void)hipFree(m->lambda); (void)hipFree(m->alpha); (void)hipFree(m->eeb); (void)hipFree(m->psi_sum);
         (void)hipFree(m->xbuf); (void)hipFree(m->xerr);
         (void)hipFree(m->partial); (void)hipFree(m->counter); (void)hipFree(m->epg); (void)hipFree(m->tw_csr);
-        (void)hipFree(m->tw_word); (void)hipFree(m->dp_gather); (void)hipFree(m->lambda_prime); (void)hipFree(m->sstats); (void)hipFree(m->gamma);
+        (void)hipFree(m->tw_word); (void)hipFree(m->dp_gather_own); (void)trlda_model_dp_direct_close(m); (void)hipFree(m->lambda_prime); (void)hipFree(m->sstats); (void)hipFree(m->gamma);
         (void)hipFree(m->wordcounts); (void)hipFree(m->rs_full); (void)hipFree(m->rs_static);
         (void)hipFree(m->upd_partial); (void)hipFree(m->ada_gradient); (void)hipFree(m->reduce_out);
         (void)hipFree(m->carry_out); (void)hipFree(m->upd_groups); (void)hipFree(m->group_counter);
@@ -3016,6 +3066,99 @@ int trlda_model_estep_resident_shard(trlda_model *m, const trlda_batch *shard, i
 }
 
 // ---- data parallelism with factor exchange (dp_kernels.h) ---------------------------------
+
+// The direct exchange: a region of this model that the peers map (hipIpc) and write their slots
+// into.  alloc -> the 64-byte handle goes to every peer by whatever means the host has ->
+// connect with all handles (rank order).  Fine-grained device memory where the runtime exports
+// it (the step counters are polled while kernels run), ordinary device memory otherwise.
+int trlda_model_dp_direct_alloc(trlda_model *m, size_t max_slot_f64, int world, void *handle_out)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!handle_out || world < 1 || world > trlda::kDpMaxWorld || max_slot_f64 == 0)
+        return fail(TRLDA_ERR_ARG, "bad dp_direct_alloc arguments");
+    if ((rc = trlda_model_dp_direct_close(m)))
+        return rc;
+    max_slot_f64 = (max_slot_f64 + 1) & ~(size_t)1;
+    const size_t bytes = 2 * (size_t)world * max_slot_f64 * sizeof(double) +
+                         (size_t)trlda::kDpMaxWorld * sizeof(unsigned long long);
+    void *region = nullptr;
+    hipIpcMemHandle_t handle;
+    bool ok = hipExtMallocWithFlags(&region, bytes, hipDeviceMallocFinegrained) == hipSuccess &&
+              hipIpcGetMemHandle(&handle, region) == hipSuccess;
+    if (!ok) {
+        if (region)
+            (void)hipFree(region);
+        (void)hipGetLastError();
+        region = nullptr;
+        HIP_TRY(hipMalloc(&region, bytes));
+        hipError_t e = hipIpcGetMemHandle(&handle, region);
+        if (e != hipSuccess) {
+            (void)hipFree(region);
+            return fail(TRLDA_ERR_HIP, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e));
+        }
+    }
+    HIP_TRY(hipMemset(region, 0, bytes));
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the ABI hands out 64-byte handles");
+    std::memcpy(handle_out, &handle, sizeof(handle));
+    m->direct.region = region;
+    m->direct.max_slot = max_slot_f64;
+    m->direct.world = world;
+    m->direct.step = 0;
+    return TRLDA_OK;
+}
+
+int trlda_model_dp_direct_connect(trlda_model *m, int rank, int world, const void *handles)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!m->direct.region || world != m->direct.world || rank < 0 || rank >= world || !handles)
+        return fail(TRLDA_ERR_ARG, "dp_direct_connect: alloc first, with the same world; rank in range");
+    const size_t flag_off = 2 * (size_t)world * m->direct.max_slot * sizeof(double);
+    for (int r = 0; r < world; ++r) {
+        void *base = m->direct.region;
+        if (r != rank) {
+            hipIpcMemHandle_t h;
+            std::memcpy(&h, static_cast<const char *>(handles) + (size_t)r * sizeof(h), sizeof(h));
+            hipError_t e = hipIpcOpenMemHandle(&base, h, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) {
+                (void)trlda_model_dp_direct_close(m);
+                return fail(TRLDA_ERR_HIP, "hipIpcOpenMemHandle (rank " + std::to_string(r) +
+                                               "): " + hipGetErrorString(e));
+            }
+            m->direct.opened.push_back(base);
+        }
+        m->direct.peers.buf[r] = static_cast<double *>(base);
+        m->direct.peers.flags[r] = reinterpret_cast<unsigned long long *>(static_cast<char *>(base) + flag_off);
+    }
+    m->direct.rank = rank;
+    m->direct.connected = true;
+    return TRLDA_OK;
+}
+
+int trlda_model_dp_direct_close(trlda_model *m)
+{
+    if (!m)
+        return fail(TRLDA_ERR_ARG, "model is NULL");
+    if (m->direct.region || !m->direct.opened.empty()) {
+        if (m->stream)
+            (void)hipStreamSynchronize(m->stream);
+        for (void *p : m->direct.opened)
+            (void)hipIpcCloseMemHandle(p);
+        m->direct.opened.clear();
+        if (m->direct.region)
+            (void)hipFree(m->direct.region);
+    }
+    m->direct.region = nullptr;
+    m->direct.connected = false;
+    m->direct.max_slot = 0;
+    m->direct.world = 0;
+    m->direct.rank = -1;
+    m->dp_gather_direct = nullptr;
+    return TRLDA_OK;
+}
 
 int trlda_model_set_allgather(trlda_model *m, trlda_allgather_fn fn, void *ctx)
 {

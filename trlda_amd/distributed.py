@@ -92,6 +92,29 @@ class HipEngine(object):
             self.comm = None
         return self.comm
 
+    def connect_direct(self, dist, group, rank, world, max_slot):
+        """The direct slot exchange (include/trlda_hip.h, trlda_model_dp_direct_*): export this
+        model's region, hand the 64-byte handle to every peer through the group, map theirs.
+        Collective; returns False (on every rank alike) if any rank could not."""
+        torch = self.torch
+        mine = C.create_string_buffer(64)
+        ok = self.lib.trlda_model_dp_direct_alloc(self.handle, int(max_slot), int(world), mine) == 0
+        backend_dev = self.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        t = torch.frombuffer(bytearray(mine.raw + bytes([int(ok)])), dtype=torch.uint8).clone().to(backend_dev)
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t, group=group)
+        raw = [p.cpu().numpy().tobytes() for p in parts]
+        ok = all(r[64] == 1 for r in raw)
+        if ok:
+            handles = b"".join(r[:64] for r in raw)
+            ok = self.lib.trlda_model_dp_direct_connect(self.handle, int(rank), int(world), handles) == 0
+        flag = torch.tensor([int(ok)]).to(backend_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) != 1:
+            self.lib.trlda_model_dp_direct_close(self.handle)
+            return False
+        return True
+
     def drop_communicator(self):
         from . import rccl
         if self.comm is not None:
@@ -257,7 +280,7 @@ class _ShardedLDA(object):
     cut of a mini-batch into per-rank document ranges, the choice of the exchange."""
 
     def _setup(self, num_words, num_topics, alpha, eta, group, engine, device, gamma_init,
-               exchange, own_communicator="auto"):
+               exchange, own_communicator="auto", direct_exchange=False):
         import torch.distributed as dist
         from .models import _alpha_vector, _default_device
         self.dist = dist
@@ -304,8 +327,13 @@ class _ShardedLDA(object):
             self._own_comm = self._all_ranks(engine.make_communicator(dist, group) is not None)
             if not self._own_comm:
                 engine.drop_communicator()            # all ranks use it, or none does
+        # direct_exchange: the factor slots written straight into the peers' buffers (hipIpc)
+        # instead of an all-gather; the region is made (and every rank's handle exchanged) when
+        # the first mini-batch says how large a slot is, again when one needs more
+        self._direct = bool(direct_exchange) and self.world > 1 and hasattr(engine, "connect_direct")
+        self._direct_slot = 0
         self._factors_ok = hasattr(engine, "update_dp") and gamma_init == "replicated" and \
-            exchange != "sstats" and (self.world == 1 or self._own_comm)
+            exchange != "sstats" and (self.world == 1 or self._own_comm or self._direct)
 
     # -- replicated state -----------------------------------------------------------------
     num_topics = property(lambda self: self._K)
@@ -404,6 +432,22 @@ class _ShardedLDA(object):
         nnz = int(np.max(np.diff(csr.indptr[cuts]))) if len(cuts) > 1 else 0
         return self.world * (docs * self._K + nnz) < 2 * self._K * self._V
 
+    def _ensure_direct(self, csr, cuts):
+        """The direct exchange region covers this mini-batch's slots (collective when it grows)."""
+        if not self._direct:
+            return
+        docs = int(np.max(np.diff(cuts)))
+        nnz = int(np.max(np.diff(csr.indptr[cuts])))
+        need = (docs * self._K + nnz + self._K - 1) // self._K * self._K
+        if need <= self._direct_slot:
+            return
+        want = max(2 * need, 1 << 16)
+        if self.engine.connect_direct(self.dist, self.group, self.rank, self.world, want):
+            self._direct_slot = want
+        else:                                        # every rank falls back together
+            self._direct, self._direct_slot = False, 0
+            self._factors_ok = self._factors_ok and self._own_comm
+
     def _cut(self, docs, presharded, total_docs, doc_range):
         """-> (whole mini-batch or None, this rank's shard, cuts or None, lo, hi, B)"""
         csr = as_csr(docs)
@@ -466,13 +510,13 @@ class ShardedOnlineLDA(_ShardedLDA):
 
     def __init__(self, num_words, num_topics, num_documents, alpha=.1, eta=.3, group=None,
                  engine=None, device=None, gamma_init="replicated", exchange="auto",
-                 own_communicator="auto"):
+                 own_communicator="auto", direct_exchange=False):
         self.num_documents = int(num_documents)
         self.update_count = 0
         # adaptive learning rate state (onlinelda.cpp:28-31)
         self._ada_tau, self._ada_rho, self._ada_sq_norm = 1000., 1. / 1000., 1.
         self._setup(num_words, num_topics, alpha, eta, group, engine, device, gamma_init, exchange,
-                    own_communicator)
+                    own_communicator, direct_exchange)
 
     def update_parameters(self, docs, max_iter_tr=10, max_iter_inference=20, kappa=.7, tau=100.,
                           rho=-1., adaptive=False, init_gamma=True, update_lambda=True,
@@ -498,11 +542,15 @@ class ShardedOnlineLDA(_ShardedLDA):
         whole = mine = None
         try:
             mine = eng.upload(shard)
-            if update_lambda and csr is not None and self.use_factors(csr, cuts):
+            factors = update_lambda and csr is not None and self.use_factors(csr, cuts)
+            if factors:
+                self._ensure_direct(csr, cuts)       # (may fall back, on every rank alike)
+                factors = self.use_factors(csr, cuts)
+            if factors:
                 # every rank holds the whole mini-batch: documents of this rank -> all-gather of
                 # the factors -> statistics of the whole mini-batch + fused M-step on every rank
                 whole = eng.upload(csr)
-                self.last_path = "factors"
+                self.last_path = "factors-direct" if self._direct else "factors"
                 rho, self.update_count = eng.update_dp(
                     whole, mine, cuts, self.rank, self.world, self.num_documents, self._eta,
                     max_iter_tr, max_iter_inference, kappa, tau, rho, init_gamma, threshold,
@@ -571,9 +619,10 @@ class ShardedBatchLDA(_ShardedLDA):
     """
 
     def __init__(self, num_words, num_topics, alpha=.1, eta=.3, group=None, engine=None,
-                 device=None, gamma_init="replicated", exchange="auto", own_communicator="auto"):
+                 device=None, gamma_init="replicated", exchange="auto", own_communicator="auto",
+                 direct_exchange=False):
         self._setup(num_words, num_topics, alpha, eta, group, engine, device, gamma_init, exchange,
-                    own_communicator)
+                    own_communicator, direct_exchange)
 
     def update_parameters(self, docs, max_epochs=100, max_iter_inference=100, max_iter_alpha=10,
                           max_iter_eta=20, update_lambda=True, update_alpha=False,
@@ -590,6 +639,9 @@ class ShardedBatchLDA(_ShardedLDA):
             eng.set_keep_sstats(False)
         emp_bayes = update_alpha or update_eta
         factors = update_lambda and csr is not None and self.use_factors(csr, cuts)
+        if factors:
+            self._ensure_direct(csr, cuts)           # (may fall back, on every rank alike)
+            factors = self.use_factors(csr, cuts)
         whole = mine = None
         try:
             mine = eng.upload(shard)
@@ -597,7 +649,7 @@ class ShardedBatchLDA(_ShardedLDA):
                 whole = eng.upload(csr)
 
             def lambda_epochs(n):                                # batchlda.cpp:48-61
-                self.last_path = "factors" if factors else \
+                self.last_path = ("factors-direct" if self._direct else "factors") if factors else \
                     "allreduce" if self._c_calls() else "allreduce-composed"
                 if factors:
                     eng.batch_update_dp(whole, mine, cuts, self.rank, self.world, self._eta, n,
