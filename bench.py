@@ -640,7 +640,9 @@ def main():
         try:
             tj = json.load(open(tpath))
             # measured for the default workload only
-            if tj.get("kernel", "").endswith(doc_kernel) and (K, V, args.batch) == (100, 7000, 200):
+            names = tj.get("kernels") or [tj.get("kernel", "")]
+            if any(n.endswith(doc_kernel) for n in names) and (K, V, args.batch) == (100, 7000, 200) \
+                    and args.lengths == "poisson" and not args.uniform:
                 traffic = tj.get("hbm_bytes_per_launch")
                 traffic_src = {k: tj.get(k) for k in ("measured_at_commit", "fetch_size_kb",
                                                       "write_size_kb") if k in tj}

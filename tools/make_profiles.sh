@@ -13,13 +13,15 @@
 #   <tag>_bench_forced_dist_world1_{factors,sstats}.json, <tag>_bench_virtual_world{2,4,8}.json,
 #   <tag>_virtual_world8_kernel_stats.csv   the data-parallel step
 #   <tag>_stamps_reg.txt         tools/stamps.sh: cycle shares inside the document kernel
-tag=${1:-r02}; commit=${2:-unknown}
+#   <tag>_length_sweep.txt, <tag>_speed_workload.txt, <tag>_bench_lengthslognormal.json, <tag>_bench_uniform.json,
+#   <tag>_xcu_probe.txt          document lengths
+tag=${1:-r03}; commit=${2:-unknown}
 export TMPDIR=/tmp
 tools/prof_stats.sh ${tag} --steps 200 --warmup 20 > /dev/null
 tools/prof_pmc.sh ${tag}_fetch "FETCH_SIZE" --steps 50 --warmup 5 > gpurun_out/${tag}_pmc_fetch.txt
 tools/prof_pmc.sh ${tag}_write "WRITE_SIZE" --steps 50 --warmup 5 > gpurun_out/${tag}_pmc_write.txt
 tools/prof_pmc.sh ${tag}_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY" --steps 50 --warmup 5 > gpurun_out/${tag}_pmc_sq.txt
-python3 tools/make_traffic.py gpurun_out/${tag}_pmc_fetch.txt gpurun_out/${tag}_pmc_write.txt estep_docs_reg_kernel ${commit} > gpurun_out/${tag}_traffic.json
+python3 tools/make_traffic.py gpurun_out/${tag}_pmc_fetch.txt gpurun_out/${tag}_pmc_write.txt estep_docs_reg_kernel,estep_docs_tiered_kernel ${commit} > gpurun_out/${tag}_traffic.json
 K500="--topics 500 --words 100000 --batch 512 --steps 20 --warmup 3"
 tools/prof_stats.sh ${tag}_k500 $K500 > /dev/null
 tools/prof_pmc.sh ${tag}_k500_fetch "FETCH_SIZE" $K500 > gpurun_out/${tag}_k500_pmc_fetch.txt
@@ -41,6 +43,14 @@ done
 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_virtual8_prof -o v8 --output-format csv -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-update-rates --virtual-world 8 > /dev/null 2>&1
 cp $(find gpurun_out/${tag}_virtual8_prof -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_virtual_world8_kernel_stats.csv
 bash tools/stamps.sh > gpurun_out/${tag}_stamps_reg.txt 2>&1
+# document lengths: the cliffs between the variants, the reference's own test_speed workload,
+# the heavy-tailed and the uniform bench workloads (with their parity legs)
+python3 tools/length_sweep.py > gpurun_out/${tag}_length_sweep.txt 2>&1
+python3 tools/speed_workload.py > gpurun_out/${tag}_speed_workload.txt 2>&1
+for a in "--lengths lognormal" "--uniform"; do
+  python3 bench.py --steps 100 --warmup 10 --parity-only --no-update-rates $a 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_$(echo $a | tr -d ' -').json
+done
+hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probes/xcu_probe.hip -o tools/probes/xcu_probe 2>/dev/null && tools/probes/xcu_probe > gpurun_out/${tag}_xcu_probe.txt 2>&1
 if [ -d _r01 ]; then
   python3 tools/update_rate.py --root _r01 --configs small,c5a,c5b,c4 --modes fused > gpurun_out/r01_update_rates.txt 2>&1
   python3 tools/host_rate.py --root _r01 > gpurun_out/r01_host_rates_rerun.txt 2>&1

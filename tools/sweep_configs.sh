@@ -3,5 +3,5 @@ for cfg in "--topics 100 --words 7000 --batch 200" "--topics 100 --words 7000 --
   timeout 300 python bench.py --steps 50 --warmup 5 --parity-only --no-update-rates $cfg 2>&1 | tail -1 | python -c "
 import sys,json
 j=json.loads(sys.stdin.read())
-print(j['value'], j['ms_per_step'], j['roofline']['kernels_us'], j['roofline']['frac'], j['roofline']['estep'], j['parity'])"
+print(j['value'], 'docs/s', j['ms_per_step'], 'ms/step', j['roofline']['kernels_us'], 'hbm frac (document launch)', j['roofline']['frac'], 'fp64 frac (document launch)', j['roofline']['fp64']['frac'], 'fp64 TFLOP/s', j['roofline']['fp64']['achieved'], j['roofline']['estep'], j['parity'])"
 done
