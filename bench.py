@@ -99,6 +99,9 @@ def parse():
                     help="N > 1: close every step with BatchLDA's M-step, lambda = eta + sstats "
                          "(batchlda.cpp:60; BASELINE.json configs[3] with --topics 200 --words 50000 "
                          "--batch 12500 --max-iter 100), instead of OnlineLDA's blend with rho = 0.01")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="profiling runs: only the headline steps (no second pass without the "
+                         "prefetch), so that per-kernel means describe one kind of launch")
     ap.add_argument("--repeats", type=int, default=7,
                     help="the timed region (--steps steps) is run this many times back to back; "
                          "the median is reported, min / max beside it")
@@ -537,7 +540,7 @@ def main():
     # N = 1: the same steps with every preamble in a launch of its own (what a caller gets who
     # does not announce its next batch, e.g. OnlineLDA.do_e_step)
     value_no_prefetch = None
-    if prefetch:
+    if prefetch and not args.headline_only:
         use_prefetch[0] = False
         for i in range(min(args.warmup, 5)):
             step(i)

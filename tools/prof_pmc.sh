@@ -5,7 +5,7 @@ tag=$1; shift; ctrs=$1; shift
 export TMPDIR=/tmp
 out=gpurun_out/pmc_$tag
 rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out -- python3 bench.py --no-cpu-baseline --no-update-rates "$@" > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $out -- python3 bench.py --no-cpu-baseline --no-update-rates --headline-only "$@" > $out/bench.log 2>&1
 f=$(find $out -name '*counter_collection.csv' | head -1)
 python3 - "$f" <<'PY' | tee gpurun_out/pmc_${tag}_summary.txt
 import csv, sys, collections

@@ -5,7 +5,7 @@ tag=$1; shift
 export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --no-cpu-baseline --no-update-rates "$@" > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --no-cpu-baseline --no-update-rates --headline-only "$@" > $out/bench.log 2>&1
 f=$(find $out -name '*kernel_stats.csv' | head -1)
 cp "$f" gpurun_out/${tag}_kernel_stats.csv 2>/dev/null
 tail -1 $out/bench.log > gpurun_out/${tag}_bench.json
