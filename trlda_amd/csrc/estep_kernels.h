@@ -845,7 +845,7 @@ __global__ __launch_bounds__(T) void estep_docs_kernel(DocKernelArgs a)
 
 // ---------------------------------------------------------------------------
 // 3c. Register-resident kernel: K <= 128 topics, documents of at most 128 words (192 with
-// the LDS tail of the <true> variant).
+// in the 144-word variant).
 //
 // tools/probes on gfx950: with the slice in LDS the two products are bound by LDS bandwidth
 // -- every iteration re-reads the 8*K*n-byte slice twice, and each broadcast operand costs a
@@ -860,7 +860,7 @@ __global__ __launch_bounds__(T) void estep_docs_kernel(DocKernelArgs a)
 // ---------------------------------------------------------------------------
 constexpr int kRegThreads = 512;
 constexpr int kRegMaxK = 128;
-constexpr int kRegMaxN = 192;      // 128 words in registers + a tail of up to 64 in LDS
+constexpr int kRegMaxN = 144;      // words of the longest register variant (8 waves x 18)
 constexpr int kRegStride = 129;    // LDS row stride of the transposition / tail buffer (odd)
 constexpr int kRegPart = 192;      // row length of the partial-sum arrays
 constexpr int kSplitMinN = 192;    // documents longer than this are split over several workgroups,
@@ -958,14 +958,9 @@ __device__ __forceinline__ double sum8_strided(const double *p)
     return ((v0 + v1) + (v2 + v3)) + ((v4 + v5) + (v6 + v7));
 }
 
-// TAIL = false: documents of at most 128 words (no tail code, no register spills);
-// TAIL = true : also handles 129..192 words (a few spilled registers).  The host picks the
-// variant per batch, by whether the batch contains such a document.
 // MODE 0: documents of at most 128 words.  MODE 1: at most 144 words, all in registers (18
 // words per wave, a third register block for the words 128..143 in the second orientation).
-// MODE 2: up to 192 words, the words past 128 as rows in LDS (register-lean exp(psi)).  The
-// host picks the variant per batch by its longest document: a launch lasts as long as its
-// longest document, and the variants cost 33 / 36 / 42 us on the bench's documents.
+// Longer documents: estep_wide.h (single orientation), or split over several workgroups.
 // The preamble of the NEXT batch as extra workgroups of this launch: a 200-document batch leaves
 // 56 of the 256 CUs idle for the ~31 us the document workgroups run, and consecutive E-steps on an
 // unchanged lambda are independent of each other -- so the workgroups past the documents fill
@@ -1009,8 +1004,9 @@ __device__ __forceinline__ void docs_launch_preamble(const PreArgs &pre, double 
 template <int MODE, bool SPLIT = false>
 __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, double *lds)
 {
+    static_assert(MODE == 0 || MODE == 1, "register variants: 128 or 144 words");
     static_assert(!SPLIT || MODE == 0, "segments hold at most 128 words");
-    constexpr bool TAIL = MODE == 2, MID = MODE == 1;
+    constexpr bool MID = MODE == 1;
     constexpr int JC = MID ? 18 : 16;                // words per wave: wave w owns [JC w, JC w + JC)
     constexpr int NREG = 8 * JC;                     // words held in registers
     constexpr int T = kRegThreads, W = T / kWave;    // 8 waves
@@ -1070,11 +1066,9 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
 #endif
 
     const int nm = min(n, NREG);                     // words held in registers
-    const int nt = TAIL ? n - nm : 0;                // tail words (LDS), <= 64
     const int KC = (((K + W - 1) / W) + 1) & ~1;     // topics per wave (even), <= 16
     const int j0 = wid * JC, k0 = wid * KC;
     const bool k_lo = lane < K, k_hi = lane + 64 < K;
-    const int TC = (nt + W - 1) / W;                 // tail words per wave, <= 8
 
     // ---- the slice: orientation B straight from eeb (coalesced K-vectors)  lda.cpp:179-181
     // Word ids of this wave's 16 rows: one vector load (lane i -> row i), handed to every lane
@@ -1175,19 +1169,6 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
         }
         __syncthreads();
     }
-    // ---- words 128.. of a long document: rows of the same LDS buffer, read by both products
-    if (nt > 0) {                                    // block-uniform
-        for (int r = wid; r < 8 * TC; r += W) {      // rows beyond the document are zero
-            const bool row = r < nt;
-            const double *rowp = a.eeb + (size_t)pids[128 + min(r, 63)] * K;
-            const double v0 = rowp[min(lane, K - 1)], v1 = rowp[min(lane + 64, K - 1)];
-            tbuf[r * kRegStride + lane] = (row && k_lo) ? v0 : 0.0;
-            tbuf[r * kRegStride + 64 + lane] = (row && k_hi) ? v1 : 0.0;
-        }
-        if (tid < 64)
-            tbuf[tid * kRegStride + 128] = 0.0;      // pad column read by nobody but keep finite
-        __syncthreads();
-    }
     TRLDA_STAMP(1);
 
     // phinorm_j = sum_k e_k beta[j][k] ; tw_j = cnt_j / phinorm_j     lda.cpp:183 / :199
@@ -1210,97 +1191,19 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
             s2 = fold<32>(s2, s2);                   // + the other lane groups
             s2 = fold<16>(s2, s2);
         }
-        if constexpr (TAIL) {
-            double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
-            // (MODE 2 requests the first half of the tail word's row ahead of these products: below)
-            double tvA[8];
-            if constexpr (TAIL) {
-                if (nt > 0) {                            // block-uniform
-                    const double *trow = tbuf + min(lane, 8 * TC - 1) * kRegStride + min(k0, K - 1);
+        double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const bool colv = i < KC && k0 + i < K;  // wave-uniform, as for bE0 / bE1
-                        const double v = trow[colv ? i : 0];
-                        tvA[i] = colv ? v : 0.0;
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                s0[(2 * i) & 3] = fma(ew[i].x, bE0[2 * i], s0[(2 * i) & 3]);
-                s1[(2 * i) & 3] = fma(ew[i].x, bE1[2 * i], s1[(2 * i) & 3]);
-                s0[(2 * i + 1) & 3] = fma(ew[i].y, bE0[2 * i + 1], s0[(2 * i + 1) & 3]);
-                s1[(2 * i + 1) & 3] = fma(ew[i].y, bE1[2 * i + 1], s1[(2 * i + 1) & 3]);
-            }
-            part[wid * kRegPart + lane] = (s0[0] + s0[1]) + (s0[2] + s0[3]);
-            part[wid * kRegPart + 64 + lane] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
-            if constexpr (MID) {
-                if (lane < 16)
-                    part[wid * kRegPart + 128 + lane] = s2;
-            }
-            if constexpr (TAIL) {
-                if (nt > 0) {
-                    // tail word 128 + lane: the second half of its row, requested before the first
-                    // half's multiply-adds -- no LDS round trip is waited for with nothing else to do
-                    const double *trow = tbuf + min(lane, 8 * TC - 1) * kRegStride + min(k0, K - 1);
-                    double tvB[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int c = 8 + i;
-                        const bool colv = c < KC && k0 + c < K;
-                        const double v = trow[colv ? c : 0];
-                        tvB[i] = colv ? v : 0.0;
-                    }
-                    double t2[4] = {0.0, 0.0, 0.0, 0.0}; // four chains
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        t2[(2 * i) & 3] = fma(ew[i].x, tvA[2 * i], t2[(2 * i) & 3]);
-                        t2[(2 * i + 1) & 3] = fma(ew[i].y, tvA[2 * i + 1], t2[(2 * i + 1) & 3]);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        t2[(2 * i) & 3] = fma(ew[4 + i].x, tvB[2 * i], t2[(2 * i) & 3]);
-                        t2[(2 * i + 1) & 3] = fma(ew[4 + i].y, tvB[2 * i + 1], t2[(2 * i + 1) & 3]);
-                    }
-                    part[wid * kRegPart + 128 + lane] = (t2[0] + t2[1]) + (t2[2] + t2[3]);
-                }
-            }
-        } else {
-            double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                s0[(2 * i) & 3] = fma(ew[i].x, bE0[2 * i], s0[(2 * i) & 3]);
-                s1[(2 * i) & 3] = fma(ew[i].x, bE1[2 * i], s1[(2 * i) & 3]);
-                s0[(2 * i + 1) & 3] = fma(ew[i].y, bE0[2 * i + 1], s0[(2 * i + 1) & 3]);
-                s1[(2 * i + 1) & 3] = fma(ew[i].y, bE1[2 * i + 1], s1[(2 * i + 1) & 3]);
-            }
-            part[wid * kRegPart + lane] = (s0[0] + s0[1]) + (s0[2] + s0[3]);
-            part[wid * kRegPart + 64 + lane] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
-            if constexpr (MID) {
-                if (lane < 16)
-                    part[wid * kRegPart + 128 + lane] = s2;
-            }
-            if (nt > 0) {                                // tail word 128 + lane from LDS
-                const double *rowp = tbuf + min(lane, 8 * TC - 1) * kRegStride + min(k0, K - 1);
-                double s2[4] = {0.0, 0.0, 0.0, 0.0};     // four chains
-#pragma unroll
-                for (int hb = 0; hb < 2; ++hb) {         // two halves of eight: fewer live registers
-                    double tv[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int c = 8 * hb + i;
-                        const bool colv = c < KC && k0 + c < K;   // wave-uniform, as for bE0 / bE1
-                        const double v = rowp[colv ? c : 0];
-                        tv[i] = colv ? v : 0.0;
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        s2[(2 * i) & 3] = fma(ew[4 * hb + i].x, tv[2 * i], s2[(2 * i) & 3]);
-                        s2[(2 * i + 1) & 3] = fma(ew[4 * hb + i].y, tv[2 * i + 1], s2[(2 * i + 1) & 3]);
-                    }
-                }
-                part[wid * kRegPart + 128 + lane] = (s2[0] + s2[1]) + (s2[2] + s2[3]);
-            }
+        for (int i = 0; i < 8; ++i) {
+            s0[(2 * i) & 3] = fma(ew[i].x, bE0[2 * i], s0[(2 * i) & 3]);
+            s1[(2 * i) & 3] = fma(ew[i].x, bE1[2 * i], s1[(2 * i) & 3]);
+            s0[(2 * i + 1) & 3] = fma(ew[i].y, bE0[2 * i + 1], s0[(2 * i + 1) & 3]);
+            s1[(2 * i + 1) & 3] = fma(ew[i].y, bE1[2 * i + 1], s1[(2 * i + 1) & 3]);
+        }
+        part[wid * kRegPart + lane] = (s0[0] + s0[1]) + (s0[2] + s0[3]);
+        part[wid * kRegPart + 64 + lane] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
+        if constexpr (MID) {
+            if (lane < 16)
+                part[wid * kRegPart + 128 + lane] = s2;
         }
         __syncthreads();
         if (tid < 128 || tid < n)                    // 0 beyond n (cnt is 0 there)
@@ -1333,41 +1236,6 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
                 a1[(2 * i) & 3] = fma(tv[i].x, bB1[2 * i], a1[(2 * i) & 3]);
                 a0[(2 * i + 1) & 3] = fma(tv[i].y, bB0[2 * i + 1], a0[(2 * i + 1) & 3]);
                 a1[(2 * i + 1) & 3] = fma(tv[i].y, bB1[2 * i + 1], a1[(2 * i + 1) & 3]);
-            }
-            if constexpr (TAIL) {
-            if (nt > 0) {                            // tail rows of this wave, from LDS
-                // rows wid * TC + r, r < TC <= 8.  All loads of a group of rows are issued before
-                // its first multiply-add (a wave-uniform branch around every pair made the
-                // compiler wait for each pair's LDS round trip in turn: 165 cycles per row);
-                // a document a little over 128 words (the usual long one) has TC <= 2 and takes
-                // the short group.  Rows past TC are clamped and weighted 0.
-                const double *rowp = tbuf + (wid * TC) * kRegStride + lane;
-                const double *twp = tw + 128 + wid * TC;
-                auto tail_rows = [&](auto NR, int r0) {      // rows r0 .. r0 + R - 1
-                    constexpr int R = decltype(NR)::value;
-                    double lo[R], hi[R], w[R];
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const int rr = r0 + r < TC ? r0 + r : TC - 1;
-                        lo[r] = rowp[rr * kRegStride];
-                        hi[r] = rowp[rr * kRegStride + 64];
-                        w[r] = twp[rr];
-                    }
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const double wr = r0 + r < TC ? w[r] : 0.0;
-                        a0[r & 3] = fma(wr, lo[r], a0[r & 3]);
-                        a1[r & 3] = fma(wr, hi[r], a1[r & 3]);
-                    }
-                };
-                if (TC <= 2) {
-                    tail_rows(std::integral_constant<int, 2>{}, 0);
-                } else {
-                    tail_rows(std::integral_constant<int, 4>{}, 0);
-                    if (TC > 4)
-                        tail_rows(std::integral_constant<int, 4>{}, 4);
-                }
-            }
             }
             part[wid * kRegPart + lane] = (a0[0] + a0[1]) + (a0[2] + a0[3]);
             part[wid * kRegPart + 64 + lane] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
@@ -1431,7 +1299,7 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
                 acc = total;
             }
             const double gnew = acc * ek + ak;
-            const double enew = (MODE == 2 ? exp_digamma_minus_lean(gnew, 0.0) : exp_digamma(gnew)) * c_psi;
+            const double enew = exp_digamma(gnew) * c_psi;
             if (psi_on) {
                 g_new[k_psi] = gnew;
                 e_new[k_psi] = enew;
@@ -2100,7 +1968,7 @@ __global__ void digamma_table_kernel(int n, double c, const double *__restrict__
     const double v = x[i];
     psi[i] = digamma(v);
     epsi[i] = exp_digamma(v);
-    epsi_lean[i] = exp_digamma_minus_lean(v, 0.0);
+    epsi_lean[i] = exp_digamma(v);          // (one schedule since round 2)
     eminus[i] = exp_digamma_minus(v, c);
 }
 

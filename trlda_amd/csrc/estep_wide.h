@@ -39,14 +39,6 @@ struct wide_cfg {
     static constexpr int JW = KS == 1 ? 32 : KS == 2 ? 24 : KS == 3 ? 16 : KS == 4 ? 12
                               : KS == 5 ? 12 : KS == 6 ? 10 : 8;
 #endif
-#ifdef TRLDA_WIDE_LEAN_PSI
-    static constexpr bool LEAN_PSI = TRLDA_WIDE_LEAN_PSI;
-#else
-    // up to 256 topics exp(psi) runs on four waves that sit on four different SIMDs: latency
-    // bound, so the version scheduled for instruction-level parallelism; beyond that two
-    // waves share a SIMD and the register-lean version is as fast and leaves room for data
-    static constexpr bool LEAN_PSI = KS > 4;
-#endif
     // groups of 16 register slots, one transposing fold each (57 instructions for 16 sums:
     // 3.6 per word; groups of 8 cost 6.5 per word -- 87 against 57 instructions at JW = 12)
     static constexpr int NH = (JW + 15) / 16;
@@ -339,7 +331,7 @@ __device__ __forceinline__ void estep_docs_wide_body(const DocKernelArgs &a, int
     // gamma / alpha / exp(psi(gamma)) of topic tid                       lda.cpp:174
     double ek = 0.0;
     if (tid < KP) {
-        const double e0 = cfg::LEAN_PSI ? exp_digamma_minus_lean(gk, 0.0) : exp_digamma(gk);
+        const double e0 = exp_digamma(gk);
         ek = k_on ? e0 : 0.0;
         ebuf[tid] = ek;                              // zero beyond K
     }
@@ -546,7 +538,7 @@ __device__ __forceinline__ void estep_docs_wide_body(const DocKernelArgs &a, int
             const double gnew = k_on ? fma(accs, ek, ak) : 1.5;
             [[maybe_unused]] const double diff = k_on ? fabs(gk - gnew) : 0.0;
             gk = gnew;
-            double enew = cfg::LEAN_PSI ? exp_digamma_minus_lean(gnew, 0.0) : exp_digamma(gnew);
+            double enew = exp_digamma(gnew);
             if constexpr (FACTORS)
                 enew *= ck;
             ek = k_on ? enew : 0.0;
@@ -636,19 +628,15 @@ __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernel
 //                     (estep_docs_reg_body<0, true>): a 600-word document takes ~50 us on five
 //                     CUs instead of 270 on one
 //   beyond            one orientation, words past the registers in LDS / streamed from L2
-// (-DTRLDA_TIER2_MAX=192 brings back the variant with the words 129..192 as LDS rows read in
-// both orientations, <2>: measured equal at 145..160 words and slower at 176..192, 60.5 against
-// 57.2 us per step, profiles/r03_sweep_tier2_*.txt)
+// (Rounds 1-2 had a third register variant for 145..192 words, the words past 128 as LDS rows read
+// in both orientations: measured equal to the single-orientation body at 145..160 words and
+// slower at 176..192 -- 60.5 against 57.2 us per step, profiles/r03_sweep_tier2_*.txt -- and
+// removed.)
 // Documents are ordered by decreasing length, so the long ones start first; the launch lasts as
 // long as its slowest document.  Workgroups past pre.n_docs prepare the next batch's preamble as
 // in estep_docs_reg_kernel.  (A launch per variant, one behind the other, made a batch with one
 // 193-word document 2.5 times slower than without it: profiles/r03_length_sweep_before.txt.)
 // ---------------------------------------------------------------------------
-#ifndef TRLDA_TIER2_MAX
-#define TRLDA_TIER2_MAX 144
-#endif
-constexpr int kTier2MaxN = TRLDA_TIER2_MAX;   // longest document of the <2> variant (144: none)
-
 template <int KS>
 __global__ __launch_bounds__(kRegThreads) void estep_docs_tiered_kernel(DocKernelArgs a, PreArgs pre,
                                                                          int lds_rows)
@@ -668,12 +656,6 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_tiered_kernel(DocKerne
     } else if (n <= 144) {
         estep_docs_reg_body<1>(a, lds);
     } else {
-        if constexpr (kTier2MaxN > 144) {            // (the LDS-tail variant: off by default)
-            if (n <= kTier2MaxN) {
-                estep_docs_reg_body<2>(a, lds);
-                return;
-            }
-        }
         const int4 meta = reinterpret_cast<const int4 *>(a.pad_meta)[(size_t)blockIdx.x * a.meta_i4];
         estep_docs_wide_body<KS, true>(a, lds_rows, lds, meta.x, meta.z, meta.y);
     }

@@ -244,11 +244,4 @@ __device__ __forceinline__ double exp_digamma_minus(double x, double c)
 
 __device__ __forceinline__ double exp_digamma(double x) { return exp_digamma_minus(x, 0.0); }
 
-// (The rational form keeps few values alive -- two Horner accumulators -- so the kernels that hold
-// most of the register file as data, estep_wide.h, use the same function.)
-__device__ __forceinline__ double exp_digamma_minus_lean(double x, double c)
-{
-    return exp_digamma_minus(x, c);
-}
-
 }  // namespace trlda

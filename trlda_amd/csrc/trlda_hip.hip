@@ -1230,7 +1230,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
             size_t lds_bytes = kRegLdsBytes;
             // (LDS rows only for what the single-orientation body cannot hold in registers:
             // with split documents that is a document beyond the split range)
-            if (tiered && db->max_n > (split ? kSplitSegN * kSplitMaxSeg : std::max(kTier2MaxN, 144))) {
+            if (tiered && db->max_n > (split ? kSplitSegN * kSplitMaxSeg : kRegMaxN)) {
                 const int jw = KS == 1 ? wide_cfg<1>::JW : wide_cfg<2>::JW;
                 const size_t fixed = wide_lds_doubles(KS, 0) * sizeof(double);
                 const int fit = (int)(((size_t)kLdsBytes - fixed) / ((size_t)(64 * KS + 1) * sizeof(double)));
