@@ -7,6 +7,10 @@
 // partial sums of acc_k).  Two protocols, slots indexed by iteration (never reused in a launch):
 //   A  data, then a per-workgroup flag (release), consumers poll the flags, then load the data
 //   B  no flag: the buffer starts as a NaN sentinel and consumers poll the data itself
+//   C  B with the loads of all rows in flight together (what the kernel does)
+//   D  C with workgroup-scope accesses: the XCD's L2 is the meeting point -- right only when the
+//      workgroups sit on ONE XCD (stride 8, if workgroups are dealt round-robin over the XCDs);
+//      with stride 1 it is expected to time out or read stale rows: that is the measurement
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probes/xcu_probe.hip -o tools/probes/xcu_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -15,6 +19,16 @@
 
 constexpr int K = 128, IT = 200;
 
+// workgroup-scope accesses (sc0): served by the XCD's L2 -- coherent between the CUs of ONE XCD
+// only, which is more than the scope promises and less than workgroups on different XCDs need
+__device__ __forceinline__ void st_wg(double *p, double v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ double ld_wg(const double *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __device__ __forceinline__ void st_agent(double *p, double v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -39,8 +53,12 @@ __global__ __launch_bounds__(512) void exchange(int C, int stride, double *buf /
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < IT; ++it) {
         double *slot = buf + ((size_t)it * C + me) * K;
-        if (tid < K)
-            st_agent(slot + tid, acc + tid * 1e-3 + it);          // never NaN
+        if (tid < K) {
+            if (PROTO == 3)
+                st_wg(slot + tid, acc + tid * 1e-3 + it);
+            else
+                st_agent(slot + tid, acc + tid * 1e-3 + it);      // never NaN
+        }
         if (PROTO == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_s_waitcnt(0);                        // the stores have left
@@ -56,6 +74,34 @@ __global__ __launch_bounds__(512) void exchange(int C, int stride, double *buf /
                 }
             }
             __syncthreads();
+        }
+        if (PROTO == 2 || PROTO == 3) {
+            // B with all rows' loads in flight together; 2: agent scope, 3: workgroup scope (L2)
+            double sum = 0.0;
+            if (tid < K) {
+                double v[8];
+                unsigned need = (1u << C) - 1u;
+                int spins = 0;
+                while (need) {
+                    for (int c = 0; c < 8; ++c)
+                        if (need >> c & 1u) {
+                            const double *p = buf + ((size_t)it * C + c) * K + tid;
+                            v[c] = PROTO == 3 ? ld_wg(p) : ld_agent(p);
+                        }
+                    for (int c = 0; c < 8; ++c)
+                        if ((need >> c & 1u) && v[c] == v[c])
+                            need &= ~(1u << c);
+                    if (++spins > (1 << 14)) { *fail = 1; break; }
+                }
+                for (int c = 0; c < C; ++c)
+                    sum += v[c];
+                sh[tid] = sum;
+            }
+            __syncthreads();
+            if (__hip_atomic_load(fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                break;                                            // somebody gave up: all leave
+            acc = sh[(tid + it) % K] * 1e-3 + me;
+            continue;
         }
         // every thread k < K adds up column k over the C workgroups, in order
         double sum = 0.0;
@@ -96,7 +142,7 @@ int main()
     hipMalloc(&out, 8 * CMAX);
     hipMalloc(&cyc, 8 * CMAX);
     hipMalloc(&fail, 4);
-    for (int proto = 0; proto < 2; ++proto)
+    for (int proto = 0; proto < 4; ++proto)
         for (int stride : {1, 8})
             for (int C : {1, 2, 3, 5, 8}) {
                 hipMemset(buf, 0xFF, sizeof(double) * IT * CMAX * K);   // NaN sentinel
@@ -108,8 +154,12 @@ int main()
                 hipEventRecord(e0, 0);
                 if (proto == 0)
                     hipLaunchKernelGGL(exchange<0>, dim3(C * stride), dim3(512), 0, 0, C, stride, buf, flags, out, cyc, fail);
-                else
+                else if (proto == 1)
                     hipLaunchKernelGGL(exchange<1>, dim3(C * stride), dim3(512), 0, 0, C, stride, buf, flags, out, cyc, fail);
+                else if (proto == 2)
+                    hipLaunchKernelGGL(exchange<2>, dim3(C * stride), dim3(512), 0, 0, C, stride, buf, flags, out, cyc, fail);
+                else
+                    hipLaunchKernelGGL(exchange<3>, dim3(C * stride), dim3(512), 0, 0, C, stride, buf, flags, out, cyc, fail);
                 hipEventRecord(e1, 0);
                 hipDeviceSynchronize();
                 float ms = 0.f;
@@ -121,8 +171,9 @@ int main()
                 unsigned long long worst = 0;
                 for (int c = 0; c < C; ++c)
                     worst = h[c] > worst ? h[c] : worst;
+                fflush(stdout);
                 printf("protocol %c  stride %d  C=%d workgroups: %6.0f s_memtime ticks, %6.0f ns per exchange "
-                       "(launch %.1f us)%s\n", proto ? 'B' : 'A', stride, C, (double)worst / IT,
+                       "(launch %.1f us)%s\n", "ABCD"[proto], stride, C, (double)worst / IT,
                        1e6 * ms / IT, 1e3 * ms, f ? "  [SPIN LIMIT HIT]" : "");
             }
     return 0;
