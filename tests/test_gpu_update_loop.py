@@ -478,6 +478,63 @@ def test_device_draw_keeps_the_early_exits_at_baseline_size(hip):
     assert relerr(out[0], out[1]) < 1e-7
 
 
+def test_gamma_drawn_ahead_keeps_the_order_of_draws(hip, oracle):
+    """The next update's gamma0 is drawn ahead on a stream of its own with the host stream
+    advanced before its turn (trlda_model_set_draw_ahead): whatever touches the generator in
+    between -- a host draw, a seed, another model, another batch size, a lower bound -- the
+    ORDER of draws stays the reference's: the same sequence of calls with drawing ahead on and
+    off ends at bitwise the same lambda, gamma and generator state, for OnlineLDA (with and
+    without the trust-region loop), BatchLDA epochs and CumulativeLDA."""
+    import trlda_amd
+    from trlda_amd.models import BatchLDA, CumulativeLDA
+    K, V, D = 60, 1500, 20000
+    lam0 = random_lambda(K, V, 91)
+    batches = [corpus(B, V, seed=950 + i, mean_unique=40) for i, B in enumerate((70, 70, 70, 33, 70, 70))]
+
+    def run(ahead):
+        out = []
+        trlda_amd.seed(123)
+        m = online_model(K, V, lam0, D)
+        other = online_model(K, V, lam0, D)
+        for mm in (m, other):
+            assert hip.trlda_model_set_draw_ahead(mm._handle, ahead) == 0
+        m.update_parameters(batches[0], max_iter_tr=0)            # draws, then draws ahead for 70
+        m.update_parameters(batches[1], max_iter_tr=3)            # claims it
+        g = np.empty((4, 5), order="F")
+        hip.trlda_sample_gamma_init(4, 5, g)                      # a host draw in between
+        out.append(g.copy())
+        m.update_parameters(batches[2], max_iter_tr=2, init_gamma=False)   # a draw per iteration
+        m.update_parameters(batches[3], max_iter_tr=0)            # another batch size
+        other.update_parameters(batches[4], max_iter_tr=1)        # another model
+        out.append(m.lower_bound(batches[4]))                     # draws its own gamma (host)
+        m.update_parameters(batches[5], max_iter_tr=2, update_alpha=True, update_eta=True)
+        trlda_amd.seed(5)                                         # a seed with a draw ahead pending
+        m.update_parameters(batches[0], max_iter_tr=0)
+        out += [m.lambdas, other.lambdas, m.alpha.copy(), np.array(m.eta)]
+        b = BatchLDA.__new__(BatchLDA)
+        b._setup(V, K, .1, .3, None, _lambda=lam0)
+        hip.trlda_model_set_draw_ahead(b._handle, ahead)
+        b.update_parameters(batches[0], max_epochs=3, max_iter_inference=30)
+        out.append(b.lambdas)
+        c = CumulativeLDA(V, K)
+        hip.trlda_model_set_draw_ahead(c._handle, ahead)
+        c.update_parameters(batches[1], max_epochs=2, max_iter_inference=30)
+        c.update_parameters(batches[2], max_epochs=2, max_iter_inference=30)
+        out.append(c.lambdas)
+        state = np.zeros(33, dtype=np.uint32)
+        hip.trlda_rng_get_state(state)
+        tail = np.empty((3, 3), order="F")
+        hip.trlda_sample_gamma_init(3, 3, tail)
+        out.append(tail)
+        for mm in (m, other, b, c):
+            mm.close()
+        return out
+
+    on, off = run(1), run(0)
+    for a, b in zip(on, off):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
 def test_host_gamma_draw_switch_gives_the_same_update(hip):
     import trlda_amd
     K, V, B, D = 50, 2000, 70, 10000

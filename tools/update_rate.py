@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--configs", default="small,c5a,c5b,c4")
     ap.add_argument("--root", default=ROOT, help="tree to import trlda_amd from")
     ap.add_argument("--modes", default="fused,plain")
+    ap.add_argument("--no-draw-ahead", action="store_true",
+                    help="every gamma0 drawn in its turn on the model's stream (trlda_model_set_draw_ahead(0))")
     ap.add_argument("--host-draw", action="store_true",
                     help="draw gamma0 on the host (bit-exact glibc logarithms) instead of on the device")
     args = ap.parse_args()
@@ -77,6 +79,8 @@ def main():
                 if not hasattr(L, "trlda_model_set_next_preamble"):
                     continue
                 L.trlda_model_set_next_preamble(m._handle, 0)
+            if args.no_draw_ahead and hasattr(L, "trlda_model_set_draw_ahead"):
+                L.trlda_model_set_draw_ahead(m._handle, 0)
             if args.host_draw and hasattr(L, "trlda_model_set_host_gamma_draw"):
                 L.trlda_model_set_host_gamma_draw(m._handle, 1)
             batch = m.upload(docs)

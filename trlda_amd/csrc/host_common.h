@@ -37,6 +37,13 @@ void jump_multiply(const JumpMatrix &x, const JumpMatrix &y, JumpMatrix &out);
 // A^n, the matrix that moves a 31-word window n draws on (by value: the cache behind it evicts)
 JumpMatrix jump_power(uint64_t n, const JumpMatrix *half = nullptr);
 void jump_apply(const JumpMatrix &m, uint32_t (&w)[31]);
+// drawing ahead (host_rng.cpp): begin saves the state (cancelling any earlier speculation) and
+// returns a token; claim(token) = that draw took its turn after all; cancel = the state goes
+// back.  Every other use of the generator cancels first.
+uint64_t rng_speculate_begin();
+bool rng_speculation_claim(uint64_t token);
+void rng_speculation_cancel();
+void rng_speculation_cancel_if(uint64_t token);      // only if that one is the pending one
 // the process generator: its window (oldest word first), and moving it on by `draws`
 void rng_current_window(uint32_t (&w)[31]);
 void rng_advance(uint64_t draws);

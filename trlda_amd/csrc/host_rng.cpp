@@ -176,6 +176,51 @@ struct RngInit {
 
 }  // namespace
 
+// ---- drawing ahead ---------------------------------------------------------------------
+// A model may draw the gamma0 of its NEXT update while this one's kernels run (trlda_hip.hip,
+// fresh_gamma_device): the stream is then advanced before its turn.  One such speculation can
+// be outstanding; whoever touches the generator for anything else cancels it first -- the state
+// goes back to where it was -- so the order of draws stays the reference's whatever comes next.
+namespace {
+struct Speculation {
+    bool pending = false;
+    uint64_t token = 0;
+    GlibcRandom before;
+} g_spec;
+uint64_t g_spec_counter = 0;
+}  // namespace
+
+uint64_t rng_speculate_begin()
+{
+    rng_speculation_cancel();
+    g_spec.pending = true;
+    g_spec.before = g_rng;
+    g_spec.token = ++g_spec_counter;
+    return g_spec.token;
+}
+
+bool rng_speculation_claim(uint64_t token)
+{
+    if (!g_spec.pending || g_spec.token != token)
+        return false;
+    g_spec.pending = false;                          // the draw took its turn after all
+    return true;
+}
+
+void rng_speculation_cancel_if(uint64_t token)
+{
+    if (g_spec.pending && g_spec.token == token)
+        rng_speculation_cancel();
+}
+
+void rng_speculation_cancel()
+{
+    if (g_spec.pending) {
+        g_rng = g_spec.before;
+        g_spec.pending = false;
+    }
+}
+
 void rng_current_window(uint32_t (&w)[31]) { rng_to_window(g_rng, w); }
 
 void rng_advance(uint64_t draws)
@@ -218,6 +263,7 @@ extern "C" {
 
 void trlda_seed(unsigned int seed)
 {
+    rng_speculation_cancel();
     srand(seed);          // keep libc's own stream in step for anything else that uses it
     g_rng.seed(seed);
 }
@@ -225,6 +271,7 @@ void trlda_seed(unsigned int seed)
 // the generator's whole state: 31 words, then the two indices
 void trlda_rng_get_state(uint32_t *state33)
 {
+    rng_speculation_cancel();
     std::memcpy(state33, g_rng.x, sizeof(g_rng.x));
     state33[31] = (uint32_t)g_rng.f;
     state33[32] = (uint32_t)g_rng.b;
@@ -232,6 +279,7 @@ void trlda_rng_get_state(uint32_t *state33)
 
 void trlda_rng_set_state(const uint32_t *state33)
 {
+    rng_speculation_cancel();
     std::memcpy(g_rng.x, state33, sizeof(g_rng.x));
     g_rng.f = (int)(state33[31] % 31u);
     g_rng.b = (int)(state33[32] % 31u);
@@ -239,6 +287,7 @@ void trlda_rng_set_state(const uint32_t *state33)
 
 void trlda_sample_gamma(int m, int n, int k, double *out)
 {
+    rng_speculation_cancel();
     const int64_t total = (int64_t)m * n;
     for (int64_t i = 0; i < total; ++i)
         out[i] = 0.0;

@@ -139,6 +139,46 @@ __global__ __launch_bounds__(T) void window_level_coop_kernel(long long S, long 
     win[(size_t)i * S + s] = acc;
 }
 
+// Two-level windows (round 3): a matrix-vector product per window is 961 multiply-adds where
+// moving a window L draws on by the recurrence itself is L additions.  So only every G-th window
+// ("coarse": segments of G L draws) comes from the matrices -- the kernels above with the
+// matrices of G L -- and thread c walks from coarse window c through its G fine windows in
+// registers: after t steps the oldest word sits in register (t mod 31), so with the loops
+// unrolled every index is a constant.  At 62 500 windows of 32 draws: 5 + 19 us of matrix
+// products become ~3 (7 800 products) + ~3 (the walk).
+constexpr int kRngWalk = 8;           // fine windows per coarse window
+
+template <int T, int L>
+__global__ __launch_bounds__(T) void window_walk_kernel(long long S, long long Sc,
+                                                        const uint32_t *__restrict__ cwin /* 31 x Sc */,
+                                                        uint32_t *__restrict__ win /* 31 x S */)
+{
+    const long long c = (long long)blockIdx.x * T + threadIdx.x;
+    if (c >= Sc)
+        return;
+    uint32_t r[31];
+#pragma unroll
+    for (int j = 0; j < 31; ++j)
+        r[j] = cwin[(size_t)j * Sc + c];
+#pragma unroll
+    for (int g = 0; g < kRngWalk; ++g) {
+        const int rot = (g * L) % 31;                // register of the oldest word now
+        const long long s = c * kRngWalk + g;
+        if (s < S) {
+#pragma unroll
+            for (int j = 0; j < 31; ++j)
+                win[(size_t)j * S + s] = r[(j + rot) % 31];
+        }
+        if (g + 1 < kRngWalk) {
+#pragma unroll
+            for (int t = 0; t < L; ++t) {            // s_n = s_(n-31) + s_(n-3): the oldest word
+                const int f = (rot + t) % 31;        // becomes the newest
+                r[f] += r[(f + 28) % 31];
+            }
+        }
+    }
+}
+
 // positions [pos_lo, pos_hi) of the stream (a whole number of passes of `total` elements);
 // vbuf[pos - pos_lo] = log|u|.  A data-parallel rank needs the elements [e_lo, e_hi) of every
 // pass only (its own documents' columns): segments that hold none of them do nothing (the

@@ -287,6 +287,24 @@ struct trlda_model {
     size_t cap_reduce = 0;
     int32_t *iters = nullptr;                   // per-document iteration counts (estep_host)
     size_t cap_iters = 0;
+    // gamma0 of the NEXT fresh E-step, drawn ahead on a stream of its own while this call's
+    // kernels run (fresh_gamma_device): two buffers alternate, `spec` says what is in flight
+    bool draw_ahead = true;                     // trlda_model_set_draw_ahead
+    hipStream_t draw_stream = nullptr;
+    hipEvent_t ev_main = nullptr, ev_draw = nullptr;
+    double *gspec[2] = {nullptr, nullptr};
+    size_t cap_gspec[2] = {0, 0};
+    struct {
+        bool valid = false;
+        uint64_t token = 0;
+        int which = 0;
+        long long total = 0, lo = 0, hi = 0;
+    } spec;
+    const double *gamma0_src = nullptr;         // the next E-step on m->gamma reads gamma0 here
+    uint32_t *rng_win2 = nullptr;               // scratch of the draw stream
+    size_t cap_rng_win2 = 0;
+    double *rng_vbuf2 = nullptr;
+    size_t cap_rng_vbuf2 = 0;
     // device-side sampleGamma (rng_kernels.h): segment windows, log|u| of a group of passes
     bool host_gamma_draw = false;               // true: the bit-exact host draw (glibc log)
     uint32_t *rng_win = nullptr;
@@ -470,12 +488,73 @@ int ensure_gamma_staging(trlda_model *m, size_t count)
 // out_dev[total] = sampleGamma(total, 1, passes) / divisor on the device, from the host's libc
 // stream, which is advanced by passes * total draws (defined below, after the generator)
 int sample_gamma_on_device(trlda_model *m, long long total, int passes, double divisor, double *out_dev,
-                           long long e_lo = 0, long long e_hi = -1);
+                           long long e_lo = 0, long long e_hi = -1, bool ahead = false);
 
 // gamma = sampleGamma(K, B, 100) / 100 (lda.cpp:135).  Default: drawn on the device from the same
 // integer stream (rng_kernels.h).  host_gamma_draw: on the host (glibc's logarithm, bit for bit
 // the reference's values), uploaded without blocking so that the draw of the next call can
 // overlap the kernels of this one.
+// The gamma0 of the next fresh E-step of the same shape, drawn while this call's kernels run:
+// on a stream of the model's own, into the buffer the current call does not read, with the host
+// stream advanced ahead of its turn (host_rng.cpp: whoever else touches the generator first
+// cancels that, and the draw is repeated in its turn).  The draw stream waits for everything the
+// main stream has been given so far -- the last reader of the target buffer is among it.
+int draw_gamma_ahead(trlda_model *m, long long total, long long lo, long long hi)
+{
+    if (!m->draw_ahead || m->host_gamma_draw || hi <= lo)
+        return TRLDA_OK;
+    if (!m->draw_stream) {
+        // (confining this stream to the ~50 CUs a 200-document launch leaves idle -- a document
+        // workgroup needs a whole CU -- was measured: the draw then takes 230 us instead of 44 and
+        // the call 174 us instead of 84)
+        HIP_TRY(hipStreamCreateWithFlags(&m->draw_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_main, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&m->ev_draw, hipEventDisableTiming));
+    }
+    const int which = m->gamma0_src == m->gspec[0] && m->gspec[0] ? 1 : 0;
+    int rc = grow(&m->gspec[which], &m->cap_gspec[which], (size_t)(hi - lo));
+    if (rc)
+        return rc;
+    HIP_TRY(hipEventRecord(m->ev_main, m->stream));
+    HIP_TRY(hipStreamWaitEvent(m->draw_stream, m->ev_main, 0));
+    const uint64_t token = trlda_host::rng_speculate_begin();
+    rc = sample_gamma_on_device(m, total, 100, 100., m->gspec[which], lo, hi, /*ahead=*/true);
+    if (rc) {
+        trlda_host::rng_speculation_cancel();
+        return rc;
+    }
+    HIP_TRY(hipEventRecord(m->ev_draw, m->draw_stream));
+    m->spec.valid = true;
+    m->spec.token = token;
+    m->spec.which = which;
+    m->spec.total = total; m->spec.lo = lo; m->spec.hi = hi;
+    return TRLDA_OK;
+}
+
+// gamma0 = elements [lo, hi) of sampleGamma(total, 1, 100) / 100 for the E-step that follows on
+// m->gamma: the draw made ahead if it is this one and still in turn, else drawn now
+int device_gamma_now_or_ahead(trlda_model *m, long long total, long long lo, long long hi)
+{
+    m->gamma0_src = nullptr;
+    bool have = false;
+    if (m->spec.valid) {
+        m->spec.valid = false;
+        if (m->spec.total == total && m->spec.lo == lo && m->spec.hi == hi &&
+            trlda_host::rng_speculation_claim(m->spec.token)) {
+            HIP_TRY(hipStreamWaitEvent(m->stream, m->ev_draw, 0));
+            m->gamma0_src = m->gspec[m->spec.which];
+            have = true;
+        }
+        // (else: sample_gamma_on_device below cancels whatever is pending)
+    }
+    int rc = TRLDA_OK;
+    if (!have)
+        rc = sample_gamma_on_device(m, total, 100, 100., m->gamma, lo, hi);
+    if (!rc)
+        rc = draw_gamma_ahead(m, total, lo, hi);
+    return rc;
+}
+
 int fresh_gamma_device(trlda_model *m, int B)
 {
     if (m->dp) {
@@ -483,7 +562,8 @@ int fresh_gamma_device(trlda_model *m, int B)
         // as in the single-process run (every rank draws from the same state: lda.cpp:135)
         const long long lo = (long long)m->K * m->dp->doc_lo(), n = (long long)m->K * m->dp->shard->B;
         if (!m->host_gamma_draw)
-            return sample_gamma_on_device(m, (long long)m->K * B, 100, 100., m->gamma, lo, lo + n);
+            return device_gamma_now_or_ahead(m, (long long)m->K * B, lo, lo + n);
+        m->gamma0_src = nullptr;
         std::vector<double> full((size_t)m->K * B);
         trlda_sample_gamma_init(m->K, B, full.data());
         if (n > 0) {
@@ -494,7 +574,8 @@ int fresh_gamma_device(trlda_model *m, int B)
         return TRLDA_OK;
     }
     if (!m->host_gamma_draw)
-        return sample_gamma_on_device(m, (long long)m->K * B, 100, 100., m->gamma);
+        return device_gamma_now_or_ahead(m, (long long)m->K * B, 0, (long long)m->K * B);
+    m->gamma0_src = nullptr;
     const size_t count = (size_t)m->K * B;
     int rc = ensure_gamma_staging(m, count);
     if (rc)
@@ -1084,6 +1165,10 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         a.indptr = db->indptr; a.ids = db->ids; a.cnts = db->cnts;
         a.eeb = m->eeb_cur; a.alpha = m->alpha;
         a.gamma = gamma_dev; a.gamma_in = gamma_in_dev ? gamma_in_dev : gamma_dev;
+        if (!gamma_in_dev && gamma_dev == m->gamma && m->gamma0_src) {
+            a.gamma_in = m->gamma0_src;              // drawn ahead (device_gamma_now_or_ahead)
+            m->gamma0_src = nullptr;
+        }
         a.epg = m->epg; a.tw_csr = m->tw_csr;
         a.wrank = db->wrank; a.tw_word = m->tw_word;
         if (dp) {
@@ -1567,10 +1652,18 @@ int rng_device_matrices(int device, int L, const uint32_t **out)
 // elements [e_lo, e_hi) only (out_dev compact, e_hi - e_lo values); e_hi < 0: all of them.  The
 // stream always advances by passes * total draws.
 int sample_gamma_on_device(trlda_model *m, long long total, int passes, double divisor, double *out_dev,
-                           long long e_lo, long long e_hi)
+                           long long e_lo, long long e_hi, bool ahead)
 {
     if (total <= 0)
         return TRLDA_OK;
+    if (!ahead)
+        trlda_host::rng_speculation_cancel();        // a draw in its turn: nothing may be ahead of it
+    // a draw made ahead runs on the draw stream with scratch of its own
+    const hipStream_t stream = ahead ? m->draw_stream : m->stream;
+    uint32_t *&win = ahead ? m->rng_win2 : m->rng_win;
+    size_t &cap_win = ahead ? m->cap_rng_win2 : m->cap_rng_win;
+    double *&vbuf = ahead ? m->rng_vbuf2 : m->rng_vbuf;
+    size_t &cap_vbuf = ahead ? m->cap_rng_vbuf2 : m->cap_rng_vbuf;
     if (e_hi < 0)
         e_hi = total;
     constexpr int T = trlda::kRngThreads;
@@ -1579,48 +1672,65 @@ int sample_gamma_on_device(trlda_model *m, long long total, int passes, double d
                   : draws < trlda::kRngSmallDraws ? trlda::kRngSegmentSmall
                                                   : trlda::kRngSegment;
     const long long S = (draws + L - 1) / L;
+    // two-level windows for the small segment lengths (rng_kernels.h): the matrices produce the
+    // windows of every kRngWalk-th segment, a walk along the recurrence the ones in between
+    static const bool walk_off = [] { const char *e = std::getenv("TRLDA_RNG_WALK"); return e && e[0] == '0'; }();
+    const bool walk = !walk_off && L != trlda::kRngSegment && S >= 4 * trlda::kRngWalk;
+    const int Lm = walk ? L * trlda::kRngWalk : L;              // segment length of the matrix level
+    const long long Sm = walk ? (S + trlda::kRngWalk - 1) / trlda::kRngWalk : S;
     const uint32_t *mats = nullptr;
-    int rc = rng_device_matrices(m->device, L, &mats);
-    if (!rc) rc = grow(&m->rng_win, &m->cap_rng_win, (size_t)31 * (size_t)S);
+    int rc = rng_device_matrices(m->device, Lm, &mats);
+    if (!rc) rc = grow(&win, &cap_win, (size_t)31 * (size_t)S + (walk ? (size_t)31 * (size_t)Sm : 0));
     // log|u| of a group of passes: at most ~1 GB at a time
     const long long group = std::max<long long>(1, std::min<long long>(passes, ((long long)1 << 27) / total));
-    if (!rc) rc = grow(&m->rng_vbuf, &m->cap_rng_vbuf, (size_t)group * (size_t)total);
+    if (!rc) rc = grow(&vbuf, &cap_vbuf, (size_t)group * (size_t)total);
     if (rc)
         return rc;
+    uint32_t *mwin = walk ? win + (size_t)31 * (size_t)S : win;  // where the matrix level writes
     RngSeedWindow w0;
     trlda_host::rng_current_window(w0.w);
     long long unit = 1;
     int levels = 0;
-    while (levels < trlda::kRngLevels && unit < S) {
+    while (levels < trlda::kRngLevels && unit < Sm) {
         unit *= 16;
         ++levels;
     }
-    if (unit < S)
+    if (unit < Sm)
         return fail(TRLDA_ERR_ARG, "sampleGamma request too large for the device generator");
-    if (S < 200000) {
+    if (Sm < 200000) {
         // few windows: the first three levels (4096 windows) straight from the seed window in one
         // launch, the levels above with one matrix-vector product per window each
         const uint32_t *mats_t = mats + (size_t)trlda::kRngLevels * 15 * 961;
         const int direct = std::min(levels, 3);
-        const long long S0 = std::min<long long>(S, 4096);
+        const long long S0 = std::min<long long>(Sm, 4096);
         hipLaunchKernelGGL(trlda::window_direct_kernel<T>, dim3((unsigned)((S0 * 32 + T - 1) / T)), dim3(T),
-                           0, m->stream, S, S0, direct, w0, mats_t, m->rng_win);
+                           0, stream, Sm, S0, direct, w0, mats_t, mwin);
         unit = 4096;
         for (int l = direct; l < levels; ++l, unit *= 16) {
-            const long long lo = unit, hi = std::min<long long>(S, unit * 16);
+            const long long lo = unit, hi = std::min<long long>(Sm, unit * 16);
             hipLaunchKernelGGL(trlda::window_level_coop_kernel<T>,
-                               dim3((unsigned)(((hi - lo) * 32 + T - 1) / T)), dim3(T), 0, m->stream, S,
-                               lo, hi, unit, mats_t + (size_t)l * 15 * 961, m->rng_win);
+                               dim3((unsigned)(((hi - lo) * 32 + T - 1) / T)), dim3(T), 0, stream, Sm,
+                               lo, hi, unit, mats_t + (size_t)l * 15 * 961, mwin);
         }
     } else {
-        hipLaunchKernelGGL(window_seed_kernel, dim3(1), dim3(64), 0, m->stream, S, w0, m->rng_win);
+        hipLaunchKernelGGL(window_seed_kernel, dim3(1), dim3(64), 0, stream, Sm, w0, mwin);
         unit = 1;
         for (int l = 0; l < levels; ++l, unit *= 16) {
-            const long long lo = unit, hi = std::min<long long>(S, unit * 16);
+            const long long lo = unit, hi = std::min<long long>(Sm, unit * 16);
             hipLaunchKernelGGL(trlda::window_level_kernel<T>, dim3((unsigned)((hi - lo + T - 1) / T)),
-                               dim3(T), 0, m->stream, S, lo, hi, unit, mats + (size_t)l * 15 * 961,
-                               m->rng_win);
+                               dim3(T), 0, stream, Sm, lo, hi, unit, mats + (size_t)l * 15 * 961,
+                               mwin);
         }
+    }
+    if (walk) {
+        constexpr int TW = 64;                       // few threads, long walks: spread them out
+        const dim3 wgrid((unsigned)((Sm + TW - 1) / TW));
+        if (L == trlda::kRngSegmentTiny)
+            hipLaunchKernelGGL((trlda::window_walk_kernel<TW, trlda::kRngSegmentTiny>), wgrid, dim3(TW), 0,
+                               stream, S, Sm, mwin, win);
+        else
+            hipLaunchKernelGGL((trlda::window_walk_kernel<TW, trlda::kRngSegmentSmall>), wgrid, dim3(TW), 0,
+                               stream, S, Sm, mwin, win);
     }
     for (long long p0 = 0; p0 < passes; p0 += group) {
         const long long p1 = std::min<long long>(passes, p0 + group);
@@ -1629,21 +1739,21 @@ int sample_gamma_on_device(trlda_model *m, long long total, int passes, double d
         const dim3 dgrid((unsigned)((seg_hi - seg_lo + T - 1) / T));
         if (L == trlda::kRngSegment)
             hipLaunchKernelGGL((trlda::draw_log_kernel<T, trlda::kRngSegment>), dgrid, dim3(T), 0,
-                               m->stream, S, seg_lo, std::min(S, seg_hi), pos_lo, pos_hi, total, e_lo,
-                               e_hi, m->rng_win, m->rng_vbuf);
+                               stream, S, seg_lo, std::min(S, seg_hi), pos_lo, pos_hi, total, e_lo,
+                               e_hi, win, vbuf);
         else if (L == trlda::kRngSegmentTiny)
             hipLaunchKernelGGL((trlda::draw_log_kernel<T, trlda::kRngSegmentTiny>), dgrid, dim3(T), 0,
-                               m->stream, S, seg_lo, std::min(S, seg_hi), pos_lo, pos_hi, total, e_lo,
-                               e_hi, m->rng_win, m->rng_vbuf);
+                               stream, S, seg_lo, std::min(S, seg_hi), pos_lo, pos_hi, total, e_lo,
+                               e_hi, win, vbuf);
         else
             hipLaunchKernelGGL((trlda::draw_log_kernel<T, trlda::kRngSegmentSmall>), dgrid, dim3(T), 0,
-                               m->stream, S, seg_lo, std::min(S, seg_hi), pos_lo, pos_hi, total, e_lo,
-                               e_hi, m->rng_win, m->rng_vbuf);
+                               stream, S, seg_lo, std::min(S, seg_hi), pos_lo, pos_hi, total, e_lo,
+                               e_hi, win, vbuf);
         if (e_hi > e_lo)
             hipLaunchKernelGGL(trlda::gamma_sum_kernel<T>,
-                               dim3((unsigned)((e_hi - e_lo + T - 1) / T)), dim3(T), 0, m->stream, total,
+                               dim3((unsigned)((e_hi - e_lo + T - 1) / T)), dim3(T), 0, stream, total,
                                e_lo, e_hi, (int)(p1 - p0), p0 == 0 ? 1 : 0,
-                               p1 == passes ? divisor : 1.0, m->rng_vbuf, out_dev);
+                               p1 == passes ? divisor : 1.0, vbuf, out_dev);
     }
     HIP_TRY(hipGetLastError());
     // the host stream moves on by the same number of draws
@@ -2092,6 +2202,8 @@ int trlda_model_destroy(trlda_model *m)
         return TRLDA_OK;
     if (hipSetDevice(m->device) == hipSuccess) {
         (void)hipStreamSynchronize(m->stream);
+        if (m->draw_stream)
+            (void)hipStreamSynchronize(m->draw_stream);
         (void)hipFree(m->lambda); (void)hipFree(m->alpha); (void)hipFree(m->eeb); (void)hipFree(m->psi_sum);
         (void)hipFree(m->xbuf); (void)hipFree(m->xerr);
         (void)hipFree(m->partial); (void)hipFree(m->counter); (void)hipFree(m->epg); (void)hipFree(m->tw_csr);
@@ -2100,6 +2212,17 @@ int trlda_model_destroy(trlda_model *m)
         (void)hipFree(m->upd_partial); (void)hipFree(m->ada_gradient); (void)hipFree(m->reduce_out);
         (void)hipFree(m->carry_out); (void)hipFree(m->upd_groups); (void)hipFree(m->group_counter);
         (void)hipFree(m->iters); (void)hipFree(m->rng_win); (void)hipFree(m->rng_vbuf);
+        // a gamma0 drawn ahead that nobody will use: the host stream goes back to its turn
+        if (m->spec.valid)
+            trlda_host::rng_speculation_cancel_if(m->spec.token);
+        if (m->draw_stream) {
+            (void)hipStreamSynchronize(m->draw_stream);
+            (void)hipStreamDestroy(m->draw_stream);
+            (void)hipEventDestroy(m->ev_main);
+            (void)hipEventDestroy(m->ev_draw);
+        }
+        (void)hipFree(m->gspec[0]); (void)hipFree(m->gspec[1]);
+        (void)hipFree(m->rng_win2); (void)hipFree(m->rng_vbuf2);
         for (int i = 0; i < 2; ++i) {
             if (m->stage[i])
                 (void)hipHostFree(m->stage[i]);
@@ -2340,6 +2463,7 @@ int trlda_model_estep_host(trlda_model *m, const trlda_batch *b, double *gamma, 
             return rc;
         iters_dev = m->iters;
     }
+    m->gamma0_src = nullptr;                           // the caller's gamma, not one drawn ahead
     if (gbytes)
         HIP_TRY(hipMemcpyAsync(m->gamma, gamma, gbytes, hipMemcpyHostToDevice, m->stream));
     rc = estep_device(m, b, m->gamma, m->sstats, max_iter, threshold, iters_dev);
@@ -2374,6 +2498,7 @@ int trlda_model_lower_bound(trlda_model *m, const trlda_batch *b, double *gamma,
     const int K = m->K, V = m->V, B = b->B;
     const size_t KV = (size_t)K * V;
     const size_t gbytes = (size_t)K * B * sizeof(double);
+    m->gamma0_src = nullptr;                           // the caller's gamma, not one drawn ahead
     HIP_TRY(hipMemcpyAsync(m->gamma, gamma, gbytes, hipMemcpyHostToDevice, m->stream));
     rc = estep_device(m, b, m->gamma, m->sstats, max_iter, threshold, nullptr);   // :309
     if (rc)
@@ -2911,11 +3036,12 @@ int fresh_gamma_columns(trlda_model *m, int B, int doc_lo, int Bl, std::vector<d
 {
     const int K = m->K;
     if (!m->host_gamma_draw)                                 // this rank's columns, on the device
-        return sample_gamma_on_device(m, (long long)K * B, 100, 100., m->gamma,
-                                      (long long)K * doc_lo, (long long)K * (doc_lo + Bl));
+        return device_gamma_now_or_ahead(m, (long long)K * B, (long long)K * doc_lo,
+                                         (long long)K * (doc_lo + Bl));
     full.resize((size_t)K * B);
     trlda_sample_gamma_init(K, B, full.data());
     if (Bl > 0) {
+        m->gamma0_src = nullptr;
         HIP_TRY(hipMemcpyAsync(m->gamma, full.data() + (size_t)K * doc_lo,
                                (size_t)K * Bl * sizeof(double), hipMemcpyHostToDevice, m->stream));
         HIP_TRY(hipStreamSynchronize(m->stream));            // `full` is reused by the next draw
@@ -3312,6 +3438,14 @@ int trlda_model_set_fused_update(trlda_model *m, int fused)
 }
 
 int64_t trlda_model_d2h_bytes(const trlda_model *m) { return m ? m->d2h_bytes : 0; }
+
+int trlda_model_set_draw_ahead(trlda_model *m, int enabled)
+{
+    if (!m)
+        return fail(TRLDA_ERR_ARG, "model is NULL");
+    m->draw_ahead = enabled != 0;
+    return TRLDA_OK;
+}
 
 int trlda_model_set_host_gamma_draw(trlda_model *m, int host)
 {
