@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/trlda_hip.h"
+#include "../../trlda_amd/csrc/host_common.h"
 
 static int failures = 0;
 #define CHECK(cond)                                                              \
@@ -130,6 +131,34 @@ static void rng_checks()
         CHECK(std::isfinite(v) && v > 0.0);
 }
 
+// a draw made ahead of its turn: cancelled, the stream is where it was; claimed, it has moved on
+static void speculation_checks()
+{
+    double a[4], b[4], c[8];
+    setenv("TRLDA_SAMPLE_THREADS", "1", 1);
+    trlda_seed(5);
+    trlda_sample_gamma(2, 2, 1, a);
+    trlda_seed(5);
+    const uint64_t t1 = trlda_host::rng_speculate_begin();
+    trlda_host::rng_advance(1000);
+    trlda_sample_gamma(2, 2, 1, b);                  // any other use of the generator cancels it
+    CHECK(!std::memcmp(a, b, sizeof(a)));
+    CHECK(!trlda_host::rng_speculation_claim(t1));
+    trlda_seed(5);
+    trlda_sample_gamma(4, 2, 1, c);                  // eight draws: the last four are ...
+    trlda_seed(5);
+    const uint64_t t2 = trlda_host::rng_speculate_begin();
+    trlda_host::rng_advance(4);
+    CHECK(trlda_host::rng_speculation_claim(t2));    // ... what follows a claimed draw of four
+    trlda_sample_gamma(2, 2, 1, b);
+    CHECK(!std::memcmp(b, c + 4, sizeof(b)));
+    const uint64_t t3 = trlda_host::rng_speculate_begin();
+    trlda_host::rng_advance(77);
+    trlda_host::rng_speculation_cancel_if(t3 + 1);   // somebody else's token: nothing happens
+    CHECK(trlda_host::rng_speculation_claim(t3));
+    unsetenv("TRLDA_SAMPLE_THREADS");
+}
+
 static void eb_checks()
 {
     const int K = 37;
@@ -159,8 +188,10 @@ int main(int argc, char **argv)
     const bool thread_mode = argc > 1 && !std::strcmp(argv[1], "threads");
     parser_checks(thread_mode);
     rng_checks();
-    if (!thread_mode)
+    if (!thread_mode) {
+        speculation_checks();
         eb_checks();
+    }
     if (failures) {
         std::fprintf(stderr, "%d check(s) failed\n", failures);
         return 1;
