@@ -471,12 +471,14 @@ int trlda_model_set_keep_sstats(trlda_model *model, int keep);
  * in gamma0) -- and the host stream is advanced by the same number of draws.  host = 1: draw on
  * the host instead, bit for bit the reference's values (K * B * 100 glibc logarithms per call). */
 int trlda_model_set_host_gamma_draw(trlda_model *model, int host);
-/* The device draw of the NEXT fresh gamma0 of the same shape is made ahead, on a stream of the
- * model's own, while the current call's kernels run (the draw is 44 of the 89 us of an update
- * without trust-region loop at K = 100, B = 200), with the host stream advanced ahead of its turn.
- * Whatever else touches the generator first -- trlda_seed, a host draw, another model, another
- * shape -- puts the stream back and the draw is repeated in its turn: the ORDER of draws is the
- * reference's in every case.  enabled = 0: every draw in its turn, on the model's stream. */
+/* enabled = 1: the device draw of the NEXT fresh gamma0 of the same shape is made ahead, on a
+ * stream of the model's own, while the current call's kernels run, with the host stream advanced
+ * ahead of its turn.  Whatever else touches the generator first -- trlda_seed, a host draw, another
+ * model, another shape -- puts the stream back and the draw is repeated in its turn: the ORDER of
+ * draws is the reference's in every case.  Off by default (TRLDA_DRAW_AHEAD=1 turns it on for
+ * every model): it gains 5 % (200 documents) to 13 % (1600) of an update without trust-region
+ * loop at K = 100 in a process with few streams, and LOSES 20 % where the process has more
+ * streams than hardware queues (bench.py beside torch): the second stream then shares a queue. */
 int trlda_model_set_draw_ahead(trlda_model *model, int enabled);
 /* out_dev[rows x cols] = sampleGamma(rows, cols, passes) / divisor (src/utils.cpp:224-231) on
  * the device, as above (divisor 1 for the bare sum). */

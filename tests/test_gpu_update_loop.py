@@ -482,7 +482,7 @@ def test_gamma_drawn_ahead_keeps_the_order_of_draws(hip, oracle):
     """The next update's gamma0 is drawn ahead on a stream of its own with the host stream
     advanced before its turn (trlda_model_set_draw_ahead): whatever touches the generator in
     between -- a host draw, a seed, another model, another batch size, a lower bound -- the
-    ORDER of draws stays the reference's: the same sequence of calls with drawing ahead on and
+    ORDER of draws stays the reference's (the switch is off by default; here it is forced): the same sequence of calls with drawing ahead on and
     off ends at bitwise the same lambda, gamma and generator state, for OnlineLDA (with and
     without the trust-region loop), BatchLDA epochs and CumulativeLDA."""
     import trlda_amd

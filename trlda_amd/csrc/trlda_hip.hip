@@ -289,7 +289,7 @@ struct trlda_model {
     size_t cap_iters = 0;
     // gamma0 of the NEXT fresh E-step, drawn ahead on a stream of its own while this call's
     // kernels run (fresh_gamma_device): two buffers alternate, `spec` says what is in flight
-    bool draw_ahead = true;                     // trlda_model_set_draw_ahead
+    bool draw_ahead = false;                    // trlda_model_set_draw_ahead / TRLDA_DRAW_AHEAD=1
     hipStream_t draw_stream = nullptr;
     hipEvent_t ev_main = nullptr, ev_draw = nullptr;
     double *gspec[2] = {nullptr, nullptr};
@@ -2192,6 +2192,8 @@ int trlda_model_create(trlda_model **out, int device, int K, int V)
         trlda_model_destroy(m);
         return rc;
     }
+    if (const char *env = std::getenv("TRLDA_DRAW_AHEAD"))       // 1 = draw the next gamma0 ahead
+        m->draw_ahead = env[0] != '0';
     *out = m;
     return TRLDA_OK;
 }
