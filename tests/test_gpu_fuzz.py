@@ -1,0 +1,26 @@
+"""A short run of the randomised E-step check (tests/fuzz_estep.py): random K, V, batch sizes,
+document lengths across every tier of the launch, duplicate ids, zero counts, iteration limits
+and thresholds; both statistics modes, split documents on and off; gamma, statistics and
+per-document iteration counts against the oracle."""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip(hip_lib):
+    from trlda_amd import _ffi
+    assert _ffi.device_count() >= 1, "GPU tests need a visible MI355X"
+    return hip_lib
+
+
+@pytest.mark.parametrize("seed", [3, 11])
+def test_random_shapes_agree_with_the_oracle(hip, seed):
+    import fuzz_estep
+    worst_g, worst_s = fuzz_estep.main(["--cases", "16", "--seed", str(seed)])   # exits non-zero on a mismatch
+    assert worst_g < 1e-8 and worst_s < 1e-7
