@@ -24,3 +24,8 @@ def test_random_shapes_agree_with_the_oracle(hip, seed):
     import fuzz_estep
     worst_g, worst_s = fuzz_estep.main(["--cases", "16", "--seed", str(seed)])   # exits non-zero on a mismatch
     assert worst_g < 1e-8 and worst_s < 1e-7
+
+
+def test_random_update_calls_agree_with_the_oracle(hip):
+    import fuzz_update
+    assert fuzz_update.main(["--cases", "8", "--seed", "5"]) < 1e-8

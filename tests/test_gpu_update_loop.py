@@ -6,6 +6,7 @@ launch sequence, size-independent invariants at the full per-GPU batch sizes, an
 empirical-Bayes reductions staying on the device.
 """
 import ctypes as C
+import math
 
 import numpy as np
 import pytest
@@ -64,7 +65,7 @@ def oracle_online_update(orc, lam, alpha, eta, D, docs, g0, count, max_iter_tr, 
     """onlinelda.cpp:53-111 composed from the oracle's pieces (its E-step on `nthreads`, which
     equals its serial one bit for bit); init_gamma=True, so g0 is the only draw."""
     B = len(docs)
-    rho = float(np.power(tau + count, -kappa))
+    rho = math.pow(tau + count, -kappa)               # libm, as the reference (numpy.power differs by an ulp at e.g. (12, -.9))
     lam_prime = lam
     g = g0
     if max_iter_tr > 0:
@@ -241,7 +242,7 @@ def test_fused_update_equals_plain_sequence(hip, oracle, sampler, K, V, B):
     lam = lam0
     sampler.seed(61)
     for i, tr in enumerate((3, 0, 2)):
-        rho = float(np.power(100. + i, -.7))
+        rho = math.pow(100. + i, -.7)
         lam_prime = lam
         if tr > 0:
             lam = oracle.tr_init(lam_prime, docs[i].indptr, docs[i].ids, docs[i].cnts, D, rho, .3)

@@ -32,6 +32,7 @@ The per-rank computation is behind a small *engine* interface so that the shardi
 :class:`HipEngine` and nothing else ships.
 """
 import ctypes as C
+import math
 
 import numpy as np
 
@@ -532,7 +533,7 @@ class ShardedOnlineLDA(_ShardedLDA):
         if rho < 0. and adaptive:
             rho = self._ada_rho                                  # onlinelda.cpp:61-62
         if rho < 0.:
-            rho = float(np.power(tau + self.update_count, -kappa))   # onlinelda.cpp:59-66
+            rho = math.pow(tau + self.update_count, -kappa)   # libm, as onlinelda.cpp:59-66 (numpy.power differs by an ulp at e.g. (12, -.9))
         eng = self.engine
         eta_old = self._eta
         keep = bool(adaptive and update_lambda)
