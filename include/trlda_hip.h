@@ -536,6 +536,18 @@ double trlda_eb_eta_line_search(double eta, double sum_psi_lambda, const double 
 int trlda_model_online_eb(trlda_model *model, void *rccl_comm, int B_local, int B_total, double rho,
                           int update_alpha, int update_eta, double min_alpha, double min_eta,
                           double *alpha_host, double *eta);
+/* The same in two halves, so that the host can prepare the next mini-batch (parse, convert,
+ * upload) while the device still works on this one: _begin enqueues the sums and their way back
+ * to pinned host memory and returns; _finish waits for them, takes the steps and puts the new
+ * alpha on the device.  Between the two the model runs no E-step (TRLDA_ERR_ARG): the caller
+ * finishes before its next call -- trlda.models.OnlineLDA does, at the start of the next
+ * update_parameters / do_e_step / lower_bound and in the alpha / eta getters.  _pending: 1 between
+ * the halves. */
+int trlda_model_online_eb_begin(trlda_model *model, void *rccl_comm, int B_local, int B_total,
+                                int update_alpha, int update_eta);
+int trlda_model_online_eb_finish(trlda_model *model, double rho, double min_alpha, double min_eta,
+                                 double *alpha_host, double *eta);
+int trlda_model_online_eb_pending(const trlda_model *model);
 /* test hook: psi and psi' as eb_steps.cpp evaluates them */
 void trlda_debug_host_psi(int n, const double *x, double *psi_out, double *psi1_out);
 

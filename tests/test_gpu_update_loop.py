@@ -724,3 +724,40 @@ def test_word_count_sums_beyond_32_bits(hip, oracle, sampler):
         assert rho == rho_o
         assert relerr(m.lambdas, lam) < 1e-8, (big, relerr(m.lambdas, lam))
         m.close()
+
+
+def test_deferred_empirical_bayes_step_changes_nothing(hip):
+    """update_parameters(update_alpha, update_eta) leaves the wait for the device sums to the next
+    call (the host prepares the next mini-batch meanwhile): same alpha, eta and lambda, bit for
+    bit, as finishing the step at once; the getters finish it; between the halves the C ABI
+    refuses E-steps and a new alpha."""
+    import trlda_amd
+    K, V, B, D = 100, 7000, 200, 100000
+    lam0 = random_lambda(K, V, 9)
+    batches = [corpus(B, V, seed=880 + i).to_list() for i in range(3)]
+    results = []
+    for at_once in (False, True):
+        m = online_model(K, V, lam0, D)
+        for i, docs in enumerate(batches):
+            trlda_amd.seed(70 + i)
+            m.update_parameters(docs, max_iter_tr=2, max_iter_inference=10, update_alpha=True,
+                                update_eta=True)
+            if at_once:
+                m._settle()
+            else:
+                assert hip.trlda_model_online_eb_pending(m._handle) == 1
+        if not at_once:
+            # the C ABI between the halves
+            dev = m.upload(batches[0])
+            assert hip.trlda_model_estep_resident(m._handle, dev.handle, 5, 1e-3) == trlda_amd._ffi.ERR_ARG
+            assert hip.trlda_model_set_alpha(m._handle, np.full(K, .1)) == trlda_amd._ffi.ERR_ARG
+            dev.close()
+            eta = m.eta                                          # finishes the step
+            assert hip.trlda_model_online_eb_pending(m._handle) == 0
+            results.append((m.alpha, eta, m.lambdas))
+        else:
+            results.append((m.alpha, m.eta, m.lambdas))
+        m.close()
+    (a0, e0, l0), (a1, e1, l1) = results
+    assert np.array_equal(a0, a1) and e0 == e1 and np.array_equal(l0, l1)
+    assert np.all(a0 != .1) and e0 != .3

@@ -2,6 +2,12 @@
 DeviceBatch) at BASELINE.json's configurations: the fused device path against the plain launch
 sequence, with and without the host-side gamma0 draw.
 
+Every OnlineLDA call gets a mini-batch of its own (a model fed the same mini-batch again and
+again fits it, and its E-steps then leave through the convergence test after a few iterations:
+0.33 instead of 0.49 ms per call at K = 100 -- what rounds 1-2 and the first half of round 3
+reported).  BatchLDA, whose epochs do revisit their corpus, starts every timed call from the same
+lambda.
+
     python tools/update_rate.py [--configs small,c5a,c5b,c4] [--package trlda_amd]
 
 Run on the GPU box from the repo root.  `--package` lets the same script time another tree
@@ -54,7 +60,9 @@ def main():
         K, V, B, kind, calls = CONFIGS[name]
         rng = np.random.RandomState(1)
         lam = np.asfortranarray(rng.gamma(100., .01, (K, V)))
-        docs = CSRDocuments(*make_corpus(B, V, seed=20150706 + K, mean_unique=100))
+        n_batches = calls + 1 if kind == "online" else 1
+        corpora = [CSRDocuments(*make_corpus(B, V, seed=20150706 + K + 1000 * i, mean_unique=100))
+                   for i in range(n_batches)]
         # time of the host-side gamma0 draw alone (sampleGamma(K, B, 100) / 100, lda.cpp:135)
         g = np.empty((K, B), order="F")
         L.trlda_sample_gamma_init(K, B, g)
@@ -83,20 +91,32 @@ def main():
                 L.trlda_model_set_draw_ahead(m._handle, 0)
             if args.host_draw and hasattr(L, "trlda_model_set_host_gamma_draw"):
                 L.trlda_model_set_host_gamma_draw(m._handle, 1)
-            batch = m.upload(docs)
+            batches = [m.upload(d) for d in corpora]
             variants = [("max_iter_tr=10", dict(max_iter_tr=10, max_iter_inference=20)),
                         ("max_iter_tr=0", dict(max_iter_tr=0, max_iter_inference=20))] \
                 if kind == "online" else \
                 [("1 epoch, max_iter_inference=100", dict(max_epochs=1, max_iter_inference=100)),
                  ("1 epoch, max_iter_inference=20", dict(max_epochs=1, max_iter_inference=20))]
             for label, kw in variants:
-                m.update_parameters(batch, **kw)          # warm-up (allocations, code objects)
-                sync(m)
-                t = time.perf_counter()
-                for _ in range(calls):
-                    m.update_parameters(batch, **kw)
-                sync(m)
-                dt = (time.perf_counter() - t) / calls
+                if kind == "online":
+                    m.lambdas = lam
+                    m.update_parameters(batches[0], **kw)     # warm-up (allocations, code objects)
+                    sync(m)
+                    t = time.perf_counter()
+                    for i in range(calls):
+                        m.update_parameters(batches[1 + i], **kw)
+                    sync(m)
+                    dt = (time.perf_counter() - t) / calls
+                else:
+                    m.update_parameters(batches[0], **kw)     # warm-up
+                    dt = 0.0
+                    for i in range(calls):
+                        m.lambdas = lam
+                        sync(m)
+                        t = time.perf_counter()
+                        m.update_parameters(batches[0], **kw)
+                        sync(m)
+                        dt += (time.perf_counter() - t) / calls
                 print("%-5s K=%d V=%d B=%d %-6s %-32s %9.3f ms/call  %10.0f docs/s  "
                       "(sampleGamma(K, B, 100) on the host alone: %.3f ms)"
                       % (name, K, V, B, mode, label, dt * 1e3, B / dt, draw_ms))

@@ -134,6 +134,10 @@ _SIGNATURES = {
                                               C.c_double, C.c_double]),
     "trlda_model_online_eb": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,
                                         C.c_double, C.c_double, f64p, C.POINTER(C.c_double)]),
+    "trlda_model_online_eb_begin": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "trlda_model_online_eb_finish": (C.c_int, [vp, C.c_double, C.c_double, C.c_double, f64p,
+                                               C.POINTER(C.c_double)]),
+    "trlda_model_online_eb_pending": (C.c_int, [vp]),
     "trlda_debug_host_psi": (None, [C.c_int, f64p, f64p, f64p]),
     "trlda_model_adaptive_stats": (C.c_int, [vp, C.c_double, C.c_double, C.c_double,
                                             C.POINTER(C.c_double), C.POINTER(C.c_double)]),

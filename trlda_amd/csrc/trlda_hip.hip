@@ -284,6 +284,15 @@ struct trlda_model {
     // adaptive learning rate: running average of the updates (onlinelda.cpp:170), K x V
     double *ada_gradient = nullptr;
     double *reduce_out = nullptr;               // small buffer for block results of reductions
+    // empirical-Bayes sums on their way to the host (trlda_model_online_eb_begin / _finish):
+    // K + G + K doubles in pinned memory, complete when eb_event has passed
+    struct {
+        bool active = false, alpha = false, eta = false;
+        int G = 0, B_total = 0;
+        double *host = nullptr;
+        size_t cap = 0;
+        hipEvent_t event = nullptr;
+    } eb;
     size_t cap_reduce = 0;
     int32_t *iters = nullptr;                   // per-document iteration counts (estep_host)
     size_t cap_iters = 0;
@@ -975,6 +984,9 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
     const size_t KV = (size_t)K * V;
     if (b->V != V || db->V != V)
         return fail(TRLDA_ERR_SHAPE, "batch was created for a different vocabulary size");
+    if (m->eb.active)
+        return fail(TRLDA_ERR_ARG, "an empirical-Bayes step is on its way (its alpha is not on the device "
+                                   "yet): trlda_model_online_eb_finish first");
     if (b->device != m->device || db->device != m->device)
         return fail(TRLDA_ERR_ARG, "batch and model live on different devices");
     int rc = ensure_batch_workspace(m, b);
@@ -2208,6 +2220,10 @@ int trlda_model_destroy(trlda_model *m)
             (void)hipStreamSynchronize(m->draw_stream);
         (void)hipFree(m->lambda); (void)hipFree(m->alpha); (void)hipFree(m->eeb); (void)hipFree(m->psi_sum);
         (void)hipFree(m->xbuf); (void)hipFree(m->xerr);
+        if (m->eb.host)
+            (void)hipHostFree(m->eb.host);
+        if (m->eb.event)
+            (void)hipEventDestroy(m->eb.event);
         (void)hipFree(m->partial); (void)hipFree(m->counter); (void)hipFree(m->epg); (void)hipFree(m->tw_csr);
         (void)hipFree(m->tw_word); (void)hipFree(m->dp_gather_own); (void)trlda_model_dp_direct_close(m); (void)hipFree(m->lambda_prime); (void)hipFree(m->sstats); (void)hipFree(m->gamma);
         (void)hipFree(m->wordcounts); (void)hipFree(m->rs_full); (void)hipFree(m->rs_static);
@@ -2364,6 +2380,9 @@ int trlda_model_set_alpha(trlda_model *m, const double *host_alpha)
         return rc;
     if (!host_alpha)
         return fail(TRLDA_ERR_ARG, "alpha is NULL");
+    if (m->eb.active)
+        return fail(TRLDA_ERR_ARG, "an empirical-Bayes step is on its way and would overwrite this alpha: "
+                                   "trlda_model_online_eb_finish first");
     for (int k = 0; k < m->K; ++k)
         if (host_alpha[k] < 0.)
             return fail(TRLDA_ERR_VALUE, "Alpha should not be negative.");  // lda.h:147-159
@@ -3608,15 +3627,16 @@ int trlda_model_eb_lambda_stats(trlda_model *m, double *sum_psi_lambda, double *
 // trip to the host: the device sums over gamma (and over the ranks, when a communicator is
 // given) and over lambda are enqueued, K + G + K doubles come back in one synchronisation, the
 // K-sized Newton steps run here (eb_steps.cpp), the new alpha goes back to the device.
-int trlda_model_online_eb(trlda_model *m, void *rccl_comm, int B_local, int B_total, double rho,
-                          int update_alpha, int update_eta, double min_alpha, double min_eta,
-                          double *alpha_host, double *eta)
+int trlda_model_online_eb_begin(trlda_model *m, void *rccl_comm, int B_local, int B_total,
+                                int update_alpha, int update_eta)
 {
     int rc = check_model(m);
     if (rc)
         return rc;
-    if (B_local < 0 || B_total <= 0 || !alpha_host || !eta)
+    if (B_local < 0 || B_total <= 0)
         return fail(TRLDA_ERR_ARG, "bad online_eb arguments");
+    if (m->eb.active)
+        return fail(TRLDA_ERR_ARG, "an empirical-Bayes step is already on its way: finish it first");
     if (!update_alpha && !update_eta)
         return TRLDA_OK;
     const int K = m->K;
@@ -3629,7 +3649,18 @@ int trlda_model_online_eb(trlda_model *m, void *rccl_comm, int B_local, int B_to
     rc = grow(&m->reduce_out, &m->cap_reduce, off_lam + (size_t)G);
     if (rc)
         return rc;
-    std::vector<double> host((size_t)K + (size_t)G + (size_t)K);
+    const size_t hn = (size_t)K + (size_t)G + (size_t)K;
+    if (m->eb.cap < hn) {
+        if (m->eb.host)
+            (void)hipHostFree(m->eb.host);
+        m->eb.host = nullptr;
+        m->eb.cap = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&m->eb.host), hn * sizeof(double), hipHostMallocDefault));
+        m->eb.cap = hn;
+    }
+    if (!m->eb.event)
+        HIP_TRY(hipEventCreateWithFlags(&m->eb.event, hipEventDisableTiming));
+    double *const host = m->eb.host;
     if (update_alpha) {
         double *sum = m->reduce_out + off_sum;
         if (B_local > 0) {
@@ -3650,8 +3681,7 @@ int trlda_model_online_eb(trlda_model *m, void *rccl_comm, int B_local, int B_to
             rc = allreduce_f64(m, rccl_comm, sum, (size_t)K);        // onlinelda.cpp:128 across ranks
         if (rc)
             return rc;
-        HIP_TRY(hipMemcpyAsync(host.data(), sum, (size_t)K * sizeof(double), hipMemcpyDeviceToHost,
-                               m->stream));
+        HIP_TRY(hipMemcpyAsync(host, sum, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, m->stream));
         m->d2h_bytes += (int64_t)K * sizeof(double);
     }
     if (update_eta) {
@@ -3675,30 +3705,67 @@ int trlda_model_online_eb(trlda_model *m, void *rccl_comm, int B_local, int B_to
         }
         if (rc)
             return rc;
-        HIP_TRY(hipMemcpyAsync(host.data() + K, m->reduce_out + off_lam, (size_t)G * sizeof(double),
+        HIP_TRY(hipMemcpyAsync(host + K, m->reduce_out + off_lam, (size_t)G * sizeof(double),
                                hipMemcpyDeviceToHost, m->stream));
-        HIP_TRY(hipMemcpyAsync(host.data() + K + G, m->rs_full, (size_t)K * sizeof(double),
-                               hipMemcpyDeviceToHost, m->stream));
+        HIP_TRY(hipMemcpyAsync(host + K + G, m->rs_full, (size_t)K * sizeof(double), hipMemcpyDeviceToHost,
+                               m->stream));
         m->d2h_bytes += (int64_t)((size_t)G + K) * sizeof(double);
     }
-    HIP_TRY(hipStreamSynchronize(m->stream));                        // the one trip
-    if (update_alpha) {
+    HIP_TRY(hipEventRecord(m->eb.event, m->stream));
+    m->eb.active = true;
+    m->eb.alpha = update_alpha != 0;
+    m->eb.eta = update_eta != 0;
+    m->eb.G = G;
+    m->eb.B_total = B_total;
+    return TRLDA_OK;
+}
+
+int trlda_model_online_eb_pending(const trlda_model *m) { return m && m->eb.active ? 1 : 0; }
+
+int trlda_model_online_eb_finish(trlda_model *m, double rho, double min_alpha, double min_eta,
+                                 double *alpha_host, double *eta)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!alpha_host || !eta)
+        return fail(TRLDA_ERR_ARG, "bad online_eb arguments");
+    if (!m->eb.active)
+        return TRLDA_OK;
+    m->eb.active = false;
+    const int K = m->K, G = m->eb.G;
+    HIP_TRY(hipEventSynchronize(m->eb.event));                       // the one trip
+    const double *host = m->eb.host;
+    if (m->eb.alpha) {
         std::vector<double> next((size_t)K);
-        rc = trlda_eb_online_alpha_step(K, alpha_host, host.data(), (double)B_total, rho, min_alpha,
+        rc = trlda_eb_online_alpha_step(K, alpha_host, host, (double)m->eb.B_total, rho, min_alpha,
                                         next.data());
         if (rc)
             return rc;
         std::memcpy(alpha_host, next.data(), (size_t)K * sizeof(double));
-        HIP_TRY(hipMemcpyAsync(m->alpha, alpha_host, (size_t)K * sizeof(double), hipMemcpyHostToDevice,
+        // (staged through the pinned buffer's first K doubles: the caller's array may be gone
+        // before the copy runs)
+        std::memcpy(m->eb.host, alpha_host, (size_t)K * sizeof(double));
+        HIP_TRY(hipMemcpyAsync(m->alpha, m->eb.host, (size_t)K * sizeof(double), hipMemcpyHostToDevice,
                                m->stream));
     }
-    if (update_eta) {
+    if (m->eb.eta) {
         double total = 0.0;
         for (int g = 0; g < G; ++g)
             total += host[(size_t)K + (size_t)g];
-        *eta = trlda_eb_online_eta_step(*eta, total, host.data() + K + G, K, m->V, rho, min_eta);
+        *eta = trlda_eb_online_eta_step(*eta, total, host + K + G, K, m->V, rho, min_eta);
     }
     return TRLDA_OK;
+}
+
+int trlda_model_online_eb(trlda_model *m, void *rccl_comm, int B_local, int B_total, double rho,
+                          int update_alpha, int update_eta, double min_alpha, double min_eta,
+                          double *alpha_host, double *eta)
+{
+    if (!alpha_host || !eta)
+        return fail(TRLDA_ERR_ARG, "bad online_eb arguments");
+    const int rc = trlda_model_online_eb_begin(m, rccl_comm, B_local, B_total, update_alpha, update_eta);
+    return rc ? rc : trlda_model_online_eb_finish(m, rho, min_alpha, min_eta, alpha_host, eta);
 }
 
 int trlda_model_adaptive_stats(trlda_model *m, double eta, double scale, double tau,

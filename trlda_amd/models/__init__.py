@@ -101,7 +101,25 @@ class LDA(Distribution):
             lam = np.asfortranarray(_lambda, dtype=np.float64)
         _ffi.check(L.trlda_model_set_lambda(self._handle, lam))
 
+    # An empirical-Bayes step whose device sums are still on their way (OnlineLDA defers the wait
+    # so that the next mini-batch is parsed, converted and uploaded meanwhile): (rho, min_alpha,
+    # min_eta), finished by whoever next needs alpha, eta or an E-step.
+    _eb_pending = None
+
+    def _settle(self):
+        pending = self._eb_pending
+        if pending is None:
+            return
+        self._eb_pending = None
+        rho, min_alpha, min_eta = pending
+        alpha = np.ascontiguousarray(self._alpha, dtype=np.float64).copy()
+        eta = C.c_double(self._eta)
+        _ffi.check(_ffi.lib().trlda_model_online_eb_finish(self._handle, rho, min_alpha, min_eta,
+                                                          alpha, C.byref(eta)))
+        self._alpha, self._eta = alpha, float(eta.value)
+
     def close(self):
+        self._eb_pending = None
         if getattr(self, "_handle", None):
             _ffi.lib().trlda_model_destroy(self._handle)
             self._handle = None
@@ -148,6 +166,7 @@ class LDA(Distribution):
 
     @property
     def alpha(self):
+        self._settle()
         return self._alpha.reshape(-1, 1).copy(order="F")            # K x 1, ldainterface.cpp:87
 
     @alpha.setter
@@ -163,11 +182,13 @@ class LDA(Distribution):
                 raise RuntimeError("Alpha has wrong dimensionality.")  # lda.h:155-156
             if (new < 0.).any():
                 raise RuntimeError("Alpha should not be negative.")
+        self._settle()
         _ffi.check(_ffi.lib().trlda_model_set_alpha(self._handle, new))
         self._alpha = new
 
     @property
     def eta(self):
+        self._settle()
         return self._eta
 
     @eta.setter
@@ -175,6 +196,7 @@ class LDA(Distribution):
         value = float(value)
         if value < 0.:
             raise RuntimeError("Eta should not be negative.")        # lda.h:172-173
+        self._settle()
         self._eta = value
 
     # -- documents ---------------------------------------------------------------
@@ -201,6 +223,7 @@ class LDA(Distribution):
                 "Gibbs inference (lda.cpp:224-293) is outside the accelerated path.")
         batch, owned = self._batch(docs)
         try:
+            self._settle()
             B = len(batch)
             L = _ffi.lib()
             if latents is not None:
@@ -254,6 +277,7 @@ class LDA(Distribution):
             num_documents = self._default_num_documents()            # onlinelda.cpp:184-191
         batch, owned = self._batch(docs)
         try:
+            self._settle()
             B = len(batch)
             if B == 0:
                 raise RuntimeError("The lower bound needs at least one document.")
@@ -295,6 +319,7 @@ class LDA(Distribution):
         raise NotImplementedError("sample (lda.cpp:88-115) is outside the accelerated path.")
 
     def __str__(self):                                               # ldainterface.cpp:473-490
+        self._settle()
         return "Number of topics: %d\nEta: %.4g\nAlpha: %.4g, %.4g (min, max)\n" % (
             self._K, self._eta, self._alpha.min(), self._alpha.max())
 
@@ -357,6 +382,9 @@ class OnlineLDA(LDA):
         host keeps the K- and scalar-sized Newton steps."""
         batch, owned = self._batch(docs)
         try:
+            # (the previous call's empirical-Bayes step, if it is still on its way: the conversion
+            # and upload above ran beside the device's work on that call)
+            self._settle()
             B = len(batch)
             if B == 0:
                 return 1.0                                           # onlinelda.cpp:54-56
@@ -381,14 +409,15 @@ class OnlineLDA(LDA):
             if update_alpha or update_eta:                           # onlinelda.cpp:116-162
                 if update_alpha and not update_lambda:
                     self._resident_estep(batch, max_iter_inference)
-                # the device sums over gamma and lambda, one synchronisation, the K-sized Newton
-                # steps on the host, the new alpha back on the device
-                alpha = np.ascontiguousarray(self._alpha, dtype=np.float64).copy()
-                eta = C.c_double(self._eta)
-                _ffi.check(L.trlda_model_online_eb(
-                    self._handle, None, B, B, rho_used, int(bool(update_alpha)),
-                    int(bool(update_eta)), float(min_alpha), float(min_eta), alpha, C.byref(eta)))
-                self._alpha, self._eta = alpha, float(eta.value)
+                # the device sums over gamma and lambda and their way back to the host are
+                # enqueued; the wait, the K-sized Newton steps on the host and the new alpha's way
+                # to the device are left to whoever next needs alpha, eta or an E-step (_settle):
+                # a loop over mini-batches prepares its next one meanwhile
+                _ffi.check(L.trlda_model_online_eb_begin(
+                    self._handle, None, B, B, int(bool(update_alpha)), int(bool(update_eta))))
+                self._eb_pending = (rho_used, float(min_alpha), float(min_eta))
+                if update_lambda and adaptive:
+                    self._settle()
 
             if update_lambda and adaptive:                           # onlinelda.cpp:167-175
                 t = self._ada_tau
@@ -407,6 +436,7 @@ class OnlineLDA(LDA):
         return rho_used
 
     def __reduce__(self):                                            # onlineldainterface.cpp:265
+        self._settle()
         args = (self._V, self._K, self._num_documents, self.alpha, self._eta)
         state = (self.lambdas, self._update_count)
         return (self.__class__, args, state)
