@@ -1399,6 +1399,15 @@ struct TwView {
 // instead of a dependent scalar load per entry -- v_readlane hands entry u to every lane,
 // the row gathers of a group of four are in flight together (groups past the end are
 // skipped: most words have a handful of entries), products are added in list order.
+#ifndef TRLDA_STAT_ROWS
+#define TRLDA_STAT_ROWS 4
+#endif
+#ifndef TRLDA_STAT_ROWS2
+#define TRLDA_STAT_ROWS2 4
+#endif
+constexpr int kStatRows = TRLDA_STAT_ROWS;      // rows of exp(psi(gamma)) in flight per wave (8-byte gathers)
+constexpr int kStatRows2 = TRLDA_STAT_ROWS2;    // ... (16-byte gathers)
+
 template <int NH>
 __device__ __forceinline__ void word_segment_sum(int q0, int q1, int K, int kbase,
                                                  const int32_t *__restrict__ wdoc,
@@ -1410,28 +1419,35 @@ __device__ __forceinline__ void word_segment_sum(int q0, int q1, int K, int kbas
 #pragma unroll
     for (int h = 0; h < NH; ++h)
         kk[h] = min(kbase + 64 * h + lane, K - 1);  // lanes past K gather topic K-1, unused
+    // (the next pass's entries are requested before this pass's rows: their latency runs under
+    // the gathers instead of in front of them)
+    int dl = lane < q1 - q0 ? wdoc[q0 + lane] : 0;   // entries past the end: row 0, weight 0
+    double tl = lane < q1 - q0 ? tw_word[q0 + lane] : 0.0;
     for (int q = q0; q < q1; q += 16) {
         const int cnt = min(16, q1 - q);
-        const bool mine = lane < cnt;
-        const int dl = mine ? wdoc[q + lane] : 0;    // entries past the end: row 0, weight 0
-        const double tl = mine ? tw_word[q + lane] : 0.0;
+        const int dcur = dl;
         const int tlo = __double2loint(tl), thi = __double2hiint(tl);
+        if (q + 16 < q1) {                           // wave-uniform
+            const bool more = lane < q1 - q - 16;
+            dl = more ? wdoc[q + 16 + lane] : 0;
+            tl = more ? tw_word[q + 16 + lane] : 0.0;
+        }
 #pragma unroll
-        for (int grp = 0; grp < 4; ++grp) {
-            if (4 * grp < cnt) {                     // wave-uniform
-                double ev[4][NH];
+        for (int grp = 0; grp < 16 / kStatRows; ++grp) {
+            if (kStatRows * grp < cnt) {             // wave-uniform
+                double ev[kStatRows][NH];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const size_t row = (size_t)__builtin_amdgcn_readlane(dl, 4 * grp + u) * K;
+                for (int u = 0; u < kStatRows; ++u) {
+                    const size_t row = (size_t)__builtin_amdgcn_readlane(dcur, kStatRows * grp + u) * K;
 #pragma unroll
                     for (int h = 0; h < NH; ++h)
                         ev[u][h] = epg[row + kk[h]];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < kStatRows; ++u) {
                     const double tu =
-                        __hiloint2double(__builtin_amdgcn_readlane(thi, 4 * grp + u),
-                                         __builtin_amdgcn_readlane(tlo, 4 * grp + u));
+                        __hiloint2double(__builtin_amdgcn_readlane(thi, kStatRows * grp + u),
+                                         __builtin_amdgcn_readlane(tlo, kStatRows * grp + u));
 #pragma unroll
                     for (int h = 0; h < NH; ++h)
                         acc[h] = fma(tu, ev[u][h], acc[h]);   // +0 * finite past the end
@@ -1441,12 +1457,19 @@ __device__ __forceinline__ void word_segment_sum(int q0, int q1, int K, int kbas
     }
 }
 
-constexpr int kLongWord = 16;   // entries above which a word's list is split over the block
+// Entries above which a word's list is split over the waves of a block instead of being walked by
+// one wave: at least kLongWord, and per batch the smallest power-of-two multiple of it that leaves
+// at most kLongWordsTarget such words (trlda_batch::long_len, chosen when the batch is indexed).
+// A block per word pays off for the few hundred longest lists; at 12 500 documents most active
+// words have more than 16 entries, and walking ~20 000 of them with 256 blocks, a few dependent
+// latencies per word, was the whole 430 us of the kernel.
+constexpr int kLongWord = 16;
+constexpr int kLongWordsTarget = 512;
 
 template <int T>
 __global__ __launch_bounds__(T) void sstats_words_kernel(
-    int K, int V, int G_short, const int32_t *__restrict__ wptr, const int32_t *__restrict__ wdoc,
-    const int32_t *__restrict__ long_words, TwView tw_word,
+    int K, int V, int G_short, int long_len, const int32_t *__restrict__ wptr,
+    const int32_t *__restrict__ wdoc, const int32_t *__restrict__ long_words, TwView tw_word,
     const double *__restrict__ epg, const double *__restrict__ eeb, double *__restrict__ sstats)
 {
     constexpr int W = T / kWave;
@@ -1455,14 +1478,14 @@ __global__ __launch_bounds__(T) void sstats_words_kernel(
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
 
     if ((int)blockIdx.x < G_short) {
-        // ---- one wavefront per word; lists longer than kLongWord are left to the blocks
+        // ---- one wavefront per word; lists longer than long_len are left to the blocks
         // below.  Words are dealt round-robin over blocks (w = wave * G + block).
         const int w = wid * G_short + (int)blockIdx.x;
         if (w >= V)
             return;
         const int q0 = __builtin_amdgcn_readfirstlane(wptr[w]);
         const int len = __builtin_amdgcn_readfirstlane(wptr[w + 1]) - q0;
-        if (len > kLongWord)
+        if (len > long_len)
             return;
         for (int kb = 0; kb < K; kb += 2 * kWave) {
             double acc[2] = {0.0, 0.0};
@@ -1617,7 +1640,7 @@ __device__ __forceinline__ double update_one(const UpdateOut &o, size_t i, doubl
 
 template <int T, int NKB, bool EMIT>                 // EMIT: also UpdateOut::u_out (K <= 128 only)
 __global__ __launch_bounds__(T) void sstats_update_kernel(
-    int K, int N, int G_short, int n_long, const int32_t *__restrict__ list,
+    int K, int N, int G_short, int n_long, int long_len, const int32_t *__restrict__ list,
     const int32_t *__restrict__ wptr, const int32_t *__restrict__ wdoc,
     const int32_t *__restrict__ long_words, TwView tw_word,
     const double *__restrict__ epg, const double *eeb /* may be o.u_out */, UpdateOut o)
@@ -1636,7 +1659,7 @@ __global__ __launch_bounds__(T) void sstats_update_kernel(
             const int w = __builtin_amdgcn_readfirstlane(list ? list[p] : p);
             const int q0 = __builtin_amdgcn_readfirstlane(wptr[w]);
             const int len = __builtin_amdgcn_readfirstlane(wptr[w + 1]) - q0;
-            if (len > kLongWord)
+            if (len > long_len)
                 continue;                            // left to the blocks below
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
@@ -1753,28 +1776,33 @@ __device__ __forceinline__ void word_segment_sum2(int q0, int q1, int K, int kba
 #pragma unroll
     for (int h = 0; h < NH; ++h)
         kk[h] = min(kbase + 128 * h + 2 * lane, K - 2);   // lanes past K gather the last pair, unused
+    int dl = lane < q1 - q0 ? wdoc[q0 + lane] : 0;
+    double tl = lane < q1 - q0 ? tw_word[q0 + lane] : 0.0;
     for (int q = q0; q < q1; q += 16) {
         const int cnt = min(16, q1 - q);
-        const bool mine = lane < cnt;
-        const int dl = mine ? wdoc[q + lane] : 0;
-        const double tl = mine ? tw_word[q + lane] : 0.0;
+        const int dcur = dl;
         const int tlo = __double2loint(tl), thi = __double2hiint(tl);
+        if (q + 16 < q1) {                           // wave-uniform
+            const bool more = lane < q1 - q - 16;
+            dl = more ? wdoc[q + 16 + lane] : 0;
+            tl = more ? tw_word[q + 16 + lane] : 0.0;
+        }
 #pragma unroll
-        for (int grp = 0; grp < 4; ++grp) {
-            if (4 * grp < cnt) {                     // wave-uniform
-                double2 ev[4][NH];
+        for (int grp = 0; grp < 16 / kStatRows2; ++grp) {
+            if (kStatRows2 * grp < cnt) {            // wave-uniform
+                double2 ev[kStatRows2][NH];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const size_t row = (size_t)__builtin_amdgcn_readlane(dl, 4 * grp + u) * K;
+                for (int u = 0; u < kStatRows2; ++u) {
+                    const size_t row = (size_t)__builtin_amdgcn_readlane(dcur, kStatRows2 * grp + u) * K;
 #pragma unroll
                     for (int h = 0; h < NH; ++h)
                         ev[u][h] = *reinterpret_cast<const double2 *>(epg + row + kk[h]);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < kStatRows2; ++u) {
                     const double tu =
-                        __hiloint2double(__builtin_amdgcn_readlane(thi, 4 * grp + u),
-                                         __builtin_amdgcn_readlane(tlo, 4 * grp + u));
+                        __hiloint2double(__builtin_amdgcn_readlane(thi, kStatRows2 * grp + u),
+                                         __builtin_amdgcn_readlane(tlo, kStatRows2 * grp + u));
 #pragma unroll
                     for (int h = 0; h < NH; ++h) {
                         acc[h].x = fma(tu, ev[u][h].x, acc[h].x);
@@ -1813,7 +1841,7 @@ __device__ __forceinline__ double2 update_pair(const UpdateOut &o, size_t i, dou
 
 template <int T, int NKB, int NH, bool EMIT>         // NKB = ceil(K / (128 NH)), K even
 __global__ __launch_bounds__(T) void sstats_update2_kernel(
-    int K, int N, int G_short, int n_long, const int32_t *__restrict__ list,
+    int K, int N, int G_short, int n_long, int long_len, const int32_t *__restrict__ list,
     const int32_t *__restrict__ wptr, const int32_t *__restrict__ wdoc,
     const int32_t *__restrict__ long_words, TwView tw_word,
     const double *__restrict__ epg, const double *eeb /* may be o.u_out */, UpdateOut o)
@@ -1835,7 +1863,7 @@ __global__ __launch_bounds__(T) void sstats_update2_kernel(
             const int w = __builtin_amdgcn_readfirstlane(list ? list[p] : p);
             const int q0 = __builtin_amdgcn_readfirstlane(wptr[w]);
             const int len = __builtin_amdgcn_readfirstlane(wptr[w + 1]) - q0;
-            if (len > kLongWord)
+            if (len > long_len)
                 continue;                            // left to the blocks below
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {

@@ -145,7 +145,8 @@ struct trlda_batch {
     int32_t *active = nullptr;  // ids of the words that occur in the batch (ascending)
     int n_active = 0;
     uint8_t *active_flag = nullptr;   // V bytes: 1 for the words in `active`
-    int32_t *long_words = nullptr;   // words with more than kLongWord entries
+    int32_t *long_words = nullptr;   // words with more than long_len entries
+    int long_len = 16;               // (estep_kernels.h, kLongWord)
     int n_long = 0;
     // per document, in `order`: (document, length, CSR offset, 0) and its first kRegMaxN word
     // ids padded to that length -- the register kernel's workgroup finds everything it needs
@@ -733,7 +734,7 @@ int rowsums_from_scratch(trlda_model *m)
     return combine_rowsums(m, m->partial, g.G, nullptr, m->rs_full);
 }
 
-using sstats_update_fn = void (*)(int, int, int, int, const int32_t *, const int32_t *, const int32_t *,
+using sstats_update_fn = void (*)(int, int, int, int, int, const int32_t *, const int32_t *, const int32_t *,
                                   const int32_t *, trlda::TwView, const double *, const double *,
                                   trlda::UpdateOut);
 template <int T, int NKB, int NH, bool EMIT>
@@ -782,7 +783,7 @@ int launch_sstats_update(trlda_model *m, const trlda_batch *b, EstepOut &out)
     }
     // (data-parallel: expElogtheta rows of all ranks in the gathered buffer, dp_kernels.h)
     hipLaunchKernelGGL(kern, dim3(G_short + G_long), dim3(T), lds, m->stream, K, N, G_short,
-                       b->n_long, out.active_only ? b->active : nullptr, b->wptr,
+                       b->n_long, b->long_len, out.active_only ? b->active : nullptr, b->wptr,
                        m->dp ? b->dp_wrow : b->wdoc, b->long_words,
                        m->dp ? trlda::TwView{m->dp_gather, b->dp_wsrc} : trlda::TwView{m->tw_word, nullptr},
                        m->dp ? m->dp_gather : m->epg, m->eeb_cur, out.upd);
@@ -1430,7 +1431,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         if ((rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds)))           \
             return rc;                                                                     \
         hipLaunchKernelGGL(kern, dim3(G_short + b->n_long), dim3(TS), lds, m->stream, K, V, \
-                           G_short, b->wptr, dp ? b->dp_wrow : b->wdoc, b->long_words,     \
+                           G_short, b->long_len, b->wptr, dp ? b->dp_wrow : b->wdoc, b->long_words, \
                            dp ? trlda::TwView{m->dp_gather, b->dp_wsrc}                    \
                               : trlda::TwView{m->tw_word, nullptr},                        \
                            dp ? m->dp_gather : m->epg, m->eeb_cur, sstats_dev);            \
@@ -1861,11 +1862,23 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     for (int64_t i = 0; i < nnz; ++i)
         ++wptr[(size_t)ids[i] + 1];
     int n_active = 0, n_long = 0;
-    for (int w = 0; w < V; ++w) {
-        const int len = wptr[(size_t)w + 1];
-        n_active += len > 0;
-        n_long += len > trlda::kLongWord;
-        wptr[(size_t)w + 1] += wptr[(size_t)w];
+    int long_len = trlda::kLongWord;
+    {
+        // over[i]: words with more than kLongWord << i entries
+        constexpr int kLevels = 16;
+        int over[kLevels] = {0};
+        for (int w = 0; w < V; ++w) {
+            const int len = wptr[(size_t)w + 1];
+            n_active += len > 0;
+            for (int i = 0; i < kLevels && len > (trlda::kLongWord << i); ++i)
+                ++over[i];
+            wptr[(size_t)w + 1] += wptr[(size_t)w];
+        }
+        int level = 0;
+        while (level + 1 < kLevels && over[level] > trlda::kLongWordsTarget)
+            ++level;
+        long_len = trlda::kLongWord << level;
+        n_long = over[level];
     }
 
     // documents of more than kSplitMinN words take several workgroups (segments)
@@ -1959,7 +1972,7 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
         b->id = next_id.fetch_add(1);
     }
     b->device = device; b->V = V; b->B = B; b->nnz = nnz; b->max_n = max_n;
-    b->n_active = n_active; b->n_long = n_long;
+    b->n_active = n_active; b->n_long = n_long; b->long_len = long_len;
     b->sorted_len.resize(Bz);
     b->indptr_host.assign(indptr, indptr + Bz + 1);
     {
@@ -2037,7 +2050,7 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
             flag[w] = len > 0;
             if (len > 0)
                 active[na++] = w;
-            if (len > trlda::kLongWord)
+            if (len > long_len)
                 longw[nl++] = w;
         }
     }
