@@ -155,6 +155,12 @@ int trlda_batch_destroy(trlda_batch *batch);
 int trlda_batch_num_docs(const trlda_batch *batch);
 int64_t trlda_batch_nnz(const trlda_batch *batch);
 int trlda_batch_max_doc_len(const trlda_batch *batch);
+/* The number of entries above which a word's list of (document, weight) pairs is walked by a
+ * whole workgroup instead of one wavefront in the statistics kernels: 16 << i, the smallest that
+ * leaves at most 512 such words in this batch (csrc/estep_kernels.h, kLongWord); and how many
+ * words that is. */
+int trlda_batch_long_word_len(const trlda_batch *batch);
+int trlda_batch_num_long_words(const trlda_batch *batch);
 
 /* ---- device-resident model ---------------------------------------------- */
 

@@ -197,16 +197,26 @@ def test_batch_update_mass_balance_full_batch(hip):
 # fused device path == plain launch sequence, small tables and odd shapes
 # --------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("K,V,B", [(100, 7000, 200), (7, 900, 33), (333, 13000, 40),
-                                   (129, 40000, 64), (512, 9000, 24)])
+                                   (129, 40000, 64), (512, 9000, 24),
+                                   (100, 1500, 3000), (200, 2000, 2500), (129, 1200, 2000)])
 def test_fused_update_equals_plain_sequence(hip, oracle, sampler, K, V, B):
     """Every update loop through both device paths: OnlineLDA with and without the trust region
     (twice, so that the second call runs on carried row sums), BatchLDA, CumulativeLDA.  K odd
-    (8-byte streaming accesses), K = 512 (four topic blocks), V not a multiple of anything."""
+    (8-byte streaming accesses), K = 512 (four topic blocks), V not a multiple of anything; and
+    thousands of documents over a small vocabulary: word lists of hundreds of entries walked by
+    single wavefronts (the statistics kernels' per-batch threshold, kLongWord), the 512 longest by
+    whole workgroups."""
     import trlda_amd
     from trlda_amd.models import BatchLDA, CumulativeLDA
     D = 20000
     lam0 = random_lambda(K, V, K)
     docs = [corpus(B, V, seed=K + i, mean_unique=min(60, V // 4)) for i in range(3)]
+    if B >= 2000:
+        from trlda_amd.documents import DeviceBatch
+        dev = DeviceBatch(docs[0], V, 0)
+        assert hip.trlda_batch_long_word_len(dev.handle) >= 64
+        assert 0 < hip.trlda_batch_num_long_words(dev.handle) <= 512
+        dev.close()
     out = {}
     for fused in (1, 0):
         m = online_model(K, V, lam0, D)

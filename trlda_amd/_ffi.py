@@ -54,6 +54,8 @@ _SIGNATURES = {
     "trlda_batch_num_docs": (C.c_int, [vp]),
     "trlda_batch_nnz": (C.c_int64, [vp]),
     "trlda_batch_max_doc_len": (C.c_int, [vp]),
+    "trlda_batch_long_word_len": (C.c_int, [vp]),
+    "trlda_batch_num_long_words": (C.c_int, [vp]),
     "trlda_model_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int]),
     "trlda_model_destroy": (C.c_int, [vp]),
     "trlda_model_set_stream": (C.c_int, [vp, vp]),

@@ -2155,6 +2155,8 @@ int trlda_batch_destroy(trlda_batch *b)
 int trlda_batch_num_docs(const trlda_batch *b) { return b ? b->B : 0; }
 int64_t trlda_batch_nnz(const trlda_batch *b) { return b ? b->nnz : 0; }
 int trlda_batch_max_doc_len(const trlda_batch *b) { return b ? b->max_n : 0; }
+int trlda_batch_long_word_len(const trlda_batch *b) { return b ? b->long_len : 0; }
+int trlda_batch_num_long_words(const trlda_batch *b) { return b ? b->n_long : 0; }
 
 // ---- model --------------------------------------------------------------------
 
