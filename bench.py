@@ -242,6 +242,12 @@ def main():
                               "torch_in_rank": "torch" in sys.modules}), flush=True)
         return
 
+    # Only the result line goes to stdout: everything else that writes to file descriptor 1 from
+    # here on -- RCCL's version banner, a library's printf -- lands on stderr.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     if torch.cuda.device_count() < world:             # (counting does not initialise the GPU)
         sys.stderr.write("bench.py: %d GPUs requested, %d visible on this node\n"
@@ -857,11 +863,10 @@ def main():
     }
     if collective and not vworld:
         dist.destroy_process_group()
-    # RCCL prints its banner through C stdio, which is block-buffered on a pipe and would
-    # otherwise come out at exit, after the JSON: drain it first
     sys.stdout.flush()
-    C.CDLL(None).fflush(None)
-    print(json.dumps(out), flush=True)                # the one JSON line, last on stdout
+    C.CDLL(None).fflush(None)                         # (C stdio of the libraries: to stderr, above)
+    os.write(result_fd, (json.dumps(out) + "\n").encode())   # the one JSON line on stdout
+    os.close(result_fd)
 
 
 if __name__ == "__main__":

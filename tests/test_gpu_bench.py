@@ -1,0 +1,72 @@
+"""bench.py's one JSON line, live on the GPU box with a short timed region: the keys the driver's
+contract names, the roofline and cpu_baseline objects, and that the numbers in the line agree
+with each other."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*extra):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "3",
+                          "--repeats", "3", "--cpu-seconds", "1.5"] + list(extra), cwd=ROOT, env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines                        # ONE line on stdout
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract(hip_lib):
+    j = run_bench()
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in j, key
+    assert j["metric"] == base["metric"].split(";")[0]           # the headline metric, by its name
+    assert j["unit"] == "docs/s" and j["n_gpus"] == 1 and j["steps"] == 10 and j["warmup"] == 3
+    assert j["higher_is_better"] is True and j["scaling"] == "weak" and j["dtype"] == "f64"
+    assert j["vs_baseline"] is None and j["data"] == "synthetic" and "workload" in j["config"]
+    assert "model" not in j["config"]
+    B = 200
+    assert abs(j["value"] - B / (j["ms_per_step"] * 1e-3)) < 1e-2 * j["value"]
+    assert j["config"]["mean_iterations_executed"] == 20.0      # no early exit skipped work
+    r = j["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1.0
+    assert r["frac_documents_only"] < r["frac"]
+    assert r["traffic"] is None or 0.3 * r["algorithmic_bytes_per_launch"] < r["traffic"] < \
+        3 * r["algorithmic_bytes_per_launch"]
+    assert sum(r["kernels_us"].values()) <= j["ms_per_step"] * 1e3 * 1.05
+    c = j["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and c["sample"]
+    assert c["unit"] == j["unit"]
+    p = j["parity"]
+    assert p["gamma_max_rel_err"] < 1e-9 and p["sstats_max_rel_err"] < 1e-9 and p["iteration_counts_equal"]
+    assert j["value_no_prefetch"]["value"] < j["value"] * 1.02
+    assert j["repeats"]["n"] == 3 and j["repeats"]["ms_per_step_min"] <= j["ms_per_step"] <= \
+        j["repeats"]["ms_per_step_max"]
+    u = j["update_parameters"]
+    assert u["device_batch_tr10"]["ms_per_call"] > u["device_batch_tr0"]["ms_per_call"]
+
+
+def test_bench_forced_distributed_line(hip_lib):
+    """The N > 1 code path on the one GPU (a one-rank process group): `rccl_ranks`, `same_step_n1`."""
+    env_key = "TRLDA_BENCH_FORCE_DIST"
+    os.environ[env_key] = "1"
+    try:
+        j = run_bench("--no-cpu-baseline", "--no-update-rates")
+    finally:
+        del os.environ[env_key]
+    assert j["n_gpus"] == 1 and j["rccl_ranks"] == 1
+    same = j["same_step_n1"]
+    assert abs(same["ms_per_step"] - j["ms_per_step"]) < 0.25 * j["ms_per_step"]
