@@ -1,0 +1,110 @@
+/* A plain C client of the drop-in boundary (include/trlda_hip.h): no Python, no torch, no C++ --
+ * what the reference's src/lda.cpp / src/onlinelda.cpp would link against.  Built with gcc and run
+ * by tests/test_gpu_c_client.py on the GPU box.
+ *
+ *   one E-step through the one-shot entry (LDA::updateVariables, src/lda.cpp:142-220), then the
+ *   resident form: model + batch handles, two OnlineLDA::updateParameters calls
+ *   (src/onlinelda.cpp:53-111), lambda read back.
+ *
+ * Prints the size-independent invariants the test checks:
+ *   sum(sstats) = sum(counts);  sum(gamma) = sum(counts) + B sum(alpha);
+ *   sum(lambda) after an update = (1 - rho) sum(lambda') + rho (K V eta + D/B sum(counts)). */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "trlda_hip.h"
+
+#define CHECK(call)                                                                      \
+    do {                                                                                 \
+        int rc_ = (call);                                                                \
+        if (rc_ != TRLDA_OK) {                                                           \
+            fprintf(stderr, "%s -> %d: %s\n", #call, rc_, trlda_last_error());           \
+            return 1;                                                                    \
+        }                                                                                \
+    } while (0)
+
+int main(void)
+{
+    enum { K = 50, V = 3000, B = 120, N = 80 };       /* N unique words per document */
+    if (trlda_device_count() < 1) {
+        fprintf(stderr, "no HIP device\n");
+        return 2;
+    }
+    int32_t *indptr = malloc((B + 1) * sizeof(int32_t));
+    int32_t *ids = malloc((size_t)B * N * sizeof(int32_t));
+    int32_t *cnts = malloc((size_t)B * N * sizeof(int32_t));
+    double total = 0.0;
+    unsigned s = 12345u;
+    for (int d = 0; d < B; ++d) {
+        indptr[d] = d * N;
+        /* N distinct ids: a stride walk over the vocabulary from a per-document offset */
+        const int off = (int)((s = s * 1664525u + 1013904223u) % V);
+        for (int j = 0; j < N; ++j) {
+            ids[d * N + j] = (off + j * 37) % V;
+            cnts[d * N + j] = 1 + (int)((s = s * 1664525u + 1013904223u) >> 30);
+            total += cnts[d * N + j];
+        }
+    }
+    indptr[B] = B * N;
+
+    double *lambda = malloc((size_t)K * V * sizeof(double));
+    double *gamma = malloc((size_t)K * B * sizeof(double));
+    double *sstats = malloc((size_t)K * V * sizeof(double));
+    double alpha[K];
+    int32_t iters[B];
+    trlda_seed(7);
+    trlda_sample_gamma_init(K, V, lambda);            /* lda.cpp:71 */
+    trlda_sample_gamma_init(K, B, gamma);             /* lda.cpp:135 */
+    for (int k = 0; k < K; ++k)
+        alpha[k] = 0.1;
+
+    /* ---- one shot, host pointers ---- */
+    CHECK(trlda_estep(K, V, B, indptr, ids, cnts, lambda, alpha, gamma, sstats, 20, 1e-3, iters, 0));
+    double ssum = 0.0, gsum = 0.0;
+    for (size_t i = 0; i < (size_t)K * V; ++i)
+        ssum += sstats[i];
+    for (size_t i = 0; i < (size_t)K * B; ++i)
+        gsum += gamma[i];
+    int itmin = iters[0], itmax = iters[0];
+    for (int d = 1; d < B; ++d) {
+        itmin = iters[d] < itmin ? iters[d] : itmin;
+        itmax = iters[d] > itmax ? iters[d] : itmax;
+    }
+    printf("estep counts %.17g sstats %.17g gamma %.17g expect_gamma %.17g iters %d %d\n", total, ssum, gsum,
+           total + B * K * 0.1, itmin, itmax);
+
+    /* ---- resident: model + batch, two online updates ---- */
+    trlda_model *model = NULL;
+    trlda_batch *batch = NULL;
+    CHECK(trlda_model_create(&model, 0, K, V));
+    CHECK(trlda_model_set_alpha(model, alpha));
+    CHECK(trlda_model_set_lambda(model, lambda));
+    CHECK(trlda_batch_create(&batch, 0, V, B, indptr, ids, cnts));
+    const double eta = 0.3;
+    const int D = 100000;
+    int count = 0;
+    double lsum_prev = 0.0;
+    for (size_t i = 0; i < (size_t)K * V; ++i)
+        lsum_prev += lambda[i];
+    for (int call = 0; call < 2; ++call) {
+        double rho = 0.0;
+        CHECK(trlda_model_online_update(model, batch, D, eta, call == 0 ? 3 : 0, 20, 0.7, 100.0, -1.0, 1, 1,
+                                        1e-3, &count, &rho, NULL));
+        CHECK(trlda_model_get_lambda(model, lambda));
+        double lsum = 0.0;
+        for (size_t i = 0; i < (size_t)K * V; ++i)
+            lsum += lambda[i];
+        const double expect = (1.0 - rho) * lsum_prev + rho * ((double)K * V * eta + (double)D / B * total);
+        printf("update %d rho %.17g lambda %.17g expect %.17g count %d\n", call, rho, lsum, expect, count);
+        lsum_prev = lsum;
+    }
+    /* an argument error comes back as a code and a message, not as a crash */
+    const int rc = trlda_model_online_update(model, NULL, D, eta, 0, 20, 0.7, 100.0, -1.0, 1, 1, 1e-3, &count,
+                                             NULL, NULL);
+    printf("null batch -> %d (%s)\n", rc, trlda_last_error());
+    CHECK(trlda_batch_destroy(batch));
+    CHECK(trlda_model_destroy(model));
+    free(indptr); free(ids); free(cnts); free(lambda); free(gamma); free(sstats);
+    return 0;
+}
