@@ -29,3 +29,14 @@ def test_random_shapes_agree_with_the_oracle(hip, seed):
 def test_random_update_calls_agree_with_the_oracle(hip):
     import fuzz_update
     assert fuzz_update.main(["--cases", "8", "--seed", "5"]) < 1e-8
+
+
+def test_random_update_calls_agree_with_the_reference_itself(hip):
+    """OnlineLDA (empirical Bayes, adaptive rate), BatchLDA (line searches) and CumulativeLDA calls on
+    random inputs against the reference's unmodified C++ core (oracle/_ref, built where
+    /root/reference exists; the library travels with the tree)."""
+    from oracle.pyoracle import Reference
+    if not Reference.available():
+        pytest.skip("oracle/_ref/libtrlda_ref.so not built (needs /root/reference at build time)")
+    import fuzz_reference
+    assert fuzz_reference.main(["--cases", "15", "--seed", "8"]) < 1e-7
