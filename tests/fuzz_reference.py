@@ -7,6 +7,8 @@ compiled into oracle/_ref/libtrlda_ref.so (oracle/Makefile; the library travels 
                                   update_eta, init_gamma, min_alpha / min_eta
   BatchLDA.update_parameters      epochs with the alpha / eta line searches
   CumulativeLDA.update_parameters two calls
+  do_e_step                       gamma and the statistics from a given gamma0 (K up to 200: the
+                                  single-orientation kernel; documents of 300..600 words: split ones)
 
 on random K, V, D, alpha (scalar or vector), eta, document lengths (empty documents, one-word
 documents, documents beyond 128 / 192 words) and counts.  gamma0 comes from the seeded libc stream on
@@ -70,8 +72,43 @@ def main(argv=None):
         eta = float(rng.choice([.05, .3, 1.]))
         alpha = float(rng.choice([.05, .2])) if rng.rand() < .6 else rng.gamma(2., .1, K) + .01
         lam0 = np.asfortranarray(rng.gamma(100., .01, (K, V)))
-        kind = ("online", "online", "online", "batch", "cumulative")[case % 5]
+        kind = ("online", "online", "online", "batch", "cumulative", "estep")[case % 6]
         what = ""
+        if kind == "estep":
+            K = int(rng.choice([7, 100, 129, 200]))
+            V = int(rng.choice([700, 2500]))
+            lam0 = np.asfortranarray(rng.gamma(100., .01, (K, V)))
+            B = int(rng.choice([1, 30, 70]))
+            docs, lens = draw_docs(rng, B, V)
+            if rng.rand() < .6:                                   # a few long documents
+                from trlda_amd.documents import CSRDocuments
+                lens = list(lens)
+                for d in rng.choice(B, size=min(B, 3), replace=False):
+                    lens[d] = int(rng.randint(300, 600))
+                ip = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+                ids = np.concatenate([rng.permutation(V)[:n] for n in lens]).astype(np.int32)
+                docs = CSRDocuments(ip, ids, rng.randint(1, 6, size=ip[-1]).astype(np.int32))
+            m = OnlineLDA(num_words=V, num_topics=K, num_documents=1000, alpha=alpha if np.isscalar(alpha) else .1,
+                          eta=eta)
+            r = ref.online(V, K, 1000, alpha=alpha if np.isscalar(alpha) else .1, eta=eta)
+            m.lambdas = lam0
+            r.lambdas = lam0
+            g0 = np.asfortranarray(rng.gamma(100., .01, (K, B)))
+            it, thr = int(rng.choice([0, 1, 20, 60])), float(rng.choice([1e-3, 1e-2]))
+            g, st = m.do_e_step(docs, latents=g0, max_iter=it, threshold=thr)
+            gr, sr = r.estep(docs.indptr, docs.ids, docs.cnts, gamma0=g0, max_iter=it, threshold=thr)
+            big = sr > 1e-150
+            errs = {"lambda": rel(st[big], sr[big]), "alpha": rel(g, gr), "eta": 0.0}
+            what = " [B=%d longest=%d it=%d thr=%g]" % (B, max(lens), it, thr)
+            m.close()
+            for k, v in errs.items():
+                worst[k] = max(worst[k], v)
+            if not (errs["lambda"] < 1e-7 and errs["alpha"] < 1e-7):
+                print("MISMATCH case %d estep K=%d V=%d: %s%s" % (case, K, V, errs, what))
+                sys.exit(1)
+            print("case %3d ok %-10s K=%3d V=%4d stats %.1e gamma %.1e%s" % (
+                case, kind, K, V, errs["lambda"], errs["alpha"], what), flush=True)
+            continue
         if kind == "online":
             D = int(rng.choice([500, 100000]))
             m = OnlineLDA(num_words=V, num_topics=K, num_documents=D, alpha=alpha, eta=eta)
@@ -139,6 +176,7 @@ def main(argv=None):
             sys.exit(1)
         print("case %3d ok %-10s K=%3d V=%4d lambda %.1e alpha %.1e eta %.1e%s" % (
             case, kind, K, V, errs["lambda"], errs["alpha"], errs["eta"], what[:150]), flush=True)
+    # (do_e_step cases report the statistics under 'lambda' and gamma under 'alpha')
     print("all %d cases agree with the reference's own C++: worst %s" % (
         args.cases, {k: "%.1e" % v for k, v in worst.items()}))
     return max(worst.values())
