@@ -74,7 +74,7 @@ constexpr int kMaxRowsumBlocks = 1025;   // rows of trlda_model::partial (block 
 constexpr int kUpdGroups = 64;           // rows the document kernel adds up itself (topic_scale_load)
 constexpr int kCarryBlocks = 8;          // preamble_fused_kernel: workgroups adding up carried partials
 constexpr int kUpdShortBlocks = 1024;    // sstats_update_kernel: blocks walking the short lists
-constexpr int kUpdLongBlocks = 256;      //                       blocks walking the long lists
+constexpr int kUpdLongBlocks = 512;      //                       blocks walking the long lists (two per CU resident)
 constexpr double kFusedRowsumFloor = 2e-3;   // psi(2e-3) = -500.6: exp(-psi(row sum)) stays finite
 
 template <typename T>
