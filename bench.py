@@ -580,9 +580,7 @@ def main():
                             "ms_per_step": round(1e3 * s_solo[len(s_solo) // 2] / args.steps, 5),
                             "what": "rank 0 alone, same kernels and M-step, no exchange"}
         dist.barrier()
-        for i in range(2):                            # every rank back on the common lambda
-            _ffi.check(L.trlda_model_set_lambda(model, lam))
-            break
+        _ffi.check(L.trlda_model_set_lambda(model, lam))   # every rank back on the common lambda
 
     # ---- per-kernel durations: HIP events on the launch stream, same steps replayed -------
     _ffi.check(L.trlda_model_set_timing(model, 1))

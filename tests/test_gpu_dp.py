@@ -211,6 +211,16 @@ def test_direct_slot_exchange_processes(hip, oracle, tmp_path, world):
     on the same device).  One E-step and two updateParameters calls (5 and 1 exchanges): every
     rank's statistics and lambda bitwise equal, equal to the one-GPU results and the oracle's."""
     K, V, D, B = 100, 4000, 20000, 75
+    # the region must be fine-grained device memory that hipIpc exports (no fallback to ordinary
+    # memory any more, ADVICE r3): a box whose runtime refuses that has no direct exchange to test
+    from trlda_amd import _ffi
+    probe, handle = _ffi.vp(), C.create_string_buffer(64)
+    _ffi.check(hip.trlda_model_create(C.byref(probe), 0, 4, 8))
+    rc = hip.trlda_model_dp_direct_alloc(probe, 64, world, handle)
+    why = hip.trlda_last_error()
+    hip.trlda_model_destroy(probe)
+    if rc != 0:
+        pytest.skip("direct exchange unavailable here: %s" % (why.decode() if isinstance(why, bytes) else why))
     csr = corpus(B, V, seed=881)
     lam = random_lambda(K, V, 43)
     g0 = np.asfortranarray(np.random.RandomState(6).gamma(100., .01, (K, B)))

@@ -120,6 +120,49 @@ def test_bounded_windows_lazy_batches_and_the_python_form(fixture, tmp_path, mon
     assert load_documents(path, chunk_bytes=1000) == whole
 
 
+def test_a_loaded_batch_is_a_mutable_sequence(fixture):
+    """what load_documents returns must survive what callers do to the reference's
+    plain lists -- shuffle, sort, append, extend, item assignment, del, changing a document in
+    place -- and the models must then see the CHANGED batch, not the arrays the loader parsed."""
+    import pickle
+    import random
+    from collections.abc import MutableSequence
+    from trlda_amd.documents import as_csr
+    from trlda_amd.utils import load_documents
+    f, path = fixture
+    batch = load_documents(path)
+    plain = [list(d) for d in load_documents(path)]
+    assert isinstance(batch, MutableSequence)
+    untouched = as_csr(batch)
+    assert batch._lists is None                      # still lazy: nothing was looked at
+    random.seed(3)
+    random.shuffle(batch)
+    random.seed(3)
+    random.shuffle(plain)
+    assert batch == plain
+    batch.append([(1, 2)])
+    batch.extend([[(3, 4), (5, 6)], []])
+    plain += [[(1, 2)], [(3, 4), (5, 6)], []]
+    batch[0] = [(7, 1)]
+    plain[0] = [(7, 1)]
+    del batch[1]
+    del plain[1]
+    batch[2].append((9, 9))                          # a document changed in place
+    plain[2].append((9, 9))
+    batch.sort(key=len)
+    plain.sort(key=len)
+    batch.reverse()
+    plain.reverse()
+    assert batch == plain and len(batch) == len(plain)
+    got, want = as_csr(batch), as_csr(plain)
+    assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.ids, want.ids)
+    assert np.array_equal(got.cnts, want.cnts)
+    assert len(got) != len(untouched) or not np.array_equal(got.ids, untouched.ids)
+    again = pickle.loads(pickle.dumps(batch))
+    assert again == plain
+    assert batch * 2 == plain * 2 and batch.copy() == plain
+
+
 def test_malformed_corpus_raises_like_the_reference(tmp_path, hip_lib):
     from trlda_amd.utils import load_documents
     bad = tmp_path / "bad.dat"

@@ -1,10 +1,11 @@
 """Diagnostic: per-segment cycle shares of estep_docs_kernel (needs the -DTRLDA_STAMPS build).
-   build:  hipcc ... -DTRLDA_STAMPS -o gpurun_tmp/libtrlda_hip_stamps.so   (see tools/stamps.sh)"""
+   build + run: tools/stamps.sh (python -m trlda_amd.build --variant stamps -DTRLDA_STAMPS ...,
+   selected through TRLDA_LIB)"""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from trlda_amd import _ffi
-_ffi.LIB_PATH = os.path.join(os.path.dirname(_ffi.LIB_PATH), "libtrlda_hip_stamps.so")
+assert "stamps" in os.path.basename(_ffi.LIB_PATH), "run through tools/stamps.sh (TRLDA_LIB=...stamps.so)"
 from trlda_amd.models import OnlineLDA
 from trlda_amd.documents import CSRDocuments
 from trlda_amd.utils.synthetic import make_corpus

@@ -1,3 +1,5 @@
 #!/bin/bash
 # diagnostic build + run (GPU box): per-segment cycle shares of the document kernel
-cd trlda_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -munsafe-fp-atomics -DTRLDA_STAMPS -DTRLDA_STAMP_THREAD=${STAMP_THREAD:-0} -o ../libtrlda_hip_stamps.so trlda_hip.hip host_common.cpp host_rng.cpp text_docs.cpp eb_steps.cpp && cd ../.. && python tools/stamps.py
+cd "$(dirname "$0")/.." || exit 1
+lib=$(python -m trlda_amd.build --variant stamps -DTRLDA_STAMPS -DTRLDA_STAMP_THREAD=${STAMP_THREAD:-0} | tail -1) || exit 1
+TRLDA_LIB=$lib python tools/stamps.py

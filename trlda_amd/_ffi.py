@@ -10,7 +10,9 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libtrlda_hip.so")
+# TRLDA_LIB: another build of the SAME library (python -m trlda_amd.build --variant ...: stamps,
+# compiler-flag and tuning-constant sweeps under tools/), a development aid -- never a fallback
+LIB_PATH = os.environ.get("TRLDA_LIB") or os.path.join(_PKG, "libtrlda_hip.so")
 
 OK = 0
 ERR_ARG, ERR_SHAPE, ERR_WORD_ID, ERR_NO_DEVICE, ERR_HIP, ERR_VALUE = -1, -2, -3, -4, -5, -6

@@ -3,6 +3,8 @@
     python -m trlda_amd.build            # build if stale
     python -m trlda_amd.build --force
     python -m trlda_amd.build --sanitize address|thread   # host-only code under ASan+UBSan / TSan
+    python -m trlda_amd.build --variant NAME -DX=1 ...    # libtrlda_hip.NAME.so with extra flags
+                                                          # (use it with TRLDA_LIB=<path>)
 """
 import os
 import shutil
@@ -70,6 +72,19 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def build_variant(name, extra_flags, verbose=False):
+    """The same sources with extra compiler flags / defines as trlda_amd/libtrlda_hip.<name>.so, for
+    the tuning sweeps and diagnostic builds under tools/ (run them with TRLDA_LIB=<that path>):
+    the package's own library is never overwritten by an experiment."""
+    out = os.path.join(_PKG, "libtrlda_hip.%s.so" % name)
+    cmd = [_hipcc()] + HIPCC_FLAGS + list(extra_flags) + ["-o", out] + \
+        [os.path.join(_CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=_CSRC)
+    return out
+
+
 def build_sanitized(kind="address", verbose=False):
     """The host-only translation units + tests/native/host_sanitize_main.cpp as ONE executable under
     a sanitizer (plain g++: no HIP in these files): `address` = ASan + UBSan, `thread` = TSan.
@@ -98,4 +113,9 @@ if __name__ == "__main__":
             else "address"
         exe = build_sanitized(kind, verbose=True)
         sys.exit(subprocess.run([exe] + (["threads"] if kind == "thread" else [])).returncode)
+    if "--variant" in sys.argv:
+        # python -m trlda_amd.build --variant NAME [flags for hipcc ...]
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], verbose=True))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, verbose=True))

@@ -104,6 +104,9 @@ __global__ __launch_bounds__(T) void slot_push_kernel(DpPeers peers, int rank, i
     double2 *__restrict__ dst = reinterpret_cast<double2 *>(peers.buf[p] + offset);
     for (size_t i = (size_t)blockIdx.x * T + threadIdx.x; i < n2; i += (size_t)gridDim.x * T)
         dst[i] = src[i];
+    // the peer polls its counter while this device's later kernels run: the stores leave this
+    // workgroup's XCD for the peer's memory here, not only at the kernel's end
+    __threadfence_system();
 }
 
 __global__ void slot_signal_wait_kernel(DpPeers peers, int rank, int world, unsigned long long step,

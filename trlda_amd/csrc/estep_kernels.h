@@ -1104,6 +1104,8 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
         tw[j] = 0.0;
         if (j < 192)
             cntd[j] = j < n ? (double)cnts[j] : 0.0;
+        if (j < 8)
+            misc[j] = 0.0;                           // [2], [3]: an exchange gave up (SPLIT)
     }
 #pragma unroll
     for (int i = 0; i < JC; ++i) {
@@ -1257,11 +1259,16 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
                 // this segment's row out, every segment's row in (segment order)
                 double *rows = a.xbuf + ((size_t)seg.z * (size_t)(a.max_iter + 1) +
                                          (size_t)it * (size_t)seg.y) * (size_t)K;
+                // (a row that has not arrived is the bit pattern the buffer was filled with, all
+                // ones; a sum that IS NaN -- NaN / inf in lambda or in a caller's gamma0 -- is
+                // published in the canonical form, so that it arrives like any other number and
+                // the document's results are NaN at once, as in the reference, lda.cpp:176-204)
                 if (psi_on)
-                    __hip_atomic_store(rows + (size_t)seg.x * K + k_psi, acc, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(rows + (size_t)seg.x * K + k_psi,
+                                       acc == acc ? acc : __longlong_as_double(0x7FF8000000000000ll),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 // eight rows at a time: all their loads in flight, then again for those that
-                // were not there yet (a row is there when it is not NaN any more)
+                // were not there yet
                 double total = 0.0;
                 for (int c0 = 0; c0 < seg.y; c0 += 8) {          // wave-uniform bounds
                     double v[8];
@@ -1276,14 +1283,23 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
                         unsigned still = 0u;
 #pragma unroll
                         for (int c = 0; c < 8; ++c)
-                            if ((need >> c & 1u) && !(v[c] == v[c]))
+                            if ((need >> c & 1u) && __double_as_longlong(v[c]) == -1ll)
                                 still |= 1u << c;
                         need = still;
                         if (!__any(need != 0u))                  // wave-uniform: every lane has every row
                             break;
-                        if (spins > (1 << 21)) {                 // a peer never came: give up, loudly
-                            if (lane == 0)
-                                *a.xerr = 1;
+                        // a peer never came (or another workgroup of the launch has given up
+                        // already: looked at now and then): give up, loudly -- the whole workgroup
+                        // leaves the iteration loop after this stage's barrier, so the launch ends
+                        // after ONE wait, whatever max_iter is
+                        const bool lost = spins > (1 << 21) ||
+                                          ((spins & 1023) == 1023 &&
+                                           __hip_atomic_load(a.xerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0);
+                        if (lost) {
+                            if (lane == 0) {
+                                __hip_atomic_store(a.xerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                                misc[2 + wid] = 1.0;
+                            }
 #pragma unroll
                             for (int c = 0; c < 8; ++c)
                                 if (need >> c & 1u)
@@ -1331,6 +1347,10 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
         // is bound by its instruction count, so the mean's division is not taken here: the
         // sum is compared with threshold * K instead
         const double change_sum = misc[0] + misc[1];
+        if constexpr (SPLIT) {
+            if (misc[2] + misc[3] != 0.0)            // an exchange gave up: results are void
+                break;
+        }
 
         product_E(e_new);                            // ends with a barrier
         TRLDA_STAMP(5);

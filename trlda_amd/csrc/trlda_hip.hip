@@ -272,7 +272,10 @@ struct trlda_model {
     // split documents: the exchange rows of a launch (NaN before it), the give-up flag
     double *xbuf = nullptr;
     size_t cap_xbuf = 0;
+    // the give-up flag: one int in pinned, host-coherent memory that the kernels see through
+    // `xerr` -- checking it after a synchronisation is a plain host read (check_split_exchange)
     int *xerr = nullptr;
+    volatile int *xerr_host = nullptr;
     bool split_docs = true;             // trlda_model_set_split_docs
     int last_split_wgs = 0;             // workgroups of the last document launch beyond one per document
     // update_parameters workspaces
@@ -818,6 +821,23 @@ int sstats_update_device(trlda_model *m, const trlda_batch *b, EstepOut &out)
                     : launch_sstats_update<1024, 2, 0>(m, b, out);
 }
 
+// the give-up flag of the exchanges that poll (split documents, the direct slot exchange)
+int ensure_xerr(trlda_model *m)
+{
+    if (m->xerr)
+        return TRLDA_OK;
+    void *host = nullptr, *dev = nullptr;
+    HIP_TRY(hipHostMalloc(&host, sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+    *static_cast<int *>(host) = 0;
+    if (hipHostGetDevicePointer(&dev, host, 0) != hipSuccess) {
+        (void)hipHostFree(host);
+        return fail(TRLDA_ERR_HIP, "hipHostGetDevicePointer failed");
+    }
+    m->xerr_host = static_cast<volatile int *>(host);
+    m->xerr = static_cast<int *>(dev);
+    return TRLDA_OK;
+}
+
 // ---- data-parallel factor exchange (dp_kernels.h) -------------------------------------------
 using nccl_allgather_fn = int (*)(const void *, void *, size_t, int, void *, hipStream_t);
 constexpr int kNcclFloat64 = 8, kNcclSum = 0;       // ncclDataType_t / ncclRedOp_t (nccl.h)
@@ -920,12 +940,9 @@ int dp_exchange(trlda_model *m, const trlda_batch *)
     double *mine = m->dp_gather + (size_t)dp->rank * dp->slot;
     if (m->dp_gather_direct && dp->world > 1) {
         // direct: this rank's slot into every peer's buffer, then signal and wait (dp_kernels.h)
-        if (!m->xerr) {
-            int rc = dev_alloc(&m->xerr, 1);
-            if (rc)
-                return rc;
-            HIP_TRY(hipMemsetAsync(m->xerr, 0, sizeof(int), m->stream));
-        }
+        if (int rc = ensure_xerr(m))
+            return rc;
+        ++m->direct.step;                            // (estep_device chose this step's half)
         constexpr int T = 256;
         const size_t offset = (size_t)(m->direct.step & 1ull) * (size_t)dp->world * m->direct.max_slot +
                               (size_t)dp->rank * dp->slot;
@@ -1002,14 +1019,15 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         return fail(TRLDA_ERR_ARG, "the factor exchange needs the segmented statistics mode");
     if (dp)
         next = nullptr;
-    if (dp && m->dp_gather_direct && dp->world > 1) {
-        // direct exchange: every E-step is a step of its own, in the other half of the region
-        ++m->direct.step;
-        m->dp_gather = m->dp_gather_direct +
-                       (size_t)(m->direct.step & 1ull) * (size_t)dp->world * m->direct.max_slot;
-    }
     if (out.upd.lambda && !fused_update_available(m))
         return fail(TRLDA_ERR_ARG, "internal: fused M-step requested where it is not available");
+    if (dp && m->dp_gather_direct && dp->world > 1) {
+        // direct exchange: every E-step is a step of its own, in the other half of the region.
+        // The step is COUNTED where the push is enqueued (dp_exchange): a rank whose call is
+        // refused before that must not be a step ahead of its peers
+        m->dp_gather = m->dp_gather_direct +
+                       (size_t)((m->direct.step + 1ull) & 1ull) * (size_t)dp->world * m->direct.max_slot;
+    }
     double *sstats_dev = out.upd.sstats;
     m->last_split_wgs = 0;
     if (m->timing && (rc = stamp(m)))
@@ -1309,11 +1327,8 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                 xcount * sizeof(double) <= ((size_t)256 << 20)) {
                 if ((rc = grow(&m->xbuf, &m->cap_xbuf, xcount)))
                     return rc;
-                if (!m->xerr) {
-                    if ((rc = dev_alloc(&m->xerr, 1)))
-                        return rc;
-                    HIP_TRY(hipMemsetAsync(m->xerr, 0, sizeof(int), m->stream));
-                }
+                if ((rc = ensure_xerr(m)))
+                    return rc;
                 HIP_TRY(hipMemsetAsync(m->xbuf, 0xFF, xcount * sizeof(double), m->stream));   // NaN
                 a.pad_meta = db->seg_meta;
                 a.pad_ids = db->seg_ids;
@@ -1585,18 +1600,21 @@ void note_host_lambda(trlda_model *m, const double *host_lambda)
 // (estep_docs_reg_body<0, true>)?  Results of that launch are void.
 int check_split_exchange(trlda_model *m)
 {
-    if (!m->xerr)
+    if (!m->xerr_host || !*m->xerr_host)
         return TRLDA_OK;
-    int flag = 0;
-    HIP_TRY(hipMemcpy(&flag, m->xerr, sizeof(int), hipMemcpyDeviceToHost));
-    if (!flag)
-        return TRLDA_OK;
-    HIP_TRY(hipMemset(m->xerr, 0, sizeof(int)));
+    *m->xerr_host = 0;
     return fail(TRLDA_ERR_HIP, "an exchange gave up waiting: a document split over several workgroups "
                                "for one of its segments (or its statistics are NaN; "
                                "trlda_model_set_split_docs(model, 0) keeps every document on one "
                                "workgroup), or the direct slot exchange for a peer's signal; the "
                                "results of that call are void");
+}
+
+// wait for the model's stream; a call whose exchange gave up has no results
+int sync_model(trlda_model *m)
+{
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    return check_split_exchange(m);
 }
 
 int check_model(const trlda_model *m)
@@ -2234,7 +2252,9 @@ int trlda_model_destroy(trlda_model *m)
         if (m->draw_stream)
             (void)hipStreamSynchronize(m->draw_stream);
         (void)hipFree(m->lambda); (void)hipFree(m->alpha); (void)hipFree(m->eeb); (void)hipFree(m->psi_sum);
-        (void)hipFree(m->xbuf); (void)hipFree(m->xerr);
+        (void)hipFree(m->xbuf);
+        if (m->xerr_host)
+            (void)hipHostFree(const_cast<int *>(m->xerr_host));
         if (m->eb.host)
             (void)hipHostFree(m->eb.host);
         if (m->eb.event)
@@ -2285,7 +2305,8 @@ int trlda_model_set_stream(trlda_model *m, void *hip_stream)
     int rc = check_model(m);
     if (rc)
         return rc;
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (int rc_sync = sync_model(m))
+        return rc_sync;
     m->stream = static_cast<hipStream_t>(hip_stream);
     return TRLDA_OK;
 }
@@ -2346,8 +2367,7 @@ int trlda_model_synchronize(trlda_model *m)
     int rc = check_model(m);
     if (rc)
         return rc;
-    HIP_TRY(hipStreamSynchronize(m->stream));
-    return check_split_exchange(m);
+    return sync_model(m);
 }
 
 int trlda_model_last_split_workgroups(const trlda_model *m) { return m ? m->last_split_wgs : 0; }
@@ -2370,7 +2390,8 @@ int trlda_model_set_lambda(trlda_model *m, const double *host_lambda)
     HIP_TRY(hipMemcpyAsync(m->lambda, host_lambda, (size_t)m->K * m->V * sizeof(double),
                            hipMemcpyHostToDevice, m->stream));
     note_host_lambda(m, host_lambda);     // while the copy runs
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (int rc_sync = sync_model(m))
+        return rc_sync;
     return TRLDA_OK;
 }
 
@@ -2384,8 +2405,7 @@ int trlda_model_get_lambda(trlda_model *m, double *host_lambda)
     HIP_TRY(hipMemcpyAsync(host_lambda, m->lambda, (size_t)m->K * m->V * sizeof(double),
                            hipMemcpyDeviceToHost, m->stream));
     m->d2h_bytes += (int64_t)((size_t)m->K * m->V * sizeof(double));
-    HIP_TRY(hipStreamSynchronize(m->stream));
-    return check_split_exchange(m);
+    return sync_model(m);
 }
 
 int trlda_model_set_alpha(trlda_model *m, const double *host_alpha)
@@ -2403,7 +2423,8 @@ int trlda_model_set_alpha(trlda_model *m, const double *host_alpha)
             return fail(TRLDA_ERR_VALUE, "Alpha should not be negative.");  // lda.h:147-159
     HIP_TRY(hipMemcpyAsync(m->alpha, host_alpha, (size_t)m->K * sizeof(double),
                            hipMemcpyHostToDevice, m->stream));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (int rc_sync = sync_model(m))
+        return rc_sync;
     return TRLDA_OK;
 }
 
@@ -2430,7 +2451,8 @@ int trlda_model_get_sstats(trlda_model *m, double *host_sstats)
     HIP_TRY(hipMemcpyAsync(host_sstats, m->sstats, (size_t)m->K * m->V * sizeof(double),
                            hipMemcpyDeviceToHost, m->stream));
     m->d2h_bytes += (int64_t)((size_t)m->K * m->V * sizeof(double));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (int rc_sync = sync_model(m))
+        return rc_sync;
     return TRLDA_OK;
 }
 
@@ -2510,7 +2532,8 @@ int trlda_model_estep_host(trlda_model *m, const trlda_batch *b, double *gamma, 
         if (iters_out && b->B)
             HIP_TRY(hipMemcpyAsync(iters_out, iters_dev, (size_t)b->B * sizeof(int32_t),
                                    hipMemcpyDeviceToHost, m->stream));
-        HIP_TRY(hipStreamSynchronize(m->stream));
+        if (int rc_sync = sync_model(m))
+            return rc_sync;
         m->d2h_bytes += (int64_t)(gbytes + sbytes);
         rc = check_split_exchange(m);
     }
@@ -2560,6 +2583,8 @@ int trlda_model_lower_bound(trlda_model *m, const trlda_batch *b, double *gamma,
     hipError_t e4 = hipStreamSynchronize(m->stream);
     HIP_TRY(e1); HIP_TRY(e2); HIP_TRY(e3); HIP_TRY(e4);
     HIP_TRY(hipGetLastError());
+    if (int rc_x = check_split_exchange(m))
+        return rc_x;
     HIP_TRY(hipMemcpy(lam_sum.data(), m->psi_sum + K, (size_t)K * sizeof(double),
                       hipMemcpyDeviceToHost));
     double pw_pb = 0.0, lg_lambda = 0.0, pz = 0.0, ptheta = 0.0;
@@ -2850,7 +2875,8 @@ int trlda_model_online_update(trlda_model *m, const trlda_batch *b, int num_docu
         if (gamma_out) {
             HIP_TRY(hipMemcpyAsync(gamma_out, m->gamma, gbytes, hipMemcpyDeviceToHost, m->stream));
             m->d2h_bytes += (int64_t)gbytes;
-            HIP_TRY(hipStreamSynchronize(m->stream));
+            if (int rc_sync = sync_model(m))
+                return rc_sync;
         }
         // no synchronisation otherwise: the kernels of this call run while the host draws the
         // next call's gamma0; every getter synchronises the stream it copies on
@@ -2929,7 +2955,8 @@ int trlda_model_batch_update(trlda_model *m, const trlda_batch *b, double eta, i
         HIP_TRY(hipMemcpyAsync(gamma_out, m->gamma, gbytes, hipMemcpyDeviceToHost, m->stream));
         m->d2h_bytes += (int64_t)gbytes;
     }
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (int rc_sync = sync_model(m))
+        return rc_sync;
     return TRLDA_OK;
 }
 
@@ -2962,7 +2989,8 @@ int trlda_model_cumulative_update(trlda_model *m, const trlda_batch *b, int max_
         HIP_TRY(hipMemcpyAsync(m->lambda, lam0.data(), KV * sizeof(double), hipMemcpyHostToDevice,
                                m->stream));
         note_host_lambda(m, lam0.data());
-        HIP_TRY(hipStreamSynchronize(m->stream));
+        if (int rc_sync = sync_model(m))
+            return rc_sync;
     } else {
         invalidate_rowsums(m);
         m->rs_floor = 0.0;
@@ -2975,7 +3003,8 @@ int trlda_model_cumulative_update(trlda_model *m, const trlda_batch *b, int max_
             if (!rc) {
                 HIP_TRY(hipMemcpyAsync(rs.data(), m->rs_full, (size_t)K * sizeof(double),
                                        hipMemcpyDeviceToHost, m->stream));
-                HIP_TRY(hipStreamSynchronize(m->stream));
+                if (int rc_sync = sync_model(m))
+                    return rc_sync;
                 m->d2h_bytes += (int64_t)K * sizeof(double);
                 double lo = rs[0];
                 for (int k = 1; k < K; ++k)
@@ -3027,7 +3056,8 @@ int trlda_model_cumulative_update(trlda_model *m, const trlda_batch *b, int max_
         HIP_TRY(hipMemcpyAsync(gamma_out, m->gamma, gbytes, hipMemcpyDeviceToHost, m->stream));
         m->d2h_bytes += (int64_t)gbytes;
     }
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (int rc_sync = sync_model(m))
+        return rc_sync;
     return TRLDA_OK;
 }
 
@@ -3080,7 +3110,8 @@ int fresh_gamma_columns(trlda_model *m, int B, int doc_lo, int Bl, std::vector<d
         m->gamma0_src = nullptr;
         HIP_TRY(hipMemcpyAsync(m->gamma, full.data() + (size_t)K * doc_lo,
                                (size_t)K * Bl * sizeof(double), hipMemcpyHostToDevice, m->stream));
-        HIP_TRY(hipStreamSynchronize(m->stream));            // `full` is reused by the next draw
+        if (int rc_sync = sync_model(m))
+            return rc_sync;            // `full` is reused by the next draw
     }
     return TRLDA_OK;
 }
@@ -3201,7 +3232,8 @@ int trlda_model_batch_update_multi(trlda_model *m, const trlda_batch *shard, voi
     }
     if (rc)
         return rc;
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (int rc_sync = sync_model(m))
+        return rc_sync;
     return TRLDA_OK;
 }
 
@@ -3245,21 +3277,21 @@ int trlda_model_dp_direct_alloc(trlda_model *m, size_t max_slot_f64, int world, 
     max_slot_f64 = (max_slot_f64 + 1) & ~(size_t)1;
     const size_t bytes = 2 * (size_t)world * max_slot_f64 * sizeof(double) +
                          (size_t)trlda::kDpMaxWorld * sizeof(unsigned long long);
+    // Fine-grained device memory or nothing: the step counters and the slots are polled and read
+    // while kernels of OTHER devices write them, which ordinary (coarse-grained) device memory
+    // does not promise to show before a kernel boundary.  No silent fallback: the
+    // caller's ranks then stay on the all-gather together (ShardedOnlineLDA, bench.py).
     void *region = nullptr;
     hipIpcMemHandle_t handle;
-    bool ok = hipExtMallocWithFlags(&region, bytes, hipDeviceMallocFinegrained) == hipSuccess &&
-              hipIpcGetMemHandle(&handle, region) == hipSuccess;
-    if (!ok) {
+    hipError_t e = hipExtMallocWithFlags(&region, bytes, hipDeviceMallocFinegrained);
+    if (e == hipSuccess)
+        e = hipIpcGetMemHandle(&handle, region);
+    if (e != hipSuccess) {
         if (region)
             (void)hipFree(region);
         (void)hipGetLastError();
-        region = nullptr;
-        HIP_TRY(hipMalloc(&region, bytes));
-        hipError_t e = hipIpcGetMemHandle(&handle, region);
-        if (e != hipSuccess) {
-            (void)hipFree(region);
-            return fail(TRLDA_ERR_HIP, std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e));
-        }
+        return fail(TRLDA_ERR_HIP, std::string("the direct exchange needs fine-grained device memory that can "
+                                               "be exported through hipIpc: ") + hipGetErrorString(e));
     }
     HIP_TRY(hipMemset(region, 0, bytes));
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "the ABI hands out 64-byte handles");
@@ -3552,7 +3584,8 @@ int trlda_model_eb_gamma_stats_multi(trlda_model *m, void *rccl_comm, int B, con
         HIP_TRY(hipMemcpyAsync(out_host, m->reduce_out, (size_t)m->K * sizeof(double),
                                hipMemcpyDeviceToHost, m->stream));
         m->d2h_bytes += (int64_t)m->K * sizeof(double);
-        HIP_TRY(hipStreamSynchronize(m->stream));
+        if (int rc_sync = sync_model(m))
+            return rc_sync;
         return TRLDA_OK;
     }
     const double *gamma = gamma_dev ? gamma_dev : m->gamma;
@@ -3578,7 +3611,8 @@ int trlda_model_eb_gamma_stats_multi(trlda_model *m, void *rccl_comm, int B, con
         return rc;
     HIP_TRY(hipMemcpyAsync(out_host, sum, (size_t)K * sizeof(double), hipMemcpyDeviceToHost, m->stream));
     m->d2h_bytes += (int64_t)K * sizeof(double);
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (int rc_sync = sync_model(m))
+        return rc_sync;
     return TRLDA_OK;
 }
 
@@ -3630,7 +3664,8 @@ int trlda_model_eb_lambda_stats(trlda_model *m, double *sum_psi_lambda, double *
     HIP_TRY(hipMemcpyAsync(rowsums_host, rs, (size_t)K * sizeof(double), hipMemcpyDeviceToHost,
                            m->stream));
     m->d2h_bytes += (int64_t)((size_t)G + K) * sizeof(double);
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (int rc_sync = sync_model(m))
+        return rc_sync;
     double total = 0.0;
     for (int g = 0; g < G; ++g)
         total += blocks[(size_t)g];
@@ -3750,6 +3785,8 @@ int trlda_model_online_eb_finish(trlda_model *m, double rho, double min_alpha, d
     m->eb.active = false;
     const int K = m->K, G = m->eb.G;
     HIP_TRY(hipEventSynchronize(m->eb.event));                       // the one trip
+    if ((rc = check_split_exchange(m)))                              // (the update before the sums)
+        return rc;
     const double *host = m->eb.host;
     if (m->eb.alpha) {
         std::vector<double> next((size_t)K);
@@ -3825,7 +3862,8 @@ int trlda_model_adaptive_stats_dev(trlda_model *m, const double *sstats_dev,
     HIP_TRY(hipMemcpyAsync(blocks.data(), m->reduce_out, blocks.size() * sizeof(double),
                            hipMemcpyDeviceToHost, m->stream));
     m->d2h_bytes += (int64_t)(blocks.size() * sizeof(double));
-    HIP_TRY(hipStreamSynchronize(m->stream));
+    if (int rc_sync = sync_model(m))
+        return rc_sync;
     double u2 = 0.0, g2 = 0.0;
     for (int g = 0; g < G; ++g) {
         u2 += blocks[2 * (size_t)g];

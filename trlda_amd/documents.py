@@ -5,6 +5,7 @@ python/src/ldainterface.cpp:152-190): same accepted input, same ``TypeError``
 messages, but the result is the flat CSR form of ``LDA::Documents``
 (include/lda.h:21-23) that the HIP kernels consume.
 """
+from collections.abc import MutableSequence
 from itertools import chain
 
 import numpy as np
@@ -65,29 +66,58 @@ class CSRDocuments(object):
         return csr_to_lists(self)
 
 
-class DocumentList(object):
-    """A batch in the reference's form -- it indexes, iterates, compares and prints like the list
-    of lists of ``(word id, count)`` tuples that ``load_documents`` returns -- that keeps its CSR
-    arrays: the tuples are built (all at once, in C) only when a document is looked at, and the
-    models take the arrays as they are (``as_csr``).  What the reference's README loop needs of
-    a batch is ``update_parameters(documents)``; everything else still works."""
+class DocumentList(MutableSequence):
+    """A batch in the reference's form -- a mutable sequence that indexes, iterates, compares,
+    prints, sorts and shuffles like the list of lists of ``(word id, count)`` tuples that
+    ``load_documents`` returns (python/utils/load_documents.py:31-69) -- that keeps its CSR arrays
+    for as long as nobody has looked at a document: the tuples are built (all at once, in C) at the
+    first look, and from then on the LISTS are the batch -- ``append`` / ``extend`` / ``sort`` /
+    ``random.shuffle(batch)`` / ``batch[i].append((w, c))`` all count, and ``as_csr`` flattens the
+    lists again instead of handing out arrays that no longer match them.  What the
+    reference's README loop needs of a batch is ``update_parameters(documents)``: that path never
+    builds a tuple.  It is not a ``list`` subclass (a list's storage cannot be filled lazily):
+    ``isinstance(batch, list)`` is false and ``json.dumps`` wants ``list(batch)``."""
 
-    __slots__ = ("csr", "_lists")
+    __slots__ = ("_csr", "_lists")
 
     def __init__(self, csr):
-        self.csr = csr
+        self._csr = csr
         self._lists = None
+
+    @property
+    def csr(self):
+        """The batch as CSR arrays: the loader's own while no document has been handed out,
+        re-flattened from the lists afterwards (a document may have been changed in place)."""
+        if self._lists is not None:
+            return as_csr(self._lists)
+        return self._csr
 
     def to_list(self):
         if self._lists is None:
-            self._lists = csr_to_lists(self.csr)
+            self._lists = csr_to_lists(self._csr)
+            self._csr = None
         return self._lists
 
     def __len__(self):
-        return len(self.csr)
+        return len(self._lists) if self._lists is not None else len(self._csr)
 
     def __getitem__(self, index):
         return self.to_list()[index]
+
+    def __setitem__(self, index, value):
+        self.to_list()[index] = value
+
+    def __delitem__(self, index):
+        del self.to_list()[index]
+
+    def insert(self, index, value):
+        self.to_list().insert(index, value)
+
+    def sort(self, **kwargs):
+        self.to_list().sort(**kwargs)
+
+    def copy(self):
+        return list(self.to_list())
 
     def __iter__(self):
         return iter(self.to_list())
@@ -111,8 +141,16 @@ class DocumentList(object):
     def __radd__(self, other):
         return list(other) + self.to_list()
 
+    def __mul__(self, n):
+        return self.to_list() * n
+
+    __rmul__ = __mul__
+
     def __repr__(self):
         return repr(self.to_list())
+
+    def __reduce__(self):
+        return (DocumentList, (self.csr,))
 
 
 def csr_to_lists(csr):
