@@ -60,7 +60,10 @@ def parse():
                     help="unique words per document: 1 + Poisson(mean - 1) (SURVEY.md 8d, the "
                          "headline) or heavy-tailed: log-normal around the mean, ~2 %% of the "
                          "documents over 192 words, a few of 300..600 (utils/synthetic.py)")
-    ap.add_argument("--num-batches", type=int, default=8, help="distinct mini-batches cycled")
+    ap.add_argument("--num-batches", type=int, default=0,
+                    help="distinct mini-batches streamed through the timed steps, one after the other "
+                         "(0 = auto: 200 = 40 000 documents at N = 1, SURVEY.md 8(d) config 2; 8 per "
+                         "rank where every rank also holds the other ranks' word lists)")
     ap.add_argument("--sstats-mode", choices=["segmented", "atomic"], default="segmented")
     ap.add_argument("--doc-threads", type=int, default=0)
     ap.add_argument("--split-preamble", action="store_true",
@@ -383,10 +386,17 @@ def main():
         if exchange == "factors" and world > 1 and rccl_comm is None and not direct:
             exchange = "sstats"                      # ncclAllGather needs the communicator
 
+    if args.num_batches <= 0:
+        args.num_batches = 200 if (world == 1 and not vworld and not force_dist) else 8
     batches, csrs, gamma0s, gbatches = [], [], [], []
     cuts = (np.arange(xworld + 1) * B).astype(np.int32)
+    # (batch i is the same documents whatever --num-batches is: a seed per batch; NumPy's samplers
+    # release the GIL, so the corpus is generated on a few host threads)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=max(1, min(16, (os.cpu_count() or 2) // 2))) as pool:
+        own_csrs = list(pool.map(lambda i: rank_corpus(rank, i), range(args.num_batches)))
     for i in range(args.num_batches):
-        csr = rank_corpus(rank, i)
+        csr = own_csrs[i]
         csrs.append(csr)
         batches.append(DeviceBatch(csr, V, local_rank))
         if exchange == "factors":
@@ -471,7 +481,8 @@ def main():
     cuts_solo = np.array([0, B], dtype=np.int32)
     use_prefetch = [prefetch]
 
-    def step(i, want_iters=False, plain=False, solo=False):
+    def step(i, want_iters=False, plain=False, solo=False, threshold=None):
+        thr = args.threshold if threshold is None else threshold
         # plain: the bare E-step (parity leg).  solo: the N > 1 step without its exchange -- this
         # rank's documents, the same kernels, the M-step -- run by one rank on its own
         j = i % args.num_batches
@@ -479,7 +490,7 @@ def main():
             _ffi.check(L.trlda_model_estep_dp(
                 model, batches[j].handle, batches[j].handle, None, 0, 1,
                 cuts_solo.ctypes.data_as(C.POINTER(C.c_int32)), gamma0s[j].data_ptr(), gamma.data_ptr(),
-                None, args.max_iter, args.threshold, None, 1, lam_prime.data_ptr(), RHO, ETA,
+                None, args.max_iter, thr, None, 1, lam_prime.data_ptr(), RHO, ETA,
                 D_TOTAL / float(B) if D_TOTAL else 1.))
             return
         # gamma0 is read-only input, gamma the output (lda.cpp:168 copies, we do not).  The batch
@@ -494,13 +505,13 @@ def main():
             _ffi.check(L.trlda_model_estep_dp(
                 model, gbatches[j].handle, batches[j].handle, rccl_comm, 0 if vworld else rank, xworld,
                 cuts.ctypes.data_as(C.POINTER(C.c_int32)), gamma0s[j].data_ptr(), gamma.data_ptr(),
-                None, args.max_iter, args.threshold, iters_dev.data_ptr() if want_iters else None, 1,
+                None, args.max_iter, thr, iters_dev.data_ptr() if want_iters else None, 1,
                 lam_prime.data_ptr(), RHO, ETA, D_TOTAL / float(B * xworld) if D_TOTAL else 1.))
             return
         nxt = batches[(i + 1) % args.num_batches].handle if use_prefetch[0] else None
         _ffi.check(L.trlda_model_estep_io_next(model, batches[j].handle, nxt, gamma0s[j].data_ptr(),
                                                gamma.data_ptr(), sstats.data_ptr(), args.max_iter,
-                                               args.threshold,
+                                               thr,
                                                iters_dev.data_ptr() if want_iters else None))
         if collective and not plain:
             if solo:
@@ -518,11 +529,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    pos = [args.warmup]                              # the stream of mini-batches goes on across repeats
+
     def timed(**kw):
-        """EXACTLY args.steps steps between two fences; the maximum over ranks."""
+        """EXACTLY args.steps steps between two fences; the maximum over ranks.  Every timed
+        region takes up the stream of mini-batches where the last one stopped (each step announces
+        its successor: nothing is announced twice, nothing comes unannounced)."""
         fence()
+        first = pos[0]
+        pos[0] += args.steps
         t0 = time.perf_counter()
-        for i in range(args.steps):
+        for i in range(first, first + args.steps):
             step(i, **kw)
         fence()
         dt = time.perf_counter() - t0
@@ -549,13 +566,30 @@ def main():
     if prefetch and not args.headline_only:
         use_prefetch[0] = False
         for i in range(min(args.warmup, 5)):
-            step(i)
+            step(pos[0] + i)
+        pos[0] += min(args.warmup, 5)
         s_np = sorted(timed() for _ in range(max(1, args.repeats)))
         value_no_prefetch = {"value": round(B * args.steps / s_np[len(s_np) // 2], 1), "unit": "docs/s",
                              "ms_per_step": round(1e3 * s_np[len(s_np) // 2] / args.steps, 5)}
         use_prefetch[0] = True
         for i in range(2):
-            step(i)
+            step(pos[0] + i)
+        pos[0] += 2
+
+    # the same steps with threshold = 0: FIXED work, every document runs all max_iter iterations
+    # whatever lambda is ("threshold 1e-3 and threshold 0")
+    value_fixed_work = None
+    if not collective and not args.headline_only:
+        for i in range(min(args.warmup, 5)):
+            step(pos[0] + i, threshold=0.)
+        pos[0] += min(args.warmup, 5)
+        s_fw = sorted(timed(threshold=0.) for _ in range(max(1, args.repeats)))
+        value_fixed_work = {"value": round(B * args.steps / s_fw[len(s_fw) // 2], 1), "unit": "docs/s",
+                            "ms_per_step": round(1e3 * s_fw[len(s_fw) // 2] / args.steps, 5),
+                            "threshold": 0.0, "iterations_per_document": args.max_iter}
+        for i in range(2):
+            step(pos[0] + i)
+        pos[0] += 2
 
     # N > 1: the identical step (documents -> statistics -> M-step, no prefetch) WITHOUT the
     # exchange, timed on rank 0 alone while the other ranks wait: the like-for-like one-GPU
@@ -585,7 +619,8 @@ def main():
     # ---- per-kernel durations: HIP events on the launch stream, same steps replayed -------
     _ffi.check(L.trlda_model_set_timing(model, 1))
     for i in range(args.steps):
-        step(i)
+        step(pos[0] + i)
+    pos[0] += args.steps
     fence()
     kernel_us = []
     for w in range(5):
@@ -677,6 +712,9 @@ def main():
         "frac_documents_only": round(docs_only_bytes / (docs_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5)
         if docs_us > 0 else 0.0,
         "traffic": traffic,
+        # counters need rocprofv3 passes of their own (MI355X_MICROARCH.md): the figure is read from
+        # profiles/traffic.json, stamped with the commit it was measured at -- not measured in this run
+        "traffic_in_run": False,
         "traffic_source": traffic_src,
         "algorithmic_bytes_per_launch": docs_bytes,
         "algorithmic_bytes_split": {"documents": docs_only_bytes, "next_batch_preamble": pre_bytes},
@@ -824,6 +862,8 @@ def main():
                                                            % max(int(np.diff(c.indptr).max()) for c in csrs)
                                                            if args.lengths == "lognormal" else ""),
                    "num_topics": K, "num_words": V, "batch_per_gpu": B, "global_batch": B * world,
+                   "num_batches": args.num_batches,
+                   "documents_streamed": args.num_batches * B * world,
                    "max_iter_inference": args.max_iter, "threshold": args.threshold,
                    "mean_iterations_executed": round(mean_iters, 2),
                    "sstats": args.sstats_mode,
@@ -852,6 +892,7 @@ def main():
                    "virtual_world": vworld or None},
         "repeats": repeats,
         "value_no_prefetch": value_no_prefetch,
+        "value_fixed_work": value_fixed_work,
         "rccl_ranks": rccl_ranks,
         "same_step_n1": same_step_n1,
         "roofline": roofline,

@@ -53,6 +53,14 @@ def test_bench_line_contract(hip_lib):
     p = j["parity"]
     assert p["gamma_max_rel_err"] < 1e-9 and p["sstats_max_rel_err"] < 1e-9 and p["iteration_counts_equal"]
     assert j["value_no_prefetch"]["value"] < j["value"] * 1.02
+    # SURVEY.md 8(d), config 2 to the letter: 200 mini-batches = 40 000 documents streamed, the
+    # fixed-work figure (threshold 0) beside the threshold-1e-3 value, and the counter traffic
+    # marked as what it is -- read from profiles/traffic.json, not measured in this run
+    assert j["config"]["num_batches"] == 200 and j["config"]["documents_streamed"] == 40000
+    fw = j["value_fixed_work"]
+    assert fw["threshold"] == 0.0 and fw["iterations_per_document"] == 20
+    assert abs(fw["value"] - j["value"]) < 0.1 * j["value"]      # every document runs 20 iterations anyway
+    assert r["traffic_in_run"] is False
     assert j["repeats"]["n"] == 3 and j["repeats"]["ms_per_step_min"] <= j["ms_per_step"] <= \
         j["repeats"]["ms_per_step_max"]
     u = j["update_parameters"]

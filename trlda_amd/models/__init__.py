@@ -119,6 +119,13 @@ class LDA(Distribution):
         self._alpha, self._eta = alpha, float(eta.value)
 
     def close(self):
+        # an empirical-Bayes step still on its way is finished, not dropped: alpha / eta stay
+        # readable after close() with the values the last update_parameters call gave them
+        if getattr(self, "_handle", None) and self._eb_pending is not None:
+            try:
+                self._settle()
+            except Exception:                        # noqa: BLE001 -- closing must not raise
+                self._eb_pending = None
         self._eb_pending = None
         if getattr(self, "_handle", None):
             _ffi.lib().trlda_model_destroy(self._handle)
