@@ -575,7 +575,10 @@ int trlda_model_adaptive_stats_dev(trlda_model *model, const double *sstats_dev,
 /* The device digamma (TRLDA::digamma, src/digamma.cpp:116-178, as compiled for gfx950)
  * evaluated at n host points: psi[i] = psi(x[i]); epsi[i] = exp(psi(x[i])) in the log-free
  * form the hot path uses (lda.cpp:173-174, :197 only ever need exp(psi)); epsi_lean[i] = the
- * register-lean schedule of the same value (bitwise equal); eminus[i] = exp(psi(x[i]) - c)
+ * call-free form for positive arguments that the M-step kernels use when they leave the next
+ * E-step's exp(psi(lambda)) behind (bitwise the same except at the integers 1..10, where the
+ * reference's exact harmonic branch and the regular form differ by a few ulp; for x <= 0 the
+ * general form); eminus[i] = exp(psi(x[i]) - c)
  * (lda.cpp:173).  Lets the parity tests check the special functions against the reference's
  * table directly. */
 int trlda_debug_digamma(int device, int n, double c, const double *x, double *psi, double *epsi,

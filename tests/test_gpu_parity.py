@@ -52,8 +52,8 @@ def test_native_library_is_loaded(hip):
 
 
 def test_device_digamma_table(hip):
-    """The device psi, and exp(psi) in the log-free form the kernels use -- latency-scheduled,
-    register-lean (bitwise the same) and with the subtrahend of lda.cpp:173 -- against the
+    """The device psi, and exp(psi) in the log-free form the kernels use -- the general one, the
+    call-free one for positive arguments and the one with the subtrahend of lda.cpp:173 -- against the
     reference's table (log grid 1e-6..1e6, small integers, reflection branch) and its three
     known answers (utils_test.py:33-51)."""
     f = golden("f0_rng_psi")
@@ -78,7 +78,19 @@ def test_device_digamma_table(hip):
         rel = np.abs(got[ok] - ref[ok]) / ref[ok] / np.maximum(1.0, np.abs(want[ok]))
         assert rel.max() < 2e-15, (rel.max(), x[ok][rel.argmax()])
         assert (got[fin & (ref == 0)] == 0).all()
-    assert np.array_equal(epsi[fin], epsi_lean[fin])          # same operations, same order
+    # the call-free form for positive arguments (what the M-step kernels emit): the same operations
+    # in the same order, except at the integers 1..10 (regular form instead of the exact harmonic
+    # branch: a few ulp, inside the bound above)
+    small_int = (x > 0) & (x <= 10) & (x == np.floor(x))
+    assert small_int.any()
+    assert np.array_equal(epsi[fin & ~small_int], epsi_lean[fin & ~small_int])
+    # ... and at the ends of its range: 0 below 1e-290 like exp(-1/x), x itself from 1e25 on, NaN
+    ends = np.array([1e-300, 5e-291, 1e25, 3e80, 1e200, np.inf, np.nan, 1.0, 2.0, 10.0])
+    eo = [np.zeros_like(ends) for _ in range(4)]
+    assert hip.trlda_debug_digamma(0, len(ends), 0., ends.ctypes.data, *[o.ctypes.data for o in eo]) == 0
+    assert list(eo[2][:2]) == [0., 0.] and list(eo[2][2:6]) == list(ends[2:6]) and np.isnan(eo[2][6])
+    assert np.max(np.abs(eo[2][7:] - eo[1][7:]) / eo[1][7:]) < 2e-15
+    assert np.max(np.abs(eo[2][2:5] - eo[1][2:5]) / eo[1][2:5]) < 1e-13     # exp(log x) is the looser one
     kx = np.ascontiguousarray(f["kat_x"])
     ko = [np.zeros_like(kx) for _ in range(4)]
     assert hip.trlda_debug_digamma(0, len(kx), 0., kx.ctypes.data, *[o.ctypes.data for o in ko]) == 0

@@ -1669,14 +1669,14 @@ __device__ __forceinline__ double update_one(const UpdateOut &o, size_t i, doubl
         const double hat = o.eta + o.scale * s;
         lam = o.lambda_prime ? o.omr * o.lambda_prime[i] + o.rho * hat : o.rho * hat;
         o.lambda[i] = lam;
-        if (EMIT && o.u_out)
-            o.u_out[i] = exp_digamma(lam);
+        if (EMIT && o.u_out)                         // (lam > 0: the host only asks for u_out then)
+            o.u_out[i] = exp_digamma_positive(lam);
     }
     return lam;
 }
 
 template <int T, int NKB, bool EMIT>                 // EMIT: also UpdateOut::u_out (K <= 128 only)
-__global__ __launch_bounds__(T) void sstats_update_kernel(
+__global__ __launch_bounds__(T, EMIT ? (T <= 512 ? 6 : 8) : 1) void sstats_update_kernel(
     int K, int N, int G_short, int n_long, int long_len, const int32_t *__restrict__ list,
     const int32_t *__restrict__ wptr, const int32_t *__restrict__ wdoc,
     const int32_t *__restrict__ long_words, TwView tw_word,
@@ -1771,14 +1771,24 @@ __global__ __launch_bounds__(T) void sstats_update_kernel(
         for (int c = 0; c < (512 + T - 1) / T; ++c) {
             const int k = threadIdx.x + c * T;
             if (k < K) {
-                double pv[W];
+                // (chunk order; EMIT: read and added one after the other -- sixteen values held at
+                // once are 32 of the 64 VGPRs this instantiation may use)
+                double acc;
+                if constexpr (EMIT) {
+                    acc = wpart[k];
+#pragma unroll 4
+                    for (int q = 1; q < W; ++q)
+                        acc += wpart[q * K + k];
+                } else {
+                    double pv[W];
 #pragma unroll
-                for (int q = 0; q < W; ++q)
-                    pv[q] = wpart[q * K + k];
-                double acc = pv[0];
+                    for (int q = 0; q < W; ++q)
+                        pv[q] = wpart[q * K + k];
+                    acc = pv[0];
 #pragma unroll
-                for (int q = 1; q < W; ++q)
-                    acc += pv[q];
+                    for (int q = 1; q < W; ++q)
+                        acc += pv[q];
+                }
                 const size_t i = (size_t)w * K + k;
                 rsl[c] += update_one<EMIT>(o, i, acc * eeb[i]);
             }
@@ -1871,14 +1881,22 @@ __device__ __forceinline__ double2 update_pair(const UpdateOut &o, size_t i, dou
             lam.y = o.rho * hy;
         }
         *reinterpret_cast<double2 *>(o.lambda + i) = lam;
-        if (EMIT && o.u_out)
-            *reinterpret_cast<double2 *>(o.u_out + i) = make_double2(exp_digamma(lam.x), exp_digamma(lam.y));
+        if (EMIT && o.u_out) {
+            // (lam > 0: the host only asks for u_out then.)  One after the other, not interleaved:
+            // the two chains side by side need ~100 VGPRs, and above 64 a CU holds ONE 1024-thread
+            // workgroup of this kernel instead of two -- the launch then runs in two rounds (15.4 us
+            // against 8.2 us without this stream in round 3)
+            const double ux = exp_digamma_positive(lam.x);
+            double ly = lam.y;
+            asm volatile("" : "+v"(ly) : "v"(ux));
+            *reinterpret_cast<double2 *>(o.u_out + i) = make_double2(ux, exp_digamma_positive(ly));
+        }
     }
     return lam;
 }
 
 template <int T, int NKB, int NH, bool EMIT>         // NKB = ceil(K / (128 NH)), K even
-__global__ __launch_bounds__(T) void sstats_update2_kernel(
+__global__ __launch_bounds__(T, EMIT ? (T <= 512 ? 6 : 8) : 1) void sstats_update2_kernel(
     int K, int N, int G_short, int n_long, int long_len, const int32_t *__restrict__ list,
     const int32_t *__restrict__ wptr, const int32_t *__restrict__ wdoc,
     const int32_t *__restrict__ long_words, TwView tw_word,
@@ -1994,14 +2012,24 @@ __global__ __launch_bounds__(T) void sstats_update2_kernel(
         for (int c = 0; c < (512 + T - 1) / T; ++c) {
             const int k = threadIdx.x + c * T;
             if (k < K) {
-                double pv[W];
+                // (chunk order; EMIT: read and added one after the other -- sixteen values held at
+                // once are 32 of the 64 VGPRs this instantiation may use)
+                double acc;
+                if constexpr (EMIT) {
+                    acc = wpart2[k];
+#pragma unroll 4
+                    for (int q = 1; q < W; ++q)
+                        acc += wpart2[q * K + k];
+                } else {
+                    double pv[W];
 #pragma unroll
-                for (int q = 0; q < W; ++q)
-                    pv[q] = wpart2[q * K + k];
-                double acc = pv[0];
+                    for (int q = 0; q < W; ++q)
+                        pv[q] = wpart2[q * K + k];
+                    acc = pv[0];
 #pragma unroll
-                for (int q = 1; q < W; ++q)
-                    acc += pv[q];
+                    for (int q = 1; q < W; ++q)
+                        acc += pv[q];
+                }
                 const size_t i = (size_t)w * K + k;
                 rsl[c] += update_one<EMIT>(o, i, acc * eeb[i]);
             }
@@ -2022,7 +2050,8 @@ __global__ __launch_bounds__(T) void sstats_update2_kernel(
 // 4b. Atomic mode finish: sstats *= eeb (lda.cpp:217): FinishOp in stream_kernels.h.
 
 // psi[i] = psi(x[i]); epsi[i] = exp(psi(x[i])) as the document kernels compute it (no
-// logarithm); epsi_lean[i] = the register-lean schedule of the same value; eminus[i] =
+// logarithm); epsi_lean[i] = the call-free form for positive arguments (psi.h,
+// exp_digamma_positive: what the M-step kernels emit); eminus[i] =
 // exp(psi(x[i]) - c): test hook for the device special functions
 // (tests/test_gpu_parity.py::test_device_digamma_table).
 __global__ void digamma_table_kernel(int n, double c, const double *__restrict__ x,
@@ -2035,7 +2064,7 @@ __global__ void digamma_table_kernel(int n, double c, const double *__restrict__
     const double v = x[i];
     psi[i] = digamma(v);
     epsi[i] = exp_digamma(v);
-    epsi_lean[i] = exp_digamma(v);          // (one schedule since round 2)
+    epsi_lean[i] = v > 0.0 ? exp_digamma_positive(v) : exp_digamma(v);   // the M-step's form
     eminus[i] = exp_digamma_minus(v, c);
 }
 

@@ -244,4 +244,25 @@ __device__ __forceinline__ double exp_digamma_minus(double x, double c)
 
 __device__ __forceinline__ double exp_digamma(double x) { return exp_digamma_minus(x, 0.0); }
 
+// exp(psi(x)) for an argument that is KNOWN to be positive (or NaN) -- the lambda an M-step has
+// just formed from a positive lambda' or a positive eta and non-negative statistics, which the
+// host keeps track of (trlda_model::lambda_positive).  Selects only, no call and no branch: the
+// general form's rare branch (x <= 0: reflection through tan, src/digamma.cpp:123-144) is a
+// function call that alone puts a kernel at ~120 VGPRs, and even a branch to a table of the
+// small integers' values costs ~35 -- the statistics kernel that also leaves the next preamble
+// behind must stay at 64 to keep two workgroups per CU (estep_kernels.h, 4c / 4d).
+//   0 < x < 1e-290   psi(x) = -1/x - ..., exp(psi(x)) = 0 like the reference's exp(-1e290)
+//   x = 1 .. 10      the regular form (the reference takes the exact harmonic sum there,
+//                    src/digamma.cpp:147-156; both are psi(n) to a few ulp: 2e-15 apart at most,
+//                    tests/test_gpu_parity.py::test_device_digamma_table)
+//   x >= 1e25        exp(psi(x)) = x - 1/2 + O(1/x) = x in fp64 (inf stays inf)
+//   NaN              NaN
+__device__ __forceinline__ double exp_digamma_positive(double x)
+{
+    const bool tiny = x < 1e-290, big = !(x < 1e25);
+    double v = exp_psi_regular((tiny || big) ? 1.5 : x, 0.0);
+    v = tiny ? 0.0 : v;
+    return big ? x : v;
+}
+
 }  // namespace trlda

@@ -171,6 +171,7 @@ struct trlda_batch {
     // indexed; valid unless a sum does not fit 32 bits (then the device adds them up)
     int32_t *wc32 = nullptr;
     bool wc32_ok = false;
+    bool cnts_nonneg = true;        // no negative count: the statistics are >= 0 (see lambda_positive)
 };
 
 // A data-parallel call in flight (dp_kernels.h): the model holds the whole mini-batch `b`, iterates
@@ -245,6 +246,11 @@ struct trlda_model {
     double rs_floor = 0.0;
     int64_t d2h_bytes = 0;              // bytes copied to the host through this model (tests)
     bool lambda_exposed = false;        // trlda_model_lambda_dev was handed out: never trust rs_*
+    // Every element of lambda is known to be > 0 (or NaN): set from the host copy when lambda is
+    // uploaded, kept by the M-steps that provably keep it (mstep_keeps_positive), dropped by
+    // everything else that writes lambda.  Only then may an M-step kernel also emit exp(psi(lambda))
+    // with the call-free positive-argument form (psi.h, exp_digamma_positive).
+    bool lambda_positive = false;
     bool pair_gathers = true;           // statistics kernel with two topics per lane (even K > 128)
     bool prefetch_next = true;          // trlda_model_set_prefetch: honour "next batch" announcements
     // per-batch workspaces, grown on demand
@@ -737,6 +743,19 @@ int rowsums_from_scratch(trlda_model *m)
     return combine_rowsums(m, m->partial, g.G, nullptr, m->rs_full);
 }
 
+// lambda = omr * lambda' + rho * (eta + scale * s) with s >= 0 (no negative count in the batch):
+// is every element of the result known to be > 0?  (lambda' = the model's own lambda, or its
+// snapshot of it from the start of the call; anything else is not known.)
+bool mstep_keeps_positive(const trlda_model *m, const trlda::UpdateOut &u, const trlda_batch *b)
+{
+    if (!b->cnts_nonneg || !(u.scale >= 0.) || !(u.rho >= 0.) || !(u.omr >= 0.))
+        return false;
+    if (u.rho * u.eta > 0.)
+        return true;
+    const bool own = u.lambda_prime == m->lambda || (u.lambda_prime && u.lambda_prime == m->lambda_prime);
+    return own && u.omr > 0. && m->lambda_positive;
+}
+
 using sstats_update_fn = void (*)(int, int, int, int, int, const int32_t *, const int32_t *, const int32_t *,
                                   const int32_t *, trlda::TwView, const double *, const double *,
                                   trlda::UpdateOut);
@@ -760,7 +779,12 @@ int launch_sstats_update(trlda_model *m, const trlda_batch *b, EstepOut &out)
     const size_t lds = (size_t)W * K * sizeof(double);
     // (the instantiation that also writes exp(psi(lambda)) needs more registers: only where asked)
     constexpr bool can_emit = NKB == 1 && NH <= 1;   // K <= 128
-    const bool emit = can_emit && out.emit_next && out.upd.lambda && out.upd.partial;
+    // (exp(psi(.)) of the lambda it writes, in the form for positive arguments: only where the
+    // result is known to be positive)
+    const bool positive = out.upd.lambda && mstep_keeps_positive(m, out.upd, b);
+    const bool emit = can_emit && out.emit_next && out.upd.lambda && out.upd.partial && positive;
+    if (out.upd.lambda)
+        m->lambda_positive = positive;
     sstats_update_fn kern = sstats_update_entry<T, NKB, NH, false>();
     if constexpr (can_emit) {
         if (emit)
@@ -802,6 +826,13 @@ int sstats_update_device(trlda_model *m, const trlda_batch *b, EstepOut &out)
     // (measured: 7.1 vs 7.4 us at K = 100, 170 vs 145 us at K = 500)
     if (K % 2 == 0 && m->pair_gathers) {
         // a lane owns two adjacent topics: 16-byte gathers, 256 topics per pass over a list
+#ifdef TRLDA_EMIT_T512
+        // measurement variant: the instantiation that also emits exp(psi(lambda)) as 512-thread
+        // workgroups at <= 80 VGPRs (three per CU) instead of 1024-thread ones at <= 64 (two per CU)
+        if (K <= 128 && out.emit_next && out.upd.lambda && out.upd.partial &&
+            mstep_keeps_positive(m, out.upd, b))
+            return launch_sstats_update<512, 1, 1>(m, b, out);
+#endif
         if (K <= 128)
             return launch_sstats_update<1024, 1, 1>(m, b, out);
         if (K < 256)
@@ -1489,6 +1520,7 @@ int blend_device(trlda_model *m, const double *lambda_prime, const double *sstat
                  double eta, double scale)
 {
     invalidate_rowsums(m);
+    m->lambda_positive = false;                 // (not tracked through this path)
     m->rs_floor = rho * m->V * eta;     // (1 - rho) lambda' >= 0 whatever lambda' is
     return launch_elementwise(m, (size_t)m->K * m->V,
                               trlda::BlendOp{rho, eta, scale, lambda_prime, sstats, m->lambda});
@@ -1541,6 +1573,7 @@ int tr_init_wc_device(trlda_model *m, const double *wc, const double *lambda_pri
                       double eta, double coef)
 {
     invalidate_rowsums(m);
+    m->lambda_positive = false;                 // (not tracked through this path)
     m->rs_floor = rho * m->V * eta;
     if (stream_available(m)) {
         int G = 0;
@@ -1583,13 +1616,18 @@ void note_host_lambda(trlda_model *m, const double *host_lambda)
 {
     invalidate_rowsums(m);
     m->rs_floor = 0.0;
+    m->lambda_positive = false;
     const size_t K = (size_t)m->K, V = (size_t)m->V;
     if (K * V >= ((size_t)1 << 22) || m->K > trlda::kRegMaxK)
         return;
     std::vector<double> sum(K, 0.0);
+    bool positive = true;
     for (size_t w = 0; w < V; ++w)
-        for (size_t k = 0; k < K; ++k)
+        for (size_t k = 0; k < K; ++k) {
             sum[k] += host_lambda[w * K + k];
+            positive = positive && host_lambda[w * K + k] > 0.0;     // (NaN: false)
+        }
+    m->lambda_positive = positive;
     double lo = sum[0];
     for (size_t k = 1; k < K; ++k)
         lo = std::min(lo, sum[k]);
@@ -1961,7 +1999,7 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     }
     std::memcpy(I(o_wptr), wptr.data(), ((size_t)V + 1) * 4);
     // stable counting sort of the CSR positions by word id, and the words' count sums
-    bool wc32_ok = true;
+    bool wc32_ok = true, cnts_nonneg = true;
     {
         int32_t *wrank = I(o_wrank), *wdoc = I(o_wdoc), *wc32 = I(o_wc32);
         std::vector<int32_t> cursor(wptr.begin(), wptr.end() - 1);
@@ -1972,6 +2010,7 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
                 wrank[p] = q;
                 wdoc[q] = d;
                 wsum[(size_t)ids[p]] += cnts[p];
+                cnts_nonneg = cnts_nonneg && cnts[p] >= 0;
             }
         for (int w = 0; w < V; ++w) {
             wc32_ok = wc32_ok && wsum[(size_t)w] >= INT32_MIN && wsum[(size_t)w] <= INT32_MAX;
@@ -2135,6 +2174,7 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     b->active_flag = reinterpret_cast<uint8_t *>(dv + o_flag);
     b->wc32 = D(o_wc32);
     b->wc32_ok = wc32_ok;
+    b->cnts_nonneg = cnts_nonneg;
     *out = b;
     return TRLDA_OK;
 }
@@ -2434,6 +2474,7 @@ void *trlda_model_lambda_dev(trlda_model *m)
         return nullptr;
     // whoever holds this pointer may write lambda: nothing is known about its row sums any more
     invalidate_rowsums(m);
+    m->lambda_positive = false;                 // (not tracked through this path)
     m->rs_floor = 0.0;
     m->lambda_exposed = true;
     return m->lambda;
@@ -2944,6 +2985,7 @@ int trlda_model_batch_update(trlda_model *m, const trlda_batch *b, double eta, i
             rc = estep_device(m, b, m->gamma, m->sstats, max_iter_inference, threshold, nullptr);
             if (!rc) {
                 invalidate_rowsums(m);
+                m->lambda_positive = false;                 // (not tracked through this path)
                 m->rs_floor = m->V * eta;
                 rc = launch_elementwise(m, KV, trlda::SetOp{eta, m->sstats, m->lambda});
             }
@@ -2983,6 +3025,7 @@ int trlda_model_cumulative_update(trlda_model *m, const trlda_batch *b, int max_
     HIP_TRY(hipMemcpyAsync(m->lambda_prime, m->lambda, KV * sizeof(double),
                            hipMemcpyDeviceToDevice, m->stream));
     const double floor_prime = m->rs_floor;
+    const bool prime_positive = m->lambda_positive;          // of lambda', which the M-steps add to
     if (m->host_gamma_draw) {
         std::vector<double> lam0(KV);
         trlda_sample_gamma_init(K, m->V, lam0.data());
@@ -3018,6 +3061,8 @@ int trlda_model_cumulative_update(trlda_model *m, const trlda_batch *b, int max_
     }
     const bool fused = fused_update_available(m) && stream_available(m);
     bool ran = false;
+    // (the drawn lambda is positive; what mstep_keeps_positive asks about is lambda' + statistics)
+    m->lambda_positive = prime_positive;
     if (update_lambda) {
         for (int epoch = 0; epoch < max_epochs; ++epoch) {    // cumulativelda.cpp:62-71
             rc = fresh_gamma_device(m, B);
@@ -3042,6 +3087,7 @@ int trlda_model_cumulative_update(trlda_model *m, const trlda_batch *b, int max_
                 rc = estep_device(m, b, m->gamma, m->sstats, max_iter_inference, threshold, nullptr);
                 if (!rc) {
                     invalidate_rowsums(m);
+                    m->lambda_positive = false;                 // (not tracked through this path)
                     m->rs_floor = floor_prime;
                     rc = launch_elementwise(
                         m, KV, trlda::AccumulateOp{m->lambda_prime, m->sstats, m->lambda});
@@ -3226,6 +3272,7 @@ int trlda_model_batch_update_multi(trlda_model *m, const trlda_batch *shard, voi
         if (!rc) rc = allreduce_f64(m, rccl_comm, m->sstats, KV);
         if (!rc) {
             invalidate_rowsums(m);
+            m->lambda_positive = false;                 // (not tracked through this path)
             m->rs_floor = m->V * eta;
             rc = launch_elementwise(m, KV, trlda::SetOp{eta, m->sstats, m->lambda});   // :60
         }
