@@ -318,6 +318,11 @@ def test_world_one_is_the_single_gpu_call(hip):
     lam0 = random_lambda(K, V, 31)
     a = Single(L, K, V, lam0, .1)
     b = Single(L, K, V, lam0, .1)
+    # (the one-GPU call with the statistics as a kernel of their own, as every *_dp call has them --
+    # an exchange sits between its documents and its statistics; as workgroups of the document
+    # launch, csrc/estep_merged.h, the row sums are added up in another order: ~1e-12 in lambda,
+    # tests/test_gpu_merged.py)
+    assert L.trlda_model_set_merged_launch(a.h, 0) == 0
     cuts = np.array([0, B], dtype=np.int32)
     for call, tr in enumerate((4, 0)):
         a.update(csr, D, .3, 40 + call, tr, 20)

@@ -553,7 +553,53 @@ struct DocKernelArgs {
     int meta_i4;
     double *xbuf;
     int *xerr;                // set to 1 when an exchange gave up waiting (never in a sane run)
+    // merged launch (estep_merged.h): the statistics are workgroups of THIS launch -- the outputs
+    // they read (epg, tw_word) go out with agent-scope stores and every document workgroup counts
+    // itself done; the topic factors `scale_in` are being finished by workgroups of this launch
+    // and are there when *scale_wait has reached scale_target
+    unsigned int *done_counter;           // or nullptr
+    unsigned int done_target;             // the workgroup that brings the counter here ...
+    unsigned int *go_flags;               // ... writes `epoch` into the n_go flags of the statistics
+    int n_go;                             //     workgroups (kMergedFlagStride apart)
+    unsigned int epoch;
+    const unsigned int *scale_wait;       // this workgroup's flag, or nullptr: scale_in (if any) is
+                                          // complete; there when the flag has reached `epoch`
 };
+
+// an output of the document kernels that the statistics stage reads
+__device__ __forceinline__ void merged_store(double *p, double v, bool coherent)
+{
+    if (coherent)                                    // launch-uniform
+        __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else
+        *p = v;
+}
+
+// The finished topic factors of a merged launch: written by workgroups of the same launch
+// (merged_combine) that are resident before any document needs them -- they follow the
+// documents in the grid and the host only takes that path when every document workgroup is
+// resident at once.  Thread k < K; workgroup 0 also leaves the three values in a.scale_out.
+__device__ __forceinline__ double scale_wait_load(const DocKernelArgs &a, int K, int k)
+{
+    int spins = 0;
+    while ((int)(__hip_atomic_load(a.scale_wait + (size_t)blockIdx.x * 16, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT) - a.epoch) < 0) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > (1 << 22)) {                   // never in a sane run: fail the call, do not hang
+            if (a.xerr)
+                __hip_atomic_store(a.xerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
+    }
+    double *in = const_cast<double *>(a.scale_in);
+    const double ck = __hip_atomic_load(in + 2 * K + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == 0 && a.scale_out) {
+        a.scale_out[k] = __hip_atomic_load(in + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.scale_out[K + k] = __hip_atomic_load(in + K + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.scale_out[2 * K + k] = ck;
+    }
+    return ck;
+}
 
 // sum_{i<count} a[i] * b[i * stride] with NA independent accumulators.  A dependent fp64
 // fma chain on gfx950 advances one link per ~37 cycles while a wave can issue one every
@@ -1039,7 +1085,7 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
     if (tid < K) {
         gk0 = a.gamma_in[(size_t)d * K + tid];
         ak0 = a.alpha[tid];
-        if (a.scale_in) {                            // finished by the launch that prepared them
+        if (a.scale_in && !a.scale_wait) {           // finished by the launch that prepared them
             ck0 = a.scale_in[2 * K + tid];
             if (blockIdx.x == 0 && a.scale_out) {
                 a.scale_out[tid] = a.scale_in[tid];
@@ -1128,7 +1174,9 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
     if (tid < K) {
         double ck = 1.0;
         if (a.partial) {                             // launch-uniform
-            ck = a.scale_in ? ck0 : topic_scale_combine(K, tid, part, a.scale_out);
+            // (merged launch: being finished by workgroups of this launch while the slice was staged)
+            ck = a.scale_in ? (a.scale_wait ? scale_wait_load(a, K, tid) : ck0)
+                            : topic_scale_combine(K, tid, part, a.scale_out);
             ebuf[tid] = e0 * ck;
         }
         c_l[tid] = ck;
@@ -1364,7 +1412,7 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
     if (!SPLIT || seg.x == 0) {
         for (int k = tid; k < K; k += T) {
             gamma_d[k] = g[k];
-            a.epg[(size_t)d * K + k] = e[k];
+            merged_store(a.epg + (size_t)d * K + k, e[k], a.done_counter != nullptr);
         }
         if (tid == 0 && a.iters_out)
             a.iters_out[d] = it;
@@ -1378,7 +1426,8 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
         }
     } else {
         if (tid < n)
-            a.tw_word[a.wrank ? a.wrank[p0 + tid] : p0 + tid] = tw[tid];
+            merged_store(a.tw_word + (a.wrank ? a.wrank[p0 + tid] : p0 + tid), tw[tid],
+                         a.done_counter != nullptr);
     }
     TRLDA_STAMP(6);
     TRLDA_STAMP_FLUSH;
@@ -1633,6 +1682,9 @@ __device__ __forceinline__ void finish_partial_groups(const UpdateOut &o, int K,
 {
     if (!o.group_rows)                               // launch-uniform
         return;
+#ifdef TRLDA_EXPT_NOGROUP                            // timing experiment: results are wrong
+    return;
+#endif
     __shared__ int last_of_group;
     const int rows = (int)gridDim.x;
     const int g = bid / o.group_size;

@@ -1,0 +1,459 @@
+// estep_merged.h -- ONE launch per E-step on small tables: the statistics stage (src/lda.cpp:207-217),
+// the M-step (src/onlinelda.cpp:99-100, src/batchlda.cpp:60) and the row sums the next E-step needs
+// (src/lda.cpp:172) as WORKGROUPS OF THE DOCUMENT LAUNCH.
+//
+// A kernel of this path costs ~4.5 us before it does anything (rocprofv3: the durations of a
+// stream's dependent kernels are back to back, and an empty one is not shorter than that:
+// profiles/r04_timeline_*.txt), and a 200-document step has two of them: documents 31 us,
+// statistics 7 us of which ~2.5 are its work.  Here the statistics are `n_short + n_long` extra
+// workgroups at the end of the document launch's grid.  They
+//
+//   * start as soon as a CU has room -- 56 of the 256 CUs have from the start -- and use the wait
+//     for everything that does not depend on the documents: their words' descriptors, the
+//     documents of their words' entries (static per batch), exp(psi(lambda)) and lambda' of
+//     their words, the zero columns of the words outside the batch;
+//   * wait until every document workgroup has counted itself done (`docs_done`, a counter that
+//     only grows: the host passes the value it must reach).  A document workgroup stores its
+//     outputs (exp(psi(gamma)) and the weights cnt / phinorm) with agent-scope stores, waits for
+//     their acknowledgement, counts; a waiting wave then invalidates its caches (agent-scope
+//     acquire) and reads them: the entries' weights and the rows of exp(psi(gamma)) of ALL its
+//     entries are in flight together -- one memory latency, where the stand-alone kernel has
+//     four dependent ones (word -> list bounds -> entries -> rows);
+//   * leave their row of the new lambda's row sums in `o.partial`; the NEXT launch's `n_comb`
+//     workgroups add the rows up and finish the topic factors c_k = exp(-psi(row sum)) while the
+//     documents stage their slices (`c_ready`, the same kind of counter) -- the stand-alone kernel
+//     combines its rows in groups behind a last-block-done counter, 3 us at its end
+//     (profiles/r04_timeline_nogroup_fused.txt).
+//
+// The document workgroups come FIRST in the grid and the host only takes this path when all of
+// them are resident at once (kMergedMaxDocWgs), so nothing they wait for (the topic factors) can
+// be queued behind them, and the helpers never hold a CU a document needs: a document workgroup
+// fills a CU's registers, a helper can only go where no document runs.
+//
+// Arithmetic: a word's entries are added in document order by ONE wave, four at a time in flight,
+// exactly as word_segment_sum2 does (estep_kernels.h, 4d); a word of more than 16 entries is cut
+// into the same sixteen chunks as the 1024-thread kernel cuts it and combined in the same order:
+// bitwise the statistics of the stand-alone kernel (tests/test_gpu_merged.py).
+#pragma once
+#include "estep_kernels.h"
+#include "estep_wide.h"
+
+namespace trlda {
+
+constexpr int kMergedMaxDocWgs = 224;   // document workgroups of a merged launch: all resident at once
+constexpr int kMergedComb = 4;          // workgroups that finish the topic factors
+constexpr int kMergedNW = 4;            // words a wave of the statistics stage works on at a time
+constexpr int kMergedFlagStride = 16;   // unsigned ints between two waiters' flags (64 bytes)
+constexpr int kMergedMaxHelpers = 512;  // flags of the statistics workgroups
+
+struct MergedArgs {
+    int first;                    // helper workgroups start here (documents + next-batch preamble before)
+    int n_comb, n_short, n_long;  // [first ..) topic factors | words of <= 16 entries | longer lists
+    // topic factors of THIS E-step from the block rows the previous M-step left (n_comb > 0)
+    const double *c_rows;         // c_n x K
+    int c_n;
+    const double *c_base;         // K or nullptr: the share of the words outside the batch
+    double *c_out;                // 3 K: psi(row sum), row sum, exp(-psi)
+    unsigned int *c_ready;        // += 1 per combine workgroup
+    unsigned int c_target;
+    // statistics
+    int K, V, N_short, N_long;
+    const int4 *desc;             // N_short + N_long x (word, first entry, entries, 0), by decreasing length
+    const int32_t *wdoc;          // document of each word-major entry
+    const double *tw_word;        // cnt / phinorm in word-major order (written by this launch's documents)
+    const double *epg;            // exp(psi(gamma)) rows (ditto); row -1 is zero
+    const double *eeb;            // exp(psi(lambda)) of the batch's words (may be o.u_out)
+    UpdateOut o;                  // o.partial: n_short + n_long rows
+    const uint8_t *active_flag;   // V bytes, or nullptr: no zero columns to write
+    unsigned int *docs_done;      // += 1 per document workgroup
+    unsigned int docs_target;
+    int *xerr;                    // set when a wait gave up (never in a sane run)
+    // Nobody polls the counters: thousands of waves asking for ONE address every few hundred
+    // cycles kept its memory channel -- and the fabric towards it -- so busy that the documents'
+    // own loads took twice as long (60 us per launch instead of 37, round 4).  Every waiter has a
+    // flag of its own, 64 bytes apart; whoever brings a counter to its target writes the launch's
+    // number (`epoch`, it only grows) into the flags of those who wait for it.
+    unsigned int *go_flags;       // one per statistics workgroup (kMergedFlagStride apart)
+    unsigned int *c_flags;        // one per document workgroup
+    unsigned int epoch;
+    int n_docs;                   // document workgroups of the launch (flags to set)
+    int dbg;                      // experiments (TRLDA_MERGED_DBG): 1 helpers return at once, 2 after the wait
+};
+
+// ---- the document side --------------------------------------------------------------------
+// (estep_kernels.h / estep_wide.h: every output the statistics read goes out with merged_store)
+__device__ __forceinline__ void docs_done_signal(const DocKernelArgs &a)
+{
+    if (!a.done_counter)                             // launch-uniform
+        return;
+    __shared__ int last_doc;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this thread's stores: acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0)
+        last_doc = __hip_atomic_fetch_add(a.done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u ==
+                   a.done_target;
+    __syncthreads();
+    if (last_doc)                                    // every document has stored and counted: go
+        for (int i = threadIdx.x; i < a.n_go; i += kRegThreads)
+            __hip_atomic_store(a.go_flags + (size_t)i * kMergedFlagStride, a.epoch, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- topic factors ----------------------------------------------------------------------------
+// c_k = exp(-psi(base_k + sum_r rows[r][k])): workgroup vb of n_comb takes a contiguous range of
+// topics; sixteen threads per topic add every sixteenth row (eight loads in flight), the parts are
+// combined in order.  The same sums on every device: replicas stay bitwise equal.
+__device__ __forceinline__ void merged_combine(const MergedArgs &mg, int vb, double *lds)
+{
+    const int tid = threadIdx.x, K = mg.K;
+    const int kper = (K + mg.n_comb - 1) / mg.n_comb;            // <= 32 (K <= 128, four workgroups)
+    const int k0 = vb * kper, kn = max(0, min(kper, K - k0));
+    const int kk = tid & 31, part = tid >> 5;                    // 32 topics x 16 parts
+    double acc = 0.0;
+    if (kk < kn) {
+        const double *col = mg.c_rows + k0 + kk;
+        for (int r = part; r < mg.c_n; r += 16 * 8) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                v[q] = col[(size_t)min(r + 16 * q, mg.c_n - 1) * K];
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                acc += (r + 16 * q < mg.c_n) ? v[q] : 0.0;
+        }
+    }
+    lds[part * 32 + kk] = acc;
+    __syncthreads();
+    if (tid < kn) {
+        double rs = mg.c_base ? mg.c_base[k0 + tid] : 0.0;
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+            rs += lds[p * 32 + tid];
+        const double ps = digamma(rs);
+        const int k = k0 + tid;
+        __hip_atomic_store(mg.c_out + k, ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mg.c_out + K + k, rs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mg.c_out + 2 * K + k, exp(-ps), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __shared__ int last_comb;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0)
+        last_comb = __hip_atomic_fetch_add(mg.c_ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u ==
+                    mg.c_target;
+    __syncthreads();
+    if (last_comb)                                   // all of c_out is in memory: tell the documents
+        for (int i = tid; i < mg.n_docs; i += kRegThreads)
+            __hip_atomic_store(mg.c_flags + (size_t)i * kMergedFlagStride, mg.epoch, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- statistics ---------------------------------------------------------------------------------
+// every document workgroup of this launch has stored its outputs
+// Block-level: thread 0 watches this workgroup's own flag (the last document to finish sets it), at
+// a rate that costs the memory system nothing.  (A flag that never comes -- it cannot: the
+// documents are resident and wait for nothing that waits for them -- ends the wait after ~1 s and
+// fails the next synchronising call.)
+__device__ __forceinline__ void merged_wait_docs(const MergedArgs &mg, int vb)
+{
+    if (threadIdx.x == 0) {
+        unsigned int *flag = mg.go_flags + (size_t)vb * kMergedFlagStride;
+        int spins = 0;
+        while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - mg.epoch) < 0) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1 << 22)) {
+                if (mg.xerr)
+                    __hip_atomic_store(mg.xerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    // No cache invalidation here.  An agent-scope acquire (buffer_inv sc1) per wave made the stage
+    // take 20 us instead of 3: two thousand invalidations of the XCDs' L2s, one after the other.
+    // Nor is one needed: the only data of this launch that a waiter reads and another workgroup
+    // of the launch has written are epg and tw_word; they went out write-through (merged_store)
+    // before the flag; no line of them can sit in this CU's L1 or this XCD's L2 from BEFORE that --
+    // the caches start a kernel empty of them (the kernel boundary's acquire), a document
+    // workgroup only writes them (bytes it wrote are valid, the others are fetched), and nothing
+    // of this stage reads them before this point.  The weights are read with agent-scope loads
+    // anyway; tests/test_gpu_merged.py alternates two batches through the same buffers 600 times.
+#ifdef TRLDA_MERGED_ACQUIRE
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+}
+
+// NS list segments of at most 16 entries each, side by side: acc[j] += sum_u tw[q0_j + u] *
+// epg[doc_u, 2 lane .. 2 lane + 1] in entry order, four rows per segment in flight per round.
+// docs[j]: lane u holds the document of entry u (or -1, the zero row); `maxlen`: the longest of
+// the segments (wave-uniform): rounds past it are skipped.
+template <int NS>
+__device__ __forceinline__ void merged_segments(const int (&docs)[NS], const double (&tw)[NS], int maxlen,
+                                                const double *__restrict__ epg, int K, int kk,
+                                                double2 (&acc)[NS])
+{
+    int tlo[NS], thi[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        tlo[j] = __double2loint(tw[j]);
+        thi[j] = __double2hiint(tw[j]);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r += 4) {
+        if (r < maxlen) {                            // wave-uniform
+            double2 ev[NS][4];
+#pragma unroll
+            for (int j = 0; j < NS; ++j)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const long long row = (long long)__builtin_amdgcn_readlane(docs[j], r + u) * K;
+                    ev[j][u] = *reinterpret_cast<const double2 *>(epg + row + kk);
+                }
+#pragma unroll
+            for (int j = 0; j < NS; ++j)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double tu = __hiloint2double(__builtin_amdgcn_readlane(thi[j], r + u),
+                                                       __builtin_amdgcn_readlane(tlo[j], r + u));
+                    acc[j].x = fma(tu, ev[j][u].x, acc[j].x);   // (+0 * 0 past a segment's end)
+                    acc[j].y = fma(tu, ev[j][u].y, acc[j].y);
+                }
+        }
+    }
+}
+
+// the pair (i, i + 1) of one word: statistics, M-step, exp(psi(lambda)) where asked for;
+// returns the two lambdas written (update_pair with the emission as a run-time switch)
+__device__ __forceinline__ double2 merged_update_pair(const UpdateOut &o, size_t i, double2 s, double2 lp)
+{
+    if (o.sstats)
+        *reinterpret_cast<double2 *>(o.sstats + i) = s;
+    double2 lam = make_double2(0.0, 0.0);
+    if (o.lambda) {
+        const double hx = o.eta + o.scale * s.x, hy = o.eta + o.scale * s.y;
+        if (o.lambda_prime) {
+            lam.x = o.omr * lp.x + o.rho * hx;
+            lam.y = o.omr * lp.y + o.rho * hy;
+        } else {
+            lam.x = o.rho * hx;
+            lam.y = o.rho * hy;
+        }
+        *reinterpret_cast<double2 *>(o.lambda + i) = lam;
+        if (o.u_out)                                 // launch-uniform; lam > 0 (the host knows)
+            *reinterpret_cast<double2 *>(o.u_out + i) =
+                make_double2(exp_digamma_positive(lam.x), exp_digamma_positive(lam.y));
+    }
+    return lam;
+}
+
+__device__ __forceinline__ void merged_stats(const MergedArgs &mg, int vb, double *lds)
+{
+    constexpr int W = kRegThreads / kWave;           // 8 waves
+    constexpr int NW = kMergedNW;
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int K = mg.K;
+    const UpdateOut &o = mg.o;
+    const int kk = min(2 * lane, K - 2);             // this lane's pair of topics (K even)
+    const bool k_on = 2 * lane < K;
+    const int n_stat = mg.n_short + mg.n_long;
+    if (mg.dbg == 1)
+        return;
+    if (mg.dbg == 2) {
+        merged_wait_docs(mg, vb);
+        return;
+    }
+    if (mg.dbg == 3 && vb >= mg.n_short)
+        return;
+    if (mg.dbg == 4 && vb < mg.n_short)
+        return;
+
+    // columns of the words outside the batch: zero (lda.cpp:169), written while the documents run
+    if (mg.active_flag && o.sstats && !o.lambda) {   // launch-uniform
+        for (int w = vb * W + wid; w < mg.V; w += n_stat * W)
+            if (!mg.active_flag[w] && k_on)
+                *reinterpret_cast<double2 *>(o.sstats + (size_t)w * K + 2 * lane) = make_double2(0.0, 0.0);
+    }
+
+    if (vb < mg.n_short) {
+        // ---- a wave per word, NW words at a time: words gw, gw + NWAVES, .. of the short list
+        const int NWAVES = mg.n_short * W;
+        const int gw = vb * W + wid;
+        double2 rs = make_double2(0.0, 0.0);
+        bool waited = false;
+        for (int t0 = gw; t0 < mg.N_short; t0 += NW * NWAVES) {     // wave-uniform
+            int wv[NW], len[NW], docs[NW], q0[NW];
+            double2 e2[NW], lp[NW], acc[NW];
+            int maxlen = 0;
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                const int t = t0 + j * NWAVES;
+                const int4 d = mg.desc[min(t, mg.N_short - 1)];
+                wv[j] = __builtin_amdgcn_readfirstlane(d.x);
+                q0[j] = __builtin_amdgcn_readfirstlane(d.y);
+                len[j] = t < mg.N_short ? __builtin_amdgcn_readfirstlane(d.z) : 0;
+                maxlen = max(maxlen, len[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                docs[j] = lane < len[j] ? mg.wdoc[q0[j] + lane] : -1;       // -1: the zero row
+                const size_t ic = (size_t)wv[j] * K + kk;
+                e2[j] = *reinterpret_cast<const double2 *>(mg.eeb + ic);
+                lp[j] = o.lambda_prime ? *reinterpret_cast<const double2 *>(o.lambda_prime + ic)
+                                       : make_double2(0.0, 0.0);
+                acc[j] = make_double2(0.0, 0.0);
+            }
+            if (!waited) {                           // (every wave of the workgroup comes by once:
+                merged_wait_docs(mg, vb);            //  here, or below when it has no word)
+                waited = true;
+            }
+            double tw[NW];
+#pragma unroll
+            for (int j = 0; j < NW; ++j)
+                tw[j] = lane < len[j] ? __hip_atomic_load(const_cast<double *>(mg.tw_word) + q0[j] + lane,
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                      : 0.0;
+            merged_segments<NW>(docs, tw, maxlen, mg.epg, K, kk, acc);
+#pragma unroll
+            for (int j = 0; j < NW; ++j) {
+                if (len[j] > 0 && k_on) {            // (len: wave-uniform)
+                    const double2 s = make_double2(acc[j].x * e2[j].x, acc[j].y * e2[j].y);
+                    const double2 lam = merged_update_pair(o, (size_t)wv[j] * K + 2 * lane, s, lp[j]);
+                    rs.x += lam.x;
+                    rs.y += lam.y;
+                }
+            }
+        }
+        if (!waited)
+            merged_wait_docs(mg, vb);
+        if (o.partial) {                             // launch-uniform
+            if (k_on)
+                *reinterpret_cast<double2 *>(lds + wid * K + 2 * lane) = rs;
+            __syncthreads();
+            for (int k = tid; k < K; k += kRegThreads) {
+                double sum = lds[k];
+#pragma unroll
+                for (int c = 1; c < W; ++c)
+                    sum += lds[c * K + k];
+                o.partial[(size_t)vb * K + k] = sum;
+            }
+        }
+        return;
+    }
+
+    // ---- a workgroup per long list: the sixteen contiguous chunks of the 1024-thread kernel
+    // (chunk = ceil(L / 16) <= 16 entries here), two per wave side by side, combined in chunk order
+    const int lb = vb - mg.n_short;
+    double rsl = 0.0;                                // thread k: row sum of what it writes
+    bool waited = false;
+    for (int t = lb; t < mg.N_long; t += mg.n_long) {
+        const int4 d = mg.desc[mg.N_short + t];
+        const int w = __builtin_amdgcn_readfirstlane(d.x), base = __builtin_amdgcn_readfirstlane(d.y);
+        const int L = __builtin_amdgcn_readfirstlane(d.z);
+        const int chunk = (L + 15) / 16;             // <= 16 (the host takes this path for L <= 256)
+        int docs[2], clen[2], c0[2];
+        double2 acc[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int v = wid + 8 * h;               // chunk index
+            c0[h] = min(L, v * chunk);
+            clen[h] = min(L, c0[h] + chunk) - c0[h];
+            docs[h] = lane < clen[h] ? mg.wdoc[base + c0[h] + lane] : -1;
+            acc[h] = make_double2(0.0, 0.0);
+        }
+        if (!waited) {
+            merged_wait_docs(mg, vb);
+            waited = true;
+        }
+        double tw[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            tw[h] = lane < clen[h] ? __hip_atomic_load(const_cast<double *>(mg.tw_word) + base + c0[h] + lane,
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                   : 0.0;
+        merged_segments<2>(docs, tw, max(clen[0], clen[1]), mg.epg, K, kk, acc);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (k_on)
+                *reinterpret_cast<double2 *>(lds + (wid + 8 * h) * K + 2 * lane) = acc[h];
+        __syncthreads();
+        if (tid < K) {
+            double sum = lds[tid];
+#pragma unroll
+            for (int c = 1; c < 16; ++c)
+                sum += lds[c * K + tid];
+            const size_t i = (size_t)w * K + tid;
+            const double s = sum * mg.eeb[i];
+            if (o.sstats)
+                o.sstats[i] = s;
+            if (o.lambda) {
+                const double hat = o.eta + o.scale * s;
+                const double lam = o.lambda_prime ? o.omr * o.lambda_prime[i] + o.rho * hat : o.rho * hat;
+                o.lambda[i] = lam;
+                if (o.u_out)
+                    o.u_out[i] = exp_digamma_positive(lam);
+                rsl += lam;
+            }
+        }
+        __syncthreads();
+    }
+    if (o.partial && tid < K)
+        o.partial[(size_t)vb * K + tid] = rsl;
+}
+
+// the workgroups past the documents and the next batch's preamble
+__device__ __forceinline__ void merged_helper(const MergedArgs &mg, double *lds)
+{
+    const int vb = (int)blockIdx.x - mg.first;
+    if (vb < mg.n_comb)
+        merged_combine(mg, vb, lds);
+    else
+        merged_stats(mg, vb - mg.n_comb, lds);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kRegThreads) void estep_docs_reg_merged_kernel(DocKernelArgs a, PreArgs pre,
+                                                                             MergedArgs mg)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if ((int)blockIdx.x >= mg.first) {               // block-uniform
+        merged_helper(mg, lds);
+        return;
+    }
+    if ((int)blockIdx.x >= pre.n_docs) {
+        docs_launch_preamble(pre, lds);
+        return;
+    }
+    estep_docs_reg_body<MODE>(a, lds);
+    docs_done_signal(a);
+}
+
+template <int KS>
+__global__ __launch_bounds__(kRegThreads) void estep_docs_tiered_merged_kernel(DocKernelArgs a, PreArgs pre,
+                                                                                int lds_rows, MergedArgs mg)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if ((int)blockIdx.x >= mg.first) {               // block-uniform
+        merged_helper(mg, lds);
+        return;
+    }
+    if ((int)blockIdx.x >= pre.n_docs) {
+        docs_launch_preamble(pre, lds);
+        return;
+    }
+    const int n = a.pad_meta[4 * (size_t)blockIdx.x * a.meta_i4 + 1];
+    if (a.meta_i4 == 2 && a.pad_meta[4 * ((size_t)blockIdx.x * 2 + 1) + 1] > 1) {
+        estep_docs_reg_body<0, true>(a, lds);        // one segment of a document split over CUs
+    } else if (n <= 128) {
+        estep_docs_reg_body<0>(a, lds);
+    } else if (n <= 144) {
+        estep_docs_reg_body<1>(a, lds);
+    } else {
+        const int4 meta = reinterpret_cast<const int4 *>(a.pad_meta)[(size_t)blockIdx.x * a.meta_i4];
+        estep_docs_wide_body<KS, true>(a, lds_rows, lds, meta.x, meta.z, meta.y);
+    }
+    docs_done_signal(a);
+}
+
+}  // namespace trlda

@@ -281,7 +281,7 @@ __device__ __forceinline__ void estep_docs_wide_body(const DocKernelArgs &a, int
         gk = a.gamma_in[(size_t)d * K + tid];
         ak = a.alpha[tid];
         if constexpr (FACTORS) {
-            if (a.scale_in) {                        // finished by the launch that prepared them
+            if (a.scale_in && !a.scale_wait) {       // finished by the launch that prepared them
                 ck = a.scale_in[2 * K + tid];
                 if (blockIdx.x == 0 && a.scale_out) {
                     a.scale_out[tid] = a.scale_in[tid];
@@ -365,6 +365,8 @@ __device__ __forceinline__ void estep_docs_wide_body(const DocKernelArgs &a, int
             if (k_on) {
                 if (!a.scale_in)
                     ck = topic_scale_combine(K, tid, part, a.scale_out);
+                else if (a.scale_wait)               // merged launch (estep_merged.h)
+                    ck = scale_wait_load(a, K, tid);
                 ek *= ck;
                 ebuf[tid] = ek;
             }
@@ -566,7 +568,7 @@ __device__ __forceinline__ void estep_docs_wide_body(const DocKernelArgs &a, int
     // ---- results
     if (k_on) {
         a.gamma[(size_t)d * K + tid] = gk;
-        a.epg[(size_t)d * K + tid] = ek;
+        merged_store(a.epg + (size_t)d * K + tid, ek, a.done_counter != nullptr);
     }
     if (tid == 0 && a.iters_out)
         a.iters_out[d] = it;
@@ -597,11 +599,13 @@ __device__ __forceinline__ void estep_docs_wide_body(const DocKernelArgs &a, int
 #pragma unroll
             for (int g = 0; g < NH; ++g)
                 if (jv[g] >= 0)
-                    a.tw_word[a.wrank ? a.wrank[p0 + jv[g]] : p0 + jv[g]] = twv[g];
+                    merged_store(a.tw_word + (a.wrank ? a.wrank[p0 + jv[g]] : p0 + jv[g]), twv[g],
+                                 a.done_counter != nullptr);
         }
         __syncthreads();                             // tw_csr of the tail words
         for (int j = n_reg + tid; j < n; j += kWideThreads)
-            a.tw_word[a.wrank ? a.wrank[p0 + j] : p0 + j] = a.tw_csr[p0 + j];
+            merged_store(a.tw_word + (a.wrank ? a.wrank[p0 + j] : p0 + j), a.tw_csr[p0 + j],
+                         a.done_counter != nullptr);
     }
     TRLDA_STAMP(7);
     TRLDA_STAMP_FLUSH;

@@ -259,6 +259,9 @@ __device__ __forceinline__ double exp_digamma(double x) { return exp_digamma_min
 //   NaN              NaN
 __device__ __forceinline__ double exp_digamma_positive(double x)
 {
+#ifdef TRLDA_EXPT_NOEXP                              // timing experiment: results are wrong
+    return x;
+#endif
     const bool tiny = x < 1e-290, big = !(x < 1e25);
     double v = exp_psi_regular((tiny || big) ? 1.5 : x, 0.0);
     v = tiny ? 0.0 : v;

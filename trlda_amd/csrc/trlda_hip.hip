@@ -35,6 +35,7 @@
 #include "host_common.h"
 #include "estep_kernels.h"
 #include "estep_wide.h"
+#include "estep_merged.h"
 #include "elbo_kernels.h"
 #include "stream_kernels.h"
 #include "eb_kernels.h"
@@ -172,6 +173,11 @@ struct trlda_batch {
     int32_t *wc32 = nullptr;
     bool wc32_ok = false;
     bool cnts_nonneg = true;        // no negative count: the statistics are >= 0 (see lambda_positive)
+    // merged launch (estep_merged.h): (word, first entry, entries, 0) of the active words, first
+    // the n_short words of at most long_len entries, then the n_long others, each group by
+    // decreasing length (a wave's words of one round are then about equally long)
+    int32_t *mdesc = nullptr;       // n_active x 4
+    int n_short = 0;
 };
 
 // A data-parallel call in flight (dp_kernels.h): the model holds the whole mini-batch `b`, iterates
@@ -236,6 +242,7 @@ struct trlda_model {
         bool valid = false, all = false;
         uint64_t version = 0, batch_id = 0;
         int n = 0;
+        bool raw = false;               // the rows are block rows still to be added up (merged launch)
     } next_pre;
     bool emit_next_preamble = true;     // trlda_model_set_fused_update(.. & 2 == 0)
     bool carry_rowsums = true;          // trlda_model_set_carry_rowsums (tests, comparisons)
@@ -275,6 +282,19 @@ struct trlda_model {
         unsigned long long step = 0;
     } direct;
     double *epg = nullptr, *tw_csr = nullptr, *tw_word = nullptr;
+    double *epg_base = nullptr;         // the allocation: K zeros (row -1 of epg), then epg
+    // merged launch (estep_merged.h): the statistics as workgroups of the document launch.
+    // Two counters that only grow (documents done | topic factors finished) and what they have
+    // been asked to reach so far; the finished topic factors of an in-launch combine
+    bool merged_launch = true;          // trlda_model_set_merged_launch
+    bool last_merged = false;
+    unsigned int *sync_counters = nullptr;
+    unsigned int docs_done_total = 0, c_ready_total = 0;
+    // ... and a flag per waiter (statistics workgroups | document workgroups, 64 bytes apart) that
+    // receives the number of the launch it may go on in (merged_epoch: only grows)
+    unsigned int *sync_flags = nullptr;
+    unsigned int merged_epoch = 0;
+    double *scale_comb = nullptr;       // 3 K
     // split documents: the exchange rows of a launch (NaN before it), the give-up flag
     double *xbuf = nullptr;
     size_t cap_xbuf = 0;
@@ -466,7 +486,18 @@ int grow(T **p, size_t *cap, size_t count)
 
 int ensure_batch_workspace(trlda_model *m, const trlda_batch *b)
 {
-    int rc = grow(&m->epg, &m->cap_docs, (size_t)std::max(b->B, 1) * m->K);
+    // (row -1 of epg is zero: where the statistics stage of a merged launch points the entries
+    // past the end of a list, estep_merged.h)
+    int rc = TRLDA_OK;
+    const size_t rows = (size_t)std::max(b->B, 1) + 1;
+    if (rows * (size_t)m->K > m->cap_docs || !m->epg_base) {
+        rc = grow(&m->epg_base, &m->cap_docs, rows * (size_t)m->K);
+        m->epg = nullptr;
+        if (!rc) {
+            HIP_TRY(hipMemsetAsync(m->epg_base, 0, (size_t)m->K * sizeof(double), m->stream));
+            m->epg = m->epg_base + m->K;
+        }
+    }
     if (!rc) rc = grow(&m->tw_csr, &m->cap_tw_csr, (size_t)std::max<int64_t>(b->nnz, 1));
     if (!rc) rc = grow(&m->tw_word, &m->cap_tw_word, (size_t)std::max<int64_t>(b->nnz, 1));
     return rc;
@@ -673,6 +704,7 @@ struct EstepOut {
     bool emit_next = false;
     const double *next_base = nullptr;
     int groups = 0;
+    bool raw_rows = false;      // out: the `groups` rows are block rows still to be added up (merged launch)
     EstepOut() { upd = trlda::UpdateOut{}; }
     explicit EstepOut(double *sstats) : EstepOut() { upd.sstats = sstats; }
 };
@@ -1061,6 +1093,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
     }
     double *sstats_dev = out.upd.sstats;
     m->last_split_wgs = 0;
+    m->last_merged = false;
     if (m->timing && (rc = stamp(m)))
         return rc;
 
@@ -1087,12 +1120,26 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
     m->eeb_cur = m->eeb;
     // this batch's preamble may have been left behind by the kernel that wrote lambda (the
     // M-step inside the statistics kernel: UpdateOut::u_out / group_rows) ...
-    const bool handed = fused && carried && m->carry_pending && m->next_pre.valid &&
-                        m->next_pre.version == m->lambda_version &&
-                        (m->next_pre.all || m->next_pre.batch_id == b->id);
+    // Merged launch (estep_merged.h): how many workgroups the documents of this launch take, and
+    // whether helper workgroups may ride on it -- only when every document workgroup is resident
+    // at once (they come first in the grid and may wait for a helper)
+    const size_t xcount_m = (size_t)db->n_xrows * (size_t)(max_iter + 1) * (size_t)K;
+    const bool will_split = db->max_n > 128 && m->split_docs && db->n_wg > 0 && db->split_pays &&
+                            max_iter > 0 && xcount_m * sizeof(double) <= ((size_t)256 << 20);
+    const int doc_wgs = will_split ? db->n_wg : B;
+    const bool merged_capable = m->merged_launch && fused && !atomic && !dp && B > 0 &&
+                                doc_wgs <= trlda::kMergedMaxDocWgs;
+    bool handed = fused && carried && m->carry_pending && m->next_pre.valid &&
+                  m->next_pre.version == m->lambda_version &&
+                  (m->next_pre.all || m->next_pre.batch_id == b->id);
+    // (block rows still to be added up need this launch's combine workgroups: without them the
+    // preamble launch below adds them up -- and fills exp(psi(lambda)) once more)
+    if (handed && m->next_pre.raw && !merged_capable)
+        handed = false;
+    const bool comb = handed && m->next_pre.raw;
     if (handed) {
-        partial_in = m->upd_groups;
-        G = m->next_pre.n;
+        partial_in = comb ? m->carry_rows : m->upd_groups;
+        G = comb ? m->carry_n : m->next_pre.n;
         if (m->timing && ((rc = stamp(m)) || (rc = stamp(m))))
             return rc;
     }
@@ -1244,6 +1291,13 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         a.max_iter = max_iter; a.threshold = threshold; a.iters_out = iters_dev;
         a.partial = fused ? partial_in : nullptr;
         a.scale_in = prefetched ? m->scale_pp[cur_buf] : nullptr;
+        a.done_counter = nullptr; a.scale_wait = nullptr; a.done_target = 0;
+        a.go_flags = nullptr; a.n_go = 0;
+        a.epoch = m->merged_epoch + 1u;              // (of this launch, if it turns out to be merged)
+        if (comb) {                                  // finished by workgroups of this launch
+            a.scale_in = m->scale_comb;
+            a.scale_wait = m->sync_flags + (size_t)trlda::kMergedMaxHelpers * trlda::kMergedFlagStride;
+        }
         a.G = G;
         a.scale_out = fused ? m->psi_sum : nullptr;
         const int Kp = K | 1;
@@ -1431,7 +1485,86 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                 m->prefetch.G = pre.G;
                 m->prefetch.dense = dense;
             }
-            if (!tiered)
+            // The statistics (and what rides on them: M-step, row sums, the next preamble) as
+            // workgroups of this launch (estep_merged.h): small batches whose words' lists the
+            // stage's waves hold in one piece, pairs of topics per lane
+            int cus = 256;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device);
+            const bool merged_stats = merged_capable && n_wgs == doc_wgs && K % 2 == 0 && m->pair_gathers &&
+                                      b->long_len == trlda::kLongWord && b->B <= 256 && b->n_active > 0 &&
+                                      fused_update_available(m) &&
+                                      (out.upd.lambda ? out.active_only : sstats_dev != nullptr);
+            m->last_merged = merged_stats;
+            MergedArgs mg{};
+            mg.first = n_wgs + pre.nb;
+            if (comb) {
+                mg.n_comb = trlda::kMergedComb;
+                mg.c_rows = m->carry_rows; mg.c_n = m->carry_n; mg.c_base = m->carry_base;
+                mg.c_out = m->scale_comb; mg.c_ready = m->sync_counters + 1;
+                mg.c_target = m->c_ready_total + (unsigned int)trlda::kMergedComb;
+                mg.c_flags = m->sync_flags + (size_t)trlda::kMergedMaxHelpers * trlda::kMergedFlagStride;
+            }
+            mg.epoch = a.epoch; mg.n_docs = n_wgs;
+            if (const char *env = std::getenv("TRLDA_MERGED_DBG"))
+                mg.dbg = std::atoi(env);
+            mg.go_flags = m->sync_flags;
+            mg.K = K; mg.V = V;
+            if (merged_stats) {
+                mg.N_short = b->n_short; mg.N_long = b->n_long;
+                const int room = std::min(cus, trlda::kMergedMaxHelpers);
+                mg.n_long = std::min(mg.N_long, room / 2);
+                mg.n_short = mg.N_short > 0
+                                 ? std::max(1, std::min((mg.N_short + 8 * trlda::kMergedNW - 1) / (8 * trlda::kMergedNW),
+                                                        room - mg.n_long))
+                                 : 0;
+                mg.desc = reinterpret_cast<const int4 *>(b->mdesc);
+                mg.wdoc = b->wdoc; mg.tw_word = m->tw_word; mg.epg = m->epg; mg.eeb = m->eeb_cur;
+                mg.active_flag = (!out.upd.lambda && !out.active_only) ? b->active_flag : nullptr;
+                mg.docs_done = m->sync_counters;
+                mg.docs_target = m->docs_done_total + (unsigned int)n_wgs;
+                a.done_counter = m->sync_counters;
+                a.done_target = mg.docs_target;
+                a.go_flags = m->sync_flags;
+                a.n_go = mg.n_short + mg.n_long;
+                // what the stage writes: as launch_sstats_update decides it for the kernel of its own
+                const bool positive = out.upd.lambda && mstep_keeps_positive(m, out.upd, b);
+                const bool emit = out.emit_next && out.upd.lambda && out.upd.partial && positive;
+                if (out.upd.lambda)
+                    m->lambda_positive = positive;
+                out.upd.u_out = emit ? m->eeb : nullptr;
+                out.upd.group_rows = nullptr; out.upd.group_base = nullptr;
+                out.upd.group_counter = nullptr; out.upd.group_size = 1;
+                out.groups = emit ? mg.n_short + mg.n_long : 0;
+                out.raw_rows = emit;
+                out.partial_rows = mg.n_short + mg.n_long;
+                mg.o = out.upd;
+            }
+            const int n_help = mg.n_comb + mg.n_short + mg.n_long;
+            if (n_help > 0) {
+                if ((rc = ensure_xerr(m)))
+                    return rc;
+                mg.xerr = m->xerr;
+                a.xerr = m->xerr;
+                const void *mk = !tiered ? reinterpret_cast<const void *>(estep_docs_reg_merged_kernel<0>)
+                                 : KS == 1 ? reinterpret_cast<const void *>(estep_docs_tiered_merged_kernel<1>)
+                                           : reinterpret_cast<const void *>(estep_docs_tiered_merged_kernel<2>);
+                if ((rc = ensure_dynamic_lds(mk, lds_bytes)))
+                    return rc;
+                const dim3 grid((unsigned)(mg.first + n_help));
+                if (!tiered)
+                    hipLaunchKernelGGL(estep_docs_reg_merged_kernel<0>, grid, dim3(kRegThreads), lds_bytes,
+                                       m->stream, a, pre, mg);
+                else if (KS == 1)
+                    hipLaunchKernelGGL(estep_docs_tiered_merged_kernel<1>, grid, dim3(kRegThreads), lds_bytes,
+                                       m->stream, a, pre, lds_rows, mg);
+                else
+                    hipLaunchKernelGGL(estep_docs_tiered_merged_kernel<2>, grid, dim3(kRegThreads), lds_bytes,
+                                       m->stream, a, pre, lds_rows, mg);
+                if (merged_stats)
+                    m->docs_done_total += (unsigned int)n_wgs;
+                m->c_ready_total += (unsigned int)mg.n_comb;
+                ++m->merged_epoch;
+            } else if (!tiered)
                 hipLaunchKernelGGL(estep_docs_reg_kernel<0>, dim3(n_wgs + pre.nb), dim3(kRegThreads),
                                    lds_bytes, m->stream, a, pre);
             else if (KS == 1)
@@ -1460,6 +1593,8 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         int GF = (int)std::max<size_t>(1, std::min<size_t>(blocks, 256 * 8));
         hipLaunchKernelGGL((elementwise_stream_kernel<kDenseThreads, FinishOp>), dim3(GF),
                            dim3(kDenseThreads), 0, m->stream, KV, FinishOp{m->eeb_cur, sstats_dev});
+    } else if (m->last_merged && !dp) {
+        // (statistics: workgroups of the document launch above)
     } else if (fused_update_available(m)) {
         rc = sstats_update_device(m, b, out);
         if (rc)
@@ -1641,11 +1776,12 @@ int check_split_exchange(trlda_model *m)
     if (!m->xerr_host || !*m->xerr_host)
         return TRLDA_OK;
     *m->xerr_host = 0;
-    return fail(TRLDA_ERR_HIP, "an exchange gave up waiting: a document split over several workgroups "
-                               "for one of its segments (or its statistics are NaN; "
-                               "trlda_model_set_split_docs(model, 0) keeps every document on one "
-                               "workgroup), or the direct slot exchange for a peer's signal; the "
-                               "results of that call are void");
+    return fail(TRLDA_ERR_HIP, "a wait inside a launch gave up: a document split over several workgroups "
+                               "for one of its segments (trlda_model_set_split_docs(model, 0) keeps "
+                               "every document on one workgroup), the statistics stage of a merged "
+                               "launch for its documents or the documents for their topic factors "
+                               "(trlda_model_set_merged_launch(model, 0)), or the direct slot exchange "
+                               "for a peer's signal; the results of that call are void");
 }
 
 // wait for the model's stream; a call whose exchange gave up has no results
@@ -1967,7 +2103,8 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
                  o_meta = section(Bz * 16), o_pids = section(Bz * trlda::kRegMaxN * 4),
                  o_smeta = section((size_t)n_wg * 32), o_spids = section((size_t)n_wg * trlda::kRegMaxN * 4),
                  o_active = section((size_t)n_active * 4), o_long = section((size_t)n_long * 4),
-                 o_flag = section((size_t)V), o_wc32 = section((size_t)V * 4);
+                 o_flag = section((size_t)V), o_wc32 = section((size_t)V * 4),
+                 o_mdesc = section((size_t)n_active * 16);
     const size_t total = off;
 
     UploadContext &u = upload_context(device);
@@ -2110,6 +2247,40 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
             if (len > long_len)
                 longw[nl++] = w;
         }
+        // descriptors for the merged launch: counting sort by length, longest first, the short
+        // lists (<= long_len entries) before the long ones
+        int32_t *md = I(o_mdesc);
+        const int n_short = n_active - n_long;
+        std::vector<int32_t> at((size_t)long_len + 2, 0);        // at[len]: next slot of a short list of `len`
+        for (int a = 0; a < na; ++a) {
+            const int len = wptr[(size_t)active[a] + 1] - wptr[(size_t)active[a]];
+            if (len <= long_len)
+                ++at[(size_t)len];
+        }
+        int run = 0;
+        for (int len = long_len; len >= 1; --len) {
+            const int c = at[(size_t)len];
+            at[(size_t)len] = run;
+            run += c;
+        }
+        std::vector<int32_t> longs;
+        for (int a = 0; a < na; ++a) {
+            const int w = active[a], q0 = wptr[(size_t)w], len = wptr[(size_t)w + 1] - q0;
+            if (len > long_len) {
+                longs.push_back(w);
+                continue;
+            }
+            int32_t *e = md + 4 * (size_t)at[(size_t)len]++;
+            e[0] = w; e[1] = q0; e[2] = len; e[3] = 0;
+        }
+        std::stable_sort(longs.begin(), longs.end(), [&](int32_t x, int32_t y) {
+            return wptr[(size_t)x + 1] - wptr[(size_t)x] > wptr[(size_t)y + 1] - wptr[(size_t)y];
+        });
+        for (size_t i = 0; i < longs.size(); ++i) {
+            const int w = longs[i];
+            int32_t *e = md + 4 * ((size_t)n_short + i);
+            e[0] = w; e[1] = wptr[(size_t)w]; e[2] = wptr[(size_t)w + 1] - wptr[(size_t)w]; e[3] = 0;
+        }
     }
 
     // a device allocation: from the cache when one fits, else new
@@ -2175,6 +2346,8 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     b->wc32 = D(o_wc32);
     b->wc32_ok = wc32_ok;
     b->cnts_nonneg = cnts_nonneg;
+    b->mdesc = D(o_mdesc);
+    b->n_short = n_active - n_long;
     *out = b;
     return TRLDA_OK;
 }
@@ -2267,6 +2440,16 @@ int trlda_model_create(trlda_model **out, int device, int K, int V)
             rc = fail(TRLDA_ERR_HIP, "hipMalloc failed");
         m->group_counter = static_cast<unsigned int *>(p);
     }
+    if (!rc) rc = dev_alloc(&m->scale_comb, 3 * (size_t)K);
+    if (!rc) rc = dev_alloc(&m->sync_counters, 2);
+    if (!rc && hipMemset(m->sync_counters, 0, 2 * sizeof(unsigned int)) != hipSuccess)
+        rc = fail(TRLDA_ERR_HIP, "hipMemset failed");
+    {
+        const size_t n_flags = (size_t)(trlda::kMergedMaxHelpers + trlda::kMergedMaxDocWgs) * trlda::kMergedFlagStride;
+        if (!rc) rc = dev_alloc(&m->sync_flags, n_flags);
+        if (!rc && hipMemset(m->sync_flags, 0, n_flags * sizeof(unsigned int)) != hipSuccess)
+            rc = fail(TRLDA_ERR_HIP, "hipMemset failed");
+    }
     // columns of words no batch has touched yet are never read for their value, but the
     // atomic-mode finish multiplies them by 0: keep them finite
     if (!rc && (hipMemset(m->counter, 0, sizeof(unsigned int)) != hipSuccess ||
@@ -2279,6 +2462,8 @@ int trlda_model_create(trlda_model **out, int device, int K, int V)
     }
     if (const char *env = std::getenv("TRLDA_DRAW_AHEAD"))       // 1 = draw the next gamma0 ahead
         m->draw_ahead = env[0] != '0';
+    if (const char *env = std::getenv("TRLDA_MERGED"))           // 0 = statistics always a launch of their own
+        m->merged_launch = env[0] != '0';
     *out = m;
     return TRLDA_OK;
 }
@@ -2299,7 +2484,8 @@ int trlda_model_destroy(trlda_model *m)
             (void)hipHostFree(m->eb.host);
         if (m->eb.event)
             (void)hipEventDestroy(m->eb.event);
-        (void)hipFree(m->partial); (void)hipFree(m->counter); (void)hipFree(m->epg); (void)hipFree(m->tw_csr);
+        (void)hipFree(m->partial); (void)hipFree(m->counter); (void)hipFree(m->epg_base); (void)hipFree(m->tw_csr);
+        (void)hipFree(m->sync_counters); (void)hipFree(m->sync_flags); (void)hipFree(m->scale_comb);
         (void)hipFree(m->tw_word); (void)hipFree(m->dp_gather_own); (void)trlda_model_dp_direct_close(m); (void)hipFree(m->lambda_prime); (void)hipFree(m->sstats); (void)hipFree(m->gamma);
         (void)hipFree(m->wordcounts); (void)hipFree(m->rs_full); (void)hipFree(m->rs_static);
         (void)hipFree(m->upd_partial); (void)hipFree(m->ada_gradient); (void)hipFree(m->reduce_out);
@@ -2411,6 +2597,16 @@ int trlda_model_synchronize(trlda_model *m)
 }
 
 int trlda_model_last_split_workgroups(const trlda_model *m) { return m ? m->last_split_wgs : 0; }
+
+int trlda_model_set_merged_launch(trlda_model *m, int enabled)
+{
+    if (!m)
+        return fail(TRLDA_ERR_ARG, "model is NULL");
+    m->merged_launch = enabled != 0;
+    return TRLDA_OK;
+}
+
+int trlda_model_last_merged(const trlda_model *m) { return m && m->last_merged ? 1 : 0; }
 
 int trlda_model_set_split_docs(trlda_model *m, int enabled)
 {
@@ -2743,6 +2939,7 @@ int finish_rowsums(trlda_model *m, const EstepOut &out, const double *base, doub
         m->next_pre.version = m->lambda_version;
         m->next_pre.batch_id = b->id;
         m->next_pre.n = out.groups;
+        m->next_pre.raw = out.raw_rows;
     }
     return rc;
 }
