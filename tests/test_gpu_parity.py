@@ -969,13 +969,21 @@ rb = [b.update_parameters(d, max_iter_tr=3) for d in docs]
 assert ra == rb and b.update_count == 2
 assert b._all_reduce_calls == 2 * (1 + 3)      # word counts + one per trust-region E-step
 assert float(np.max(np.abs(a.lambdas - b.lambdas) / b.lambdas)) < 1e-10   # fused vs composed M-step
-# the factor exchange (the default where it moves fewer bytes): the single-GPU call, bit for bit
+# the factor exchange (the default where it moves fewer bytes): the single-GPU call with the
+# statistics as a kernel of their own (as the *_dp calls have them: an exchange sits in between),
+# bit for bit; with the statistics inside the document launch (csrc/estep_merged.h) to rounding
 trlda_amd.seed(3)
 c = ShardedOnlineLDA(V, K, D, device=0)
 assert c.use_factors(docs[0], docs[0].shard_cuts(1))
 rc = [c.update_parameters(d, max_iter_tr=3) for d in docs]
 assert rc == ra and c.update_count == 2
-assert np.array_equal(a.lambdas, c.lambdas)
+assert float(np.max(np.abs(a.lambdas - c.lambdas) / c.lambdas)) < 1e-11
+from trlda_amd import _ffi
+trlda_amd.seed(3)
+a2 = OnlineLDA(num_words=V, num_topics=K, num_documents=D)
+_ffi.check(_ffi.lib().trlda_model_set_merged_launch(a2._handle, 0))
+assert [a2.update_parameters(d, max_iter_tr=3) for d in docs] == ra
+assert np.array_equal(a2.lambdas, c.lambdas)
 dist.destroy_process_group()
 print("RCCL1-OK")
 """ % ROOT_DIR)
