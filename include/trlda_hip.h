@@ -212,14 +212,15 @@ int trlda_model_set_split_docs(trlda_model *model, int enabled);
  * a batch whose launch would not end sooner with split documents stays unsplit) */
 int trlda_model_last_split_workgroups(const trlda_model *model);
 /* Small tables, batches of at most 224 document workgroups (K <= 128 even, a mini-batch of 200):
- * the statistics (src/lda.cpp:207-217) -- and where an update asks for them the M-step
- * (src/onlinelda.cpp:99-100), the row sums the next E-step needs (src/lda.cpp:172) and its
- * exp(psi(lambda)) -- are extra WORKGROUPS OF THE DOCUMENT LAUNCH that wait for a documents-done
- * counter, instead of a kernel of their own behind it: one launch per E-step, one per trust-region
- * iteration (csrc/estep_merged.h).  Same sums in the same order: bitwise the statistics of the
- * stand-alone kernel.  enabled = 0 (or TRLDA_MERGED=0 in the environment): always the kernel of
- * its own (default 1).  last_merged: what the model's last E-step did. */
-int trlda_model_set_merged_launch(trlda_model *model, int enabled);
+ * the statistics (src/lda.cpp:207-217) with the M-step (src/onlinelda.cpp:99-100,
+ * src/batchlda.cpp:60), the row sums the next E-step needs (src/lda.cpp:172) and its
+ * exp(psi(lambda)) can be extra WORKGROUPS OF THE DOCUMENT LAUNCH that wait for a documents-done
+ * counter, instead of a kernel of their own behind it: one launch per trust-region iteration
+ * (csrc/estep_merged.h).  Same sums in the same order: bitwise the statistics of the stand-alone
+ * kernel.  level 1 (default): where the statistics carry an M-step (the update entry points);
+ * 2: plain E-steps too (the two forms take the same time there); 0, or TRLDA_MERGED=0 in the
+ * environment: always the kernel of its own.  last_merged: what the model's last E-step did. */
+int trlda_model_set_merged_launch(trlda_model *model, int level);
 int trlda_model_last_merged(const trlda_model *model);
 
 int trlda_model_set_lambda(trlda_model *model, const double *host_lambda /* K x V */);

@@ -48,6 +48,29 @@ def test_library_contains_gfx950_code_object(hip_lib):
     assert b"estep_docs_kernel" in blob
 
 
+def test_occupancy_critical_kernels_keep_their_registers(hip_lib):
+    """What two measured slowdowns of round 4 came from, pinned on the compiled code object:
+    the statistics stage inside the document launch must not touch scratch memory beyond the
+    16 bytes of the rare psi branch's call frame (a build whose stage indexed a small array
+    dynamically spent 50 us per launch instead of 37), and the stand-alone statistics kernel that
+    also emits exp(psi(lambda)) must stay at 64 VGPRs -- two 1024-thread workgroups per CU."""
+    import os
+    from helpers import kernel_resources
+    from trlda_amd import _ffi
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("llvm-readelf not available")
+    res = kernel_resources(_ffi.LIB_PATH)
+    merged = {k: v for k, v in res.items() if "merged_kernel" in k}
+    assert len(merged) >= 3, sorted(res)[:5]
+    for name, f in merged.items():
+        assert f["private_segment_fixed_size"] <= 32 and f["vgpr_spill_count"] <= 4, (name, f)
+        assert f["vgpr_count"] <= 256
+    emit = [v for k, v in res.items() if "sstats_update2_kernelILi1024ELi1ELi1ELb1" in k]
+    assert len(emit) == 1 and emit[0]["vgpr_count"] <= 64, emit
+    docs = [v for k, v in res.items() if "estep_docs_reg_kernelILi0" in k]
+    assert len(docs) == 1 and docs[0]["vgpr_spill_count"] == 0, docs
+
+
 def test_product_never_imports_the_oracle():
     """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use oracle/."""
     pkg = os.path.join(ROOT, "trlda_amd")

@@ -57,7 +57,7 @@ def test_estep_merged_equals_the_kernel_of_its_own(hip, oracle, sampler, K, V, B
     m = make_model(K, V, lam)
     res = {}
     for merged in (1, 0):
-        assert hip.trlda_model_set_merged_launch(m._handle, merged) == 0
+        assert hip.trlda_model_set_merged_launch(m._handle, 2 * merged) == 0     # 2: plain E-steps too
         res[merged] = m.update_variables(docs, latents=g0, max_iter=20, threshold=1e-3,
                                          return_iterations=True)
         assert hip.trlda_model_last_merged(m._handle) == merged
@@ -69,7 +69,7 @@ def test_estep_merged_equals_the_kernel_of_its_own(hip, oracle, sampler, K, V, B
     assert np.array_equal(i1, ito) and relerr(g1, go) < TIGHT_RTOL
     check_sstats(s1, so)
     # run to run, and the counters after many launches
-    hip.trlda_model_set_merged_launch(m._handle, 1)
+    hip.trlda_model_set_merged_launch(m._handle, 2)
     for _ in range(40):
         g, s = m.update_variables(docs, latents=g0, max_iter=20, threshold=1e-3)
         assert hip.trlda_model_last_merged(m._handle) == 1
@@ -97,7 +97,7 @@ def test_merged_launch_carries_every_document_variant(hip, oracle, sampler):
         hip.trlda_model_set_split_docs(m._handle, split)
         res = {}
         for merged in (1, 0):
-            hip.trlda_model_set_merged_launch(m._handle, merged)
+            hip.trlda_model_set_merged_launch(m._handle, 2 * merged)
             res[merged] = m.update_variables(docs, latents=g0, max_iter=30, threshold=1e-3,
                                              return_iterations=True)
             assert hip.trlda_model_last_merged(m._handle) == merged
@@ -114,6 +114,9 @@ def test_outside_its_range_the_statistics_stay_a_kernel_of_their_own(hip, sample
     K, V = 100, 2000
     lam = seeded_lambda(sampler, 7, K, V)
     m = make_model(K, V, lam)
+    m.update_variables(corpus(50, V, seed=2), max_iter=5)             # level 1 (default): updates only
+    assert hip.trlda_model_last_merged(m._handle) == 0
+    hip.trlda_model_set_merged_launch(m._handle, 2)
     m.update_variables(corpus(300, V, seed=1), max_iter=5)            # more documents than ride along
     assert hip.trlda_model_last_merged(m._handle) == 0
     m.update_variables(corpus(50, V, seed=2), max_iter=5)
@@ -123,9 +126,11 @@ def test_outside_its_range_the_statistics_stay_a_kernel_of_their_own(hip, sample
     assert hip.trlda_model_last_merged(m._handle) == 0
     hip.trlda_model_set_sstats_mode(m._handle, 0)
     m7 = make_model(7, V, seeded_lambda(sampler, 7, 7, V))            # odd K: no pairs of topics
+    hip.trlda_model_set_merged_launch(m7._handle, 2)
     m7.update_variables(corpus(50, V, seed=2), max_iter=5)
     assert hip.trlda_model_last_merged(m7._handle) == 0
     m200 = make_model(200, V, seeded_lambda(sampler, 7, 200, V))      # beyond the register kernel
+    hip.trlda_model_set_merged_launch(m200._handle, 2)
     m200.update_variables(corpus(50, V, seed=2), max_iter=5)
     assert hip.trlda_model_last_merged(m200._handle) == 0
 
@@ -188,6 +193,7 @@ def test_many_merged_launches_in_a_row(hip, sampler):
     K, V, B = 100, 7000, 200
     lam = seeded_lambda(sampler, 17, K, V)
     m = make_model(K, V, lam)
+    hip.trlda_model_set_merged_launch(m._handle, 2)
     a, b = m.upload(corpus(B, V, seed=1, mean_unique=100)), m.upload(corpus(B - 9, V, seed=2, mean_unique=100))
     ga, gb = seeded_gamma(sampler, 18, K, B), seeded_gamma(sampler, 19, K, B - 9)
     first_a = m.update_variables(a, latents=ga, max_iter=20)

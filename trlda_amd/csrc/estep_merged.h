@@ -78,6 +78,10 @@ struct MergedArgs {
     unsigned int epoch;
     int n_docs;                   // document workgroups of the launch (flags to set)
     int dbg;                      // experiments (TRLDA_MERGED_DBG): 1 helpers return at once, 2 after the wait
+    unsigned long long *tstamps;  // diagnostics (TRLDA_MERGED_STAMPS=1, tools/merged_stamps.py) or nullptr:
+                                  // s_memrealtime (100 MHz, one clock for the chip) of [start, flag seen,
+                                  // end] per statistics workgroup, then [start, end of the document,
+                                  // counted] per document workgroup from 3 * 512 on
 };
 
 // ---- the document side --------------------------------------------------------------------
@@ -150,37 +154,40 @@ __device__ __forceinline__ void merged_combine(const MergedArgs &mg, int vb, dou
 
 // ---- statistics ---------------------------------------------------------------------------------
 // every document workgroup of this launch has stored its outputs
-// Block-level: thread 0 watches this workgroup's own flag (the last document to finish sets it), at
-// a rate that costs the memory system nothing.  (A flag that never comes -- it cannot: the
-// documents are resident and wait for nothing that waits for them -- ends the wait after ~1 s and
-// fails the next synchronising call.)
-__device__ __forceinline__ void merged_wait_docs(const MergedArgs &mg, int vb)
+// Every wave watches its workgroup's flag (the last document to finish sets it) on its own: eight
+// waves per address, at a rate that costs the memory system nothing.  `seen` is the flag as the wave
+// read it FIRST THING -- a workgroup that is dispatched when the documents have already finished
+// finds it set and goes straight on, its weights in flight together with its static loads.  (A flag
+// that never comes -- it cannot: the documents are resident and wait for nothing that waits for
+// them -- ends the wait after ~1 s and fails the next synchronising call.)
+__device__ __forceinline__ unsigned int merged_flag_load(const MergedArgs &mg, int vb)
 {
-    if (threadIdx.x == 0) {
-        unsigned int *flag = mg.go_flags + (size_t)vb * kMergedFlagStride;
-        int spins = 0;
-        while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - mg.epoch) < 0) {
-            __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1 << 22)) {
-                if (mg.xerr)
-                    __hip_atomic_store(mg.xerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                break;
-            }
+    return __hip_atomic_load(mg.go_flags + (size_t)vb * kMergedFlagStride, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void merged_wait_docs(const MergedArgs &mg, int vb, unsigned int seen)
+{
+    int spins = 0;
+    while ((int)(seen - mg.epoch) < 0) {
+        __builtin_amdgcn_s_sleep(8);
+        seen = merged_flag_load(mg, vb);
+        if (++spins > (1 << 22)) {
+            if (mg.xerr)
+                __hip_atomic_store(mg.xerr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
         }
     }
-    __syncthreads();
-    // No cache invalidation here.  An agent-scope acquire (buffer_inv sc1) per wave made the stage
-    // take 20 us instead of 3: two thousand invalidations of the XCDs' L2s, one after the other.
-    // Nor is one needed: the only data of this launch that a waiter reads and another workgroup
-    // of the launch has written are epg and tw_word; they went out write-through (merged_store)
-    // before the flag; no line of them can sit in this CU's L1 or this XCD's L2 from BEFORE that --
-    // the caches start a kernel empty of them (the kernel boundary's acquire), a document
-    // workgroup only writes them (bytes it wrote are valid, the others are fetched), and nothing
-    // of this stage reads them before this point.  The weights are read with agent-scope loads
-    // anyway; tests/test_gpu_merged.py alternates two batches through the same buffers 600 times.
-#ifdef TRLDA_MERGED_ACQUIRE
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
+    if (mg.tstamps && threadIdx.x == 0)
+        mg.tstamps[3 * vb + 1] = __builtin_amdgcn_s_memrealtime();
+    // No cache invalidation here.  An agent-scope acquire (buffer_inv sc1) per wave is two thousand
+    // invalidations of the XCDs' L2s, one after the other.  Nor is one needed: the only data of
+    // this launch that a waiter reads and another workgroup of the launch has written are epg and
+    // tw_word; they went out write-through (merged_store) before the flag; no line of them can
+    // sit in this CU's L1 or this XCD's L2 from BEFORE that -- the caches start a kernel empty of
+    // them (the kernel boundary's acquire), a document workgroup only writes them (bytes it wrote
+    // are valid, the others are fetched), and nothing of this stage reads them before this
+    // point.  The weights are read with agent-scope loads anyway; tests/test_gpu_merged.py
+    // alternates two batches through the same buffers 600 times.
 }
 
 // NS list segments of at most 16 entries each, side by side: acc[j] += sum_u tw[q0_j + u] *
@@ -258,10 +265,11 @@ __device__ __forceinline__ void merged_stats(const MergedArgs &mg, int vb, doubl
     const int kk = min(2 * lane, K - 2);             // this lane's pair of topics (K even)
     const bool k_on = 2 * lane < K;
     const int n_stat = mg.n_short + mg.n_long;
+    const unsigned int seen = merged_flag_load(mg, vb);          // (requested before everything else)
     if (mg.dbg == 1)
         return;
     if (mg.dbg == 2) {
-        merged_wait_docs(mg, vb);
+        merged_wait_docs(mg, vb, seen);
         return;
     }
     if (mg.dbg == 3 && vb >= mg.n_short)
@@ -304,8 +312,8 @@ __device__ __forceinline__ void merged_stats(const MergedArgs &mg, int vb, doubl
                                        : make_double2(0.0, 0.0);
                 acc[j] = make_double2(0.0, 0.0);
             }
-            if (!waited) {                           // (every wave of the workgroup comes by once:
-                merged_wait_docs(mg, vb);            //  here, or below when it has no word)
+            if (!waited) {
+                merged_wait_docs(mg, vb, seen);
                 waited = true;
             }
             double tw[NW];
@@ -325,8 +333,6 @@ __device__ __forceinline__ void merged_stats(const MergedArgs &mg, int vb, doubl
                 }
             }
         }
-        if (!waited)
-            merged_wait_docs(mg, vb);
         if (o.partial) {                             // launch-uniform
             if (k_on)
                 *reinterpret_cast<double2 *>(lds + wid * K + 2 * lane) = rs;
@@ -362,8 +368,13 @@ __device__ __forceinline__ void merged_stats(const MergedArgs &mg, int vb, doubl
             docs[h] = lane < clen[h] ? mg.wdoc[base + c0[h] + lane] : -1;
             acc[h] = make_double2(0.0, 0.0);
         }
+        // exp(psi(lambda)) and lambda' of the element this thread finishes: requested now, while
+        // the documents still run (behind the barrier below they would be one more memory latency)
+        const size_t i = (size_t)w * K + min(tid, K - 1);
+        const double ek = mg.eeb[i];
+        const double lpk = o.lambda_prime ? o.lambda_prime[i] : 0.0;
         if (!waited) {
-            merged_wait_docs(mg, vb);
+            merged_wait_docs(mg, vb, seen);
             waited = true;
         }
         double tw[2];
@@ -383,13 +394,12 @@ __device__ __forceinline__ void merged_stats(const MergedArgs &mg, int vb, doubl
 #pragma unroll
             for (int c = 1; c < 16; ++c)
                 sum += lds[c * K + tid];
-            const size_t i = (size_t)w * K + tid;
-            const double s = sum * mg.eeb[i];
+            const double s = sum * ek;
             if (o.sstats)
                 o.sstats[i] = s;
             if (o.lambda) {
                 const double hat = o.eta + o.scale * s;
-                const double lam = o.lambda_prime ? o.omr * o.lambda_prime[i] + o.rho * hat : o.rho * hat;
+                const double lam = o.lambda_prime ? o.omr * lpk + o.rho * hat : o.rho * hat;
                 o.lambda[i] = lam;
                 if (o.u_out)
                     o.u_out[i] = exp_digamma_positive(lam);
@@ -406,10 +416,22 @@ __device__ __forceinline__ void merged_stats(const MergedArgs &mg, int vb, doubl
 __device__ __forceinline__ void merged_helper(const MergedArgs &mg, double *lds)
 {
     const int vb = (int)blockIdx.x - mg.first;
-    if (vb < mg.n_comb)
+    if (vb < mg.n_comb) {
         merged_combine(mg, vb, lds);
-    else
-        merged_stats(mg, vb - mg.n_comb, lds);
+        return;
+    }
+    if (mg.tstamps && threadIdx.x == 0)
+        mg.tstamps[3 * (vb - mg.n_comb)] = __builtin_amdgcn_s_memrealtime();
+    merged_stats(mg, vb - mg.n_comb, lds);
+    if (mg.tstamps && threadIdx.x == 0)
+        mg.tstamps[3 * (vb - mg.n_comb) + 2] = __builtin_amdgcn_s_memrealtime();
+}
+
+// diagnostics: a document workgroup's [start, end of its document, counted]
+__device__ __forceinline__ void merged_doc_stamp(const MergedArgs &mg, int which)
+{
+    if (mg.tstamps && threadIdx.x == 0)
+        mg.tstamps[3 * (512 + blockIdx.x) + which] = __builtin_amdgcn_s_memrealtime();
 }
 
 template <int MODE>
@@ -425,8 +447,11 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_merged_kernel(DocK
         docs_launch_preamble(pre, lds);
         return;
     }
+    merged_doc_stamp(mg, 0);
     estep_docs_reg_body<MODE>(a, lds);
+    merged_doc_stamp(mg, 1);
     docs_done_signal(a);
+    merged_doc_stamp(mg, 2);
 }
 
 template <int KS>
@@ -442,6 +467,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_tiered_merged_kernel(D
         docs_launch_preamble(pre, lds);
         return;
     }
+    merged_doc_stamp(mg, 0);
     const int n = a.pad_meta[4 * (size_t)blockIdx.x * a.meta_i4 + 1];
     if (a.meta_i4 == 2 && a.pad_meta[4 * ((size_t)blockIdx.x * 2 + 1) + 1] > 1) {
         estep_docs_reg_body<0, true>(a, lds);        // one segment of a document split over CUs
@@ -453,7 +479,9 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_tiered_merged_kernel(D
         const int4 meta = reinterpret_cast<const int4 *>(a.pad_meta)[(size_t)blockIdx.x * a.meta_i4];
         estep_docs_wide_body<KS, true>(a, lds_rows, lds, meta.x, meta.z, meta.y);
     }
+    merged_doc_stamp(mg, 1);
     docs_done_signal(a);
+    merged_doc_stamp(mg, 2);
 }
 
 }  // namespace trlda

@@ -286,7 +286,11 @@ struct trlda_model {
     // merged launch (estep_merged.h): the statistics as workgroups of the document launch.
     // Two counters that only grow (documents done | topic factors finished) and what they have
     // been asked to reach so far; the finished topic factors of an in-launch combine
-    bool merged_launch = true;          // trlda_model_set_merged_launch
+    // 0: never; 1 (default): where the statistics carry an M-step -- the update loops, where a
+    // launch of their own costs 13 us against ~9 inside the document launch (round 4: 0.53 -> 0.50 ms
+    // per update_parameters(max_iter_tr=10)); 2: also for plain E-steps, where the two forms take
+    // the same time to 1 % (39.6 / 40.0 us per step) and the kernel of its own is the default
+    int merged_launch = 1;              // trlda_model_set_merged_launch
     bool last_merged = false;
     unsigned int *sync_counters = nullptr;
     unsigned int docs_done_total = 0, c_ready_total = 0;
@@ -294,6 +298,7 @@ struct trlda_model {
     // receives the number of the launch it may go on in (merged_epoch: only grows)
     unsigned int *sync_flags = nullptr;
     unsigned int merged_epoch = 0;
+    unsigned long long *merged_stamps = nullptr;   // diagnostics, TRLDA_MERGED_STAMPS=1
     double *scale_comb = nullptr;       // 3 K
     // split documents: the exchange rows of a launch (NaN before it), the give-up flag
     double *xbuf = nullptr;
@@ -1127,7 +1132,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
     const bool will_split = db->max_n > 128 && m->split_docs && db->n_wg > 0 && db->split_pays &&
                             max_iter > 0 && xcount_m * sizeof(double) <= ((size_t)256 << 20);
     const int doc_wgs = will_split ? db->n_wg : B;
-    const bool merged_capable = m->merged_launch && fused && !atomic && !dp && B > 0 &&
+    const bool merged_capable = m->merged_launch > 0 && fused && !atomic && !dp && B > 0 &&
                                 doc_wgs <= trlda::kMergedMaxDocWgs;
     bool handed = fused && carried && m->carry_pending && m->next_pre.valid &&
                   m->next_pre.version == m->lambda_version &&
@@ -1493,7 +1498,8 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
             const bool merged_stats = merged_capable && n_wgs == doc_wgs && K % 2 == 0 && m->pair_gathers &&
                                       b->long_len == trlda::kLongWord && b->B <= 256 && b->n_active > 0 &&
                                       fused_update_available(m) &&
-                                      (out.upd.lambda ? out.active_only : sstats_dev != nullptr);
+                                      (out.upd.lambda ? out.active_only
+                                                      : sstats_dev != nullptr && m->merged_launch >= 2);
             m->last_merged = merged_stats;
             MergedArgs mg{};
             mg.first = n_wgs + pre.nb;
@@ -1507,6 +1513,13 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
             mg.epoch = a.epoch; mg.n_docs = n_wgs;
             if (const char *env = std::getenv("TRLDA_MERGED_DBG"))
                 mg.dbg = std::atoi(env);
+
+            {
+                static const bool want_stamps = std::getenv("TRLDA_MERGED_STAMPS") != nullptr;
+                if (want_stamps && !m->merged_stamps && dev_alloc(&m->merged_stamps, 3 * 1024) == TRLDA_OK)
+                    (void)hipMemset(m->merged_stamps, 0, 3 * 1024 * sizeof(unsigned long long));
+                mg.tstamps = want_stamps ? m->merged_stamps : nullptr;
+            }
             mg.go_flags = m->sync_flags;
             mg.K = K; mg.V = V;
             if (merged_stats) {
@@ -2463,7 +2476,7 @@ int trlda_model_create(trlda_model **out, int device, int K, int V)
     if (const char *env = std::getenv("TRLDA_DRAW_AHEAD"))       // 1 = draw the next gamma0 ahead
         m->draw_ahead = env[0] != '0';
     if (const char *env = std::getenv("TRLDA_MERGED"))           // 0 = statistics always a launch of their own
-        m->merged_launch = env[0] != '0';
+        m->merged_launch = std::max(0, std::min(std::atoi(env), 2));
     *out = m;
     return TRLDA_OK;
 }
@@ -2602,7 +2615,7 @@ int trlda_model_set_merged_launch(trlda_model *m, int enabled)
 {
     if (!m)
         return fail(TRLDA_ERR_ARG, "model is NULL");
-    m->merged_launch = enabled != 0;
+    m->merged_launch = enabled < 0 ? 0 : std::min(enabled, 2);
     return TRLDA_OK;
 }
 
@@ -4181,6 +4194,16 @@ int trlda_tr_init(int K, int V, int B, int num_documents, double rho, double eta
     trlda_batch_destroy(b);
     trlda_model_destroy(m);
     return rc;
+}
+
+// diagnostics: the s_memtime stamps of the model's last merged launch (3 x 1024 values)
+extern "C" int trlda_debug_merged_stamps(trlda_model *m, unsigned long long *host)
+{
+    if (!m || !host || !m->merged_stamps)
+        return TRLDA_ERR_ARG;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(hipMemcpy(host, m->merged_stamps, 3 * 1024 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return TRLDA_OK;
 }
 
 #ifdef TRLDA_STAMPS
