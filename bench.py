@@ -62,8 +62,9 @@ def parse():
                          "documents over 192 words, a few of 300..600 (utils/synthetic.py)")
     ap.add_argument("--num-batches", type=int, default=0,
                     help="distinct mini-batches streamed through the timed steps, one after the other "
-                         "(0 = auto: 200 = 40 000 documents at N = 1, SURVEY.md 8(d) config 2; 8 per "
-                         "rank where every rank also holds the other ranks' word lists)")
+                         "(0 = auto: 40 000 documents at N = 1 -- 200 batches of 200, SURVEY.md 8(d) config "
+                         "2 -- but at least 8 batches; 8 per rank where every rank also holds the other "
+                         "ranks' word lists)")
     ap.add_argument("--sstats-mode", choices=["segmented", "atomic"], default="segmented")
     ap.add_argument("--doc-threads", type=int, default=0)
     ap.add_argument("--split-preamble", action="store_true",
@@ -93,6 +94,10 @@ def parse():
                     help="development aid for a one-GPU box: time what ONE rank of this many executes "
                          "per step with --exchange factors (the other ranks' slots hold a copy of "
                          "this rank's factors; no collective runs)")
+    ap.add_argument("--whole-stats", action="store_true",
+                    help="N > 1 with the factor exchange: every rank forms the statistics of the whole "
+                         "mini-batch (rounds 2-3) instead of its range of the vocabulary + an exchange of "
+                         "the lambda columns (word-sharded M-step, the default)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="every step launches its own preamble kernel instead of having it prepared "
                          "by extra workgroups of the previous step's document-kernel launch")
@@ -326,6 +331,7 @@ def main():
     _ffi.check(L.trlda_model_set_doc_threads(model, args.doc_threads))
     _ffi.check(L.trlda_model_set_dense_preamble(model, int(args.dense_preamble)))
     _ffi.check(L.trlda_model_set_split_preamble(model, int(args.split_preamble)))
+    _ffi.check(L.trlda_model_set_word_sharding(model, int(not args.whole_stats)))
 
     if collective:
         # every rank has the communicator, or none uses it (a rank on its own in a collective hangs)
@@ -387,7 +393,9 @@ def main():
             exchange = "sstats"                      # ncclAllGather needs the communicator
 
     if args.num_batches <= 0:
-        args.num_batches = 200 if (world == 1 and not vworld and not force_dist) else 8
+        # 40 000 documents streamed (200 batches of 200), at least 8 batches
+        args.num_batches = max(8, min(200, 40000 // max(B, 1))) if (world == 1 and not vworld and
+                                                                    not force_dist) else 8
     batches, csrs, gamma0s, gbatches = [], [], [], []
     cuts = (np.arange(xworld + 1) * B).astype(np.int32)
     # (batch i is the same documents whatever --num-batches is: a seed per batch; NumPy's samplers
@@ -477,6 +485,14 @@ def main():
             return 0
         virtual_hook = HOOK(fill_once)
         _ffi.check(L.trlda_model_set_allgather(model, C.cast(virtual_hook, C.c_void_p), None))
+        # the word-sharded M-step's exchange of lambda columns: nothing moves (the other ranks'
+        # ranges keep their old values: finite, plausible); --whole-stats: every rank forms the
+        # whole mini-batch's statistics as in rounds 2-3
+        HOOKV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.c_int, C.c_int,
+                            C.c_void_p)
+        virtual_hookv = HOOKV(lambda ctx, table, offs, r, w, st: 0)
+        if not args.whole_stats:
+            _ffi.check(L.trlda_model_set_allgatherv(model, C.cast(virtual_hookv, C.c_void_p), None))
 
     cuts_solo = np.array([0, B], dtype=np.int32)
     use_prefetch = [prefetch]
@@ -658,6 +674,7 @@ def main():
     mean_iters = iter_sum / args.num_batches
     doc_flops = float(np.mean(doc_flops))
 
+    word_sharded = bool(collective and exchange == "factors" and L.trlda_model_last_word_sharded(model))
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -880,15 +897,22 @@ def main():
                                      if exchange == "factors" else
                                      "trlda_model_allreduce_sstats (own ncclComm_t)" if rccl_comm is not None
                                      else "torch.distributed.all_reduce") if collective else None),
-                   "exchange": ("all-gather of the documents' factors (expElogtheta rows + entry weights, "
-                                "%.2f MB per rank and step); every rank forms the statistics of the whole "
-                                "%d-document mini-batch and the M-step (onlinelda.cpp:99-100) in one kernel"
-                                % (8e-6 * xworld * slot, B * xworld) if exchange == "factors" else
+                   "exchange": ((("all-gather of the documents' factors (expElogtheta rows + entry weights, "
+                                  "%.2f MB per rank and step); every rank forms statistics + M-step "
+                                  "(onlinelda.cpp:99-100) for ITS range of the vocabulary and the ranks exchange "
+                                  "the lambda columns they wrote, in place (%.2f MB received per rank and step)"
+                                  % (8e-6 * xworld * slot, 8e-6 * KV * (xworld - 1) / xworld))
+                                 if word_sharded else
+                                 ("all-gather of the documents' factors (expElogtheta rows + entry weights, "
+                                  "%.2f MB per rank and step); every rank forms the statistics of the whole "
+                                  "%d-document mini-batch and the M-step (onlinelda.cpp:99-100) in one kernel"
+                                  % (8e-6 * xworld * slot, B * xworld))) if exchange == "factors" else
                                 "RCCL all-reduce of K x V fp64 sstats, then the M-step "
                                 "(%s) that the next step's E-step reads"
                                 % ("batchlda.cpp:60" if args.batch_lda else "onlinelda.cpp:99-100"))
                    if collective else "none",
                    "exchange_check": exchange_probe,
+                   "word_sharded_m_step": word_sharded if collective else None,
                    "virtual_world": vworld or None},
         "repeats": repeats,
         "value_no_prefetch": value_no_prefetch,

@@ -161,6 +161,14 @@ int trlda_batch_max_doc_len(const trlda_batch *batch);
  * words that is. */
 int trlda_batch_long_word_len(const trlda_batch *batch);
 int trlda_batch_num_long_words(const trlda_batch *batch);
+/* Lists of more than 1024 entries (a word present in most documents of a large batch) are cut into
+ * segments of at most 1024: a segment is a task for a whole workgroup of the statistics kernels, and
+ * the workgroup that finishes a word's last segment adds the segments' sums up in segment order
+ * (csrc/estep_kernels.h, VeryLongArgs) -- the kernel no longer lasts as long as its longest list
+ * (K = 200, 12 500 documents: one list of 12 500 entries kept a workgroup busy for ~100 us).  The
+ * number of such words in the batch; trlda_model_set_split_lists(model, 0) (or TRLDA_SPLIT_LISTS=0)
+ * keeps every list with one workgroup, for comparisons: same results to rounding. */
+int trlda_batch_num_very_long_words(const trlda_batch *batch);
 
 /* ---- device-resident model ---------------------------------------------- */
 
@@ -221,6 +229,7 @@ int trlda_model_last_split_workgroups(const trlda_model *model);
  * 2: plain E-steps too (the two forms take the same time there); 0, or TRLDA_MERGED=0 in the
  * environment: always the kernel of its own.  last_merged: what the model's last E-step did. */
 int trlda_model_set_merged_launch(trlda_model *model, int level);
+int trlda_model_set_split_lists(trlda_model *model, int enabled);
 int trlda_model_last_merged(const trlda_model *model);
 
 int trlda_model_set_lambda(trlda_model *model, const double *host_lambda /* K x V */);
@@ -415,6 +424,29 @@ int trlda_model_eb_gamma_stats_multi(trlda_model *model, void *rccl_comm, int B,
 typedef int (*trlda_allgather_fn)(void *ctx, const void *send_dev, void *recv_dev,
                                   size_t count_f64, void *hip_stream);
 int trlda_model_set_allgather(trlda_model *model, trlda_allgather_fn fn, void *ctx);
+/* WORD-SHARDED M-STEP (default for world > 1 where a transport for it exists).  After the factor
+ * exchange every rank holds every document's factors, so any rank can form any word's statistics:
+ * rank r forms statistics + M-step (src/lda.cpp:207-217, src/onlinelda.cpp:99-100,
+ * src/batchlda.cpp:60) for ITS contiguous range of the vocabulary only -- the ranges are balanced
+ * by the words' entries, the same cut points on every rank -- and the ranks then exchange the
+ * lambda columns they wrote, IN PLACE in the replicated table.  Every column is computed once, by
+ * its owner, with a word's entries added in document order: the replicas are bitwise equal and
+ * equal the one-GPU result.  Per rank and E-step the statistics stage shrinks by the world size
+ * (8 x 200 documents, K = 100: 8 us instead of 38 us of kernels), and the second exchange moves
+ * the lambda table once (5.6 MB received per rank at K = 100, V = 7000 -- half of what the
+ * all-reduce of the statistics moves).  The next E-step's row sums and exp(psi(lambda)) are formed
+ * from the exchanged lambda by its own preamble.
+ * Transport: `rccl_comm` (one grouped launch of `world` ncclBroadcast calls: ranges of unequal
+ * size), or the host's own -- the hook is called with the table, world + 1 offsets in doubles
+ * (rank r wrote [offsets[r], offsets[r + 1])), this rank, the world size and the model's
+ * hipStream_t, and must leave every range in place in stream order.  Without either (only the
+ * equal-slot hook above, or the direct slot exchange) every rank forms the statistics of the
+ * whole mini-batch as before.  set_word_sharding(model, 0) does the same by choice. */
+typedef int (*trlda_allgatherv_fn)(void *ctx, void *table_dev, const size_t *offsets_f64 /* world + 1 */,
+                                   int rank, int world, void *hip_stream);
+int trlda_model_set_allgatherv(trlda_model *model, trlda_allgatherv_fn fn, void *ctx);
+int trlda_model_set_word_sharding(trlda_model *model, int enabled);
+int trlda_model_last_word_sharded(const trlda_model *model);
 /* A DIRECT exchange of the slots, behind this switch (the all-gather above stays the default):
  * xGMI is point to point and a slot is a few hundred kB, so every rank writes its slot straight
  * into its peers' gather buffers -- device memory the peers export through hipIpc -- and signals

@@ -26,11 +26,50 @@ class FileTransport(object):
 
     def __init__(self, path, rank, world, max_count, lib, device):
         self.rank, self.world, self.lib, self.device = rank, world, lib, device
+        self.path = path
         self.arrive = np.memmap(path + ".bar", dtype=np.int64, mode="r+", shape=(world,))
         self.slots = np.memmap(path + ".dat", dtype=np.float64, mode="r+", shape=(world, max_count))
         self.epoch = 0
         self.calls = 0
         self.bytes = 0
+        self.table = None               # the shared K x V table of the word-sharded M-step
+        self.vcalls = 0
+        self.vbytes = 0
+
+    def gatherv(self, ctx, table, offsets, rank, world, stream):
+        """trlda_allgatherv_fn: every rank wrote its range [offsets[r], offsets[r + 1]) of `table`
+        (doubles) and receives the others', in place"""
+        try:
+            L = self.lib
+            offs = [int(offsets[r]) for r in range(world + 1)]
+            assert rank == self.rank and world == self.world
+            if self.table is None:
+                self.table = np.memmap(self.path + ".lam", dtype=np.float64, mode="r+", shape=(offs[-1],))
+            if L.trlda_dev_synchronize(self.device) != 0:      # this rank's columns are complete
+                return 1
+            lo, hi = offs[rank], offs[rank + 1]
+            if hi > lo:
+                mine = self.table[lo:hi]
+                if L.trlda_dev_download(self.device, C.c_void_p(mine.ctypes.data),
+                                        C.c_void_p(table + lo * 8), (hi - lo) * 8) != 0:
+                    return 2
+                self.table.flush()
+            self.barrier()
+            for r in range(world):
+                lo, hi = offs[r], offs[r + 1]
+                if r == rank or hi == lo:
+                    continue
+                src = np.ascontiguousarray(self.table[lo:hi])
+                if L.trlda_dev_upload(self.device, C.c_void_p(table + lo * 8), C.c_void_p(src.ctypes.data),
+                                      (hi - lo) * 8) != 0:
+                    return 3
+            self.barrier()                 # nobody rewrites its range before everyone has read it
+            self.vcalls += 1
+            self.vbytes += (offs[-1] - (offs[rank + 1] - offs[rank])) * 8
+            return 0
+        except Exception as exc:           # noqa: BLE001 -- a raise cannot cross the C frame
+            sys.stderr.write("gatherv transport failed: %r\n" % (exc,))
+            return 9
 
     def barrier(self):
         self.epoch += 1
@@ -112,6 +151,12 @@ def main():
         transport.barrier()
     else:
         _ffi.check(L.trlda_model_set_allgather(model, C.cast(hook, C.c_void_p), None))
+    # the word-sharded M-step's transport (ranges of unequal size, in place) -- unless the run is
+    # to form the whole mini-batch's statistics on every rank
+    HOOKV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_void_p)
+    hookv = HOOKV(transport.gatherv)
+    if cfg.get("word_sharded", True) and not cfg.get("direct"):
+        _ffi.check(L.trlda_model_set_allgatherv(model, C.cast(hookv, C.c_void_p), None))
 
     out = {}
     count = C.c_int(0)
@@ -172,6 +217,8 @@ def main():
     _ffi.check(L.trlda_model_get_lambda(model, lam_out))
     out["lambda"] = lam_out
     out["exchanges"] = np.array([transport.calls, transport.bytes])
+    out["lambda_exchanges"] = np.array([transport.vcalls, transport.vbytes])
+    out["word_sharded"] = np.array([L.trlda_model_last_word_sharded(model)])
     out["update_count"] = np.array([count.value])
     np.savez(cfg["path"] + ".rank%d.npz" % rank, **out)
     _ffi.check(L.trlda_model_synchronize(model))

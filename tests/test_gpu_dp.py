@@ -49,6 +49,7 @@ def run_ranks(tmp_path, cfg, world):
     cfg = dict(cfg, world=world, path=path)
     np.memmap(path + ".bar", dtype=np.int64, mode="w+", shape=(world,)).flush()
     np.memmap(path + ".dat", dtype=np.float64, mode="w+", shape=(world, cfg["max_count"])).flush()
+    np.memmap(path + ".lam", dtype=np.float64, mode="w+", shape=(cfg["K"] * cfg["V"],)).flush()
     cfg_path = str(tmp_path / "cfg.json")
     json.dump(cfg, open(cfg_path, "w"))
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), cfg_path, str(r)],
@@ -57,7 +58,12 @@ def run_ranks(tmp_path, cfg, world):
     outs = [p.communicate(timeout=900) for p in procs]
     for r, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and "DP-RANK-OK" in so, (r, so[-1500:], se[-3000:])
-    return [np.load(path + ".rank%d.npz" % r) for r in range(world)]
+    # (read now: a later run in the same directory rewrites the files)
+    out = []
+    for r in range(world):
+        with np.load(path + ".rank%d.npz" % r) as f:
+            out.append({k: f[k] for k in f.files})
+    return out
 
 
 class Single(object):
@@ -70,6 +76,10 @@ class Single(object):
         _ffi.check(L.trlda_model_create(C.byref(self.h), 0, K, V))
         _ffi.check(L.trlda_model_set_lambda(self.h, lam))
         _ffi.check(L.trlda_model_set_alpha(self.h, np.full(K, alpha)))
+        # (the statistics as a kernel of their own, as every *_dp call has them: an exchange sits
+        # between its documents and its statistics -- csrc/estep_merged.h adds the row sums up in
+        # another order, ~1e-12 in lambda after a few calls)
+        _ffi.check(L.trlda_model_set_merged_launch(self.h, 0))
         self.count = C.c_int(0)
 
     def update(self, csr, D, eta, seed, max_iter_tr, max_iter_inference):
@@ -180,6 +190,53 @@ def test_online_update_dp_processes(hip, tmp_path, world, max_iter_tr):
         assert int(r["exchanges"][0]) == 2 * max(max_iter_tr, 1)
     assert np.array_equal(res[0]["lambda"], lam_one) or relerr(res[0]["lambda"], lam_one) < 1e-12
     assert relerr(res[0]["lambda"], lam_one) < 1e-12
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_word_sharded_m_step_processes(hip, tmp_path, world):
+    """The word-sharded M-step (include/trlda_hip.h, trlda_model_set_allgatherv): after the factor
+    exchange rank r forms statistics + M-step for ITS range of the vocabulary only and the ranks
+    exchange the lambda columns they wrote, in place.  Two updateParameters calls with a
+    trust-region loop, one without, and two BatchLDA epochs, over 2 / 3 / 4 ranks as processes:
+    every rank's lambda bitwise equal; equal to the run in which every rank forms the whole
+    mini-batch's statistics and to the one-GPU model (the columns bitwise after the first M-step;
+    later E-steps see row sums added up in another order: 1e-12); one factor exchange per E-step,
+    one lambda exchange per M-step, nothing else."""
+    K, V, D = 100, 4000, 20000
+    specs = [dict(kind="update", B=90, corpus_seed=871, seed=5, max_iter_tr=3, max_iter_inference=20),
+             dict(kind="update", B=64, corpus_seed=872, seed=6, max_iter_tr=0, max_iter_inference=20),
+             dict(kind="update", B=75, corpus_seed=873, seed=7, max_iter_tr=2, max_iter_inference=20),
+             dict(kind="batch", B=80, corpus_seed=874, seed=8, max_epochs=2, max_iter_inference=20)]
+    csrs = [corpus(s["B"], V, seed=s["corpus_seed"]) for s in specs]
+    cfg = dict(K=K, V=V, D=D, alpha=.1, eta=.3, lambda_seed=53,
+               max_count=slot_bound(csrs, K, world), calls=specs)
+    res = run_ranks(tmp_path, cfg, world)
+    whole = run_ranks(tmp_path, dict(cfg, word_sharded=False), world)
+    e_steps = 3 + 1 + 2 + 2
+    for r in res:
+        assert int(r["word_sharded"][0]) == 1
+        assert np.array_equal(r["lambda"], res[0]["lambda"])          # replicas: bitwise
+        assert int(r["exchanges"][0]) == e_steps and int(r["lambda_exchanges"][0]) == e_steps
+        # what a rank receives per M-step: the table minus its own range
+        assert 0 < int(r["lambda_exchanges"][1]) < e_steps * K * V * 8
+    for r in whole:
+        assert int(r["word_sharded"][0]) == 0 and int(r["lambda_exchanges"][0]) == 0
+        assert np.array_equal(r["lambda"], whole[0]["lambda"])
+    assert relerr(res[0]["lambda"], whole[0]["lambda"]) < 1e-11
+    one = Single(hip, K, V, random_lambda(K, V, 53), .1)
+    rhos = [one.update(c, D, .3, s["seed"], s["max_iter_tr"], 20) for c, s in zip(csrs[:3], specs[:3])]
+    assert [float(res[0]["rho%d" % i][0]) for i in range(3)] == rhos
+    one.batch_update(csrs[3], .3, 8, 2, 20)
+    assert relerr(res[0]["lambda"], one.lambdas()) < 1e-11
+    one.close()
+    # one call, one M-step (no trust-region loop): nothing downstream of the M-step -- bitwise the
+    # one-GPU lambda, whoever computed a column
+    first = run_ranks(tmp_path, dict(cfg, calls=specs[1:2]), world)
+    one = Single(hip, K, V, random_lambda(K, V, 53), .1)
+    one.update(csrs[1], D, .3, 6, 0, 20)
+    assert np.array_equal(first[0]["lambda"], one.lambdas())
+    assert int(first[0]["word_sharded"][0]) == 1
+    one.close()
 
 
 def test_online_update_dp_large_table_and_plain_sequence(hip, tmp_path):

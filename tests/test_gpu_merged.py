@@ -205,3 +205,65 @@ def test_many_merged_launches_in_a_row(hip, sampler):
     assert np.array_equal(ra[0], first_a[0]) and np.array_equal(ra[1], first_a[1])
     assert np.array_equal(rb[0], first_b[0]) and np.array_equal(rb[1], first_b[1])
     assert hip.trlda_model_synchronize(m._handle) == 0
+
+
+@pytest.mark.parametrize("K,V,B", [(100, 3000, 2500), (200, 5000, 3300), (33, 800, 1100)])
+def test_very_long_lists_are_cut_into_segments(hip, oracle, sampler, K, V, B):
+    """csrc/estep_kernels.h, VeryLongArgs: a word with more than 1024 entries (here: words present
+    in every one of 1100 .. 3300 documents, beside a Zipf vocabulary) is walked as segment tasks by
+    whole workgroups and finished by whichever of them comes last -- against the one-workgroup-per-
+    list form (to rounding: other partial sums), the oracle, run to run (bitwise), for plain
+    E-steps and for update calls whose M-step rides on the statistics (even and odd K)."""
+    import trlda_amd
+    from trlda_amd.documents import CSRDocuments
+    base = corpus(B, V, seed=7 + K, mean_unique=40)
+    # three words in every document (ids no document has yet)
+    ip, ids, cnts = [0], [], []
+    for d in range(B):
+        row = list(base.ids[base.indptr[d]:base.indptr[d + 1]])
+        cn = list(base.cnts[base.indptr[d]:base.indptr[d + 1]])
+        for w in (V - 1, V - 2, V - 3):
+            if w not in row:
+                row.append(w)
+                cn.append(1 + (d + w) % 3)
+        ids += row
+        cnts += cn
+        ip.append(len(ids))
+    docs = CSRDocuments(np.array(ip, np.int32), np.array(ids, np.int32), np.array(cnts, np.int32))
+    lam = seeded_lambda(sampler, 3, K, V)
+    g0 = seeded_gamma(sampler, 4, K, B)
+    m = make_model(K, V, lam)
+    batch = m.upload(docs)
+    assert hip.trlda_batch_num_very_long_words(batch.handle) >= 3
+    res = {}
+    for split in (1, 0):
+        assert hip.trlda_model_set_split_lists(m._handle, split) == 0
+        res[split] = m.update_variables(batch, latents=g0, max_iter=10, threshold=1e-3)
+    again = m.update_variables(batch, latents=g0, max_iter=10, threshold=1e-3)
+    hip.trlda_model_set_split_lists(m._handle, 1)
+    once = m.update_variables(batch, latents=g0, max_iter=10, threshold=1e-3)
+    twice = m.update_variables(batch, latents=g0, max_iter=10, threshold=1e-3)
+    assert np.array_equal(once[1], twice[1]) and np.array_equal(once[1], res[1][1])
+    assert np.array_equal(again[1], res[0][1])
+    assert np.array_equal(res[1][0], res[0][0])
+    assert relerr(res[1][1], res[0][1], floor=1e-200) < 1e-12
+    go, so, ito = oracle.estep(lam, .1, docs.indptr, docs.ids, docs.cnts, g0, 10, 1e-3, nthreads=8)
+    assert relerr(res[1][0], go) < TIGHT_RTOL
+    check_sstats(res[1][1], so)
+    # update calls: the M-step, the row sums and the next preamble ride on the same kernel
+    D = 100000
+    lams = {}
+    for split in (1, 0):
+        mm = make_model(K, V, lam, D=D)
+        hip.trlda_model_set_split_lists(mm._handle, split)
+        trlda_amd.seed(9)
+        rho = [mm.update_parameters(batch, max_iter_tr=tr, max_iter_inference=10) for tr in (2, 0)]
+        lams[split] = (np.array(mm.lambdas), rho)
+    assert lams[1][1] == lams[0][1] and relerr(lams[1][0], lams[0][0]) < 1e-11
+    oracle.seed(9)
+    lo, count = lam, 0
+    for tr in (2, 0):
+        _, lo, _, _ = oracle.online_update_parameters(lo, .1, .3, D, docs.indptr, docs.ids, docs.cnts, count,
+                                                       max_iter_tr=tr, max_iter_inference=10)
+        count += 1
+    assert relerr(lams[1][0], lo) < 1e-8

@@ -71,7 +71,12 @@ _SIGNATURES = {
     "trlda_model_dp_direct_connect": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "trlda_model_dp_direct_close": (C.c_int, [vp]),
     "trlda_model_last_split_workgroups": (C.c_int, [vp]),
+    "trlda_model_set_allgatherv": (C.c_int, [vp, vp, vp]),
+    "trlda_model_set_word_sharding": (C.c_int, [vp, C.c_int]),
+    "trlda_model_last_word_sharded": (C.c_int, [vp]),
     "trlda_model_set_merged_launch": (C.c_int, [vp, C.c_int]),
+    "trlda_model_set_split_lists": (C.c_int, [vp, C.c_int]),
+    "trlda_batch_num_very_long_words": (C.c_int, [vp]),
     "trlda_model_last_merged": (C.c_int, [vp]),
     "trlda_model_set_lambda": (C.c_int, [vp, f64p]),
     "trlda_model_get_lambda": (C.c_int, [vp, f64p]),

@@ -1535,6 +1535,35 @@ __device__ __forceinline__ void word_segment_sum(int q0, int q1, int K, int kbas
 constexpr int kLongWord = 16;
 constexpr int kLongWordsTarget = 512;
 
+// VERY long lists (round 4).  A word present in all 12 500 documents of a BatchLDA shard kept ONE
+// workgroup busy for ~100 us -- 98 passes of 16 entries per wave, each a dependent gather -- while
+// the mean wavefront of the launch lived a tenth of that (profiles/r03_stats_kernel_notes.txt); at
+// 1600 documents the longest list alone set the kernel's 24 us.  A list of more than kVeryLong
+// entries is therefore cut into SEGMENTS of at most kVeryLong: a segment is a task for a whole
+// workgroup (a pass or two per wave), its K sums go to a row of `seg_partial`, and the workgroup
+// that finishes a word's LAST segment (a counter per word; rows stored and loaded with agent-scope
+// accesses, as in finish_partial_groups) adds the rows up in segment order and applies the
+// epilogue.  The sums and their order are fixed by the list's length alone: bitwise reproducible,
+// the same on every rank.
+#ifndef TRLDA_VERY_LONG
+#define TRLDA_VERY_LONG 1024
+#endif
+constexpr int kVeryLong = TRLDA_VERY_LONG;   // (256: a pass per wave and task -- the tasks' fixed costs,
+                                             //  ~3 us of barriers and round trips each, then outweigh what
+                                             //  they save at K = 100: 60 -> 70 us at 6400 documents)
+constexpr int kOneWaveMax = 256;             // long_len never exceeds this: a wave walks 16 entries per pass
+struct VeryLongArgs {
+    int G_seg;                    // workgroups walking the segment tasks (0: none)
+    int n_tasks, n_words;         // of this launch (a rank's slice, data-parallel)
+    const int4 *task;             // (word index j, segment, first entry, entries), by (j, segment)
+    const int4 *word;             // j -> (word id, first task = first row of seg_partial, segments, 0)
+    int j0, t0;                   // first word index / task of the launch: rows and tasks are relative to them
+    double *seg_partial;          // n_tasks x K
+    unsigned int *seg_counter;    // one per word (indexed by j), zero between launches
+    int row_base;                 // o.partial row of word j: row_base + j - j0
+    int n_rows;                   // rows of o.partial in all (for the groups)
+};
+
 // At large batches (long_len above its floor: most entries sit in the longest lists) the blocks
 // that walk those lists are the last to finish: they take the FIRST physical workgroups of the
 // launch (dispatched first) and the one-wave-per-word blocks follow -- K = 200 / 12 500 documents:
@@ -1660,6 +1689,9 @@ struct UpdateOut {
     const double *group_base;     // K, added into group 0 (the words outside the batch), or nullptr
     unsigned int *group_counter;  // one per group, zero between launches
     int group_size;
+    // word-sharded M-step (data-parallel, dp_kernels.h): without a list the kernel walks the words
+    // w0 .. w0 + N - 1 -- this rank's range of the vocabulary
+    int w0;
 };
 
 // Row k of a block's partial sums, for finish_partial_groups: stored and loaded with agent-scope
@@ -1678,7 +1710,7 @@ __device__ __forceinline__ void store_partial(const UpdateOut &o, size_t idx, do
 
 // the end of a block of the statistics kernels, after its row of o.partial has been written
 template <int T>
-__device__ __forceinline__ void finish_partial_groups(const UpdateOut &o, int K, int bid)
+__device__ __forceinline__ void finish_partial_groups(const UpdateOut &o, int K, int bid, int rows)
 {
     if (!o.group_rows)                               // launch-uniform
         return;
@@ -1686,7 +1718,6 @@ __device__ __forceinline__ void finish_partial_groups(const UpdateOut &o, int K,
     return;
 #endif
     __shared__ int last_of_group;
-    const int rows = (int)gridDim.x;
     const int g = bid / o.group_size;
     const int r0 = g * o.group_size, r1 = min(rows, r0 + o.group_size);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this thread's row stores: acknowledged
@@ -1727,12 +1758,72 @@ __device__ __forceinline__ double update_one(const UpdateOut &o, size_t i, doubl
     return lam;
 }
 
+// The end of a segment task of a very long list (VeryLongArgs): the W per-wave sums of the segment
+// are in wpart[W][K]; they become one row of seg_partial, and the workgroup that brings the word's
+// counter to its number of segments adds all rows up (segment order, four or eight loads in flight) and
+// applies the epilogue; its lambdas are a row of o.partial of their own (so that the row sums do
+// not depend on which workgroup came last).
+template <int T, int W, bool EMIT>
+__device__ __forceinline__ void segment_finish(const UpdateOut &o, const VeryLongArgs &vl, int K, int4 tk,
+                                               const double *wpart, const double *eeb)
+{
+    __shared__ int last_seg;
+    const int tid = threadIdx.x;
+    const int4 wd = vl.word[tk.x];                   // (word, first task, segments, 0)
+    const size_t row = (size_t)(wd.y + tk.y - vl.t0);
+    __syncthreads();                                 // wpart complete
+    for (int k = tid; k < K; k += T) {
+        double sum = wpart[k];
+#pragma unroll
+        for (int c = 1; c < W; ++c)
+            sum += wpart[c * K + k];
+        __hip_atomic_store(vl.seg_partial + row * K + k, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // this thread's row stores: acknowledged
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int seen = __hip_atomic_fetch_add(vl.seg_counter + tk.x, 1u, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+        const int last = seen + 1u == (unsigned int)wd.z;
+        if (last)                                    // for the next launch (stream order)
+            __hip_atomic_store(vl.seg_counter + tk.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_seg = last;
+    }
+    __syncthreads();
+    if (last_seg) {                                  // block-uniform
+        const double *rows = vl.seg_partial + (size_t)(wd.y - vl.t0) * K;
+        const int prow = vl.row_base + tk.x - vl.j0;
+        for (int k = tid; k < K; k += T) {
+            const size_t i = (size_t)wd.x * K + k;
+            const double ek = eeb[i];
+            double sum = 0.0;
+            constexpr int NV = EMIT ? 4 : 8;         // (the emitting instantiation lives on 64 VGPRs)
+            for (int s0 = 0; s0 < wd.z; s0 += NV) {
+                double v[NV];
+#pragma unroll
+                for (int q = 0; q < NV; ++q)
+                    v[q] = __hip_atomic_load(rows + (size_t)min(s0 + q, wd.z - 1) * K + k, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int q = 0; q < NV; ++q)
+                    sum += (s0 + q < wd.z) ? v[q] : 0.0;
+            }
+            const double lam = update_one<EMIT>(o, i, sum * ek);
+            if (o.partial)
+                store_partial(o, (size_t)prow * K + k, lam);
+        }
+        if (o.partial)
+            finish_partial_groups<T>(o, K, prow, vl.n_rows);
+    }
+    __syncthreads();                                 // wpart is free again
+}
+
 template <int T, int NKB, bool EMIT>                 // EMIT: also UpdateOut::u_out (K <= 128 only)
 __global__ __launch_bounds__(T, EMIT ? (T <= 512 ? 6 : 8) : 1) void sstats_update_kernel(
     int K, int N, int G_short, int n_long, int long_len, const int32_t *__restrict__ list,
     const int32_t *__restrict__ wptr, const int32_t *__restrict__ wdoc,
     const int32_t *__restrict__ long_words, TwView tw_word,
-    const double *__restrict__ epg, const double *eeb /* may be o.u_out */, UpdateOut o)
+    const double *__restrict__ epg, const double *eeb /* may be o.u_out */, UpdateOut o, VeryLongArgs vl)
 {
     constexpr int W = T / kWave;
     extern __shared__ double wpart[];                // W x K
@@ -1746,7 +1837,7 @@ __global__ __launch_bounds__(T, EMIT ? (T <= 512 ? 6 : 8) : 1) void sstats_updat
         for (int kb = 0; kb < NKB; ++kb)
             rs[kb][0] = rs[kb][1] = 0.0;
         for (int p = wid * G_short + bid; p < N; p += W * G_short) {
-            const int w = __builtin_amdgcn_readfirstlane(list ? list[p] : p);
+            const int w = __builtin_amdgcn_readfirstlane(list ? list[p] : p + o.w0);
             const int q0 = __builtin_amdgcn_readfirstlane(wptr[w]);
             const int len = __builtin_amdgcn_readfirstlane(wptr[w + 1]) - q0;
             if (len > long_len)
@@ -1786,14 +1877,39 @@ __global__ __launch_bounds__(T, EMIT ? (T <= 512 ? 6 : 8) : 1) void sstats_updat
                     sum += wpart[c * K + k];
                 store_partial(o, (size_t)bid * K + k, sum);
             }
-            finish_partial_groups<T>(o, K, bid);
+            finish_partial_groups<T>(o, K, bid, vl.n_rows);
+        }
+        return;
+    }
+
+    // ---- segments of the very long lists (VeryLongArgs): the last vl.G_seg blocks
+    const int G_long = (int)gridDim.x - G_short - vl.G_seg;
+    if (bid >= G_short + G_long) {
+        for (int t = bid - G_short - G_long; t < vl.n_tasks; t += vl.G_seg) {      // block-uniform
+            const int4 tk = vl.task[vl.t0 + t];      // (word index, segment, first entry, entries)
+            const int chunk = (tk.w + W - 1) / W;
+            const int c0 = __builtin_amdgcn_readfirstlane(min(tk.w, wid * chunk));
+            const int c1 = __builtin_amdgcn_readfirstlane(min(tk.w, c0 + chunk));
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                if (kb * 2 * kWave < K) {
+                    double acc[2] = {0.0, 0.0};
+                    word_segment_sum<2>(tk.z + c0, tk.z + c1, K, kb * 2 * kWave, wdoc, tw_word, epg, acc);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int k = kb * 2 * kWave + 64 * h + lane;
+                        if (k < K)
+                            wpart[wid * K + k] = acc[h];
+                    }
+                }
+            }
+            segment_finish<T, W, EMIT>(o, vl, K, tk, wpart, eeb);
         }
         return;
     }
 
     // ---- long lists: the remaining blocks walk long_words, one word per pass, the entries
     // split into W contiguous chunks whose sums are combined in chunk order
-    const int G_long = (int)gridDim.x - G_short;
     double rsl[(512 + T - 1) / T];                   // row sums of thread k = tid (+ T ..)
 #pragma unroll
     for (int c = 0; c < (512 + T - 1) / T; ++c)
@@ -1802,6 +1918,8 @@ __global__ __launch_bounds__(T, EMIT ? (T <= 512 ? 6 : 8) : 1) void sstats_updat
         const int w = long_words[lw];
         const int base = __builtin_amdgcn_readfirstlane(wptr[w]);
         const int L = __builtin_amdgcn_readfirstlane(wptr[w + 1]) - base;
+        if (vl.G_seg > 0 && L > kVeryLong)
+            continue;                                // cut into segments (above)
         const int chunk = (L + W - 1) / W;
         const int c0 = __builtin_amdgcn_readfirstlane(min(L, wid * chunk));
         const int c1 = __builtin_amdgcn_readfirstlane(min(L, c0 + chunk));
@@ -1854,7 +1972,7 @@ __global__ __launch_bounds__(T, EMIT ? (T <= 512 ? 6 : 8) : 1) void sstats_updat
             if (k < K)
                 store_partial(o, (size_t)bid * K + k, rsl[c]);
         }
-        finish_partial_groups<T>(o, K, bid);
+        finish_partial_groups<T>(o, K, bid, vl.n_rows);
     }
 }
 
@@ -1952,7 +2070,7 @@ __global__ __launch_bounds__(T, EMIT ? (T <= 512 ? 6 : 8) : 1) void sstats_updat
     int K, int N, int G_short, int n_long, int long_len, const int32_t *__restrict__ list,
     const int32_t *__restrict__ wptr, const int32_t *__restrict__ wdoc,
     const int32_t *__restrict__ long_words, TwView tw_word,
-    const double *__restrict__ epg, const double *eeb /* may be o.u_out */, UpdateOut o)
+    const double *__restrict__ epg, const double *eeb /* may be o.u_out */, UpdateOut o, VeryLongArgs vl)
 {
     constexpr int W = T / kWave;
     constexpr int BW = 128 * NH;                     // topics per pass over a word's list
@@ -1969,7 +2087,7 @@ __global__ __launch_bounds__(T, EMIT ? (T <= 512 ? 6 : 8) : 1) void sstats_updat
             for (int h = 0; h < NH; ++h)
                 rs[kb][h] = make_double2(0.0, 0.0);
         for (int p = wid * G_short + bid; p < N; p += W * G_short) {
-            const int w = __builtin_amdgcn_readfirstlane(list ? list[p] : p);
+            const int w = __builtin_amdgcn_readfirstlane(list ? list[p] : p + o.w0);
             const int q0 = __builtin_amdgcn_readfirstlane(wptr[w]);
             const int len = __builtin_amdgcn_readfirstlane(wptr[w + 1]) - q0;
             if (len > long_len)
@@ -2025,13 +2143,41 @@ __global__ __launch_bounds__(T, EMIT ? (T <= 512 ? 6 : 8) : 1) void sstats_updat
                     sum += wpart2[c * K + k];
                 store_partial(o, (size_t)bid * K + k, sum);
             }
-            finish_partial_groups<T>(o, K, bid);
+            finish_partial_groups<T>(o, K, bid, vl.n_rows);
+        }
+        return;
+    }
+
+    // ---- segments of the very long lists, as in 4c
+    const int G_long = (int)gridDim.x - G_short - vl.G_seg;
+    if (bid >= G_short + G_long) {
+        for (int t = bid - G_short - G_long; t < vl.n_tasks; t += vl.G_seg) {      // block-uniform
+            const int4 tk = vl.task[vl.t0 + t];
+            const int chunk = (tk.w + W - 1) / W;
+            const int c0 = __builtin_amdgcn_readfirstlane(min(tk.w, wid * chunk));
+            const int c1 = __builtin_amdgcn_readfirstlane(min(tk.w, c0 + chunk));
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                if (kb * BW < K) {
+                    double2 acc[NH];
+#pragma unroll
+                    for (int h = 0; h < NH; ++h)
+                        acc[h] = make_double2(0.0, 0.0);
+                    word_segment_sum2<NH>(tk.z + c0, tk.z + c1, K, kb * BW, wdoc, tw_word, epg, acc);
+#pragma unroll
+                    for (int h = 0; h < NH; ++h) {
+                        const int k = kb * BW + 128 * h + 2 * lane;
+                        if (k < K)
+                            *reinterpret_cast<double2 *>(wpart2 + wid * K + k) = acc[h];
+                    }
+                }
+            }
+            segment_finish<T, W, EMIT>(o, vl, K, tk, wpart2, eeb);
         }
         return;
     }
 
     // ---- long lists, as in 4c
-    const int G_long = (int)gridDim.x - G_short;
     double rsl[(512 + T - 1) / T];
 #pragma unroll
     for (int c = 0; c < (512 + T - 1) / T; ++c)
@@ -2040,6 +2186,8 @@ __global__ __launch_bounds__(T, EMIT ? (T <= 512 ? 6 : 8) : 1) void sstats_updat
         const int w = long_words[lw];
         const int base = __builtin_amdgcn_readfirstlane(wptr[w]);
         const int L = __builtin_amdgcn_readfirstlane(wptr[w + 1]) - base;
+        if (vl.G_seg > 0 && L > kVeryLong)
+            continue;                                // cut into segments (above)
         const int chunk = (L + W - 1) / W;
         const int c0 = __builtin_amdgcn_readfirstlane(min(L, wid * chunk));
         const int c1 = __builtin_amdgcn_readfirstlane(min(L, c0 + chunk));
@@ -2095,7 +2243,7 @@ __global__ __launch_bounds__(T, EMIT ? (T <= 512 ? 6 : 8) : 1) void sstats_updat
             if (k < K)
                 store_partial(o, (size_t)bid * K + k, rsl[c]);
         }
-        finish_partial_groups<T>(o, K, bid);
+        finish_partial_groups<T>(o, K, bid, vl.n_rows);
     }
 }
 

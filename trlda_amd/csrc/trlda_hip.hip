@@ -76,6 +76,9 @@ constexpr int kUpdGroups = 64;           // rows the document kernel adds up its
 constexpr int kCarryBlocks = 8;          // preamble_fused_kernel: workgroups adding up carried partials
 constexpr int kUpdShortBlocks = 1024;    // sstats_update_kernel: blocks walking the short lists
 constexpr int kUpdLongBlocks = 512;      //                       blocks walking the long lists (two per CU resident)
+constexpr int kUpdSegBlocks = 2048;      //                       blocks walking the segments of the very long lists
+constexpr int kUpdVlRows = 4096;         // very long words whose lambdas take a row of upd_partial each; a batch
+                                         // with more of them keeps them in the one-block-per-word path
 constexpr double kFusedRowsumFloor = 2e-3;   // psi(2e-3) = -500.6: exp(-psi(row sum)) stays finite
 
 template <typename T>
@@ -168,6 +171,12 @@ struct trlda_batch {
     // in the gathered buffer, for the cut points / geometry in dp_sig (built on first use)
     int32_t *dp_wsrc = nullptr, *dp_wrow = nullptr;
     std::vector<int64_t> dp_sig;
+    // word-sharded M-step (data-parallel): host copies of the word-major offsets and of the long
+    // words, and per world size the ranks' ranges of the vocabulary (word ids, positions in
+    // `active`, positions in `long_words`: world + 1 cut points each), balanced by entries
+    std::vector<int32_t> wptr_host, long_host;
+    int ws_world = 0;
+    std::vector<int32_t> ws_wcuts, ws_acuts, ws_lcuts;
     // sum of the counts per word (onlinelda.cpp:79-82), formed on the host while the batch is
     // indexed; valid unless a sum does not fit 32 bits (then the device adds them up)
     int32_t *wc32 = nullptr;
@@ -178,6 +187,14 @@ struct trlda_batch {
     // decreasing length (a wave's words of one round are then about equally long)
     int32_t *mdesc = nullptr;       // n_active x 4
     int n_short = 0;
+    // very long lists (estep_kernels.h, VeryLongArgs): words of more than kVeryLong entries, by word
+    // id -- (word, first task, segments, 0) -- and their segment tasks (word index, segment, first
+    // entry, entries)
+    int32_t *vl_word = nullptr, *vl_task = nullptr;
+    int n_vl = 0, n_vl_tasks = 0;
+    std::vector<int32_t> vl_host;   // host copy of the very long words' ids (ranks' slices)
+    std::vector<int32_t> vl_first;  // ... and of their first tasks, + the total (n_vl + 1)
+    std::vector<int32_t> ws_vcuts;  // word-sharded M-step: cut points in the very long words
 };
 
 // A data-parallel call in flight (dp_kernels.h): the model holds the whole mini-batch `b`, iterates
@@ -189,6 +206,10 @@ struct DpContext {
     void *comm = nullptr;               // ncclComm_t, unless the model has an all-gather hook
     size_t slot = 0, tw_off = 0;        // doubles
     int doc_lo() const { return cuts[(size_t)rank]; }
+    // Word-sharded M-step: after the factor exchange every rank forms statistics + M-step for ITS
+    // range of the vocabulary only (batch->ws_*cuts) and the ranks exchange the lambda columns
+    // they wrote, in place
+    bool word_sharded = false;
 };
 
 struct trlda_model {
@@ -270,6 +291,11 @@ struct trlda_model {
     size_t cap_dp_gather = 0;
     int (*allgather_hook)(void *, const void *, void *, size_t, void *) = nullptr;
     void *allgather_ctx = nullptr;
+    int (*allgatherv_hook)(void *, void *, const size_t *, int, int, void *) = nullptr;
+    void *allgatherv_ctx = nullptr;
+    bool word_sharding = true;          // trlda_model_set_word_sharding
+    bool split_long_lists = true;       // TRLDA_SPLIT_LISTS=0: very long lists stay one workgroup's (comparisons)
+    bool last_word_sharded = false;     // the last *_dp call's M-steps were word-sharded
     // direct exchange (dp_kernels.h): this process's region [2 x world x max_slot doubles |
     // kDpMaxWorld step counters], exported through hipIpc; the peers' regions mapped here
     struct {
@@ -283,6 +309,11 @@ struct trlda_model {
     } direct;
     double *epg = nullptr, *tw_csr = nullptr, *tw_word = nullptr;
     double *epg_base = nullptr;         // the allocation: K zeros (row -1 of epg), then epg
+    // very long lists (VeryLongArgs): a row of K sums per segment task, a counter per word
+    double *seg_partial = nullptr;
+    size_t cap_seg_partial = 0;
+    unsigned int *seg_counter = nullptr;
+    size_t cap_seg_counter = 0;
     // merged launch (estep_merged.h): the statistics as workgroups of the document launch.
     // Two counters that only grow (documents done | topic factors finished) and what they have
     // been asked to reach so far; the finished topic factors of an in-launch combine
@@ -710,6 +741,12 @@ struct EstepOut {
     const double *next_base = nullptr;
     int groups = 0;
     bool raw_rows = false;      // out: the `groups` rows are block rows still to be added up (merged launch)
+    // word-sharded M-step (set by estep_device for the statistics launch): this rank's slice --
+    // positions [slice_lo, slice_lo + slice_n) of the active list (active_only) or word ids, and
+    // its part [long_lo, long_lo + long_n) of the long words
+    bool sliced = false;
+    int slice_lo = 0, slice_n = 0, long_lo = 0, long_n = 0, vl_lo = 0, vl_n = 0;
+    bool no_rows = false;       // out: no row sums were left behind (the next E-step adds lambda up)
     EstepOut() { upd = trlda::UpdateOut{}; }
     explicit EstepOut(double *sstats) : EstepOut() { upd.sstats = sstats; }
 };
@@ -795,7 +832,7 @@ bool mstep_keeps_positive(const trlda_model *m, const trlda::UpdateOut &u, const
 
 using sstats_update_fn = void (*)(int, int, int, int, int, const int32_t *, const int32_t *, const int32_t *,
                                   const int32_t *, trlda::TwView, const double *, const double *,
-                                  trlda::UpdateOut);
+                                  trlda::UpdateOut, trlda::VeryLongArgs);
 template <int T, int NKB, int NH, bool EMIT>
 sstats_update_fn sstats_update_entry()
 {
@@ -810,9 +847,36 @@ int launch_sstats_update(trlda_model *m, const trlda_batch *b, EstepOut &out)
 {
     constexpr int W = T / trlda::kWave;
     const int K = m->K;
-    const int N = out.active_only ? b->n_active : m->V;
+    // (word-sharded M-step: this rank's slice of the list / of the vocabulary and of the long words)
+    const int N = out.sliced ? out.slice_n : out.active_only ? b->n_active : m->V;
+    const int n_long = out.sliced ? out.long_n : b->n_long;
     const int G_short = std::max(1, std::min(kUpdShortBlocks, (N + W - 1) / W));
-    const int G_long = std::min(kUpdLongBlocks, b->n_long);
+    const int G_long = std::min(kUpdLongBlocks, n_long);
+    // the very long lists (of this rank's slice): segment tasks for whole workgroups
+    trlda::VeryLongArgs vl{};
+    const bool segments = b->n_vl > 0 && b->n_vl <= kUpdVlRows && m->split_long_lists;
+    if (segments) {
+        const int j_lo = out.sliced ? out.vl_lo : 0, j_n = out.sliced ? out.vl_n : b->n_vl;
+        vl.j0 = j_lo;
+        vl.t0 = b->vl_first[(size_t)j_lo];
+        vl.n_words = j_n;
+        vl.n_tasks = b->vl_first[(size_t)(j_lo + j_n)] - vl.t0;
+        vl.G_seg = std::min(kUpdSegBlocks, vl.n_tasks);
+        vl.task = reinterpret_cast<const int4 *>(b->vl_task);
+        vl.word = reinterpret_cast<const int4 *>(b->vl_word);
+        int rc0 = grow(&m->seg_partial, &m->cap_seg_partial, std::max<size_t>((size_t)vl.n_tasks * K, 1));
+        if (!rc0 && (size_t)b->n_vl > m->cap_seg_counter) {
+            rc0 = grow(&m->seg_counter, &m->cap_seg_counter, (size_t)b->n_vl + 64);
+            if (!rc0 && hipMemsetAsync(m->seg_counter, 0, m->cap_seg_counter * sizeof(unsigned int), m->stream) != hipSuccess)
+                rc0 = fail(TRLDA_ERR_HIP, "hipMemsetAsync failed");
+        }
+        if (rc0)
+            return rc0;
+        vl.seg_partial = m->seg_partial;
+        vl.seg_counter = m->seg_counter;
+        vl.row_base = G_short + G_long;
+    }
+    vl.n_rows = G_short + G_long + vl.n_words;
     const size_t lds = (size_t)W * K * sizeof(double);
     // (the instantiation that also writes exp(psi(lambda)) needs more registers: only where asked)
     constexpr bool can_emit = NKB == 1 && NH <= 1;   // K <= 128
@@ -837,7 +901,7 @@ int launch_sstats_update(trlda_model *m, const trlda_batch *b, EstepOut &out)
     out.upd.group_counter = nullptr;
     out.upd.group_size = 1;
     if (emit) {
-        const int rows = G_short + G_long;
+        const int rows = vl.n_rows;
         out.upd.u_out = m->eeb;
         out.upd.group_rows = m->upd_groups;
         out.upd.group_base = out.next_base;
@@ -846,13 +910,15 @@ int launch_sstats_update(trlda_model *m, const trlda_batch *b, EstepOut &out)
         out.groups = (rows + out.upd.group_size - 1) / out.upd.group_size;
     }
     // (data-parallel: expElogtheta rows of all ranks in the gathered buffer, dp_kernels.h)
-    hipLaunchKernelGGL(kern, dim3(G_short + G_long), dim3(T), lds, m->stream, K, N, G_short,
-                       b->n_long, b->long_len, out.active_only ? b->active : nullptr, b->wptr,
-                       m->dp ? b->dp_wrow : b->wdoc, b->long_words,
+    out.upd.w0 = (out.sliced && !out.active_only) ? out.slice_lo : 0;
+    const int32_t *list = out.active_only ? b->active + (out.sliced ? out.slice_lo : 0) : nullptr;
+    hipLaunchKernelGGL(kern, dim3(G_short + G_long + vl.G_seg), dim3(T), lds, m->stream, K, N, G_short,
+                       n_long, b->long_len, list, b->wptr,
+                       m->dp ? b->dp_wrow : b->wdoc, b->long_words + (out.sliced ? out.long_lo : 0),
                        m->dp ? trlda::TwView{m->dp_gather, b->dp_wsrc} : trlda::TwView{m->tw_word, nullptr},
-                       m->dp ? m->dp_gather : m->epg, m->eeb_cur, out.upd);
+                       m->dp ? m->dp_gather : m->epg, m->eeb_cur, out.upd, vl);
     HIP_TRY(hipGetLastError());
-    out.partial_rows = G_short + G_long;
+    out.partial_rows = vl.n_rows;
     return TRLDA_OK;
 }
 
@@ -998,6 +1064,81 @@ int dp_prepare(trlda_model *m, const trlda_batch *b, DpContext *dp)
         HIP_TRY(hipGetLastError());
         bb->dp_sig = sig;
     }
+    // Word-sharded M-step: the ranks' ranges of the vocabulary, balanced by what a word costs the
+    // statistics kernel (its entries, a constant per active word, a little for the others).  A
+    // property of (mini-batch, world): every rank computes the same cut points.  Needs a transport
+    // for ranges of unequal size: RCCL (grouped broadcasts) or the host's all-gather-v hook.
+    dp->word_sharded = world > 1 && m->word_sharding && fused_update_available(m) &&
+                       (m->allgatherv_hook || (dp->comm && !m->allgather_hook && !m->dp_gather_direct)) &&
+                       (int)b->wptr_host.size() == m->V + 1;
+    if (dp->word_sharded && bb->ws_world != world) {
+        const int V = m->V;
+        std::vector<int64_t> cost((size_t)V + 1, 0);
+        for (int w = 0; w < V; ++w) {
+            const int len = b->wptr_host[(size_t)w + 1] - b->wptr_host[(size_t)w];
+            cost[(size_t)w + 1] = cost[(size_t)w] + (len > 0 ? 4 + len : 1);
+        }
+        bb->ws_wcuts.assign((size_t)world + 1, 0);
+        bb->ws_acuts.assign((size_t)world + 1, 0);
+        bb->ws_lcuts.assign((size_t)world + 1, 0);
+        bb->ws_vcuts.assign((size_t)world + 1, 0);
+        int w = 0, na = 0, nl = 0, nv = 0;
+        for (int r = 1; r <= world; ++r) {
+            const int64_t target = r == world ? cost[(size_t)V] : cost[(size_t)V] * r / world;
+            while (w < V && (r == world || cost[(size_t)w + 1] <= target)) {
+                const int len = b->wptr_host[(size_t)w + 1] - b->wptr_host[(size_t)w];
+                na += len > 0;
+                nl += len > b->long_len;
+                nv += len > trlda::kVeryLong;
+                ++w;
+            }
+            bb->ws_wcuts[(size_t)r] = w;
+            bb->ws_acuts[(size_t)r] = na;
+            bb->ws_lcuts[(size_t)r] = nl;
+            bb->ws_vcuts[(size_t)r] = nv;
+        }
+        bb->ws_world = world;
+    }
+    return TRLDA_OK;
+}
+
+// Word-sharded M-step: every rank has written lambda[:, wcuts[rank] .. wcuts[rank + 1]) and
+// receives the other ranks' ranges IN PLACE -- the replicas are bitwise equal afterwards, every
+// column computed once, by its owner (src/onlinelda.cpp:99-100 / src/batchlda.cpp:60 across ranks).
+// RCCL: one grouped launch of `world` broadcasts (ranges of unequal size; ncclAllGather wants equal
+// counts); or the host's own transport (trlda_model_set_allgatherv).
+using nccl_broadcast_fn = int (*)(const void *, void *, size_t, int, int, void *, hipStream_t);
+using nccl_group_fn = int (*)();
+int dp_exchange_lambda(trlda_model *m, const trlda_batch *b)
+{
+    DpContext *dp = m->dp;
+    const int world = dp->world;
+    const size_t K = (size_t)m->K;
+    if (m->allgatherv_hook) {
+        std::vector<size_t> offs((size_t)world + 1);
+        for (int r = 0; r <= world; ++r)
+            offs[(size_t)r] = (size_t)b->ws_wcuts[(size_t)r] * K;
+        const int rc = m->allgatherv_hook(m->allgatherv_ctx, m->lambda, offs.data(), dp->rank, world, m->stream);
+        if (rc != 0)
+            return fail(TRLDA_ERR_HIP, "the all-gather-v hook failed with " + std::to_string(rc));
+        return TRLDA_OK;
+    }
+    static nccl_broadcast_fn bcast = reinterpret_cast<nccl_broadcast_fn>(rccl_symbol("ncclBroadcast"));
+    static nccl_group_fn gstart = reinterpret_cast<nccl_group_fn>(rccl_symbol("ncclGroupStart"));
+    static nccl_group_fn gend = reinterpret_cast<nccl_group_fn>(rccl_symbol("ncclGroupEnd"));
+    if (!bcast || !gstart || !gend)
+        return fail(TRLDA_ERR_ARG, "ncclBroadcast / ncclGroupStart / ncclGroupEnd not found: load RCCL "
+                                   "(librccl.so) into the process");
+    int rc = gstart();
+    for (int r = 0; r < world && rc == 0; ++r) {
+        const size_t lo = (size_t)b->ws_wcuts[(size_t)r] * K, hi = (size_t)b->ws_wcuts[(size_t)r + 1] * K;
+        if (hi > lo)
+            rc = bcast(m->lambda + lo, m->lambda + lo, hi - lo, kNcclFloat64, r, dp->comm, m->stream);
+    }
+    const int rc_end = gend();
+    if (rc != 0 || rc_end != 0)
+        return fail(TRLDA_ERR_HIP, "ncclBroadcast (word-sharded M-step) failed with ncclResult_t " +
+                                       std::to_string(rc != 0 ? rc : rc_end));
     return TRLDA_OK;
 }
 
@@ -1608,6 +1749,34 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                            dim3(kDenseThreads), 0, m->stream, KV, FinishOp{m->eeb_cur, sstats_dev});
     } else if (m->last_merged && !dp) {
         // (statistics: workgroups of the document launch above)
+    } else if (dp && dp->word_sharded && out.upd.lambda && !out.upd.sstats) {
+        // Word-sharded M-step (data-parallel): statistics + M-step for THIS RANK's range of the
+        // vocabulary only -- every rank holds all factors, so any rank can form any word's
+        // statistics; a word's entries are added in document order by whoever owns it -- then the
+        // ranks exchange the lambda columns they wrote.  No row sums and no exp(psi(lambda)) ride
+        // along: the next E-step's preamble forms them from the exchanged lambda.
+        EstepOut part = out;
+        part.sliced = true;
+        part.upd.partial = nullptr;
+        part.emit_next = false;
+        const int r = dp->rank;
+        if (out.active_only) {
+            part.slice_lo = b->ws_acuts[(size_t)r];
+            part.slice_n = b->ws_acuts[(size_t)r + 1] - part.slice_lo;
+        } else {
+            part.slice_lo = b->ws_wcuts[(size_t)r];
+            part.slice_n = b->ws_wcuts[(size_t)r + 1] - part.slice_lo;
+        }
+        part.long_lo = b->ws_lcuts[(size_t)r];
+        part.long_n = b->ws_lcuts[(size_t)r + 1] - part.long_lo;
+        part.vl_lo = b->ws_vcuts[(size_t)r];
+        part.vl_n = b->ws_vcuts[(size_t)r + 1] - part.vl_lo;
+        if ((rc = sstats_update_device(m, b, part)) || (rc = dp_exchange_lambda(m, b)))
+            return rc;
+        out.no_rows = true;
+        out.groups = 0;
+        out.partial_rows = 0;
+        m->last_word_sharded = true;
     } else if (fused_update_available(m)) {
         rc = sstats_update_device(m, b, out);
         if (rc)
@@ -1808,6 +1977,10 @@ int check_model(const trlda_model *m)
 {
     if (!m)
         return fail(TRLDA_ERR_ARG, "model is NULL");
+    // (whatever another library of the process left in this thread's "last error" -- torch's
+    // allocator probes stream capture and leaves "operation not permitted when stream is
+    // capturing" behind -- is not an error of the launches this entry point is about to check)
+    (void)hipGetLastError();
     return use_device(m->device);
 }
 
@@ -2084,6 +2257,21 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
             ++level;
         long_len = trlda::kLongWord << level;
         n_long = over[level];
+        // (the longest lists are cut into segments, estep_kernels.h: the one-wave range stays short)
+        if (long_len > trlda::kOneWaveMax) {
+            long_len = trlda::kOneWaveMax;
+            n_long = 0;
+            for (int w = 0; w < V; ++w)
+                n_long += wptr[(size_t)w + 1] - wptr[(size_t)w] > long_len;
+        }
+    }
+    int n_vl = 0, n_vl_tasks = 0;
+    for (int w = 0; w < V; ++w) {
+        const int len = wptr[(size_t)w + 1] - wptr[(size_t)w];
+        if (len > trlda::kVeryLong) {
+            ++n_vl;
+            n_vl_tasks += (len + trlda::kVeryLong - 1) / trlda::kVeryLong;
+        }
     }
 
     // documents of more than kSplitMinN words take several workgroups (segments)
@@ -2117,7 +2305,8 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
                  o_smeta = section((size_t)n_wg * 32), o_spids = section((size_t)n_wg * trlda::kRegMaxN * 4),
                  o_active = section((size_t)n_active * 4), o_long = section((size_t)n_long * 4),
                  o_flag = section((size_t)V), o_wc32 = section((size_t)V * 4),
-                 o_mdesc = section((size_t)n_active * 16);
+                 o_mdesc = section((size_t)n_active * 16), o_vlw = section((size_t)n_vl * 16),
+                 o_vlt = section((size_t)n_vl_tasks * 16);
     const size_t total = off;
 
     UploadContext &u = upload_context(device);
@@ -2182,6 +2371,7 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     b->n_active = n_active; b->n_long = n_long; b->long_len = long_len;
     b->sorted_len.resize(Bz);
     b->indptr_host.assign(indptr, indptr + Bz + 1);
+    b->wptr_host = wptr;
     {
         int32_t *meta = I(o_meta), *pids = I(o_pids);
         for (int i = 0; i < B; ++i) {
@@ -2260,6 +2450,28 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
             if (len > long_len)
                 longw[nl++] = w;
         }
+        b->long_host.assign(longw, longw + nl);
+        // the very long lists: equal segments of at most kVeryLong entries
+        int32_t *vw = I(o_vlw), *vt = I(o_vlt);
+        int j = 0, t = 0;
+        for (int w = 0; w < V && n_vl > 0; ++w) {
+            const int q0 = wptr[(size_t)w], len = wptr[(size_t)w + 1] - q0;
+            if (len <= trlda::kVeryLong)
+                continue;
+            const int ns = (len + trlda::kVeryLong - 1) / trlda::kVeryLong;
+            const int base = len / ns, rem = len % ns;
+            vw[4 * j] = w; vw[4 * j + 1] = t; vw[4 * j + 2] = ns; vw[4 * j + 3] = 0;
+            b->vl_host.push_back(w);
+            b->vl_first.push_back(t);
+            int start = 0;
+            for (int sg = 0; sg < ns; ++sg, ++t) {
+                const int sl = base + (sg < rem ? 1 : 0);
+                vt[4 * t] = j; vt[4 * t + 1] = sg; vt[4 * t + 2] = q0 + start; vt[4 * t + 3] = sl;
+                start += sl;
+            }
+            ++j;
+        }
+        b->vl_first.push_back(t);
         // descriptors for the merged launch: counting sort by length, longest first, the short
         // lists (<= long_len entries) before the long ones
         int32_t *md = I(o_mdesc);
@@ -2361,6 +2573,8 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     b->cnts_nonneg = cnts_nonneg;
     b->mdesc = D(o_mdesc);
     b->n_short = n_active - n_long;
+    b->vl_word = D(o_vlw); b->vl_task = D(o_vlt);
+    b->n_vl = n_vl; b->n_vl_tasks = n_vl_tasks;
     *out = b;
     return TRLDA_OK;
 }
@@ -2401,6 +2615,7 @@ int64_t trlda_batch_nnz(const trlda_batch *b) { return b ? b->nnz : 0; }
 int trlda_batch_max_doc_len(const trlda_batch *b) { return b ? b->max_n : 0; }
 int trlda_batch_long_word_len(const trlda_batch *b) { return b ? b->long_len : 0; }
 int trlda_batch_num_long_words(const trlda_batch *b) { return b ? b->n_long : 0; }
+int trlda_batch_num_very_long_words(const trlda_batch *b) { return b ? b->n_vl : 0; }
 
 // ---- model --------------------------------------------------------------------
 
@@ -2442,7 +2657,7 @@ int trlda_model_create(trlda_model **out, int device, int K, int V)
     }
     if (!rc) rc = dev_alloc(&m->rs_full, (size_t)K);
     if (!rc) rc = dev_alloc(&m->rs_static, (size_t)K);
-    if (!rc) rc = dev_alloc(&m->upd_partial, (size_t)(kUpdShortBlocks + kUpdLongBlocks) * K);
+    if (!rc) rc = dev_alloc(&m->upd_partial, (size_t)(kUpdShortBlocks + kUpdLongBlocks + kUpdVlRows) * K);
     if (!rc) rc = dev_alloc(&m->carry_out, (size_t)kCarryBlocks * K);
     if (!rc) rc = dev_alloc(&m->upd_groups, (size_t)kUpdGroups * K);
     if (!rc) {
@@ -2475,6 +2690,8 @@ int trlda_model_create(trlda_model **out, int device, int K, int V)
     }
     if (const char *env = std::getenv("TRLDA_DRAW_AHEAD"))       // 1 = draw the next gamma0 ahead
         m->draw_ahead = env[0] != '0';
+    if (const char *env = std::getenv("TRLDA_SPLIT_LISTS"))
+        m->split_long_lists = env[0] != '0';
     if (const char *env = std::getenv("TRLDA_MERGED"))           // 0 = statistics always a launch of their own
         m->merged_launch = std::max(0, std::min(std::atoi(env), 2));
     *out = m;
@@ -2499,6 +2716,7 @@ int trlda_model_destroy(trlda_model *m)
             (void)hipEventDestroy(m->eb.event);
         (void)hipFree(m->partial); (void)hipFree(m->counter); (void)hipFree(m->epg_base); (void)hipFree(m->tw_csr);
         (void)hipFree(m->sync_counters); (void)hipFree(m->sync_flags); (void)hipFree(m->scale_comb);
+        (void)hipFree(m->seg_partial); (void)hipFree(m->seg_counter);
         (void)hipFree(m->tw_word); (void)hipFree(m->dp_gather_own); (void)trlda_model_dp_direct_close(m); (void)hipFree(m->lambda_prime); (void)hipFree(m->sstats); (void)hipFree(m->gamma);
         (void)hipFree(m->wordcounts); (void)hipFree(m->rs_full); (void)hipFree(m->rs_static);
         (void)hipFree(m->upd_partial); (void)hipFree(m->ada_gradient); (void)hipFree(m->reduce_out);
@@ -2944,6 +3162,14 @@ int carry_rowsums_from(trlda_model *m, const double *rows, int n, const double *
 int finish_rowsums(trlda_model *m, const EstepOut &out, const double *base, double floor,
                    const trlda_batch *b = nullptr)
 {
+    if (out.no_rows) {
+        // word-sharded M-step: every rank wrote a part of lambda and received the rest; the next
+        // E-step adds the rows up from lambda itself (lda.cpp:172 as written)
+        invalidate_rowsums(m);
+        m->rs_floor = floor;
+        m->next_pre.valid = false;
+        return TRLDA_OK;
+    }
     int rc = carry_rowsums_from(m, out.upd.partial, out.partial_rows, base, floor);
     // (carry_rowsums_from moved lambda_version on: what the kernel left behind belongs to the new one)
     m->next_pre.valid = !rc && out.groups > 0 && b && base == out.next_base;
@@ -3620,6 +3846,33 @@ int trlda_model_set_allgather(trlda_model *m, trlda_allgather_fn fn, void *ctx)
     return TRLDA_OK;
 }
 
+int trlda_model_set_allgatherv(trlda_model *m, trlda_allgatherv_fn fn, void *ctx)
+{
+    if (!m)
+        return fail(TRLDA_ERR_ARG, "model is NULL");
+    m->allgatherv_hook = fn;
+    m->allgatherv_ctx = ctx;
+    return TRLDA_OK;
+}
+
+int trlda_model_set_word_sharding(trlda_model *m, int enabled)
+{
+    if (!m)
+        return fail(TRLDA_ERR_ARG, "model is NULL");
+    m->word_sharding = enabled != 0;
+    return TRLDA_OK;
+}
+
+int trlda_model_last_word_sharded(const trlda_model *m) { return m && m->last_word_sharded ? 1 : 0; }
+
+int trlda_model_set_split_lists(trlda_model *m, int enabled)
+{
+    if (!m)
+        return fail(TRLDA_ERR_ARG, "model is NULL");
+    m->split_long_lists = enabled != 0;
+    return TRLDA_OK;
+}
+
 } // extern "C"
 
 namespace {
@@ -3638,6 +3891,7 @@ int dp_enter(trlda_model *m, DpContext &dp, const trlda_batch *batch, const trld
     dp.world = world;
     dp.comm = rccl_comm;
     dp.cuts.assign(doc_cuts, doc_cuts + world + 1);
+    m->last_word_sharded = false;
     int rc = dp_prepare(m, batch, &dp);
     if (!rc)
         m->dp = &dp;
