@@ -467,6 +467,44 @@ def main():
             if rank == 0:
                 print("bench: factor exchange failed its check (%s); using the all-reduce of sstats"
                       % (exchange_probe,), file=sys.stderr)
+    if exchange == "factors" and not vworld and not args.whole_stats and \
+            (world > 1 or (force_dist and os.environ.get("TRLDA_BENCH_SHARD_CHECK") == "1")):
+        # One check of the word-sharded M-step (grouped ncclBroadcast of the ranks' lambda ranges,
+        # never run on this box's one GPU): a step on the first mini-batch must leave the SAME
+        # lambda on every rank, and the one that the whole-statistics form leaves.  Any failure, on
+        # any rank, switches the sharding off on all ranks together.
+        ok, detail = 0, None
+        try:
+            def one_step(sharded):
+                _ffi.check(L.trlda_model_set_lambda(model, lam))
+                _ffi.check(L.trlda_model_set_word_sharding(model, int(sharded)))
+                _ffi.check(L.trlda_model_estep_dp(
+                    model, gbatches[0].handle, batches[0].handle, rccl_comm, rank, world,
+                    cuts.ctypes.data_as(C.POINTER(C.c_int32)), gamma0s[0].data_ptr(), gamma.data_ptr(),
+                    None, args.max_iter, args.threshold, None, 1, lam_prime.data_ptr(), RHO, ETA,
+                    D_TOTAL / float(B * world) if D_TOTAL else 1.))
+                got = np.empty((K, V), order="F")
+                _ffi.check(L.trlda_model_get_lambda(model, got))
+                return got, bool(L.trlda_model_last_word_sharded(model))
+            lam_sh, was_sharded = one_step(True)
+            lam_wh, _ = one_step(False)
+            chk = torch.tensor([float(lam_sh.sum()), -float(lam_sh.sum())], dtype=torch.float64, device=device)
+            dist.all_reduce(chk, op=dist.ReduceOp.MAX)
+            same = float(chk[0].item()) == -float(chk[1].item())
+            dev_ = float(np.max(np.abs(lam_sh - lam_wh) / lam_wh))
+            ok = int(was_sharded and same and dev_ < 1e-9)
+            detail = {"word_sharded": was_sharded, "replicas_equal": same, "max_rel_dev_vs_whole_statistics": dev_}
+        except Exception as exc:                      # noqa: BLE001
+            detail = {"error": repr(exc)[:200]}
+        flag = torch.tensor([ok], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        sharding_ok = int(flag.item()) == 1
+        _ffi.check(L.trlda_model_set_word_sharding(model, int(sharding_ok)))
+        _ffi.check(L.trlda_model_set_lambda(model, lam))
+        exchange_probe = dict(exchange_probe or {}, word_sharded_m_step=detail)
+        if not sharding_ok and rank == 0:
+            print("bench: word-sharded M-step failed its check (%s); every rank forms the whole "
+                  "mini-batch's statistics" % (detail,), file=sys.stderr)
     if vworld:
         # no collective: the first call copies this rank's slot into the other ranks' (finite,
         # plausible factors), later calls leave the buffer alone

@@ -71,10 +71,15 @@ def test_bench_forced_distributed_line(hip_lib):
     """The N > 1 code path on the one GPU (a one-rank process group): `rccl_ranks`, `same_step_n1`."""
     env_key = "TRLDA_BENCH_FORCE_DIST"
     os.environ[env_key] = "1"
-    try:
-        j = run_bench("--no-cpu-baseline", "--no-update-rates")
+    os.environ["TRLDA_BENCH_SHARD_CHECK"] = "1"      # walk through the N > 1 check of the word-sharded
+    try:                                             # M-step too (one rank: nothing to shard, it says so)
+        j = run_bench("--no-cpu-baseline", "--no-update-rates", "--exchange", "factors")
     finally:
         del os.environ[env_key]
+        del os.environ["TRLDA_BENCH_SHARD_CHECK"]
+    chk = j["config"]["exchange_check"]["word_sharded_m_step"]
+    assert chk["word_sharded"] is False and chk["replicas_equal"] is True
+    assert j["config"]["word_sharded_m_step"] is False
     assert j["n_gpus"] == 1 and j["rccl_ranks"] == 1
     same = j["same_step_n1"]
     assert abs(same["ms_per_step"] - j["ms_per_step"]) < 0.25 * j["ms_per_step"]

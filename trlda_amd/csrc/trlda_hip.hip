@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -4448,6 +4449,61 @@ int trlda_tr_init(int K, int V, int B, int num_documents, double rho, double eta
     trlda_batch_destroy(b);
     trlda_model_destroy(m);
     return rc;
+}
+
+// Experiment (tools/graph_probe.py): one OnlineLDA::updateParameters call (src/onlinelda.cpp:
+// 89-101: its 1 + 2 x max_iter_tr .. launches) recorded ONCE into a HIP graph and replayed, against
+// the same call enqueued launch by launch.  The replay repeats the recorded call exactly -- the same
+// gamma0 windows, the same batch -- so it is a measurement of what a graph could save, not a product
+// path.  usec_out[0] = per call, direct; [1] = per replayed graph launch.
+extern "C" int trlda_debug_graph_update(trlda_model *m, const trlda_batch *b, int num_documents, double eta,
+                                        int max_iter_tr, int max_iter_inference, int reps, double *usec_out)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!b || !usec_out || reps < 1)
+        return fail(TRLDA_ERR_ARG, "bad graph probe arguments");
+    int count = 0;
+    double rho = 0.;
+    auto call = [&]() {
+        return trlda_model_online_update(m, b, num_documents, eta, max_iter_tr, max_iter_inference, .7, 100.,
+                                         0.01, 1, 1, 1e-3, &count, &rho, nullptr);
+    };
+    for (int i = 0; i < 3 && !rc; ++i)                            // allocations, attributes, caches
+        rc = call();
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t0 = now();
+    for (int i = 0; i < reps && !rc; ++i)
+        rc = call();
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    usec_out[0] = std::chrono::duration<double, std::micro>(now() - t0).count() / reps;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    HIP_TRY(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+    rc = call();
+    hipError_t e = hipStreamEndCapture(m->stream, &graph);
+    if (rc || e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(TRLDA_ERR_HIP, std::string("capture failed: ") + (rc ? trlda_last_error() : hipGetErrorString(e)));
+    }
+    HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    for (int i = 0; i < 3; ++i)
+        HIP_TRY(hipGraphLaunch(exec, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    t0 = now();
+    for (int i = 0; i < reps; ++i)
+        HIP_TRY(hipGraphLaunch(exec, m->stream));
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    usec_out[1] = std::chrono::duration<double, std::micro>(now() - t0).count() / reps;
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
+    return TRLDA_OK;
 }
 
 // diagnostics: the s_memtime stamps of the model's last merged launch (3 x 1024 values)
