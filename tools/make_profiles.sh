@@ -15,7 +15,10 @@
 #   <tag>_stamps_reg.txt         tools/stamps.sh: cycle shares inside the document kernel
 #   <tag>_length_sweep.txt, <tag>_speed_workload.txt, <tag>_bench_lengthslognormal.json, <tag>_bench_uniform.json,
 #   <tag>_xcu_probe.txt          document lengths
-tag=${1:-r03}; commit=${2:-unknown}
+#   <tag>_timeline_*.txt, <tag>_merged_stamps.txt, <tag>_graph_probe.txt, <tag>_anyorder_probe.txt,
+#   <tag>_configs_lists_unsplit.txt, <tag>_bench_merged_level{0,2}.json, <tag>_update_rates_unmerged.txt,
+#   <tag>_bench_virtual_world*_whole_stats.json    round 4: merged launch, list segments, word-sharded M-step
+tag=${1:-r04}; commit=${2:-unknown}
 export TMPDIR=/tmp
 tools/prof_stats.sh ${tag} --steps 200 --warmup 20 > /dev/null
 tools/prof_pmc.sh ${tag}_fetch "FETCH_SIZE" --steps 50 --warmup 5 > gpurun_out/${tag}_pmc_fetch.txt
@@ -39,10 +42,30 @@ done
 TRLDA_BENCH_FORCE_DIST=1 python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-update-rates --global-batch 1600 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_forced_dist_world1_b1600.json
 for w in 2 4 8; do
   python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-update-rates --virtual-world $w 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_virtual_world${w}.json
+  python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-update-rates --virtual-world $w --whole-stats 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_virtual_world${w}_whole_stats.json
 done
 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_virtual8_prof -o v8 --output-format csv -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-update-rates --virtual-world 8 > /dev/null 2>&1
 cp $(find gpurun_out/${tag}_virtual8_prof -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_virtual_world8_kernel_stats.csv
 bash tools/stamps.sh > gpurun_out/${tag}_stamps_reg.txt 2>&1
+# round 4: where a trust-region iteration's time goes (durations back to back, no idle gaps), the
+# merged launch from the inside, and the HIP-graph experiment
+for mgd in 1 0; do
+  rm -rf gpurun_out/${tag}_tl; mkdir -p gpurun_out/${tag}_tl
+  TRLDA_MERGED=$mgd rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${tag}_tl -- python3 tools/update_rate.py --configs small --modes fused > /dev/null 2>&1
+  python3 tools/timeline.py gpurun_out/${tag}_tl --dump 26 > gpurun_out/${tag}_timeline_update_merged${mgd}.txt 2>&1
+done
+rm -rf gpurun_out/${tag}_tl; mkdir -p gpurun_out/${tag}_tl
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${tag}_tl -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-update-rates --headline-only > /dev/null 2>&1
+python3 tools/timeline.py gpurun_out/${tag}_tl --dump 12 > gpurun_out/${tag}_timeline_bench.txt 2>&1
+rm -rf gpurun_out/${tag}_tl
+(python3 tools/merged_stamps.py; python3 tools/merged_stamps.py --update) 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_merged_stamps.txt
+python3 tools/graph_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_graph_probe.txt
+TRLDA_SPLIT_LISTS=0 bash tools/sweep_configs.sh > gpurun_out/${tag}_configs_lists_unsplit.txt 2>&1
+for mgd in 2 0; do
+  TRLDA_MERGED=$mgd python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-update-rates --headline-only 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_merged_level${mgd}.json
+done
+TRLDA_MERGED=0 python3 tools/update_rate.py --configs small,c3 --modes fused > gpurun_out/${tag}_update_rates_unmerged.txt 2>&1
+hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probes/anyorder_probe.hip -o tools/probes/anyorder_probe 2>/dev/null && tools/probes/anyorder_probe > gpurun_out/${tag}_anyorder_probe.txt 2>&1
 # document lengths: the cliffs between the variants, the reference's own test_speed workload,
 # the heavy-tailed and the uniform bench workloads (with their parity legs)
 python3 tools/length_sweep.py > gpurun_out/${tag}_length_sweep.txt 2>&1
@@ -51,10 +74,6 @@ for a in "--lengths lognormal" "--uniform"; do
   python3 bench.py --steps 100 --warmup 10 --parity-only --no-update-rates $a 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_$(echo $a | tr -d ' -').json
 done
 hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probes/xcu_probe.hip -o tools/probes/xcu_probe 2>/dev/null && tools/probes/xcu_probe > gpurun_out/${tag}_xcu_probe.txt 2>&1
-if [ -d _r01 ]; then
-  python3 tools/update_rate.py --root _r01 --configs small,c5a,c5b,c4 --modes fused > gpurun_out/r01_update_rates.txt 2>&1
-  python3 tools/host_rate.py --root _r01 > gpurun_out/r01_host_rates_rerun.txt 2>&1
-fi
 for cfg in small c5a c5b c4; do
   tools/prof_update.sh ${tag}_${cfg}_fused $cfg fused > /dev/null 2>&1
 done
