@@ -161,8 +161,9 @@ int trlda_batch_max_doc_len(const trlda_batch *batch);
  * words that is. */
 int trlda_batch_long_word_len(const trlda_batch *batch);
 int trlda_batch_num_long_words(const trlda_batch *batch);
-/* Lists of more than 1024 entries (a word present in most documents of a large batch) are cut into
- * segments of at most 1024: a segment is a task for a whole workgroup of the statistics kernels, and
+/* Lists of more than 256 .. 1024 entries (a word present in most documents of a large batch; the
+ * length is chosen per batch so that there are about a thousand tasks) are cut into segments of at
+ * most that many: a segment is a task for a whole workgroup of the statistics kernels, and
  * the workgroup that finishes a word's last segment adds the segments' sums up in segment order
  * (csrc/estep_kernels.h, VeryLongArgs) -- the kernel no longer lasts as long as its longest list
  * (K = 200, 12 500 documents: one list of 12 500 entries kept a workgroup busy for ~100 us).  The

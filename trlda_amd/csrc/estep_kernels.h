@@ -1538,22 +1538,25 @@ constexpr int kLongWordsTarget = 512;
 // VERY long lists (round 4).  A word present in all 12 500 documents of a BatchLDA shard kept ONE
 // workgroup busy for ~100 us -- 98 passes of 16 entries per wave, each a dependent gather -- while
 // the mean wavefront of the launch lived a tenth of that (profiles/r03_stats_kernel_notes.txt); at
-// 1600 documents the longest list alone set the kernel's 24 us.  A list of more than kVeryLong
-// entries is therefore cut into SEGMENTS of at most kVeryLong: a segment is a task for a whole
+// 1600 documents the longest list alone set the kernel's 24 us.  A list of more than seg_len
+// entries is therefore cut into SEGMENTS of at most seg_len: a segment is a task for a whole
 // workgroup (a pass or two per wave), its K sums go to a row of `seg_partial`, and the workgroup
 // that finishes a word's LAST segment (a counter per word; rows stored and loaded with agent-scope
 // accesses, as in finish_partial_groups) adds the rows up in segment order and applies the
 // epilogue.  The sums and their order are fixed by the list's length alone: bitwise reproducible,
 // the same on every rank.
-#ifndef TRLDA_VERY_LONG
-#define TRLDA_VERY_LONG 1024
-#endif
-constexpr int kVeryLong = TRLDA_VERY_LONG;   // (256: a pass per wave and task -- the tasks' fixed costs,
-                                             //  ~3 us of barriers and round trips each, then outweigh what
-                                             //  they save at K = 100: 60 -> 70 us at 6400 documents)
+// The segment length is chosen per batch (trlda_batch::seg_len): the power of two between
+// kSegMin and kSegMax that makes at most about kSegTasks tasks of the entries in the lists of more than
+// kSegMin -- 256 (a pass per wave and task) where there are few such entries and the launch is a
+// handful of latencies long (1600 documents at K = 100; one rank's range of it: 7.7 us), 1024 where
+// there are a million of them and a task's fixed costs (~3 us of barriers and round trips) would
+// otherwise dominate (256 everywhere: K = 100 / 6400 documents 60 -> 70 us; 1024 everywhere: one
+// rank of eight at 8 x 200 documents 7.7 -> 15 us).
+constexpr int kSegMin = 256, kSegMax = 1024, kSegTasks = 512;
 constexpr int kOneWaveMax = 256;             // long_len never exceeds this: a wave walks 16 entries per pass
 struct VeryLongArgs {
     int G_seg;                    // workgroups walking the segment tasks (0: none)
+    int seg_len;                  // lists of more than this many entries are cut into segments
     int n_tasks, n_words;         // of this launch (a rank's slice, data-parallel)
     const int4 *task;             // (word index j, segment, first entry, entries), by (j, segment)
     const int4 *word;             // j -> (word id, first task = first row of seg_partial, segments, 0)
@@ -1918,7 +1921,7 @@ __global__ __launch_bounds__(T, EMIT ? (T <= 512 ? 6 : 8) : 1) void sstats_updat
         const int w = long_words[lw];
         const int base = __builtin_amdgcn_readfirstlane(wptr[w]);
         const int L = __builtin_amdgcn_readfirstlane(wptr[w + 1]) - base;
-        if (vl.G_seg > 0 && L > kVeryLong)
+        if (vl.G_seg > 0 && L > vl.seg_len)
             continue;                                // cut into segments (above)
         const int chunk = (L + W - 1) / W;
         const int c0 = __builtin_amdgcn_readfirstlane(min(L, wid * chunk));
@@ -2186,7 +2189,7 @@ __global__ __launch_bounds__(T, EMIT ? (T <= 512 ? 6 : 8) : 1) void sstats_updat
         const int w = long_words[lw];
         const int base = __builtin_amdgcn_readfirstlane(wptr[w]);
         const int L = __builtin_amdgcn_readfirstlane(wptr[w + 1]) - base;
-        if (vl.G_seg > 0 && L > kVeryLong)
+        if (vl.G_seg > 0 && L > vl.seg_len)
             continue;                                // cut into segments (above)
         const int chunk = (L + W - 1) / W;
         const int c0 = __builtin_amdgcn_readfirstlane(min(L, wid * chunk));

@@ -188,11 +188,11 @@ struct trlda_batch {
     // decreasing length (a wave's words of one round are then about equally long)
     int32_t *mdesc = nullptr;       // n_active x 4
     int n_short = 0;
-    // very long lists (estep_kernels.h, VeryLongArgs): words of more than kVeryLong entries, by word
+    // very long lists (estep_kernels.h, VeryLongArgs): words of more than seg_len entries, by word
     // id -- (word, first task, segments, 0) -- and their segment tasks (word index, segment, first
     // entry, entries)
     int32_t *vl_word = nullptr, *vl_task = nullptr;
-    int n_vl = 0, n_vl_tasks = 0;
+    int n_vl = 0, n_vl_tasks = 0, seg_len = 256;
     std::vector<int32_t> vl_host;   // host copy of the very long words' ids (ranks' slices)
     std::vector<int32_t> vl_first;  // ... and of their first tasks, + the total (n_vl + 1)
     std::vector<int32_t> ws_vcuts;  // word-sharded M-step: cut points in the very long words
@@ -863,6 +863,7 @@ int launch_sstats_update(trlda_model *m, const trlda_batch *b, EstepOut &out)
         vl.n_words = j_n;
         vl.n_tasks = b->vl_first[(size_t)(j_lo + j_n)] - vl.t0;
         vl.G_seg = std::min(kUpdSegBlocks, vl.n_tasks);
+        vl.seg_len = b->seg_len;
         vl.task = reinterpret_cast<const int4 *>(b->vl_task);
         vl.word = reinterpret_cast<const int4 *>(b->vl_word);
         int rc0 = grow(&m->seg_partial, &m->cap_seg_partial, std::max<size_t>((size_t)vl.n_tasks * K, 1));
@@ -1090,7 +1091,7 @@ int dp_prepare(trlda_model *m, const trlda_batch *b, DpContext *dp)
                 const int len = b->wptr_host[(size_t)w + 1] - b->wptr_host[(size_t)w];
                 na += len > 0;
                 nl += len > b->long_len;
-                nv += len > trlda::kVeryLong;
+                nv += len > b->seg_len;
                 ++w;
             }
             bb->ws_wcuts[(size_t)r] = w;
@@ -2266,12 +2267,22 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
                 n_long += wptr[(size_t)w + 1] - wptr[(size_t)w] > long_len;
         }
     }
-    int n_vl = 0, n_vl_tasks = 0;
+    // the longest lists as segment tasks (estep_kernels.h, VeryLongArgs): segment length per batch
+    int n_vl = 0, n_vl_tasks = 0, seg_len = trlda::kSegMin;
+    {
+        long long heavy = 0;
+        for (int w = 0; w < V; ++w) {
+            const int len = wptr[(size_t)w + 1] - wptr[(size_t)w];
+            heavy += len > trlda::kSegMin ? len : 0;
+        }
+        while (seg_len < trlda::kSegMax && heavy / seg_len > trlda::kSegTasks)
+            seg_len *= 2;
+    }
     for (int w = 0; w < V; ++w) {
         const int len = wptr[(size_t)w + 1] - wptr[(size_t)w];
-        if (len > trlda::kVeryLong) {
+        if (len > seg_len) {
             ++n_vl;
-            n_vl_tasks += (len + trlda::kVeryLong - 1) / trlda::kVeryLong;
+            n_vl_tasks += (len + seg_len - 1) / seg_len;
         }
     }
 
@@ -2452,14 +2463,14 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
                 longw[nl++] = w;
         }
         b->long_host.assign(longw, longw + nl);
-        // the very long lists: equal segments of at most kVeryLong entries
+        // the very long lists: equal segments of at most seg_len entries
         int32_t *vw = I(o_vlw), *vt = I(o_vlt);
         int j = 0, t = 0;
         for (int w = 0; w < V && n_vl > 0; ++w) {
             const int q0 = wptr[(size_t)w], len = wptr[(size_t)w + 1] - q0;
-            if (len <= trlda::kVeryLong)
+            if (len <= seg_len)
                 continue;
-            const int ns = (len + trlda::kVeryLong - 1) / trlda::kVeryLong;
+            const int ns = (len + seg_len - 1) / seg_len;
             const int base = len / ns, rem = len % ns;
             vw[4 * j] = w; vw[4 * j + 1] = t; vw[4 * j + 2] = ns; vw[4 * j + 3] = 0;
             b->vl_host.push_back(w);
@@ -2575,7 +2586,7 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     b->mdesc = D(o_mdesc);
     b->n_short = n_active - n_long;
     b->vl_word = D(o_vlw); b->vl_task = D(o_vlt);
-    b->n_vl = n_vl; b->n_vl_tasks = n_vl_tasks;
+    b->n_vl = n_vl; b->n_vl_tasks = n_vl_tasks; b->seg_len = seg_len;
     *out = b;
     return TRLDA_OK;
 }
