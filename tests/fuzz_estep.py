@@ -66,10 +66,14 @@ def main(argv=None):
         m._setup(V, K, alpha, .3, None, _lambda=lam)
         go, so, ito = orc.estep(lam, alpha, ip, ids, cnts, g0, max_iter, thr, nthreads=8)
         docs = CSRDocuments(ip, ids, cnts)
+        # (round 4: the statistics as workgroups of the document launch -- level 2 -- in every other
+        # pass over a case; the longest lists cut into segments or not)
         for mode in (0, 1):
             for split in (1, 0):
                 L.trlda_model_set_sstats_mode(m._handle, mode)
                 L.trlda_model_set_split_docs(m._handle, split)
+                L.trlda_model_set_merged_launch(m._handle, 2 if split else 0)
+                L.trlda_model_set_split_lists(m._handle, int((case + split) % 2))
                 g, s, it = m.update_variables(docs, latents=g0, max_iter=max_iter, threshold=thr,
                                               return_iterations=True)
                 eg = float(np.max(np.abs(g - go) / np.abs(go))) if g.size else 0.0

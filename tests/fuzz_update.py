@@ -34,7 +34,7 @@ def draw_docs(rng, B, V):
         lens.append(int(min(n, V)))
     ip = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     ids = np.concatenate([rng.permutation(V)[:n] for n in lens] + [np.zeros(0, int)]).astype(np.int32)
-    cnts = rng.randint(1, 5, size=ip[-1]).astype(np.int32)
+    cnts = rng.randint(0 if rng.rand() < .3 else 1, 5, size=ip[-1]).astype(np.int32)   # zero counts are legal
     return CSRDocuments(ip, ids, cnts), lens
 
 
@@ -81,10 +81,15 @@ def main(argv=None):
             m = online_model(K, V, lam0, D, alpha=alpha, eta=eta)
             L.trlda_model_set_fused_update(m._handle, fused)
             L.trlda_model_set_carry_rowsums(m._handle, fused and carry)
+            # (round 4: statistics inside the document launch never / for updates / always; the
+            # longest lists cut into segments or not)
+            merged, segs = int(rng.choice([0, 1, 2])), int(rng.rand() < .7)
+            L.trlda_model_set_merged_launch(m._handle, merged)
+            L.trlda_model_set_split_lists(m._handle, segs)
             lam = lam0
             shapes = []
             for call in range(3):
-                B = int(rng.choice([1, 7, 64, 200]))
+                B = int(rng.choice([1, 7, 64, 200, 224, 330]))
                 docs, lens = draw_docs(rng, B, V)
                 tr, inf = int(rng.choice([0, 1, 2, 4])), int(rng.choice([1, 5, 20]))
                 shapes.append((B, tr, inf, max(lens)))
@@ -98,7 +103,8 @@ def main(argv=None):
                     print("MISMATCH case %d call %d: rho %r vs %r" % (case, call, rho, rho_o))
                     sys.exit(1)
             err = relerr(m.lambdas, lam)
-            what = "OnlineLDA fused=%d carry=%d (B, tr, inf, longest) %s" % (fused, carry, shapes)
+            what = "OnlineLDA fused=%d carry=%d merged=%d segments=%d (B, tr, inf, longest) %s" % (
+                fused, carry, merged, segs, shapes)
         m.close()
         worst = max(worst, err)
         if not err < 1e-8:

@@ -192,6 +192,10 @@ struct trlda_batch {
     // id -- (word, first task, segments, 0) -- and their segment tasks (word index, segment, first
     // entry, entries)
     int32_t *vl_word = nullptr, *vl_task = nullptr;
+    // the same tasks ordered by where in the document range their segment lies (all words' first
+    // sixteenth, then the second ..): workgroups that run at the same time then gather rows of the
+    // same few hundred documents -- L2 hits instead of 20 MB of rows streaming through 4 MB caches
+    int32_t *vl_task_tiled = nullptr;
     int n_vl = 0, n_vl_tasks = 0, seg_len = 256;
     std::vector<int32_t> vl_host;   // host copy of the very long words' ids (ranks' slices)
     std::vector<int32_t> vl_first;  // ... and of their first tasks, + the total (n_vl + 1)
@@ -296,6 +300,7 @@ struct trlda_model {
     void *allgatherv_ctx = nullptr;
     bool word_sharding = true;          // trlda_model_set_word_sharding
     bool split_long_lists = true;       // TRLDA_SPLIT_LISTS=0: very long lists stay one workgroup's (comparisons)
+    bool tiled_tasks = true;            // TRLDA_TILED_TASKS=0: segment tasks in word order (comparisons)
     bool last_word_sharded = false;     // the last *_dp call's M-steps were word-sharded
     // direct exchange (dp_kernels.h): this process's region [2 x world x max_slot doubles |
     // kDpMaxWorld step counters], exported through hipIpc; the peers' regions mapped here
@@ -864,7 +869,9 @@ int launch_sstats_update(trlda_model *m, const trlda_batch *b, EstepOut &out)
         vl.n_tasks = b->vl_first[(size_t)(j_lo + j_n)] - vl.t0;
         vl.G_seg = std::min(kUpdSegBlocks, vl.n_tasks);
         vl.seg_len = b->seg_len;
-        vl.task = reinterpret_cast<const int4 *>(b->vl_task);
+        // (a rank's slice: its words' tasks are contiguous in the by-word order; the whole batch:
+        // the order that keeps concurrently running workgroups on the same documents)
+        vl.task = reinterpret_cast<const int4 *>(out.sliced || !m->tiled_tasks ? b->vl_task : b->vl_task_tiled);
         vl.word = reinterpret_cast<const int4 *>(b->vl_word);
         int rc0 = grow(&m->seg_partial, &m->cap_seg_partial, std::max<size_t>((size_t)vl.n_tasks * K, 1));
         if (!rc0 && (size_t)b->n_vl > m->cap_seg_counter) {
@@ -2275,7 +2282,9 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
             const int len = wptr[(size_t)w + 1] - wptr[(size_t)w];
             heavy += len > trlda::kSegMin ? len : 0;
         }
-        while (seg_len < trlda::kSegMax && heavy / seg_len > trlda::kSegTasks)
+        static const long long seg_tasks = std::getenv("TRLDA_SEG_TASKS") ? std::atoll(std::getenv("TRLDA_SEG_TASKS"))
+                                                                          : (long long)trlda::kSegTasks;
+        while (seg_len < trlda::kSegMax && heavy / seg_len > seg_tasks)
             seg_len *= 2;
     }
     for (int w = 0; w < V; ++w) {
@@ -2318,7 +2327,7 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
                  o_active = section((size_t)n_active * 4), o_long = section((size_t)n_long * 4),
                  o_flag = section((size_t)V), o_wc32 = section((size_t)V * 4),
                  o_mdesc = section((size_t)n_active * 16), o_vlw = section((size_t)n_vl * 16),
-                 o_vlt = section((size_t)n_vl_tasks * 16);
+                 o_vlt = section((size_t)n_vl_tasks * 16), o_vltt = section((size_t)n_vl_tasks * 16);
     const size_t total = off;
 
     UploadContext &u = upload_context(device);
@@ -2484,6 +2493,21 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
             ++j;
         }
         b->vl_first.push_back(t);
+        {
+            // (counting sort of the tasks by sixteenth of the list their segment starts in, stable
+            // in the word index)
+            int32_t *vtt = I(o_vltt);
+            int start[17] = {0};
+            auto bucket = [&](int q) { return std::min(15, 16 * vt[4 * q + 1] / std::max(1, vw[4 * vt[4 * q] + 2])); };
+            for (int q = 0; q < t; ++q)
+                ++start[bucket(q) + 1];
+            for (int i = 0; i < 16; ++i)
+                start[i + 1] += start[i];
+            for (int q = 0; q < t; ++q) {
+                int32_t *e = vtt + 4 * (size_t)start[bucket(q)]++;
+                e[0] = vt[4 * q]; e[1] = vt[4 * q + 1]; e[2] = vt[4 * q + 2]; e[3] = vt[4 * q + 3];
+            }
+        }
         // descriptors for the merged launch: counting sort by length, longest first, the short
         // lists (<= long_len entries) before the long ones
         int32_t *md = I(o_mdesc);
@@ -2585,7 +2609,7 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     b->cnts_nonneg = cnts_nonneg;
     b->mdesc = D(o_mdesc);
     b->n_short = n_active - n_long;
-    b->vl_word = D(o_vlw); b->vl_task = D(o_vlt);
+    b->vl_word = D(o_vlw); b->vl_task = D(o_vlt); b->vl_task_tiled = D(o_vltt);
     b->n_vl = n_vl; b->n_vl_tasks = n_vl_tasks; b->seg_len = seg_len;
     *out = b;
     return TRLDA_OK;
@@ -2704,6 +2728,8 @@ int trlda_model_create(trlda_model **out, int device, int K, int V)
         m->draw_ahead = env[0] != '0';
     if (const char *env = std::getenv("TRLDA_SPLIT_LISTS"))
         m->split_long_lists = env[0] != '0';
+    if (const char *env = std::getenv("TRLDA_TILED_TASKS"))
+        m->tiled_tasks = env[0] != '0';
     if (const char *env = std::getenv("TRLDA_MERGED"))           // 0 = statistics always a launch of their own
         m->merged_launch = std::max(0, std::min(std::atoi(env), 2));
     *out = m;
