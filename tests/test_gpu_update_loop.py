@@ -247,7 +247,9 @@ def test_fused_update_equals_plain_sequence(hip, oracle, sampler, K, V, B):
             c.close()
     for kind in ("online", "batch", "cumulative"):
         if (kind, 1) in out:
-            assert relerr(out[kind, 1], out[kind, 0]) < 1e-11, (kind, relerr(out[kind, 1], out[kind, 0]))
+            # (round 4: the fused path adds its row sums up in another order again -- merged launch,
+            # list segments: a few 1e-12 after three calls)
+            assert relerr(out[kind, 1], out[kind, 0]) < 5e-11, (kind, relerr(out[kind, 1], out[kind, 0]))
     # and the fused online trajectory against the oracle
     lam = lam0
     sampler.seed(61)

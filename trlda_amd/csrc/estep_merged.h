@@ -77,7 +77,6 @@ struct MergedArgs {
     unsigned int *c_flags;        // one per document workgroup
     unsigned int epoch;
     int n_docs;                   // document workgroups of the launch (flags to set)
-    int dbg;                      // experiments (TRLDA_MERGED_DBG): 1 helpers return at once, 2 after the wait
     unsigned long long *tstamps;  // diagnostics (TRLDA_MERGED_STAMPS=1, tools/merged_stamps.py) or nullptr:
                                   // s_memrealtime (100 MHz, one clock for the chip) of [start, flag seen,
                                   // end] per statistics workgroup, then [start, end of the document,
@@ -266,16 +265,6 @@ __device__ __forceinline__ void merged_stats(const MergedArgs &mg, int vb, doubl
     const bool k_on = 2 * lane < K;
     const int n_stat = mg.n_short + mg.n_long;
     const unsigned int seen = merged_flag_load(mg, vb);          // (requested before everything else)
-    if (mg.dbg == 1)
-        return;
-    if (mg.dbg == 2) {
-        merged_wait_docs(mg, vb, seen);
-        return;
-    }
-    if (mg.dbg == 3 && vb >= mg.n_short)
-        return;
-    if (mg.dbg == 4 && vb < mg.n_short)
-        return;
 
     // columns of the words outside the batch: zero (lda.cpp:169), written while the documents run
     if (mg.active_flag && o.sstats && !o.lambda) {   // launch-uniform

@@ -1661,8 +1661,6 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                 mg.c_flags = m->sync_flags + (size_t)trlda::kMergedMaxHelpers * trlda::kMergedFlagStride;
             }
             mg.epoch = a.epoch; mg.n_docs = n_wgs;
-            if (const char *env = std::getenv("TRLDA_MERGED_DBG"))
-                mg.dbg = std::atoi(env);
 
             {
                 static const bool want_stamps = std::getenv("TRLDA_MERGED_STAMPS") != nullptr;
