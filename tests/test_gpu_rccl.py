@@ -141,7 +141,14 @@ def check(got, want, world):
     assert relerr(got["run1_lambda"], got["run2_lambda"]) < 1e-11
     assert relerr(got["run3_lambda"], got["run4_lambda"]) < 1e-9
     assert relerr(got["run5_lambda"], got["run6_lambda"]) < 1e-11
-    assert np.array_equal(got["run8_lambda"], got["run0_lambda"])      # direct == all-gather, bitwise
+    # direct == all-gather: bitwise at one rank; beyond that the all-gather run shards the M-step by
+    # words (round 4: every rank its range of the vocabulary, lambda columns exchanged in place, the
+    # next row sums from the exchanged table) while the direct run still forms the whole mini-batch's
+    # statistics on every rank -- other row sums downstream, 1e-12
+    if world == 1:
+        assert np.array_equal(got["run8_lambda"], got["run0_lambda"])
+    else:
+        assert relerr(got["run8_lambda"], got["run0_lambda"]) < 1e-11
 
 
 def test_rccl_world_one_exercises_the_same_entry_points(hip, tmp_path):
