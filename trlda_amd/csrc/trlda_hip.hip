@@ -137,6 +137,13 @@ struct trlda_batch {
     // stream settles the first one on the spot
     hipStream_t last_stream = nullptr;
     bool last_owned = false;      // last_stream is a model's own stream (see live_own_streams)
+    // the stream `done` was last recorded on (null: never recorded).  The runtime follows an event
+    // back to the stream object that recorded it -- a wait on an event whose stream has been
+    // destroyed writes into freed host memory (tools/probes/event_stream_probe.hip; found by the
+    // round-4 fuzz run as a document count that changed under a later model) -- so an event is
+    // waited on, recorded again or recycled only while that stream exists (stream_alive)
+    hipStream_t done_on = nullptr;
+    bool done_on_owned = false;
     bool ready_seen = false;      // the upload has been seen complete: no more waits
     uint64_t id = 0;            // unique per batch (an address can be reused by a later batch)
     int device = 0;
@@ -418,6 +425,8 @@ struct UploadContext {
         void *ptr;
         size_t bytes;
         hipEvent_t done;      // last reader of the previous owner (may be null)
+        hipStream_t on = nullptr;     // the stream it was recorded on, and whether that is a model's
+        bool on_owned = false;        // own stream (purged when the model goes: purge_stream_guards)
     };
     std::vector<Blob> cache;
     size_t cached_bytes = 0;
@@ -464,20 +473,52 @@ LiveStreams &live_own_streams()
     return *all;
 }
 
-// `done` <- everything the batch's last stream has been given so far
-void batch_settle(trlda_batch *b)
+// a model's own stream that has been destroyed must not be reached through an event it recorded
+bool stream_alive(hipStream_t s, bool owned)
+{
+    if (!owned || !s)
+        return true;                                 // the host's stream: alive by contract
+    LiveStreams &ls = live_own_streams();
+    std::lock_guard<std::mutex> lock(ls.mu);
+    return ls.own.count(s) != 0;
+}
+
+// `done` <- everything the batch's last stream has been given so far.  True when `done` now holds
+// a record that may be waited on (false: nothing to wait for -- never used, or the last stream is
+// gone and its work with it)
+bool batch_settle(trlda_batch *b)
 {
     if (!b->used || !b->done)
-        return;
-    if (b->last_owned && b->last_stream) {
-        LiveStreams &ls = live_own_streams();
-        std::lock_guard<std::mutex> lock(ls.mu);
-        if (!ls.own.count(b->last_stream))
-            return;                                  // stream gone, its work complete
-        (void)hipEventRecord(b->done, b->last_stream);
-        return;
+        return false;
+    if (!stream_alive(b->last_stream, b->last_owned))
+        return false;                                // stream gone, its work complete
+    if (b->done_on && !stream_alive(b->done_on, b->done_on_owned)) {
+        // the event's previous record sits on a stream that no longer exists: a fresh event
+        // (the old one is dropped, not destroyed: neither call is known to stay off that stream)
+        hipEvent_t fresh = nullptr;
+        if (hipEventCreateWithFlags(&fresh, hipEventDisableTiming) != hipSuccess)
+            return false;
+        b->done = fresh;
+        b->done_on = nullptr;
     }
-    (void)hipEventRecord(b->done, b->last_stream);   // the host's stream: alive by contract
+    (void)hipEventRecord(b->done, b->last_stream);
+    b->done_on = b->last_stream;
+    b->done_on_owned = b->last_owned;
+    return true;
+}
+
+// a model's own stream is about to go (synchronised by the caller): drop the guards it recorded
+void purge_stream_guards(int device, hipStream_t s)
+{
+    UploadContext &u = upload_context(device);
+    std::lock_guard<std::mutex> lock(u.mu);
+    for (UploadContext::Blob &c : u.cache)
+        if (c.done && c.on_owned && c.on == s) {
+            (void)hipEventDestroy(c.done);           // while its stream still exists
+            c.done = nullptr;
+            c.on = nullptr;
+            c.on_owned = false;
+        }
 }
 
 // every reader of a batch: wait for its upload, and leave a mark behind
@@ -498,8 +539,8 @@ int batch_end(trlda_model *m, const trlda_batch *b)
         if (bb->used && bb->last_stream != m->stream) {
             // second stream: it continues behind the first one's readers, so that one record
             // on it (at destruction) covers both
-            batch_settle(bb);
-            HIP_TRY(hipStreamWaitEvent(m->stream, bb->done, 0));
+            if (batch_settle(bb))
+                HIP_TRY(hipStreamWaitEvent(m->stream, bb->done, 0));
         }
         bb->last_stream = m->stream;
         bb->last_owned = m->stream == m->own_stream;
@@ -2552,7 +2593,7 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
             const UploadContext::Blob &c = u.cache[i];
             if (c.bytes < total || c.bytes > 4 * total + ((size_t)1 << 20))
                 continue;
-            if (pass == 0 && c.done && hipEventQuery(c.done) != hipSuccess)
+            if (pass == 0 && c.done && stream_alive(c.on, c.on_owned) && hipEventQuery(c.done) != hipSuccess)
                 continue;
             if (pass == 1 && u.cache.size() < kBlobCacheMax / 2)
                 break;                               // rather a new allocation than a wait
@@ -2575,10 +2616,10 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     b->blob = blob.ptr;
     b->blob_bytes = blob.bytes;
     hipError_t err = hipSuccess;
-    if (blob.done) {                                 // the previous owner's last reader
+    if (blob.done && stream_alive(blob.on, blob.on_owned)) {   // the previous owner's last reader
         err = hipStreamWaitEvent(u.stream, blob.done, 0);
         u.events.push_back(blob.done);
-    }
+    }                                                // (else: that stream and its work are gone; the event is dropped)
     if (err == hipSuccess)
         err = hipMemcpyAsync(b->blob, st.host, total, hipMemcpyHostToDevice, u.stream);
     if (err == hipSuccess)
@@ -2626,13 +2667,24 @@ int trlda_batch_destroy(trlda_batch *b)
         std::lock_guard<std::mutex> lock(u.mu);
         // recycle: whoever takes the allocation next waits (on the upload stream) for this
         // batch's last reader; a batch nobody read is guarded by its own upload
-        batch_settle(b);
-        hipEvent_t guard = b->used ? b->done : b->ready;
+        const bool settled = batch_settle(b);
+        // the guard: the last reader's record; a batch nobody read is guarded by its own upload
+        // (`ready`, recorded on the upload stream, which lives as long as the process); a batch
+        // whose last stream is gone needs none -- and its `done` event, if that stream recorded
+        // it, is dropped rather than recycled
+        hipEvent_t guard = b->used ? (settled ? b->done : nullptr) : b->ready;
         hipEvent_t spare = b->used ? b->ready : b->done;
         if (spare)
             u.events.push_back(spare);
+        if (b->used && !settled && b->done && stream_alive(b->done_on, b->done_on_owned))
+            u.events.push_back(b->done);             // never recorded, or on a stream that exists
+        UploadContext::Blob blob{b->blob, b->blob_bytes, guard};
+        if (b->used && settled) {
+            blob.on = b->done_on;
+            blob.on_owned = b->done_on_owned;
+        }
         if (u.cache.size() < kBlobCacheMax && u.cached_bytes + b->blob_bytes <= kBlobCacheBytes) {
-            u.cache.push_back(UploadContext::Blob{b->blob, b->blob_bytes, guard});
+            u.cache.push_back(blob);
             u.cached_bytes += b->blob_bytes;
         } else {
             (void)hipFree(b->blob);                  // waits for the device: nothing reads it after
@@ -2761,11 +2813,12 @@ int trlda_model_destroy(trlda_model *m)
         // a gamma0 drawn ahead that nobody will use: the host stream goes back to its turn
         if (m->spec.valid)
             trlda_host::rng_speculation_cancel_if(m->spec.token);
+        // (events go before the streams that recorded them: batch_settle's note)
         if (m->draw_stream) {
             (void)hipStreamSynchronize(m->draw_stream);
-            (void)hipStreamDestroy(m->draw_stream);
             (void)hipEventDestroy(m->ev_main);
             (void)hipEventDestroy(m->ev_draw);
+            (void)hipStreamDestroy(m->draw_stream);
         }
         (void)hipFree(m->gspec[0]); (void)hipFree(m->gspec[1]);
         (void)hipFree(m->rng_win2); (void)hipFree(m->rng_vbuf2);
@@ -2781,9 +2834,12 @@ int trlda_model_destroy(trlda_model *m)
             (void)hipFree(m->eeb_pp[i]); (void)hipFree(m->partial_pp[i]); (void)hipFree(m->scale_pp[i]);
         }
         if (m->own_stream) {
+            (void)hipStreamSynchronize(m->own_stream);
+            // the recycled batch allocations whose last reader ran on this stream: their work is
+            // complete, and their guard events must not outlive the stream (batch_settle's note)
+            purge_stream_guards(m->device, m->own_stream);
             LiveStreams &ls = live_own_streams();
             std::lock_guard<std::mutex> lock(ls.mu);
-            (void)hipStreamSynchronize(m->own_stream);
             ls.own.erase(m->own_stream);
             (void)hipStreamDestroy(m->own_stream);
         }
@@ -4548,6 +4604,24 @@ extern "C" int trlda_debug_merged_stamps(trlda_model *m, unsigned long long *hos
         return TRLDA_ERR_ARG;
     HIP_TRY(hipStreamSynchronize(m->stream));
     HIP_TRY(hipMemcpy(host, m->merged_stamps, 3 * 1024 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return TRLDA_OK;
+}
+
+// diagnostics: copy out one of the model's intermediate buffers of the last E-step
+//   0  exp(psi(lambda)) / exp E[log beta] as the last call's kernels read it (K x V)
+//   1  the documents' exp E[log theta] rows (count values)
+//   2  cnt / phinorm per entry in word order (count values)
+//   3  the sstats buffer of the host entry points (K x V)
+extern "C" int trlda_debug_peek(trlda_model *m, int which, double *host, size_t count)
+{
+    if (!m || !host)
+        return TRLDA_ERR_ARG;
+    const double *src = which == 0 ? m->eeb_cur : which == 1 ? m->epg : which == 2 ? m->tw_word
+                        : which == 3 ? m->sstats : nullptr;
+    if (!src)
+        return TRLDA_ERR_ARG;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(hipMemcpy(host, src, count * sizeof(double), hipMemcpyDeviceToHost));
     return TRLDA_OK;
 }
 
