@@ -40,6 +40,15 @@ def test_a_batch_after_a_closed_model_leaves_the_callers_arrays_alone(hip):
     assert worst_g < 1e-8 and worst_s < 1e-7
 
 
+def test_models_and_batches_with_overlapping_lifetimes(hip):
+    """tests/fuzz_lifecycle.py: up to three models alive at once on streams of their own, torch's
+    current stream or a torch side stream, resident batches that outlive the model that last read
+    them, E-steps and update calls interleaved -- every result against the oracle, every host array
+    handed over (and blocks of freshly taken host memory after each closed model) unchanged."""
+    import fuzz_lifecycle
+    assert fuzz_lifecycle.main(["--steps", "120", "--seed", "2"]) < 1e-8
+
+
 def test_random_update_calls_agree_with_the_oracle(hip):
     import fuzz_update
     assert fuzz_update.main(["--cases", "8", "--seed", "5"]) < 1e-8
