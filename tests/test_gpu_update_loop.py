@@ -445,6 +445,32 @@ def test_device_gamma_draw_is_the_libc_stream(hip, rows, cols, passes):
     hip.trlda_dev_free(0, dev)
 
 
+@pytest.mark.parametrize("rows,cols,lo,hi,passes", [(100, 200, 0, 200, 100), (7, 3, 0, 3, 100), (13, 77, 0, 77, 31),
+                                                     (37, 53, 7, 30, 100), (37, 53, 30, 53, 128), (100, 224, 0, 224, 100)])
+def test_device_gamma_draw_summed_where_it_is_formed(hip, rows, cols, lo, hi, passes, monkeypatch):
+    """draw_sum_kernel (logarithms summed in the workgroup that forms them, windows in segment-major
+    order) against draw_log_kernel + gamma_sum_kernel: the same values subtracted in the same order --
+    bitwise equal, whole matrices and a data-parallel rank's columns, element counts that are and are
+    not multiples of the segment length."""
+    import trlda_amd
+    from trlda_amd import _ffi
+    m = online_model(4, 16, random_lambda(4, 16, 1), 10)
+    n = rows * (hi - lo)
+    dev = _ffi.vp()
+    _ffi.check(hip.trlda_dev_alloc(0, n * 8, C.byref(dev)))
+    got = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("TRLDA_RNG_FUSED", fused)
+        trlda_amd.seed(31)
+        _ffi.check(hip.trlda_model_sample_gamma_cols(m._handle, rows, cols, lo, hi, passes, 100., dev))
+        _ffi.check(hip.trlda_model_synchronize(m._handle))
+        got[fused] = np.empty((rows, hi - lo), order="F")
+        _ffi.check(hip.trlda_dev_download(0, got[fused].ctypes.data, dev, n * 8))
+    hip.trlda_dev_free(0, dev)
+    assert np.array_equal(got["0"], got["1"])
+    assert np.isfinite(got["1"]).all() and (got["1"] > 0).all()
+
+
 def test_device_draw_keeps_the_early_exits_at_baseline_size(hip):
     """The device's gamma0 can differ from glibc's in the last bit of a logarithm (<= 2e-15): at
     BASELINE's headline size that must not flip a document's early exit (lda.cpp:202-203) --

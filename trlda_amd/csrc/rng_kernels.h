@@ -148,10 +148,10 @@ __global__ __launch_bounds__(T) void window_level_coop_kernel(long long S, long 
 // products become ~3 (7 800 products) + ~3 (the walk).
 constexpr int kRngWalk = 8;           // fine windows per coarse window
 
-template <int T, int L>
+template <int T, int L, bool SEGMENT_MAJOR = false>      // (segment-major: for draw_sum_kernel below)
 __global__ __launch_bounds__(T) void window_walk_kernel(long long S, long long Sc,
                                                         const uint32_t *__restrict__ cwin /* 31 x Sc */,
-                                                        uint32_t *__restrict__ win /* 31 x S */)
+                                                        uint32_t *__restrict__ win /* 31 x S, or S x 32 */)
 {
     const long long c = (long long)blockIdx.x * T + threadIdx.x;
     if (c >= Sc)
@@ -165,9 +165,21 @@ __global__ __launch_bounds__(T) void window_walk_kernel(long long S, long long S
         const int rot = (g * L) % 31;                // register of the oldest word now
         const long long s = c * kRngWalk + g;
         if (s < S) {
+            // (segment-major: a window is one 128-byte line.  Handing the words out through an LDS
+            // tile so that a store instruction writes two whole lines instead of one word into each
+            // of 64 was measured: 19.0 us against 8.0 -- 256 LDS round trips in a row; the stores
+            // straight from the registers go out back to back)
+            if constexpr (SEGMENT_MAJOR) {
+                uint4 *line = reinterpret_cast<uint4 *>(win + (size_t)s * 32);   // eight 16-byte stores
 #pragma unroll
-            for (int j = 0; j < 31; ++j)
-                win[(size_t)j * S + s] = r[(j + rot) % 31];
+                for (int j = 0; j < 32; j += 4)
+                    line[j / 4] = make_uint4(r[(j + rot) % 31], r[(j + 1 + rot) % 31], r[(j + 2 + rot) % 31],
+                                             j + 3 < 31 ? r[(j + 3 + rot) % 31] : 0u);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 31; ++j)
+                    win[(size_t)j * S + s] = r[(j + rot) % 31];
+            }
         }
         if (g + 1 < kRngWalk) {
 #pragma unroll
@@ -238,6 +250,81 @@ __global__ __launch_bounds__(T) void draw_log_kernel(long long S, long long seg_
             if (src_on && pos >= pos_lo && pos < pos_hi)
                 vbuf[pos - pos_lo] = wave_tile[src * 9 + o];
         }
+    }
+}
+
+// draw_log_kernel and gamma_sum_kernel in one (round 4), for requests of at most kRngFusedPasses
+// passes whose fine windows come from the walk: a workgroup owns 32 consecutive ELEMENTS and all
+// their passes.  Pass p of element i is draw p * total + i, so the workgroup needs, of every pass, the
+// 32 draws from p * total + i0 on: those of one segment when that position is a multiple of the
+// segment length, of two otherwise -- thread (h, p) walks segment h of pass p in full (a segment's
+// draws come one after the other) and leaves log|u| of the draws that are the workgroup's in an LDS
+// tile; 32 lanes then subtract their element's passes in pass order and divide, as
+// gamma_sum_kernel does: the same values in the same order, bit for bit, without the round trip
+// of passes x total logarithms through memory and without the launch.
+// Windows in segment-major order here (win[s * 32 + j]: a thread's 31 words are one 124-byte run;
+// threads of a wave are total / 32 segments apart).
+constexpr int kRngFusedPasses = 128;
+
+// The launch has kRngFusedPasses threads per workgroup when every pass's share of a chunk is ONE
+// segment (total and e_lo multiples of the segment length), twice that otherwise; LDS (dynamic):
+// 31 words of generator state per thread and the passes x 33 tile -- 42 kB at 100 passes, three
+// workgroups per CU, so that the ~625 workgroups of a 200-document mini-batch are resident at once
+// (a thread's 32 draws are ~4000 instructions one after the other: a second round doubles the launch).
+template <int L>
+__global__ __launch_bounds__(2 * kRngFusedPasses) void draw_sum_kernel(
+    long long S, long long total, long long e_lo, long long e_hi, int passes, double divisor,
+    const uint32_t *__restrict__ win /* S x 32 */, double *__restrict__ out)
+{
+    static_assert(L == 32, "an element chunk is one segment long");
+    extern __shared__ __attribute__((aligned(16))) double draw_sum_lds[];
+    const int T = (int)blockDim.x;                   // kRngFusedPasses or twice that
+    double *vals = draw_sum_lds;                     // [pass][element of the chunk], rows padded to 33
+    uint32_t *x = reinterpret_cast<uint32_t *>(vals + (size_t)passes * 33);
+    const int p = threadIdx.x & (kRngFusedPasses - 1), h = threadIdx.x / kRngFusedPasses;
+    const long long i0 = e_lo + (long long)blockIdx.x * L;       // first element of the chunk
+    const int n_e = (int)min((long long)L, e_hi - i0);           // its elements
+    const long long pos0 = (long long)p * total + i0;            // pass p's first draw of the chunk
+    const long long s = pos0 / L + h;
+    // draws [s L, s L + L) against [pos0, pos0 + n_e)
+    const int e_first = (int)(s * L - pos0);                     // chunk element of the segment's draw 0
+    const bool on = p < passes && s < S && e_first < n_e && e_first + L > 0;
+    if (__ballot(on) == 0) {
+        // (nothing in this wave: it still meets the others at the barrier below)
+    } else {
+        const uint32_t *w = win + (size_t)(on ? s : 0) * 32;
+#pragma unroll
+        for (int j = 0; j < 31; ++j)
+            x[j * T + threadIdx.x] = on ? w[j] : 0u;
+        int f = 0, b = 28;
+#pragma unroll 8
+        for (int q = 0; q < L; ++q) {
+            const uint32_t v = x[f * T + threadIdx.x] + x[b * T + threadIdx.x];
+            x[f * T + threadIdx.x] = v;
+            f = f == 30 ? 0 : f + 1;
+            b = b == 30 ? 0 : b + 1;
+            const double u = -1.0 + 2.0 * (double)(v >> 1) / (double)2147483647;   // as draw_log_kernel
+            const int e = e_first + q;
+            if (on && e >= 0 && e < n_e)
+                vals[p * 33 + e] = log_normal(fabs(u));
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < n_e) {
+        double acc = 0.0;
+        int q0 = 0;
+        for (; q0 + 20 <= passes; q0 += 20) {        // (in gamma_sum_kernel's order)
+            double v[20];
+#pragma unroll
+            for (int q = 0; q < 20; ++q)
+                v[q] = vals[(q0 + q) * 33 + threadIdx.x];
+#pragma unroll
+            for (int q = 0; q < 20; ++q)
+                acc -= v[q];
+        }
+        for (; q0 < passes; ++q0)
+            acc -= vals[q0 * 33 + threadIdx.x];
+        out[i0 - e_lo + threadIdx.x] = divisor != 1.0 ? acc / divisor : acc;
     }
 }
 

@@ -2119,13 +2119,19 @@ int sample_gamma_on_device(trlda_model *m, long long total, int passes, double d
     const long long Sm = walk ? (S + trlda::kRngWalk - 1) / trlda::kRngWalk : S;
     const uint32_t *mats = nullptr;
     int rc = rng_device_matrices(m->device, Lm, &mats);
-    if (!rc) rc = grow(&win, &cap_win, (size_t)31 * (size_t)S + (walk ? (size_t)31 * (size_t)Sm : 0));
     // log|u| of a group of passes: at most ~1 GB at a time
     const long long group = std::max<long long>(1, std::min<long long>(passes, ((long long)1 << 27) / total));
-    if (!rc) rc = grow(&vbuf, &cap_vbuf, (size_t)group * (size_t)total);
+    // small requests (a mini-batch's gamma0): the logarithms are summed where they are formed
+    // (rng_kernels.h, draw_sum_kernel), fine windows in segment-major order
+    const char *fused_env = std::getenv("TRLDA_RNG_FUSED");      // (read per call: the tests switch it)
+    const bool fused_off = fused_env && fused_env[0] == '0';
+    const bool fused = !fused_off && walk && L == trlda::kRngSegmentTiny && passes <= trlda::kRngFusedPasses &&
+                       group == passes && e_hi > e_lo;
+    if (!rc) rc = grow(&win, &cap_win, (size_t)(fused ? 32 : 31) * (size_t)S + (walk ? (size_t)31 * (size_t)Sm : 0));
+    if (!rc && !fused) rc = grow(&vbuf, &cap_vbuf, (size_t)group * (size_t)total);
     if (rc)
         return rc;
-    uint32_t *mwin = walk ? win + (size_t)31 * (size_t)S : win;  // where the matrix level writes
+    uint32_t *mwin = walk ? win + (size_t)(fused ? 32 : 31) * (size_t)S : win;  // where the matrix level writes
     RngSeedWindow w0;
     trlda_host::rng_current_window(w0.w);
     long long unit = 1;
@@ -2140,8 +2146,11 @@ int sample_gamma_on_device(trlda_model *m, long long total, int passes, double d
         // few windows: the first three levels (4096 windows) straight from the seed window in one
         // launch, the levels above with one matrix-vector product per window each
         const uint32_t *mats_t = mats + (size_t)trlda::kRngLevels * 15 * 961;
-        const int direct = std::min(levels, 3);
-        const long long S0 = std::min<long long>(Sm, 4096);
+        // (up to 16 384 windows: every level in that launch -- a window past the first 4096 costs
+        // four products instead of one, and the launch of its own that the fourth level took goes)
+        const bool all_direct = Sm <= 16384;
+        const int direct = all_direct ? levels : std::min(levels, 3);
+        const long long S0 = all_direct ? Sm : std::min<long long>(Sm, 4096);
         hipLaunchKernelGGL(trlda::window_direct_kernel<T>, dim3((unsigned)((S0 * 32 + T - 1) / T)), dim3(T),
                            0, stream, Sm, S0, direct, w0, mats_t, mwin);
         unit = 4096;
@@ -2164,14 +2173,25 @@ int sample_gamma_on_device(trlda_model *m, long long total, int passes, double d
     if (walk) {
         constexpr int TW = 64;                       // few threads, long walks: spread them out
         const dim3 wgrid((unsigned)((Sm + TW - 1) / TW));
-        if (L == trlda::kRngSegmentTiny)
+        if (fused)
+            hipLaunchKernelGGL((trlda::window_walk_kernel<TW, trlda::kRngSegmentTiny, true>), wgrid, dim3(TW), 0,
+                               stream, S, Sm, mwin, win);
+        else if (L == trlda::kRngSegmentTiny)
             hipLaunchKernelGGL((trlda::window_walk_kernel<TW, trlda::kRngSegmentTiny>), wgrid, dim3(TW), 0,
                                stream, S, Sm, mwin, win);
         else
             hipLaunchKernelGGL((trlda::window_walk_kernel<TW, trlda::kRngSegmentSmall>), wgrid, dim3(TW), 0,
                                stream, S, Sm, mwin, win);
     }
-    for (long long p0 = 0; p0 < passes; p0 += group) {
+    if (fused) {
+        const long long chunks = (e_hi - e_lo + trlda::kRngSegmentTiny - 1) / trlda::kRngSegmentTiny;
+        const bool one_segment = total % trlda::kRngSegmentTiny == 0 && e_lo % trlda::kRngSegmentTiny == 0;
+        const int threads = (one_segment ? 1 : 2) * trlda::kRngFusedPasses;
+        const size_t lds = (size_t)passes * 33 * sizeof(double) + (size_t)31 * threads * sizeof(uint32_t);
+        hipLaunchKernelGGL((trlda::draw_sum_kernel<trlda::kRngSegmentTiny>), dim3((unsigned)chunks),
+                           dim3(threads), lds, stream, S, total, e_lo, e_hi, passes, divisor, win, out_dev);
+    }
+    for (long long p0 = 0; !fused && p0 < passes; p0 += group) {
         const long long p1 = std::min<long long>(passes, p0 + group);
         const long long pos_lo = p0 * total, pos_hi = p1 * total;
         const long long seg_lo = pos_lo / L, seg_hi = (pos_hi + L - 1) / L;
