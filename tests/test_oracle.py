@@ -219,3 +219,20 @@ def test_lower_bound_restatement(oracle):
         assert 0 < abs(fixed - ref) < 1e-3 * abs(ref)     # the indexing matters, a little
     assert abs(float(f["elbo_oracle"]) - float(f["elbo_hoffman"])) < 1e-9 * abs(float(f["elbo_hoffman"]))
 
+
+
+def test_division_by_rand_max_is_exact(tmp_path):
+    """The device draws form u = -1 + 2 rand() / RAND_MAX with three instructions instead of the IEEE
+    division's dozen (trlda_amd/csrc/rng_kernels.h, unit_draw): a product with the rounded reciprocal
+    and one refinement.  tools/probes/div_check.c compares that with the division for every one of
+    the 2^31 possible numerators."""
+    import os
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "probes", "div_check.c")
+    exe = str(tmp_path / "div_check")
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", "-march=native", "-o", exe, src, "-lm"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "mismatches: 0 of 2147483648" in out.stdout, out.stdout + out.stderr

@@ -15,6 +15,32 @@
 
 namespace trlda {
 
+// d = a b + c as the three-address instruction, whatever the register allocator thinks: left to
+// itself the compiler forms Horner steps as v_fmac_f64 (d += a b) with a v_mov_b64 of the
+// coefficient in front of each -- 15 moves in the exp(psi) stage of the document kernels, whose
+// waves are bound by their instruction count.  fma3s: the addend from a scalar
+// register pair (a literal coefficient: no vector register held for it).
+__device__ __forceinline__ double fma3(double a, double b, double c)
+{
+#ifdef TRLDA_NO_FMA3
+    return fma(a, b, c);
+#else
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+#endif
+}
+__device__ __forceinline__ double fma3s(double a, double b, double c)
+{
+#ifdef TRLDA_NO_FMA3
+    return fma(a, b, c);
+#else
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+#endif
+}
+
 __device__ __forceinline__ double psi_series(double z)
 {
     // polevl(z, A, 6), src/digamma.cpp:96-110 (coefficients :44-52), evaluated pairwise
@@ -59,15 +85,16 @@ __device__ __forceinline__ double log_normal(double s)
     const double u = f * rcp_pos<true>(2.0 + f);
     const double z = u * u;
     const double z2 = z * z, z4 = z2 * z2, z8 = z4 * z4;
-    const double p01 = fma(2.0 / 3.0, z, 2.0);
-    const double p23 = fma(2.0 / 7.0, z, 2.0 / 5.0);
-    const double p45 = fma(2.0 / 11.0, z, 2.0 / 9.0);
-    const double p67 = fma(2.0 / 15.0, z, 2.0 / 13.0);
-    const double p89 = fma(2.0 / 19.0, z, 2.0 / 17.0);
-    const double q0 = fma(p23, z2, p01);
-    const double q1 = fma(p67, z2, p45);
-    const double q2 = fma(2.0 / 21.0, z2, p89);
-    const double poly = fma(q2, z8, fma(q1, z4, q0));
+    // (three-address steps, the addend from a scalar register: no coefficient moves -- fma3s above)
+    const double p01 = fma3s(2.0 / 3.0, z, 2.0);
+    const double p23 = fma3s(2.0 / 7.0, z, 2.0 / 5.0);
+    const double p45 = fma3s(2.0 / 11.0, z, 2.0 / 9.0);
+    const double p67 = fma3s(2.0 / 15.0, z, 2.0 / 13.0);
+    const double p89 = fma3s(2.0 / 19.0, z, 2.0 / 17.0);
+    const double q0 = fma3(p23, z2, p01);
+    const double q1 = fma3(p67, z2, p45);
+    const double q2 = fma3(2.0 / 21.0, z2, p89);
+    const double poly = fma3(q2, z8, fma3(q1, z4, q0));
     const double ed = (double)e;
     return fma(ed, 6.93147180369123816490e-01, fma(u, poly, ed * 1.90821492927058770002e-10));
 }
@@ -176,6 +203,46 @@ __device__ __forceinline__ double rcp_pair(double a)
 // 1 / (P s), which also yields 1/s = P / (P s).  The stage that evaluates this is bound by
 // the instruction count of a single wave (~8.6 cycles per fp64 instruction).
 // Needs x^11 finite: callers keep x below 1e25.
+// exp(a) for a <= 0 (or NaN: some finite value -- every caller multiplies by a NaN then).  The
+// library's exp spends two compares and three selects on the overflow / underflow ends; here the
+// argument is clamped once (exp(-800) and everything below it round to 0 through v_ldexp_f64, as
+// the reference's exp(-1e290) does) and the rest is the usual reduction a = n ln2 + r,
+// |r| <= ln2 / 2, and 1 + r + r^2 q(r) with q the degree-9 Chebyshev fit of (e^r - 1 - r) / r^2
+// (fit error 1e-16 of q = 1.3e-17 of the result; within 1.5 ulp of exp over the interval).
+__device__ __forceinline__ double exp_nonpos(double a)
+{
+    a = fmax(a, -800.0);
+    const double n = rint(a * 1.44269504088896340736);
+    double r = fma(n, -6.93147180369123816490e-01, a);           // ln2 in two pieces
+    r = fma(n, -1.90821492927058770002e-10, r);
+    double p = fma3(r, 2.51003758325612340e-08, 2.76200758799833672e-07);
+    p = fma3(r, p, 2.75572684803100238e-06);
+    p = fma3(r, p, 2.48015213223686919e-05);
+    p = fma3(r, p, 1.98412698630405450e-04);
+    p = fma3(r, p, 1.38888889171967186e-03);
+    p = fma3(r, p, 8.33333333333006500e-03);
+    p = fma3(r, p, 4.16666666666241636e-02);
+    p = fma3(r, p, 1.66666666666666685e-01);
+    p = fma3(r, p, 5.00000000000000111e-01);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    return ldexp(p, (int)n);
+}
+
+// the same polynomial by Horner's rule with three-address steps, coefficients from scalar registers:
+// six instructions where the pairwise form is seven plus three moves (the stage this is for is
+// bound by its instruction count, not by the depth of the chain)
+__device__ __forceinline__ double psi_series_horner(double z)
+{
+    double p = fma3s(8.33333333333333333333E-2, z, -2.10927960927960927961E-2);
+    p = fma3s(p, z, 7.57575757575757575758E-3);
+    p = fma3s(p, z, -4.16666666666666666667E-3);
+    p = fma3s(p, z, 3.96825396825396825397E-3);
+    p = fma3s(p, z, -8.33333333333333333333E-3);
+    return fma3s(p, z, 8.33333333333333333333E-2);
+}
+
+template <bool ZERO_C = false>
 __device__ __forceinline__ double exp_psi_regular(double x, double c)
 {
     double q = x + 45.0;
@@ -202,6 +269,12 @@ __device__ __forceinline__ double exp_psi_regular(double x, double c)
     const double r = P * inv;                        // 1 / s
     const double w = (dP * s) * inv;                 // P' / P
     const double z = r * r;
+    if constexpr (ZERO_C) {
+#ifndef TRLDA_LIBRARY_EXP
+        const double yh = z * psi_series_horner(z);
+        return s * exp_nonpos(-((fma(0.5, r, yh)) + w));         // psi(x) < log(x + 10): the argument is <= 0
+#endif
+    }
     const double y = z * psi_series(z);
     return s * exp(-((fma(0.5, r, y)) + w) - c);
 }
@@ -242,7 +315,14 @@ __device__ __forceinline__ double exp_digamma_minus(double x, double c)
     return v;
 }
 
-__device__ __forceinline__ double exp_digamma(double x) { return exp_digamma_minus(x, 0.0); }
+// c = 0 (the document kernels, the fused preamble): the same with the short exponential
+__device__ __forceinline__ double exp_digamma(double x)
+{
+    const double v = exp_psi_regular<true>(x, 0.0);
+    if (__builtin_expect(!(x > 1e-290 && x < 1e25) || (x <= 10.0 && x == floor(x)), 0))
+        return exp_digamma_rare(x, 0.0);
+    return v;
+}
 
 // exp(psi(x)) for an argument that is KNOWN to be positive (or NaN) -- the lambda an M-step has
 // just formed from a positive lambda' or a positive eta and non-negative statistics, which the
@@ -263,7 +343,7 @@ __device__ __forceinline__ double exp_digamma_positive(double x)
     return x;
 #endif
     const bool tiny = x < 1e-290, big = !(x < 1e25);
-    double v = exp_psi_regular((tiny || big) ? 1.5 : x, 0.0);
+    double v = exp_psi_regular<true>((tiny || big) ? 1.5 : x, 0.0);
     v = tiny ? 0.0 : v;
     return big ? x : v;
 }

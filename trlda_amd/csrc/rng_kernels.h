@@ -41,6 +41,22 @@ constexpr long long kRngTinyDraws = (long long)1 << 22;
 constexpr int kRngLevels = 8;         // 16^8 segments: more than any table needs
 constexpr int kRngThreads = 256;
 
+// u = -1 + 2 rand() / RAND_MAX (utils.cpp:224-231) from the generator's word v (rand() = v >> 1):
+// the host's expression with its IEEE division -- which the compiler expands into a dozen
+// instructions (scale, reciprocal, refinement, fix-up) per draw.  The divisor is a constant: with
+// y = RN(1 / (2^31 - 1)), q0 = RN(x y), r = x - q0 d (exact, one fma) and q1 = RN(q0 + r y) the
+// quotient is the correctly rounded one for EVERY x = 2 k, k < 2^31 -- checked exhaustively
+// (tools/probes/div_check.c, tests/test_oracle.py::test_division_by_rand_max_is_exact) -- so the
+// same u, bit for bit, in three instructions.
+__device__ __forceinline__ double unit_draw(uint32_t v)
+{
+    const double d = 2147483647.0, y = 0x1.00000002p-31;        // y = RN(1 / d)
+    const double x = 2.0 * (double)(v >> 1);
+    const double q0 = x * y;
+    const double r = fma(-q0, d, x);
+    return -1.0 + fma(r, y, q0);
+}
+
 // windows are stored word-major: win[j * S + s], j < 31.
 //   window_level_kernel   one level, one thread per window (961 serial multiply-adds: fine when
 //                         there are hundreds of thousands of windows to keep the chip busy)
@@ -234,10 +250,9 @@ __global__ __launch_bounds__(T) void draw_log_kernel(long long S, long long seg_
             x[f * T + threadIdx.x] = v;
             f = f == 30 ? 0 : f + 1;
             b = b == 30 ? 0 : b + 1;
-            // the host's expression, operation for operation (an IEEE division: the same u);
-            // |u| is a normal number in [4.6e-10, 1]: the short logarithm of psi.h (within an ulp
-            // of the library's, a third of its instructions)
-            const double u = -1.0 + 2.0 * (double)(v >> 1) / (double)2147483647;
+            // the host's u (unit_draw); |u| is a normal number in [4.6e-10, 1]: the short logarithm
+            // of psi.h (within an ulp of the library's, a third of its instructions)
+            const double u = unit_draw(v);
             mine[q] = log_normal(fabs(u));
         }
         // (LDS traffic of one wave is in order: no barrier between the writes and these reads)
@@ -303,7 +318,7 @@ __global__ __launch_bounds__(2 * kRngFusedPasses) void draw_sum_kernel(
             x[f * T + threadIdx.x] = v;
             f = f == 30 ? 0 : f + 1;
             b = b == 30 ? 0 : b + 1;
-            const double u = -1.0 + 2.0 * (double)(v >> 1) / (double)2147483647;   // as draw_log_kernel
+            const double u = unit_draw(v);
             const int e = e_first + q;
             if (on && e >= 0 && e < n_e)
                 vals[p * 33 + e] = log_normal(fabs(u));
