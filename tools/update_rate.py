@@ -28,7 +28,7 @@ CONFIGS = {
     "small": (100, 7000, 200, "online", 40),
     "c3": (100, 7000, 1600, "online", 20),
     "c5a": (500, 100000, 512, "online", 6),
-    "c5b": (500, 100000, 4096, "online", 3),
+    "c5b": (500, 100000, 4096, "online", 8),
     "c4": (200, 50000, 12500, "batch", 2),
 }
 
