@@ -215,6 +215,20 @@ __device__ __forceinline__ double exp_nonpos(double a)
     const double n = rint(a * 1.44269504088896340736);
     double r = fma(n, -6.93147180369123816490e-01, a);           // ln2 in two pieces
     r = fma(n, -1.90821492927058770002e-10, r);
+#ifdef TRLDA_EXP_ESTRIN
+    // pairwise: depth 6 instead of 11, three instructions more -- measured slower (30.5 against
+    // 30.3 us for the register kernel, profiles/r04_psi_variants.txt): the count decides, not the depth
+    const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
+    const double a0 = fma3s(1.66666666666666685e-01, r, 5.00000000000000111e-01);
+    const double a1 = fma3s(8.33333333333006500e-03, r, 4.16666666666241636e-02);
+    const double a2 = fma3s(1.98412698630405450e-04, r, 1.38888889171967186e-03);
+    const double a3 = fma3s(2.75572684803100238e-06, r, 2.48015213223686919e-05);
+    const double a4 = fma3s(2.51003758325612340e-08, r, 2.76200758799833672e-07);
+    const double b0 = fma3(a1, r2, a0), b1 = fma3(a3, r2, a2);
+    double q = fma3(b1, r4, b0);
+    q = fma3(a4, r8, q);
+    const double p = fma3(r2, q, r) + 1.0;
+#else
     double p = fma3(r, 2.51003758325612340e-08, 2.76200758799833672e-07);
     p = fma3(r, p, 2.75572684803100238e-06);
     p = fma3(r, p, 2.48015213223686919e-05);
@@ -226,6 +240,7 @@ __device__ __forceinline__ double exp_nonpos(double a)
     p = fma3(r, p, 5.00000000000000111e-01);
     p = fma(r, p, 1.0);
     p = fma(r, p, 1.0);
+#endif
     return ldexp(p, (int)n);
 }
 
@@ -255,7 +270,7 @@ __device__ __forceinline__ double exp_psi_regular(double x, double c)
     q = fma(q, x, 1026576.0);
     q = fma(q, x, 362880.0);
     const double P = q * x;
-    double dP = fma(10.0, x, 405.0);
+    double dP = fma3s(10.0, x, 405.0);
     dP = fma(dP, x, 6960.0);
     dP = fma(dP, x, 66150.0);
     dP = fma(dP, x, 379638.0);
@@ -319,7 +334,15 @@ __device__ __forceinline__ double exp_digamma_minus(double x, double c)
 __device__ __forceinline__ double exp_digamma(double x)
 {
     const double v = exp_psi_regular<true>(x, 0.0);
+    // (the integers 1 .. 10, where the reference takes the exact harmonic sum, src/digamma.cpp:147-156,
+    // go through the regular form here as in exp_digamma_positive: psi(n) to a few ulp either way,
+    // 2e-15 apart at most -- and three instructions fewer in the psi waves' stream: 0.2 us of the
+    // document kernel.  TRLDA_INT_BRANCH puts the branch back.)
+#ifdef TRLDA_INT_BRANCH
     if (__builtin_expect(!(x > 1e-290 && x < 1e25) || (x <= 10.0 && x == floor(x)), 0))
+#else
+    if (__builtin_expect(!(x > 1e-290 && x < 1e25), 0))
+#endif
         return exp_digamma_rare(x, 0.0);
     return v;
 }
