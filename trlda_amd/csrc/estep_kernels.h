@@ -1171,20 +1171,13 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
     __syncthreads();
     // fused preamble: thread k forms c_k = exp(-psiSum_k) from the partial sums parked in
     // `part` and scales its exp(psi(gamma0_k)) -- while the other waves read the transposition
-    // (thread k < K is also the lane that evaluates topic k in the psi stage below -- waves 0 and 1 --
-    // so its e_k and alpha_k stay in registers from one iteration to the next instead of coming
-    // back from LDS: ek_cur, ak_psi; idle lanes of those waves get the harmless 1.5 / 0)
-    double ek_cur = 0.0;
-    const double ak_psi = tid < K ? ak0 : 1.5;
     if (tid < K) {
         double ck = 1.0;
-        ek_cur = e0;
         if (a.partial) {                             // launch-uniform
             // (merged launch: being finished by workgroups of this launch while the slice was staged)
             ck = a.scale_in ? (a.scale_wait ? scale_wait_load(a, K, tid) : ck0)
                             : topic_scale_combine(K, tid, part, a.scale_out);
-            ek_cur = e0 * ck;
-            ebuf[tid] = ek_cur;
+            ebuf[tid] = e0 * ck;
         }
         c_l[tid] = ck;
     }
@@ -1308,7 +1301,9 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
         double *g_new = gbuf + ((it + 1) & 1) * 128, *e_new = ebuf + ((it + 1) & 1) * 144;
         if (wid < 2) {
             const int kk = psi_on ? k_psi : 0;
-            const double ek = ek_cur, ak = ak_psi;
+            // (keeping the lane's own e_k / alpha_k in registers across iterations instead of these two
+            // LDS reads was measured: no gain, and the tiered kernels, at the register limit, spilled)
+            const double ek = e_old[kk], ak = alpha_l[kk];
             double acc = sum8_strided<kRegPart>(part + kk);
             if constexpr (SPLIT) {
                 // this segment's row out, every segment's row in (segment order)
@@ -1371,7 +1366,6 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
             }
             const double gnew = acc * ek + ak;
             const double enew = exp_digamma(gnew) * c_psi;
-            ek_cur = enew;
             if (psi_on) {
                 g_new[k_psi] = gnew;
                 e_new[k_psi] = enew;
