@@ -1,10 +1,11 @@
 #!/bin/bash
+# end-of-round check on the GPU box: build entry, smoke, the whole GPU suite, the driver's bench command
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -4
-timeout 600 python tools/update_rate.py --configs small --modes fused 2>&1 | grep max_iter
-TRLDA_MERGED=2 bash tools/runs/r4_quick.sh
-bash tools/runs/r4_quick.sh
-timeout 300 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 | python3 -c "
+o=gpurun_out
+( python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+  timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+  timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 | cut -c1-400
+  timeout 600 python bench.py 2>/dev/null | tail -1 | python -c "
 import sys,json
-j=json.loads(sys.stdin.read())
-print('driver-style', j['value'], j['ms_per_step'], j['repeats'], j['update_parameters']['device_batch_tr10'], j['update_parameters']['device_batch_tr0'])"
+j=json.loads(sys.stdin.read()); print('default bench:', j['value'], j['ms_per_step'], j['steps'], j['roofline']['frac'], j['cpu_baseline']['value'], j['update_parameters']['device_batch_tr10'])"
+) 2>&1 | grep -v amdgpu.ids | tee $o/r04_final_check.txt
