@@ -631,6 +631,15 @@ int trlda_debug_digamma(int device, int n, double c, const double *x, double *ps
  * (row = lane); out16 / out4 / out2 [64] = what each lane receives from the 16-, 4- and
  * 2-value folds of its row's leading values */
 int trlda_debug_fold16(int device, const double *in, double *out16, double *out4, double *out2);
+/* diagnostics: copy out one of the model's intermediate buffers of its last E-step (after
+ * synchronising its stream).  which = 0: exp(psi(lambda)) / exp E[log beta] as the kernels read it
+ * (K x V; only the batch's words are filled), 1: the documents' exp E[log theta] rows, 2: cnt /
+ * phinorm per entry in word order, 3: the sstats buffer of the host entry points (K x V).
+ * tests/fuzz_estep.py --passes uses it to say WHICH input of the statistics went wrong. */
+int trlda_debug_peek(trlda_model *model, int which, double *host_out, size_t count);
+/* diagnostics: the s_memrealtime stamps of the model's last merged launch, 3 x 1024 values
+ * (TRLDA_MERGED_STAMPS=1; tools/merged_stamps.py) */
+int trlda_debug_merged_stamps(trlda_model *model, unsigned long long *host_out);
 
 /* ---- measurement --------------------------------------------------------- */
 

@@ -155,6 +155,8 @@ _SIGNATURES = {
     "trlda_model_adaptive_stats_dev": (C.c_int, [vp, vp, vp, C.c_double, C.c_double, C.c_double,
                                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "trlda_debug_fold16": (C.c_int, [C.c_int, vp, vp, vp, vp]),
+    "trlda_debug_peek": (C.c_int, [vp, C.c_int, vp, C.c_size_t]),
+    "trlda_debug_merged_stamps": (C.c_int, [vp, vp]),
     "trlda_model_set_doc_kernel": (C.c_int, [vp, C.c_int]),
     "trlda_model_last_doc_kernel": (C.c_char_p, [vp]),
     "trlda_model_set_split_preamble": (C.c_int, [vp, C.c_int]),
