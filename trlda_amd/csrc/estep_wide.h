@@ -55,6 +55,14 @@ struct wide_cfg {
     static constexpr int TCH = KS <= 4 ? 4 : 2;
 #endif
     static constexpr int KP = 64 * KS;               // padded topic count
+    // exp(psi)'s polynomial coefficients from scalar registers (psi.h, exp_nonpos<SC>): where the
+    // vector registers run out -- at KS >= 7 the kernel spilled without it (1518 -> 1318 us per 4096
+    // documents at K = 500); KS = 5, 6 gain 1.5 %, KS <= 4 lose 1 % (profiles/r04_scoef_*.txt)
+#ifdef TRLDA_WIDE_SC
+    static constexpr bool SC = KS >= TRLDA_WIDE_SC;
+#else
+    static constexpr bool SC = KS >= 5;
+#endif
 };
 
 // LDS carve (doubles): part[8][KP] | ebuf[2][KP] | misc[2][8] | cnt_tail[lds_rows] |
@@ -331,7 +339,7 @@ __device__ __forceinline__ void estep_docs_wide_body(const DocKernelArgs &a, int
     // gamma / alpha / exp(psi(gamma)) of topic tid                       lda.cpp:174
     double ek = 0.0;
     if (tid < KP) {
-        const double e0 = exp_digamma(gk);
+        const double e0 = exp_digamma<cfg::SC>(gk);
         ek = k_on ? e0 : 0.0;
         ebuf[tid] = ek;                              // zero beyond K
     }
@@ -540,7 +548,7 @@ __device__ __forceinline__ void estep_docs_wide_body(const DocKernelArgs &a, int
             const double gnew = k_on ? fma(accs, ek, ak) : 1.5;
             [[maybe_unused]] const double diff = k_on ? fabs(gk - gnew) : 0.0;
             gk = gnew;
-            double enew = exp_digamma(gnew);
+            double enew = exp_digamma<cfg::SC>(gnew);
             if constexpr (FACTORS)
                 enew *= ck;
             ek = k_on ? enew : 0.0;

@@ -209,6 +209,14 @@ __device__ __forceinline__ double rcp_pair(double a)
 // the reference's exp(-1e290) does) and the rest is the usual reduction a = n ln2 + r,
 // |r| <= ln2 / 2, and 1 + r + r^2 q(r) with q the degree-9 Chebyshev fit of (e^r - 1 - r) / r^2
 // (fit error 1e-16 of q = 1.3e-17 of the result; within 1.5 ulp of exp over the interval).
+// SC: the polynomial's coefficients from scalar registers instead of vector ones -- 20 vector
+// registers fewer.  For the kernels that are out of them: the single-orientation document kernel
+// at K > 384 spilled 14-18 registers and reloaded six of them in every iteration's psi stage;
+// with SC nothing spills and its launches are 13 % shorter (K = 500: 1518 -> 1318 us per 4096
+// documents).  Not for the others: where the scalar registers are the scarce ones (the K <= 128
+// kernels, above all with the statistics stage inside) the same switch costs 1.5 %
+// (profiles/r04_scoef_ab.txt).
+template <bool SC = false>
 __device__ __forceinline__ double exp_nonpos(double a)
 {
     a = fmax(a, -800.0);
@@ -229,15 +237,28 @@ __device__ __forceinline__ double exp_nonpos(double a)
     q = fma3(a4, r8, q);
     const double p = fma3(r2, q, r) + 1.0;
 #else
-    double p = fma3(r, 2.51003758325612340e-08, 2.76200758799833672e-07);
-    p = fma3(r, p, 2.75572684803100238e-06);
-    p = fma3(r, p, 2.48015213223686919e-05);
-    p = fma3(r, p, 1.98412698630405450e-04);
-    p = fma3(r, p, 1.38888889171967186e-03);
-    p = fma3(r, p, 8.33333333333006500e-03);
-    p = fma3(r, p, 4.16666666666241636e-02);
-    p = fma3(r, p, 1.66666666666666685e-01);
-    p = fma3(r, p, 5.00000000000000111e-01);
+    double p;
+    if constexpr (SC) {
+        p = fma3s(r, 2.51003758325612340e-08, 2.76200758799833672e-07);
+        p = fma3s(r, p, 2.75572684803100238e-06);
+        p = fma3s(r, p, 2.48015213223686919e-05);
+        p = fma3s(r, p, 1.98412698630405450e-04);
+        p = fma3s(r, p, 1.38888889171967186e-03);
+        p = fma3s(r, p, 8.33333333333006500e-03);
+        p = fma3s(r, p, 4.16666666666241636e-02);
+        p = fma3s(r, p, 1.66666666666666685e-01);
+        p = fma3s(r, p, 5.00000000000000111e-01);
+    } else {
+        p = fma3(r, 2.51003758325612340e-08, 2.76200758799833672e-07);
+        p = fma3(r, p, 2.75572684803100238e-06);
+        p = fma3(r, p, 2.48015213223686919e-05);
+        p = fma3(r, p, 1.98412698630405450e-04);
+        p = fma3(r, p, 1.38888889171967186e-03);
+        p = fma3(r, p, 8.33333333333006500e-03);
+        p = fma3(r, p, 4.16666666666241636e-02);
+        p = fma3(r, p, 1.66666666666666685e-01);
+        p = fma3(r, p, 5.00000000000000111e-01);
+    }
     p = fma(r, p, 1.0);
     p = fma(r, p, 1.0);
 #endif
@@ -257,7 +278,7 @@ __device__ __forceinline__ double psi_series_horner(double z)
     return fma3s(p, z, 8.33333333333333333333E-2);
 }
 
-template <bool ZERO_C = false>
+template <bool ZERO_C = false, bool SC = false>
 __device__ __forceinline__ double exp_psi_regular(double x, double c)
 {
     double q = x + 45.0;
@@ -287,7 +308,7 @@ __device__ __forceinline__ double exp_psi_regular(double x, double c)
     if constexpr (ZERO_C) {
 #ifndef TRLDA_LIBRARY_EXP
         const double yh = z * psi_series_horner(z);
-        return s * exp_nonpos(-((fma(0.5, r, yh)) + w));         // psi(x) < log(x + 10): the argument is <= 0
+        return s * exp_nonpos<SC>(-((fma(0.5, r, yh)) + w));     // psi(x) < log(x + 10): the argument is <= 0
 #endif
     }
     const double y = z * psi_series(z);
@@ -331,9 +352,10 @@ __device__ __forceinline__ double exp_digamma_minus(double x, double c)
 }
 
 // c = 0 (the document kernels, the fused preamble): the same with the short exponential
+template <bool SC = false>
 __device__ __forceinline__ double exp_digamma(double x)
 {
-    const double v = exp_psi_regular<true>(x, 0.0);
+    const double v = exp_psi_regular<true, SC>(x, 0.0);
     // (the integers 1 .. 10, where the reference takes the exact harmonic sum, src/digamma.cpp:147-156,
     // go through the regular form here as in exp_digamma_positive: psi(n) to a few ulp either way,
     // 2e-15 apart at most -- and three instructions fewer in the psi waves' stream: 0.2 us of the
