@@ -102,6 +102,36 @@ def test_config5_online_update_trust_region(hip, oracle, sampler):
     assert m.update_count == 2
 
 
+@pytest.mark.parametrize("K,V,B", [(200, 25000, 96), (500, 20000, 40), (384, 20000, 200)])
+def test_big_table_m_step_leaves_exp_psi_lambda_behind(hip, oracle, sampler, monkeypatch, K, V, B):
+    """K > 128 on a big table: from the second trust-region iteration on the M-step kernel has left
+    exp(psi(lambda)) of the batch's words behind and the single-orientation document kernel applies
+    the topic factors (estep_docs_wide_kernel<KS, true>) -- no exp_elog_beta_kernel.  Against the
+    oracle, against the same calls with the switch off (TRLDA_BIG_EMIT=0), and the path is the one
+    that ran: trlda_model_last_preamble_fused."""
+    import trlda_amd
+    D = 200000
+    lam0 = random_lambda(K, V, 9)
+    docs = [corpus(B, V, seed=900 + i) for i in range(2)]
+    got = {}
+    for switch in ("1", "0"):
+        monkeypatch.setenv("TRLDA_BIG_EMIT", switch)
+        m = online_model(K, V, lam0, D)
+        for i, (tr, seed) in enumerate(((3, 51), (2, 52))):
+            trlda_amd.seed(seed)
+            m.update_parameters(docs[i], max_iter_tr=tr, max_iter_inference=20)
+            assert hip.trlda_model_last_preamble_fused(m._handle) == int(switch)
+        got[switch] = m.lambdas
+        m.close()
+    lam = lam0
+    for i, (tr, seed) in enumerate(((3, 51), (2, 52))):
+        g0 = seeded_gamma(sampler, seed, K, B)
+        _r, lam, _g = oracle_online_update(oracle, lam, .1, .3, D, docs[i], g0, i, tr, 20)
+    assert relerr(got["1"], lam) < TIGHT_RTOL, relerr(got["1"], lam)
+    assert relerr(got["0"], lam) < TIGHT_RTOL
+    assert relerr(got["1"], got["0"]) < 1e-10
+
+
 def test_config5_single_step_and_plain_sequence(hip, oracle, sampler):
     """max_iter_tr=0 (onlinelda.cpp:103-109: the in-place M-step on the active words plus the
     decay of the others), and the plain launch sequence (fused update and carried row sums off)

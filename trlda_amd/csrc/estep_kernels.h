@@ -2071,7 +2071,8 @@ __device__ __forceinline__ double2 update_pair(const UpdateOut &o, size_t i, dou
 }
 
 template <int T, int NKB, int NH, bool EMIT>         // NKB = ceil(K / (128 NH)), K even
-__global__ __launch_bounds__(T, EMIT ? (T <= 512 ? 6 : 8) : 1) void sstats_update2_kernel(
+__global__ __launch_bounds__(T, (EMIT && NH <= 1 && NKB == 1) ? (T <= 512 ? 6 : 8)
+                                   : (EMIT && T <= 512) ? 4 : 1) void sstats_update2_kernel(
     int K, int N, int G_short, int n_long, int long_len, const int32_t *__restrict__ list,
     const int32_t *__restrict__ wptr, const int32_t *__restrict__ wdoc,
     const int32_t *__restrict__ long_words, TwView tw_word,

@@ -247,7 +247,7 @@ __device__ __forceinline__ void estep_docs_wide_body(const DocKernelArgs &a, int
     // fused preamble: the block partials of the row sums are fetched first (they depend on
     // nothing) and consumed once the row loads below are in flight
     [[maybe_unused]] double pv[2][8];
-    if constexpr (FACTORS) {
+    if constexpr (FACTORS && KS <= 2) {              // (K > 128: the factors always come finished)
         if (a.partial && !a.scale_in)                // launch-uniform
             topic_scale_load<kWideThreads>(K, a.G, a.partial, pv);
     }
@@ -343,7 +343,7 @@ __device__ __forceinline__ void estep_docs_wide_body(const DocKernelArgs &a, int
         ek = k_on ? e0 : 0.0;
         ebuf[tid] = ek;                              // zero beyond K
     }
-    if constexpr (FACTORS) {
+    if constexpr (FACTORS && KS <= 2) {
         if (a.partial && !a.scale_in)                // `part` is idle until the first product
             topic_scale_partials<kWideThreads>(K, a.G, pv, part);
     }
@@ -371,10 +371,12 @@ __device__ __forceinline__ void estep_docs_wide_body(const DocKernelArgs &a, int
             // e is kept as c_k exp(psi(gamma_k)) throughout: phinorm and gamma come out the same
             // with u = exp(psi(lambda)) in place of exp E[log beta] (estep_kernels.h 2b)
             if (k_on) {
-                if (!a.scale_in)
-                    ck = topic_scale_combine(K, tid, part, a.scale_out);
-                else if (a.scale_wait)               // merged launch (estep_merged.h)
-                    ck = scale_wait_load(a, K, tid);
+                if constexpr (KS <= 2) {
+                    if (!a.scale_in)
+                        ck = topic_scale_combine(K, tid, part, a.scale_out);
+                    else if (a.scale_wait)           // merged launch (estep_merged.h)
+                        ck = scale_wait_load(a, K, tid);
+                }
                 ek *= ck;
                 ebuf[tid] = ek;
             }
@@ -619,13 +621,16 @@ __device__ __forceinline__ void estep_docs_wide_body(const DocKernelArgs &a, int
     TRLDA_STAMP_FLUSH;
 }
 
-template <int KS>
+// FACTORS: exp(psi(lambda)) in place of exp E[log beta] (left behind by the M-step of the previous
+// trust-region iteration, sstats_update2_kernel<.., EMIT>), the topic factors from a.scale_in
+// (stream_kernels.h, topic_factors_kernel)
+template <int KS, bool FACTORS = false>
 __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernelArgs a, int lds_rows)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int d = a.order[blockIdx.x];
     const int p0 = a.indptr[d];
-    estep_docs_wide_body<KS, false>(a, lds_rows, lds, d, p0, a.indptr[d + 1] - p0);
+    estep_docs_wide_body<KS, FACTORS>(a, lds_rows, lds, d, p0, a.indptr[d + 1] - p0);
 }
 
 // ---------------------------------------------------------------------------

@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "psi.h"
+
 namespace trlda {
 
 constexpr int kStreamThreads = 1024;
@@ -157,6 +159,23 @@ __global__ __launch_bounds__(T) void rowsum_stream_kernel(int K, int V, int P, i
         }
     }
     stream_block_partial<T, VEC>(K, P, cpb, slot, kp, acc, scratch, partial + (size_t)blockIdx.x * K);
+}
+
+// out[k] = psi(rs[k]), out[K + k] = rs[k], out[2 K + k] = exp(-psi(rs[k])): what topic_scale_combine
+// leaves behind for the K <= 128 kernels (estep_kernels.h), here from finished row sums -- for the
+// single-orientation document kernel when the M-step has left exp(psi(lambda)) behind (round 4)
+template <int T>
+__global__ __launch_bounds__(T) void topic_factors_kernel(int K, const double *__restrict__ rs,
+                                                          double *__restrict__ out)
+{
+    const int k = blockIdx.x * T + threadIdx.x;
+    if (k >= K)
+        return;
+    const double s = rs[k];
+    const double ps = digamma(s);
+    out[k] = ps;
+    out[K + k] = s;
+    out[2 * K + k] = exp(-ps);
 }
 
 // combined[k] = (base ? base[k] : 0) + sum_{g < G} partial[g][k]: one wavefront per topic, lane

@@ -277,6 +277,15 @@ struct trlda_model {
         int n = 0;
         bool raw = false;               // the rows are block rows still to be added up (merged launch)
     } next_pre;
+    // Big tables (K > 128): the M-step of a trust-region iteration left u = exp(psi(lambda)) of the
+    // batch's words in `eeb` (sstats_update2_kernel<.., EMIT>): the next E-step on the same batch
+    // and the same lambda needs no exp_elog_beta_kernel -- the single-orientation document kernel
+    // applies the topic factors instead (estep_docs_wide_kernel<KS, true>)
+    struct {
+        bool valid = false;
+        uint64_t batch_id = 0, version = 0;
+    } u_left;
+    bool big_emit = true;               // TRLDA_BIG_EMIT=0: exp_elog_beta_kernel in every iteration
     bool emit_next_preamble = true;     // trlda_model_set_fused_update(.. & 2 == 0)
     bool carry_rowsums = true;          // trlda_model_set_carry_rowsums (tests, comparisons)
     bool fused_update = true;           // trlda_model_set_fused_update: statistics + M-step in one pass
@@ -794,6 +803,8 @@ struct EstepOut {
     bool sliced = false;
     int slice_lo = 0, slice_n = 0, long_lo = 0, long_n = 0, vl_lo = 0, vl_n = 0;
     bool no_rows = false;       // out: no row sums were left behind (the next E-step adds lambda up)
+    bool emit_u = false;        // in: big tables -- also leave exp(psi(lambda)) of the written words in eeb
+    bool u_emitted = false;     // out: it did
     EstepOut() { upd = trlda::UpdateOut{}; }
     explicit EstepOut(double *sstats) : EstepOut() { upd.sstats = sstats; }
 };
@@ -934,11 +945,16 @@ int launch_sstats_update(trlda_model *m, const trlda_batch *b, EstepOut &out)
     // result is known to be positive)
     const bool positive = out.upd.lambda && mstep_keeps_positive(m, out.upd, b);
     const bool emit = can_emit && out.emit_next && out.upd.lambda && out.upd.partial && positive;
+    // (K > 128, two topics per lane: exp(psi(lambda)) only -- the row sums go the carried way)
+    constexpr bool can_emit_u = NH == 2;
+    const bool emit_u = can_emit_u && !can_emit && out.emit_u && out.upd.lambda && out.active_only && positive &&
+                        !out.sliced;
+    out.u_emitted = false;
     if (out.upd.lambda)
         m->lambda_positive = positive;
     sstats_update_fn kern = sstats_update_entry<T, NKB, NH, false>();
-    if constexpr (can_emit) {
-        if (emit)
+    if constexpr (can_emit || can_emit_u) {
+        if (emit || emit_u)
             kern = sstats_update_entry<T, NKB, NH, true>();
     }
     int rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
@@ -950,6 +966,10 @@ int launch_sstats_update(trlda_model *m, const trlda_batch *b, EstepOut &out)
     out.upd.group_base = nullptr;
     out.upd.group_counter = nullptr;
     out.upd.group_size = 1;
+    if (emit_u) {
+        out.upd.u_out = m->eeb;
+        out.u_emitted = true;
+    }
     if (emit) {
         const int rows = vl.n_rows;
         out.upd.u_out = m->eeb;
@@ -1310,7 +1330,16 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
     // agree on what the gathered factors mean: with the fused preamble a rank publishes c_k
     // expElogtheta and keeps exp(psi(lambda)) unnormalised, without it plain expElogtheta)
     const bool fused = fused_preamble_possible(m, b) && trust && m->rs_floor >= kFusedRowsumFloor;
-    m->last_preamble_fused = fused;
+    // Big table, single-orientation document kernel: the previous trust-region iteration's M-step
+    // left exp(psi(lambda)) of THIS batch's words behind and the row sums came with it (carried):
+    // no exp_elog_beta_kernel -- the document kernel applies the K topic factors
+    const bool fused_big = !fused && big && carried && trust && !dp && !atomic && B > 0 && m->big_emit &&
+                           m->u_left.valid && m->u_left.batch_id == b->id &&
+                           m->u_left.version == m->lambda_version && m->rs_floor >= kFusedRowsumFloor &&
+                           K > kRegMaxK && K <= kWideMaxK && m->doc_threads == 0 &&
+                           m->doc_kernel == TRLDA_DOCS_AUTO && !m->dense_preamble;
+    m->u_left.valid = false;
+    m->last_preamble_fused = fused || fused_big;
     if (!fused && carried && (rc = resolve_carry(m)))   // everything else wants one row of sums
         return rc;
     m->eeb_cur = m->eeb;
@@ -1425,8 +1454,13 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         return rc;
 
     // 2. psiSum + exp E[log beta] (lda.cpp:172-173), on the batch's active words unless the
-    // dense preamble was asked for
-    {
+    // dense preamble was asked for -- or, with exp(psi(lambda)) left behind by the M-step, the K
+    // topic factors only (psi_sum: psi of the row sums, the sums, exp(-psi))
+    if (fused_big) {
+        hipLaunchKernelGGL(trlda::topic_factors_kernel<256>, dim3((K + 255) / 256), dim3(256), 0, m->stream, K,
+                           partial_in, m->psi_sum);
+        HIP_TRY(hipGetLastError());
+    } else {
         constexpr int TE = 1024;
         const bool dense = m->dense_preamble;
         const size_t total = dense ? KV : (size_t)K * (size_t)b->n_active;
@@ -1485,8 +1519,8 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         }
         a.sstats_acc = atomic ? sstats_dev : nullptr;
         a.max_iter = max_iter; a.threshold = threshold; a.iters_out = iters_dev;
-        a.partial = fused ? partial_in : nullptr;
-        a.scale_in = prefetched ? m->scale_pp[cur_buf] : nullptr;
+        a.partial = (fused || fused_big) ? partial_in : nullptr;
+        a.scale_in = fused_big ? m->psi_sum : prefetched ? m->scale_pp[cur_buf] : nullptr;
         a.done_counter = nullptr; a.scale_wait = nullptr; a.done_target = 0;
         a.go_flags = nullptr; a.n_go = 0;
         a.epoch = m->merged_epoch + 1u;              // (of this launch, if it turns out to be merged)
@@ -1539,7 +1573,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
             a.order = db->order;
 #define TRLDA_LAUNCH_WIDE(KSV)                                                             \
     do {                                                                                   \
-        auto kern = estep_docs_wide_kernel<KSV>;                                           \
+        auto kern = fused_big ? estep_docs_wide_kernel<KSV, true> : estep_docs_wide_kernel<KSV, false>; \
         if ((rc = ensure_dynamic_lds(reinterpret_cast<const void *>(kern), lds_bytes)))     \
             return rc;                                                                     \
         hipLaunchKernelGGL(kern, dim3(n_wide), dim3(kWideThreads), lds_bytes, m->stream, a, \
@@ -2800,6 +2834,8 @@ int trlda_model_create(trlda_model **out, int device, int K, int V)
         m->split_long_lists = env[0] != '0';
     if (const char *env = std::getenv("TRLDA_TILED_TASKS"))
         m->tiled_tasks = env[0] != '0';
+    if (const char *env = std::getenv("TRLDA_BIG_EMIT"))
+        m->big_emit = env[0] != '0';
     if (const char *env = std::getenv("TRLDA_MERGED"))           // 0 = statistics always a launch of their own
         m->merged_launch = std::max(0, std::min(std::atoi(env), 2));
     *out = m;
@@ -3359,10 +3395,17 @@ int online_update_fused(trlda_model *m, const trlda_batch *b, int num_documents,
             // was written: whatever batch comes next is covered)
             out.next_base = out.active_only ? m->rs_static : nullptr;
             out.emit_next = can_emit_next(m, b) && (!last || !out.active_only);
+            // (big tables: the same for exp(psi(lambda)) alone, while the batch comes round again)
+            out.emit_u = !last && m->big_emit && m->carry_rowsums && K > trlda::kRegMaxK;
             if (!rc)
                 rc = estep_device(m, b, m->gamma, out, max_iter_inference, threshold, nullptr);
             if (!rc)
                 rc = finish_rowsums(m, out, out.next_base, floor_after, b);
+            if (!rc && out.u_emitted) {
+                m->u_left.valid = true;
+                m->u_left.batch_id = b->id;
+                m->u_left.version = m->lambda_version;
+            }
         }
         return rc;
     }
