@@ -65,11 +65,12 @@ struct wide_cfg {
 #endif
 };
 
-// LDS carve (doubles): part[8][KP] | ebuf[2][KP] | misc[2][8] | cnt_tail[lds_rows] |
+// LDS carve (doubles): part[8][KP] | ebuf[2][KP] | cbuf[KP] (topic factors, FACTORS at K > 128) |
+// misc[2][8] | cnt_tail[lds_rows] |
 // rows[lds_rows][KP]
 __host__ __device__ constexpr size_t wide_lds_doubles(int KS, int lds_rows)
 {
-    return (size_t)(kWideWaves + 2) * 64 * KS + 16 + (size_t)lds_rows * (64 * KS + 1);
+    return (size_t)(kWideWaves + 3) * 64 * KS + 16 + (size_t)lds_rows * (64 * KS + 1);
 }
 
 // (fold<D>, the transposing butterfly step, lives in estep_kernels.h: the register kernel uses
@@ -256,7 +257,9 @@ __device__ __forceinline__ void estep_docs_wide_body(const DocKernelArgs &a, int
 
     double *part = lds;                              // 8 x KP
     double *ebuf = part + W * KP;                    // 2 x KP
-    double *misc = ebuf + 2 * KP;                    // 2 x 8
+    double *cbuf = ebuf + 2 * KP;                    // KP: c_k at K > 128 (two registers fewer in the loop:
+                                                     // the K = 500 instantiation spilled four with them)
+    double *misc = cbuf + KP;                        // 2 x 8
     double *cnt_tail = misc + 16;                    // lds_rows: counts of the words in LDS rows
     double *rows = cnt_tail + lds_rows;              // lds_rows x KP
 
@@ -379,6 +382,8 @@ __device__ __forceinline__ void estep_docs_wide_body(const DocKernelArgs &a, int
                 }
                 ek *= ck;
                 ebuf[tid] = ek;
+                if constexpr (KS > 2)
+                    cbuf[tid] = ck;
             }
             __syncthreads();                         // `part` is free again, e complete
         }
@@ -552,7 +557,7 @@ __device__ __forceinline__ void estep_docs_wide_body(const DocKernelArgs &a, int
             gk = gnew;
             double enew = exp_digamma<cfg::SC>(gnew);
             if constexpr (FACTORS)
-                enew *= ck;
+                enew *= KS > 2 ? cbuf[tid] : ck;
             ek = k_on ? enew : 0.0;
             ebuf[nxt * KP + tid] = ek;
             if constexpr (!MIRROR) {
