@@ -120,7 +120,9 @@ def test_big_table_m_step_leaves_exp_psi_lambda_behind(hip, oracle, sampler, mon
         for i, (tr, seed) in enumerate(((3, 51), (2, 52))):
             trlda_amd.seed(seed)
             m.update_parameters(docs[i], max_iter_tr=tr, max_iter_inference=20)
-            assert hip.trlda_model_last_preamble_fused(m._handle) == int(switch)
+            # (taken from K = 257 on: below that the factor multiply costs the document kernel more
+            # than the separate kernel takes)
+            assert hip.trlda_model_last_preamble_fused(m._handle) == (int(switch) if K > 256 else 0)
         got[switch] = m.lambdas
         m.close()
     lam = lam0

@@ -3396,7 +3396,10 @@ int online_update_fused(trlda_model *m, const trlda_batch *b, int num_documents,
             out.next_base = out.active_only ? m->rs_static : nullptr;
             out.emit_next = can_emit_next(m, b) && (!last || !out.active_only);
             // (big tables: the same for exp(psi(lambda)) alone, while the batch comes round again)
-            out.emit_u = !last && m->big_emit && m->carry_rowsums && K > trlda::kRegMaxK;
+            // (K > 256: there the document kernel carries the factor multiply for nothing measurable
+            // -- coefficients from scalar registers, factors in LDS; at K = 129 .. 256 it cost 1.9 % of
+            // the document launches, more than exp_elog_beta_kernel takes at large batches)
+            out.emit_u = !last && m->big_emit && m->carry_rowsums && K > 256;
             if (!rc)
                 rc = estep_device(m, b, m->gamma, out, max_iter_inference, threshold, nullptr);
             if (!rc)
