@@ -68,6 +68,10 @@ using trlda_host::fail;                  // the thread-local message behind trld
     } while (0)
 
 constexpr int kLdsBytes = 160 * 1024;   // LDS per workgroup on gfx950
+// what a kernel may ask for dynamically: the rest belongs to its static __shared__ variables (a
+// flag, a counter: 16 bytes in the kernels here).  Round 4: a tiered launch whose LDS rows came out
+// at exactly 160 kB was refused by hipFuncSetAttribute (tests/fuzz_estep.py, seed 3)
+constexpr int kLdsDynBytes = kLdsBytes - 256;
 #ifdef TRLDA_STAMPS
 unsigned long long *g_stamp_buf = nullptr;
 #endif
@@ -1565,7 +1569,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
             }
             // LDS rows for the words past the registers, as many as the longest document needs
             const size_t fixed = wide_lds_doubles(KS, 0) * sizeof(double);
-            const int fit = (int)(((size_t)kLdsBytes - fixed) / ((size_t)(64 * KS + 1) * sizeof(double)));
+            const int fit = (int)(((size_t)kLdsDynBytes - fixed) / ((size_t)(64 * KS + 1) * sizeof(double)));
             const int lds_rows = std::max(0, std::min(fit, db->max_n - kWideWaves * jw));
             const size_t lds_bytes = wide_lds_doubles(KS, lds_rows) * sizeof(double);
             a.n_cap = 0;
@@ -1594,13 +1598,13 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         } else if (n_stream > 0) {
             int T = m->doc_threads > 0 ? m->doc_threads : 256;
             size_t fixed = docs_lds_bytes(K, Kp, 0, T);
-            int n_fit = fixed >= (size_t)kLdsBytes
+            int n_fit = fixed >= (size_t)kLdsDynBytes
                             ? 0
-                            : (int)(((size_t)kLdsBytes - fixed) /
+                            : (int)(((size_t)kLdsDynBytes - fixed) /
                                     ((size_t)(Kp + 2) * sizeof(double)));
             int gen_cap = std::min(db->max_n, n_fit);
             size_t lds_bytes = docs_lds_bytes(K, Kp, gen_cap, T);
-            if (lds_bytes > (size_t)kLdsBytes)
+            if (lds_bytes > (size_t)kLdsDynBytes)
                 return fail(TRLDA_ERR_ARG,
                             "num_topics too large for the document kernel's LDS layout");
             a.n_cap = gen_cap;
@@ -1661,7 +1665,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
             if (tiered && db->max_n > (split ? kSplitSegN * kSplitMaxSeg : kRegMaxN)) {
                 const int jw = KS == 1 ? wide_cfg<1>::JW : wide_cfg<2>::JW;
                 const size_t fixed = wide_lds_doubles(KS, 0) * sizeof(double);
-                const int fit = (int)(((size_t)kLdsBytes - fixed) / ((size_t)(64 * KS + 1) * sizeof(double)));
+                const int fit = (int)(((size_t)kLdsDynBytes - fixed) / ((size_t)(64 * KS + 1) * sizeof(double)));
                 lds_rows = std::max(0, std::min(fit, db->max_n - kWideWaves * jw));
                 lds_bytes = std::max(lds_bytes, wide_lds_doubles(KS, lds_rows) * sizeof(double));
             }
