@@ -42,6 +42,10 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=30)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--host-draw", action="store_true",
+                    help="gamma0 from the host's glibc logarithms (bit for bit the oracle's) instead of the device "
+                         "draw, whose logarithm may differ in the last bit: tells a flipped early exit from a defect")
+    ap.add_argument("--per-call", type=int, default=-1, help="print lambda's error after every call of this case")
     args = ap.parse_args(argv)
     import trlda_amd
     from helpers import HipSampler, relerr
@@ -64,6 +68,8 @@ def main(argv=None):
             docs, lens = draw_docs(rng, B, V)
             epochs, inf = int(rng.choice([1, 3])), int(rng.choice([1, 10, 100]))
             m = batch_model(K, V, lam0, alpha=alpha, eta=eta)
+            if args.host_draw:
+                L.trlda_model_set_host_gamma_draw(m._handle, 1)
             trlda_amd.seed(900 + case)
             m.update_parameters(docs, max_epochs=epochs, max_iter_inference=inf)
             sampler.seed(900 + case)
@@ -79,6 +85,8 @@ def main(argv=None):
             kappa, tau = float(rng.choice([.6, .9])), float(rng.choice([10., 1024.]))
             fused, carry = int(rng.rand() < .7), int(rng.rand() < .7)
             m = online_model(K, V, lam0, D, alpha=alpha, eta=eta)
+            if args.host_draw:
+                L.trlda_model_set_host_gamma_draw(m._handle, 1)
             L.trlda_model_set_fused_update(m._handle, fused)
             L.trlda_model_set_carry_rowsums(m._handle, fused and carry)
             # (round 4: statistics inside the document launch never / for updates / always; the
@@ -102,12 +110,32 @@ def main(argv=None):
                 if rho != rho_o:
                     print("MISMATCH case %d call %d: rho %r vs %r" % (case, call, rho, rho_o))
                     sys.exit(1)
+                if call == 0:
+                    # (the first call starts from the same lambda on both sides: rounding only)
+                    first = relerr(m.lambdas, lam)
+                    if not first < 1e-8:
+                        print("MISMATCH case %d K=%d V=%d after the first call (B=%d tr=%d inf=%d): lambda %.2e"
+                              % (case, K, V, B, tr, inf, first))
+                        sys.exit(1)
+                if case == args.per_call:
+                    got = m.lambdas
+                    d = np.abs(got - lam) / np.abs(lam)
+                    k, w = np.unravel_index(np.argmax(d), d.shape)
+                    act = np.zeros(V, bool); act[docs.ids] = True
+                    print("   call %d (B=%d tr=%d inf=%d): lambda err %.2e at topic %d word %d (in this batch: %s; "
+                          "lambda %.4g); over the batch's words %.2e, over the others %.2e" % (
+                              call, B, tr, inf, d.max(), k, w, bool(act[w]), lam[k, w], d[:, act].max(),
+                              d[:, ~act].max() if (~act).any() else 0.))
             err = relerr(m.lambdas, lam)
             what = "OnlineLDA fused=%d carry=%d merged=%d segments=%d (B, tr, inf, longest) %s" % (
                 fused, carry, merged, segs, shapes)
         m.close()
         worst = max(worst, err)
-        if not err < 1e-8:
+        # (three calls in a row: each trust-region loop starts from the previous call's lambda and multiplies
+        # what the two sides differ by -- 1e-10 after the first call, up to ~5e-8 after the third in the
+        # worst of 1200 cases (seeds 503 / 504, the same with the host's bit-exact gamma0 and with round
+        # 3's exp(psi)): the bound on the end of a case is 2e-7, the first call's stays 1e-8 above)
+        if not err < 2e-7:
             print("MISMATCH case %d K=%d V=%d eta=%g alpha=%g %s: lambda %.2e" % (case, K, V, eta, alpha, what, err))
             sys.exit(1)
         print("case %3d ok (%.1e): K=%3d V=%5d %s" % (case, err, K, V, what), flush=True)
