@@ -216,10 +216,17 @@ __device__ __forceinline__ double rcp_pair(double a)
 // documents).  Not for the others: where the scalar registers are the scarce ones (the K <= 128
 // kernels, above all with the statistics stage inside) the same switch costs 1.5 %
 // (profiles/r04_scoef_ab.txt).
-template <bool SC = false>
+// ANY: the argument may be positive, infinite or NaN (exp(psi(x) - c) with a row sum's psi as c):
+// clamped at both ends by selects -- a NaN stays one, +-inf come out as inf / 0 through v_ldexp_f64
+template <bool SC = false, bool ANY = false>
 __device__ __forceinline__ double exp_nonpos(double a)
 {
-    a = fmax(a, -800.0);
+    if constexpr (ANY) {
+        a = a < -800.0 ? -800.0 : a;
+        a = a > 720.0 ? 720.0 : a;
+    } else {
+        a = fmax(a, -800.0);
+    }
     const double n = rint(a * 1.44269504088896340736);
     double r = fma(n, -6.93147180369123816490e-01, a);           // ln2 in two pieces
     r = fma(n, -1.90821492927058770002e-10, r);
@@ -311,8 +318,13 @@ __device__ __forceinline__ double exp_psi_regular(double x, double c)
         return s * exp_nonpos<SC>(-((fma(0.5, r, yh)) + w));     // psi(x) < log(x + 10): the argument is <= 0
 #endif
     }
+#ifdef TRLDA_GENERAL_LIBRARY_EXP
     const double y = z * psi_series(z);
     return s * exp(-((fma(0.5, r, y)) + w) - c);
+#else
+    const double y = z * psi_series_horner(z);
+    return s * exp_nonpos<SC, true>(-((fma(0.5, r, y)) + w) - c);
+#endif
 }
 
 // the form with five reciprocal pairs: valid up to 1e150 (the rational form needs x^11 finite)
