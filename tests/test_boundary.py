@@ -34,6 +34,38 @@ def test_python_binding_covers_the_header(hip_lib):
     assert sorted(_ffi.EXPORTED_SYMBOLS) == header_symbols()
 
 
+def test_every_header_is_a_build_dependency():
+    """a header missing from build.HEADERS let build() hand out a library
+    older than its source.  The list is found now (csrc/*.h); every header #included by a
+    translation unit (directly or through another header) must be in it, and touching any of
+    them must make the library stale."""
+    from trlda_amd import build
+    csrc = os.path.join(ROOT, "trlda_amd", "csrc")
+    listed = {os.path.basename(h) for h in build.HEADERS}
+    seen, todo = set(), list(build.SOURCES)
+    while todo:
+        text = open(os.path.join(csrc, todo.pop())).read()
+        for inc in re.findall(r'#include\s+"([^"]+)"', text):
+            name = os.path.basename(inc)
+            if name not in seen:
+                seen.add(name)
+                assert name in listed, "%s is #included but not a build dependency" % name
+                if os.path.exists(os.path.join(csrc, name)):
+                    todo.append(name)
+    assert {"estep_merged.h", "estep_kernels.h", "psi.h", "trlda_hip.h"} <= seen
+    for h in build.HEADERS:
+        assert os.path.exists(os.path.join(csrc, h)), h
+    if os.path.exists(build.LIB_PATH):
+        built = os.path.getmtime(build.LIB_PATH)
+        victim = os.path.join(csrc, "estep_merged.h")
+        old = os.stat(victim)
+        try:
+            os.utime(victim, (built + 5, built + 5))
+            assert build.is_stale()
+        finally:
+            os.utime(victim, (old.st_atime, old.st_mtime))
+
+
 def test_library_has_no_torch_or_python_dependency(hip_lib):
     from trlda_amd import _ffi
     out = subprocess.run(["ldd", _ffi.LIB_PATH], capture_output=True, text=True).stdout

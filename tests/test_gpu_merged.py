@@ -135,6 +135,63 @@ def test_outside_its_range_the_statistics_stay_a_kernel_of_their_own(hip, sample
     assert hip.trlda_model_last_merged(m200._handle) == 0
 
 
+def test_repeated_ids_make_lists_longer_than_the_batch(hip, oracle, sampler):
+    """ids may repeat within a document (reference src/lda.cpp:108 emits them, and
+    nothing merges them), so a word's list can hold more entries than the batch has documents.
+    The statistics stage of a merged launch walks a long list as sixteen chunks of at most 16
+    entries; a batch of <= 256 documents with a list of more than 256 entries must not take it
+    (round 4's condition looked at B only and dropped entries 16.. of every chunk).  V = 12,
+    60 documents of 40..120 draws WITH replacement: lists of ~400 entries."""
+    import trlda_amd
+    from trlda_amd.documents import CSRDocuments
+    K, V, B, D = 100, 12, 60, 5000
+    rng = np.random.RandomState(4)
+    lens = rng.randint(40, 121, size=B)
+    ip = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ids = rng.randint(0, V, size=ip[-1]).astype(np.int32)
+    cnts = rng.randint(0, 4, size=ip[-1]).astype(np.int32)
+    docs = CSRDocuments(ip, ids, cnts)
+    assert np.bincount(ids, minlength=V).max() > 256
+    lam = seeded_lambda(sampler, 31, K, V)
+    g0 = seeded_gamma(sampler, 32, K, B)
+    go, so, ito = oracle.estep(lam, .1, ip, ids, cnts, g0, 20, 1e-3, nthreads=8)
+    m = make_model(K, V, lam, D=D)
+    for level in (2, 0):
+        hip.trlda_model_set_merged_launch(m._handle, level)
+        g, s, it = m.update_variables(docs, latents=g0, max_iter=20, threshold=1e-3, return_iterations=True)
+        assert hip.trlda_model_last_merged(m._handle) == 0           # outside the stage's range
+        assert np.array_equal(it, ito) and relerr(g, go) < TIGHT_RTOL
+        check_sstats(s, so)
+    # ... and a batch just inside: every list <= 256 entries although ids repeat
+    lens2 = rng.randint(20, 41, size=B)
+    ip2 = np.concatenate([[0], np.cumsum(lens2)]).astype(np.int32)
+    ids2 = rng.randint(0, V, size=ip2[-1]).astype(np.int32)
+    cnts2 = rng.randint(1, 4, size=ip2[-1]).astype(np.int32)
+    longest = np.bincount(ids2, minlength=V).max()
+    assert B < longest <= 256
+    docs2 = CSRDocuments(ip2, ids2, cnts2)
+    go2, so2, ito2 = oracle.estep(lam, .1, ip2, ids2, cnts2, g0, 20, 1e-3, nthreads=8)
+    hip.trlda_model_set_merged_launch(m._handle, 2)
+    g, s, it = m.update_variables(docs2, latents=g0, max_iter=20, threshold=1e-3, return_iterations=True)
+    assert hip.trlda_model_last_merged(m._handle) == 1
+    assert np.array_equal(it, ito2) and relerr(g, go2) < TIGHT_RTOL
+    check_sstats(s, so2)
+    # the default update loop (merged level 1) on the long-list batch against the oracle
+    lams = {}
+    for level in (1, 0):
+        mm = make_model(K, V, lam, D=D)
+        hip.trlda_model_set_merged_launch(mm._handle, level)
+        trlda_amd.seed(6)
+        rho = mm.update_parameters(docs, max_iter_tr=3, max_iter_inference=20)
+        lams[level] = (np.array(mm.lambdas), rho)
+    oracle.seed(6)
+    r_o, lam_o, _, _ = oracle.online_update_parameters(lam, .1, .3, D, ip, ids, cnts, 0, max_iter_tr=3,
+                                                       max_iter_inference=20)
+    assert lams[1][1] == lams[0][1] == r_o
+    assert relerr(lams[1][0], lam_o) < 1e-9 and relerr(lams[0][0], lam_o) < 1e-9
+    assert hip.trlda_model_synchronize(m._handle) == 0
+
+
 @pytest.mark.parametrize("K,V,B", [(100, 7000, 200), (64, 900, 90)])
 def test_update_loops_merged_against_the_kernels_of_their_own(hip, oracle, sampler, K, V, B):
     """OnlineLDA.update_parameters with and without the trust-region loop, three calls on three

@@ -18,7 +18,18 @@ LIB_PATH = os.path.join(_PKG, "libtrlda_hip.so")
 # ones (no HIP: they also build with a plain C++ compiler under the sanitizers, `--sanitize`)
 SOURCES = ["trlda_hip.hip", "host_common.cpp", "host_rng.cpp", "text_docs.cpp", "eb_steps.cpp"]
 HOST_SOURCES = SOURCES[1:]
-HEADERS = ["host_common.h", "estep_kernels.h", "estep_wide.h", "elbo_kernels.h", "stream_kernels.h", "eb_kernels.h", "rng_kernels.h", "dp_kernels.h", "psi.h", os.path.join("..", "..", "include", "trlda_hip.h")]
+
+
+def _headers():
+    """Every header the library is built from: csrc/*.h (found, not listed -- a new header
+    cannot be forgotten; tests/test_boundary.py checks each one is #included somewhere) and
+    the public C ABI."""
+    import glob
+    found = sorted(os.path.basename(h) for h in glob.glob(os.path.join(_CSRC, "*.h")))
+    return found + [os.path.join("..", "..", "include", "trlda_hip.h")]
+
+
+HEADERS = _headers()
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
                "-munsafe-fp-atomics", "-Wall"]
 

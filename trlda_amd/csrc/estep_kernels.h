@@ -27,6 +27,32 @@ namespace trlda {
 
 constexpr int kWave = 64;
 
+// "Everything this thread has stored so far has been acknowledged by the memory side" -- the
+// release half of every counter / flag hand-off between workgroups of one launch in this library
+// (finish_partial_groups, segment_finish, the prefetched preamble's row sums, estep_merged.h).
+// The data that crosses workgroups goes out with agent-scope (sc1, write-through) stores; what
+// remains is that those stores have LEFT before the workgroup's counter increment is issued.
+// A workgroup-scope release fence does not do that: outside threadgroup-split mode the compiler
+// emits no vector-memory wait for it (`global_store ... sc1 ; s_barrier ;
+// global_atomic_add` with only lgkmcnt(0) in between), so the wait is spelled out -- on gfx9
+// stores count in vmcnt like loads.  An agent-scope fence would add the write-back of the XCD's
+// whole L2 (300 us per launch when it was tried) and is not needed for
+// write-through stores.  The fence that follows keeps the compiler from moving stores across.
+__device__ __forceinline__ void stores_acknowledged()
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+}
+
+// The acquire half on a waiter's side, after it has seen its flag: compiler ordering only (no
+// buffer_inv -- estep_merged.h, merged_wait_docs, says why no cache line can be stale), so that
+// no load of the data is hoisted above the flag's.
+__device__ __forceinline__ void flag_seen()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -338,7 +364,7 @@ __device__ __forceinline__ void preamble_fused_body(
         // release before the counter, no agent-scope fence.
         if (c_out) {                                 // launch-uniform
             __shared__ int last_rows;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            stores_acknowledged();
             __syncthreads();
             if (tid == 0) {
                 const unsigned int seen = __hip_atomic_fetch_add(c_counter, 1u, __ATOMIC_RELAXED,
@@ -512,7 +538,7 @@ __device__ __forceinline__ double topic_scale_combine(int K, int k, const double
     do {                                                                      \
         if (threadIdx.x == TRLDA_STAMP_THREAD)                                \
             for (int q__ = 0; q__ < 8; ++q__)                                 \
-                a.stamps[blockIdx.x * 8 + q__] += stamp_acc[q__];             \
+                a.stamps[doc_block(a) * 8 + q__] += stamp_acc[q__];           \
     } while (0)
 #else
 #define TRLDA_STAMP_DECL do { } while (0)
@@ -564,7 +590,13 @@ struct DocKernelArgs {
     unsigned int epoch;
     const unsigned int *scale_wait;       // this workgroup's flag, or nullptr: scale_in (if any) is
                                           // complete; there when the flag has reached `epoch`
+    int block0;                           // workgroups of the grid in front of the documents (a merged
+                                          // launch's topic-factor workgroups come FIRST, so that nothing
+                                          // a document waits for can be queued behind it); else 0
 };
+
+// the document workgroup's index among the launch's document workgroups
+__device__ __forceinline__ int doc_block(const DocKernelArgs &a) { return (int)blockIdx.x - a.block0; }
 
 // an output of the document kernels that the statistics stage reads
 __device__ __forceinline__ void merged_store(double *p, double v, bool coherent)
@@ -576,13 +608,13 @@ __device__ __forceinline__ void merged_store(double *p, double v, bool coherent)
 }
 
 // The finished topic factors of a merged launch: written by workgroups of the same launch
-// (merged_combine) that are resident before any document needs them -- they follow the
-// documents in the grid and the host only takes that path when every document workgroup is
-// resident at once.  Thread k < K; workgroup 0 also leaves the three values in a.scale_out.
+// (merged_combine) that come BEFORE the documents in the grid, i.e. are dispatched before them
+// and wait for nothing.  Thread k < K; document workgroup 0 also leaves the three values in
+// a.scale_out.
 __device__ __forceinline__ double scale_wait_load(const DocKernelArgs &a, int K, int k)
 {
     int spins = 0;
-    while ((int)(__hip_atomic_load(a.scale_wait + (size_t)blockIdx.x * 16, __ATOMIC_RELAXED,
+    while ((int)(__hip_atomic_load(a.scale_wait + (size_t)doc_block(a) * 16, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT) - a.epoch) < 0) {
         __builtin_amdgcn_s_sleep(2);
         if (++spins > (1 << 22)) {                   // never in a sane run: fail the call, do not hang
@@ -591,9 +623,10 @@ __device__ __forceinline__ double scale_wait_load(const DocKernelArgs &a, int K,
             break;
         }
     }
+    flag_seen();
     double *in = const_cast<double *>(a.scale_in);
     const double ck = __hip_atomic_load(in + 2 * K + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (blockIdx.x == 0 && a.scale_out) {
+    if (doc_block(a) == 0 && a.scale_out) {
         a.scale_out[k] = __hip_atomic_load(in + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         a.scale_out[K + k] = __hip_atomic_load(in + K + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         a.scale_out[2 * K + k] = ck;
@@ -833,7 +866,7 @@ __global__ __launch_bounds__(T) void estep_docs_kernel(DocKernelArgs a)
     const int wid = tid / kWave;
     constexpr int W = T / kWave;
 
-    const int d = a.order ? a.order[blockIdx.x] : blockIdx.x;
+    const int d = a.order ? a.order[doc_block(a)] : doc_block(a);
     const int K = a.K;
     const int p0 = a.indptr[d];
     const int n = a.indptr[d + 1] - p0;
@@ -1025,10 +1058,11 @@ struct PreArgs {
     unsigned int *c_counter;
 };
 
-// the preamble workgroups of a document-kernel launch (blockIdx.x >= pre.n_docs)
-__device__ __forceinline__ void docs_launch_preamble(const PreArgs &pre, double *lds)
+// the preamble workgroups of a document-kernel launch (block >= pre.n_docs, counted from the
+// first document workgroup)
+__device__ __forceinline__ void docs_launch_preamble(const PreArgs &pre, double *lds, int block)
 {
-    preamble_fused_body<kRegThreads>((int)blockIdx.x - pre.n_docs, pre.nb, lds, pre.K, pre.V, pre.G,
+    preamble_fused_body<kRegThreads>(block - pre.n_docs, pre.nb, lds, pre.K, pre.V, pre.G,
                                      pre.wpb, pre.total, pre.lambda, pre.partial, pre.u, pre.active,
                                      0, nullptr, 0, nullptr, nullptr, pre.c_out, pre.c_counter,
                                      lds + kRegThreads);
@@ -1070,11 +1104,12 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
     // One load gives (document, length, CSR offset); the word ids sit at an address that
     // depends on the workgroup index only, so they are fetched at the same time: two dependent
     // memory latencies (descriptor | ids -> rows) instead of four (order -> indptr -> ids -> rows)
-    const int4 meta = reinterpret_cast<const int4 *>(a.pad_meta)[(size_t)blockIdx.x * a.meta_i4];
+    const int bid = doc_block(a);
+    const int4 meta = reinterpret_cast<const int4 *>(a.pad_meta)[(size_t)bid * a.meta_i4];
     [[maybe_unused]] int4 seg = make_int4(0, 1, 0, 0);
     if constexpr (SPLIT)
-        seg = reinterpret_cast<const int4 *>(a.pad_meta)[(size_t)blockIdx.x * a.meta_i4 + 1];
-    const int32_t *__restrict__ pids = a.pad_ids + (size_t)blockIdx.x * kRegMaxN;
+        seg = reinterpret_cast<const int4 *>(a.pad_meta)[(size_t)bid * a.meta_i4 + 1];
+    const int32_t *__restrict__ pids = a.pad_ids + (size_t)bid * kRegMaxN;
     const int myid = pids[wid * JC + min(lane, JC - 1)];   // word wid * JC + i of the document
     const int d = meta.x, n = meta.y, p0 = meta.z;
     const int32_t *__restrict__ cnts = a.cnts + p0;
@@ -1087,7 +1122,7 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
         ak0 = a.alpha[tid];
         if (a.scale_in && !a.scale_wait) {           // finished by the launch that prepared them
             ck0 = a.scale_in[2 * K + tid];
-            if (blockIdx.x == 0 && a.scale_out) {
+            if (bid == 0 && a.scale_out) {
                 a.scale_out[tid] = a.scale_in[tid];
                 a.scale_out[K + tid] = a.scale_in[K + tid];
                 a.scale_out[2 * K + tid] = ck0;
@@ -1440,7 +1475,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if ((int)blockIdx.x >= pre.n_docs) {             // block-uniform
-        docs_launch_preamble(pre, lds);
+        docs_launch_preamble(pre, lds, (int)blockIdx.x);
         return;
     }
     estep_docs_reg_body<MODE>(a, lds);
@@ -1725,7 +1760,7 @@ __device__ __forceinline__ void finish_partial_groups(const UpdateOut &o, int K,
     __shared__ int last_of_group;
     const int g = bid / o.group_size;
     const int r0 = g * o.group_size, r1 = min(rows, r0 + o.group_size);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this thread's row stores: acknowledged
+    stores_acknowledged();
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned int seen = __hip_atomic_fetch_add(&o.group_counter[g], 1u, __ATOMIC_RELAXED,
@@ -1784,7 +1819,7 @@ __device__ __forceinline__ void segment_finish(const UpdateOut &o, const VeryLon
             sum += wpart[c * K + k];
         __hip_atomic_store(vl.seg_partial + row * K + k, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // this thread's row stores: acknowledged
+    stores_acknowledged();
     __syncthreads();
     if (tid == 0) {
         const unsigned int seen = __hip_atomic_fetch_add(vl.seg_counter + tk.x, 1u, __ATOMIC_RELAXED,

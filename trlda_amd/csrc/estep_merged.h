@@ -25,10 +25,11 @@
 //     combines its rows in groups behind a last-block-done counter, 3 us at its end
 //     (profiles/r04_timeline_nogroup_fused.txt).
 //
-// The document workgroups come FIRST in the grid and the host only takes this path when all of
-// them are resident at once (kMergedMaxDocWgs), so nothing they wait for (the topic factors) can
-// be queued behind them, and the helpers never hold a CU a document needs: a document workgroup
-// fills a CU's registers, a helper can only go where no document runs.
+// Order in the grid = order of dispatch: topic factors, documents, (next batch's preamble,)
+// statistics -- nothing waits for a workgroup behind it, so the launch makes progress whatever
+// part of it is resident (see the kernels at the end of this file).  The host takes this path for
+// launches whose documents fit the device at once (kMergedMaxDocWgs and the CU count), because
+// only then do the helpers run UNDER the documents; that is a matter of speed, not of safety.
 //
 // Arithmetic: a word's entries are added in document order by ONE wave, four at a time in flight,
 // exactly as word_segment_sum2 does (estep_kernels.h, 4d); a word of more than 16 entries is cut
@@ -47,8 +48,10 @@ constexpr int kMergedFlagStride = 16;   // unsigned ints between two waiters' fl
 constexpr int kMergedMaxHelpers = 512;  // flags of the statistics workgroups
 
 struct MergedArgs {
-    int first;                    // helper workgroups start here (documents + next-batch preamble before)
-    int n_comb, n_short, n_long;  // [first ..) topic factors | words of <= 16 entries | longer lists
+    int first;                    // the statistics workgroups start here, counted from the first document
+                                  // workgroup (documents + next-batch preamble before)
+    int n_comb, n_short, n_long;  // topic factors (the FIRST workgroups of the grid) | words of <= 16
+                                  // entries | longer lists
     // topic factors of THIS E-step from the block rows the previous M-step left (n_comb > 0)
     const double *c_rows;         // c_n x K
     int c_n;
@@ -90,7 +93,7 @@ __device__ __forceinline__ void docs_done_signal(const DocKernelArgs &a)
     if (!a.done_counter)                             // launch-uniform
         return;
     __shared__ int last_doc;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // this thread's stores: acknowledged
+    stores_acknowledged();                           // this thread's epg / tw_word stores have left
     __syncthreads();
     if (threadIdx.x == 0)
         last_doc = __hip_atomic_fetch_add(a.done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u ==
@@ -139,7 +142,7 @@ __device__ __forceinline__ void merged_combine(const MergedArgs &mg, int vb, dou
         __hip_atomic_store(mg.c_out + 2 * K + k, exp(-ps), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __shared__ int last_comb;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    stores_acknowledged();                           // c_out has left before the count
     __syncthreads();
     if (tid == 0)
         last_comb = __hip_atomic_fetch_add(mg.c_ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u ==
@@ -176,6 +179,7 @@ __device__ __forceinline__ void merged_wait_docs(const MergedArgs &mg, int vb, u
             break;
         }
     }
+    flag_seen();                                     // (no load of the data above the flag's)
     if (mg.tstamps && threadIdx.x == 0)
         mg.tstamps[3 * vb + 1] = __builtin_amdgcn_s_memrealtime();
     // No cache invalidation here.  An agent-scope acquire (buffer_inv sc1) per wave is two thousand
@@ -401,39 +405,46 @@ __device__ __forceinline__ void merged_stats(const MergedArgs &mg, int vb, doubl
         o.partial[(size_t)vb * K + tid] = rsl;
 }
 
-// the workgroups past the documents and the next batch's preamble
-__device__ __forceinline__ void merged_helper(const MergedArgs &mg, double *lds)
+// the statistics workgroups: past the documents and the next batch's preamble
+__device__ __forceinline__ void merged_helper(const MergedArgs &mg, double *lds, int vb)
 {
-    const int vb = (int)blockIdx.x - mg.first;
-    if (vb < mg.n_comb) {
-        merged_combine(mg, vb, lds);
-        return;
-    }
     if (mg.tstamps && threadIdx.x == 0)
-        mg.tstamps[3 * (vb - mg.n_comb)] = __builtin_amdgcn_s_memrealtime();
-    merged_stats(mg, vb - mg.n_comb, lds);
+        mg.tstamps[3 * vb] = __builtin_amdgcn_s_memrealtime();
+    merged_stats(mg, vb, lds);
     if (mg.tstamps && threadIdx.x == 0)
-        mg.tstamps[3 * (vb - mg.n_comb) + 2] = __builtin_amdgcn_s_memrealtime();
+        mg.tstamps[3 * vb + 2] = __builtin_amdgcn_s_memrealtime();
 }
 
 // diagnostics: a document workgroup's [start, end of its document, counted]
 __device__ __forceinline__ void merged_doc_stamp(const MergedArgs &mg, int which)
 {
     if (mg.tstamps && threadIdx.x == 0)
-        mg.tstamps[3 * (512 + blockIdx.x) + which] = __builtin_amdgcn_s_memrealtime();
+        mg.tstamps[3 * (512 + (int)blockIdx.x - mg.n_comb) + which] = __builtin_amdgcn_s_memrealtime();
 }
 
+// Grid of a merged launch: [0, n_comb) topic factors | documents | the next batch's preamble
+// (pre.nb) | statistics (n_short + n_long).  Workgroups are dispatched in this order, and nothing
+// waits for anything behind it: the topic-factor workgroups wait for nothing, a document only for
+// them, a statistics workgroup only for the documents.  So a merged launch ends whatever part of it
+// is resident at a time -- on a device with fewer CUs than document workgroups, or beside another
+// stream's kernels, it is slower, never stuck (round 4 had the topic factors BEHIND the
+// documents and relied on every document being resident at once).
 template <int MODE>
 __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_merged_kernel(DocKernelArgs a, PreArgs pre,
                                                                              MergedArgs mg)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    if ((int)blockIdx.x >= mg.first) {               // block-uniform
-        merged_helper(mg, lds);
+    if ((int)blockIdx.x < mg.n_comb) {               // block-uniform
+        merged_combine(mg, (int)blockIdx.x, lds);
         return;
     }
-    if ((int)blockIdx.x >= pre.n_docs) {
-        docs_launch_preamble(pre, lds);
+    const int rel = (int)blockIdx.x - mg.n_comb;     // == doc_block(a): a.block0 = mg.n_comb
+    if (rel >= mg.first) {
+        merged_helper(mg, lds, rel - mg.first);
+        return;
+    }
+    if (rel >= pre.n_docs) {
+        docs_launch_preamble(pre, lds, rel);
         return;
     }
     merged_doc_stamp(mg, 0);
@@ -448,24 +459,29 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_tiered_merged_kernel(D
                                                                                 int lds_rows, MergedArgs mg)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    if ((int)blockIdx.x >= mg.first) {               // block-uniform
-        merged_helper(mg, lds);
+    if ((int)blockIdx.x < mg.n_comb) {               // block-uniform
+        merged_combine(mg, (int)blockIdx.x, lds);
         return;
     }
-    if ((int)blockIdx.x >= pre.n_docs) {
-        docs_launch_preamble(pre, lds);
+    const int rel = (int)blockIdx.x - mg.n_comb;
+    if (rel >= mg.first) {
+        merged_helper(mg, lds, rel - mg.first);
+        return;
+    }
+    if (rel >= pre.n_docs) {
+        docs_launch_preamble(pre, lds, rel);
         return;
     }
     merged_doc_stamp(mg, 0);
-    const int n = a.pad_meta[4 * (size_t)blockIdx.x * a.meta_i4 + 1];
-    if (a.meta_i4 == 2 && a.pad_meta[4 * ((size_t)blockIdx.x * 2 + 1) + 1] > 1) {
+    const int n = a.pad_meta[4 * (size_t)rel * a.meta_i4 + 1];
+    if (a.meta_i4 == 2 && a.pad_meta[4 * ((size_t)rel * 2 + 1) + 1] > 1) {
         estep_docs_reg_body<0, true>(a, lds);        // one segment of a document split over CUs
     } else if (n <= 128) {
         estep_docs_reg_body<0>(a, lds);
     } else if (n <= 144) {
         estep_docs_reg_body<1>(a, lds);
     } else {
-        const int4 meta = reinterpret_cast<const int4 *>(a.pad_meta)[(size_t)blockIdx.x * a.meta_i4];
+        const int4 meta = reinterpret_cast<const int4 *>(a.pad_meta)[(size_t)rel * a.meta_i4];
         estep_docs_wide_body<KS, true>(a, lds_rows, lds, meta.x, meta.z, meta.y);
     }
     merged_doc_stamp(mg, 1);

@@ -294,7 +294,7 @@ __device__ __forceinline__ void estep_docs_wide_body(const DocKernelArgs &a, int
         if constexpr (FACTORS) {
             if (a.scale_in && !a.scale_wait) {       // finished by the launch that prepared them
                 ck = a.scale_in[2 * K + tid];
-                if (blockIdx.x == 0 && a.scale_out) {
+                if (doc_block(a) == 0 && a.scale_out) {
                     a.scale_out[tid] = a.scale_in[tid];
                     a.scale_out[K + tid] = a.scale_in[K + tid];
                     a.scale_out[2 * K + tid] = ck;
@@ -633,7 +633,7 @@ template <int KS, bool FACTORS = false>
 __global__ __launch_bounds__(kWideThreads) void estep_docs_wide_kernel(DocKernelArgs a, int lds_rows)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int d = a.order[blockIdx.x];
+    const int d = a.order[doc_block(a)];
     const int p0 = a.indptr[d];
     estep_docs_wide_body<KS, FACTORS>(a, lds_rows, lds, d, p0, a.indptr[d + 1] - p0);
 }
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_tiered_kernel(DocKerne
     static_assert(kRegThreads == kWideThreads, "one workgroup shape for every tier");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if ((int)blockIdx.x >= pre.n_docs) {             // block-uniform
-        docs_launch_preamble(pre, lds);
+        docs_launch_preamble(pre, lds, (int)blockIdx.x);
         return;
     }
     // (document, length, CSR offset, 0) [, (segment, segments, exchange row, document length)]

@@ -199,6 +199,8 @@ struct trlda_batch {
     // decreasing length (a wave's words of one round are then about equally long)
     int32_t *mdesc = nullptr;       // n_active x 4
     int n_short = 0;
+    int max_list = 0;               // entries of the longest word list (repeated ids within a document
+                                    // are legal, lda.cpp:108: a list can be longer than B)
     // very long lists (estep_kernels.h, VeryLongArgs): words of more than seg_len entries, by word
     // id -- (word, first task, segments, 0) -- and their segment tasks (word index, segment, first
     // entry, entries)
@@ -1350,14 +1352,17 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
     // this batch's preamble may have been left behind by the kernel that wrote lambda (the
     // M-step inside the statistics kernel: UpdateOut::u_out / group_rows) ...
     // Merged launch (estep_merged.h): how many workgroups the documents of this launch take, and
-    // whether helper workgroups may ride on it -- only when every document workgroup is resident
-    // at once (they come first in the grid and may wait for a helper)
+    // whether helper workgroups ride on it
     const size_t xcount_m = (size_t)db->n_xrows * (size_t)(max_iter + 1) * (size_t)K;
     const bool will_split = db->max_n > 128 && m->split_docs && db->n_wg > 0 && db->split_pays &&
                             max_iter > 0 && xcount_m * sizeof(double) <= ((size_t)256 << 20);
     const int doc_wgs = will_split ? db->n_wg : B;
+    // (... a matter of speed: the helpers run UNDER the documents only when the documents leave
+    // CUs free -- a document workgroup fills one.  Safety does not depend on it: estep_merged.h)
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device);
     const bool merged_capable = m->merged_launch > 0 && fused && !atomic && !dp && B > 0 &&
-                                doc_wgs <= trlda::kMergedMaxDocWgs;
+                                doc_wgs <= std::min(trlda::kMergedMaxDocWgs, cus - 32);
     bool handed = fused && carried && m->carry_pending && m->next_pre.valid &&
                   m->next_pre.version == m->lambda_version &&
                   (m->next_pre.all || m->next_pre.batch_id == b->id);
@@ -1526,7 +1531,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         a.partial = (fused || fused_big) ? partial_in : nullptr;
         a.scale_in = fused_big ? m->psi_sum : prefetched ? m->scale_pp[cur_buf] : nullptr;
         a.done_counter = nullptr; a.scale_wait = nullptr; a.done_target = 0;
-        a.go_flags = nullptr; a.n_go = 0;
+        a.go_flags = nullptr; a.n_go = 0; a.block0 = 0;
         a.epoch = m->merged_epoch + 1u;              // (of this launch, if it turns out to be merged)
         if (comb) {                                  // finished by workgroups of this launch
             a.scale_in = m->scale_comb;
@@ -1722,10 +1727,11 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
             // The statistics (and what rides on them: M-step, row sums, the next preamble) as
             // workgroups of this launch (estep_merged.h): small batches whose words' lists the
             // stage's waves hold in one piece, pairs of topics per lane
-            int cus = 256;
-            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, m->device);
+            // (a long list goes to the stage's sixteen chunks of at most 16 entries: 256 entries --
+            // a list can be longer than B when ids repeat within documents)
             const bool merged_stats = merged_capable && n_wgs == doc_wgs && K % 2 == 0 && m->pair_gathers &&
-                                      b->long_len == trlda::kLongWord && b->B <= 256 && b->n_active > 0 &&
+                                      b->long_len == trlda::kLongWord && b->B <= 256 && b->max_list <= 256 &&
+                                      b->n_active > 0 &&
                                       fused_update_available(m) &&
                                       (out.upd.lambda ? out.active_only
                                                       : sstats_dev != nullptr && m->merged_launch >= 2);
@@ -1790,6 +1796,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                                            : reinterpret_cast<const void *>(estep_docs_tiered_merged_kernel<2>);
                 if ((rc = ensure_dynamic_lds(mk, lds_bytes)))
                     return rc;
+                a.block0 = mg.n_comb;                // the topic-factor workgroups come first
                 const dim3 grid((unsigned)(mg.first + n_help));
                 if (!tiered)
                     hipLaunchKernelGGL(estep_docs_reg_merged_kernel<0>, grid, dim3(kRegThreads), lds_bytes,
@@ -2559,9 +2566,10 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     {
         int32_t *active = I(o_active), *longw = I(o_long);
         uint8_t *flag = reinterpret_cast<uint8_t *>(h + o_flag);
-        int na = 0, nl = 0;
+        int na = 0, nl = 0, longest = 0;
         for (int w = 0; w < V; ++w) {
             const int len = wptr[(size_t)w + 1] - wptr[(size_t)w];
+            longest = std::max(longest, len);
             flag[w] = len > 0;
             if (len > 0)
                 active[na++] = w;
@@ -2569,6 +2577,7 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
                 longw[nl++] = w;
         }
         b->long_host.assign(longw, longw + nl);
+        b->max_list = longest;
         // the very long lists: equal segments of at most seg_len entries
         int32_t *vw = I(o_vlw), *vt = I(o_vlt);
         int j = 0, t = 0;
