@@ -39,6 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+SETTLE_MIN_S, SETTLE_MAX_S = 0.03, 0.3   # the untimed settle phase in front of the first timed region
 FP64_PEAK_TFLOPS = 78.6        # fp64 vector: half the 157.3 TF fp32 vector peak of the same guide
 KERNEL_NAMES = ["rowsum_partial_kernel", "exp_elog_beta_kernel", "estep_docs_kernel",
                 "sstats_words_kernel"]
@@ -113,6 +114,9 @@ def parse():
     ap.add_argument("--repeats", type=int, default=7,
                     help="the timed region (--steps steps) is run this many times back to back; "
                          "the median is reported, min / max beside it")
+    ap.add_argument("--no-settle", action="store_true",
+                    help="skip the untimed settle phase in front of the first timed region (clock ramp "
+                         "after the set-up; reported as settle_steps / settle_ms)")
     ap.add_argument("--launch-timeout", type=float, default=1500.,
                     help="`--gpus N` without a launcher starts the N ranks itself; seconds after "
                          "which it ends them and fails")
@@ -605,6 +609,43 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+
+    def settle(**kw):
+        """An UNTIMED, declared settle phase in front of a timed leg: `--warmup
+        5` is 0.2 ms of device work after seconds of host-side set-up, and the first timed region
+        then runs on a GPU whose clocks are still on their way up -- in round 4's driver run the
+        same fixed work measured 43.4 us per step in the first leg and 39.9 two legs later.  Steps
+        of the same stream of mini-batches, in samples of min(--steps, 20), until two consecutive
+        samples agree within 2 % and at least SETTLE_MIN_S have passed, at most SETTLE_MAX_S; the
+        decision is taken on the maximum over ranks, so every rank runs the same number of steps.
+        `warmup` in the result line stays what was asked for; this phase is reported beside it
+        (`settle_steps`, `settle_ms`) and `--no-settle` switches it off."""
+        if args.no_settle:
+            return {"settle_steps": 0, "settle_ms": 0.0}
+        chunk, total, n, last = max(1, min(args.steps, 20)), 0.0, 0, None
+        while True:
+            fence()
+            first = pos[0]
+            pos[0] += chunk
+            t0 = time.perf_counter()
+            for i in range(first, first + chunk):
+                step(i, **kw)
+            fence()
+            dt = time.perf_counter() - t0
+            if collective and not vworld:
+                t = torch.tensor([dt], dtype=torch.float64, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            total += dt
+            n += chunk
+            agree = last is not None and abs(dt - last) <= 0.02 * max(dt, last)
+            last = dt
+            if (agree and total >= SETTLE_MIN_S) or total >= SETTLE_MAX_S:
+                break
+        return {"settle_steps": n, "settle_ms": round(1e3 * total, 3),
+                "settle_last_ms_per_step": round(1e3 * last / chunk, 5)}
+
+    settled = settle()
     # the timed region, `--repeats` times back to back: the median is the result (20 steps of
     # 40 us are under a millisecond -- one scheduling hiccup moves a single sample by 10 %)
     samples = sorted(timed() for _ in range(max(1, args.repeats)))
@@ -953,6 +994,11 @@ def main():
                    "word_sharded_m_step": word_sharded if collective else None,
                    "virtual_world": vworld or None},
         "repeats": repeats,
+        # the untimed, declared settle phase in front of the first timed region (settle(), above)
+        "settle_steps": settled["settle_steps"], "settle_ms": settled["settle_ms"],
+        "settle": dict(settled, rule="samples of min(steps, 20) steps until two consecutive ones agree "
+                                     "within 2 %% and %g s have passed, at most %g s; untimed; --no-settle "
+                                     "switches it off" % (SETTLE_MIN_S, SETTLE_MAX_S)),
         "value_no_prefetch": value_no_prefetch,
         "value_fixed_work": value_fixed_work,
         "rccl_ranks": rccl_ranks,

@@ -65,6 +65,19 @@ def test_bench_line_contract(hip_lib):
         j["repeats"]["ms_per_step_max"]
     u = j["update_parameters"]
     assert u["device_batch_tr10"]["ms_per_call"] > u["device_batch_tr0"]["ms_per_call"]
+    # the untimed, declared settle phase in front of the first timed region:
+    # its keys, its bounds (30 ms .. 0.3 s + one sample), whole samples of min(steps, 20) steps --
+    # and what it is for: the first timed leg runs at the speed of the later ones
+    assert j["warmup"] == 3                                      # (what was asked, not what settled)
+    assert j["settle_steps"] > 0 and j["settle_steps"] % 10 == 0
+    assert 30.0 <= j["settle_ms"] <= 400.0
+    assert j["settle"]["settle_steps"] == j["settle_steps"] and "rule" in j["settle"]
+    assert abs(fw["ms_per_step"] - j["ms_per_step"]) < 0.05 * j["ms_per_step"]
+
+
+def test_bench_without_the_settle_phase(hip_lib):
+    j = run_bench("--no-settle", "--no-cpu-baseline", "--no-update-rates", "--headline-only")
+    assert j["settle_steps"] == 0 and j["settle_ms"] == 0.0
 
 
 def test_bench_forced_distributed_line(hip_lib):

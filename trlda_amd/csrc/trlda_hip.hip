@@ -141,11 +141,16 @@ struct trlda_batch {
     // stream settles the first one on the spot
     hipStream_t last_stream = nullptr;
     bool last_owned = false;      // last_stream is a model's own stream (see live_own_streams)
-    // the stream `done` was last recorded on (null: never recorded).  The runtime follows an event
-    // back to the stream object that recorded it -- a wait on an event whose stream has been
-    // destroyed writes into freed host memory (tools/probes/event_stream_probe.hip; found by the
-    // round-4 fuzz run as a document count that changed under a later model) -- so an event is
-    // waited on, recorded again or recycled only while that stream exists (stream_alive)
+    // the stream `done` was last recorded on (null: never recorded).  Round 4's fuzz run found a
+    // caller's array changed under the library, and a watchpoint build put the write inside
+    // hipEventQuery on a guard event whose recording stream had been destroyed
+    // (profiles/r04_fuzz_watchpoint.txt).  The stand-alone probe (tools/probes/event_stream_probe.hip,
+    // profiles/r04_event_stream_probe.txt) does NOT reproduce it -- 0 bytes written in all twelve
+    // orders -- so the mechanism inside the runtime is inferred, not shown; the rule the library
+    // keeps is the conservative one: an event is waited on, queried, recorded again or recycled
+    // only while the stream that recorded it exists (stream_alive), and every event a model's own
+    // stream has recorded is destroyed BEFORE that stream is (purge_stream_guards: cached
+    // allocations' guards, spare events, live batches' `done`)
     hipStream_t done_on = nullptr;
     bool done_on_owned = false;
     bool ready_seen = false;      // the upload has been seen complete: no more waits
@@ -445,7 +450,20 @@ struct UploadContext {
     };
     std::vector<Blob> cache;
     size_t cached_bytes = 0;
-    std::vector<hipEvent_t> events;   // spare events
+    // spare events, each with the stream its last record sits on (null: never recorded, or the
+    // upload stream, which lives as long as the process)
+    struct Spare {
+        hipEvent_t ev;
+        hipStream_t on;
+        bool on_owned;
+    };
+    std::vector<Spare> events;
+    std::set<trlda_batch *> live;     // batches that exist (their `done` may sit on a model's stream)
+    void spare(hipEvent_t ev, hipStream_t on = nullptr, bool owned = false)
+    {
+        if (ev)
+            events.push_back(Spare{ev, owned ? on : nullptr, owned});
+    }
 };
 
 UploadContext &upload_context(int device)
@@ -465,8 +483,8 @@ constexpr size_t kBlobCacheBytes = (size_t)1 << 30;
 
 int take_event(UploadContext &u, hipEvent_t *ev)
 {
-    if (!u.events.empty()) {
-        *ev = u.events.back();
+    if (!u.events.empty()) {                         // (none of them sits on a stream that is gone:
+        *ev = u.events.back().ev;                    // purge_stream_guards)
         u.events.pop_back();
         return TRLDA_OK;
     }
@@ -508,8 +526,8 @@ bool batch_settle(trlda_batch *b)
     if (!stream_alive(b->last_stream, b->last_owned))
         return false;                                // stream gone, its work complete
     if (b->done_on && !stream_alive(b->done_on, b->done_on_owned)) {
-        // the event's previous record sits on a stream that no longer exists: a fresh event
-        // (the old one is dropped, not destroyed: neither call is known to stay off that stream)
+        // (cannot happen since purge_stream_guards replaces the `done` of every live batch when a
+        // model's stream goes; kept as the second line: a fresh event, the old one dropped)
         hipEvent_t fresh = nullptr;
         if (hipEventCreateWithFlags(&fresh, hipEventDisableTiming) != hipSuccess)
             return false;
@@ -533,6 +551,28 @@ void purge_stream_guards(int device, hipStream_t s)
             c.done = nullptr;
             c.on = nullptr;
             c.on_owned = false;
+        }
+    // spare events whose last record sits on it (they were handed out and recorded
+    // again after the stream had gone)
+    size_t kept = 0;
+    for (size_t i = 0; i < u.events.size(); ++i) {
+        if (u.events[i].on_owned && u.events[i].on == s)
+            (void)hipEventDestroy(u.events[i].ev);
+        else
+            u.events[kept++] = u.events[i];
+    }
+    u.events.resize(kept);
+    // live batches: the stream is synchronised, so whatever it read of them is complete -- their
+    // `done` gets a fresh, unrecorded event (batch_settle then has nothing to replace or leak)
+    for (trlda_batch *b : u.live)
+        if (b->done && b->done_on_owned && b->done_on == s) {
+            hipEvent_t fresh = nullptr;
+            if (hipEventCreateWithFlags(&fresh, hipEventDisableTiming) != hipSuccess)
+                fresh = nullptr;
+            (void)hipEventDestroy(b->done);
+            b->done = fresh;
+            b->done_on = nullptr;
+            b->done_on_owned = false;
         }
 }
 
@@ -888,9 +928,12 @@ bool mstep_keeps_positive(const trlda_model *m, const trlda::UpdateOut &u, const
 {
     if (!b->cnts_nonneg || !(u.scale >= 0.) || !(u.rho >= 0.) || !(u.omr >= 0.))
         return false;
-    if (u.rho * u.eta > 0.)
-        return true;
+    // (rho eta > 0 alone does not do it: omr * lambda' with a caller's lambda that has elements
+    // <= 0 can outweigh it -- ADVICE r4; the reference's digamma takes its reflection branch there,
+    // exp_digamma_positive does not)
     const bool own = u.lambda_prime == m->lambda || (u.lambda_prime && u.lambda_prime == m->lambda_prime);
+    if (u.rho * u.eta > 0.)
+        return !u.lambda_prime || u.omr == 0. || (own && m->lambda_positive);
     return own && u.omr > 0. && m->lambda_positive;
 }
 
@@ -2685,7 +2728,7 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     hipError_t err = hipSuccess;
     if (blob.done && stream_alive(blob.on, blob.on_owned)) {   // the previous owner's last reader
         err = hipStreamWaitEvent(u.stream, blob.done, 0);
-        u.events.push_back(blob.done);
+        u.spare(blob.done, blob.on, blob.on_owned);
     }                                                // (else: that stream and its work are gone; the event is dropped)
     if (err == hipSuccess)
         err = hipMemcpyAsync(b->blob, st.host, total, hipMemcpyHostToDevice, u.stream);
@@ -2717,6 +2760,7 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     b->n_short = n_active - n_long;
     b->vl_word = D(o_vlw); b->vl_task = D(o_vlt); b->vl_task_tiled = D(o_vltt);
     b->n_vl = n_vl; b->n_vl_tasks = n_vl_tasks; b->seg_len = seg_len;
+    u.live.insert(b);
     *out = b;
     return TRLDA_OK;
 }
@@ -2739,12 +2783,14 @@ int trlda_batch_destroy(trlda_batch *b)
         // (`ready`, recorded on the upload stream, which lives as long as the process); a batch
         // whose last stream is gone needs none -- and its `done` event, if that stream recorded
         // it, is dropped rather than recycled
+        u.live.erase(b);
         hipEvent_t guard = b->used ? (settled ? b->done : nullptr) : b->ready;
-        hipEvent_t spare = b->used ? b->ready : b->done;
-        if (spare)
-            u.events.push_back(spare);
+        if (b->used)
+            u.spare(b->ready);                       // (recorded on the upload stream only)
+        else
+            u.spare(b->done, b->done_on, b->done_on_owned);
         if (b->used && !settled && b->done && stream_alive(b->done_on, b->done_on_owned))
-            u.events.push_back(b->done);             // never recorded, or on a stream that exists
+            u.spare(b->done, b->done_on, b->done_on_owned);   // never recorded, or on a stream that exists
         UploadContext::Blob blob{b->blob, b->blob_bytes, guard};
         if (b->used && settled) {
             blob.on = b->done_on;
@@ -2755,8 +2801,7 @@ int trlda_batch_destroy(trlda_batch *b)
             u.cached_bytes += b->blob_bytes;
         } else {
             (void)hipFree(b->blob);                  // waits for the device: nothing reads it after
-            if (guard)
-                u.events.push_back(guard);
+            u.spare(guard, blob.on, blob.on_owned);
         }
     }
     delete b;
