@@ -114,6 +114,9 @@ def parse():
     ap.add_argument("--repeats", type=int, default=7,
                     help="the timed region (--steps steps) is run this many times back to back; "
                          "the median is reported, min / max beside it")
+    ap.add_argument("--no-deferred", action="store_true",
+                    help="every step launches its own statistics kernel (round 4's step) instead of "
+                         "leaving them to the next step's document launch")
     ap.add_argument("--no-settle", action="store_true",
                     help="skip the untimed settle phase in front of the first timed region (clock ramp "
                          "after the set-up; reported as settle_steps / settle_ms)")
@@ -437,6 +440,12 @@ def main():
         RHO, D_TOTAL = 1.0, None
 
     prefetch = not collective and not args.no_prefetch
+    # Deferred statistics (include/trlda_hip.h, trlda_model_set_deferred_stats): the headline is a
+    # stream of E-steps on a fixed lambda; the statistics of step i ride on step i + 1's document
+    # launch.  Every fence() flushes what is pending BEFORE the clock stops, so a timed region of
+    # K steps holds K statistics stages: K - 1 inside document launches + the last one as a kernel.
+    deferred = prefetch and not args.no_deferred
+    _ffi.check(L.trlda_model_set_deferred_stats(model, int(deferred)))
     exchange_probe = None
     if exchange == "factors" and not vworld and (world > 1 or force_dist):
         # One check of the factor path against the trusted composition (E-step on the shard,
@@ -583,6 +592,7 @@ def main():
                                            D_TOTAL / float(B * (1 if solo else world)) if D_TOTAL else 1.))
 
     def fence():
+        _ffi.check(L.trlda_model_flush(model))       # deferred statistics: enqueued now, waited for below
         if collective and not vworld:
             dist.barrier()
         torch.cuda.synchronize()
@@ -728,6 +738,10 @@ def main():
     # events' share of every interval: taken out, so that the figures agree with rocprofv3's
     # kernel durations (profiles/*_kernel_stats.csv).
     event_pair_us = kernel_us.pop()
+    carried = bool(deferred and L.trlda_model_last_deferred(model) & 2)
+    if carried:
+        # one launch per step: the other intervals hold no kernel (two event records back to back)
+        kernel_us = [0.0, 0.0, kernel_us[2], 0.0]
     launches = [u for u in kernel_us if u > 0.5 * event_pair_us]
     step_us = 1e6 * elapsed / args.steps
     event_us = 0.0
@@ -769,10 +783,22 @@ def main():
         pre_bytes = float(np.mean([8. * K * V + 16. * K * len(np.unique(c.ids)) for c in csrs]))
     docs_only_bytes = docs_bytes
     docs_bytes = docs_bytes + pre_bytes
+    # ... and, with deferred statistics, the statistics of the step before: exp(psi(lambda)) of
+    # its active words in, K x V statistics out, the rows of exp(psi(gamma)) gathered once per
+    # entry + (document, weight) per entry (kernel 4) -- together with the
+    # two shares above one whole E-step of SURVEY.md 8(d)'s bytes_alg per launch
+    stats_bytes = 0.0
+    if carried:
+        stats_bytes = float(np.mean([8. * K * len(np.unique(c.ids)) + 8. * K * V +
+                                     (8. * K + 12.) * float(c.indptr[-1]) for c in csrs]))
+        docs_bytes = min(docs_bytes + stats_bytes, estep_bytes)
+        stats_bytes = docs_bytes - docs_only_bytes - pre_bytes
     achieved = docs_bytes / (docs_us * 1e-6) / 1e9 if docs_us > 0 else 0.0
     traffic, traffic_src = None, None
     # the document stage under the name rocprofv3 lists it by (profiles/*_kernel_stats.csv)
     doc_kernel = (L.trlda_model_last_doc_kernel(model) or b"estep_docs_kernel").decode()
+    if carried:                                      # (estep_merged.h: the launch that also carries statistics)
+        doc_kernel = doc_kernel.replace("_kernel", "_deferred_kernel")
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
@@ -799,6 +825,9 @@ def main():
             # ... or as workgroups [n_docs, ..) of the previous step's document-kernel launch
             kernel_pairs = [(doc_kernel + " (documents of this step + preamble workgroups for "
                              "the next step's batch)", kernel_us[2])] + kernel_pairs[2:]
+        if carried:
+            kernel_pairs = [(doc_kernel + " (documents of this step + preamble workgroups for the next "
+                             "step's batch + statistics workgroups for the step before)", kernel_us[2])]
     roofline = {
         "bound": "hbm", "kernel": "trlda::" + doc_kernel,
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -813,7 +842,8 @@ def main():
         "traffic_in_run": False,
         "traffic_source": traffic_src,
         "algorithmic_bytes_per_launch": docs_bytes,
-        "algorithmic_bytes_split": {"documents": docs_only_bytes, "next_batch_preamble": pre_bytes},
+        "algorithmic_bytes_split": {"documents": docs_only_bytes, "next_batch_preamble": pre_bytes,
+                                    "previous_batch_statistics": stats_bytes},
         "avg_launch_us": round(docs_us, 2),
         "method": "HIP events on the launch stream around every launch in a replay of the timed "
                   "steps, minus the events' own share (replay time over timed time, per launch)",
@@ -969,6 +999,10 @@ def main():
                    "preamble": ("prepared by extra workgroups of the previous step's document-kernel "
                                 "launch (trlda_model_estep_io_next)" if prefetch else
                                 "a kernel launch of its own every step"),
+                   "statistics": ("formed by extra workgroups of the NEXT step's document-kernel launch "
+                                  "(trlda_model_set_deferred_stats); the last step's by a kernel of their "
+                                  "own, inside the timed region" if carried else
+                                  "a kernel launch of its own every step"),
                    "parallelism": "dp%d" % world,
                    "exchange_via": (("trlda_model_estep_dp (direct: peers' buffers through hipIpc, a step "
                                      "counter per source)" if exchange == "factors" and direct else

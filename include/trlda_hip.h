@@ -272,6 +272,27 @@ int trlda_model_estep_io_next(trlda_model *model, const trlda_batch *batch, cons
                               int max_iter, double threshold, int32_t *iters_dev);
 int trlda_model_set_prefetch(trlda_model *model, int enabled);
 
+/* Deferred statistics for a STREAM of E-steps on an unchanged lambda (a corpus pass of
+ * LDA::updateVariablesVI calls, src/lda.cpp:160-220: the statistics of one call, :207-217, feed
+ * nothing of the next).  With the switch on, trlda_model_estep_io_next returns once its document
+ * launch is enqueued; the statistics of that call are formed by extra workgroups of the NEXT
+ * trlda_model_estep_io_next call's document launch (on the CUs a 200-document batch leaves idle:
+ * a step is then one launch), and are written into the `sstats_dev` THAT call was given.  They
+ * are complete -- enqueued on the model's stream ahead of everything that follows -- after the
+ * next trlda_model_estep_io_next call or after ANY other call on the model (trlda_model_flush,
+ * trlda_model_synchronize, an update, trlda_model_destroy, trlda_batch_destroy of the batch): a
+ * caller that reads `sstats_dev` on the stream after one E-step and before the next calls
+ * trlda_model_flush first.  gamma and the iteration counts are written by the call itself, as
+ * always.  The sums and their order are those of the kernel of its own: bitwise the same
+ * statistics.  Same range as the announcement above (small tables, K <= 128 even, batches of at
+ * most 256 documents); elsewhere, and for whatever cannot ride along, the statistics are launched
+ * as their own kernel.  Off by default: the Python classes never turn it on.
+ * trlda_model_last_deferred: bit 0 = the last E-step left its statistics pending, bit 1 = its
+ * launch formed the statistics of the call before. */
+int trlda_model_set_deferred_stats(trlda_model *model, int enabled);
+int trlda_model_flush(trlda_model *model);
+int trlda_model_last_deferred(const trlda_model *model);
+
 /* Host-pointer convenience around trlda_model_estep (uploads gamma0, downloads
  * gamma / sstats / iters, synchronises). */
 int trlda_model_estep_host(trlda_model *model, const trlda_batch *batch,

@@ -256,6 +256,10 @@ __device__ __forceinline__ double2 merged_update_pair(const UpdateOut &o, size_t
     return lam;
 }
 
+// DEFER: the stage works on the PREVIOUS E-step's outputs (a fixed-lambda stream of E-steps,
+// trlda_model_set_deferred_stats): nothing of this launch is waited for, no flag is looked at, the
+// weights are ordinary loads, and there is no M-step (o.lambda is null by construction).
+template <bool DEFER = false>
 __device__ __forceinline__ void merged_stats(const MergedArgs &mg, int vb, double *lds)
 {
     constexpr int W = kRegThreads / kWave;           // 8 waves
@@ -268,10 +272,12 @@ __device__ __forceinline__ void merged_stats(const MergedArgs &mg, int vb, doubl
     const int kk = min(2 * lane, K - 2);             // this lane's pair of topics (K even)
     const bool k_on = 2 * lane < K;
     const int n_stat = mg.n_short + mg.n_long;
-    const unsigned int seen = merged_flag_load(mg, vb);          // (requested before everything else)
+    [[maybe_unused]] unsigned int seen = 0u;
+    if constexpr (!DEFER)
+        seen = merged_flag_load(mg, vb);             // (requested before everything else)
 
     // columns of the words outside the batch: zero (lda.cpp:169), written while the documents run
-    if (mg.active_flag && o.sstats && !o.lambda) {   // launch-uniform
+    if (mg.active_flag && o.sstats && (DEFER || !o.lambda)) {   // launch-uniform
         for (int w = vb * W + wid; w < mg.V; w += n_stat * W)
             if (!mg.active_flag[w] && k_on)
                 *reinterpret_cast<double2 *>(o.sstats + (size_t)w * K + 2 * lane) = make_double2(0.0, 0.0);
@@ -301,32 +307,42 @@ __device__ __forceinline__ void merged_stats(const MergedArgs &mg, int vb, doubl
                 docs[j] = lane < len[j] ? mg.wdoc[q0[j] + lane] : -1;       // -1: the zero row
                 const size_t ic = (size_t)wv[j] * K + kk;
                 e2[j] = *reinterpret_cast<const double2 *>(mg.eeb + ic);
-                lp[j] = o.lambda_prime ? *reinterpret_cast<const double2 *>(o.lambda_prime + ic)
-                                       : make_double2(0.0, 0.0);
+                lp[j] = (!DEFER && o.lambda_prime) ? *reinterpret_cast<const double2 *>(o.lambda_prime + ic)
+                                                   : make_double2(0.0, 0.0);
                 acc[j] = make_double2(0.0, 0.0);
             }
-            if (!waited) {
-                merged_wait_docs(mg, vb, seen);
-                waited = true;
+            if constexpr (!DEFER) {
+                if (!waited) {
+                    merged_wait_docs(mg, vb, seen);
+                    waited = true;
+                }
             }
             double tw[NW];
 #pragma unroll
-            for (int j = 0; j < NW; ++j)
-                tw[j] = lane < len[j] ? __hip_atomic_load(const_cast<double *>(mg.tw_word) + q0[j] + lane,
-                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                      : 0.0;
+            for (int j = 0; j < NW; ++j) {
+                if constexpr (DEFER)
+                    tw[j] = lane < len[j] ? mg.tw_word[q0[j] + lane] : 0.0;
+                else
+                    tw[j] = lane < len[j] ? __hip_atomic_load(const_cast<double *>(mg.tw_word) + q0[j] + lane,
+                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                          : 0.0;
+            }
             merged_segments<NW>(docs, tw, maxlen, mg.epg, K, kk, acc);
 #pragma unroll
             for (int j = 0; j < NW; ++j) {
                 if (len[j] > 0 && k_on) {            // (len: wave-uniform)
                     const double2 s = make_double2(acc[j].x * e2[j].x, acc[j].y * e2[j].y);
-                    const double2 lam = merged_update_pair(o, (size_t)wv[j] * K + 2 * lane, s, lp[j]);
-                    rs.x += lam.x;
-                    rs.y += lam.y;
+                    if constexpr (DEFER) {
+                        *reinterpret_cast<double2 *>(o.sstats + (size_t)wv[j] * K + 2 * lane) = s;
+                    } else {
+                        const double2 lam = merged_update_pair(o, (size_t)wv[j] * K + 2 * lane, s, lp[j]);
+                        rs.x += lam.x;
+                        rs.y += lam.y;
+                    }
                 }
             }
         }
-        if (o.partial) {                             // launch-uniform
+        if (!DEFER && o.partial) {                   // launch-uniform
             if (k_on)
                 *reinterpret_cast<double2 *>(lds + wid * K + 2 * lane) = rs;
             __syncthreads();
@@ -365,17 +381,23 @@ __device__ __forceinline__ void merged_stats(const MergedArgs &mg, int vb, doubl
         // the documents still run (behind the barrier below they would be one more memory latency)
         const size_t i = (size_t)w * K + min(tid, K - 1);
         const double ek = mg.eeb[i];
-        const double lpk = o.lambda_prime ? o.lambda_prime[i] : 0.0;
-        if (!waited) {
-            merged_wait_docs(mg, vb, seen);
-            waited = true;
+        const double lpk = (!DEFER && o.lambda_prime) ? o.lambda_prime[i] : 0.0;
+        if constexpr (!DEFER) {
+            if (!waited) {
+                merged_wait_docs(mg, vb, seen);
+                waited = true;
+            }
         }
         double tw[2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-            tw[h] = lane < clen[h] ? __hip_atomic_load(const_cast<double *>(mg.tw_word) + base + c0[h] + lane,
-                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                   : 0.0;
+        for (int h = 0; h < 2; ++h) {
+            if constexpr (DEFER)
+                tw[h] = lane < clen[h] ? mg.tw_word[base + c0[h] + lane] : 0.0;
+            else
+                tw[h] = lane < clen[h] ? __hip_atomic_load(const_cast<double *>(mg.tw_word) + base + c0[h] + lane,
+                                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                       : 0.0;
+        }
         merged_segments<2>(docs, tw, max(clen[0], clen[1]), mg.epg, K, kk, acc);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -390,7 +412,7 @@ __device__ __forceinline__ void merged_stats(const MergedArgs &mg, int vb, doubl
             const double s = sum * ek;
             if (o.sstats)
                 o.sstats[i] = s;
-            if (o.lambda) {
+            if (!DEFER && o.lambda) {
                 const double hat = o.eta + o.scale * s;
                 const double lam = o.lambda_prime ? o.omr * lpk + o.rho * hat : o.rho * hat;
                 o.lambda[i] = lam;
@@ -401,7 +423,7 @@ __device__ __forceinline__ void merged_stats(const MergedArgs &mg, int vb, doubl
         }
         __syncthreads();
     }
-    if (o.partial && tid < K)
+    if (!DEFER && o.partial && tid < K)
         o.partial[(size_t)vb * K + tid] = rsl;
 }
 
@@ -487,6 +509,60 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_tiered_merged_kernel(D
     merged_doc_stamp(mg, 1);
     docs_done_signal(a);
     merged_doc_stamp(mg, 2);
+}
+
+// ---- deferred statistics: a stream of E-steps on an unchanged lambda -----------------------------
+// (trlda_model_set_deferred_stats; reference: consecutive LDA::updateVariablesVI calls of a corpus
+// pass, src/lda.cpp:160-220 -- the statistics of one call, :207-217, do not feed the next call.)
+// The statistics of E-step i are workgroups of E-step i + 1's document launch: grid = documents of
+// this step | preamble of the next step's batch (pre.nb) | statistics of the PREVIOUS step
+// (n_short + n_long workgroups, merged_stats<true>).  The previous step's launch has ended -- its
+// exp(psi(gamma)) rows and weights are ordinary memory -- so nobody waits for anybody; the helpers
+// run on the CUs the documents leave free (56 of 256 at 200 documents) and a step is ONE launch of
+// the documents' length.  Same sums in the same order as the kernel of its own
+// (sstats_update2_kernel): bitwise the same statistics (tests/test_gpu_deferred.py).
+template <int MODE>
+__global__ __launch_bounds__(kRegThreads) void estep_docs_reg_deferred_kernel(DocKernelArgs a, PreArgs pre,
+                                                                               MergedArgs mg)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int bid = (int)blockIdx.x;
+    if (bid >= mg.first) {                           // block-uniform
+        merged_stats<true>(mg, bid - mg.first, lds);
+        return;
+    }
+    if (bid >= pre.n_docs) {
+        docs_launch_preamble(pre, lds, bid);
+        return;
+    }
+    estep_docs_reg_body<MODE>(a, lds);
+}
+
+template <int KS>
+__global__ __launch_bounds__(kRegThreads) void estep_docs_tiered_deferred_kernel(DocKernelArgs a, PreArgs pre,
+                                                                                  int lds_rows, MergedArgs mg)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int bid = (int)blockIdx.x;
+    if (bid >= mg.first) {                           // block-uniform
+        merged_stats<true>(mg, bid - mg.first, lds);
+        return;
+    }
+    if (bid >= pre.n_docs) {
+        docs_launch_preamble(pre, lds, bid);
+        return;
+    }
+    const int n = a.pad_meta[4 * (size_t)bid * a.meta_i4 + 1];
+    if (a.meta_i4 == 2 && a.pad_meta[4 * ((size_t)bid * 2 + 1) + 1] > 1) {
+        estep_docs_reg_body<0, true>(a, lds);        // one segment of a document split over CUs
+    } else if (n <= 128) {
+        estep_docs_reg_body<0>(a, lds);
+    } else if (n <= 144) {
+        estep_docs_reg_body<1>(a, lds);
+    } else {
+        const int4 meta = reinterpret_cast<const int4 *>(a.pad_meta)[(size_t)bid * a.meta_i4];
+        estep_docs_wide_body<KS, true>(a, lds_rows, lds, meta.x, meta.z, meta.y);
+    }
 }
 
 }  // namespace trlda

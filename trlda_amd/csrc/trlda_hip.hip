@@ -204,6 +204,7 @@ struct trlda_batch {
     // decreasing length (a wave's words of one round are then about equally long)
     int32_t *mdesc = nullptr;       // n_active x 4
     int n_short = 0;
+    trlda_model *pending_in = nullptr;   // a model whose deferred statistics still read this batch
     int max_list = 0;               // entries of the longest word list (repeated ids within a document
                                     // are legal, lda.cpp:108: a list can be longer than B)
     // very long lists (estep_kernels.h, VeryLongArgs): words of more than seg_len entries, by word
@@ -246,8 +247,30 @@ struct trlda_model {
     // call's document-kernel launch (estep_kernels.h, PreArgs) in alternating buffers; valid for
     // that batch while lambda has not been written (lambda_version).
     uint64_t lambda_version = 1;
-    double *eeb_pp[2] = {nullptr, nullptr}, *partial_pp[2] = {nullptr, nullptr};
-    double *scale_pp[2] = {nullptr, nullptr};   // 3 K each: the finished topic factors (PreArgs::c_out)
+    // (three of each: with deferred statistics the batch before this one still reads its buffer)
+    double *eeb_pp[3] = {nullptr, nullptr, nullptr}, *partial_pp[3] = {nullptr, nullptr, nullptr};
+    double *scale_pp[3] = {nullptr, nullptr, nullptr};   // 3 K each: the finished topic factors (PreArgs::c_out)
+    // Deferred statistics (trlda_model_set_deferred_stats; estep_merged.h): in a stream of E-steps
+    // on an unchanged lambda (trlda_model_estep_io_next) the statistics of a call (lda.cpp:207-217)
+    // are not launched by that call -- they ride on the NEXT call's document launch, or are
+    // launched as the kernel of their own by whatever touches the model next (flush_pending:
+    // every entry point, trlda_model_flush, trlda_batch_destroy of the batch they read).  What the
+    // pending statistics read is kept apart from what the next call writes: exp(psi(gamma)) rows
+    // and weights in two alternating buffers, exp(psi(lambda)) of its batch in a third buffer.
+    bool deferred_stats = false;
+    struct {
+        bool valid = false;
+        const trlda_batch *batch = nullptr;
+        double *sstats = nullptr;         // the caller's K x V
+        double *epg = nullptr, *tw_word = nullptr;
+        double *eeb = nullptr;
+        int eeb_buf = -1;                 // index into eeb_pp, or -1: m->eeb
+    } pending;
+    double *dfr_epg_base[2] = {nullptr, nullptr}, *dfr_tw[2] = {nullptr, nullptr};
+    size_t dfr_cap_docs[2] = {0, 0}, dfr_cap_tw[2] = {0, 0};
+    int dfr_cur = 0;
+    bool last_deferred = false;           // the last E-step left its statistics pending
+    bool last_carried = false;            // ... / its launch carried the call before's
     struct {
         bool valid = false;
         uint64_t batch_id = 0, version = 0;
@@ -1074,6 +1097,44 @@ int sstats_update_device(trlda_model *m, const trlda_batch *b, EstepOut &out)
                     : launch_sstats_update<1024, 2, 0>(m, b, out);
 }
 
+// Deferred statistics: the statistics an E-step left pending (trlda_model::pending), as the
+// kernel of their own on the model's stream -- what the call itself would have launched, from the
+// buffers the call kept apart.  Every entry point that is not the next E-step of the stream gets
+// here first (check_model), so nobody ever sees a model with statistics outstanding.
+int flush_pending(trlda_model *m)
+{
+    if (!m->pending.valid)
+        return TRLDA_OK;
+    const auto p = m->pending;
+    m->pending.valid = false;
+    const_cast<trlda_batch *>(p.batch)->pending_in = nullptr;
+    double *epg = m->epg, *tw = m->tw_word, *eeb_cur = m->eeb_cur;
+    m->epg = p.epg; m->tw_word = p.tw_word; m->eeb_cur = p.eeb;
+    EstepOut out(p.sstats);
+    int rc = sstats_update_device(m, p.batch, out);
+    m->epg = epg; m->tw_word = tw; m->eeb_cur = eeb_cur;
+    if (!rc && hipGetLastError() != hipSuccess)
+        rc = fail(TRLDA_ERR_HIP, "the deferred statistics' launch failed");
+    if (!rc)
+        rc = batch_end(m, p.batch);
+    return rc;
+}
+
+// the two buffers the documents of a deferred E-step write into, in turn
+int ensure_deferred_workspace(trlda_model *m, const trlda_batch *b, int which)
+{
+    const size_t rows = (size_t)std::max(b->B, 1) + 1, K = (size_t)m->K;
+    int rc = TRLDA_OK;
+    if (rows * K > m->dfr_cap_docs[which] || !m->dfr_epg_base[which]) {
+        rc = grow(&m->dfr_epg_base[which], &m->dfr_cap_docs[which], rows * K);
+        if (!rc)                                     // row -1 is zero (estep_merged.h)
+            HIP_TRY(hipMemsetAsync(m->dfr_epg_base[which], 0, K * sizeof(double), m->stream));
+    }
+    if (!rc)
+        rc = grow(&m->dfr_tw[which], &m->dfr_cap_tw[which], (size_t)std::max<int64_t>(b->nnz, 1));
+    return rc;
+}
+
 // the give-up flag of the exchanges that poll (split documents, the direct slot exchange)
 int ensure_xerr(trlda_model *m)
 {
@@ -1434,6 +1495,30 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
             return rc;
     }
     m->prefetch.valid = false;
+
+    // Deferred statistics (trlda_model::pending).  launch_ok: this call is a plain E-step whose one
+    // document launch can take helper workgroups; defer_self: its own statistics wait for the next
+    // call; carry: its launch forms the statistics the call before left pending.  What cannot be
+    // carried is launched as the kernel of its own, now -- before anything of this call overwrites
+    // what it reads (the exp(psi(lambda)) buffer m->eeb, when this call fills it).
+    auto stage_fits = [&](const trlda_batch *x) {
+        return K % 2 == 0 && m->pair_gathers && x->long_len == trlda::kLongWord && x->B <= 256 &&
+               x->max_list <= 256 && x->n_active > 0 && x->V == V && x->device == m->device;
+    };
+    const bool launch_ok = m->deferred_stats && fused && !dp && !atomic && !out.upd.lambda && sstats_dev &&
+                           B > 0 && m->doc_threads == 0 && K <= kRegMaxK && m->doc_kernel == TRLDA_DOCS_AUTO &&
+                           fused_update_available(m) && !comb;
+    const bool defer_self = launch_ok && stage_fits(b);
+    const bool writes_eeb = !(prefetched || handed);
+    bool carry = false;
+    if (m->pending.valid) {
+        carry = launch_ok && stage_fits(m->pending.batch) && !(m->pending.eeb_buf < 0 && writes_eeb);
+        if (!carry && (rc = flush_pending(m)))
+            return rc;
+    }
+    m->last_deferred = false;
+    m->last_carried = carry;
+
     if (fused && !prefetched && !handed) {
         constexpr int TP = 512;
         int wpb = 0, GC = 0;
@@ -1568,6 +1653,15 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
             a.epg = m->dp_gather + (size_t)dp->rank * dp->slot;
             a.tw_word = a.epg + dp->tw_off;
             a.wrank = nullptr;
+        }
+        if (defer_self) {
+            // kept apart from what the next call writes: its launch reads them (estep_merged.h)
+            const int which = 1 - m->dfr_cur;
+            if ((rc = ensure_deferred_workspace(m, db, which)))
+                return rc;
+            m->dfr_cur = which;
+            a.epg = m->dfr_epg_base[which] + K;
+            a.tw_word = m->dfr_tw[which];
         }
         a.sstats_acc = atomic ? sstats_dev : nullptr;
         a.max_iter = max_iter; a.threshold = threshold; a.iters_out = iters_dev;
@@ -1729,7 +1823,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
             if (next && fused && n_reg == B && !out.upd.lambda && !atomic && next->V == V &&
                 next->device == m->device && next->B > 0 && !m->lambda_exposed && m->prefetch_next) {
                 if (!m->eeb_pp[0]) {
-                    for (int i = 0; i < 2 && !rc; ++i) {
+                    for (int i = 0; i < 3 && !rc; ++i) {
                         rc = dev_alloc(&m->eeb_pp[i], KV);
                         if (!rc) rc = dev_alloc(&m->partial_pp[i], (size_t)kRowsumBlocks * K);
                         if (!rc) rc = dev_alloc(&m->scale_pp[i], 3 * (size_t)K);
@@ -1741,7 +1835,10 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                 }
                 if ((rc = batch_begin(m, next)))
                     return rc;
-                const int nbuf = cur_buf == 0 ? 1 : 0;
+                // (not the buffer this batch reads, nor the one the carried statistics read)
+                int nbuf = 0;
+                while (nbuf == cur_buf || (carry && nbuf == m->pending.eeb_buf))
+                    ++nbuf;
                 const bool dense = m->dense_preamble;
                 pre.K = K; pre.V = V;
                 pre.G = std::min(kRowsumBlocks, std::max(1, V / 32));
@@ -1772,7 +1869,8 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
             // stage's waves hold in one piece, pairs of topics per lane
             // (a long list goes to the stage's sixteen chunks of at most 16 entries: 256 entries --
             // a list can be longer than B when ids repeat within documents)
-            const bool merged_stats = merged_capable && n_wgs == doc_wgs && K % 2 == 0 && m->pair_gathers &&
+            const bool merged_stats = !launch_ok &&
+                                      merged_capable && n_wgs == doc_wgs && K % 2 == 0 && m->pair_gathers &&
                                       b->long_len == trlda::kLongWord && b->B <= 256 && b->max_list <= 256 &&
                                       b->n_active > 0 &&
                                       fused_update_available(m) &&
@@ -1829,7 +1927,50 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                 mg.o = out.upd;
             }
             const int n_help = mg.n_comb + mg.n_short + mg.n_long;
-            if (n_help > 0) {
+            if (carry) {
+                // the statistics of the call before as workgroups of this launch (estep_merged.h,
+                // deferred statistics): from the buffers that call kept apart, into its caller's array
+                const trlda_batch *pb = m->pending.batch;
+                MergedArgs dg{};
+                dg.first = n_wgs + pre.nb;
+                dg.K = K; dg.V = V;
+                dg.N_short = pb->n_short; dg.N_long = pb->n_long;
+                static const int helper_cap = [] {
+                    const char *e = std::getenv("TRLDA_DEFER_WGS");
+                    return e ? std::max(2, std::atoi(e)) : 0;
+                }();
+                const int room = helper_cap > 0 ? helper_cap : std::min(cus, trlda::kMergedMaxHelpers);
+                dg.n_long = std::min(dg.N_long, room / 2);
+                dg.n_short = dg.N_short > 0
+                                 ? std::max(1, std::min((dg.N_short + 8 * trlda::kMergedNW - 1) / (8 * trlda::kMergedNW),
+                                                        room - dg.n_long))
+                                 : 0;
+                dg.desc = reinterpret_cast<const int4 *>(pb->mdesc);
+                dg.wdoc = pb->wdoc; dg.tw_word = m->pending.tw_word; dg.epg = m->pending.epg;
+                dg.eeb = m->pending.eeb;
+                dg.active_flag = pb->active_flag;
+                dg.o = trlda::UpdateOut{};
+                dg.o.sstats = m->pending.sstats;
+                const void *dk = !tiered ? reinterpret_cast<const void *>(estep_docs_reg_deferred_kernel<0>)
+                                 : KS == 1 ? reinterpret_cast<const void *>(estep_docs_tiered_deferred_kernel<1>)
+                                           : reinterpret_cast<const void *>(estep_docs_tiered_deferred_kernel<2>);
+                if ((rc = ensure_dynamic_lds(dk, lds_bytes)))
+                    return rc;
+                const dim3 grid((unsigned)(dg.first + dg.n_short + dg.n_long));
+                if (!tiered)
+                    hipLaunchKernelGGL(estep_docs_reg_deferred_kernel<0>, grid, dim3(kRegThreads), lds_bytes,
+                                       m->stream, a, pre, dg);
+                else if (KS == 1)
+                    hipLaunchKernelGGL(estep_docs_tiered_deferred_kernel<1>, grid, dim3(kRegThreads), lds_bytes,
+                                       m->stream, a, pre, lds_rows, dg);
+                else
+                    hipLaunchKernelGGL(estep_docs_tiered_deferred_kernel<2>, grid, dim3(kRegThreads), lds_bytes,
+                                       m->stream, a, pre, lds_rows, dg);
+                m->pending.valid = false;
+                const_cast<trlda_batch *>(pb)->pending_in = nullptr;
+                if ((rc = batch_end(m, pb)))
+                    return rc;
+            } else if (n_help > 0) {
                 if ((rc = ensure_xerr(m)))
                     return rc;
                 mg.xerr = m->xerr;
@@ -1885,6 +2026,17 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                            dim3(kDenseThreads), 0, m->stream, KV, FinishOp{m->eeb_cur, sstats_dev});
     } else if (m->last_merged && !dp) {
         // (statistics: workgroups of the document launch above)
+    } else if (defer_self) {
+        // (statistics: workgroups of the NEXT call's document launch, or flush_pending)
+        m->pending.valid = true;
+        m->pending.batch = b;
+        m->pending.sstats = sstats_dev;
+        m->pending.epg = m->dfr_epg_base[m->dfr_cur] + K;
+        m->pending.tw_word = m->dfr_tw[m->dfr_cur];
+        m->pending.eeb = m->eeb_cur;
+        m->pending.eeb_buf = prefetched ? cur_buf : -1;
+        const_cast<trlda_batch *>(b)->pending_in = m;
+        m->last_deferred = true;
     } else if (dp && dp->word_sharded && out.upd.lambda && !out.upd.sstats) {
         // Word-sharded M-step (data-parallel): statistics + M-step for THIS RANK's range of the
         // vocabulary only -- every rank holds all factors, so any rank can form any word's
@@ -2071,8 +2223,26 @@ void note_host_lambda(trlda_model *m, const double *host_lambda)
     m->rs_floor = 0.0;
     m->lambda_positive = false;
     const size_t K = (size_t)m->K, V = (size_t)m->V;
-    if (K * V >= ((size_t)1 << 22) || m->K > trlda::kRegMaxK)
+    if (K * V >= ((size_t)1 << 22) || m->K > trlda::kRegMaxK) {
+        // big tables: only "every element > 0" is needed (the M-step may then leave exp(psi(lambda))
+        // behind through the call-free exp_digamma_positive, mstep_keeps_positive) -- one pass on a
+        // few host threads while the copy to the device runs
+        const size_t total = K * V;
+        const int nt = (int)std::max<size_t>(1, std::min<size_t>(16, total >> 20));
+        std::vector<char> ok((size_t)nt, 1);
+        trlda_host::host_pool().run(nt, [&](int t) {
+            const size_t i0 = total * (size_t)t / (size_t)nt, i1 = total * (size_t)(t + 1) / (size_t)nt;
+            bool good = true;
+            for (size_t i = i0; i < i1; ++i)
+                good &= host_lambda[i] > 0.0;        // (NaN: false)
+            ok[(size_t)t] = good;
+        });
+        bool positive = true;
+        for (char c : ok)
+            positive = positive && c;
+        m->lambda_positive = positive;
         return;
+    }
     std::vector<double> sum(K, 0.0);
     bool positive = true;
     for (size_t w = 0; w < V; ++w)
@@ -2109,7 +2279,9 @@ int sync_model(trlda_model *m)
     return check_split_exchange(m);
 }
 
-int check_model(const trlda_model *m)
+// keep_pending: the caller is the next E-step of a deferred stream (it decides itself whether its
+// launch carries the pending statistics); everybody else finds none outstanding
+int check_model(const trlda_model *m, bool keep_pending = false)
 {
     if (!m)
         return fail(TRLDA_ERR_ARG, "model is NULL");
@@ -2117,7 +2289,10 @@ int check_model(const trlda_model *m)
     // allocator probes stream capture and leaves "operation not permitted when stream is
     // capturing" behind -- is not an error of the launches this entry point is about to check)
     (void)hipGetLastError();
-    return use_device(m->device);
+    int rc = use_device(m->device);
+    if (!rc && m->pending.valid && !keep_pending)
+        rc = flush_pending(const_cast<trlda_model *>(m));
+    return rc;
 }
 
 }  // namespace
@@ -2769,6 +2944,10 @@ int trlda_batch_destroy(trlda_batch *b)
 {
     if (!b)
         return TRLDA_OK;
+    // a model's deferred statistics still read this batch: they are launched first (the guard
+    // event below then covers them)
+    if (b->pending_in && hipSetDevice(b->device) == hipSuccess)
+        (void)flush_pending(b->pending_in);
     if (b->dp_wsrc && hipSetDevice(b->device) == hipSuccess) {
         (void)hipFree(b->dp_wsrc);                   // (waits for the device)
         (void)hipFree(b->dp_wrow);
@@ -2905,6 +3084,7 @@ int trlda_model_destroy(trlda_model *m)
     if (!m)
         return TRLDA_OK;
     if (hipSetDevice(m->device) == hipSuccess) {
+        (void)flush_pending(m);                      // deferred statistics: into the caller's array
         (void)hipStreamSynchronize(m->stream);
         if (m->draw_stream)
             (void)hipStreamSynchronize(m->draw_stream);
@@ -2944,8 +3124,11 @@ int trlda_model_destroy(trlda_model *m)
         }
         for (auto &e : m->ev_pool)
             (void)hipEventDestroy(e);
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 3; ++i) {
             (void)hipFree(m->eeb_pp[i]); (void)hipFree(m->partial_pp[i]); (void)hipFree(m->scale_pp[i]);
+        }
+        for (int i = 0; i < 2; ++i) {
+            (void)hipFree(m->dfr_epg_base[i]); (void)hipFree(m->dfr_tw[i]);
         }
         if (m->own_stream) {
             (void)hipStreamSynchronize(m->own_stream);
@@ -2959,6 +3142,8 @@ int trlda_model_destroy(trlda_model *m)
         }
 
     }
+    if (m->pending.valid)
+        const_cast<trlda_batch *>(m->pending.batch)->pending_in = nullptr;
     delete m;
     return TRLDA_OK;
 }
@@ -3157,13 +3342,36 @@ int trlda_model_estep_io_next(trlda_model *m, const trlda_batch *b, const trlda_
                               const double *gamma0_dev, double *gamma_dev, double *sstats_dev,
                               int max_iter, double threshold, int32_t *iters_dev)
 {
-    int rc = check_model(m);
+    // (the next E-step of a deferred stream: estep_device decides whether its launch carries the
+    // statistics the call before left pending, or launches them first)
+    int rc = check_model(m, true);
     if (rc)
         return rc;
-    if (!b || !sstats_dev || (b->B > 0 && (!gamma_dev || !gamma0_dev)))
+    if (!b || !sstats_dev || (b->B > 0 && (!gamma_dev || !gamma0_dev))) {
+        (void)flush_pending(m);
         return fail(TRLDA_ERR_ARG, "NULL batch / gamma / sstats");
+    }
     EstepOut out(sstats_dev);
-    return estep_device(m, b, gamma_dev, out, max_iter, threshold, iters_dev, gamma0_dev, next);
+    rc = estep_device(m, b, gamma_dev, out, max_iter, threshold, iters_dev, gamma0_dev, next);
+    if (rc && m->pending.valid)                      // a refused call leaves nothing outstanding
+        (void)flush_pending(m);
+    return rc;
+}
+
+int trlda_model_set_deferred_stats(trlda_model *m, int enabled)
+{
+    int rc = check_model(m);                         // (flushes what is pending)
+    if (rc)
+        return rc;
+    m->deferred_stats = enabled != 0;
+    return TRLDA_OK;
+}
+
+int trlda_model_flush(trlda_model *m) { return check_model(m); }
+
+int trlda_model_last_deferred(const trlda_model *m)
+{
+    return m ? (m->last_deferred ? 1 : 0) | (m->last_carried ? 2 : 0) : 0;
 }
 
 int trlda_model_set_prefetch(trlda_model *m, int enabled)
