@@ -8,10 +8,17 @@
  *
  * Prints the size-independent invariants the test checks:
  *   sum(sstats) = sum(counts);  sum(gamma) = sum(counts) + B sum(alpha);
- *   sum(lambda) after an update = (1 - rho) sum(lambda') + rho (K V eta + D/B sum(counts)). */
+ *   sum(lambda) after an update = (1 - rho) sum(lambda') + rho (K V eta + D/B sum(counts)).
+ *
+ * With a file name as its argument it first runs a GOLDEN VECTOR of the compiled reference
+ * (tests/golden/f1a_estep.npz, flattened by tests/test_gpu_c_client.py: documents, seeds of
+ * lambda and gamma0, alpha, and the reference's gamma / sstats / the oracle's iteration counts at
+ * max_iter = 20) through the one-shot entry AND through the handle API, and prints the largest
+ * relative error of gamma and of the statistics for each -- values, not only mass balances. */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "trlda_hip.h"
 
@@ -24,13 +31,99 @@
         }                                                                                \
     } while (0)
 
-int main(void)
+static double max_rel_err(const double *got, const double *want, size_t n, int *zeros_agree)
+{
+    double worst = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        if (want[i] == 0.0 || got[i] == 0.0) {       /* untouched words: exactly zero on both sides */
+            if (want[i] != got[i])
+                *zeros_agree = 0;
+            continue;
+        }
+        const double e = fabs(got[i] - want[i]) / fabs(want[i]);
+        worst = e > worst ? e : worst;
+    }
+    return worst;
+}
+
+/* file: int32 header {K, V, B, nnz, lambda_seed, gamma0_seed, max_iter, 0}, indptr[B + 1], ids[nnz],
+ * cnts[nnz] (int32), then doubles alpha[K], gamma[K B], sstats[K V], then int32 iters[B] */
+static int run_golden(const char *path)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f) {
+        fprintf(stderr, "cannot open %s\n", path);
+        return 1;
+    }
+    int32_t h[8];
+    if (fread(h, sizeof(int32_t), 8, f) != 8)
+        return 1;
+    const int K = h[0], V = h[1], B = h[2], nnz = h[3], max_iter = h[6];
+    int32_t *indptr = malloc((size_t)(B + 1) * sizeof(int32_t));
+    int32_t *ids = malloc((size_t)nnz * sizeof(int32_t)), *cnts = malloc((size_t)nnz * sizeof(int32_t));
+    int32_t *iters_want = malloc((size_t)B * sizeof(int32_t)), *iters = malloc((size_t)B * sizeof(int32_t));
+    double *alpha = malloc((size_t)K * sizeof(double));
+    double *g_want = malloc((size_t)K * B * sizeof(double)), *s_want = malloc((size_t)K * V * sizeof(double));
+    double *lambda = malloc((size_t)K * V * sizeof(double)), *gamma0 = malloc((size_t)K * B * sizeof(double));
+    double *gamma = malloc((size_t)K * B * sizeof(double)), *sstats = malloc((size_t)K * V * sizeof(double));
+    size_t ok = fread(indptr, sizeof(int32_t), (size_t)B + 1, f) == (size_t)B + 1;
+    ok = ok && fread(ids, sizeof(int32_t), (size_t)nnz, f) == (size_t)nnz;
+    ok = ok && fread(cnts, sizeof(int32_t), (size_t)nnz, f) == (size_t)nnz;
+    ok = ok && fread(alpha, sizeof(double), (size_t)K, f) == (size_t)K;
+    ok = ok && fread(g_want, sizeof(double), (size_t)K * B, f) == (size_t)K * B;
+    ok = ok && fread(s_want, sizeof(double), (size_t)K * V, f) == (size_t)K * V;
+    ok = ok && fread(iters_want, sizeof(int32_t), (size_t)B, f) == (size_t)B;
+    fclose(f);
+    if (!ok) {
+        fprintf(stderr, "short read on %s\n", path);
+        return 1;
+    }
+    trlda_seed((unsigned)h[4]);
+    trlda_sample_gamma_init(K, V, lambda);            /* srand(seed); sampleGamma(K, V, 100) / 100 */
+    trlda_seed((unsigned)h[5]);
+    trlda_sample_gamma_init(K, B, gamma0);
+
+    /* one shot, host pointers (LDA::updateVariables with latents, src/lda.cpp:142-220) */
+    memcpy(gamma, gamma0, (size_t)K * B * sizeof(double));
+    CHECK(trlda_estep(K, V, B, indptr, ids, cnts, lambda, alpha, gamma, sstats, max_iter, 1e-3, iters, 0));
+    int zeros = 1;
+    double ge = max_rel_err(gamma, g_want, (size_t)K * B, &zeros);
+    double se = max_rel_err(sstats, s_want, (size_t)K * V, &zeros);
+    printf("golden oneshot gamma_err %.3e sstats_err %.3e zeros_agree %d iters_equal %d\n", ge, se, zeros,
+           memcmp(iters, iters_want, (size_t)B * sizeof(int32_t)) == 0);
+
+    /* the handle API: resident model and batch */
+    trlda_model *model = NULL;
+    trlda_batch *batch = NULL;
+    CHECK(trlda_model_create(&model, 0, K, V));
+    CHECK(trlda_model_set_alpha(model, alpha));
+    CHECK(trlda_model_set_lambda(model, lambda));
+    CHECK(trlda_batch_create(&batch, 0, V, B, indptr, ids, cnts));
+    memcpy(gamma, gamma0, (size_t)K * B * sizeof(double));
+    memset(sstats, 0xff, (size_t)K * V * sizeof(double));
+    memset(iters, 0xff, (size_t)B * sizeof(int32_t));
+    CHECK(trlda_model_estep_host(model, batch, gamma, sstats, max_iter, 1e-3, iters));
+    zeros = 1;
+    ge = max_rel_err(gamma, g_want, (size_t)K * B, &zeros);
+    se = max_rel_err(sstats, s_want, (size_t)K * V, &zeros);
+    printf("golden handle gamma_err %.3e sstats_err %.3e zeros_agree %d iters_equal %d\n", ge, se, zeros,
+           memcmp(iters, iters_want, (size_t)B * sizeof(int32_t)) == 0);
+    CHECK(trlda_batch_destroy(batch));
+    CHECK(trlda_model_destroy(model));
+    free(indptr); free(ids); free(cnts); free(iters_want); free(iters); free(alpha); free(g_want);
+    free(s_want); free(lambda); free(gamma0); free(gamma); free(sstats);
+    return 0;
+}
+
+int main(int argc, char **argv)
 {
     enum { K = 50, V = 3000, B = 120, N = 80 };       /* N unique words per document */
     if (trlda_device_count() < 1) {
         fprintf(stderr, "no HIP device\n");
         return 2;
     }
+    if (argc > 1 && run_golden(argv[1]) != 0)
+        return 3;
     int32_t *indptr = malloc((B + 1) * sizeof(int32_t));
     int32_t *ids = malloc((size_t)B * N * sizeof(int32_t));
     int32_t *cnts = malloc((size_t)B * N * sizeof(int32_t));

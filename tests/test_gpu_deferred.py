@@ -134,6 +134,31 @@ def test_a_deferred_stream_equals_the_plain_one(hip, oracle, sampler, K, V, B):
         assert relerr(s[so > 0], so[so > 0]) < TIGHT_RTOL and np.array_equal(s == 0, so == 0)
 
 
+@pytest.mark.parametrize("K,V,B,n", [(100, 12, 60, 9), (10, 40, 256, 3), (128, 500, 200, 1)])
+def test_deferred_stage_corner_shapes(hip, oracle, sampler, K, V, B, n):
+    """Every list long (V = 12: the stage has no short-list workgroups, the long-list ones write the
+    zero columns), lists of up to 256 entries, one word per document."""
+    from trlda_amd import _ffi
+    lam = seeded_lambda(sampler, 3, K, V)
+    csrs = [corpus(B, V, seed=60 + i, lengths=np.full(B, n)) for i in range(3)]
+    g0s = [seeded_gamma(sampler, 70 + i, K, B) for i in range(3)]
+    m = make_model(K, V, lam)
+    _ffi.check(hip.trlda_model_set_deferred_stats(m._handle, 1))
+    dev = [m.upload(c) for c in csrs]
+    slots = [Slots(hip, K, V, c, g) for c, g in zip(csrs, g0s)]
+    flags = [estep(hip, m, dev, slots, i, (i + 1) % 3) for i in range(3)]
+    assert flags == [1, 3, 3], flags
+    _ffi.check(hip.trlda_model_synchronize(m._handle))
+    for i in range(3):
+        c = csrs[i]
+        go, so, ito = oracle.estep(lam, .1, c.indptr, c.ids, c.cnts, g0s[i], 20, 1e-3, nthreads=8)
+        g, s, it = slots[i].read()
+        assert np.array_equal(it, ito) and relerr(g, go) < TIGHT_RTOL
+        assert relerr(s[so > 0], so[so > 0]) < TIGHT_RTOL and np.array_equal(s == 0, so == 0)
+        slots[i].free()
+    m.close()
+
+
 def test_what_must_flush_does(hip, oracle, sampler):
     """The statistics of a deferred call are in their array after trlda_model_flush + a wait for
     the stream -- and after anything else that touches the model or the batch."""

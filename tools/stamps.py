@@ -14,8 +14,13 @@ L.trlda_debug_read_stamps.argtypes = [C.c_void_p, C.c_int]
 K, V, B = (int(os.environ.get(k, d)) for k, d in (("STAMPS_K", "100"), ("STAMPS_V", "7000"), ("STAMPS_B", "200")))
 WIDE = int(os.environ.get("STAMPS_WIDE", "0")) or K > 128 or int(os.environ.get("STAMPS_LEN", "0")) > 192
 LEN = int(os.environ.get("STAMPS_LEN", "0"))         # every document exactly this long
+ONE = int(os.environ.get("STAMPS_ONE", "0"))         # B - 1 documents of 100 words and one this long
+lengths = np.full(B, LEN) if LEN else None
+if ONE:
+    lengths = np.full(B, 100)
+    lengths[B // 2] = ONE
 indptr, ids, cnts = make_corpus(B, V, seed=20150707, mean_unique=int(os.environ.get("STAMPS_MEAN", "95")),
-                                lengths=np.full(B, LEN) if LEN else None)
+                                lengths=lengths)
 print("max doc length", np.diff(indptr).max())
 L.trlda_seed(1)
 m = OnlineLDA(V, K, 1000000)
@@ -32,6 +37,13 @@ for T in (0,):
     L.trlda_debug_read_stamps(buf.ctypes.data, B)
     m.update_variables(batch, latents=g0, max_iter=20, threshold=0.0)
     L.trlda_debug_read_stamps(buf.ctypes.data, B)
+    tot = buf.astype(np.float64).sum(axis=1)
+    print("kernel %s; slowest workgroup %.0f cycles, median %.0f" % (
+        L.trlda_model_last_doc_kernel(m._handle).decode(), tot.max(), np.median(tot)))
+    if ONE:
+        # (workgroups are in order of decreasing length: the long document is workgroup 0)
+        print("workgroup 0 (the %d-word document):" % ONE, " ".join("%.0f" % v for v in buf[0]))
+        buf = buf[1:]
     mean = buf.astype(np.float64).mean(axis=0)
     print("T=%d  total %.0f cycles/doc" % (T, mean.sum()))
     for i, nme in enumerate(names[:8]):

@@ -279,7 +279,28 @@ __global__ __launch_bounds__(T) void exp_elog_beta_kernel(
 // (vb, nb: this workgroup's index and the number of workgroups doing this job -- the kernel's
 // own grid, or the extra workgroups of a document-kernel launch that prepare the NEXT batch's
 // preamble, estep_docs_reg_kernel; red: T doubles of LDS)
-template <int T>
+// A deferred launch's helper publishes its NEXT item (estep_merged.h, deferred_helper) from inside
+// the current one, at a point where the item's loads have been consumed and none of its stores has
+// been issued: the value comes from an atomic issued before the item, the counter that orders
+// vector-memory operations is one per wave and in order, so reading it THERE waits for nothing that
+// is not waited for anyway -- at the item's end it would wait for the stores' acknowledgements.
+struct NoPublish {
+    __device__ __forceinline__ void operator()() const {}
+};
+struct PublishNext {
+    unsigned int *slot;           // LDS
+    unsigned int fetched, base;
+    __device__ __forceinline__ void operator()() const
+    {
+        if (threadIdx.x == 0)
+            *slot = fetched - base;
+    }
+};
+
+// FAT: the fill workgroups take 16 elements per thread, all their loads in flight before the first
+// exp(psi) (a deferred launch's helpers: one 512-thread workgroup per CU, so a workgroup's time is
+// its chain of memory latencies -- two passes of two dependent loads each cost four of them)
+template <int T, bool FAT = false, class Pub = NoPublish>
 __device__ __forceinline__ void preamble_fused_body(
     int vb, int nb, double *red, int K, int V, int G, int wpb, size_t total,
     const double *__restrict__ lambda, double *__restrict__ partial /* G x K */,
@@ -287,9 +308,10 @@ __device__ __forceinline__ void preamble_fused_body(
     const double *__restrict__ carry_rows /* carry_n x K */, int carry_n,
     const double *__restrict__ carry_base /* K or nullptr */, double *__restrict__ carry_out /* GC x K */,
     double *__restrict__ c_out = nullptr /* 3 K: psi(row sums), row sums, exp(-psi) */,
-    unsigned int *c_counter = nullptr, double *c_scratch = nullptr /* 8 K doubles of LDS */)
+    unsigned int *c_counter = nullptr, double *c_scratch = nullptr /* 8 K doubles of LDS */,
+    const Pub &pub = Pub(), int tid_bias = 0 /* see deferred_helper: an opaque zero */)
 {
-    const int tid = threadIdx.x;
+    const int tid = (int)threadIdx.x + tid_bias;
     // Row sums carried over from the kernel that wrote lambda, still in carry_n block partials
     // (sstats_update_kernel, or the streaming pass of the initial step): the first GC workgroups
     // add up a contiguous range of the rows each -- four threads per topic, eight loads in
@@ -312,6 +334,7 @@ __device__ __forceinline__ void preamble_fused_body(
             }
         }
         red[tid] = acc[0] + acc[1];
+        pub();
         __syncthreads();
         if (tid < K) {
             double sum = (red[tid] + red[128 + tid]) + (red[256 + tid] + red[384 + tid]);
@@ -343,6 +366,7 @@ __device__ __forceinline__ void preamble_fused_body(
             }
         }
         red[tid] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        pub();
         __syncthreads();
         if (tid < K) {
             double sum = red[tid];
@@ -415,6 +439,48 @@ __device__ __forceinline__ void preamble_fused_body(
     // their loads overlap
     // (total < 2^22 here: 32-bit index arithmetic, a 64-bit division costs as much as psi)
     const unsigned stride = (nb - lead) * T, tot = (unsigned)total, Ku = (unsigned)K;
+    if constexpr (FAT) {
+        constexpr int U = 16;
+        for (unsigned i0 = (vb - lead) * T + tid; i0 < tot; i0 += U * stride) {
+            size_t idx[U];
+            double l[U];
+            unsigned a[U];
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                const unsigned i = min(i0 + q * stride, tot - 1u);
+                a[q] = i / Ku;
+                idx[q] = i - a[q] * Ku;
+            }
+            if (active) {                            // launch-uniform
+                int w[U];
+#pragma unroll
+                for (int q = 0; q < U; ++q)
+                    w[q] = active[a[q]];
+#pragma unroll
+                for (int q = 0; q < U; ++q)
+                    idx[q] += (size_t)w[q] * K;
+            } else {
+#pragma unroll
+                for (int q = 0; q < U; ++q)
+                    idx[q] += (size_t)a[q] * K;
+            }
+#pragma unroll
+            for (int q = 0; q < U; ++q)
+                l[q] = lambda[idx[q]];
+#pragma unroll
+            for (int q = 0; q < U; ++q)
+                l[q] = exp_digamma(l[q]);
+            if (i0 == (vb - lead) * T + tid)         // (first pass: every load consumed, no store issued)
+                pub();
+#pragma unroll
+            for (int q = 0; q < U; ++q)
+                if (i0 + q * stride < tot)
+                    u[idx[q]] = l[q];
+        }
+        if ((vb - lead) * T + tid >= tot)            // (a thread without a pass: thread 0 has one whenever
+            pub();                                   //  the workgroup has any element; else publish here)
+        return;
+    }
     for (unsigned i = (vb - lead) * T + tid; i < tot; i += 2 * stride) {
         const unsigned i2 = i + stride;
         const bool two = i2 < tot;
@@ -428,6 +494,7 @@ __device__ __forceinline__ void preamble_fused_body(
         if (two)
             u[idx2] = u2;
     }
+    pub();
 }
 
 template <int T>
@@ -1060,12 +1127,14 @@ struct PreArgs {
 
 // the preamble workgroups of a document-kernel launch (block >= pre.n_docs, counted from the
 // first document workgroup)
-__device__ __forceinline__ void docs_launch_preamble(const PreArgs &pre, double *lds, int block)
+template <bool FAT = false, class Pub = NoPublish>
+__device__ __forceinline__ void docs_launch_preamble(const PreArgs &pre, double *lds, int block,
+                                                     const Pub &pub = Pub(), int tid_bias = 0)
 {
-    preamble_fused_body<kRegThreads>(block - pre.n_docs, pre.nb, lds, pre.K, pre.V, pre.G,
+    preamble_fused_body<kRegThreads, FAT, Pub>(block - pre.n_docs, pre.nb, lds, pre.K, pre.V, pre.G,
                                      pre.wpb, pre.total, pre.lambda, pre.partial, pre.u, pre.active,
                                      0, nullptr, 0, nullptr, nullptr, pre.c_out, pre.c_counter,
-                                     lds + kRegThreads);
+                                     lds + kRegThreads, pub, tid_bias);
 }
 
 // One document = one workgroup: the body of estep_docs_reg_kernel<MODE>, also instantiated by

@@ -80,6 +80,12 @@ struct MergedArgs {
     unsigned int *c_flags;        // one per document workgroup
     unsigned int epoch;
     int n_docs;                   // document workgroups of the launch (flags to set)
+    // deferred launch: the short / long lists by length class, longest first (the descriptors are
+    // sorted by decreasing length): entries 9..16 | 5..8 | 3..4 | 1..2 of a short list, chunks (a
+    // sixteenth of a long list, rounded up) of 9..16 | 5..8 | 3..4 | 1..2 entries
+    int cls_short[4], cls_long[4];
+    unsigned int *work_counter;   // deferred launch: the helpers' item counter (only grows) ...
+    unsigned int work_base;       // ... and its value at the start of the launch
     unsigned long long *tstamps;  // diagnostics (TRLDA_MERGED_STAMPS=1, tools/merged_stamps.py) or nullptr:
                                   // s_memrealtime (100 MHz, one clock for the chip) of [start, flag seen,
                                   // end] per statistics workgroup, then [start, end of the document,
@@ -197,7 +203,7 @@ __device__ __forceinline__ void merged_wait_docs(const MergedArgs &mg, int vb, u
 // epg[doc_u, 2 lane .. 2 lane + 1] in entry order, four rows per segment in flight per round.
 // docs[j]: lane u holds the document of entry u (or -1, the zero row); `maxlen`: the longest of
 // the segments (wave-uniform): rounds past it are skipped.
-template <int NS>
+template <int NS, int R = 4, int MAXLEN = 16>
 __device__ __forceinline__ void merged_segments(const int (&docs)[NS], const double (&tw)[NS], int maxlen,
                                                 const double *__restrict__ epg, int K, int kk,
                                                 double2 (&acc)[NS])
@@ -209,20 +215,20 @@ __device__ __forceinline__ void merged_segments(const int (&docs)[NS], const dou
         thi[j] = __double2hiint(tw[j]);
     }
 #pragma unroll
-    for (int r = 0; r < 16; r += 4) {
+    for (int r = 0; r < MAXLEN; r += R) {
         if (r < maxlen) {                            // wave-uniform
-            double2 ev[NS][4];
+            double2 ev[NS][R];
 #pragma unroll
             for (int j = 0; j < NS; ++j)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < R; ++u) {
                     const long long row = (long long)__builtin_amdgcn_readlane(docs[j], r + u) * K;
                     ev[j][u] = *reinterpret_cast<const double2 *>(epg + row + kk);
                 }
 #pragma unroll
             for (int j = 0; j < NS; ++j)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < R; ++u) {
                     const double tu = __hiloint2double(__builtin_amdgcn_readlane(thi[j], r + u),
                                                        __builtin_amdgcn_readlane(tlo[j], r + u));
                     acc[j].x = fma(tu, ev[j][u].x, acc[j].x);   // (+0 * 0 past a segment's end)
@@ -511,6 +517,249 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_tiered_merged_kernel(D
     merged_doc_stamp(mg, 2);
 }
 
+// ---- the statistics stage of a deferred launch ---------------------------------------------------
+// merged_stats<true> does the job (and did, in the first form of the deferred launch: 34.3 us per
+// launch where the documents alone take 30.9 -- profiles/r05_deferred_first.txt).  What differs
+// here is what bounds it: nobody waits for a flag, so there is no idle time that hides anything;
+// the helpers (this stage + the next batch's preamble) share the ~56 CUs the documents leave free,
+// ONE 512-thread workgroup per CU at a time (the launch's registers are the documents'), and a
+// workgroup lasts as long as its chain of dependent memory latencies -- ~1 us each.  The stamps of
+// that first form (profiles/r05_deferred_stamps_first.txt) show workgroups of 4 to 11 us, the
+// longest the ones whose words have the longest lists: merged_segments walks a list four rows at
+// a time, a list of 16 entries is four dependent rounds of gathers.  Here every workgroup is ONE
+// round: the lists are in classes by length (they are sorted by it), and a wave takes as many
+// words of a class as keep 16 rows (16-byte gathers per lane) in flight --
+//     entries   9..16 | 5..8 | 3..4 | 1..2          chunk of a long list  9..16 | 5..8 | 3..4 | 1..2
+//     words / wave  1 |   2  |   4  |   8          lists / workgroup          1  |   1  |   2  |   4
+// -- so a workgroup is: descriptors -> (documents, weights, exp(psi(lambda))) -> rows -> store.
+// The zero columns of the words outside the batch: a wave reads 64 flags with ONE load and writes
+// the zeros of those that are clear.  The sums and their order are unchanged (a word's entries in
+// document order; long lists in the sixteen chunks of the 1024-thread kernel, combined in chunk
+// order): bitwise the statistics of sstats_update2_kernel.
+constexpr int kDeferShortNW[4] = {1, 2, 4, 8};   // words per wave, by class
+constexpr int kDeferLongLW[4] = {1, 1, 2, 4};    // lists per workgroup, by class
+constexpr int kDeferLog2R[4] = {4, 3, 2, 1};     // log2 of the longest list / chunk of a class
+
+// workgroups the stage takes for a batch with these class counts (host and device agree through it)
+__host__ __device__ inline int deferred_short_items(const int (&c)[4])
+{
+    int n = 0;
+    for (int i = 0; i < 4; ++i)
+        n += (c[i] + 8 * kDeferShortNW[i] - 1) / (8 * kDeferShortNW[i]);
+    return n;
+}
+__host__ __device__ inline int deferred_long_items(const int (&c)[4])
+{
+    int n = 0;
+    for (int i = 0; i < 4; ++i)
+        n += (c[i] + kDeferLongLW[i] - 1) / kDeferLongLW[i];
+    return n;
+}
+
+// ONE code path for every class: a wave has 16 SLOTS, slot s = (segment s >> lr, entry s & (R - 1)),
+// R = 1 << lr the class's longest list (wave-uniform at run time).  Lane l < 16 looks after slot l:
+// it fetches its segment's descriptor, then the document and the weight of its entry (all
+// addresses per lane: no arrays indexed at run time); the 16 rows are gathered through v_readlane
+// with constant lane numbers and added up slot by slot -- a segment's entries in order -- into one
+// running pair that is finished and reset at every segment boundary (a wave-uniform test).
+// (Eight instantiations of the array form, one per class, spilled 60 to 90 vector registers of
+// the whole launch.)
+//
+// short lists: the wave's words [t, t + (16 >> lr)) below t_end
+template <class Pub>
+__device__ __forceinline__ void deferred_short_wave(const MergedArgs &mg, int t, int t_end, int lr, int lane,
+                                                    int kk, bool k_on, const Pub &pub)
+{
+    const int K = mg.K;
+    const int R = 1 << lr;
+    const int sl = min(lane, 15), j = sl >> lr, u = sl & (R - 1);
+    const bool w_on = t + j < t_end;
+    const int4 d = mg.desc[min(t + j, t_end - 1)];                  // (word, first entry, entries, 0)
+    const bool on = lane < 16 && w_on && u < d.z;
+    const int q = on ? d.y + u : 0;
+    const int doc = on ? mg.wdoc[q] : -1;                           // -1: the zero row
+    const double tw = on ? mg.tw_word[q] : 0.0;
+    const int tlo = __double2loint(tw), thi = __double2hiint(tw);
+    const int wword = w_on ? d.x : -1;
+    // exp(psi(lambda)) of the segments' words: requested with the rows
+    double2 e2[8];                                   // (R >= 2: segments start at even slots)
+#pragma unroll
+    for (int s0 = 0; s0 < 16; s0 += 2) {
+        if ((s0 & (R - 1)) == 0) {                   // wave-uniform: a segment starts here
+            const int w = max(__builtin_amdgcn_readlane(wword, s0), 0);
+            e2[s0 >> 1] = *reinterpret_cast<const double2 *>(mg.eeb + (size_t)w * K + kk);
+        }
+    }
+    double2 ev[16];
+#pragma unroll
+    for (int s0 = 0; s0 < 16; ++s0) {
+        const long long row = (long long)__builtin_amdgcn_readlane(doc, s0) * K;
+        ev[s0] = *reinterpret_cast<const double2 *>(mg.epg + row + kk);
+    }
+    pub();                                           // (every load requested, no store issued yet)
+    double2 acc = make_double2(0.0, 0.0), ec = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int s0 = 0; s0 < 16; ++s0) {
+        if ((s0 & 1) == 0 && (s0 & (R - 1)) == 0)    // (the segment's exp(psi(lambda)): constant index --
+            ec = e2[s0 >> 1];                        // an index computed at run time would put e2 in scratch)
+        const double tu = __hiloint2double(__builtin_amdgcn_readlane(thi, s0), __builtin_amdgcn_readlane(tlo, s0));
+        acc.x = fma(tu, ev[s0].x, acc.x);            // (+0 * 0 past a list's end)
+        acc.y = fma(tu, ev[s0].y, acc.y);
+        if (((s0 + 1) & (R - 1)) == 0) {             // wave-uniform: the segment ends here
+            const int w = __builtin_amdgcn_readlane(wword, s0);
+            if (w >= 0 && k_on)
+                *reinterpret_cast<double2 *>(mg.o.sstats + (size_t)w * K + 2 * lane) =
+                    make_double2(acc.x * ec.x, acc.y * ec.y);
+            acc = make_double2(0.0, 0.0);
+        }
+    }
+}
+
+// long lists: LW = 16 >> (lr + 1) lists [t, t + LW) (below t_end; indices into the long
+// descriptors) per workgroup and pass; a list is cut into the sixteen chunks of the 1024-thread
+// kernel (chunk = ceil(L / 16) <= R entries), wave `wid` walks chunks wid and wid + 8 of each list:
+// segment g = (list g >> 1, half g & 1).  The longest class (chunks of 9..16 entries) takes the
+// two halves in two passes.  Thread (i, k) = (tid / TPW, tid % TPW) finishes topic k of list i.
+template <class Pub>
+__device__ __forceinline__ void deferred_long_group(const MergedArgs &mg, int t, int t_end, int lr, double *lds,
+                                                    int tid, int lane, int wid, int kk, bool k_on, const Pub &pub)
+{
+    const int K = mg.K;
+    const int R = 1 << lr;
+    const bool two_pass = lr == 4;                   // one list, its two chunks one after the other
+    const int LW = two_pass ? 1 : 16 >> (lr + 1);
+    const int TPW = kRegThreads / LW;                // >= 128 >= K
+    const int fi = tid / TPW, fk = tid % TPW;
+    // the epilogue's operands: requested first
+    const int4 df = mg.desc[mg.N_short + min(t + fi, t_end - 1)];
+    const bool fin_on = t + fi < t_end && fk < K;
+    const size_t fidx = (size_t)df.x * K + min(fk, K - 1);
+    const double ek = mg.eeb[fidx];
+    for (int pass = 0; pass < (two_pass ? 2 : 1); ++pass) {          // block-uniform
+        const int sl = min(lane, 15), g = two_pass ? pass : sl >> lr, u = sl & (R - 1);
+        const int i = g >> 1, h = g & 1;
+        const bool w_on = t + i < t_end;
+        const int4 d = mg.desc[mg.N_short + min(t + i, t_end - 1)];
+        const int L = w_on ? d.z : 0;
+        const int chunk = (L + 15) / 16;             // <= R
+        const int c0 = min(L, (wid + 8 * h) * chunk);
+        const int cl = min(L, c0 + chunk) - c0;
+        const bool on = lane < 16 && u < cl;
+        const int q = on ? d.y + c0 + u : 0;
+        const int doc = on ? mg.wdoc[q] : -1;
+        const double tw = on ? mg.tw_word[q] : 0.0;
+        const int tlo = __double2loint(tw), thi = __double2hiint(tw);
+        double2 ev[16];
+#pragma unroll
+        for (int s0 = 0; s0 < 16; ++s0) {
+            const long long row = (long long)__builtin_amdgcn_readlane(doc, s0) * K;
+            ev[s0] = *reinterpret_cast<const double2 *>(mg.epg + row + kk);
+        }
+        double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int s0 = 0; s0 < 16; ++s0) {
+            const double tu = __hiloint2double(__builtin_amdgcn_readlane(thi, s0),
+                                               __builtin_amdgcn_readlane(tlo, s0));
+            acc.x = fma(tu, ev[s0].x, acc.x);
+            acc.y = fma(tu, ev[s0].y, acc.y);
+            if (((s0 + 1) & (R - 1)) == 0) {         // wave-uniform: the segment ends here
+                const int gs = two_pass ? pass : s0 >> lr;           // (list gs >> 1, half gs & 1)
+                if (k_on)
+                    *reinterpret_cast<double2 *>(lds + (size_t)((gs >> 1) * 16 + wid + 8 * (gs & 1)) * K + 2 * lane) = acc;
+                acc = make_double2(0.0, 0.0);
+            }
+        }
+    }
+    pub();                                           // (the rows are in, the only stores come below)
+    __syncthreads();
+    if (fin_on) {
+        const double *col = lds + (size_t)(fi * 16) * K + fk;
+        double sum = col[0];
+#pragma unroll
+        for (int c = 1; c < 16; ++c)
+            sum += col[(size_t)c * K];
+        mg.o.sstats[fidx] = sum * ek;
+    }
+    __syncthreads();
+}
+
+template <class Pub>
+__device__ __forceinline__ void deferred_stats(const MergedArgs &mg, int vb, double *lds, const Pub &pub,
+                                               int tid_bias)
+{
+    constexpr int W = kRegThreads / kWave;           // 8 waves
+    const int tid = (int)threadIdx.x + tid_bias;     // (an opaque zero: deferred_helper)
+    const int lane = tid & (kWave - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int K = mg.K;
+    const int kk = min(2 * lane, K - 2);             // this lane's pair of topics (K even)
+    const bool k_on = 2 * lane < K;
+
+    // columns of the words outside the batch: zero (lda.cpp:169) -- by the short-list workgroups
+    // (the long-list ones end with two barriers), or by everybody when there are none
+    const int zero_wgs = mg.n_short > 0 ? mg.n_short : mg.n_long;
+    // (the first block's flags are requested NOW and looked at after the lists: behind them the
+    // load would be one more latency at the end of the workgroup)
+    const int zw0 = (vb * W + wid) * kWave;
+    const bool zero_mine = vb < zero_wgs && zw0 < mg.V;
+    const unsigned char flag0 = (zero_mine && zw0 + lane < mg.V) ? mg.active_flag[zw0 + lane] : (unsigned char)1;
+    auto zero_columns = [&]() {
+        if (!zero_mine)
+            return;
+        for (int w0 = zw0; w0 < mg.V; w0 += zero_wgs * W * kWave) {
+            const int w = w0 + lane;
+            const bool clear = w0 == zw0 ? flag0 == 0 : (w < mg.V && mg.active_flag[w] == 0);
+            unsigned long long todo = __ballot(clear);
+            while (todo) {                           // wave-uniform
+                const int j = __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                if (k_on)
+                    *reinterpret_cast<double2 *>(mg.o.sstats + (size_t)(w0 + j) * K + 2 * lane) =
+                        make_double2(0.0, 0.0);
+            }
+        }
+    };
+
+    if (vb < mg.n_short) {
+        // which class, which item of it: this wave's words [t, t + NW)
+        int cls = 0, it = vb, base = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int items = (mg.cls_short[c] + W * kDeferShortNW[c] - 1) / (W * kDeferShortNW[c]);
+            if (cls == c && it >= items) {
+                it -= items;
+                base += mg.cls_short[c];
+                cls = c + 1;
+            }
+        }
+        const int lr = 4 - cls, nw = 16 >> lr;       // kDeferLog2R / kDeferShortNW
+        const int t_end = base + (cls == 0 ? mg.cls_short[0] : cls == 1 ? mg.cls_short[1]
+                                  : cls == 2 ? mg.cls_short[2] : mg.cls_short[3]);
+        const int t = base + (it * W + wid) * nw;
+        if (t < t_end)                               // wave-uniform (wave 0 always has words)
+            deferred_short_wave(mg, t, t_end, lr, lane, kk, k_on, pub);
+        zero_columns();
+        return;
+    }
+
+    if (mg.n_short == 0)
+        zero_columns();
+    int cls = 0, it = vb - mg.n_short, base = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int items = (mg.cls_long[c] + kDeferLongLW[c] - 1) / kDeferLongLW[c];
+        if (cls == c && it >= items) {
+            it -= items;
+            base += mg.cls_long[c];
+            cls = c + 1;
+        }
+    }
+    const int lw = cls == 0 ? 1 : 16 >> (5 - cls);   // kDeferLongLW: 1, 1, 2, 4
+    const int t_end = base + (cls == 0 ? mg.cls_long[0] : cls == 1 ? mg.cls_long[1]
+                              : cls == 2 ? mg.cls_long[2] : mg.cls_long[3]);
+    deferred_long_group(mg, base + it * lw, t_end, 4 - cls, lds, tid, lane, wid, kk, k_on, pub);
+}
+
 // ---- deferred statistics: a stream of E-steps on an unchanged lambda -----------------------------
 // (trlda_model_set_deferred_stats; reference: consecutive LDA::updateVariablesVI calls of a corpus
 // pass, src/lda.cpp:160-220 -- the statistics of one call, :207-217, do not feed the next call.)
@@ -521,21 +770,128 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_tiered_merged_kernel(D
 // run on the CUs the documents leave free (56 of 256 at 200 documents) and a step is ONE launch of
 // the documents' length.  Same sums in the same order as the kernel of its own
 // (sstats_update2_kernel): bitwise the same statistics (tests/test_gpu_deferred.py).
+// diagnostics (TRLDA_MERGED_STAMPS=1, tools/deferred_stamps.py): [s_memrealtime at the start, where
+// it ran (XCC << 16 | HW_ID: SE, CU), s_memrealtime at the end] of every workgroup of a deferred
+// launch -- statistics at rows [0, 1024), documents from 1024, the next batch's preamble from 2048
+struct DeferredStamp {
+    unsigned long long *row;
+    __device__ __forceinline__ DeferredStamp(const MergedArgs &mg, int r) : row(nullptr)
+    {
+        if (mg.tstamps && threadIdx.x == 0) {        // launch-uniform test first
+            row = mg.tstamps + 3 * (size_t)r;
+            row[0] = __builtin_amdgcn_s_memrealtime();
+            row[1] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 16) |
+                     (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 0xffffu);
+        }
+    }
+    __device__ __forceinline__ void end()
+    {
+        if (row)
+            row[2] = __builtin_amdgcn_s_memrealtime();
+    }
+};
+
+// The helpers of a deferred launch take their work from a COUNTER: the launch has H helper
+// workgroups behind the documents (as many as it has helper items, at most one per CU); a helper
+// takes whatever item comes next -- first the pre.nb workgroups' worth
+// of the next batch's preamble, then the n_short + n_long of the statistics.  The helpers that are
+// resident from the start (the CUs the documents leave free) work through the list while the
+// documents run; the ones dispatched when documents end take what is left.  Measured on the way
+// here (profiles/r05_deferred_notes.txt): a workgroup per item pays ~1.2 us between its
+// predecessor's end and its own first instruction (375 items on 56 CUs: a fifth of the shadow the
+// documents cast); H persistent workgroups with a FIXED share each cannot spread over the CUs the
+// documents free (49.8 against 41.8 us per step).  The next item is requested (one relaxed atomic by
+// thread 0) before the current one is worked on, so its latency is not on anybody's path; the
+// counter only grows -- the host passes the value it has at the start of the launch and adds the
+// launch's items afterwards.
+// The kernel's arguments (~700 bytes: three structures) are fetched where they are first used, a
+// scalar load and a wait at a time -- in the helper's path ten of them one behind the other, each a
+// miss in the scalar cache: ~3 us before a helper's first item (profiles/r05_deferred_notes.txt:
+// documents start 0.2 us into the launch, helpers 3.2).  One word of every 64-byte line of the
+// argument segment, all requested at once, brings the lines into the scalar cache.
+__device__ __forceinline__ void warm_kernel_arguments()
+{
+    // (the deferred kernels' explicit arguments: 696 bytes in the code object's metadata, the tiered
+    // one with its extra int; eleven lines = 704 bytes, none of them past the segment's last line)
+    static_assert(sizeof(DocKernelArgs) + sizeof(PreArgs) + sizeof(MergedArgs) <= 11 * 64 &&
+                      sizeof(DocKernelArgs) + sizeof(PreArgs) + sizeof(MergedArgs) > 10 * 64,
+                  "eleven lines cover the argument segment and none lies beyond it");
+    typedef __attribute__((address_space(4))) const unsigned int *karg_ptr;
+    karg_ptr kp = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned int r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10;
+    // (one block: left to the compiler the twelve loads came in three batches with a wait each)
+    asm volatile("s_load_dword %0, %11, 0x0\n\t"
+                 "s_load_dword %1, %11, 0x40\n\t"
+                 "s_load_dword %2, %11, 0x80\n\t"
+                 "s_load_dword %3, %11, 0xc0\n\t"
+                 "s_load_dword %4, %11, 0x100\n\t"
+                 "s_load_dword %5, %11, 0x140\n\t"
+                 "s_load_dword %6, %11, 0x180\n\t"
+                 "s_load_dword %7, %11, 0x1c0\n\t"
+                 "s_load_dword %8, %11, 0x200\n\t"
+                 "s_load_dword %9, %11, 0x240\n\t"
+                 "s_load_dword %10, %11, 0x280\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(r0), "=&s"(r1), "=&s"(r2), "=&s"(r3), "=&s"(r4), "=&s"(r5), "=&s"(r6), "=&s"(r7),
+                   "=&s"(r8), "=&s"(r9), "=&s"(r10)
+                 : "s"(kp)
+                 : "memory");
+}
+
+__device__ __forceinline__ void deferred_helper(const PreArgs &pre, const MergedArgs &mg, double *lds)
+{
+    __shared__ unsigned int next_item[2];
+    const int n_items = pre.nb + mg.n_short + mg.n_long;
+    // (EVERY item comes from the counter, the first one too: with item h for helper h the items past
+    // the resident helpers' waited for the helpers that are dispatched when the documents end -- 38.3
+    // against 32.9 us per step; a fixed first item for just the resident ones gained 0.3 us of the
+    // ~3 us a helper needs to get going and is not worth its bookkeeping)
+    if (threadIdx.x == 0)
+        next_item[1] = __hip_atomic_fetch_add(mg.work_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                       mg.work_base;
+    __syncthreads();
+    int v = (int)next_item[1];
+    for (int round = 0; v < n_items; ++round) {      // block-uniform
+        unsigned int fetched = 0u;
+        if (threadIdx.x == 0)                        // (needed at the end of the round)
+            fetched = __hip_atomic_fetch_add(mg.work_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (published from inside the item, between its loads and its stores: PublishNext)
+        const PublishNext pub{&next_item[round & 1], fetched, mg.work_base};
+        // A zero the compiler cannot see through, added to every item's thread index: without it
+        // everything in the items that does not depend on the item -- a few hundred instructions of
+        // per-lane addresses, class tables, argument loads, and 25 registers spilled to make room for
+        // them -- is hoisted in front of the loop, and a helper's first item started 3 us into the
+        // launch (the documents: 0.2 us; profiles/r05_deferred_notes.txt).
+        int zero = 0;
+        asm volatile("" : "+v"(zero));
+        if (v < pre.nb) {
+            DeferredStamp st(mg, 2048 + min(v, 1023));
+            docs_launch_preamble<true>(pre, lds, pre.n_docs + v, pub, zero);
+            st.end();
+        } else {
+            DeferredStamp st(mg, min(v - pre.nb, 1023));
+            deferred_stats(mg, v - pre.nb, lds, pub, zero);
+            st.end();
+        }
+        __syncthreads();                             // (also: the next item reuses the LDS)
+        v = (int)next_item[round & 1];
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_deferred_kernel(DocKernelArgs a, PreArgs pre,
                                                                                MergedArgs mg)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    warm_kernel_arguments();                         // (first thing: every later argument load hits)
     const int bid = (int)blockIdx.x;
-    if (bid >= mg.first) {                           // block-uniform
-        merged_stats<true>(mg, bid - mg.first, lds);
+    if (bid >= pre.n_docs) {                         // block-uniform
+        deferred_helper(pre, mg, lds);
         return;
     }
-    if (bid >= pre.n_docs) {
-        docs_launch_preamble(pre, lds, bid);
-        return;
-    }
+    DeferredStamp st(mg, 1024 + min(bid, 1023));
     estep_docs_reg_body<MODE>(a, lds);
+    st.end();
 }
 
 template <int KS>
@@ -543,13 +899,10 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_tiered_deferred_kernel
                                                                                   int lds_rows, MergedArgs mg)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    warm_kernel_arguments();
     const int bid = (int)blockIdx.x;
-    if (bid >= mg.first) {                           // block-uniform
-        merged_stats<true>(mg, bid - mg.first, lds);
-        return;
-    }
-    if (bid >= pre.n_docs) {
-        docs_launch_preamble(pre, lds, bid);
+    if (bid >= pre.n_docs) {                         // block-uniform
+        deferred_helper(pre, mg, lds);
         return;
     }
     const int n = a.pad_meta[4 * (size_t)bid * a.meta_i4 + 1];

@@ -205,6 +205,10 @@ struct trlda_batch {
     int32_t *mdesc = nullptr;       // n_active x 4
     int n_short = 0;
     trlda_model *pending_in = nullptr;   // a model whose deferred statistics still read this batch
+    // the lists by length class, longest first (estep_merged.h, deferred_stats): short lists of
+    // 9..16 | 5..8 | 3..4 | 1..2 entries, long lists whose chunks (a sixteenth, rounded up) have
+    // 9..16 | 5..8 | 3..4 | 1..2; meaningful when long_len == kLongWord and max_list <= 256
+    int cls_short[4] = {0, 0, 0, 0}, cls_long[4] = {0, 0, 0, 0};
     int max_list = 0;               // entries of the longest word list (repeated ids within a document
                                     // are legal, lda.cpp:108: a list can be longer than B)
     // very long lists (estep_kernels.h, VeryLongArgs): words of more than seg_len entries, by word
@@ -269,6 +273,7 @@ struct trlda_model {
     double *dfr_epg_base[2] = {nullptr, nullptr}, *dfr_tw[2] = {nullptr, nullptr};
     size_t dfr_cap_docs[2] = {0, 0}, dfr_cap_tw[2] = {0, 0};
     int dfr_cur = 0;
+    unsigned int defer_work_total = 0;    // what sync_counters[32] holds: the helpers' items so far
     bool last_deferred = false;           // the last E-step left its statistics pending
     bool last_carried = false;            // ... / its launch carried the call before's
     struct {
@@ -386,6 +391,7 @@ struct trlda_model {
     unsigned int *sync_flags = nullptr;
     unsigned int merged_epoch = 0;
     unsigned long long *merged_stamps = nullptr;   // diagnostics, TRLDA_MERGED_STAMPS=1
+    unsigned long long *deferred_stamps = nullptr; // ... of a deferred launch (3 x 3072)
     double *scale_comb = nullptr;       // 3 K
     // split documents: the exchange rows of a launch (NaN before it), the give-up flag
     double *xbuf = nullptr;
@@ -1849,7 +1855,8 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                 // that add up the rows -- three rounds on the 56 CUs the documents leave free.
                 // (Letting them start a few microseconds late, so as not to disturb the documents'
                 // staging, was measured: every s_sleep step made the launch longer.)
-                const size_t per = (size_t)kRegThreads * 8;
+                // (a deferred launch's helpers: 16 per thread, all loads in flight -- estep_kernels.h, FAT)
+                const size_t per = (size_t)kRegThreads * (carry ? 16 : 8);
                 pre.nb = pre.G + (int)std::max<size_t>(1, std::min<size_t>((pre.total + per - 1) / per, 448));
                 pre.lambda = m->lambda;
                 pre.partial = m->partial_pp[nbuf];
@@ -1935,28 +1942,42 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                 dg.first = n_wgs + pre.nb;
                 dg.K = K; dg.V = V;
                 dg.N_short = pb->n_short; dg.N_long = pb->n_long;
-                static const int helper_cap = [] {
-                    const char *e = std::getenv("TRLDA_DEFER_WGS");
-                    return e ? std::max(2, std::atoi(e)) : 0;
-                }();
-                const int room = helper_cap > 0 ? helper_cap : std::min(cus, trlda::kMergedMaxHelpers);
-                dg.n_long = std::min(dg.N_long, room / 2);
-                dg.n_short = dg.N_short > 0
-                                 ? std::max(1, std::min((dg.N_short + 8 * trlda::kMergedNW - 1) / (8 * trlda::kMergedNW),
-                                                        room - dg.n_long))
-                                 : 0;
+                for (int c = 0; c < 4; ++c) {
+                    dg.cls_short[c] = pb->cls_short[c];
+                    dg.cls_long[c] = pb->cls_long[c];
+                }
+                dg.n_short = trlda::deferred_short_items(dg.cls_short);    // a workgroup per item
+                dg.n_long = trlda::deferred_long_items(dg.cls_long);
                 dg.desc = reinterpret_cast<const int4 *>(pb->mdesc);
                 dg.wdoc = pb->wdoc; dg.tw_word = m->pending.tw_word; dg.epg = m->pending.epg;
                 dg.eeb = m->pending.eeb;
                 dg.active_flag = pb->active_flag;
                 dg.o = trlda::UpdateOut{};
                 dg.o.sstats = m->pending.sstats;
+                {
+                    static const bool want_stamps = std::getenv("TRLDA_MERGED_STAMPS") != nullptr;
+                    if (want_stamps && !m->deferred_stamps && dev_alloc(&m->deferred_stamps, 3 * 3072) == TRLDA_OK)
+                        (void)hipMemset(m->deferred_stamps, 0, 3 * 3072 * sizeof(unsigned long long));
+                    dg.tstamps = want_stamps ? m->deferred_stamps : nullptr;
+                }
                 const void *dk = !tiered ? reinterpret_cast<const void *>(estep_docs_reg_deferred_kernel<0>)
                                  : KS == 1 ? reinterpret_cast<const void *>(estep_docs_tiered_deferred_kernel<1>)
                                            : reinterpret_cast<const void *>(estep_docs_tiered_deferred_kernel<2>);
                 if ((rc = ensure_dynamic_lds(dk, lds_bytes)))
                     return rc;
-                const dim3 grid((unsigned)(dg.first + dg.n_short + dg.n_long));
+                // helper workgroups: one per item, at most one per CU (estep_merged.h, deferred_helper:
+                // they take their items from a counter)
+                static const int helpers_env = [] {
+                    const char *e = std::getenv("TRLDA_DEFER_HELPERS");
+                    return e ? std::max(1, std::atoi(e)) : 0;
+                }();
+                const int n_items = pre.nb + dg.n_short + dg.n_long;
+                const int H = std::min(n_items, helpers_env > 0 ? helpers_env : cus);
+                dg.work_counter = m->sync_counters + 32;        // (a cache line of its own)
+                dg.work_base = m->defer_work_total;
+                // (one fetch per item, and every helper's last fetch, which finds nothing)
+                m->defer_work_total += (unsigned int)(n_items + H);
+                const dim3 grid((unsigned)(n_wgs + H));
                 if (!tiered)
                     hipLaunchKernelGGL(estep_docs_reg_deferred_kernel<0>, grid, dim3(kRegThreads), lds_bytes,
                                        m->stream, a, pre, dg);
@@ -2858,6 +2879,12 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
             int32_t *e = md + 4 * (size_t)at[(size_t)len]++;
             e[0] = w; e[1] = q0; e[2] = len; e[3] = 0;
         }
+        for (int a = 0; a < na; ++a) {
+            const int len = wptr[(size_t)active[a] + 1] - wptr[(size_t)active[a]];
+            const int unit = len <= long_len ? len : (len + 15) / 16;       // a list, or a chunk of one
+            const int c = unit > 8 ? 0 : unit > 4 ? 1 : unit > 2 ? 2 : 3;
+            ++(len <= long_len ? b->cls_short : b->cls_long)[c];
+        }
         std::stable_sort(longs.begin(), longs.end(), [&](int32_t x, int32_t y) {
             return wptr[(size_t)x + 1] - wptr[(size_t)x] > wptr[(size_t)y + 1] - wptr[(size_t)y];
         });
@@ -3046,8 +3073,8 @@ int trlda_model_create(trlda_model **out, int device, int K, int V)
         m->group_counter = static_cast<unsigned int *>(p);
     }
     if (!rc) rc = dev_alloc(&m->scale_comb, 3 * (size_t)K);
-    if (!rc) rc = dev_alloc(&m->sync_counters, 2);
-    if (!rc && hipMemset(m->sync_counters, 0, 2 * sizeof(unsigned int)) != hipSuccess)
+    if (!rc) rc = dev_alloc(&m->sync_counters, 64);          // [0], [1]: merged launch; [32]: deferred helpers
+    if (!rc && hipMemset(m->sync_counters, 0, 64 * sizeof(unsigned int)) != hipSuccess)
         rc = fail(TRLDA_ERR_HIP, "hipMemset failed");
     {
         const size_t n_flags = (size_t)(trlda::kMergedMaxHelpers + trlda::kMergedMaxDocWgs) * trlda::kMergedFlagStride;
@@ -4930,6 +4957,16 @@ extern "C" int trlda_debug_graph_update(trlda_model *m, const trlda_batch *b, in
 }
 
 // diagnostics: the s_memtime stamps of the model's last merged launch (3 x 1024 values)
+extern "C" int trlda_debug_deferred_stamps(trlda_model *m, unsigned long long *host)
+{
+    if (!m || !host || !m->deferred_stamps)
+        return TRLDA_ERR_ARG;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    HIP_TRY(hipMemcpy(host, m->deferred_stamps, 3 * 3072 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(m->deferred_stamps, 0, 3 * 3072 * sizeof(unsigned long long)));
+    return TRLDA_OK;
+}
+
 extern "C" int trlda_debug_merged_stamps(trlda_model *m, unsigned long long *host)
 {
     if (!m || !host || !m->merged_stamps)
