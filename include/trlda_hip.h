@@ -600,6 +600,10 @@ int trlda_eb_alpha_line_search(int K, const double *alpha, const double *psi_gam
                                double threshold, double *alpha_out);
 double trlda_eb_eta_line_search(double eta, double sum_psi_lambda, const double *rowsums, int K,
                                 int V, int max_iter_eta, double min_eta, double threshold);
+/* `verbosity` of LDA::Parameters for the two line searches above (per calling thread): above 1 they
+ * print their progress to stdout as the reference does (src/batchlda.cpp:78-88,120-123,155-165,
+ * 184-187; src/cumulativelda.cpp:87-97,129-132). */
+void trlda_eb_set_verbosity(int verbosity);
 /* Both online steps after an update, with ONE synchronisation: the device sums over the gamma
  * the update left behind (B_local documents of this rank; summed over the ranks of rccl_comm
  * when that is not NULL) and over lambda, the host steps above, the new alpha back on the

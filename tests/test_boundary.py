@@ -408,3 +408,35 @@ def test_gamma_draw_survives_fork(hip_lib):
     _, status = os.waitpid(pid, 0)
     assert status == 0
 
+
+
+def test_line_searches_print_their_progress_at_verbosity_2(hip_lib):
+    """`verbosity > 1` (reference src/batchlda.cpp:78-88,120-123,155-165,184-187,
+    src/cumulativelda.cpp:87-97,129-132): "Optimizing alpha..." / "Optimizing eta...", then per
+    Newton step the current function value, the accepted step width and the gradient
+    (magnitude), tab-indented, in std::cout's default format; nothing at verbosity <= 1."""
+    code = r"""
+import numpy as np
+from trlda_amd.models import _alpha_line_search, _eta_line_search
+for v in (0, 1, 2):
+    print("verbosity", v)
+    a = _alpha_line_search(np.full(5, .1), -np.array([30., 40, 50, 35, 45]), 25., 3, 1e-6, 1e-8, verbosity=v)
+    e = _eta_line_search(.3, -90000., np.full(5, 300.), 5, 900, 2, 1e-6, 1e-8, verbosity=v)
+    print("done", v, "%.12g %.12g" % (a[0], e))
+"""
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, check=True).stdout
+    lines = out.splitlines()
+    i0, i1, i2 = [lines.index("verbosity %d" % v) for v in (0, 1, 2)]
+    assert lines[i0 + 1].startswith("done 0") and lines[i1 + 1].startswith("done 1")      # silent
+    assert lines[i0 + 1].split()[2:] == lines[i1 + 1].split()[2:] == lines[-1].split()[2:]  # same results
+    loud = lines[i2 + 1:-1]
+    assert loud[0] == "Optimizing alpha..."
+    eta_at = loud.index("Optimizing eta...")
+    num = r"-?\d+(\.\d+)?(e[-+]\d+)?"
+    for block, grad in ((loud[1:eta_at], "Gradient magnitude"), (loud[eta_at + 1:], "Gradient")):
+        assert len(block) % 3 == 0 and len(block) >= 3
+        for j in range(0, len(block), 3):
+            assert re.fullmatch(r"\tCurrent function value: " + num, block[j]), block[j]
+            assert re.fullmatch(r"\tStep width: " + num, block[j + 1]), block[j + 1]
+            assert re.fullmatch(r"\t" + grad + ": " + num, block[j + 2]), block[j + 2]
+    assert len(loud[1:eta_at]) == 9 and len(loud[eta_at + 1:]) == 6    # three / two Newton steps

@@ -144,6 +144,7 @@ _SIGNATURES = {
                                               C.c_double]),
     "trlda_eb_alpha_line_search": (C.c_int, [C.c_int, f64p, f64p, C.c_double, C.c_int, C.c_double,
                                              C.c_double, f64p]),
+    "trlda_eb_set_verbosity": (None, [C.c_int]),
     "trlda_eb_eta_line_search": (C.c_double, [C.c_double, C.c_double, f64p, C.c_int, C.c_int, C.c_int,
                                               C.c_double, C.c_double]),
     "trlda_model_online_eb": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int,

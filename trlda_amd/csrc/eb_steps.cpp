@@ -9,6 +9,7 @@
 // (src/digamma.cpp) and polygamma(1, .) = zeta(2, .) (src/utils.cpp:107-111, src/zeta.cpp);
 // log Gamma is libm's, as in the reference (src/utils.cpp:75-91).
 #include <cmath>
+#include <cstdio>
 #include <vector>
 
 #include "../../include/trlda_hip.h"
@@ -122,14 +123,30 @@ double trlda_eb_online_eta_step(double eta, double sum_psi_lambda, const double 
     return e < min_eta ? min_eta : e;
 }
 
+// `verbosity > 1` of the reference's line searches (src/batchlda.cpp:78-88,120-123,155-165,184-187,
+// src/cumulativelda.cpp:87-97,129-132): progress on stdout in the reference's own words and
+// std::cout's default format (six significant digits).  Per thread; the Python classes set it around
+// the call from their `verbosity` argument.
+static thread_local int g_verbosity = 0;
+void trlda_eb_set_verbosity(int verbosity) { g_verbosity = verbosity; }
+static void say(const char *what, double v)
+{
+    std::printf("\t%s: %g\n", what, v);
+}
+
 int trlda_eb_alpha_line_search(int K, const double *alpha, const double *psi_gamma_diff, double num_docs,
                                int max_iter_alpha, double min_alpha, double threshold, double *alpha_out)
 {
     if (K <= 0 || !alpha || !psi_gamma_diff || !alpha_out)
         return fail(TRLDA_ERR_ARG, "bad alpha line search arguments");
     std::vector<double> cur(alpha, alpha + K), cand((size_t)K), g((size_t)K), h((size_t)K);
+    const bool loud = g_verbosity > 1;
+    if (loud)
+        std::printf("Optimizing alpha...\n");
     double L = alpha_bound(K, cur.data(), psi_gamma_diff, num_docs), Lprime = L;
     for (int it = 0; it < max_iter_alpha; ++it) {                    // batchlda.cpp:81-141
+        if (loud)
+            say("Current function value", L);
         double c = 0.0;
         alpha_newton_terms(K, cur.data(), psi_gamma_diff, num_docs, g, h, &c);
         double rho = .2;
@@ -145,6 +162,13 @@ int trlda_eb_alpha_line_search(int K, const double *alpha, const double *psi_gam
             }
             Lprime = alpha_bound(K, cand.data(), psi_gamma_diff, num_docs);
             if (L <= Lprime) {
+                if (loud) {
+                    double g2 = 0.0;
+                    for (int k = 0; k < K; ++k)
+                        g2 += g[(size_t)k] * g[(size_t)k];
+                    say("Step width", rho);
+                    say("Gradient magnitude", std::sqrt(g2));
+                }
                 cur = cand;
                 break;
             }
@@ -156,6 +180,8 @@ int trlda_eb_alpha_line_search(int K, const double *alpha, const double *psi_gam
     }
     for (int k = 0; k < K; ++k)
         alpha_out[k] = cur[(size_t)k];
+    if (loud)
+        std::fflush(stdout);
     return TRLDA_OK;
 }
 
@@ -168,8 +194,13 @@ double trlda_eb_eta_line_search(double eta, double sum_psi_lambda, const double 
     const double KV = (double)K * (double)V;
     const double c = sum_psi_lambda - V * psi_rows;
     auto bound = [&](double e) { return (e - 1) * c + K * lngamma(V * e) - KV * lngamma(e); };
+    const bool loud = g_verbosity > 1;
+    if (loud)
+        std::printf("Optimizing eta...\n");
     double Lb = bound(eta), Lprime = Lb;
     for (int it = 0; it < max_iter_eta; ++it) {                      // batchlda.cpp:160-203
+        if (loud)
+            say("Current function value", Lb);
         const double g = c - KV * (psi(eta) - psi(V * eta));
         const double h = KV * (psi1(V * eta) - psi1(eta));
         double rho = .5;
@@ -181,6 +212,10 @@ double trlda_eb_eta_line_search(double eta, double sum_psi_lambda, const double 
             }
             Lprime = bound(cand);
             if (Lb <= Lprime) {
+                if (loud) {
+                    say("Step width", rho);
+                    say("Gradient", g);
+                }
                 eta = cand;
                 break;
             }
@@ -190,6 +225,8 @@ double trlda_eb_eta_line_search(double eta, double sum_psi_lambda, const double 
             break;
         Lb = Lprime;
     }
+    if (loud)
+        std::fflush(stdout);
     return eta;
 }
 

@@ -1236,6 +1236,24 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
         }
     }
 
+    // ---- MODE 1: the words 128..143 in the second orientation.  Only 16 words: four lane groups
+    // share them, each with four of the wave's 16 topics -- lane l holds word 128 + (l & 15), topics
+    // k0 + 4 (l >> 4) + {0..3}: 4 doubles per lane instead of 16 that three quarters of the lanes
+    // would not use.  They are read from eeb directly, 32 contiguous bytes per lane of rows that
+    // wave 7 requests anyway (round 5; through the transposition buffer they cost a second pass
+    // with two more barriers: staging 12.6 k cycles against 10.7 k, profiles/r05_stamps_modes.txt).
+    [[maybe_unused]] double bE2[4] = {0.0, 0.0, 0.0, 0.0};
+    [[maybe_unused]] const int kq = 4 * (lane >> 4); // this lane group's topic offset
+    if constexpr (MID) {
+        const int KCm = (((K + W - 1) / W) + 1) & ~1;
+        const int k2 = wid * KCm + kq;               // first of this lane's four topics
+        const int id2 = pids[128 + (lane & 15)];
+        const double *row2 = a.eeb + (size_t)id2 * K;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            bE2[i] = row2[min(k2 + i, K - 1)];
+    }
+
     double *gamma_d = a.gamma + (size_t)d * K;
     double e0 = 0.0;                                 // thread k < K: exp(psi(gamma0_k))
     if (tid < 144) {                                 // lda.cpp:174
@@ -1299,29 +1317,13 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
         }
     }
     __syncthreads();
-    // ---- MODE 1: the words 128..143 in the second orientation, through the same buffer
-    // Only 16 words: four lane groups share them, each with four of the wave's 16 topics --
-    // lane l holds word 128 + (l & 15), topics k0 + 4 (l >> 4) + {0..3}: 4 doubles per lane
-    // instead of 16 that three quarters of the lanes would not use.
-    [[maybe_unused]] double bE2[4];
-    [[maybe_unused]] const int kq = 4 * (lane >> 4); // this lane group's topic offset
-    if constexpr (MID) {
-#pragma unroll
-        for (int i = 0; i < JC; ++i) {
-            if (j0 + i >= 128) {                     // wave-uniform (wave 7: words 126..143)
-                tbuf[(j0 + i - 128) * kRegStride + lane] = bB0[i];
-                tbuf[(j0 + i - 128) * kRegStride + 64 + lane] = bB1[i];
-            }
-        }
-        __syncthreads();
-        const double *t2 = tbuf + (lane & 15) * kRegStride + k0;
+    if constexpr (MID) {                             // (out-of-range words and topics: zero)
+        const bool row2_on = 128 + (lane & 15) < nm;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool colv = kq + i < KC && k0 + kq + i < K;
-            const double v2 = t2[colv ? kq + i : 0];
-            bE2[i] = colv ? v2 : 0.0;
+            bE2[i] = (colv && row2_on) ? bE2[i] : 0.0;
         }
-        __syncthreads();
     }
     TRLDA_STAMP(1);
 

@@ -680,13 +680,15 @@ class ShardedBatchLDA(_ShardedLDA):
                             self._composed_estep(mine, True, B, lo, hi, max_iter_inference,
                                                  threshold)
                     alpha = _alpha_line_search(self._alpha, self._psi_gamma_diff(hi - lo), B,
-                                               max_iter_alpha, min_alpha, emp_bayes_threshold)
+                                               max_iter_alpha, min_alpha, emp_bayes_threshold,
+                                               verbosity if self.rank == 0 else 0)
                     eng.set_alpha(alpha)
                     self._alpha = alpha
                 if update_eta:                                   # batchlda.cpp:147-205
                     sum_psi, rowsums = eng.lambda_psi_stats()
                     self._eta = _eta_line_search(self._eta, sum_psi, rowsums, self._K, self._V,
-                                                 max_iter_eta, min_eta, emp_bayes_threshold)
+                                                 max_iter_eta, min_eta, emp_bayes_threshold,
+                                                 verbosity if self.rank == 0 else 0)
         finally:
             for b in (whole, mine):
                 if b is not None and hasattr(b, "close"):

@@ -473,22 +473,42 @@ def _online_eta_step(eta, sum_psi_lambda, rowsums, K, V, rho, min_eta):
         int(V), float(rho), float(min_eta)))
 
 
-def _eta_line_search(eta, sum_psi_lambda, rowsums, K, V, max_iter_eta, min_eta, threshold):
+class _Verbosity(object):
+    """`verbosity > 1`: the line searches print their progress to stdout in the reference's words
+    (batchlda.cpp:78-88,120-123,155-165,184-187; cumulativelda.cpp:87-97,129-132) -- from C, so
+    Python's own buffer is flushed first to keep the order of what a caller prints around it."""
+
+    def __init__(self, verbosity):
+        self.verbosity = int(verbosity)
+
+    def __enter__(self):
+        if self.verbosity > 1:
+            import sys
+            sys.stdout.flush()
+        _ffi.lib().trlda_eb_set_verbosity(self.verbosity)
+
+    def __exit__(self, *exc):
+        _ffi.lib().trlda_eb_set_verbosity(0)
+
+
+def _eta_line_search(eta, sum_psi_lambda, rowsums, K, V, max_iter_eta, min_eta, threshold, verbosity=0):
     """Newton steps on eta with a step-halving line search on the lower bound,
     batchlda.cpp:147-205 (csrc/eb_steps.cpp)."""
-    return float(_ffi.lib().trlda_eb_eta_line_search(
-        float(eta), float(sum_psi_lambda), np.ascontiguousarray(rowsums, dtype=np.float64), int(K),
-        int(V), int(max_iter_eta), float(min_eta), float(threshold)))
+    with _Verbosity(verbosity):
+        return float(_ffi.lib().trlda_eb_eta_line_search(
+            float(eta), float(sum_psi_lambda), np.ascontiguousarray(rowsums, dtype=np.float64), int(K),
+            int(V), int(max_iter_eta), float(min_eta), float(threshold)))
 
 
-def _alpha_line_search(alpha, psi_gamma_diff, num_docs, max_iter_alpha, min_alpha, threshold):
+def _alpha_line_search(alpha, psi_gamma_diff, num_docs, max_iter_alpha, min_alpha, threshold, verbosity=0):
     """Newton / natural-gradient steps on alpha with a step-halving line search on the lower
     bound: batchlda.cpp:81-141 == cumulativelda.cpp:90-150 (csrc/eb_steps.cpp)."""
     alpha = np.ascontiguousarray(alpha, dtype=np.float64)
     out = np.empty_like(alpha)
-    _ffi.check(_ffi.lib().trlda_eb_alpha_line_search(
-        alpha.size, alpha, np.ascontiguousarray(psi_gamma_diff, dtype=np.float64), float(num_docs),
-        int(max_iter_alpha), float(min_alpha), float(threshold), out))
+    with _Verbosity(verbosity):
+        _ffi.check(_ffi.lib().trlda_eb_alpha_line_search(
+            alpha.size, alpha, np.ascontiguousarray(psi_gamma_diff, dtype=np.float64), float(num_docs),
+            int(max_iter_alpha), float(min_alpha), float(threshold), out))
     return out
 
 
@@ -527,13 +547,13 @@ class BatchLDA(LDA):
                     if not update_lambda:
                         self._resident_estep(batch, max_iter_inference)
                     alpha = _alpha_line_search(self._alpha, self._psi_gamma_diff_device(B), B,
-                                               max_iter_alpha, min_alpha, emp_bayes_threshold)
+                                               max_iter_alpha, min_alpha, emp_bayes_threshold, verbosity)
                     _ffi.check(L.trlda_model_set_alpha(self._handle, np.ascontiguousarray(alpha)))
                     self._alpha = alpha
                 if update_eta:                                       # batchlda.cpp:147-205
                     sum_psi, rowsums = self._lambda_psi_stats_device()
                     self._eta = _eta_line_search(self._eta, sum_psi, rowsums, K, V, max_iter_eta,
-                                                 min_eta, emp_bayes_threshold)
+                                                 min_eta, emp_bayes_threshold, verbosity)
         finally:
             if owned:
                 batch.close()
@@ -582,7 +602,7 @@ class CumulativeLDA(LDA):
                 self._psi_gamma_diff = self._psi_gamma_diff + self._psi_gamma_diff_device(B)
                 self._num_documents += B
                 alpha = _alpha_line_search(self._alpha, self._psi_gamma_diff, self._num_documents,
-                                           max_iter_alpha, min_alpha, emp_bayes_threshold)
+                                           max_iter_alpha, min_alpha, emp_bayes_threshold, verbosity)
                 _ffi.check(L.trlda_model_set_alpha(self._handle, np.ascontiguousarray(alpha)))
                 self._alpha = alpha
         finally:
