@@ -141,6 +141,28 @@ def algorithmic_bytes(K, V, indptr):
     return estep, docs_kernel, B
 
 
+def exchange_plan(args, world, virtual_world=0):
+    """What crosses ranks in the N > 1 step, decided from the ARGUMENTS only, so
+    that every rank takes the same decision without talking to the others: the factor exchange
+    (all-gather of the documents' exp(psi(gamma)) rows and entry weights) when it moves fewer bytes
+    than the all-reduce of the K x V statistics, with the statistics + M-step sharded by vocabulary
+    range unless --whole-stats; `direct` (hipIpc pushes) only on request.  The run-time checks may
+    fall back from it -- all ranks together -- never pick something else."""
+    K, V = args.topics, args.words
+    B = args.global_batch // world if args.global_batch > 0 else args.batch
+    xworld = virtual_world or world
+    slot = B * K + int(B * args.mean_unique * 1.2)   # ~ max_r(docs) K + max_r(nnz)
+    factors_bytes, sstats_bytes = 8. * xworld * slot, 8. * 2. * K * V
+    exchange = args.exchange if args.exchange not in ("auto", "direct") else \
+        ("factors" if factors_bytes < sstats_bytes or args.exchange == "direct" else "sstats")
+    if virtual_world:
+        exchange = "factors"
+    return {"exchange": exchange, "slot_doubles": slot, "batch_per_gpu": B,
+            "factors_bytes_per_rank": factors_bytes, "allreduce_bytes_per_rank": sstats_bytes,
+            "word_sharded_m_step": bool(exchange == "factors" and not args.whole_stats),
+            "direct_requested": args.exchange == "direct"}
+
+
 def launch_ranks(n, argv, timeout_s):
     """`python bench.py --gpus N` without a launcher: start the N rank processes ourselves.
 
@@ -248,13 +270,16 @@ def main():
         if os.environ.get("TRLDA_BENCH_DRY_HANG_RANK") == str(rank):
             time.sleep(3600)
         mark = os.environ.get("TRLDA_BENCH_DRY_DIR")
+        plan = exchange_plan(args, world)
         if mark:
             with open(os.path.join(mark, "rank%d" % rank), "w") as f:
                 f.write("%d %d %s %s\n" % (rank, world, os.environ.get("MASTER_ADDR"),
                                           os.environ.get("TRLDA_BENCH_PARENT_HAD_TORCH")))
+            with open(os.path.join(mark, "plan%d.json" % rank), "w") as f:
+                json.dump(plan, f, sort_keys=True)
         if rank == 0:
             print(json.dumps({"metric": "dry run of the rank launch", "n_gpus": world,
-                              "torch_in_rank": "torch" in sys.modules}), flush=True)
+                              "torch_in_rank": "torch" in sys.modules, "plan": plan}), flush=True)
         return
 
     # Only the result line goes to stdout: everything else that writes to file descriptor 1 from
@@ -373,13 +398,9 @@ def main():
                                          zipf=not args.uniform, lengths=lengths))
     exchange, direct = "none", False
     if collective:
-        # ~ max_r(docs) K + max_r(nnz), from the arguments only: the same choice on every rank
-        slot = B * K + int(B * args.mean_unique * 1.2)
-        factors_bytes, sstats_bytes = 8. * xworld * slot, 8. * 2. * KV
-        exchange = args.exchange if args.exchange not in ("auto", "direct") else \
-            ("factors" if factors_bytes < sstats_bytes or args.exchange == "direct" else "sstats")
-        if vworld:
-            exchange = "factors"
+        # from the arguments only: the same choice on every rank (exchange_plan, above)
+        plan = exchange_plan(args, world, vworld)
+        slot, exchange = plan["slot_doubles"], plan["exchange"]
         if args.exchange == "direct" and world > 1:
             # every rank exports its region, the handles travel through the process group,
             # every rank maps its peers' regions (all ranks together, or none)

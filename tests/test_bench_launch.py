@@ -27,7 +27,7 @@ def test_self_launch_spawns_every_rank_and_relays_one_line(tmp_path):
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 4 and out["torch_in_rank"] is False
-    seen = sorted(os.listdir(tmp_path))
+    seen = sorted(n for n in os.listdir(tmp_path) if n.startswith("rank"))
     assert seen == ["rank0", "rank1", "rank2", "rank3"]
     for i, name in enumerate(seen):
         rank, world, addr, parent_had_torch = open(tmp_path / name).read().split()
@@ -59,4 +59,34 @@ def test_under_a_launcher_it_does_not_spawn(tmp_path):
     r = run(2, {"RANK": "1", "LOCAL_RANK": "1", "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1",
                 "MASTER_PORT": "29999", "TRLDA_BENCH_DRY_DIR": str(tmp_path)})
     assert r.returncode == 0 and r.stdout.strip() == ""
-    assert os.listdir(tmp_path) == ["rank1"]
+    assert sorted(os.listdir(tmp_path)) == ["plan1.json", "rank1"]
+
+
+def test_eight_ranks_build_the_same_exchange_plan(tmp_path):
+    """`bench.py --gpus 8` (BASELINE.json config 3: K = 100, V = 7000, 200 documents per GPU): every
+    rank, from its arguments alone, arrives at the same plan for what crosses ranks -- `auto` = the
+    factor all-gather (1.4 MB per rank and step against 11.2 MB for the all-reduce) with the
+    statistics + M-step sharded by vocabulary range; the direct (hipIpc) exchange only on request;
+    the same at config 5's shape (K = 500, V = 100 000, 512 documents per GPU); the all-reduce
+    where it moves fewer bytes (a tiny vocabulary under large batches)."""
+    r = run(8, {"TRLDA_BENCH_DRY_DIR": str(tmp_path)})
+    assert r.returncode == 0, r.stderr
+    plans = [json.load(open(tmp_path / ("plan%d.json" % i))) for i in range(8)]
+    assert all(p == plans[0] for p in plans)
+    p = plans[0]
+    assert p["exchange"] == "factors" and p["word_sharded_m_step"] is True and p["direct_requested"] is False
+    assert p["batch_per_gpu"] == 200 and p["factors_bytes_per_rank"] < p["allreduce_bytes_per_rank"]
+    assert json.loads(r.stdout)["plan"] == p
+    for extra, want in ((["--whole-stats"], ("factors", False, False)),
+                        (["--exchange", "sstats"], ("sstats", False, False)),
+                        (["--exchange", "direct"], ("factors", True, True)),
+                        (["--global-batch", "1600"], ("factors", True, False)),
+                        (["--topics", "500", "--words", "100000", "--batch", "512"], ("factors", True, False)),
+                        (["--topics", "10", "--words", "100", "--batch", "4000"], ("sstats", False, False))):
+        d = tmp_path / ("x" + "_".join(extra).replace("-", ""))
+        d.mkdir()
+        r = run(8, {"TRLDA_BENCH_DRY_DIR": str(d)}, args=extra)
+        assert r.returncode == 0, r.stderr
+        ps = [json.load(open(d / ("plan%d.json" % i))) for i in range(8)]
+        assert all(q == ps[0] for q in ps)
+        assert (ps[0]["exchange"], ps[0]["word_sharded_m_step"], ps[0]["direct_requested"]) == want, (extra, ps[0])

@@ -239,6 +239,48 @@ def test_word_sharded_m_step_processes(hip, tmp_path, world):
     one.close()
 
 
+def test_config3_literally_eight_ranks(hip, tmp_path):
+    """BASELINE.json config 3 as it is worded: OnlineLDA K = 100, V = 7000, a mini-batch of 1600
+    documents sharded 200 per rank over EIGHT ranks (here: eight processes on the one GPU, the
+    all-gather hook as transport), the default exchange plan -- factors all-gathered, statistics +
+    M-step sharded by vocabulary range, lambda columns exchanged in place -- with the trust-region
+    loop (max_iter_tr = 3) and without (0): eight bitwise-equal replicas; the call without a loop
+    bitwise the one-GPU lambda of the whole 1600-document mini-batch, the trajectory to 1e-11;
+    one factor exchange per E-step, one lambda exchange per M-step.  (the
+    world-8 shape had never run, even as processes.)"""
+    K, V, D, world = 100, 7000, 1000000, 8
+    specs = [dict(kind="update", B=1600, corpus_seed=941, seed=15, max_iter_tr=0, max_iter_inference=20),
+             dict(kind="update", B=1600, corpus_seed=942, seed=16, max_iter_tr=3, max_iter_inference=20)]
+    csrs = [corpus(1600, V, seed=s["corpus_seed"], mean_unique=100) for s in specs]
+    for c in csrs:                                   # 200 documents per rank, to a few by nnz balance
+        assert np.all(np.abs(np.diff(c.shard_cuts(world)) - 200) <= 12)
+    cfg = dict(K=K, V=V, D=D, alpha=.1, eta=.3, lambda_seed=61,
+               max_count=slot_bound(csrs, K, world), calls=specs)
+    # the call without a trust-region loop on its own: one M-step, nothing downstream of it
+    first = run_ranks(tmp_path, dict(cfg, calls=specs[:1]), world)
+    one = Single(hip, K, V, random_lambda(K, V, 61), .1)
+    rho0 = one.update(csrs[0], D, .3, 15, 0, 20)
+    for r in first:
+        assert int(r["word_sharded"][0]) == 1
+        assert np.array_equal(r["lambda"], first[0]["lambda"])
+        assert int(r["exchanges"][0]) == 1 and int(r["lambda_exchanges"][0]) == 1
+    assert float(first[0]["rho0"][0]) == rho0
+    assert np.array_equal(first[0]["lambda"], one.lambdas())
+    # both calls: 1 + 3 E-steps
+    res = run_ranks(tmp_path, cfg, world)
+    rho1 = one.update(csrs[1], D, .3, 16, 3, 20)
+    for r in res:
+        assert int(r["word_sharded"][0]) == 1
+        assert np.array_equal(r["lambda"], res[0]["lambda"])          # replicas: bitwise
+        assert int(r["exchanges"][0]) == 4 and int(r["lambda_exchanges"][0]) == 4
+        # per M-step a rank receives the table minus its own range: 7/8 of it on average
+        got = int(r["lambda_exchanges"][1])
+        assert 4 * K * V * 8 * 0.6 < got < 4 * K * V * 8
+    assert [float(res[0]["rho%d" % i][0]) for i in range(2)] == [rho0, rho1]
+    assert relerr(res[0]["lambda"], one.lambdas()) < 1e-11
+    one.close()
+
+
 def test_online_update_dp_large_table_and_plain_sequence(hip, tmp_path):
     """K = 500 (the one-orientation document kernel, streaming row sums, the pair-gather
     statistics kernel) over two ranks; and the plain launch sequence (fused update off) through
