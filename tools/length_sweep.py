@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--lengths", default="32,64,100,128,129,144,145,160,192,193,224,256,320,400,600")
     ap.add_argument("--series", default="all,one")
     ap.add_argument("--wide", action="store_true", help="force the single-orientation kernel")
+    ap.add_argument("--no-deferred", action="store_true",
+                    help="every step launches its statistics kernel (rounds 1-4) instead of leaving them "
+                         "to the next step's document launch (trlda_model_set_deferred_stats)")
     args = ap.parse_args()
     import torch
     from trlda_amd import _ffi
@@ -49,6 +52,7 @@ def main():
     _ffi.check(L.trlda_model_set_alpha(model, np.full(K, .1)))
     if args.wide:
         _ffi.check(L.trlda_model_set_doc_kernel(model, 2))
+    _ffi.check(L.trlda_model_set_deferred_stats(model, int(not args.no_deferred)))
     g0 = np.empty((K, B), order="F")
     L.trlda_sample_gamma_init(K, B, g0)
     gamma0 = torch.from_numpy(np.ascontiguousarray(g0.T)).to(dev)
@@ -73,11 +77,13 @@ def main():
             t = time.perf_counter()
             for i in range(args.steps):
                 step(i)
+            flags = L.trlda_model_last_deferred(model)
+            _ffi.check(L.trlda_model_flush(model))    # (the last step's statistics: inside the clock)
             torch.cuda.synchronize()
             us = (time.perf_counter() - t) / args.steps * 1e6
-            print("%-4s n=%4d  %8.1f us  %s  fused_preamble=%d" % (
+            print("%-4s n=%4d  %8.1f us  %s  fused_preamble=%d deferred=%d" % (
                 series, n, us, L.trlda_model_last_doc_kernel(model).decode(),
-                L.trlda_model_last_preamble_fused(model)), flush=True)
+                L.trlda_model_last_preamble_fused(model), flags), flush=True)
             for b in batches:
                 b.close()
 

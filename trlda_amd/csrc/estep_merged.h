@@ -84,6 +84,7 @@ struct MergedArgs {
     // sorted by decreasing length): entries 9..16 | 5..8 | 3..4 | 1..2 of a short list, chunks (a
     // sixteenth of a long list, rounded up) of 9..16 | 5..8 | 3..4 | 1..2 entries
     int cls_short[4], cls_long[4];
+    int slots;                    // merged launch: the statistics stage in its 16-slot form (merged_stats_slots)
     unsigned int *work_counter;   // deferred launch: the helpers' item counter (only grows) ...
     unsigned int work_base;       // ... and its value at the start of the launch
     unsigned long long *tstamps;  // diagnostics (TRLDA_MERGED_STAMPS=1, tools/merged_stamps.py) or nullptr:
@@ -433,12 +434,17 @@ __device__ __forceinline__ void merged_stats(const MergedArgs &mg, int vb, doubl
         o.partial[(size_t)vb * K + tid] = rsl;
 }
 
+__device__ __forceinline__ void merged_stats_slots(const MergedArgs &mg, int vb, double *lds);   // (below)
+
 // the statistics workgroups: past the documents and the next batch's preamble
 __device__ __forceinline__ void merged_helper(const MergedArgs &mg, double *lds, int vb)
 {
     if (mg.tstamps && threadIdx.x == 0)
         mg.tstamps[3 * vb] = __builtin_amdgcn_s_memrealtime();
-    merged_stats(mg, vb, lds);
+    if (mg.slots)                                    // launch-uniform
+        merged_stats_slots(mg, vb, lds);
+    else
+        merged_stats(mg, vb, lds);
     if (mg.tstamps && threadIdx.x == 0)
         mg.tstamps[3 * vb + 2] = __builtin_amdgcn_s_memrealtime();
 }
@@ -804,6 +810,243 @@ struct DeferredStamp {
 // thread 0) before the current one is worked on, so its latency is not on anybody's path; the
 // counter only grows -- the host passes the value it has at the start of the launch and adds the
 // launch's items afterwards.
+// ---- the statistics stage of a MERGED launch in the same 16-slot form (round 5) ---------------------
+// merged_stats walks a list four rows at a time: the workgroups with the longest lists go through
+// up to four dependent rounds of gathers after the documents' flag (flag -> end: median 2.6 us, the
+// longest 4.7; with the M-step 3.6 / 5.6 -- profiles/r04_merged_stamps.txt), and the launch ends
+// with them.  Here every wave is ONE round of at most 16 rows, the lists in classes by length as
+// in the deferred stage, at most four words per wave (the M-step's exp(psi(lambda)) is two
+// evaluations per lane and word, one after the other).  Before the flag: descriptors, documents,
+// exp(psi(lambda)) and lambda' of the wave's words; after it: weights and rows together (one
+// latency), the sums, the M-step.  Same sums in the same order: bitwise the statistics of
+// merged_stats and of the kernel of its own.
+constexpr int kMergedSlotNW[4] = {1, 2, 4, 4};   // words per wave by class (entries 9..16 | 5..8 | 3..4 | 1..2)
+
+__host__ __device__ inline int merged_slot_short_items(const int (&c)[4])
+{
+    int n = 0;
+    for (int i = 0; i < 4; ++i)
+        n += (c[i] + 8 * kMergedSlotNW[i] - 1) / (8 * kMergedSlotNW[i]);
+    return n;
+}
+
+__device__ __forceinline__ void merged_stats_slots(const MergedArgs &mg, int vb, double *lds)
+{
+    constexpr int W = kRegThreads / kWave;           // 8 waves
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int K = mg.K;
+    const UpdateOut &o = mg.o;
+    const int kk = min(2 * lane, K - 2);             // this lane's pair of topics (K even)
+    const bool k_on = 2 * lane < K;
+    const int n_stat = mg.n_short + mg.n_long;
+    const unsigned int seen = merged_flag_load(mg, vb);          // (requested before everything else)
+
+    // columns of the words outside the batch: zero (lda.cpp:169), written while the documents run
+    if (mg.active_flag && o.sstats && !o.lambda) {   // launch-uniform
+        for (int w0 = (vb * W + wid) * kWave; w0 < mg.V; w0 += n_stat * W * kWave) {
+            const int w = w0 + lane;
+            unsigned long long todo = __ballot(w < mg.V && mg.active_flag[w] == 0);
+            while (todo) {                           // wave-uniform
+                const int j = __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                if (k_on)
+                    *reinterpret_cast<double2 *>(o.sstats + (size_t)(w0 + j) * K + 2 * lane) = make_double2(0.0, 0.0);
+            }
+        }
+    }
+
+    if (vb < mg.n_short) {
+        int cls = 0, it = vb, base = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int items = (mg.cls_short[c] + W * kMergedSlotNW[c] - 1) / (W * kMergedSlotNW[c]);
+            if (cls == c && it >= items) {
+                it -= items;
+                base += mg.cls_short[c];
+                cls = c + 1;
+            }
+        }
+        const int lr = 4 - cls, R = 1 << lr;
+        const int nw = cls == 0 ? 1 : cls == 1 ? 2 : 4;          // kMergedSlotNW
+        const int t_end = base + (cls == 0 ? mg.cls_short[0] : cls == 1 ? mg.cls_short[1]
+                                  : cls == 2 ? mg.cls_short[2] : mg.cls_short[3]);
+        const int t = base + (it * W + wid) * nw;
+        // ---- before the flag: everything that does not depend on the documents
+        const int sl = min(lane, 15), j = sl >> lr, u = sl & (R - 1);
+        const bool w_on = j < nw && t + j < t_end;
+        const int4 d = mg.desc[min(t + j, mg.N_short - 1)];     // (word, first entry, entries, 0)
+        const bool on = lane < 16 && w_on && u < d.z;
+        const int q = on ? d.y + u : 0;
+        const int doc = on ? mg.wdoc[q] : -1;                   // -1: the zero row
+        const int wword = w_on ? d.x : -1;
+        double2 e2[8], lp[8];                        // (R >= 2: segments start at even slots)
+#pragma unroll
+        for (int s0 = 0; s0 < 16; s0 += 2) {
+            e2[s0 >> 1] = make_double2(0.0, 0.0);
+            lp[s0 >> 1] = make_double2(0.0, 0.0);
+            if ((s0 & (R - 1)) == 0) {               // wave-uniform: a segment starts here
+                const size_t ic = (size_t)max(__builtin_amdgcn_readlane(wword, s0), 0) * K + kk;
+                e2[s0 >> 1] = *reinterpret_cast<const double2 *>(mg.eeb + ic);
+                if (o.lambda_prime)                  // launch-uniform
+                    lp[s0 >> 1] = *reinterpret_cast<const double2 *>(o.lambda_prime + ic);
+            }
+        }
+        merged_wait_docs(mg, vb, seen);
+        // ---- after it: the weights and the rows together
+        const double tw = on ? __hip_atomic_load(const_cast<double *>(mg.tw_word) + q, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT)
+                             : 0.0;
+        double2 ev[16];
+#pragma unroll
+        for (int s0 = 0; s0 < 16; ++s0) {
+            const long long row = (long long)__builtin_amdgcn_readlane(doc, s0) * K;
+            ev[s0] = *reinterpret_cast<const double2 *>(mg.epg + row + kk);
+        }
+        const int tlo = __double2loint(tw), thi = __double2hiint(tw);
+        double2 acc = make_double2(0.0, 0.0), ec = make_double2(0.0, 0.0), lc = make_double2(0.0, 0.0);
+        double2 rs = make_double2(0.0, 0.0);
+#pragma unroll
+        for (int s0 = 0; s0 < 16; ++s0) {
+            if ((s0 & 1) == 0 && (s0 & (R - 1)) == 0) {
+                ec = e2[s0 >> 1];
+                lc = lp[s0 >> 1];
+            }
+            const double tu = __hiloint2double(__builtin_amdgcn_readlane(thi, s0), __builtin_amdgcn_readlane(tlo, s0));
+            acc.x = fma(tu, ev[s0].x, acc.x);        // (+0 * 0 past a list's end)
+            acc.y = fma(tu, ev[s0].y, acc.y);
+            if (((s0 + 1) & (R - 1)) == 0) {         // wave-uniform: the segment ends here
+                const int w = __builtin_amdgcn_readlane(wword, s0);
+                if (w >= 0 && k_on) {
+                    const double2 lam = merged_update_pair(o, (size_t)w * K + 2 * lane,
+                                                           make_double2(acc.x * ec.x, acc.y * ec.y), lc);
+                    rs.x += lam.x;
+                    rs.y += lam.y;
+                }
+                acc = make_double2(0.0, 0.0);
+            }
+        }
+        if (o.partial) {                             // launch-uniform
+            if (k_on)
+                *reinterpret_cast<double2 *>(lds + wid * K + 2 * lane) = rs;
+            __syncthreads();
+            for (int k = tid; k < K; k += kRegThreads) {
+                double sum = lds[k];
+#pragma unroll
+                for (int c = 1; c < W; ++c)
+                    sum += lds[c * K + k];
+                o.partial[(size_t)vb * K + k] = sum;
+            }
+        }
+        return;
+    }
+
+    // ---- long lists: LW per workgroup (1 | 1 | 2 | 4 by class), wave `wid` walks chunks wid and
+    // wid + 8 of each; thread (i, k) = (tid / TPW, tid % TPW) finishes topic k of list i
+    int cls = 0, it = vb - mg.n_short, base = 0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int items = (mg.cls_long[c] + kDeferLongLW[c] - 1) / kDeferLongLW[c];
+        if (cls == c && it >= items) {
+            it -= items;
+            base += mg.cls_long[c];
+            cls = c + 1;
+        }
+    }
+    const int lr = 4 - cls, R = 1 << lr;
+    const bool two_pass = lr == 4;
+    const int LW = cls == 0 ? 1 : 16 >> (5 - cls);   // kDeferLongLW: 1, 1, 2, 4
+    const int t_end = base + (cls == 0 ? mg.cls_long[0] : cls == 1 ? mg.cls_long[1]
+                              : cls == 2 ? mg.cls_long[2] : mg.cls_long[3]);
+    const int t = base + it * LW;
+    const int TPW = kRegThreads / LW;                // >= 128 >= K
+    const int fi = tid / TPW, fk = tid % TPW;
+    const int4 df = mg.desc[mg.N_short + min(t + fi, t_end - 1)];
+    const bool fin_on = t + fi < t_end && fk < K;
+    const size_t fidx = (size_t)df.x * K + min(fk, K - 1);
+    const double ek = mg.eeb[fidx];
+    const double lpk = o.lambda_prime ? o.lambda_prime[fidx] : 0.0;
+    // the segments' documents (static): pass 0 and, for the longest class, pass 1
+    int docs[2], qq[2];
+    bool ons[2];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int sl = min(lane, 15), g = two_pass ? pass : sl >> lr, u = sl & (R - 1);
+        const int i = g >> 1, h = g & 1;
+        const bool w_on = t + i < t_end && (two_pass || pass == 0);
+        const int4 d = mg.desc[mg.N_short + min(t + i, t_end - 1)];
+        const int L = w_on ? d.z : 0;
+        const int chunk = (L + 15) / 16;             // <= R
+        const int c0 = min(L, (wid + 8 * h) * chunk);
+        const int cl = min(L, c0 + chunk) - c0;
+        ons[pass] = lane < 16 && u < cl;
+        qq[pass] = ons[pass] ? d.y + c0 + u : 0;
+        docs[pass] = ons[pass] ? mg.wdoc[qq[pass]] : -1;
+    }
+    merged_wait_docs(mg, vb, seen);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 0 || two_pass) {                 // block-uniform
+            const double tw = ons[pass] ? __hip_atomic_load(const_cast<double *>(mg.tw_word) + qq[pass],
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                        : 0.0;
+            double2 ev[16];
+#pragma unroll
+            for (int s0 = 0; s0 < 16; ++s0) {
+                const long long row = (long long)__builtin_amdgcn_readlane(docs[pass], s0) * K;
+                ev[s0] = *reinterpret_cast<const double2 *>(mg.epg + row + kk);
+            }
+            const int tlo = __double2loint(tw), thi = __double2hiint(tw);
+            double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int s0 = 0; s0 < 16; ++s0) {
+                const double tu = __hiloint2double(__builtin_amdgcn_readlane(thi, s0),
+                                                   __builtin_amdgcn_readlane(tlo, s0));
+                acc.x = fma(tu, ev[s0].x, acc.x);
+                acc.y = fma(tu, ev[s0].y, acc.y);
+                if (((s0 + 1) & (R - 1)) == 0) {     // wave-uniform: the segment ends here
+                    const int gs = two_pass ? pass : s0 >> lr;
+                    if (k_on)
+                        *reinterpret_cast<double2 *>(lds + (size_t)((gs >> 1) * 16 + wid + 8 * (gs & 1)) * K + 2 * lane) = acc;
+                    acc = make_double2(0.0, 0.0);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    double lam = 0.0;
+    if (fin_on) {
+        const double *col = lds + (size_t)(fi * 16) * K + fk;
+        double sum = col[0];
+#pragma unroll
+        for (int c = 1; c < 16; ++c)
+            sum += col[(size_t)c * K];
+        const double sv = sum * ek;
+        if (o.sstats)
+            o.sstats[fidx] = sv;
+        if (o.lambda) {
+            const double hat = o.eta + o.scale * sv;
+            lam = o.lambda_prime ? o.omr * lpk + o.rho * hat : o.rho * hat;
+            o.lambda[fidx] = lam;
+            if (o.u_out)
+                o.u_out[fidx] = exp_digamma_positive(lam);
+        }
+    }
+    if (o.partial) {                                 // launch-uniform: this workgroup's row of lambda sums
+        __syncthreads();                             // (the chunk sums have been read)
+        if (fk < K)
+            lds[fi * K + fk] = lam;                  // (0 for a list past the end)
+        __syncthreads();
+        if (tid < K) {
+            double sum = lds[tid];
+            for (int i = 1; i < LW; ++i)
+                sum += lds[i * K + tid];
+            o.partial[(size_t)vb * K + tid] = sum;
+        }
+    }
+}
+
 // The kernel's arguments (~700 bytes: three structures) are fetched where they are first used, a
 // scalar load and a wait at a time -- in the helper's path ten of them one behind the other, each a
 // miss in the scalar cache: ~3 us before a helper's first item (profiles/r05_deferred_notes.txt:

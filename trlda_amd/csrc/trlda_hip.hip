@@ -1911,6 +1911,23 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                                  ? std::max(1, std::min((mg.N_short + 8 * trlda::kMergedNW - 1) / (8 * trlda::kMergedNW),
                                                         room - mg.n_long))
                                  : 0;
+                // the stage in its 16-slot form (estep_merged.h, merged_stats_slots): a workgroup per
+                // item of a length class, when the batch's items fit the stage's flags
+                static const bool slots_off = [] {
+                    const char *e = std::getenv("TRLDA_MERGED_SLOTS");
+                    return e && std::atoi(e) == 0;
+                }();
+                for (int c = 0; c < 4; ++c) {
+                    mg.cls_short[c] = b->cls_short[c];
+                    mg.cls_long[c] = b->cls_long[c];
+                }
+                const int s_short = trlda::merged_slot_short_items(mg.cls_short);
+                const int s_long = trlda::deferred_long_items(mg.cls_long);
+                mg.slots = !slots_off && s_short + s_long <= trlda::kMergedMaxHelpers;
+                if (mg.slots) {
+                    mg.n_short = s_short;
+                    mg.n_long = s_long;
+                }
                 mg.desc = reinterpret_cast<const int4 *>(b->mdesc);
                 mg.wdoc = b->wdoc; mg.tw_word = m->tw_word; mg.epg = m->epg; mg.eeb = m->eeb_cur;
                 mg.active_flag = (!out.upd.lambda && !out.active_only) ? b->active_flag : nullptr;
@@ -4953,6 +4970,93 @@ extern "C" int trlda_debug_graph_update(trlda_model *m, const trlda_batch *b, in
     usec_out[1] = std::chrono::duration<double, std::micro>(now() - t0).count() / reps;
     (void)hipGraphExecDestroy(exec);
     (void)hipGraphDestroy(graph);
+    return TRLDA_OK;
+}
+
+// Experiment, second form (round 5): what a PRODUCT path would have to do -- every call has other
+// arguments (batch, grids, gamma0 windows, counters), so every call is captured anew and the
+// instantiated graph is brought up to date with hipGraphExecUpdate (re-instantiated when that is
+// refused), then launched.  Two batches in turn.  usec_out: [0] per call enqueued launch by launch,
+// [1] per call through capture + update + launch, [2] host time of capture + update per call,
+// [3] share of calls whose update was refused.
+extern "C" int trlda_debug_graph_update2(trlda_model *m, const trlda_batch *b0, const trlda_batch *b1,
+                                         int num_documents, double eta, int max_iter_tr, int max_iter_inference,
+                                         int reps, double *usec_out)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (!b0 || !b1 || !usec_out || reps < 1)
+        return fail(TRLDA_ERR_ARG, "bad graph probe arguments");
+    int count = 0;
+    double rho = 0.;
+    auto call = [&](int i) {
+        return trlda_model_online_update(m, (i & 1) ? b1 : b0, num_documents, eta, max_iter_tr, max_iter_inference,
+                                         .7, 100., 0.01, 1, 1, 1e-3, &count, &rho, nullptr);
+    };
+    for (int i = 0; i < 4 && !rc; ++i)
+        rc = call(i);
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto t0 = now();
+    for (int i = 0; i < reps && !rc; ++i)
+        rc = call(i);
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    usec_out[0] = std::chrono::duration<double, std::micro>(now() - t0).count() / reps;
+    hipGraphExec_t exec = nullptr;
+    double host_us = 0.;
+    int refused = 0;
+    auto graph_call = [&](int i) -> int {
+        auto h0 = now();
+        hipGraph_t graph = nullptr;
+        HIP_TRY(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+        int r = call(i);
+        hipError_t e = hipStreamEndCapture(m->stream, &graph);
+        if (r || e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(TRLDA_ERR_HIP, std::string("capture failed: ") + (r ? trlda_last_error() : hipGetErrorString(e)));
+        }
+        bool fresh = exec == nullptr;
+        if (exec) {
+            hipGraphNode_t bad = nullptr;
+            hipGraphExecUpdateResult res;
+            if (hipGraphExecUpdate(exec, graph, &bad, &res) != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipGraphExecDestroy(exec);
+                exec = nullptr;
+                ++refused;
+            }
+        }
+        if (!exec)
+            HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        (void)fresh;
+        host_us += std::chrono::duration<double, std::micro>(now() - h0).count();
+        HIP_TRY(hipGraphLaunch(exec, m->stream));
+        (void)hipGraphDestroy(graph);
+        return TRLDA_OK;
+    };
+    for (int i = 0; i < 4 && !rc; ++i)
+        rc = graph_call(i);
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    host_us = 0.;
+    refused = 0;
+    t0 = now();
+    for (int i = 0; i < reps && !rc; ++i)
+        rc = graph_call(i);
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(m->stream));
+    usec_out[1] = std::chrono::duration<double, std::micro>(now() - t0).count() / reps;
+    usec_out[2] = host_us / reps;
+    usec_out[3] = (double)refused / reps;
+    if (exec)
+        (void)hipGraphExecDestroy(exec);
     return TRLDA_OK;
 }
 
