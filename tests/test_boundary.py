@@ -100,6 +100,15 @@ def test_occupancy_critical_kernels_keep_their_registers(hip_lib):
         # array indexed dynamically would add its own size on top)
         assert f["private_segment_fixed_size"] <= 48 and f["vgpr_spill_count"] <= 4, (name, f)
         assert f["vgpr_count"] <= 256
+    # the deferred launches (round 5): what the helpers need must not cost the documents anything --
+    # the register kernel's deferred form spills no vector register and touches no scratch beyond
+    # the rare psi branch's call frame (with the helpers' item code hoisted in front of their loop
+    # it spilled 25 and every helper started 3 us late); the tiered forms stay within one spill
+    deferred = {k: v for k, v in res.items() if "deferred_kernel" in k}
+    assert len(deferred) == 3, sorted(deferred)
+    for name, f in deferred.items():
+        assert f["private_segment_fixed_size"] <= 48 and f["vgpr_count"] <= 256, (name, f)
+        assert f["vgpr_spill_count"] <= (0 if "estep_docs_reg_deferred" in name else 2), (name, f)
     emit = [v for k, v in res.items() if "sstats_update2_kernelILi1024ELi1ELi1ELb1" in k]
     assert len(emit) == 1 and emit[0]["vgpr_count"] <= 64, emit
     docs = [v for k, v in res.items() if "estep_docs_reg_kernelILi0" in k]

@@ -1,84 +1,156 @@
 #!/bin/bash
-# Run on the GPU box from the repo root:  tools/make_profiles.sh <round-tag> <commit>
-# Produces under gpurun_out/ (copy what is to be judged into profiles/):
-#   <tag>_kernel_stats.csv       rocprofv3 --kernel-trace --stats of the default bench command
-#   <tag>_pmc_fetch.txt / _write.txt / _sq.txt   PMC passes (separate runs, kernel-trace only)
-#   <tag>_traffic.json           tools/make_traffic.py from the two passes, stamped with <commit>
-#   <tag>_bench.json             the un-profiled default bench line
-#   <tag>_k500_*                 the same three for the E-step at K = 500, V = 100 000, B = 512
-#   <tag>_configs.txt            tools/sweep_configs.sh: the other BASELINE.json configurations, with parity
-#   <tag>_host_rates.txt         tools/host_rate.py: ingestion and PCIe-inclusive entry points
-#   <tag>_update_rates.txt       tools/update_rate.py: whole update_parameters calls
-#   <tag>_<cfg>_update_kernel_stats.csv   tools/prof_update.sh: kernels of the update loops
-#   <tag>_bench_forced_dist_world1_{factors,sstats}.json, <tag>_bench_virtual_world{2,4,8}.json,
-#   <tag>_virtual_world8_kernel_stats.csv   the data-parallel step
-#   <tag>_stamps_reg.txt         tools/stamps.sh: cycle shares inside the document kernel
-#   <tag>_length_sweep.txt, <tag>_speed_workload.txt, <tag>_bench_lengthslognormal.json, <tag>_bench_uniform.json,
-#   <tag>_xcu_probe.txt          document lengths
-#   <tag>_timeline_*.txt, <tag>_merged_stamps.txt, <tag>_graph_probe.txt, <tag>_anyorder_probe.txt,
-#   <tag>_configs_lists_unsplit.txt, <tag>_bench_merged_level{0,2}.json, <tag>_update_rates_unmerged.txt,
-#   <tag>_bench_virtual_world*_whole_stats.json    round 4: merged launch, list segments, word-sharded M-step
-tag=${1:-r04}; commit=${2:-unknown}
+# Run on the GPU box from the repo root:
+#     tools/make_profiles.sh <round-tag> <commit> [target ...]
+# Everything the profiles/ directory is made from, as TARGETS (default: all of `core`); each writes
+# gpurun_out/<tag>_*, from where what is to be judged is copied into profiles/ (tracked).
+#
+#   check      smoke, the whole GPU suite, the driver's bench command, the 200-step bench, lifecycle fuzz
+#   headline   rocprofv3 --kernel-trace --stats of the default bench command; the un-profiled line
+#   pmc        FETCH_SIZE / WRITE_SIZE / SQ_* passes (separate runs, kernel-trace only) + traffic.json
+#   k500       the same three for the E-step at K = 500, V = 100 000, B = 512
+#   configs    tools/sweep_configs.sh: the other BASELINE.json configurations, with parity
+#   updates    tools/update_rate.py, tools/host_rate.py, kernels of the update loops (prof_update.sh)
+#   dp         the N > 1 code path on one GPU: forced 1-rank group, --virtual-world 2 / 4 / 8
+#   stamps     cycle stamps inside the document kernel (per variant), the deferred launch's timeline,
+#              the merged launch's stamps, timelines of an update call and of the bench
+#   lengths    tools/length_sweep.py, the reference's test_speed workload, log-normal / uniform bench
+#   deferred   the headline with and without deferred statistics / prefetch; helper counts
+#   probes     graph probe, any-order probe, xcu probe (stand-alone HIP programs under tools/probes)
+#   fuzz       the four fuzzers at a few seeds each (long: ~15 min)
+#   core       check headline pmc configs updates dp stamps lengths deferred
+tag=${1:-r05}; commit=${2:-unknown}; shift; shift
+targets=${@:-core}
 export TMPDIR=/tmp
-tools/prof_stats.sh ${tag} --steps 200 --warmup 20 > /dev/null
-tools/prof_pmc.sh ${tag}_fetch "FETCH_SIZE" --steps 50 --warmup 5 > gpurun_out/${tag}_pmc_fetch.txt
-tools/prof_pmc.sh ${tag}_write "WRITE_SIZE" --steps 50 --warmup 5 > gpurun_out/${tag}_pmc_write.txt
-tools/prof_pmc.sh ${tag}_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY" --steps 50 --warmup 5 > gpurun_out/${tag}_pmc_sq.txt
-python3 tools/make_traffic.py gpurun_out/${tag}_pmc_fetch.txt gpurun_out/${tag}_pmc_write.txt estep_docs_reg_kernel,estep_docs_tiered_kernel ${commit} > gpurun_out/${tag}_traffic.json
-K500="--topics 500 --words 100000 --batch 512 --steps 20 --warmup 3"
-tools/prof_stats.sh ${tag}_k500 $K500 > /dev/null
-tools/prof_pmc.sh ${tag}_k500_fetch "FETCH_SIZE" $K500 > gpurun_out/${tag}_k500_pmc_fetch.txt
-tools/prof_pmc.sh ${tag}_k500_write "WRITE_SIZE" $K500 > gpurun_out/${tag}_k500_pmc_write.txt
-python3 bench.py --steps 200 --warmup 20 > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
-bash tools/sweep_configs.sh > gpurun_out/${tag}_configs.txt 2>&1
-python3 tools/host_rate.py > gpurun_out/${tag}_host_rates.txt 2>&1
-python3 tools/update_rate.py --configs small,c3,c5a,c5b,c4 --modes fused,fused_sep,plain > gpurun_out/${tag}_update_rates.txt 2>&1
-python3 tools/update_rate.py --configs small,c5a,c5b,c4 --modes fused --host-draw > gpurun_out/${tag}_update_rates_host_draw.txt 2>&1
-# the N > 1 code path on one GPU (1-rank process group), both exchanges; and what ONE rank of 2 / 4 / 8
-# executes per step with the factor exchange (--virtual-world: no collective runs)
-for ex in factors sstats; do
-  TRLDA_BENCH_FORCE_DIST=1 python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-update-rates --exchange $ex 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_forced_dist_world1_${ex}.json
+o=gpurun_out
+mkdir -p $o
+clean() { grep -v "amdgpu.ids"; }
+benchline() { python3 bench.py --no-cpu-baseline --no-update-rates "$@" 2>/dev/null | tail -1; }
+
+t_check() {
+  ( python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+    timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -6
+    timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $o/${tag}_bench_driver.json
+    python3 - <<PY
+import json
+j = json.loads(open("$o/${tag}_bench_driver.json").read())
+print("driver bench:", j["value"], j["ms_per_step"], "fixed", j.get("value_fixed_work"), "frac", j["roofline"]["frac"],
+      "cpu", j["cpu_baseline"]["value"], "tr10", j["update_parameters"]["device_batch_tr10"],
+      "tr0", j["update_parameters"]["device_batch_tr0"], "settle", j.get("settle_steps"), j.get("settle_ms"))
+PY
+    timeout 600 python bench.py --steps 200 --warmup 20 2>/dev/null | tail -1 > $o/${tag}_bench.json
+    python3 -c "
+import json; j=json.loads(open('$o/${tag}_bench.json').read()); print('200 steps:', j['value'], j['ms_per_step'], j['roofline']['frac'], j['roofline']['kernels_us'], j['parity'])"
+    for sd in 1 2; do timeout 900 python tests/fuzz_lifecycle.py --steps 300 --seed $sd 2>&1 | tail -1; done
+  ) 2>&1 | clean | tee $o/${tag}_final_check.txt
+}
+
+t_headline() {
+  tools/prof_stats.sh ${tag} --steps 200 --warmup 20 > /dev/null
+  cut -c1-160 $o/${tag}_kernel_stats.csv | head -8
+}
+
+t_pmc() {
+  tools/prof_pmc.sh ${tag}_fetch "FETCH_SIZE" --steps 50 --warmup 5 > $o/${tag}_pmc_fetch.txt
+  tools/prof_pmc.sh ${tag}_write "WRITE_SIZE" --steps 50 --warmup 5 > $o/${tag}_pmc_write.txt
+  tools/prof_pmc.sh ${tag}_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY" --steps 50 --warmup 5 > $o/${tag}_pmc_sq.txt
+  # the dominant launch: documents + next preamble + previous statistics (estep_merged.h, deferred)
+  python3 tools/make_traffic.py $o/${tag}_pmc_fetch.txt $o/${tag}_pmc_write.txt estep_docs_reg_deferred_kernel,estep_docs_tiered_deferred_kernel ${commit} > $o/${tag}_traffic.json
+  cat $o/${tag}_pmc_fetch.txt $o/${tag}_pmc_write.txt
+}
+
+t_k500() {
+  K500="--topics 500 --words 100000 --batch 512 --steps 20 --warmup 3"
+  tools/prof_stats.sh ${tag}_k500 $K500 > /dev/null
+  tools/prof_pmc.sh ${tag}_k500_fetch "FETCH_SIZE" $K500 > $o/${tag}_k500_pmc_fetch.txt
+  tools/prof_pmc.sh ${tag}_k500_write "WRITE_SIZE" $K500 > $o/${tag}_k500_pmc_write.txt
+}
+
+t_configs() { bash tools/sweep_configs.sh 2>&1 | clean > $o/${tag}_configs.txt; tail -12 $o/${tag}_configs.txt | cut -c1-200; }
+
+t_updates() {
+  python3 tools/update_rate.py --configs small,c3,c5a,c5b,c4 --modes fused,plain 2>&1 | clean > $o/${tag}_update_rates.txt
+  python3 tools/host_rate.py 2>&1 | clean > $o/${tag}_host_rates.txt
+  for cfg in small c5a; do tools/prof_update.sh ${tag}_${cfg}_fused $cfg fused > /dev/null 2>&1; done
+  for sl in 1 0; do
+    TRLDA_MERGED_SLOTS=$sl python3 tools/update_rate.py --configs small --modes fused 2>&1 | clean | tail -2
+  done > $o/${tag}_update_rates_merged_slots.txt
+  cat $o/${tag}_update_rates.txt
+}
+
+t_dp() {
+  for ex in factors sstats; do
+    TRLDA_BENCH_FORCE_DIST=1 benchline --steps 200 --warmup 20 --exchange $ex > $o/${tag}_bench_forced_dist_world1_${ex}.json
+  done
+  for w in 2 4 8; do
+    benchline --steps 200 --warmup 20 --virtual-world $w > $o/${tag}_bench_virtual_world${w}.json
+    benchline --steps 200 --warmup 20 --virtual-world $w --whole-stats > $o/${tag}_bench_virtual_world${w}_whole_stats.json
+  done
+  python3 -c "
+import json
+for w in (2, 4, 8):
+    j = json.load(open('$o/${tag}_bench_virtual_world%d.json' % w)); print('virtual world', w, j['ms_per_step'], j['roofline']['kernels_us'])"
+}
+
+t_stamps() {
+  ( for env in "STAMPS_LEN=100" "STAMPS_LEN=128" "STAMPS_LEN=129" "STAMPS_ONE=129" "STAMPS_ONE=144" "STAMPS_ONE=160"; do
+      echo "== $env"; env $env bash tools/stamps.sh 2>&1 | grep -v "amdgpu.ids\|hipcc\|^/"
+    done ) > $o/${tag}_stamps_modes.txt 2>&1
+  python3 tools/deferred_stamps.py 2>&1 | clean > $o/${tag}_deferred_stamps.txt
+  (python3 tools/merged_stamps.py; python3 tools/merged_stamps.py --update) 2>&1 | clean > $o/${tag}_merged_stamps.txt
+  for what in update bench; do
+    rm -rf $o/${tag}_tl; mkdir -p $o/${tag}_tl
+    if [ $what = update ]; then
+      rocprofv3 --kernel-trace --output-format csv -d $o/${tag}_tl -- python3 tools/update_rate.py --configs small --modes fused > /dev/null 2>&1
+    else
+      rocprofv3 --kernel-trace --output-format csv -d $o/${tag}_tl -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-update-rates --headline-only > /dev/null 2>&1
+    fi
+    python3 tools/timeline.py $o/${tag}_tl --dump 26 > $o/${tag}_timeline_${what}.txt 2>&1
+  done
+  rm -rf $o/${tag}_tl
+  head -12 $o/${tag}_deferred_stamps.txt | cut -c1-250
+}
+
+t_lengths() {
+  python3 tools/length_sweep.py 2>&1 | clean > $o/${tag}_length_sweep.txt
+  python3 tools/length_sweep.py --no-deferred --lengths 100,128,129,144,145,192,193,400 2>&1 | clean > $o/${tag}_length_sweep_no_deferred.txt
+  python3 tools/speed_workload.py 2>&1 | clean > $o/${tag}_speed_workload.txt
+  for a in "--lengths lognormal" "--uniform"; do
+    python3 bench.py --steps 100 --warmup 10 --parity-only --no-update-rates $a 2>/dev/null | tail -1 > $o/${tag}_bench_$(echo $a | tr -d ' -').json
+  done
+  cat $o/${tag}_length_sweep.txt
+  python3 -c "
+import json
+for n in ('lengthslognormal', 'uniform'):
+    j = json.load(open('$o/${tag}_bench_%s.json' % n)); print(n, j['ms_per_step'], j['value'], j['parity'])"
+}
+
+t_deferred() {
+  ( for a in "" "--no-deferred" "--no-prefetch"; do
+      benchline --steps 200 --warmup 20 --headline-only $a | python3 -c "
+import sys,json; j=json.loads(sys.stdin.read()); print('bench $a:', j['ms_per_step'], j['value'], list(j['roofline']['kernels_us'].values()))"
+    done
+    for h in 56 128; do
+      TRLDA_DEFER_HELPERS=$h benchline --steps 200 --warmup 20 --headline-only | python3 -c "
+import sys,json; j=json.loads(sys.stdin.read()); print('helper workgroups capped at $h:', j['ms_per_step'])"
+    done ) 2>&1 | tee $o/${tag}_deferred_ab.txt
+}
+
+t_probes() {
+  python3 tools/graph_probe.py 2>&1 | clean > $o/${tag}_graph_probe.txt
+  for p in anyorder_probe xcu_probe; do
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probes/$p.hip -o tools/probes/$p 2>/dev/null && tools/probes/$p > $o/${tag}_$p.txt 2>&1
+  done
+  tail -3 $o/${tag}_graph_probe.txt
+}
+
+t_fuzz() {
+  ( for sd in 401 402; do timeout 1200 python tests/fuzz_estep.py --cases 120 --seed $sd 2>&1 | tail -1; done
+    for sd in 501 502; do timeout 1500 python tests/fuzz_update.py --cases 120 --seed $sd 2>&1 | tail -1; done
+    for sd in 601; do timeout 1500 python tests/fuzz_reference.py --cases 120 --seed $sd 2>&1 | tail -1; done
+    for sd in 31 32; do timeout 900 python tests/fuzz_lifecycle.py --steps 300 --seed $sd 2>&1 | tail -1; done ) | clean | tee $o/${tag}_fuzz.txt
+}
+
+for t in $targets; do
+  if [ $t = core ]; then set -- check headline pmc configs updates dp stamps lengths deferred; else set -- $t; fi
+  for u in "$@"; do echo "#### $u"; t_$u; done
 done
-TRLDA_BENCH_FORCE_DIST=1 python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-update-rates --global-batch 1600 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_forced_dist_world1_b1600.json
-for w in 2 4 8; do
-  python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-update-rates --virtual-world $w 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_virtual_world${w}.json
-  python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-update-rates --virtual-world $w --whole-stats 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_virtual_world${w}_whole_stats.json
-done
-rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_virtual8_prof -o v8 --output-format csv -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-update-rates --virtual-world 8 > /dev/null 2>&1
-cp $(find gpurun_out/${tag}_virtual8_prof -name "*kernel_stats.csv" | head -1) gpurun_out/${tag}_virtual_world8_kernel_stats.csv
-bash tools/stamps.sh > gpurun_out/${tag}_stamps_reg.txt 2>&1
-# round 4: where a trust-region iteration's time goes (durations back to back, no idle gaps), the
-# merged launch from the inside, and the HIP-graph experiment
-for mgd in 1 0; do
-  rm -rf gpurun_out/${tag}_tl; mkdir -p gpurun_out/${tag}_tl
-  TRLDA_MERGED=$mgd rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${tag}_tl -- python3 tools/update_rate.py --configs small --modes fused > /dev/null 2>&1
-  python3 tools/timeline.py gpurun_out/${tag}_tl --dump 26 > gpurun_out/${tag}_timeline_update_merged${mgd}.txt 2>&1
-done
-rm -rf gpurun_out/${tag}_tl; mkdir -p gpurun_out/${tag}_tl
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/${tag}_tl -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-update-rates --headline-only > /dev/null 2>&1
-python3 tools/timeline.py gpurun_out/${tag}_tl --dump 12 > gpurun_out/${tag}_timeline_bench.txt 2>&1
-rm -rf gpurun_out/${tag}_tl
-(python3 tools/merged_stamps.py; python3 tools/merged_stamps.py --update) 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_merged_stamps.txt
-python3 tools/graph_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/${tag}_graph_probe.txt
-TRLDA_SPLIT_LISTS=0 bash tools/sweep_configs.sh > gpurun_out/${tag}_configs_lists_unsplit.txt 2>&1
-for mgd in 2 0; do
-  TRLDA_MERGED=$mgd python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-update-rates --headline-only 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_merged_level${mgd}.json
-done
-TRLDA_MERGED=0 python3 tools/update_rate.py --configs small,c3 --modes fused > gpurun_out/${tag}_update_rates_unmerged.txt 2>&1
-hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probes/anyorder_probe.hip -o tools/probes/anyorder_probe 2>/dev/null && tools/probes/anyorder_probe > gpurun_out/${tag}_anyorder_probe.txt 2>&1
-# document lengths: the cliffs between the variants, the reference's own test_speed workload,
-# the heavy-tailed and the uniform bench workloads (with their parity legs)
-python3 tools/length_sweep.py > gpurun_out/${tag}_length_sweep.txt 2>&1
-python3 tools/speed_workload.py > gpurun_out/${tag}_speed_workload.txt 2>&1
-for a in "--lengths lognormal" "--uniform"; do
-  python3 bench.py --steps 100 --warmup 10 --parity-only --no-update-rates $a 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_$(echo $a | tr -d ' -').json
-done
-hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probes/xcu_probe.hip -o tools/probes/xcu_probe 2>/dev/null && tools/probes/xcu_probe > gpurun_out/${tag}_xcu_probe.txt 2>&1
-for cfg in small c5a c5b c4; do
-  tools/prof_update.sh ${tag}_${cfg}_fused $cfg fused > /dev/null 2>&1
-done
-tools/prof_update.sh ${tag}_c5a_plain c5a plain > /dev/null 2>&1
-python3 tools/allreduce_cost.py 2>/dev/null | grep "K=" > gpurun_out/${tag}_allreduce_world1.txt
-cut -c1-160 gpurun_out/${tag}_kernel_stats.csv | head -8
-cat gpurun_out/${tag}_pmc_fetch.txt gpurun_out/${tag}_pmc_write.txt
-tail -1 gpurun_out/${tag}_bench.json | cut -c1-600

@@ -93,6 +93,40 @@ struct MergedArgs {
                                   // counted] per document workgroup from 3 * 512 on
 };
 
+// The kernel's arguments (~700 bytes: three structures) are fetched where they are first used, a
+// scalar load and a wait at a time -- in the helper's path ten of them one behind the other, each a
+// miss in the scalar cache: ~3 us before a helper's first item (profiles/r05_deferred_notes.txt:
+// documents start 0.2 us into the launch, helpers 3.2).  One word of every 64-byte line of the
+// argument segment, all requested at once, brings the lines into the scalar cache.
+__device__ __forceinline__ void warm_kernel_arguments()
+{
+    // (the deferred kernels' explicit arguments: 696 bytes in the code object's metadata, the tiered
+    // one with its extra int; eleven lines = 704 bytes, none of them past the segment's last line)
+    static_assert(sizeof(DocKernelArgs) + sizeof(PreArgs) + sizeof(MergedArgs) <= 11 * 64 &&
+                      sizeof(DocKernelArgs) + sizeof(PreArgs) + sizeof(MergedArgs) > 10 * 64,
+                  "eleven lines cover the argument segment and none lies beyond it");
+    typedef __attribute__((address_space(4))) const unsigned int *karg_ptr;
+    karg_ptr kp = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned int r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10;
+    // (one block: left to the compiler the twelve loads came in three batches with a wait each)
+    asm volatile("s_load_dword %0, %11, 0x0\n\t"
+                 "s_load_dword %1, %11, 0x40\n\t"
+                 "s_load_dword %2, %11, 0x80\n\t"
+                 "s_load_dword %3, %11, 0xc0\n\t"
+                 "s_load_dword %4, %11, 0x100\n\t"
+                 "s_load_dword %5, %11, 0x140\n\t"
+                 "s_load_dword %6, %11, 0x180\n\t"
+                 "s_load_dword %7, %11, 0x1c0\n\t"
+                 "s_load_dword %8, %11, 0x200\n\t"
+                 "s_load_dword %9, %11, 0x240\n\t"
+                 "s_load_dword %10, %11, 0x280\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(r0), "=&s"(r1), "=&s"(r2), "=&s"(r3), "=&s"(r4), "=&s"(r5), "=&s"(r6), "=&s"(r7),
+                   "=&s"(r8), "=&s"(r9), "=&s"(r10)
+                 : "s"(kp)
+                 : "memory");
+}
+
 // ---- the document side --------------------------------------------------------------------
 // (estep_kernels.h / estep_wide.h: every output the statistics read goes out with merged_store)
 __device__ __forceinline__ void docs_done_signal(const DocKernelArgs &a)
@@ -468,6 +502,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_merged_kernel(DocK
                                                                              MergedArgs mg)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    warm_kernel_arguments();
     if ((int)blockIdx.x < mg.n_comb) {               // block-uniform
         merged_combine(mg, (int)blockIdx.x, lds);
         return;
@@ -493,6 +528,7 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_tiered_merged_kernel(D
                                                                                 int lds_rows, MergedArgs mg)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    warm_kernel_arguments();
     if ((int)blockIdx.x < mg.n_comb) {               // block-uniform
         merged_combine(mg, (int)blockIdx.x, lds);
         return;
@@ -1045,40 +1081,6 @@ __device__ __forceinline__ void merged_stats_slots(const MergedArgs &mg, int vb,
             o.partial[(size_t)vb * K + tid] = sum;
         }
     }
-}
-
-// The kernel's arguments (~700 bytes: three structures) are fetched where they are first used, a
-// scalar load and a wait at a time -- in the helper's path ten of them one behind the other, each a
-// miss in the scalar cache: ~3 us before a helper's first item (profiles/r05_deferred_notes.txt:
-// documents start 0.2 us into the launch, helpers 3.2).  One word of every 64-byte line of the
-// argument segment, all requested at once, brings the lines into the scalar cache.
-__device__ __forceinline__ void warm_kernel_arguments()
-{
-    // (the deferred kernels' explicit arguments: 696 bytes in the code object's metadata, the tiered
-    // one with its extra int; eleven lines = 704 bytes, none of them past the segment's last line)
-    static_assert(sizeof(DocKernelArgs) + sizeof(PreArgs) + sizeof(MergedArgs) <= 11 * 64 &&
-                      sizeof(DocKernelArgs) + sizeof(PreArgs) + sizeof(MergedArgs) > 10 * 64,
-                  "eleven lines cover the argument segment and none lies beyond it");
-    typedef __attribute__((address_space(4))) const unsigned int *karg_ptr;
-    karg_ptr kp = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
-    unsigned int r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10;
-    // (one block: left to the compiler the twelve loads came in three batches with a wait each)
-    asm volatile("s_load_dword %0, %11, 0x0\n\t"
-                 "s_load_dword %1, %11, 0x40\n\t"
-                 "s_load_dword %2, %11, 0x80\n\t"
-                 "s_load_dword %3, %11, 0xc0\n\t"
-                 "s_load_dword %4, %11, 0x100\n\t"
-                 "s_load_dword %5, %11, 0x140\n\t"
-                 "s_load_dword %6, %11, 0x180\n\t"
-                 "s_load_dword %7, %11, 0x1c0\n\t"
-                 "s_load_dword %8, %11, 0x200\n\t"
-                 "s_load_dword %9, %11, 0x240\n\t"
-                 "s_load_dword %10, %11, 0x280\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&s"(r0), "=&s"(r1), "=&s"(r2), "=&s"(r3), "=&s"(r4), "=&s"(r5), "=&s"(r6), "=&s"(r7),
-                   "=&s"(r8), "=&s"(r9), "=&s"(r10)
-                 : "s"(kp)
-                 : "memory");
 }
 
 __device__ __forceinline__ void deferred_helper(const PreArgs &pre, const MergedArgs &mg, double *lds)
