@@ -63,3 +63,11 @@ def test_random_update_calls_agree_with_the_reference_itself(hip):
         pytest.skip("oracle/_ref/libtrlda_ref.so not built (needs /root/reference at build time)")
     import fuzz_reference
     assert fuzz_reference.main(["--cases", "15", "--seed", "8"]) < 1e-7
+
+
+def test_random_deferred_streams_equal_the_plain_ones(hip):
+    """tests/fuzz_deferred.py: random streams of announced E-steps with deferred statistics, shapes
+    inside and outside the stage, and everything that must flush in between -- bitwise the outputs
+    of the same stream with the switch off, at the oracle's values."""
+    import fuzz_deferred
+    assert fuzz_deferred.main(["--cases", "6", "--seed", "4"]) < 1e-8

@@ -1,40 +1,39 @@
 // estep_merged.h -- ONE launch per E-step on small tables: the statistics stage (src/lda.cpp:207-217),
 // the M-step (src/onlinelda.cpp:99-100, src/batchlda.cpp:60) and the row sums the next E-step needs
-// (src/lda.cpp:172) as WORKGROUPS OF THE DOCUMENT LAUNCH.
+// (src/lda.cpp:172) as WORKGROUPS OF A DOCUMENT LAUNCH.  Two forms:
 //
-// A kernel of this path costs ~4.5 us before it does anything (rocprofv3: the durations of a
-// stream's dependent kernels are back to back, and an empty one is not shorter than that:
-// profiles/r04_timeline_*.txt), and a 200-document step has two of them: documents 31 us,
-// statistics 7 us of which ~2.5 are its work.  Here the statistics are `n_short + n_long` extra
-// workgroups at the end of the document launch's grid.  They
-//
-//   * start as soon as a CU has room -- 56 of the 256 CUs have from the start -- and use the wait
-//     for everything that does not depend on the documents: their words' descriptors, the
-//     documents of their words' entries (static per batch), exp(psi(lambda)) and lambda' of
-//     their words, the zero columns of the words outside the batch;
-//   * wait until every document workgroup has counted itself done (`docs_done`, a counter that
-//     only grows: the host passes the value it must reach).  A document workgroup stores its
-//     outputs (exp(psi(gamma)) and the weights cnt / phinorm) with agent-scope stores, waits for
-//     their acknowledgement, counts; a waiting wave then invalidates its caches (agent-scope
-//     acquire) and reads them: the entries' weights and the rows of exp(psi(gamma)) of ALL its
-//     entries are in flight together -- one memory latency, where the stand-alone kernel has
-//     four dependent ones (word -> list bounds -> entries -> rows);
+// MERGED (update calls; round 4, the stage rewritten in round 5): the statistics of THIS launch's
+// documents.  A kernel of this path costs ~4.5 us before it does anything (the durations of a
+// stream's dependent kernels are back to back, profiles/r04_timeline_*.txt), and a trust-region
+// iteration had two of them.  Here the stage is `n_short + n_long` extra workgroups of the document
+// launch.  They
+//   * start as soon as a CU has room and use the wait for everything that does not depend on the
+//     documents: their words' descriptors, the documents of their entries (static per batch),
+//     exp(psi(lambda)) and lambda' of their words, the zero columns of the words outside the batch;
+//   * wait until every document workgroup has counted itself done (`docs_done`, a counter that only
+//     grows).  A document workgroup stores exp(psi(gamma)) and the weights cnt / phinorm with
+//     agent-scope (write-through) stores, waits for their acknowledgement (stores_acknowledged),
+//     counts; the last one writes the launch's number into one FLAG PER WAITER (thousands of waves
+//     polling one address cost 20 us per launch);
+//   * then have the weights and ALL rows of their entries in flight together, one round whatever
+//     the lists' lengths (merged_stats_slots: 16 slots per wave, lists in classes by length);
 //   * leave their row of the new lambda's row sums in `o.partial`; the NEXT launch's `n_comb`
 //     workgroups add the rows up and finish the topic factors c_k = exp(-psi(row sum)) while the
-//     documents stage their slices (`c_ready`, the same kind of counter) -- the stand-alone kernel
-//     combines its rows in groups behind a last-block-done counter, 3 us at its end
-//     (profiles/r04_timeline_nogroup_fused.txt).
-//
+//     documents stage their slices.
 // Order in the grid = order of dispatch: topic factors, documents, (next batch's preamble,)
-// statistics -- nothing waits for a workgroup behind it, so the launch makes progress whatever
-// part of it is resident (see the kernels at the end of this file).  The host takes this path for
-// launches whose documents fit the device at once (kMergedMaxDocWgs and the CU count), because
-// only then do the helpers run UNDER the documents; that is a matter of speed, not of safety.
+// statistics -- nothing waits for a workgroup behind it, so the launch makes progress whatever part
+// of it is resident.  The host takes the path for launches whose documents leave CUs free, because
+// only then do the helpers run UNDER the documents: a matter of speed, not of safety.
 //
-// Arithmetic: a word's entries are added in document order by ONE wave, four at a time in flight,
-// exactly as word_segment_sum2 does (estep_kernels.h, 4d); a word of more than 16 entries is cut
-// into the same sixteen chunks as the 1024-thread kernel cuts it and combined in the same order:
-// bitwise the statistics of the stand-alone kernel (tests/test_gpu_merged.py).
+// DEFERRED (a stream of E-steps on an unchanged lambda; round 5): the statistics of the PREVIOUS
+// call's documents and the preamble of the NEXT call's batch, as items that helper workgroups take
+// from a counter (deferred_helper) -- nobody waits for anybody, a step is one launch of the
+// documents' length.
+//
+// Arithmetic, both forms: a word's entries are added in document order by ONE wave; a word of more
+// than 16 entries is cut into the same sixteen chunks as the 1024-thread kernel cuts it and
+// combined in the same order: bitwise the statistics of the stand-alone kernel
+// (tests/test_gpu_merged.py, tests/test_gpu_deferred.py).
 #pragma once
 #include "estep_kernels.h"
 #include "estep_wide.h"
