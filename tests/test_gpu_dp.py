@@ -245,7 +245,7 @@ def test_config3_literally_eight_ranks(hip, tmp_path):
     all-gather hook as transport), the default exchange plan -- factors all-gathered, statistics +
     M-step sharded by vocabulary range, lambda columns exchanged in place -- with the trust-region
     loop (max_iter_tr = 3) and without (0): eight bitwise-equal replicas; the call without a loop
-    bitwise the one-GPU lambda of the whole 1600-document mini-batch, the trajectory to 1e-11;
+    at the one-GPU lambda of the whole 1600-document mini-batch to 1e-12, the trajectory to 1e-11;
     one factor exchange per E-step, one lambda exchange per M-step.  (the
     world-8 shape had never run, even as processes.)"""
     K, V, D, world = 100, 7000, 1000000, 8
@@ -265,7 +265,11 @@ def test_config3_literally_eight_ranks(hip, tmp_path):
         assert np.array_equal(r["lambda"], first[0]["lambda"])
         assert int(r["exchanges"][0]) == 1 and int(r["lambda_exchanges"][0]) == 1
     assert float(first[0]["rho0"][0]) == rho0
-    assert np.array_equal(first[0]["lambda"], one.lambdas())
+    # (bitwise when the shards select the document-kernel variant the whole batch selects -- at 1600
+    # documents the whole batch holds documents of more than 128 words, most shards of 200 do not:
+    # the same arithmetic compiled inside another kernel; test_word_sharded_m_step_processes has the
+    # bitwise case)
+    assert relerr(first[0]["lambda"], one.lambdas()) < 1e-12
     # both calls: 1 + 3 E-steps
     res = run_ranks(tmp_path, cfg, world)
     rho1 = one.update(csrs[1], D, .3, 16, 3, 20)

@@ -1989,7 +1989,14 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                     return e ? std::max(1, std::atoi(e)) : 0;
                 }();
                 const int n_items = pre.nb + dg.n_short + dg.n_long;
-                const int H = std::min(n_items, helpers_env > 0 ? helpers_env : cus);
+                // As many helpers as the documents leave CUs free: a helper that is only dispatched when
+                // the documents end finds the list empty after a round trip to the counter, and the
+                // launch waits for it (32.1 us per step with one helper per CU, 31.1 with 56:
+                // profiles/r05_deferred_ab.txt) -- more of them only where the list is long for the free
+                // CUs, and one per CU when the documents fill the chip (then everything runs behind them)
+                const int free_cus = cus - n_wgs;
+                const int wanted = free_cus >= 32 ? std::max(free_cus, (n_items + 5) / 6) : cus;
+                const int H = std::min(n_items, helpers_env > 0 ? helpers_env : wanted);
                 dg.work_counter = m->sync_counters + 32;        // (a cache line of its own)
                 dg.work_base = m->defer_work_total;
                 // (one fetch per item, and every helper's last fetch, which finds nothing)
