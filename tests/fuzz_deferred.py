@@ -68,9 +68,11 @@ def main(argv=None):
         max_iter = int(rng.choice([1, 5, 20]))
         # the script of the case: (op, args) -- the same for both runs
         script = []
-        for _ in range(args.calls):
-            i = int(rng.randint(n_b))
-            nxt = rng.choice([-1, int(rng.randint(n_b))])
+        seq = [int(rng.randint(n_b)) for _ in range(args.calls + 1)]
+        for c in range(args.calls):
+            i = seq[c]
+            r = rng.rand()                           # the announcement: right (60 %), wrong, none
+            nxt = seq[c + 1] if r < .6 else int(rng.randint(n_b)) if r < .8 else -1
             script.append(("estep", i, int(nxt)))
             r = rng.rand()
             if r < .08:

@@ -245,13 +245,15 @@ def test_config3_literally_eight_ranks(hip, tmp_path):
     all-gather hook as transport), the default exchange plan -- factors all-gathered, statistics +
     M-step sharded by vocabulary range, lambda columns exchanged in place -- with the trust-region
     loop (max_iter_tr = 3) and without (0): eight bitwise-equal replicas; the call without a loop
-    at the one-GPU lambda of the whole 1600-document mini-batch to 1e-12, the trajectory to 1e-11;
+    bitwise the one-GPU lambda of the whole 1600-document mini-batch, the trajectory to 1e-11;
     one factor exchange per E-step, one lambda exchange per M-step.  (the
     world-8 shape had never run, even as processes.)"""
     K, V, D, world = 100, 7000, 1000000, 8
-    specs = [dict(kind="update", B=1600, corpus_seed=941, seed=15, max_iter_tr=0, max_iter_inference=20),
-             dict(kind="update", B=1600, corpus_seed=942, seed=16, max_iter_tr=3, max_iter_inference=20)]
-    csrs = [corpus(1600, V, seed=s["corpus_seed"], mean_unique=100) for s in specs]
+    specs = [dict(kind="update", B=1600, corpus_seed=941, seed=15, max_iter_tr=0, max_iter_inference=20,
+                  mean_unique=100),
+             dict(kind="update", B=1600, corpus_seed=942, seed=16, max_iter_tr=3, max_iter_inference=20,
+                  mean_unique=100)]
+    csrs = [corpus(1600, V, seed=s["corpus_seed"], mean_unique=s["mean_unique"]) for s in specs]
     for c in csrs:                                   # 200 documents per rank, to a few by nnz balance
         assert np.all(np.abs(np.diff(c.shard_cuts(world)) - 200) <= 12)
     cfg = dict(K=K, V=V, D=D, alpha=.1, eta=.3, lambda_seed=61,
@@ -265,11 +267,8 @@ def test_config3_literally_eight_ranks(hip, tmp_path):
         assert np.array_equal(r["lambda"], first[0]["lambda"])
         assert int(r["exchanges"][0]) == 1 and int(r["lambda_exchanges"][0]) == 1
     assert float(first[0]["rho0"][0]) == rho0
-    # (bitwise when the shards select the document-kernel variant the whole batch selects -- at 1600
-    # documents the whole batch holds documents of more than 128 words, most shards of 200 do not:
-    # the same arithmetic compiled inside another kernel; test_word_sharded_m_step_processes has the
-    # bitwise case)
-    assert relerr(first[0]["lambda"], one.lambdas()) < 1e-12
+    # bitwise: every column computed once, by its owner, in document order
+    assert np.array_equal(first[0]["lambda"], one.lambdas())
     # both calls: 1 + 3 E-steps
     res = run_ranks(tmp_path, cfg, world)
     rho1 = one.update(csrs[1], D, .3, 16, 3, 20)
@@ -277,9 +276,13 @@ def test_config3_literally_eight_ranks(hip, tmp_path):
         assert int(r["word_sharded"][0]) == 1
         assert np.array_equal(r["lambda"], res[0]["lambda"])          # replicas: bitwise
         assert int(r["exchanges"][0]) == 4 and int(r["lambda_exchanges"][0]) == 4
-        # per M-step a rank receives the table minus its own range: 7/8 of it on average
-        got = int(r["lambda_exchanges"][1])
-        assert 4 * K * V * 8 * 0.6 < got < 4 * K * V * 8
+        # per M-step a rank receives the table minus its own range (ranges are balanced by entries,
+        # not by words: the owner of the rare words holds many columns)
+        assert 0 < int(r["lambda_exchanges"][1]) < 4 * K * V * 8
+    # ... over all ranks: 7/8 of the table per rank and M-step
+    assert sum(int(r["lambda_exchanges"][1]) for r in res) == 4 * (world - 1) * K * V * 8
+    for r in res:
+        pass
     assert [float(res[0]["rho%d" % i][0]) for i in range(2)] == [rho0, rho1]
     assert relerr(res[0]["lambda"], one.lambdas()) < 1e-11
     one.close()
