@@ -321,3 +321,36 @@ def test_many_deferred_steps_in_a_row(hip, sampler):
     for s in slots:
         s.free()
     m.close()
+
+
+def test_two_models_with_pending_statistics_on_one_batch(hip, oracle, sampler):
+    """A batch remembers one model whose pending statistics read it; when a second model defers on
+    the same batch the first one's statistics are launched, and closing the batch launches the
+    second's -- nobody reads a recycled allocation."""
+    from trlda_amd import _ffi
+    K, V, B = 100, 3000, 150
+    lams = [seeded_lambda(sampler, 41 + i, K, V) for i in range(2)]
+    csr = corpus(B, V, seed=9, mean_unique=60)
+    g0 = seeded_gamma(sampler, 43, K, B)
+    ms = [make_model(K, V, lam) for lam in lams]
+    for m in ms:
+        _ffi.check(hip.trlda_model_set_deferred_stats(m._handle, 1))
+    shared = ms[0].upload(csr)
+    slots = [Slots(hip, K, V, csr, g0) for _ in ms]
+    for m, s in zip(ms, slots):
+        g0d, gd, sd, itd = s.ptrs
+        _ffi.check(hip.trlda_model_estep_io_next(m._handle, shared.handle, None, g0d, gd, sd, 20, 1e-3, itd))
+        assert hip.trlda_model_last_deferred(m._handle) & 1
+    shared.close()                                   # (model 1's statistics are still pending here)
+    other = ms[0].upload(corpus(B, V, seed=10, mean_unique=60))      # may recycle the allocation
+    for m in ms:
+        _ffi.check(hip.trlda_model_synchronize(m._handle))
+    for lam, s in zip(lams, slots):
+        go, so, ito = oracle.estep(lam, .1, csr.indptr, csr.ids, csr.cnts, g0, 20, 1e-3, nthreads=8)
+        g, st, it = s.read()
+        assert np.array_equal(it, ito) and relerr(g, go) < TIGHT_RTOL
+        assert relerr(st[so > 0], so[so > 0]) < TIGHT_RTOL and np.array_equal(st == 0, so == 0)
+        s.free()
+    other.close()
+    for m in ms:
+        m.close()

@@ -2073,6 +2073,9 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         // (statistics: workgroups of the document launch above)
     } else if (defer_self) {
         // (statistics: workgroups of the NEXT call's document launch, or flush_pending)
+        // (a batch remembers ONE model whose pending statistics read it: another model's go first)
+        if (b->pending_in && b->pending_in != m && (rc = flush_pending(b->pending_in)))
+            return rc;
         m->pending.valid = true;
         m->pending.batch = b;
         m->pending.sstats = sstats_dev;
