@@ -1341,11 +1341,15 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
         if constexpr (MID) {                         // words 128 + (lane & 15)
             // the lane group's four weights (not a broadcast: they differ between groups); the
             // dependent chain of the two folds is started first and runs under the products
+#ifndef TRLDA_EXPT_M1_NOS2                           // (timing experiments: results are wrong)
             const double2 *eq = reinterpret_cast<const double2 *>(e + k0 + kq);
             const double2 ea = eq[0], eb = eq[1];
             s2 = fma(ea.x, bE2[0], ea.y * bE2[1]) + fma(eb.x, bE2[2], eb.y * bE2[3]);
+#ifndef TRLDA_EXPT_M1_NOFOLD
             s2 = fold<32>(s2, s2);                   // + the other lane groups
             s2 = fold<16>(s2, s2);
+#endif
+#endif
         }
         double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
