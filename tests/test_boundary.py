@@ -108,7 +108,7 @@ def test_occupancy_critical_kernels_keep_their_registers(hip_lib):
     assert len(deferred) == 3, sorted(deferred)
     for name, f in deferred.items():
         assert f["private_segment_fixed_size"] <= 48 and f["vgpr_count"] <= 256, (name, f)
-        assert f["vgpr_spill_count"] <= (0 if "estep_docs_reg_deferred" in name else 2), (name, f)
+        assert f["vgpr_spill_count"] <= (0 if "estep_docs_reg_deferred" in name else 4), (name, f)
     emit = [v for k, v in res.items() if "sstats_update2_kernelILi1024ELi1ELi1ELb1" in k]
     assert len(emit) == 1 and emit[0]["vgpr_count"] <= 64, emit
     docs = [v for k, v in res.items() if "estep_docs_reg_kernelILi0" in k]

@@ -1095,6 +1095,31 @@ __device__ __forceinline__ double fold(double a, double b)
     }
 }
 
+// acc += vals(lane N of this lane's ROW of 16) * b -- v_fmac_f64 with the DPP control row_newbcast:N
+// (gfx90a+: the one DPP form 64-bit operands have, made for exactly this).  A wave's sixteen
+// weights sit in one register (lane l holds weight l & 15, the same in all four rows) and are handed
+// out inside the vector ALU; as eight broadcast ds_read_b128 per wave and product they were 64 kB of
+// LDS traffic per stage and workgroup -- the LDS pipe, 512 of a stage's ~800 cycles, was what bounded
+// the two products.  `vals` comes straight from an LDS load and is never written by
+// the vector ALU, so the VALU-write -> DPP-read hazard does not arise; the s_nop in front of the
+// FIRST use of a register covers a copy the register allocator might put there.
+template <int N, bool FIRST = false>
+__device__ __forceinline__ void fmac_row_bcast(double &acc, double vals, double b)
+{
+    static_assert(N >= 0 && N < 16, "a lane of the row");
+    if constexpr (FIRST)
+        asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+            : "+v"(acc)
+            : "v"(vals), "v"(b), "n"(N));
+    else
+        asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(vals), "v"(b), "n"(N));
+}
+#ifndef TRLDA_NO_DPP_BCAST
+constexpr bool kDppBcast = true;
+#else
+constexpr bool kDppBcast = false;                    // (A/B: the broadcast reads of rounds 1-4)
+#endif
+
 // eight partial sums at a compile-time stride, all reads in flight, pairwise combine
 template <int STRIDE>
 __device__ __forceinline__ double sum8_strided(const double *p)
@@ -1333,12 +1358,28 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
         // eight reads are issued before the first fma and nothing is branched over: weights
         // past K are zero in LDS and the matching registers are zero.  Eight chains.
         const double2 *ep = reinterpret_cast<const double2 *>(e + k0);
-        double2 ew[8];
+        [[maybe_unused]] double2 ew[8];
+        [[maybe_unused]] double evals = 0.0, evals2 = 0.0;
+        if constexpr (kDppBcast) {
+            evals = e[k0 + (lane & 15)];             // (16-lane rows: every row holds the wave's 16 weights)
+            if constexpr (MID)
+                evals2 = e[k0 + kq + (lane & 3)];    // row q: its own four
+        } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            ew[i] = ep[i];
+            for (int i = 0; i < 8; ++i)
+                ew[i] = ep[i];
+        }
         [[maybe_unused]] double s2 = 0.0;
-        if constexpr (MID) {                         // words 128 + (lane & 15)
+        if constexpr (MID && kDppBcast) {            // words 128 + (lane & 15): the row's four topics
+            double s2b = 0.0;
+            fmac_row_bcast<0, true>(s2, evals2, bE2[0]);
+            fmac_row_bcast<1>(s2b, evals2, bE2[1]);
+            fmac_row_bcast<2>(s2, evals2, bE2[2]);
+            fmac_row_bcast<3>(s2b, evals2, bE2[3]);
+            s2 += s2b;
+            s2 = fold<32>(s2, s2);                   // + the other lane groups
+            s2 = fold<16>(s2, s2);
+        } else if constexpr (MID) {                  // words 128 + (lane & 15)
             // the lane group's four weights (not a broadcast: they differ between groups); the
             // dependent chain of the two folds is started first and runs under the products
 #ifndef TRLDA_EXPT_M1_NOS2                           // (timing experiments: results are wrong)
@@ -1352,12 +1393,23 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
 #endif
         }
         double s0[4] = {0.0, 0.0, 0.0, 0.0}, s1[4] = {0.0, 0.0, 0.0, 0.0};
+        if constexpr (kDppBcast) {
+#define TRLDA_E_STEP(t, F)                                       \
+    fmac_row_bcast<t, F>(s0[(t) & 3], evals, bE0[t]);            \
+    fmac_row_bcast<t>(s1[(t) & 3], evals, bE1[t]);
+            TRLDA_E_STEP(0, true) TRLDA_E_STEP(1, false) TRLDA_E_STEP(2, false) TRLDA_E_STEP(3, false)
+            TRLDA_E_STEP(4, false) TRLDA_E_STEP(5, false) TRLDA_E_STEP(6, false) TRLDA_E_STEP(7, false)
+            TRLDA_E_STEP(8, false) TRLDA_E_STEP(9, false) TRLDA_E_STEP(10, false) TRLDA_E_STEP(11, false)
+            TRLDA_E_STEP(12, false) TRLDA_E_STEP(13, false) TRLDA_E_STEP(14, false) TRLDA_E_STEP(15, false)
+#undef TRLDA_E_STEP
+        } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            s0[(2 * i) & 3] = fma(ew[i].x, bE0[2 * i], s0[(2 * i) & 3]);
-            s1[(2 * i) & 3] = fma(ew[i].x, bE1[2 * i], s1[(2 * i) & 3]);
-            s0[(2 * i + 1) & 3] = fma(ew[i].y, bE0[2 * i + 1], s0[(2 * i + 1) & 3]);
-            s1[(2 * i + 1) & 3] = fma(ew[i].y, bE1[2 * i + 1], s1[(2 * i + 1) & 3]);
+            for (int i = 0; i < 8; ++i) {
+                s0[(2 * i) & 3] = fma(ew[i].x, bE0[2 * i], s0[(2 * i) & 3]);
+                s1[(2 * i) & 3] = fma(ew[i].x, bE1[2 * i], s1[(2 * i) & 3]);
+                s0[(2 * i + 1) & 3] = fma(ew[i].y, bE0[2 * i + 1], s0[(2 * i + 1) & 3]);
+                s1[(2 * i + 1) & 3] = fma(ew[i].y, bE1[2 * i + 1], s1[(2 * i + 1) & 3]);
+            }
         }
         part[wid * kRegPart + lane] = (s0[0] + s0[1]) + (s0[2] + s0[3]);
         part[wid * kRegPart + 64 + lane] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
@@ -1384,18 +1436,41 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
     while (it < a.max_iter) {                        // lda.cpp:185-204
         // acc_k = sum_j tw_j beta[j][k]                               lda.cpp:189-193
         {
-            const double2 *tp = reinterpret_cast<const double2 *>(tw + j0);
-            double2 tv[JC / 2];
-#pragma unroll
-            for (int i = 0; i < JC / 2; ++i)
-                tv[i] = tp[i];
             double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
+            // (the 144-word variant keeps its broadcast reads here: with the DPP form the tiered kernels,
+            // at the register limit, spilled and this stage went from 840 to 939 cycles)
+            if constexpr (kDppBcast && !MID) {
+                const double tvals = tw[j0 + (lane & 15)];
+                [[maybe_unused]] double tvals2 = 0.0;
+                if constexpr (MID)
+                    tvals2 = tw[j0 + 16 + (lane & 1)];           // words 16, 17 of the wave
+#define TRLDA_B_STEP(w, F)                                       \
+    fmac_row_bcast<w, F>(a0[(w) & 3], tvals, bB0[w]);            \
+    fmac_row_bcast<w>(a1[(w) & 3], tvals, bB1[w]);
+                TRLDA_B_STEP(0, true) TRLDA_B_STEP(1, false) TRLDA_B_STEP(2, false) TRLDA_B_STEP(3, false)
+                TRLDA_B_STEP(4, false) TRLDA_B_STEP(5, false) TRLDA_B_STEP(6, false) TRLDA_B_STEP(7, false)
+                TRLDA_B_STEP(8, false) TRLDA_B_STEP(9, false) TRLDA_B_STEP(10, false) TRLDA_B_STEP(11, false)
+                TRLDA_B_STEP(12, false) TRLDA_B_STEP(13, false) TRLDA_B_STEP(14, false) TRLDA_B_STEP(15, false)
+#undef TRLDA_B_STEP
+                if constexpr (MID) {
+                    fmac_row_bcast<0, true>(a0[0], tvals2, bB0[16]);
+                    fmac_row_bcast<0>(a1[0], tvals2, bB1[16]);
+                    fmac_row_bcast<1>(a0[1], tvals2, bB0[17]);
+                    fmac_row_bcast<1>(a1[1], tvals2, bB1[17]);
+                }
+            } else {
+                const double2 *tp = reinterpret_cast<const double2 *>(tw + j0);
+                double2 tv[JC / 2];
 #pragma unroll
-            for (int i = 0; i < JC / 2; ++i) {
-                a0[(2 * i) & 3] = fma(tv[i].x, bB0[2 * i], a0[(2 * i) & 3]);
-                a1[(2 * i) & 3] = fma(tv[i].x, bB1[2 * i], a1[(2 * i) & 3]);
-                a0[(2 * i + 1) & 3] = fma(tv[i].y, bB0[2 * i + 1], a0[(2 * i + 1) & 3]);
-                a1[(2 * i + 1) & 3] = fma(tv[i].y, bB1[2 * i + 1], a1[(2 * i + 1) & 3]);
+                for (int i = 0; i < JC / 2; ++i)
+                    tv[i] = tp[i];
+#pragma unroll
+                for (int i = 0; i < JC / 2; ++i) {
+                    a0[(2 * i) & 3] = fma(tv[i].x, bB0[2 * i], a0[(2 * i) & 3]);
+                    a1[(2 * i) & 3] = fma(tv[i].x, bB1[2 * i], a1[(2 * i) & 3]);
+                    a0[(2 * i + 1) & 3] = fma(tv[i].y, bB0[2 * i + 1], a0[(2 * i + 1) & 3]);
+                    a1[(2 * i + 1) & 3] = fma(tv[i].y, bB1[2 * i + 1], a1[(2 * i + 1) & 3]);
+                }
             }
             part[wid * kRegPart + lane] = (a0[0] + a0[1]) + (a0[2] + a0[3]);
             part[wid * kRegPart + 64 + lane] = (a1[0] + a1[1]) + (a1[2] + a1[3]);

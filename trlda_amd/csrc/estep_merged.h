@@ -86,6 +86,8 @@ struct MergedArgs {
     int slots;                    // merged launch: the statistics stage in its 16-slot form (merged_stats_slots)
     unsigned int *work_counter;   // deferred launch: the helpers' item counter (only grows) ...
     unsigned int work_base;       // ... and its value at the start of the launch
+    int first_static;             // H (every helper starts with item h: all of them are resident from the
+                                  // start) or 0 (every first item comes from the counter)
     unsigned long long *tstamps;  // diagnostics (TRLDA_MERGED_STAMPS=1, tools/merged_stamps.py) or nullptr:
                                   // s_memrealtime (100 MHz, one clock for the chip) of [start, flag seen,
                                   // end] per statistics workgroup, then [start, end of the document,
@@ -1086,21 +1088,25 @@ __device__ __forceinline__ void deferred_helper(const PreArgs &pre, const Merged
 {
     __shared__ unsigned int next_item[2];
     const int n_items = pre.nb + mg.n_short + mg.n_long;
-    // (EVERY item comes from the counter, the first one too: with item h for helper h the items past
-    // the resident helpers' waited for the helpers that are dispatched when the documents end -- 38.3
-    // against 32.9 us per step; a fixed first item for just the resident ones gained 0.3 us of the
-    // ~3 us a helper needs to get going and is not worth its bookkeeping)
-    if (threadIdx.x == 0)
-        next_item[1] = __hip_atomic_fetch_add(mg.work_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
-                       mg.work_base;
-    __syncthreads();
-    int v = (int)next_item[1];
+    // The first item: the helper's own index when ALL helpers are resident from the start (the
+    // host launches exactly as many as the documents leave CUs free: first_static = H) -- a round
+    // trip to the counter is ~1.8 us in front of a helper's first item; from the counter otherwise
+    // (with item h for helpers that are only dispatched when the documents end, the items past the
+    // resident ones waited for them: 38.3 against 32.9 us per step).
+    int v = (int)blockIdx.x - pre.n_docs;
+    if (mg.first_static == 0) {                      // launch-uniform
+        if (threadIdx.x == 0)
+            next_item[1] = __hip_atomic_fetch_add(mg.work_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
+                           mg.work_base;
+        __syncthreads();
+        v = (int)next_item[1];
+    }
     for (int round = 0; v < n_items; ++round) {      // block-uniform
         unsigned int fetched = 0u;
         if (threadIdx.x == 0)                        // (needed at the end of the round)
             fetched = __hip_atomic_fetch_add(mg.work_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // (published from inside the item, between its loads and its stores: PublishNext)
-        const PublishNext pub{&next_item[round & 1], fetched, mg.work_base};
+        const PublishNext pub{&next_item[round & 1], fetched, mg.work_base - (unsigned int)mg.first_static};
         // A zero the compiler cannot see through, added to every item's thread index: without it
         // everything in the items that does not depend on the item -- a few hundred instructions of
         // per-lane addresses, class tables, argument loads, and 25 registers spilled to make room for

@@ -1999,8 +1999,12 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                 const int H = std::min(n_items, helpers_env > 0 ? helpers_env : wanted);
                 dg.work_counter = m->sync_counters + 32;        // (a cache line of its own)
                 dg.work_base = m->defer_work_total;
-                // (one fetch per item, and every helper's last fetch, which finds nothing)
-                m->defer_work_total += (unsigned int)(n_items + H);
+                // every helper resident from the start: its first item is its own index, the counter
+                // hands out the items from H on (one fetch per item in all: each helper's last one finds
+                // nothing); else every item comes from the counter (n_items + H fetches)
+                static const bool no_static = std::getenv("TRLDA_DEFER_STATIC0") != nullptr;   // (A/B)
+                dg.first_static = (!no_static && free_cus >= 32 && H <= free_cus) ? H : 0;
+                m->defer_work_total += (unsigned int)(dg.first_static ? n_items : n_items + H);
                 const dim3 grid((unsigned)(n_wgs + H));
                 if (!tiered)
                     hipLaunchKernelGGL(estep_docs_reg_deferred_kernel<0>, grid, dim3(kRegThreads), lds_bytes,
