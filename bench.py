@@ -117,6 +117,11 @@ def parse():
     ap.add_argument("--no-deferred", action="store_true",
                     help="every step launches its own statistics kernel (round 4's step) instead of "
                          "leaving them to the next step's document launch")
+    ap.add_argument("--lanes", type=int, default=2, choices=(1, 2),
+                    help="N = 1, deferred statistics: E-steps of the stream in flight at once "
+                         "(trlda_model_set_stream_lanes: the steps go in turn to two streams of the "
+                         "library's own, output arrays alternate between two sets; every fence() joins "
+                         "them before the clock stops).  1 = one launch at a time, as in rounds 1-4")
     ap.add_argument("--no-settle", action="store_true",
                     help="skip the untimed settle phase in front of the first timed region (clock ramp "
                          "after the set-up; reported as settle_steps / settle_ms)")
@@ -449,6 +454,9 @@ def main():
     gamma = torch.empty(B * K, dtype=torch.float64, device=device)
     sstats = torch.empty(KV, dtype=torch.float64, device=device)
     iters_dev = torch.zeros(B, dtype=torch.int32, device=device)
+    # (two E-steps in flight write two sets of arrays: --lanes)
+    out_sets = [(gamma, sstats, iters_dev),
+                (torch.empty_like(gamma), torch.empty_like(sstats), torch.zeros_like(iters_dev))]
     # N > 1: the M-step (onlinelda.cpp:99-100) closes the dependency chain E-step -> all-reduce
     # -> lambda -> next E-step, so the collective cannot hide behind the next step's kernels.
     # lambda' stays the initial lambda and rho is small: lambda moves, the workload does not drift.
@@ -467,6 +475,14 @@ def main():
     # K steps holds K statistics stages: K - 1 inside document launches + the last one as a kernel.
     deferred = prefetch and not args.no_deferred
     _ffi.check(L.trlda_model_set_deferred_stats(model, int(deferred)))
+    # Stream lanes (include/trlda_hip.h, trlda_model_set_stream_lanes): the steps of that stream
+    # share nothing but lambda, so two of them may be in flight -- step i + 1's workgroups take the
+    # CUs as step i's leave them (its documents end 1-2 us apart, a 129..144-word one 5 us after
+    # the others).  Every step still is one E-step on one mini-batch, its results bitwise those
+    # of the one-lane stream; fence() joins the lanes before the clock stops.
+    lanes = [args.lanes if deferred else 1]
+    _ffi.check(L.trlda_model_set_stream_lanes(model, lanes[0]))
+    upcoming = (C.c_void_p * 2)()
     exchange_probe = None
     if exchange == "factors" and not vworld and (world > 1 or force_dist):
         # One check of the factor path against the trusted composition (E-step on the shard,
@@ -569,8 +585,11 @@ def main():
     cuts_solo = np.array([0, B], dtype=np.int32)
     use_prefetch = [prefetch]
 
-    def step(i, want_iters=False, plain=False, solo=False, threshold=None):
+    def step(i, want_iters=False, plain=False, solo=False, threshold=None, out_set=None):
         thr = args.threshold if threshold is None else threshold
+        # (whose results are read afterwards: set 0; a stream through two lanes: alternating)
+        g_out, s_out, it_out = out_sets[out_set if out_set is not None else
+                                        (i & 1 if lanes[0] > 1 and not want_iters else 0)]
         # plain: the bare E-step (parity leg).  solo: the N > 1 step without its exchange -- this
         # rank's documents, the same kernels, the M-step -- run by one rank on its own
         j = i % args.num_batches
@@ -596,20 +615,28 @@ def main():
                 None, args.max_iter, thr, iters_dev.data_ptr() if want_iters else None, 1,
                 lam_prime.data_ptr(), RHO, ETA, D_TOTAL / float(B * xworld) if D_TOTAL else 1.))
             return
-        nxt = batches[(i + 1) % args.num_batches].handle if use_prefetch[0] else None
-        _ffi.check(L.trlda_model_estep_io_next(model, batches[j].handle, nxt, gamma0s[j].data_ptr(),
-                                               gamma.data_ptr(), sstats.data_ptr(), args.max_iter,
-                                               thr,
-                                               iters_dev.data_ptr() if want_iters else None))
+        if use_prefetch[0]:
+            # the batches of the next two steps, in order: with two lanes a step's launch prepares the
+            # preamble of the step AFTER the next (one lane: of the next, as trlda_model_estep_io_next)
+            upcoming[0] = batches[(i + 1) % args.num_batches].handle.value
+            upcoming[1] = batches[(i + 2) % args.num_batches].handle.value
+            _ffi.check(L.trlda_model_estep_io_ahead(model, batches[j].handle, upcoming, 2,
+                                                    gamma0s[j].data_ptr(), g_out.data_ptr(), s_out.data_ptr(),
+                                                    args.max_iter, thr,
+                                                    it_out.data_ptr() if want_iters else None))
+        else:
+            _ffi.check(L.trlda_model_estep_io_next(model, batches[j].handle, None, gamma0s[j].data_ptr(),
+                                                   g_out.data_ptr(), s_out.data_ptr(), args.max_iter, thr,
+                                                   it_out.data_ptr() if want_iters else None))
         if collective and not plain:
             if solo:
                 pass                                  # the sum over one rank
             elif rccl_comm is not None:               # RCCL over xGMI: K x V fp64 sum
                 _ffi.check(L.trlda_model_allreduce_sstats(model, rccl_comm,
-                                                          C.c_void_p(sstats.data_ptr())))
+                                                          C.c_void_p(s_out.data_ptr())))
             else:
-                dist.all_reduce(sstats)
-            _ffi.check(L.trlda_model_blend(model, lam_prime.data_ptr(), sstats.data_ptr(), RHO, ETA,
+                dist.all_reduce(s_out)
+            _ffi.check(L.trlda_model_blend(model, lam_prime.data_ptr(), s_out.data_ptr(), RHO, ETA,
                                            D_TOTAL / float(B * (1 if solo else world)) if D_TOTAL else 1.))
 
     def fence():
@@ -702,6 +729,26 @@ def main():
             step(pos[0] + i)
         pos[0] += 2
 
+    # the same steps one launch at a time (rounds 1-4's stream: what rocprofv3's per-launch durations
+    # of `--lanes 1` describe)
+    value_one_lane = None
+    if lanes[0] > 1 and not args.headline_only:
+        fence()
+        lanes[0] = 1
+        _ffi.check(L.trlda_model_set_stream_lanes(model, 1))
+        for i in range(min(args.warmup, 5)):
+            step(pos[0] + i)
+        pos[0] += min(args.warmup, 5)
+        s_1l = sorted(timed() for _ in range(max(1, args.repeats)))
+        value_one_lane = {"value": round(B * args.steps / s_1l[len(s_1l) // 2], 1), "unit": "docs/s",
+                          "ms_per_step": round(1e3 * s_1l[len(s_1l) // 2] / args.steps, 5)}
+        fence()
+        lanes[0] = args.lanes
+        _ffi.check(L.trlda_model_set_stream_lanes(model, lanes[0]))
+        for i in range(4):
+            step(pos[0] + i)
+        pos[0] += 4
+
     # the same steps with threshold = 0: FIXED work, every document runs all max_iter iterations
     # whatever lambda is ("threshold 1e-3 and threshold 0")
     value_fixed_work = None
@@ -766,9 +813,17 @@ def main():
     launches = [u for u in kernel_us if u > 0.5 * event_pair_us]
     step_us = 1e6 * elapsed / args.steps
     event_us = 0.0
-    if not collective and launches:
+    laned = bool(carried and lanes[0] > 1 and L.trlda_model_lane_steps(model) > 0)
+    if not collective and launches and not laned:
         event_us = min(max((sum(launches) - step_us) / len(launches), 0.0), event_pair_us)
     kernel_us = [max(u - event_us, 0.0) if u > 0.5 * event_pair_us else 0.0 for u in kernel_us]
+    if laned:
+        # two lanes: a lane's launches run back to back on its stream -- one pair of events per lane
+        # around the replay's whole stretch, divided by the lane's launches (no event between two
+        # launches: that would change how they overlap)
+        us, cnt = C.c_double(), C.c_int64()
+        _ffi.check(L.trlda_model_get_lane_timing(model, C.byref(us), C.byref(cnt)))
+        kernel_us = [0.0, 0.0, us.value / max(cnt.value, 1), 0.0]
     _ffi.check(L.trlda_model_set_timing(model, 0))
 
     # executed iterations per document, every batch: mean, and the fp64 work of the document
@@ -814,6 +869,13 @@ def main():
                                      (8. * K + 12.) * float(c.indptr[-1]) for c in csrs]))
         docs_bytes = min(docs_bytes + stats_bytes, estep_bytes)
         stats_bytes = docs_bytes - docs_only_bytes - pre_bytes
+    # Two lanes: two launches are in flight at any time, each waiting for the CUs the other one's
+    # workgroups still hold -- a launch's duration (events around it on its lane's stream; what
+    # rocprofv3 lists) is then about twice the time the device spends per launch.  The roofline is
+    # priced on that time: the timed region divided by its launches (one per step).
+    launch_us = docs_us
+    if laned:
+        docs_us = step_us
     achieved = docs_bytes / (docs_us * 1e-6) / 1e9 if docs_us > 0 else 0.0
     traffic, traffic_src = None, None
     # the document stage under the name rocprofv3 lists it by (profiles/*_kernel_stats.csv)
@@ -865,8 +927,16 @@ def main():
         "algorithmic_bytes_per_launch": docs_bytes,
         "algorithmic_bytes_split": {"documents": docs_only_bytes, "next_batch_preamble": pre_bytes,
                                     "previous_batch_statistics": stats_bytes},
-        "avg_launch_us": round(docs_us, 2),
-        "method": "HIP events on the launch stream around every launch in a replay of the timed "
+        "avg_launch_us": round(launch_us, 2),
+        "launches_in_flight": round(launch_us / docs_us, 2) if laned and docs_us > 0 else 1,
+        "device_time_per_launch_us": round(docs_us, 2),
+        "method": ("two stream lanes: `achieved` = algorithmic bytes per launch / (timed region / its "
+                   "launches); avg_launch_us = HIP events on the lanes' streams in a "
+                   "replay of the timed steps, one pair of events per lane around its whole stretch of "
+                   "back-to-back launches -- launches of the two lanes overlap, so it is launches_in_flight "
+                   "times the device time per launch (rocprofv3's per-launch duration is this figure; "
+                   "`--lanes 1`: one launch at a time, value_one_lane)") if laned else
+                  "HIP events on the launch stream around every launch in a replay of the timed "
                   "steps, minus the events' own share (replay time over timed time, per launch)",
         "event_share_us": round(event_us, 2), "empty_event_pair_us": round(event_pair_us, 2),
         "kernels_us": {n: round(u, 2) for n, u in kernel_pairs},
@@ -1024,6 +1094,10 @@ def main():
                                   "(trlda_model_set_deferred_stats); the last step's by a kernel of their "
                                   "own, inside the timed region" if carried else
                                   "a kernel launch of its own every step"),
+                   "in_flight": ("two E-steps at a time: the steps go in turn to two streams of the library's "
+                                 "own (trlda_model_set_stream_lanes(2), trlda_model_estep_io_ahead); output "
+                                 "arrays alternate between two sets; joined by every fence" if laned else
+                                 "one E-step at a time"),
                    "parallelism": "dp%d" % world,
                    "exchange_via": (("trlda_model_estep_dp (direct: peers' buffers through hipIpc, a step "
                                      "counter per source)" if exchange == "factors" and direct else
@@ -1055,6 +1129,8 @@ def main():
                                      "within 2 %% and %g s have passed, at most %g s; untimed; --no-settle "
                                      "switches it off" % (SETTLE_MIN_S, SETTLE_MAX_S)),
         "value_no_prefetch": value_no_prefetch,
+        "value_one_lane": value_one_lane,
+        "lanes": lanes[0],
         "value_fixed_work": value_fixed_work,
         "rccl_ranks": rccl_ranks,
         "same_step_n1": same_step_n1,

@@ -293,6 +293,39 @@ int trlda_model_set_deferred_stats(trlda_model *model, int enabled);
 int trlda_model_flush(trlda_model *model);
 int trlda_model_last_deferred(const trlda_model *model);
 
+/* Stream lanes: two E-steps of such a stream in flight at once.  The calls of a corpus pass of
+ * LDA::updateVariablesVI (src/lda.cpp:160-220) on an unchanged lambda share nothing but lambda,
+ * and a document launch does not end all at once: its documents finish 1-2 us apart (a
+ * 129..144-word one 5 us after the others), the helper workgroups at a time of their own.  With
+ * two lanes the library deals the stream's calls in turn to two streams of its own (each with the
+ * buffers of a model: preamble, factors, pending statistics), so that the next call's workgroups
+ * take the CUs as the current one's leave them.
+ *   trlda_model_estep_io_ahead   trlda_model_estep_io_next with the batches of the following calls
+ *       in order (upcoming[0] is the next call's, upcoming[1] the one after; n_upcoming may be 0):
+ *       a lane prepares the preamble of ITS next call, which is two calls ahead.  Identical to
+ *       trlda_model_estep_io_next(.., upcoming[0], ..) while lanes are off (the default) or the
+ *       call is outside the range of deferred statistics.
+ *   visibility   gamma, the iteration counts and the statistics of a call that went through a lane
+ *       are complete on the model's stream after trlda_model_flush or ANY other call on the model
+ *       that is not the next trlda_model_estep_io_ahead -- not after the call itself.  What the
+ *       caller enqueued on the model's stream before a call (its gamma0, the last reader of its
+ *       output arrays) is waited for by the lane.
+ *   outputs   calls in flight together must not share output arrays.  A call whose arrays meet
+ *       those of the other lane's outstanding work waits for it (correct, and no faster than one
+ *       lane): a streaming caller alternates between two sets of gamma / sstats arrays.
+ * Results are those of the one-lane stream, bit for bit.  trlda_model_lane_steps: E-steps that went
+ * through the lanes so far. */
+int trlda_model_set_stream_lanes(trlda_model *model, int lanes /* 1 or 2 */);
+int trlda_model_estep_io_ahead(trlda_model *model, const trlda_batch *batch,
+                               const trlda_batch *const *upcoming, int n_upcoming,
+                               const double *gamma0_dev, double *gamma_dev, double *sstats_dev,
+                               int max_iter, double threshold, int32_t *iters_dev);
+long long trlda_model_lane_steps(const trlda_model *model);
+/* with trlda_model_set_timing on: the summed duration (HIP events on the lanes' streams, one pair per
+ * lane around each stretch of calls between joins -- a lane's launches run back to back) and the
+ * number of the document launches that went through the lanes; joins the lanes */
+int trlda_model_get_lane_timing(trlda_model *model, double *usec_sum, int64_t *launches);
+
 /* Host-pointer convenience around trlda_model_estep (uploads gamma0, downloads
  * gamma / sstats / iters, synchronises). */
 int trlda_model_estep_host(trlda_model *model, const trlda_batch *batch,

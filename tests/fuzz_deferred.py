@@ -8,7 +8,12 @@ the switch turned off and on, the model closed).  Every call's gamma, iteration 
 statistics (from the array THAT call was given) must equal, bit for bit, those of the same stream
 with the switch off; one call in three is also compared with the oracle.
 
-    python tests/fuzz_deferred.py [--cases 20] [--seed 1]     (tests/test_gpu_fuzz.py runs a short one)
+`--lanes`: the stream goes through trlda_model_estep_io_ahead with two stream lanes
+(trlda_model_set_stream_lanes: consecutive calls in flight at once on two streams of the library's
+own), the batch after the next announced rightly, wrongly or not at all, the lanes switched off and
+on in between -- against the same plain stream.
+
+    python tests/fuzz_deferred.py [--cases 20] [--seed 1] [--lanes]   (tests/test_gpu_fuzz.py runs short ones)
 """
 import argparse
 import ctypes as C
@@ -46,6 +51,7 @@ def main(argv=None):
     ap.add_argument("--cases", type=int, default=20)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--calls", type=int, default=14)
+    ap.add_argument("--lanes", action="store_true")
     args = ap.parse_args(argv)
     from oracle.pyoracle import Oracle                 # the checker
     import trlda_amd
@@ -56,7 +62,7 @@ def main(argv=None):
     orc = Oracle()
     rng = np.random.RandomState(args.seed)
     worst = 0.0
-    deferred_calls = carried_calls = 0
+    deferred_calls = carried_calls = lane_calls = 0
     for case in range(args.cases):
         K = int(rng.choice([6, 7, 32, 100, 100, 128, 200]))
         V = int(rng.choice([40, 300, 2500, 7000]))
@@ -68,12 +74,20 @@ def main(argv=None):
         max_iter = int(rng.choice([1, 5, 20]))
         # the script of the case: (op, args) -- the same for both runs
         script = []
-        seq = [int(rng.randint(n_b)) for _ in range(args.calls + 1)]
+        seq = [int(rng.randint(n_b)) for _ in range(args.calls + 2)]
         for c in range(args.calls):
             i = seq[c]
             r = rng.rand()                           # the announcement: right (60 %), wrong, none
             nxt = seq[c + 1] if r < .6 else int(rng.randint(n_b)) if r < .8 else -1
-            script.append(("estep", i, int(nxt)))
+            nxt2 = -1
+            if args.lanes:                           # ... and of the call after the next
+                r = rng.rand()
+                nxt2 = seq[c + 2] if r < .7 else int(rng.randint(n_b)) if r < .85 else -1
+                if nxt < 0:
+                    nxt, nxt2 = nxt2, -1             # (a list: no gap in front)
+            script.append(("estep", i, int(nxt), int(nxt2)))
+            if args.lanes and rng.rand() < .08:
+                script.append(("lanes",))
             r = rng.rand()
             if r < .08:
                 script.append(("flush",))
@@ -89,7 +103,7 @@ def main(argv=None):
                 script.append(("toggle",))
 
         def run(deferred):
-            nonlocal deferred_calls, carried_calls
+            nonlocal deferred_calls, carried_calls, lane_calls
             trlda_amd.seed(1000 + case)
             m = OnlineLDA(num_words=V, num_topics=K, num_documents=50000, alpha=.1, eta=.3)
             m.lambdas = lams[0]
@@ -97,9 +111,12 @@ def main(argv=None):
             _ffi.check(L.trlda_model_set_deferred_stats(m._handle, deferred))
             dev = [m.upload(CSRDocuments(*r_)) for r_ in raw]
             outs, slots, on = [], [], bool(deferred)
+            two = bool(deferred and args.lanes)
+            if two:
+                _ffi.check(L.trlda_model_set_stream_lanes(m._handle, 2))
             for step in script:
                 if step[0] == "estep":
-                    _, i, nxt = step
+                    _, i, nxt, nxt2 = step
                     B = Bs[i]
                     ptrs = [_ffi.vp() for _ in range(4)]
                     for p, nbytes in zip(ptrs, (K * B * 8, K * B * 8, K * V * 8, B * 4)):
@@ -107,9 +124,19 @@ def main(argv=None):
                     _ffi.check(L.trlda_dev_upload(0, ptrs[0], g0s[i].ctypes.data, g0s[i].nbytes))
                     nan = np.full(K * V, np.nan)
                     _ffi.check(L.trlda_dev_upload(0, ptrs[2], nan.ctypes.data, nan.nbytes))
-                    _ffi.check(L.trlda_model_estep_io_next(m._handle, dev[i].handle,
-                                                           dev[nxt].handle if nxt >= 0 else None,
-                                                           ptrs[0], ptrs[1], ptrs[2], max_iter, 1e-3, ptrs[3]))
+                    if deferred and args.lanes:
+                        up = (C.c_void_p * 2)()
+                        n_up = 0
+                        for x in (nxt, nxt2):
+                            if x >= 0:
+                                up[n_up] = dev[x].handle.value
+                                n_up += 1
+                        _ffi.check(L.trlda_model_estep_io_ahead(m._handle, dev[i].handle, up, n_up, ptrs[0],
+                                                                ptrs[1], ptrs[2], max_iter, 1e-3, ptrs[3]))
+                    else:
+                        _ffi.check(L.trlda_model_estep_io_next(m._handle, dev[i].handle,
+                                                               dev[nxt].handle if nxt >= 0 else None,
+                                                               ptrs[0], ptrs[1], ptrs[2], max_iter, 1e-3, ptrs[3]))
                     f = L.trlda_model_last_deferred(m._handle)
                     if deferred:
                         deferred_calls += f & 1
@@ -128,9 +155,15 @@ def main(argv=None):
                 elif step[0] == "recreate":
                     dev[step[1]].close()
                     dev[step[1]] = m.upload(CSRDocuments(*raw[step[1]]))
+                elif step[0] == "lanes":
+                    if deferred:
+                        two = not two
+                        _ffi.check(L.trlda_model_set_stream_lanes(m._handle, 2 if two else 1))
                 elif step[0] == "toggle":
                     on = not on
                     _ffi.check(L.trlda_model_set_deferred_stats(m._handle, int(on and deferred)))
+            if deferred:
+                lane_calls += L.trlda_model_lane_steps(m._handle)
             _ffi.check(L.trlda_model_synchronize(m._handle))
             for ptrs, i, lam_at in slots:
                 B = Bs[i]
@@ -163,8 +196,12 @@ def main(argv=None):
                 assert eg < 1e-8 and es < 1e-7, (case, n, eg, es)
         for r_, keep in zip(raw, [tuple(np.array(v) for v in r2) for r2 in raw]):
             assert all(np.array_equal(u, v) for u, v in zip(r_, keep))
-    print("%d cases, %d calls left their statistics pending, %d launches carried them: all equal to the plain "
-          "stream; worst against the oracle %.1e" % (args.cases, deferred_calls, carried_calls, worst))
+    print("%d cases, %d calls left their statistics pending, %d launches carried them%s: all equal to the plain "
+          "stream; worst against the oracle %.1e"
+          % (args.cases, deferred_calls, carried_calls,
+             ", %d calls went through the two lanes" % lane_calls if args.lanes else "", worst))
+    if args.lanes:
+        assert lane_calls > 0
     return worst
 
 

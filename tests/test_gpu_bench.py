@@ -42,11 +42,18 @@ def test_bench_line_contract(hip_lib):
     r = j["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
-    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1.0
+    # two stream lanes (the default): two launches in flight -- the roofline is priced on the device
+    # time per launch (the timed region over its launches), the launches' own duration beside it
+    assert j["lanes"] == 2 and "two E-steps at a time" in j["config"]["in_flight"]
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["device_time_per_launch_us"] * 1e-6) / 1e9) < 1.0
+    assert abs(r["device_time_per_launch_us"] - j["ms_per_step"] * 1e3) < 0.02
+    assert 1.1 < r["launches_in_flight"] < 2.3
+    assert abs(r["launches_in_flight"] - r["avg_launch_us"] / r["device_time_per_launch_us"]) < 0.02
+    assert j["value_one_lane"]["value"] < 1.1 * j["value"]
     assert r["frac_documents_only"] < r["frac"]
     assert r["traffic"] is None or 0.3 * r["algorithmic_bytes_per_launch"] < r["traffic"] < \
         3 * r["algorithmic_bytes_per_launch"]
-    assert sum(r["kernels_us"].values()) <= j["ms_per_step"] * 1e3 * 1.05
+    assert sum(r["kernels_us"].values()) / r["launches_in_flight"] <= j["ms_per_step"] * 1e3 * 1.05
     c = j["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and c["sample"]
     assert c["unit"] == j["unit"]
@@ -78,6 +85,16 @@ def test_bench_line_contract(hip_lib):
 def test_bench_without_the_settle_phase(hip_lib):
     j = run_bench("--no-settle", "--no-cpu-baseline", "--no-update-rates", "--headline-only")
     assert j["settle_steps"] == 0 and j["settle_ms"] == 0.0
+
+
+def test_bench_one_lane(hip_lib):
+    """`--lanes 1`: one launch at a time, as in rounds 1-4 -- a launch's duration is the device time"""
+    j = run_bench("--lanes", "1", "--no-cpu-baseline", "--no-update-rates", "--headline-only")
+    r = j["roofline"]
+    assert j["lanes"] == 1 and j["value_one_lane"] is None and r["launches_in_flight"] == 1
+    assert j["config"]["in_flight"] == "one E-step at a time"
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1.0
+    assert sum(r["kernels_us"].values()) <= j["ms_per_step"] * 1e3 * 1.05
 
 
 def test_bench_forced_distributed_line(hip_lib):

@@ -71,3 +71,11 @@ def test_random_deferred_streams_equal_the_plain_ones(hip):
     of the same stream with the switch off, at the oracle's values."""
     import fuzz_deferred
     assert fuzz_deferred.main(["--cases", "6", "--seed", "4"]) < 1e-8
+
+
+def test_random_streams_through_two_lanes_equal_the_plain_ones(hip):
+    """tests/fuzz_deferred.py --lanes: the same random streams through trlda_model_estep_io_ahead with
+    two stream lanes (consecutive calls in flight at once), announcements two calls ahead right,
+    wrong or missing, the lanes switched off and on, and everything that must join them in between."""
+    import fuzz_deferred
+    assert fuzz_deferred.main(["--cases", "6", "--seed", "9", "--lanes"]) < 1e-8

@@ -1,0 +1,388 @@
+"""Stream lanes (trlda_model_set_stream_lanes, trlda_model_estep_io_ahead): the E-steps of a deferred
+stream -- a corpus pass of LDA::updateVariablesVI calls on an unchanged lambda, reference
+src/lda.cpp:160-220, whose calls share nothing but lambda -- dealt in turn to two streams of the
+library's own, so that consecutive calls' launches overlap on the device.
+
+Checked here, through the C ABI: a stream through two lanes against the same stream one launch at a
+time and against the plain E-step -- bitwise the same gamma, statistics and iteration counts, every
+call's results in the arrays THAT call was given; against the oracle; what joins the lanes (flush,
+synchronize, lambda replaced, an update, a batch destroyed, the model destroyed); callers that hand
+consecutive calls the same arrays or chain gamma into the next gamma0 (one lane, still right); work
+the caller enqueued on the model's stream just before a call; batches a lane does not take; wrong
+and missing announcements."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import TIGHT_RTOL, HipSampler, relerr, seeded_gamma, seeded_lambda
+from test_gpu_deferred import Slots, corpus, make_model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip(hip_lib):
+    from trlda_amd import _ffi
+    assert _ffi.device_count() >= 1, "GPU tests need a visible MI355X"
+    return hip_lib
+
+
+@pytest.fixture(scope="module")
+def sampler(hip):
+    return HipSampler(hip)
+
+
+def ahead(hip, m, devs, slots, n, announce=2, max_iter=20):
+    """call n of the stream `devs`, the next `announce` batches announced"""
+    from trlda_amd import _ffi
+    up = (C.c_void_p * 2)()
+    k = 0
+    for a in range(announce):
+        if n + 1 + a < len(devs):
+            up[k] = devs[n + 1 + a].handle.value
+            k += 1
+    g0d, gd, sd, itd = slots[n].ptrs
+    _ffi.check(hip.trlda_model_estep_io_ahead(m._handle, devs[n].handle, up, k, g0d, gd, sd, max_iter,
+                                              1e-3, itd))
+
+
+def run_stream(hip, K, V, lam, csrs, g0s, order, lanes, deferred=1, announce=2, max_iter=20):
+    from trlda_amd import _ffi
+    m = make_model(K, V, lam)
+    dev = [m.upload(c) for c in csrs]
+    slots = [Slots(hip, K, V, csrs[i], g0s[i]) for i in order]
+    devs = [dev[i] for i in order]
+    _ffi.check(hip.trlda_model_set_deferred_stats(m._handle, deferred))
+    _ffi.check(hip.trlda_model_set_stream_lanes(m._handle, lanes))
+    for n in range(len(order)):
+        ahead(hip, m, devs, slots, n, announce, max_iter)
+    through = hip.trlda_model_lane_steps(m._handle)
+    _ffi.check(hip.trlda_model_synchronize(m._handle))
+    res = [s.read() for s in slots]
+    for s in slots:
+        s.free()
+    m.close()
+    return res, through
+
+
+@pytest.mark.parametrize("K,V,B", [(100, 7000, 200), (64, 900, 90), (128, 3000, 256)])
+def test_a_stream_through_two_lanes_equals_the_one_lane_stream(hip, oracle, sampler, K, V, B):
+    lam = seeded_lambda(sampler, 3, K, V)
+    lens = [None, None, None, np.r_[[129, 140, 150], np.full(B - 3, 60)], None,
+            np.r_[[200, 400], np.full(B - 2, 80)]]      # tiered launches, a split document
+    csrs = [corpus(B - (i % 2) * 7, V, seed=40 + i, mean_unique=min(100, V // 8),
+                   lengths=None if l is None else l[:B - (i % 2) * 7]) for i, l in enumerate(lens)]
+    g0s = [seeded_gamma(sampler, 50 + i, K, len(c)) for i, c in enumerate(csrs)]
+    order = [0, 1, 2, 3, 4, 5, 0, 3, 1, 2, 2, 5]
+    two, through = run_stream(hip, K, V, lam, csrs, g0s, order, lanes=2)
+    assert through == len(order)
+    one, through1 = run_stream(hip, K, V, lam, csrs, g0s, order, lanes=1)
+    assert through1 == 0
+    plain, _ = run_stream(hip, K, V, lam, csrs, g0s, order, lanes=1, deferred=0, announce=0)
+    for n in range(len(order)):
+        for q in range(3):
+            assert np.array_equal(two[n][q], one[n][q]), (n, q)
+            assert np.array_equal(two[n][q], plain[n][q]), (n, q)
+        assert not np.isnan(two[n][1]).any()
+    for n in (0, 3, 5, 11):
+        c, g0 = csrs[order[n]], g0s[order[n]]
+        go, so, ito = oracle.estep(lam, .1, c.indptr, c.ids, c.cnts, g0, 20, 1e-3, nthreads=8)
+        g, s, it = two[n]
+        assert np.array_equal(it, ito) and relerr(g, go) < TIGHT_RTOL
+        assert relerr(s[so > 0], so[so > 0]) < TIGHT_RTOL and np.array_equal(s == 0, so == 0)
+
+
+@pytest.mark.parametrize("announce", [0, 1, 2])
+def test_announcements_missing_short_or_wrong(hip, sampler, announce):
+    """a lane prepares the preamble of ITS next call from upcoming[1]: without it (or with a promise
+    that is not kept) the call fills its own -- the same results"""
+    from trlda_amd import _ffi
+    K, V, B = 100, 3000, 120
+    lam = seeded_lambda(sampler, 5, K, V)
+    csrs = [corpus(B, V, seed=70 + i, mean_unique=60) for i in range(5)]
+    g0s = [seeded_gamma(sampler, 80 + i, K, B) for i in range(5)]
+    order = [0, 1, 2, 3, 4, 2, 0]
+    ref, _ = run_stream(hip, K, V, lam, csrs, g0s, order, lanes=1, deferred=0, announce=0)
+    got, through = run_stream(hip, K, V, lam, csrs, g0s, order, lanes=2, announce=announce)
+    assert through == len(order)
+    for n in range(len(order)):
+        for q in range(3):
+            assert np.array_equal(got[n][q], ref[n][q]), (n, q)
+    # promises that are not kept: every call announces batches 3 and 4, whatever comes
+    m = make_model(K, V, lam)
+    dev = [m.upload(c) for c in csrs]
+    slots = [Slots(hip, K, V, csrs[i], g0s[i]) for i in order]
+    _ffi.check(hip.trlda_model_set_deferred_stats(m._handle, 1))
+    _ffi.check(hip.trlda_model_set_stream_lanes(m._handle, 2))
+    up = (C.c_void_p * 2)(dev[3].handle.value, dev[4].handle.value)
+    for n, i in enumerate(order):
+        g0d, gd, sd, itd = slots[n].ptrs
+        _ffi.check(hip.trlda_model_estep_io_ahead(m._handle, dev[i].handle, up, 2, g0d, gd, sd, 20, 1e-3, itd))
+    _ffi.check(hip.trlda_model_flush(m._handle))
+    _ffi.check(hip.trlda_model_synchronize(m._handle))
+    for n in range(len(order)):
+        r = slots[n].read()
+        for q in range(3):
+            assert np.array_equal(r[q], ref[n][q]), (n, q)
+        slots[n].free()
+    m.close()
+
+
+def test_what_joins_the_lanes(hip, oracle, sampler):
+    """between calls of a stream through the lanes: flush, synchronize, a host read of the statistics'
+    array after a flush, lambda replaced (the lanes' prepared preambles are void), an update call, the
+    batch destroyed while a lane's statistics still read it -- and the model destroyed with both lanes
+    busy: every call's results complete and right"""
+    from trlda_amd import _ffi
+    K, V, B = 100, 4000, 150
+    lam = seeded_lambda(sampler, 7, K, V)
+    lam2 = seeded_lambda(sampler, 8, K, V)
+    csrs = [corpus(B, V, seed=90 + i, mean_unique=80) for i in range(4)]
+    g0s = [seeded_gamma(sampler, 95 + i, K, B) for i in range(4)]
+
+    def want(l, i):
+        return oracle.estep(l, .1, csrs[i].indptr, csrs[i].ids, csrs[i].cnts, g0s[i], 20, 1e-3, nthreads=8)
+
+    def check(slot, l, i):
+        g, s, it = slot.read()
+        go, so, ito = want(l, i)
+        assert np.array_equal(it, ito) and relerr(g, go) < TIGHT_RTOL
+        assert relerr(s[so > 0], so[so > 0]) < TIGHT_RTOL and np.array_equal(s == 0, so == 0)
+
+    m = make_model(K, V, lam)
+    dev = [m.upload(c) for c in csrs]
+    _ffi.check(hip.trlda_model_set_deferred_stats(m._handle, 1))
+    _ffi.check(hip.trlda_model_set_stream_lanes(m._handle, 2))
+    order = [0, 1, 2, 3, 0, 1, 2, 3, 0, 1]
+    slots = [Slots(hip, K, V, csrs[i], g0s[i]) for i in order]
+    devs = [dev[i] for i in order]
+    ahead(hip, m, devs, slots, 0)
+    ahead(hip, m, devs, slots, 1)
+    _ffi.check(hip.trlda_model_flush(m._handle))               # flush: both complete on the model's stream
+    _ffi.check(hip.trlda_dev_synchronize(0))
+    check(slots[0], lam, 0)
+    check(slots[1], lam, 1)
+    ahead(hip, m, devs, slots, 2)
+    ahead(hip, m, devs, slots, 3)
+    ahead(hip, m, devs, slots, 4)
+    m.lambdas = lam2                                           # joins; the prepared preambles are void
+    check(slots[2], lam, 2)
+    check(slots[3], lam, 3)
+    check(slots[4], lam, 0)
+    ahead(hip, m, devs, slots, 5)
+    ahead(hip, m, devs, slots, 6)
+    through = hip.trlda_model_lane_steps(m._handle)
+    assert through == 7
+    m.update_parameters(dev[3], max_iter_tr=2, max_iter_inference=20)      # an update joins, lambda moves
+    lam3 = np.asfortranarray(m.lambdas)
+    check(slots[5], lam2, 1)
+    check(slots[6], lam2, 2)
+    ahead(hip, m, devs, slots, 7)
+    ahead(hip, m, devs, slots, 8)
+    # the batch of call 8 goes while a lane's statistics still read it
+    csr_x = corpus(B, V, seed=333, mean_unique=80)
+    g0x = seeded_gamma(sampler, 334, K, B)
+    bx = m.upload(csr_x)
+    sx = Slots(hip, K, V, csr_x, g0x)
+    up = (C.c_void_p * 2)()
+    _ffi.check(hip.trlda_model_estep_io_ahead(m._handle, bx.handle, up, 0, sx.ptrs[0], sx.ptrs[1], sx.ptrs[2],
+                                              20, 1e-3, sx.ptrs[3]))
+    bx.close()
+    ahead(hip, m, devs, slots, 9)
+    m.close()                                                  # both lanes busy
+    _ffi.check(hip.trlda_dev_synchronize(0))
+    check(slots[7], lam3, 3)
+    check(slots[8], lam3, 0)
+    check(slots[9], lam3, 1)
+    g, s, it = sx.read()
+    go, so, ito = oracle.estep(lam3, .1, csr_x.indptr, csr_x.ids, csr_x.cnts, g0x, 20, 1e-3, nthreads=8)
+    assert np.array_equal(it, ito) and relerr(g, go) < TIGHT_RTOL and relerr(s[so > 0], so[so > 0]) < TIGHT_RTOL
+    for s_ in slots + [sx]:
+        s_.free()
+
+
+def test_shared_and_chained_arrays_take_one_lane(hip, sampler):
+    """the same output arrays for consecutive calls, or the last call's gamma as this call's gamma0:
+    nothing to run side by side -- such calls go one at a time, with the results of the plain stream"""
+    from trlda_amd import _ffi
+    K, V, B = 100, 2500, 100
+    lam = seeded_lambda(sampler, 11, K, V)
+    csrs = [corpus(B, V, seed=120 + i, mean_unique=70) for i in range(3)]
+    g0 = seeded_gamma(sampler, 130, K, B)
+    n_calls = 7
+
+    def stream(lanes, deferred, mode):
+        m = make_model(K, V, lam)
+        dev = [m.upload(c) for c in csrs]
+        _ffi.check(hip.trlda_model_set_deferred_stats(m._handle, deferred))
+        _ffi.check(hip.trlda_model_set_stream_lanes(m._handle, lanes))
+        slots = [Slots(hip, K, V, csrs[0], g0) for _ in range(n_calls + 1)]
+        up = (C.c_void_p * 2)()
+        out = []
+        for n in range(n_calls):
+            up[0] = dev[(n + 1) % 3].handle.value
+            up[1] = dev[(n + 2) % 3].handle.value
+            if mode == "shared":                     # one set of arrays for every call
+                g0d, gd, sd, itd = slots[0].ptrs
+            else:                                    # chained: gamma of call n - 1 is gamma0 of call n
+                g0d = slots[n].ptrs[1] if n else slots[0].ptrs[0]
+                gd, sd, itd = slots[n + 1].ptrs[1:]
+            _ffi.check(hip.trlda_model_estep_io_ahead(m._handle, dev[n % 3].handle, up, 2, g0d, gd, sd, 20,
+                                                      1e-3, itd))
+            if mode == "shared":
+                _ffi.check(hip.trlda_model_flush(m._handle))
+                _ffi.check(hip.trlda_dev_synchronize(0))
+                out.append(slots[0].read())
+        through = hip.trlda_model_lane_steps(m._handle)
+        _ffi.check(hip.trlda_model_synchronize(m._handle))
+        if mode == "chained":
+            out = [slots[n + 1].read() for n in range(n_calls)]
+        for s in slots:
+            s.free()
+        m.close()
+        return out, through
+
+    for mode in ("chained", "shared"):
+        ref, _ = stream(1, 0, mode)
+        got, through = stream(2, 1, mode)
+        for n in range(n_calls):
+            for q in range(3):
+                assert np.array_equal(got[n][q], ref[n][q]), (mode, n, q)
+        if mode == "chained":
+            assert through <= 1, through             # (the first call has no predecessor)
+
+    # ... and WITHOUT a flush in between, shared arrays: the last call's results are what is left
+    m = make_model(K, V, lam)
+    dev = [m.upload(c) for c in csrs]
+    _ffi.check(hip.trlda_model_set_deferred_stats(m._handle, 1))
+    _ffi.check(hip.trlda_model_set_stream_lanes(m._handle, 2))
+    s = Slots(hip, K, V, csrs[0], g0)
+    up = (C.c_void_p * 2)()
+    for n in range(6):
+        up[0] = dev[(n + 1) % 3].handle.value
+        up[1] = dev[(n + 2) % 3].handle.value
+        _ffi.check(hip.trlda_model_estep_io_ahead(m._handle, dev[n % 3].handle, up, 2, s.ptrs[0], s.ptrs[1],
+                                                  s.ptrs[2], 20, 1e-3, s.ptrs[3]))
+    _ffi.check(hip.trlda_model_synchronize(m._handle))
+    last = s.read()
+    s.poison()
+    _ffi.check(hip.trlda_model_set_stream_lanes(m._handle, 1))
+    _ffi.check(hip.trlda_model_set_deferred_stats(m._handle, 0))
+    _ffi.check(hip.trlda_model_estep_io(m._handle, dev[5 % 3].handle, s.ptrs[0], s.ptrs[1], s.ptrs[2], 20, 1e-3,
+                                        s.ptrs[3]))
+    _ffi.check(hip.trlda_model_synchronize(m._handle))
+    want = s.read()
+    for q in range(3):
+        assert np.array_equal(last[q], want[q]), q
+    s.free()
+    m.close()
+
+
+def test_the_callers_stream_comes_first(hip, sampler):
+    """gamma0 produced by work on the model's stream right before the call (a device copy enqueued on
+    torch's current stream, which the model is told to use), results consumed on that stream after
+    trlda_model_flush without a host synchronisation in between"""
+    import torch
+    from trlda_amd import _ffi
+    K, V, B = 100, 3000, 128
+    lam = seeded_lambda(sampler, 13, K, V)
+    csrs = [corpus(B, V, seed=140 + i, mean_unique=90) for i in range(4)]
+    g0s = [seeded_gamma(sampler, 150 + i, K, B) for i in range(4)]
+    dev_t = torch.device("cuda", 0)
+    m = make_model(K, V, lam)
+    stream = torch.cuda.Stream(dev_t)
+    _ffi.check(hip.trlda_model_set_stream(m._handle, _ffi.vp(stream.cuda_stream)))
+    _ffi.check(hip.trlda_model_set_deferred_stats(m._handle, 1))
+    _ffi.check(hip.trlda_model_set_stream_lanes(m._handle, 2))
+    devb = [m.upload(c) for c in csrs]
+    host_g0 = [torch.from_numpy(np.ascontiguousarray(g.T)).pin_memory() for g in g0s]
+    big = torch.empty(64 << 20, dtype=torch.float64, device=dev_t)      # keeps the stream busy
+    g0_dev = [torch.empty(B * K, dtype=torch.float64, device=dev_t) for _ in range(4)]
+    gam = [torch.empty(B * K, dtype=torch.float64, device=dev_t) for _ in range(4)]
+    sst = [torch.full((K * V,), float("nan"), dtype=torch.float64, device=dev_t) for _ in range(4)]
+    sums = []
+    up = (C.c_void_p * 2)()
+    with torch.cuda.stream(stream):
+        for n in range(4):
+            big.fill_(float(n))                                       # ~ a millisecond of work in front
+            g0_dev[n].copy_(host_g0[n].reshape(-1), non_blocking=True)
+            k = 0
+            for a in (1, 2):
+                if n + a < 4:
+                    up[k] = devb[n + a].handle.value
+                    k += 1
+            _ffi.check(hip.trlda_model_estep_io_ahead(m._handle, devb[n].handle, up, k, g0_dev[n].data_ptr(),
+                                                      gam[n].data_ptr(), sst[n].data_ptr(), 20, 1e-3, None))
+        assert hip.trlda_model_lane_steps(m._handle) == 4
+        _ffi.check(hip.trlda_model_flush(m._handle))
+        for n in range(4):
+            sums.append((gam[n].sum(), sst[n].sum()))                 # on the stream, behind the join
+    stream.synchronize()
+    want, _ = run_stream(hip, K, V, lam, csrs, g0s, [0, 1, 2, 3], lanes=1, deferred=0, announce=0)
+    for n in range(4):
+        gg = np.asfortranarray(gam[n].cpu().numpy().reshape(B, K).T)
+        ss = np.asfortranarray(sst[n].cpu().numpy().reshape(V, K).T)
+        assert np.array_equal(gg, want[n][0]) and np.array_equal(ss, want[n][1]), n
+        # what the caller's own kernels saw on the stream behind the join: the finished arrays
+        assert float(sums[n][0]) == float(gam[n].sum()) and float(sums[n][1]) == float(sst[n].sum())
+        assert np.isfinite(float(sums[n][1]))
+    m.close()
+
+
+@pytest.mark.parametrize("K,V,B,why", [(101, 600, 50, "odd K"), (100, 3000, 300, "more than 256 documents"),
+                                       (200, 2000, 64, "K > 128")])
+def test_batches_a_lane_does_not_take(hip, sampler, K, V, B, why):
+    lam = seeded_lambda(sampler, 17, K, V)
+    csrs = [corpus(B, V, seed=170 + i, mean_unique=min(80, V // 8)) for i in range(3)]
+    g0s = [seeded_gamma(sampler, 175 + i, K, B) for i in range(3)]
+    order = [0, 1, 2, 0, 1]
+    ref, _ = run_stream(hip, K, V, lam, csrs, g0s, order, lanes=1, deferred=0, announce=0)
+    got, through = run_stream(hip, K, V, lam, csrs, g0s, order, lanes=2)
+    assert through == 0, why
+    for n in range(len(order)):
+        for q in range(3):
+            assert np.array_equal(got[n][q], ref[n][q]), (why, n, q)
+
+
+def test_four_hundred_steps_through_two_lanes(hip, sampler):
+    """a long stream over eight batches, two sets of output arrays in turn (bench.py's step): the
+    last two calls' results against the plain E-step, and the counters' wrap-free bookkeeping"""
+    from trlda_amd import _ffi
+    K, V, B = 100, 7000, 200
+    lam = seeded_lambda(sampler, 19, K, V)
+    csrs = [corpus(B, V, seed=200 + i) for i in range(8)]
+    g0s = [seeded_gamma(sampler, 210 + i, K, B) for i in range(8)]
+    m = make_model(K, V, lam)
+    dev = [m.upload(c) for c in csrs]
+    _ffi.check(hip.trlda_model_set_deferred_stats(m._handle, 1))
+    _ffi.check(hip.trlda_model_set_stream_lanes(m._handle, 2))
+    g0_slots = [Slots(hip, K, V, csrs[i], g0s[i]) for i in range(8)]
+    outs = [Slots(hip, K, V, csrs[0], g0s[0]) for _ in range(2)]
+    up = (C.c_void_p * 2)()
+    N = 401
+    for n in range(N):
+        up[0] = dev[(n + 1) % 8].handle.value
+        up[1] = dev[(n + 2) % 8].handle.value
+        o = outs[n & 1]
+        _ffi.check(hip.trlda_model_estep_io_ahead(m._handle, dev[n % 8].handle, up, 2, g0_slots[n % 8].ptrs[0],
+                                                  o.ptrs[1], o.ptrs[2], 20, 1e-3, o.ptrs[3]))
+        if n % 97 == 50:
+            _ffi.check(hip.trlda_model_flush(m._handle))
+    assert hip.trlda_model_lane_steps(m._handle) == N
+    _ffi.check(hip.trlda_model_synchronize(m._handle))
+    got = {(N - 1) & 1: outs[(N - 1) & 1].read(), (N - 2) & 1: outs[(N - 2) & 1].read()}
+    _ffi.check(hip.trlda_model_set_stream_lanes(m._handle, 1))
+    _ffi.check(hip.trlda_model_set_deferred_stats(m._handle, 0))
+    for n in (N - 1, N - 2):
+        s = Slots(hip, K, V, csrs[n % 8], g0s[n % 8])
+        _ffi.check(hip.trlda_model_estep_io(m._handle, dev[n % 8].handle, s.ptrs[0], s.ptrs[1], s.ptrs[2], 20,
+                                            1e-3, s.ptrs[3]))
+        _ffi.check(hip.trlda_model_synchronize(m._handle))
+        want = s.read()
+        for q in range(3):
+            assert np.array_equal(got[n & 1][q], want[q]), (n, q)
+        s.free()
+    for s in g0_slots + outs:
+        s.free()
+    m.close()

@@ -276,6 +276,31 @@ struct trlda_model {
     unsigned int defer_work_total = 0;    // what sync_counters[32] holds: the helpers' items so far
     bool last_deferred = false;           // the last E-step left its statistics pending
     bool last_carried = false;            // ... / its launch carried the call before's
+    // Stream lanes (trlda_model_set_stream_lanes): the E-steps of a deferred stream
+    // dealt in turn to two models of their own -- own streams, own workspaces, lambda and alpha
+    // THIS model's -- so that the launches of consecutive calls may overlap on the device: the
+    // documents of a launch end 1-2 us apart (a 129..144-word one 5 us after the others) and the
+    // next launch's workgroups take the CUs as they come free.  Nothing of a lane's work is on this
+    // model's stream until lanes_join() (every entry point except the next E-step of the stream).
+    int lanes_wanted = 1;
+    trlda_model *lane[2] = {nullptr, nullptr};
+    trlda_model *lane_owner = nullptr;    // set in a lane: whose lambda / alpha it reads
+    int lane_turn = 0;
+    bool lanes_live = false;              // a lane holds work this model's stream has not waited for
+    hipEvent_t lane_in[2] = {nullptr, nullptr}, lane_out[2] = {nullptr, nullptr};
+    struct LaneRange {
+        const char *lo = nullptr, *hi = nullptr;
+    } lane_writes[2][8];                  // what the lane's outstanding launches write (ring of two calls)
+    int lane_calls[2] = {0, 0};
+    LaneRange prev_writes[3];             // the arrays of the stream's last call (whichever way it went)
+    // timing (trlda_model_set_timing): a lane's launches run back to back on its stream, so one pair
+    // of events per lane around a whole stretch of calls -- first call after a join to the join --
+    // gives the launches' mean duration without an event between any two of them
+    hipEvent_t lane_span[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    bool lane_span_open[2] = {false, false};
+    int64_t lane_span_launches[2] = {0, 0}, lane_span_count = 0;
+    double lane_span_us = 0.0;
+    int64_t lane_steps = 0;               // E-steps that went through the lanes (tests)
     struct {
         bool valid = false;
         uint64_t batch_id = 0, version = 0;
@@ -2328,12 +2353,50 @@ int check_split_exchange(trlda_model *m)
 int sync_model(trlda_model *m)
 {
     HIP_TRY(hipStreamSynchronize(m->stream));
-    return check_split_exchange(m);
+    int rc = check_split_exchange(m);
+    for (trlda_model *l : m->lane)                   // (joined before: the stream waited for theirs)
+        if (l) {
+            const int r = check_split_exchange(l);
+            if (!rc)
+                rc = r;
+        }
+    return rc;
+}
+
+// Stream lanes: what the lanes hold is brought to an end -- their pending statistics launched on
+// their streams -- and the model's stream continues behind all of it.
+int lanes_join(trlda_model *m)
+{
+    if (!m->lanes_live)
+        return TRLDA_OK;
+    m->lanes_live = false;
+    m->lane_turn = 0;
+    int rc = TRLDA_OK;
+    for (int p = 0; p < 2; ++p) {
+        trlda_model *l = m->lane[p];
+        if (!l)
+            continue;
+        if (m->lane_span_open[p])                    // (the documents' launches: not the flush below)
+            (void)hipEventRecord(m->lane_span[p][1], l->stream);
+        const int r = flush_pending(l);
+        if (!rc)
+            rc = r;
+        if (hipEventRecord(m->lane_out[p], l->stream) != hipSuccess ||
+            hipStreamWaitEvent(m->stream, m->lane_out[p], 0) != hipSuccess) {
+            // (no way to order the streams: wait here)
+            (void)hipStreamSynchronize(l->stream);
+        }
+        m->lane_calls[p] = 0;
+        for (auto &w : m->lane_writes[p])
+            w = trlda_model::LaneRange{};
+    }
+    return rc;
 }
 
 // keep_pending: the caller is the next E-step of a deferred stream (it decides itself whether its
 // launch carries the pending statistics); everybody else finds none outstanding
-int check_model(const trlda_model *m, bool keep_pending = false)
+// keep_lanes: the caller is the next E-step of a stream that runs through the lanes
+int check_model(const trlda_model *m, bool keep_pending = false, bool keep_lanes = false)
 {
     if (!m)
         return fail(TRLDA_ERR_ARG, "model is NULL");
@@ -2344,6 +2407,8 @@ int check_model(const trlda_model *m, bool keep_pending = false)
     int rc = use_device(m->device);
     if (!rc && m->pending.valid && !keep_pending)
         rc = flush_pending(const_cast<trlda_model *>(m));
+    if (!rc && m->lanes_live && !keep_lanes)
+        rc = lanes_join(const_cast<trlda_model *>(m));
     return rc;
 }
 
@@ -3054,7 +3119,26 @@ int trlda_batch_num_very_long_words(const trlda_batch *b) { return b ? b->n_vl :
 
 // ---- model --------------------------------------------------------------------
 
+}  // extern "C"
+
+namespace {
+// (stream_priority != 0: the model's own stream is created with that priority -- the lanes of
+// another model, lanes_ensure)
+int model_create(trlda_model **out, int device, int K, int V, int stream_priority);
+}  // namespace
+
+extern "C" {
+
 int trlda_model_create(trlda_model **out, int device, int K, int V)
+{
+    return model_create(out, device, K, V, 0);
+}
+
+}  // extern "C"
+
+namespace {
+
+int model_create(trlda_model **out, int device, int K, int V, int stream_priority)
 {
     if (!out)
         return fail(TRLDA_ERR_ARG, "out is NULL");
@@ -3081,7 +3165,10 @@ int trlda_model_create(trlda_model **out, int device, int K, int V)
     if (!rc) rc = dev_alloc(&m->partial, (size_t)kMaxRowsumBlocks * K);
     if (!rc) rc = dev_alloc(&m->counter, 1);
     if (!rc && !std::getenv("TRLDA_NULL_STREAM")) {
-        if (hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking) != hipSuccess)
+        const hipError_t e = stream_priority != 0
+                                 ? hipStreamCreateWithPriority(&m->own_stream, hipStreamNonBlocking, stream_priority)
+                                 : hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking);
+        if (e != hipSuccess)
             rc = fail(TRLDA_ERR_HIP, "hipStreamCreateWithFlags failed");
         m->stream = m->own_stream;
         if (!rc) {
@@ -3137,13 +3224,34 @@ int trlda_model_create(trlda_model **out, int device, int K, int V)
     return TRLDA_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
 int trlda_model_destroy(trlda_model *m)
 {
     if (!m)
         return TRLDA_OK;
     if (hipSetDevice(m->device) == hipSuccess) {
         (void)flush_pending(m);                      // deferred statistics: into the caller's array
+        (void)lanes_join(m);                         // ... and the lanes' (their streams end below)
         (void)hipStreamSynchronize(m->stream);
+        for (int p = 0; p < 2; ++p) {
+            if (m->lane[p])
+                (void)trlda_model_destroy(m->lane[p]);
+            m->lane[p] = nullptr;
+            if (m->lane_in[p])
+                (void)hipEventDestroy(m->lane_in[p]);
+            if (m->lane_out[p])
+                (void)hipEventDestroy(m->lane_out[p]);
+            for (int q = 0; q < 2; ++q)
+                if (m->lane_span[p][q])
+                    (void)hipEventDestroy(m->lane_span[p][q]);
+        }
+        if (m->lane_owner) {                         // a lane: lambda and alpha are its owner's
+            m->lambda = nullptr;
+            m->alpha = nullptr;
+        }
         if (m->draw_stream)
             (void)hipStreamSynchronize(m->draw_stream);
         (void)hipFree(m->lambda); (void)hipFree(m->alpha); (void)hipFree(m->eeb); (void)hipFree(m->psi_sum);
@@ -3430,6 +3538,221 @@ int trlda_model_flush(trlda_model *m) { return check_model(m); }
 int trlda_model_last_deferred(const trlda_model *m)
 {
     return m ? (m->last_deferred ? 1 : 0) | (m->last_carried ? 2 : 0) : 0;
+}
+
+}  // extern "C"
+
+namespace {
+
+// what a stream lane may take: exactly the calls whose statistics can wait for the lane's next one
+// (estep_device: launch_ok && defer_self), on a model that holds nothing a lane could not see
+bool lane_takes(const trlda_model *m, const trlda_batch *b)
+{
+    return m->lanes_wanted >= 2 && m->deferred_stats && !m->dp && !m->eb.active && m->prefetch_next &&
+           m->sstats_mode == TRLDA_SSTATS_SEGMENTED && b->B > 0 && b->V == m->V && b->device == m->device &&
+           fused_preamble_possible(m, b) && m->rs_floor >= kFusedRowsumFloor && fused_update_available(m) &&
+           m->K % 2 == 0 && m->pair_gathers && b->long_len == trlda::kLongWord && b->B <= 256 &&
+           b->max_list <= 256 && b->n_active > 0;
+}
+
+int lanes_ensure(trlda_model *m)
+{
+    for (int p = 0; p < 2; ++p) {
+        if (m->lane[p])
+            continue;
+        // The lanes' streams get the device's HIGH priority: the runtime keeps a pool of hardware queues
+        // per priority (four each by default) and hands a stream beyond the pool's size a queue that
+        // another stream of that priority already has -- two lanes on ONE queue run one after the other,
+        // and a lane sharing the queue of the caller's stream has that stream's event records queue up
+        // behind its launches (measured: 35.3 us per step, against 26.8 with queues of their own and
+        // 30.9 with one lane; profiles/r05_lanes_queues.txt).  Nobody else in the process normally asks
+        // for that priority, so the two lanes have two queues to themselves.
+        static const int lane_priority = [] {
+            if (const char *e = std::getenv("TRLDA_LANE_PRIORITY"))   // (A/B; 0: the default priority)
+                return std::atoi(e);
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess)
+                return 0;
+            return greatest;
+        }();
+        trlda_model *l = nullptr;
+        int rc = model_create(&l, m->device, m->K, m->V, lane_priority);
+        if (rc)
+            return rc;
+        (void)hipFree(l->lambda);
+        (void)hipFree(l->alpha);
+        l->lambda = m->lambda;
+        l->alpha = m->alpha;
+        l->lane_owner = m;
+        m->lane[p] = l;
+        if (hipEventCreateWithFlags(&m->lane_in[p], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&m->lane_out[p], hipEventDisableTiming) != hipSuccess)
+            return fail(TRLDA_ERR_HIP, "hipEventCreateWithFlags failed");
+    }
+    return TRLDA_OK;
+}
+
+// a lane follows its owner's switches and what the owner knows about lambda (what a lane keeps
+// about lambda -- a prefetched preamble -- is stamped with the version: a new one voids it)
+void lane_follow(const trlda_model *m, trlda_model *l)
+{
+    l->sstats_mode = m->sstats_mode; l->doc_threads = m->doc_threads; l->doc_kernel = m->doc_kernel;
+    l->split_preamble = m->split_preamble; l->dense_preamble = m->dense_preamble;
+    l->pair_gathers = m->pair_gathers; l->prefetch_next = m->prefetch_next; l->split_docs = m->split_docs;
+    l->merged_launch = m->merged_launch; l->split_long_lists = m->split_long_lists;
+    l->tiled_tasks = m->tiled_tasks; l->fused_update = m->fused_update; l->carry_rowsums = m->carry_rowsums;
+    l->emit_next_preamble = m->emit_next_preamble;
+    l->deferred_stats = true;
+    l->rs_floor = m->rs_floor; l->lambda_positive = m->lambda_positive; l->lambda_exposed = false;
+    l->lambda_version = m->lambda_version;
+    // (not the per-launch event stamps of trlda_model_set_timing: events between a lane's launches
+    // would change what they measure -- lane_span above)
+}
+
+// closed spans -> lane_span_us / lane_span_count (waits for the lanes' end events)
+void lane_spans_collect(trlda_model *m)
+{
+    for (int p = 0; p < 2; ++p) {
+        if (!m->lane_span_open[p] || m->lanes_live)
+            continue;
+        float ms = 0.f;
+        if (hipEventSynchronize(m->lane_span[p][1]) == hipSuccess &&
+            hipEventElapsedTime(&ms, m->lane_span[p][0], m->lane_span[p][1]) == hipSuccess) {
+            m->lane_span_us += 1e3 * (double)ms;
+            m->lane_span_count += m->lane_span_launches[p];
+        }
+        m->lane_span_open[p] = false;
+        m->lane_span_launches[p] = 0;
+    }
+}
+
+bool ranges_meet(const trlda_model::LaneRange &w, const void *p, size_t bytes)
+{
+    const char *lo = static_cast<const char *>(p);
+    return w.lo && p && bytes && lo < w.hi && w.lo < lo + bytes;
+}
+
+}  // namespace
+
+extern "C" {
+
+int trlda_model_set_stream_lanes(trlda_model *m, int lanes)
+{
+    int rc = check_model(m);                         // (joins what the lanes hold)
+    if (rc)
+        return rc;
+    if (lanes < 1 || lanes > 2)
+        return fail(TRLDA_ERR_ARG, "stream lanes: 1 or 2");
+    m->lanes_wanted = lanes;
+    return TRLDA_OK;
+}
+
+long long trlda_model_lane_steps(const trlda_model *m) { return m ? (long long)m->lane_steps : 0; }
+
+int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda_batch *const *upcoming,
+                               int n_upcoming, const double *gamma0_dev, double *gamma_dev,
+                               double *sstats_dev, int max_iter, double threshold, int32_t *iters_dev)
+{
+    if (!m)
+        return fail(TRLDA_ERR_ARG, "model is NULL");
+    if (n_upcoming < 0 || (n_upcoming > 0 && !upcoming))
+        return fail(TRLDA_ERR_ARG, "upcoming batches: a count without a list");
+    const trlda_batch *next = n_upcoming > 0 ? upcoming[0] : nullptr;
+    if (!b || !sstats_dev || (b->B > 0 && (!gamma_dev || !gamma0_dev)))
+        return trlda_model_estep_io_next(m, b, next, gamma0_dev, gamma_dev, sstats_dev, max_iter,
+                                         threshold, iters_dev);
+    // A caller that hands consecutive calls the same arrays (or reads the last call's gamma as this
+    // call's gamma0) has nothing to run side by side: one lane, as without the switch
+    const size_t g_bytes = (size_t)b->B * m->K * sizeof(double), s_bytes = (size_t)m->K * m->V * sizeof(double);
+    const size_t i_bytes = (size_t)b->B * sizeof(int32_t);
+    auto meets_any = [&](const trlda_model::LaneRange *w, int n) {
+        bool hit = false;
+        for (int i = 0; i < n; ++i)
+            hit = hit || ranges_meet(w[i], gamma_dev, g_bytes) || ranges_meet(w[i], gamma0_dev, g_bytes) ||
+                  ranges_meet(w[i], sstats_dev, s_bytes) || ranges_meet(w[i], iters_dev, i_bytes);
+        return hit;
+    };
+    const bool chained = meets_any(m->prev_writes, 3);
+    {
+        const char *g = reinterpret_cast<const char *>(gamma_dev), *st = reinterpret_cast<const char *>(sstats_dev),
+                   *it = reinterpret_cast<const char *>(iters_dev);
+        m->prev_writes[0] = {g, g ? g + g_bytes : g};
+        m->prev_writes[1] = {st, st + s_bytes};
+        m->prev_writes[2] = {it, it ? it + i_bytes : it};
+    }
+    if (chained || !lane_takes(m, b))
+        return trlda_model_estep_io_next(m, b, next, gamma0_dev, gamma_dev, sstats_dev, max_iter,
+                                         threshold, iters_dev);
+    // (statistics this model itself holds pending go first; what the lanes hold stays)
+    int rc = check_model(m, false, true);
+    if (!rc)
+        rc = lanes_ensure(m);
+    if (rc)
+        return rc;
+    const int p = m->lane_turn;
+    trlda_model *l = m->lane[p], *o = m->lane[1 - p];
+    lane_follow(m, l);
+    // whatever the caller enqueued on the model's stream so far -- this call's gamma0, the last
+    // reader of the arrays it writes, an upload of lambda -- comes first (nothing of the lanes is
+    // on that stream: the record passes as soon as the caller's own work has)
+    static const bool input_events = [] {
+        const char *e = std::getenv("TRLDA_LANE_INPUT_EVENTS");
+        return !(e && e[0] == '0');
+    }();
+    // (a stream with nothing outstanding has nothing to wait for: no record, no packet in its queue --
+    // at the start of a stream of calls that is two hops between three hardware queues before the
+    // first launch may begin)
+    const bool first = !m->lanes_live;
+    if ((input_events || first) && hipStreamQuery(m->stream) != hipSuccess) {
+        (void)hipGetLastError();                     // (hipErrorNotReady is not an error)
+        HIP_TRY(hipEventRecord(m->lane_in[p], m->stream));
+        HIP_TRY(hipStreamWaitEvent(l->stream, m->lane_in[p], 0));
+        if (first)                                   // (the other lane's first call may skip its own)
+            HIP_TRY(hipStreamWaitEvent(o->stream, m->lane_in[p], 0));
+    }
+    // the OTHER lane's outstanding launches write arrays this call reads or writes (a caller that
+    // hands the same gamma / sstats to consecutive calls): they go first -- correct, and serial
+    if (meets_any(m->lane_writes[1 - p], 8)) {
+        if ((rc = flush_pending(o)))
+            return rc;
+        HIP_TRY(hipEventRecord(m->lane_out[1 - p], o->stream));
+        HIP_TRY(hipStreamWaitEvent(l->stream, m->lane_out[1 - p], 0));
+        for (auto &w : m->lane_writes[1 - p])
+            w = trlda_model::LaneRange{};
+    }
+    if (m->timing && !m->lane_span_open[p]) {        // (the first call of a stretch on this lane)
+        lane_spans_collect(m);
+        for (int q = 0; q < 2 && !m->lane_span[p][q]; ++q)
+            HIP_TRY(hipEventCreate(&m->lane_span[p][q]));
+        HIP_TRY(hipEventRecord(m->lane_span[p][0], l->stream));
+        m->lane_span_open[p] = true;
+        m->lane_span_launches[p] = 0;
+    }
+    if (m->lane_span_open[p])
+        ++m->lane_span_launches[p];
+    m->lanes_live = true;
+    EstepOut out(sstats_dev);
+    rc = estep_device(l, b, gamma_dev, out, max_iter, threshold, iters_dev, gamma0_dev,
+                      n_upcoming > 1 ? upcoming[1] : nullptr);
+    if (rc) {                                        // a refused call leaves nothing outstanding
+        (void)lanes_join(m);
+        return rc;
+    }
+    {
+        trlda_model::LaneRange *w = m->lane_writes[p] + 4 * (m->lane_calls[p] & 1);
+        const char *g = reinterpret_cast<const char *>(gamma_dev), *s = reinterpret_cast<const char *>(sstats_dev),
+                   *it = reinterpret_cast<const char *>(iters_dev);
+        w[0] = {g, g + g_bytes};
+        w[1] = {s, s + s_bytes};
+        w[2] = it ? trlda_model::LaneRange{it, it + i_bytes} : trlda_model::LaneRange{};
+        ++m->lane_calls[p];
+    }
+    m->lane_turn = 1 - p;
+    ++m->lane_steps;
+    m->last_deferred = l->last_deferred; m->last_carried = l->last_carried;
+    m->last_doc_kernel = l->last_doc_kernel; m->last_preamble_fused = l->last_preamble_fused;
+    m->last_split_wgs = l->last_split_wgs; m->last_merged = l->last_merged;
+    return TRLDA_OK;
 }
 
 int trlda_model_set_prefetch(trlda_model *m, int enabled)
@@ -5193,6 +5516,26 @@ int trlda_model_set_timing(trlda_model *m, int enabled)
         m->usec_sum[i] = 0;
         m->usec_cnt[i] = 0;
     }
+    if (m->lanes_live)
+        (void)lanes_join(m);
+    lane_spans_collect(m);
+    m->lane_span_us = 0.0;
+    m->lane_span_count = 0;
+    return TRLDA_OK;
+}
+
+// E-steps that went through the lanes while timing was on: the mean duration of their launches
+// (a lane's launches run back to back; two lanes' overlap)
+int trlda_model_get_lane_timing(trlda_model *m, double *usec_sum, int64_t *launches)
+{
+    if (!m || !usec_sum || !launches)
+        return fail(TRLDA_ERR_ARG, "bad timing query");
+    int rc = check_model(m);                         // (joins: the spans end)
+    if (rc)
+        return rc;
+    lane_spans_collect(m);
+    *usec_sum = m->lane_span_us;
+    *launches = m->lane_span_count;
     return TRLDA_OK;
 }
 
