@@ -183,7 +183,12 @@ def main(argv=None):
         assert len(a) == len(b)
         for n, (x, y) in enumerate(zip(a, b)):
             for q in range(3):
-                assert np.array_equal(x[q], y[q]), "case %d call %d output %d differs from the plain stream" % (case, n, q)
+                if not np.array_equal(x[q], y[q]):
+                    bad = np.argwhere(np.asarray(x[q]) != np.asarray(y[q]))
+                    raise AssertionError("case %d call %d output %d differs from the plain stream: K %d V %d Bs %s "
+                                         "max_iter %d batch %d; %d elements, first %s (%r against %r); script %s"
+                                         % (case, n, q, K, V, Bs, max_iter, x[3], len(bad), bad[:3].tolist(),
+                                            np.asarray(x[q])[tuple(bad[0])], np.asarray(y[q])[tuple(bad[0])], script))
             assert not np.isnan(x[1]).any(), "case %d call %d: statistics never written" % (case, n)
             if n % 3 == 0 and Bs[x[3]] > 0:
                 ip, ids, cnts = raw[x[3]]

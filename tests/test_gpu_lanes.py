@@ -176,6 +176,14 @@ def test_what_joins_the_lanes(hip, oracle, sampler):
     assert through == 7
     m.update_parameters(dev[3], max_iter_tr=2, max_iter_inference=20)      # an update joins, lambda moves
     lam3 = np.asfortranarray(m.lambdas)
+    # (the update's kernels left lambda's row sums behind and E-steps on that lambda use them -- one
+    # lane; lambda set anew: two again)
+    ahead(hip, m, devs, slots, 7)
+    assert hip.trlda_model_lane_steps(m._handle) == through
+    _ffi.check(hip.trlda_model_synchronize(m._handle))
+    check(slots[7], lam3, 3)
+    slots[7].poison()
+    m.lambdas = lam3
     check(slots[5], lam2, 1)
     check(slots[6], lam2, 2)
     ahead(hip, m, devs, slots, 7)
@@ -190,6 +198,8 @@ def test_what_joins_the_lanes(hip, oracle, sampler):
                                               20, 1e-3, sx.ptrs[3]))
     bx.close()
     ahead(hip, m, devs, slots, 9)
+    # (call 7 again into the arrays of the call before it: one lane, by the rule for shared arrays)
+    assert hip.trlda_model_lane_steps(m._handle) == through + 3
     m.close()                                                  # both lanes busy
     _ffi.check(hip.trlda_dev_synchronize(0))
     check(slots[7], lam3, 3)

@@ -3546,9 +3546,13 @@ namespace {
 
 // what a stream lane may take: exactly the calls whose statistics can wait for the lane's next one
 // (estep_device: launch_ok && defer_self), on a model that holds nothing a lane could not see
+// (row sums an M-step kernel left behind, rowsums_carried: the model's own E-steps use them -- other
+// sums than a lane would form from lambda, an ulp apart -- and prepare nothing ahead: no lanes until
+// lambda is set anew, so that a stream through the lanes stays bitwise the one-lane stream)
 bool lane_takes(const trlda_model *m, const trlda_batch *b)
 {
     return m->lanes_wanted >= 2 && m->deferred_stats && !m->dp && !m->eb.active && m->prefetch_next &&
+           !rowsums_carried(m) &&
            m->sstats_mode == TRLDA_SSTATS_SEGMENTED && b->B > 0 && b->V == m->V && b->device == m->device &&
            fused_preamble_possible(m, b) && m->rs_floor >= kFusedRowsumFloor && fused_update_available(m) &&
            m->K % 2 == 0 && m->pair_gathers && b->long_len == trlda::kLongWord && b->B <= 256 &&
