@@ -33,6 +33,9 @@ def main():
     ap.add_argument("--no-deferred", action="store_true",
                     help="every step launches its statistics kernel (rounds 1-4) instead of leaving them "
                          "to the next step's document launch (trlda_model_set_deferred_stats)")
+    ap.add_argument("--lanes", type=int, default=2, choices=(1, 2),
+                    help="two E-steps in flight (trlda_model_set_stream_lanes, the bench's default): the "
+                         "long document's tail runs under the next step's documents; 1: one launch at a time")
     args = ap.parse_args()
     import torch
     from trlda_amd import _ffi
@@ -56,9 +59,12 @@ def main():
     g0 = np.empty((K, B), order="F")
     L.trlda_sample_gamma_init(K, B, g0)
     gamma0 = torch.from_numpy(np.ascontiguousarray(g0.T)).to(dev)
-    gamma = torch.empty(B * K, dtype=torch.float64, device=dev)
-    sstats = torch.empty(K * V, dtype=torch.float64, device=dev)
-    print("K=%d V=%d B=%d, %d steps per point; us per E-step (documents kernel name)" % (K, V, B, args.steps))
+    _ffi.check(L.trlda_model_set_stream_lanes(model, 1 if args.no_deferred else args.lanes))
+    outs = [(torch.empty(B * K, dtype=torch.float64, device=dev), torch.empty(K * V, dtype=torch.float64, device=dev))
+            for _ in range(2)]
+    up = (C.c_void_p * 2)()
+    print("K=%d V=%d B=%d, %d steps per point, %d lane(s); us per E-step (documents kernel name)"
+          % (K, V, B, args.steps, 1 if args.no_deferred else args.lanes))
     for series in args.series.split(","):
         for n in [int(x) for x in args.lengths.split(",")]:
             if n > V:
@@ -68,8 +74,11 @@ def main():
                        for i in range(4)]
 
             def step(i):
-                _ffi.check(L.trlda_model_estep_io_next(
-                    model, batches[i % 4].handle, batches[(i + 1) % 4].handle, gamma0.data_ptr(),
+                up[0] = batches[(i + 1) % 4].handle.value
+                up[1] = batches[(i + 2) % 4].handle.value
+                gamma, sstats = outs[i & 1]
+                _ffi.check(L.trlda_model_estep_io_ahead(
+                    model, batches[i % 4].handle, up, 2, gamma0.data_ptr(),
                     gamma.data_ptr(), sstats.data_ptr(), 20, 0., None))
             for i in range(10):
                 step(i)

@@ -14,7 +14,8 @@
 #   stamps     cycle stamps inside the document kernel (per variant), the deferred launch's timeline,
 #              the merged launch's stamps, timelines of an update call and of the bench
 #   lengths    tools/length_sweep.py, the reference's test_speed workload, log-normal / uniform bench
-#   deferred   the headline with and without deferred statistics / prefetch; helper counts
+#   deferred   the headline with one and two lanes, without deferred statistics / prefetch; helper counts;
+#              the two-stream probes
 #   probes     graph probe, any-order probe, xcu probe (stand-alone HIP programs under tools/probes)
 #   fuzz       the four fuzzers at a few seeds each (long: ~15 min)
 #   core       check headline pmc configs updates dp stamps lengths deferred
@@ -45,14 +46,23 @@ import json; j=json.loads(open('$o/${tag}_bench.json').read()); print('200 steps
 }
 
 t_headline() {
+  # the default command: two stream lanes, launches overlap (a launch's duration is about twice the
+  # device time per launch); then one launch at a time
   tools/prof_stats.sh ${tag} --steps 200 --warmup 20 > /dev/null
-  cut -c1-160 $o/${tag}_kernel_stats.csv | head -8
+  tools/prof_stats.sh ${tag}_one_lane --lanes 1 --steps 200 --warmup 20 > /dev/null
+  cut -c1-160 $o/${tag}_kernel_stats.csv | head -6
+  cut -c1-160 $o/${tag}_one_lane_kernel_stats.csv | head -6
+  # ... and how the launches of the two lanes lie in time (kernel trace of a short run)
+  rm -rf $o/${tag}_ltl; mkdir -p $o/${tag}_ltl
+  STEPS=20 rocprofv3 --kernel-trace --output-format csv -d $o/${tag}_ltl -- python3 tools/probes/lanes_dbg.py plain > /dev/null 2>&1
+  python3 tools/probes/lanes_timeline.py $o/${tag}_ltl > $o/${tag}_lanes_timeline.txt 2>&1
+  rm -rf $o/${tag}_ltl
 }
 
 t_pmc() {
-  tools/prof_pmc.sh ${tag}_fetch "FETCH_SIZE" --steps 50 --warmup 5 > $o/${tag}_pmc_fetch.txt
-  tools/prof_pmc.sh ${tag}_write "WRITE_SIZE" --steps 50 --warmup 5 > $o/${tag}_pmc_write.txt
-  tools/prof_pmc.sh ${tag}_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY" --steps 50 --warmup 5 > $o/${tag}_pmc_sq.txt
+  tools/prof_pmc.sh ${tag}_fetch "FETCH_SIZE" --lanes 1 --steps 50 --warmup 5 > $o/${tag}_pmc_fetch.txt
+  tools/prof_pmc.sh ${tag}_write "WRITE_SIZE" --lanes 1 --steps 50 --warmup 5 > $o/${tag}_pmc_write.txt
+  tools/prof_pmc.sh ${tag}_sq "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_ANY" --lanes 1 --steps 50 --warmup 5 > $o/${tag}_pmc_sq.txt
   # the dominant launch: documents + next preamble + previous statistics (estep_merged.h, deferred)
   python3 tools/make_traffic.py $o/${tag}_pmc_fetch.txt $o/${tag}_pmc_write.txt estep_docs_reg_deferred_kernel,estep_docs_tiered_deferred_kernel ${commit} > $o/${tag}_traffic.json
   cat $o/${tag}_pmc_fetch.txt $o/${tag}_pmc_write.txt
@@ -112,6 +122,7 @@ t_stamps() {
 
 t_lengths() {
   python3 tools/length_sweep.py 2>&1 | clean > $o/${tag}_length_sweep.txt
+  python3 tools/length_sweep.py --lanes 1 --lengths 100,128,129,144,145,192,193,400,600 2>&1 | clean > $o/${tag}_length_sweep_one_lane.txt
   python3 tools/length_sweep.py --no-deferred --lengths 100,128,129,144,145,192,193,400 2>&1 | clean > $o/${tag}_length_sweep_no_deferred.txt
   python3 tools/speed_workload.py 2>&1 | clean > $o/${tag}_speed_workload.txt
   for a in "--lengths lognormal" "--uniform"; do
@@ -125,14 +136,18 @@ for n in ('lengthslognormal', 'uniform'):
 }
 
 t_deferred() {
-  ( for a in "" "--no-deferred" "--no-prefetch"; do
+  ( for a in "" "--lanes 1" "--lanes 1 --no-deferred" "--no-prefetch"; do
       benchline --steps 200 --warmup 20 --headline-only $a | python3 -c "
 import sys,json; j=json.loads(sys.stdin.read()); print('bench $a:', j['ms_per_step'], j['value'], list(j['roofline']['kernels_us'].values()))"
     done
-    for h in 56 128; do
+    for h in 40 56 128; do
       TRLDA_DEFER_HELPERS=$h benchline --steps 200 --warmup 20 --headline-only | python3 -c "
 import sys,json; j=json.loads(sys.stdin.read()); print('helper workgroups capped at $h:', j['ms_per_step'])"
-    done ) 2>&1 | tee $o/${tag}_deferred_ab.txt
+    done
+    TRLDA_LANE_PRIORITY=0 benchline --steps 200 --warmup 20 --headline-only | python3 -c "
+import sys,json; j=json.loads(sys.stdin.read()); print('lanes on streams of the default priority:', j['ms_per_step'])"
+    python3 tools/probes/two_streams.py 2>&1 | grep -v amdgpu.ids
+    python3 tools/probes/two_streams_modes.py 2>&1 | grep -v amdgpu.ids ) 2>&1 | tee $o/${tag}_deferred_ab.txt
 }
 
 t_probes() {
