@@ -8,5 +8,5 @@ rm -rf $out; mkdir -p $out
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --no-cpu-baseline --no-update-rates --headline-only "$@" > $out/bench.log 2>&1
 f=$(find $out -name '*kernel_stats.csv' | head -1)
 cp "$f" gpurun_out/${tag}_kernel_stats.csv 2>/dev/null
-tail -1 $out/bench.log > gpurun_out/${tag}_bench.json
+grep "^{\"metric\"" $out/bench.log | tail -1 > gpurun_out/${tag}_bench.json
 cat gpurun_out/${tag}_kernel_stats.csv
