@@ -1114,6 +1114,17 @@ __device__ __forceinline__ void fmac_row_bcast(double &acc, double vals, double 
     else
         asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(vals), "v"(b), "n"(N));
 }
+// The weights tw_j of product B formed by the wave that consumes them, from product E's partials (no
+// LDS round trip, one barrier fewer per iteration): measured and NOT adopted -- in the plain register
+// kernel a document goes from 67.5 k to 65.8 k cycles, inside the deferred and merged launches (other
+// register allocation, all eight waves on the LDS pipe at once) from 27.2 to 27.5 us; same box:
+// two lanes 26.8 = 26.8 us per step, one lane 31.55 against 31.26, update_parameters(TR 10) 0.465
+// against 0.458 ms, B = 1600 2.09 against 2.11 (profiles/r05_wave_weights_ab.txt).  -DTRLDA_WAVE_WEIGHTS
+#ifdef TRLDA_WAVE_WEIGHTS
+constexpr bool kWaveWeights = true;                  // (estep_docs_reg_body, wave_weights)
+#else
+constexpr bool kWaveWeights = false;                 // a thread per word, through LDS and a barrier
+#endif
 #ifndef TRLDA_NO_DPP_BCAST
 constexpr bool kDppBcast = true;
 #else
@@ -1351,8 +1362,12 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
         }
     }
     TRLDA_STAMP(1);
+    // (kWaveWeights: the partial sums of product B live in the transposition buffer, which is free
+    // from here on -- the waves of product B read product E's partials while others already write
+    // their own)
+    double *partB = kWaveWeights ? tbuf : part;      // 8 x 192
 
-    // phinorm_j = sum_k e_k beta[j][k] ; tw_j = cnt_j / phinorm_j     lda.cpp:183 / :199
+    // phinorm_j = sum_k e_k beta[j][k]: its eight partials per word     lda.cpp:183 / :199
     auto product_E = [&](const double *e) {
         // k0 is even and e is 16-byte aligned: one ds_read_b128 broadcasts two weights.  All
         // eight reads are issued before the first fma and nothing is branched over: weights
@@ -1418,9 +1433,21 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
                 part[wid * kRegPart + 128 + lane] = s2;
         }
         __syncthreads();
-        if (tid < 128 || tid < n)                    // 0 beyond n (cnt is 0 there)
-            tw[tid] = cntd[tid] * rcp_pos<true>(sum8_strided<kRegPart>(part + tid) + 1e-100);
-        __syncthreads();
+        if constexpr (!kWaveWeights) {
+            if (tid < 128 || tid < n)
+                tw[tid] = cntd[tid] * rcp_pos<true>(sum8_strided<kRegPart>(part + tid) + 1e-100);
+            __syncthreads();
+        }
+    };
+    // tw_j = cnt_j / phinorm_j for the words of THIS wave's product B (lane l: word j0 + (l & 15), or
+    // j0 + min(l, 17) in the 144-word variant): read back from LDS, where one thread per word has left
+    // them behind a barrier -- or (kWaveWeights, not adopted) formed by the consuming wave from the
+    // eight partials with the same additions, reciprocal and product.  0 beyond n (cnt is 0).
+    auto wave_weights = [&]() {
+        const int jl = j0 + (MID ? min(lane, JC - 1) : (lane & 15));
+        if constexpr (!kWaveWeights)
+            return tw[jl];
+        return cntd[jl] * rcp_pos<true>(sum8_strided<kRegPart>(part + jl) + 1e-100);
     };
 
     product_E(ebuf);
@@ -1439,8 +1466,9 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
             double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
             // (the 144-word variant keeps its broadcast reads here: with the DPP form the tiered kernels,
             // at the register limit, spilled and this stage went from 840 to 939 cycles)
+            const double tvals_w = wave_weights();
             if constexpr (kDppBcast && !MID) {
-                const double tvals = tw[j0 + (lane & 15)];
+                const double tvals = tvals_w;
                 [[maybe_unused]] double tvals2 = 0.0;
                 if constexpr (MID)
                     tvals2 = tw[j0 + 16 + (lane & 1)];           // words 16, 17 of the wave
@@ -1459,6 +1487,13 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
                     fmac_row_bcast<1>(a1[1], tvals2, bB1[17]);
                 }
             } else {
+                if constexpr (kWaveWeights) {
+                    // (the wave's own words through LDS: one wave's LDS traffic is in order, no barrier)
+                    if (lane < JC)
+                        tw[j0 + lane] = tvals_w;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
                 const double2 *tp = reinterpret_cast<const double2 *>(tw + j0);
                 double2 tv[JC / 2];
 #pragma unroll
@@ -1472,8 +1507,8 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
                     a1[(2 * i + 1) & 3] = fma(tv[i].y, bB1[2 * i + 1], a1[(2 * i + 1) & 3]);
                 }
             }
-            part[wid * kRegPart + lane] = (a0[0] + a0[1]) + (a0[2] + a0[3]);
-            part[wid * kRegPart + 64 + lane] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+            partB[wid * kRegPart + lane] = (a0[0] + a0[1]) + (a0[2] + a0[3]);
+            partB[wid * kRegPart + 64 + lane] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
         }
         __syncthreads();
         TRLDA_STAMP(3);
@@ -1489,7 +1524,7 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
             // (keeping the lane's own e_k / alpha_k in registers across iterations instead of these two
             // LDS reads was measured: no gain, and the tiered kernels, at the register limit, spilled)
             const double ek = e_old[kk], ak = alpha_l[kk];
-            double acc = sum8_strided<kRegPart>(part + kk);
+            double acc = sum8_strided<kRegPart>(partB + kk);
             if constexpr (SPLIT) {
                 // this segment's row out, every segment's row in (segment order)
                 double *rows = a.xbuf + ((size_t)seg.z * (size_t)(a.max_iter + 1) +
@@ -1569,7 +1604,7 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
             const int kc = (wid - (W - 2)) * 64 + lane;
             const bool on = kc < K;
             const int ka = on ? kc : 0;
-            const double ga = sum8_strided<kRegPart>(part + ka) * e_old[ka] + alpha_l[ka];
+            const double ga = sum8_strided<kRegPart>(partB + ka) * e_old[ka] + alpha_l[ka];
             const double v = on ? fabs(g_old[ka] - ga) : 0.0;
             const double half = wave_sum_dpp(v);
             if (lane == 0)
@@ -1594,6 +1629,12 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
             break;
     }
     const double *g = gbuf + (it & 1) * 128, *e = ebuf + (it & 1) * 144;
+    // the weights that go with the last phinorm (every product E ends with a barrier)
+    if constexpr (kWaveWeights) {
+        if (tid < 128 || tid < n)                    // 0 beyond n (cnt is 0 there)
+            tw[tid] = cntd[tid] * rcp_pos<true>(sum8_strided<kRegPart>(part + tid) + 1e-100);
+        __syncthreads();
+    }
 
     // results (a split document's gamma by its first segment; every segment holds the same)
     if (!SPLIT || seg.x == 0) {

@@ -3653,6 +3653,25 @@ int trlda_model_set_stream_lanes(trlda_model *m, int lanes)
 
 long long trlda_model_lane_steps(const trlda_model *m) { return m ? (long long)m->lane_steps : 0; }
 
+namespace {
+// TRLDA_LANE_TRACE=1: host time of the phases of the first calls after a join (stderr)
+struct LaneTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    double us[6] = {0, 0, 0, 0, 0, 0};
+    int n = 0;
+    explicit LaneTrace(bool enabled) : on(enabled) { if (on) t0 = std::chrono::steady_clock::now(); }
+    void mark()
+    {
+        if (!on || n >= 6)
+            return;
+        const auto t = std::chrono::steady_clock::now();
+        us[n++] = std::chrono::duration<double, std::micro>(t - t0).count();
+        t0 = t;
+    }
+};
+}  // namespace
+
 int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda_batch *const *upcoming,
                                int n_upcoming, const double *gamma0_dev, double *gamma_dev,
                                double *sstats_dev, int max_iter, double threshold, int32_t *iters_dev)
@@ -3687,6 +3706,8 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
     if (chained || !lane_takes(m, b))
         return trlda_model_estep_io_next(m, b, next, gamma0_dev, gamma_dev, sstats_dev, max_iter,
                                          threshold, iters_dev);
+    static const bool trace_on = std::getenv("TRLDA_LANE_TRACE") != nullptr;
+    LaneTrace tr(trace_on && m->lane_calls[0] + m->lane_calls[1] < 3);
     // (statistics this model itself holds pending go first; what the lanes hold stays)
     int rc = check_model(m, false, true);
     if (!rc)
@@ -3696,6 +3717,7 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
     const int p = m->lane_turn;
     trlda_model *l = m->lane[p], *o = m->lane[1 - p];
     lane_follow(m, l);
+    tr.mark();
     // whatever the caller enqueued on the model's stream so far -- this call's gamma0, the last
     // reader of the arrays it writes, an upload of lambda -- comes first (nothing of the lanes is
     // on that stream: the record passes as soon as the caller's own work has)
@@ -3716,6 +3738,7 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
     }
     // the OTHER lane's outstanding launches write arrays this call reads or writes (a caller that
     // hands the same gamma / sstats to consecutive calls): they go first -- correct, and serial
+    tr.mark();
     if (meets_any(m->lane_writes[1 - p], 8)) {
         if ((rc = flush_pending(o)))
             return rc;
@@ -3738,6 +3761,10 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
     EstepOut out(sstats_dev);
     rc = estep_device(l, b, gamma_dev, out, max_iter, threshold, iters_dev, gamma0_dev,
                       n_upcoming > 1 ? upcoming[1] : nullptr);
+    tr.mark();
+    if (tr.on)
+        std::fprintf(stderr, "lane %d call %d of the stretch: set-up %.1f us, caller's stream %.1f us, "
+                             "launch sequence %.1f us\n", p, m->lane_calls[p], tr.us[0], tr.us[1], tr.us[2]);
     if (rc) {                                        // a refused call leaves nothing outstanding
         (void)lanes_join(m);
         return rc;
