@@ -827,11 +827,12 @@ def main():
     _ffi.check(L.trlda_model_set_timing(model, 0))
 
     # executed iterations per document, every batch: mean, and the fp64 work of the document
-    # kernel, sum_d I_d (4 K n_d + c_psi K) with c_psi = 106 fp64 operations per exp(psi) as
-    # implemented (two Horner chains of nine fmas, one reciprocal, the seven-term series, exp;
+    # kernel, sum_d I_d (4 K n_d + c_psi K) with c_psi = 91 fp64 operations per exp(psi) as
+    # implemented (the two chains of the rational part in u = x (x + 9): 13 instructions, one reciprocal, the
+    # seven-term series, exp; the chains in x of rounds 2-5a: 106;
     # a fused multiply-add counted as two: the five-reciprocal-pair form of round 1 was 140)
     # (csrc/psi.h; SURVEY.md 8d's secondary figure) plus the first phinorm (2 K n_d)
-    C_PSI = 106.
+    C_PSI = 91.
     doc_flops, iter_sum = [], 0.
     for j in range(args.num_batches):
         step(j, want_iters=True)
@@ -947,7 +948,7 @@ def main():
                  "achieved": round(doc_flops / (docs_us * 1e-6) / 1e12, 3) if docs_us > 0 else 0.0,
                  "frac": round(doc_flops / (docs_us * 1e-6) / 1e12 / FP64_PEAK_TFLOPS, 5)
                  if docs_us > 0 else 0.0,
-                 "model": "sum_d I_d (4 K n_d + 106 K) + 2 K n_d + 106 K"},
+                 "model": "sum_d I_d (4 K n_d + 91 K) + 2 K n_d + 91 K"},
         "estep": {   # the whole path against SURVEY.md 8(d)'s bytes_alg
             "algorithmic_bytes_per_step": estep_bytes,
             "achieved": round(estep_bytes * args.steps / elapsed / 1e9, 2),

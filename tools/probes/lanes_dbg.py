@@ -12,6 +12,8 @@ L.trlda_seed(1)
 lam = np.empty((K, V), order="F"); L.trlda_sample_gamma_init(K, V, lam)
 variant = sys.argv[1]
 m = _ffi.vp(); _ffi.check(L.trlda_model_create(C.byref(m), 0, K, V))
+if os.environ.get("OWN_STREAM"):                     # a stream of torch's pool instead of the null stream
+    torch.cuda.set_stream(torch.cuda.Stream(device))
 _ffi.check(L.trlda_model_set_stream(m, _ffi.vp(torch.cuda.current_stream(device).cuda_stream)))
 _ffi.check(L.trlda_model_set_lambda(m, lam)); _ffi.check(L.trlda_model_set_alpha(m, np.full(K, .1)))
 if variant == "benchlike":

@@ -1467,8 +1467,13 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
             // (the 144-word variant keeps its broadcast reads here: with the DPP form the tiered kernels,
             // at the register limit, spilled and this stage went from 840 to 939 cycles)
             const double tvals_w = wave_weights();
-            if constexpr (kDppBcast && !MID) {
-                const double tvals = tvals_w;
+#ifdef TRLDA_M1_DPP_B
+            constexpr bool dpp_b = kDppBcast;        // (A/B: also in the 144-word variant)
+#else
+            constexpr bool dpp_b = kDppBcast && !MID;
+#endif
+            if constexpr (dpp_b) {
+                const double tvals = MID ? tw[j0 + min(lane & 15, JC - 1)] : tvals_w;
                 [[maybe_unused]] double tvals2 = 0.0;
                 if constexpr (MID)
                     tvals2 = tw[j0 + 16 + (lane & 1)];           // words 16, 17 of the wave
@@ -1984,7 +1989,7 @@ __device__ __forceinline__ double update_one(const UpdateOut &o, size_t i, doubl
         lam = o.lambda_prime ? o.omr * o.lambda_prime[i] + o.rho * hat : o.rho * hat;
         o.lambda[i] = lam;
         if (EMIT && o.u_out)                         // (lam > 0: the host only asks for u_out then)
-            o.u_out[i] = exp_digamma_positive(lam);
+            o.u_out[i] = exp_digamma_positive<true>(lam);
     }
     return lam;
 }
@@ -2287,10 +2292,10 @@ __device__ __forceinline__ double2 update_pair(const UpdateOut &o, size_t i, dou
             // the two chains side by side need ~100 VGPRs, and above 64 a CU holds ONE 1024-thread
             // workgroup of this kernel instead of two -- the launch then runs in two rounds (15.4 us
             // against 8.2 us without this stream in round 3)
-            const double ux = exp_digamma_positive(lam.x);
+            const double ux = exp_digamma_positive<true>(lam.x);
             double ly = lam.y;
             asm volatile("" : "+v"(ly) : "v"(ux));
-            *reinterpret_cast<double2 *>(o.u_out + i) = make_double2(ux, exp_digamma_positive(ly));
+            *reinterpret_cast<double2 *>(o.u_out + i) = make_double2(ux, exp_digamma_positive<true>(ly));
         }
     }
     return lam;

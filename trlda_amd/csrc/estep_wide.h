@@ -63,6 +63,9 @@ struct wide_cfg {
 #else
     static constexpr bool SC = KS >= 5;
 #endif
+    // exp(psi)'s rational part by Horner's rule in x (psi.h, exp_psi_regular<.., XF>): the widest
+    // variant spills four registers with the shorter form in u = x (x + 9)
+    static constexpr bool XF = KS >= 8;
 };
 
 // LDS carve (doubles): part[8][KP] | ebuf[2][KP] | cbuf[KP] (topic factors, FACTORS at K > 128) |
@@ -342,7 +345,7 @@ __device__ __forceinline__ void estep_docs_wide_body(const DocKernelArgs &a, int
     // gamma / alpha / exp(psi(gamma)) of topic tid                       lda.cpp:174
     double ek = 0.0;
     if (tid < KP) {
-        const double e0 = exp_digamma<cfg::SC>(gk);
+        const double e0 = exp_digamma<cfg::SC, cfg::XF>(gk);
         ek = k_on ? e0 : 0.0;
         ebuf[tid] = ek;                              // zero beyond K
     }
@@ -555,7 +558,7 @@ __device__ __forceinline__ void estep_docs_wide_body(const DocKernelArgs &a, int
             const double gnew = k_on ? fma(accs, ek, ak) : 1.5;
             [[maybe_unused]] const double diff = k_on ? fabs(gk - gnew) : 0.0;
             gk = gnew;
-            double enew = exp_digamma<cfg::SC>(gnew);
+            double enew = exp_digamma<cfg::SC, cfg::XF>(gnew);
             if constexpr (FACTORS)
                 enew *= KS > 2 ? cbuf[tid] : ck;
             ek = k_on ? enew : 0.0;

@@ -199,7 +199,7 @@ __device__ __forceinline__ double rcp_pair(double a)
 // For x > 0 every coefficient of P and P' (Stirling numbers of the first kind, exact in fp64)
 // and every Horner step is positive -- no cancellation: the quotient is within ~3 ulp of the
 // exact sum, like the five reciprocal pairs it replaces (rcp_pair, kept for the rare branch) --
-// and it is 23 instructions shorter: two Horner chains of nine fmas and ONE reciprocal,
+// and it is 23 instructions shorter: two Horner chains (in u = x (x + 9) since round 5: another six) and ONE reciprocal,
 // 1 / (P s), which also yields 1/s = P / (P s).  The stage that evaluates this is bound by
 // the instruction count of a single wave (~8.6 cycles per fp64 instruction).
 // Needs x^11 finite: callers keep x below 1e25.
@@ -285,28 +285,57 @@ __device__ __forceinline__ double psi_series_horner(double z)
     return fma3s(p, z, 8.33333333333333333333E-2);
 }
 
-template <bool ZERO_C = false, bool SC = false>
+// XF: Horner's rule in x (rounds 2-5a) -- for the one kernel that spills with the shorter form, the
+// single-orientation document kernel at K > 448 (4 registers, 2.79 against 2.65 ms per
+// update_parameters call at K = 500 / 512 documents)
+template <bool ZERO_C = false, bool SC = false, bool XF = false>
 __device__ __forceinline__ double exp_psi_regular(double x, double c)
 {
-    double q = x + 45.0;
-    q = fma(q, x, 870.0);
-    q = fma(q, x, 9450.0);
-    q = fma(q, x, 63273.0);
-    q = fma(q, x, 269325.0);
-    q = fma(q, x, 723680.0);
-    q = fma(q, x, 1172700.0);
-    q = fma(q, x, 1026576.0);
-    q = fma(q, x, 362880.0);
-    const double P = q * x;
-    double dP = fma3s(10.0, x, 405.0);
-    dP = fma(dP, x, 6960.0);
-    dP = fma(dP, x, 66150.0);
-    dP = fma(dP, x, 379638.0);
-    dP = fma(dP, x, 1346625.0);
-    dP = fma(dP, x, 2894720.0);
-    dP = fma(dP, x, 3518100.0);
-    dP = fma(dP, x, 2053152.0);
-    dP = fma(dP, x, 362880.0);
+    double P, dP;
+#ifdef TRLDA_PSI_HORNER_X                            // (A/B: everywhere)
+    constexpr bool in_x = true;
+#else
+    constexpr bool in_x = XF;
+#endif
+    if constexpr (in_x) {
+        double q = x + 45.0;
+        q = fma(q, x, 870.0);
+        q = fma(q, x, 9450.0);
+        q = fma(q, x, 63273.0);
+        q = fma(q, x, 269325.0);
+        q = fma(q, x, 723680.0);
+        q = fma(q, x, 1172700.0);
+        q = fma(q, x, 1026576.0);
+        q = fma(q, x, 362880.0);
+        P = q * x;
+        dP = fma3s(10.0, x, 405.0);
+        dP = fma(dP, x, 6960.0);
+        dP = fma(dP, x, 66150.0);
+        dP = fma(dP, x, 379638.0);
+        dP = fma(dP, x, 1346625.0);
+        dP = fma(dP, x, 2894720.0);
+        dP = fma(dP, x, 3518100.0);
+        dP = fma(dP, x, 2053152.0);
+        dP = fma(dP, x, 362880.0);
+    } else {
+        // The factors pair up, (x + i)(x + 9 - i) = u + i (9 - i) with u = x (x + 9):
+        //   P = u (u + 8)(u + 14)(u + 18)(u + 20) = u^5 + 60 u^4 + 1308 u^3 + 12176 u^2 + 40320 u,
+        //   P' = dP/du (2x + 9)
+        // -- thirteen instructions for the two where Horner's rule in x takes nineteen; every coefficient
+        // and every step is positive for x > 0 as before (P'/P against the exact sum in binary128 over
+        // 1e-10 .. 1e4: 8.5e-16 relative at worst, the form in x 1.0e-15; tools/probes/psi_u_form.c)
+        const double u = x * (x + 9.0);
+        double q = u + 60.0;
+        q = fma(q, u, 1308.0);
+        q = fma(q, u, 12176.0);
+        q = fma(q, u, 40320.0);
+        P = q * u;
+        dP = fma3s(5.0, u, 240.0);
+        dP = fma(dP, u, 3924.0);
+        dP = fma(dP, u, 24352.0);
+        dP = fma(dP, u, 40320.0);
+        dP *= fma(2.0, x, 9.0);
+    }
     const double s = x + 10.0;
     const double inv = rcp_pos<true>(P * s);
     const double r = P * inv;                        // 1 / s
@@ -364,10 +393,10 @@ __device__ __forceinline__ double exp_digamma_minus(double x, double c)
 }
 
 // c = 0 (the document kernels, the fused preamble): the same with the short exponential
-template <bool SC = false>
+template <bool SC = false, bool XF = false>
 __device__ __forceinline__ double exp_digamma(double x)
 {
-    const double v = exp_psi_regular<true, SC>(x, 0.0);
+    const double v = exp_psi_regular<true, SC, XF>(x, 0.0);
     // (the integers 1 .. 10, where the reference takes the exact harmonic sum, src/digamma.cpp:147-156,
     // go through the regular form here as in exp_digamma_positive: psi(n) to a few ulp either way,
     // 2e-15 apart at most -- and three instructions fewer in the psi waves' stream: 0.2 us of the
@@ -394,13 +423,16 @@ __device__ __forceinline__ double exp_digamma(double x)
 //                    tests/test_gpu_parity.py::test_device_digamma_table)
 //   x >= 1e25        exp(psi(x)) = x - 1/2 + O(1/x) = x in fp64 (inf stays inf)
 //   NaN              NaN
+// XF: Horner's rule in x, as exp_psi_regular -- the stand-alone statistics kernels (at their register
+// caps the shorter form spills more, and K = 500's update calls were 2-5 % slower with it)
+template <bool XF = false>
 __device__ __forceinline__ double exp_digamma_positive(double x)
 {
 #ifdef TRLDA_EXPT_NOEXP                              // timing experiment: results are wrong
     return x;
 #endif
     const bool tiny = x < 1e-290, big = !(x < 1e25);
-    double v = exp_psi_regular<true>((tiny || big) ? 1.5 : x, 0.0);
+    double v = exp_psi_regular<true, false, XF>((tiny || big) ? 1.5 : x, 0.0);
     v = tiny ? 0.0 : v;
     return big ? x : v;
 }

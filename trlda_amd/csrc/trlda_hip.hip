@@ -749,7 +749,13 @@ int draw_gamma_ahead(trlda_model *m, long long total, long long lo, long long hi
         // (confining this stream to the ~50 CUs a 200-document launch leaves idle -- a document
         // workgroup needs a whole CU -- was measured: the draw then takes 230 us instead of 44 and
         // the call 174 us instead of 84)
-        HIP_TRY(hipStreamCreateWithFlags(&m->draw_stream, hipStreamNonBlocking));
+        // (a priority of its own, TRLDA_DRAW_PRIORITY: the runtime hands a fifth stream of a priority a
+        // hardware queue that is in use -- lanes_ensure)
+        static const int prio = [] { const char *e = std::getenv("TRLDA_DRAW_PRIORITY"); return e ? std::atoi(e) : 0; }();
+        if (prio != 0)
+            HIP_TRY(hipStreamCreateWithPriority(&m->draw_stream, hipStreamNonBlocking, prio));
+        else
+            HIP_TRY(hipStreamCreateWithFlags(&m->draw_stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&m->ev_main, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&m->ev_draw, hipEventDisableTiming));
     }
