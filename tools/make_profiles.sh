@@ -40,7 +40,7 @@ print("driver bench:", j["value"], j["ms_per_step"], "fixed", j.get("value_fixed
 PY
     timeout 600 python bench.py --steps 200 --warmup 20 2>/dev/null | tail -1 > $o/${tag}_bench_200.json
     python3 -c "
-import json; j=json.loads(open("$o/${tag}_bench_200.json").read()); print('200 steps:', j['value'], j['ms_per_step'], j['roofline']['frac'], j['roofline']['kernels_us'], j['parity'])"
+import json; j=json.loads(open('$o/${tag}_bench_200.json').read()); print('200 steps:', j['value'], j['ms_per_step'], j['roofline']['frac'], j['roofline']['kernels_us'], j['parity'])"
     for sd in 1 2; do timeout 900 python tests/fuzz_lifecycle.py --steps 300 --seed $sd 2>&1 | tail -1; done
   ) 2>&1 | clean | tee $o/${tag}_final_check.txt
 }
