@@ -707,6 +707,9 @@ def main():
     # the timed region, `--repeats` times back to back: the median is the result (20 steps of
     # 40 us are under a millisecond -- one scheduling hiccup moves a single sample by 10 %)
     samples = sorted(timed() for _ in range(max(1, args.repeats)))
+    # (did the last launch of a timed region carry the statistics of an earlier step? -- asked here:
+    # the first launches after a fence never do)
+    carried_flag = bool(deferred and L.trlda_model_last_deferred(model) & 2)
     elapsed = samples[len(samples) // 2]
     docs_per_s = world * B * args.steps / elapsed
     repeats = {"n": len(samples), "value": "median",
@@ -790,6 +793,17 @@ def main():
         _ffi.check(L.trlda_model_set_lambda(model, lam))   # every rank back on the common lambda
 
     # ---- per-kernel durations: HIP events on the launch stream, same steps replayed -------
+    # (two lanes whose steps are several kernels -- shapes outside the deferred statistics' range --
+    # are replayed one launch at a time: per-kernel durations as rocprofv3 lists them for --lanes 1)
+    fence()
+    replay_one_lane = lanes[0] > 1 and not carried_flag
+    if replay_one_lane:
+        lanes[0] = 1
+        _ffi.check(L.trlda_model_set_stream_lanes(model, 1))
+        for i in range(4):
+            step(pos[0] + i)
+        pos[0] += 4
+        one_lane_s = sorted(timed() for _ in range(3))[1]
     _ffi.check(L.trlda_model_set_timing(model, 1))
     for i in range(args.steps):
         step(pos[0] + i)
@@ -806,12 +820,12 @@ def main():
     # events' share of every interval: taken out, so that the figures agree with rocprofv3's
     # kernel durations (profiles/*_kernel_stats.csv).
     event_pair_us = kernel_us.pop()
-    carried = bool(deferred and L.trlda_model_last_deferred(model) & 2)
+    carried = carried_flag
     if carried:
         # one launch per step: the other intervals hold no kernel (two event records back to back)
         kernel_us = [0.0, 0.0, kernel_us[2], 0.0]
     launches = [u for u in kernel_us if u > 0.5 * event_pair_us]
-    step_us = 1e6 * elapsed / args.steps
+    step_us = 1e6 * (one_lane_s if replay_one_lane else elapsed) / args.steps   # (of the replayed form)
     event_us = 0.0
     laned = bool(carried and lanes[0] > 1 and L.trlda_model_lane_steps(model) > 0)
     if not collective and launches and not laned:
@@ -825,6 +839,9 @@ def main():
         _ffi.check(L.trlda_model_get_lane_timing(model, C.byref(us), C.byref(cnt)))
         kernel_us = [0.0, 0.0, us.value / max(cnt.value, 1), 0.0]
     _ffi.check(L.trlda_model_set_timing(model, 0))
+    if replay_one_lane:
+        lanes[0] = args.lanes
+        _ffi.check(L.trlda_model_set_stream_lanes(model, lanes[0]))
 
     # executed iterations per document, every batch: mean, and the fp64 work of the document
     # kernel, sum_d I_d (4 K n_d + c_psi K) with c_psi = 91 fp64 operations per exp(psi) as
@@ -1097,8 +1114,8 @@ def main():
                                   "a kernel launch of its own every step"),
                    "in_flight": ("two E-steps at a time: the steps go in turn to two streams of the library's "
                                  "own (trlda_model_set_stream_lanes(2), trlda_model_estep_io_ahead); output "
-                                 "arrays alternate between two sets; joined by every fence" if laned else
-                                 "one E-step at a time"),
+                                 "arrays alternate between two sets; joined by every fence"
+                                 if (laned or replay_one_lane) else "one E-step at a time"),
                    "parallelism": "dp%d" % world,
                    "exchange_via": (("trlda_model_estep_dp (direct: peers' buffers through hipIpc, a step "
                                      "counter per source)" if exchange == "factors" and direct else

@@ -303,9 +303,12 @@ int trlda_model_last_deferred(const trlda_model *model);
  *   trlda_model_estep_io_ahead   trlda_model_estep_io_next with the batches of the following calls
  *       in order (upcoming[0] is the next call's, upcoming[1] the one after; n_upcoming may be 0):
  *       a lane prepares the preamble of ITS next call, which is two calls ahead.  Identical to
- *       trlda_model_estep_io_next(.., upcoming[0], ..) while lanes are off (the default), the
- *       call is outside the range of deferred statistics, or lambda was last written by an update
- *       call (whose kernels leave lambda's row sums behind: E-steps on that lambda use those).
+ *       trlda_model_estep_io_next(.., upcoming[0], ..) while lanes are off (the default) or
+ *       lambda was last written by an update call (whose kernels leave lambda's row sums behind:
+ *       E-steps on that lambda use those).  Any shape goes through the lanes: where deferred
+ *       statistics and announcements apply (or are switched on) a call is one launch, elsewhere
+ *       its preamble, document and statistics kernels -- whose tails and small launches then run
+ *       under the other lane's documents (K = 100, 1600 documents: 188 against 211 us per step).
  *   visibility   gamma, the iteration counts and the statistics of a call that went through a lane
  *       are complete on the model's stream after trlda_model_flush or ANY other call on the model
  *       that is not the next trlda_model_estep_io_ahead -- not after the call itself.  What the

@@ -341,18 +341,60 @@ def test_the_callers_stream_comes_first(hip, sampler):
 
 
 @pytest.mark.parametrize("K,V,B,why", [(101, 600, 50, "odd K"), (100, 3000, 300, "more than 256 documents"),
-                                       (200, 2000, 64, "K > 128")])
-def test_batches_a_lane_does_not_take(hip, sampler, K, V, B, why):
+                                       (200, 2000, 64, "K > 128"), (100, 7000, 1600, "config 3's batch")])
+def test_shapes_outside_the_deferred_range_go_through_the_lanes_too(hip, sampler, K, V, B, why):
+    """their steps are several kernels (preamble, documents, statistics) on the lane's stream, with
+    the deferred statistics switched on or off -- the results of the plain stream either way"""
     lam = seeded_lambda(sampler, 17, K, V)
     csrs = [corpus(B, V, seed=170 + i, mean_unique=min(80, V // 8)) for i in range(3)]
     g0s = [seeded_gamma(sampler, 175 + i, K, B) for i in range(3)]
     order = [0, 1, 2, 0, 1]
     ref, _ = run_stream(hip, K, V, lam, csrs, g0s, order, lanes=1, deferred=0, announce=0)
-    got, through = run_stream(hip, K, V, lam, csrs, g0s, order, lanes=2)
-    assert through == 0, why
-    for n in range(len(order)):
-        for q in range(3):
-            assert np.array_equal(got[n][q], ref[n][q]), (why, n, q)
+    for deferred in (1, 0):
+        got, through = run_stream(hip, K, V, lam, csrs, g0s, order, lanes=2, deferred=deferred)
+        assert through == len(order), why
+        for n in range(len(order)):
+            for q in range(3):
+                assert np.array_equal(got[n][q], ref[n][q]), (why, deferred, n, q)
+
+
+def test_atomic_statistics_and_a_dense_preamble_through_the_lanes(hip, sampler):
+    from trlda_amd import _ffi
+    K, V, B = 100, 2000, 120
+    lam = seeded_lambda(sampler, 23, K, V)
+    csrs = [corpus(B, V, seed=270 + i, mean_unique=60) for i in range(3)]
+    g0s = [seeded_gamma(sampler, 275 + i, K, B) for i in range(3)]
+    order = [0, 1, 2, 1]
+
+    def stream(lanes, mode, dense):
+        m = make_model(K, V, lam)
+        dev = [m.upload(c) for c in csrs]
+        slots = [Slots(hip, K, V, csrs[i], g0s[i]) for i in order]
+        devs = [dev[i] for i in order]
+        _ffi.check(hip.trlda_model_set_sstats_mode(m._handle, mode))
+        _ffi.check(hip.trlda_model_set_dense_preamble(m._handle, dense))
+        _ffi.check(hip.trlda_model_set_deferred_stats(m._handle, 1))
+        _ffi.check(hip.trlda_model_set_stream_lanes(m._handle, lanes))
+        for n in range(len(order)):
+            ahead(hip, m, devs, slots, n)
+        through = hip.trlda_model_lane_steps(m._handle)
+        _ffi.check(hip.trlda_model_synchronize(m._handle))
+        res = [s.read() for s in slots]
+        for s in slots:
+            s.free()
+        m.close()
+        return res, through
+
+    for mode, dense in ((1, 0), (0, 1)):
+        ref, _ = stream(1, mode, dense)
+        got, through = stream(2, mode, dense)
+        assert through == len(order)
+        for n in range(len(order)):
+            assert np.array_equal(got[n][0], ref[n][0]) and np.array_equal(got[n][2], ref[n][2])
+            if mode == 1:                            # atomic additions: the order is not fixed
+                assert relerr(got[n][1], ref[n][1]) < TIGHT_RTOL
+            else:
+                assert np.array_equal(got[n][1], ref[n][1])
 
 
 def test_four_hundred_steps_through_two_lanes(hip, sampler):

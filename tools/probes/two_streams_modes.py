@@ -21,8 +21,9 @@ def main():
     from trlda_amd.utils.synthetic import SEED_BASE, make_corpus
     L = _ffi.lib()
     _ffi.require_gpu()
-    K, V, B, NB = 100, 7000, 200, 120
-    steps = 600
+    K, V, B, NB = [int(x) for x in os.environ.get("SHAPE", "100,7000,200,120").split(",")]
+    steps = int(os.environ.get("STEPS", "600"))
+    max_p = int(os.environ.get("MAXP", "4"))
     device = torch.device("cuda", 0)
     L.trlda_seed(1)
     lam = np.empty((K, V), order="F")
@@ -35,7 +36,7 @@ def main():
         L.trlda_sample_gamma_init(K, B, g0)
         g0s.append(torch.from_numpy(np.ascontiguousarray(g0.T)).to(device))
     for deferred, announce in ((1, 1), (0, 1), (0, 0)):
-        for P in (1, 2, 3, 4):
+        for P in range(1, max_p + 1):
             models, streams, outs = [], [], []
             for p in range(P):
                 m = _ffi.vp()
@@ -69,8 +70,8 @@ def main():
             fence()
             pos = 3 * P
             for _ in range(3):
-                run(pos, 200)
-                pos += 200
+                run(pos, min(200, steps))
+                pos += min(200, steps)
                 fence()
             samples = []
             for _ in range(3):

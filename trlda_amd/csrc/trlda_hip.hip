@@ -3550,19 +3550,17 @@ int trlda_model_last_deferred(const trlda_model *m)
 
 namespace {
 
-// what a stream lane may take: exactly the calls whose statistics can wait for the lane's next one
-// (estep_device: launch_ok && defer_self), on a model that holds nothing a lane could not see
-// (row sums an M-step kernel left behind, rowsums_carried: the model's own E-steps use them -- other
-// sums than a lane would form from lambda, an ulp apart -- and prepare nothing ahead: no lanes until
-// lambda is set anew, so that a stream through the lanes stays bitwise the one-lane stream)
+// what a stream lane may take: any E-step on device arrays of a model that holds nothing a lane
+// could not see -- no data-parallel context, no empirical-Bayes step on its way, and no row sums
+// left behind by an M-step kernel (rowsums_carried: the model's own E-steps use those -- other
+// sums than a lane would form from lambda, an ulp apart: no lanes until lambda is set anew, so
+// that a stream through the lanes stays bitwise the one-lane stream).  Inside the lane the call
+// is what it would have been on the model: with deferred statistics and announcements where they
+// apply (small tables, K <= 128, <= 256 documents), the kernels of their own elsewhere.
 bool lane_takes(const trlda_model *m, const trlda_batch *b)
 {
-    return m->lanes_wanted >= 2 && m->deferred_stats && !m->dp && !m->eb.active && m->prefetch_next &&
-           !rowsums_carried(m) &&
-           m->sstats_mode == TRLDA_SSTATS_SEGMENTED && b->B > 0 && b->V == m->V && b->device == m->device &&
-           fused_preamble_possible(m, b) && m->rs_floor >= kFusedRowsumFloor && fused_update_available(m) &&
-           m->K % 2 == 0 && m->pair_gathers && b->long_len == trlda::kLongWord && b->B <= 256 &&
-           b->max_list <= 256 && b->n_active > 0;
+    return m->lanes_wanted >= 2 && !m->dp && !m->eb.active && !rowsums_carried(m) && b->B > 0 &&
+           b->V == m->V && b->device == m->device;
 }
 
 int lanes_ensure(trlda_model *m)
@@ -3612,8 +3610,9 @@ void lane_follow(const trlda_model *m, trlda_model *l)
     l->merged_launch = m->merged_launch; l->split_long_lists = m->split_long_lists;
     l->tiled_tasks = m->tiled_tasks; l->fused_update = m->fused_update; l->carry_rowsums = m->carry_rowsums;
     l->emit_next_preamble = m->emit_next_preamble;
-    l->deferred_stats = true;
-    l->rs_floor = m->rs_floor; l->lambda_positive = m->lambda_positive; l->lambda_exposed = false;
+    l->deferred_stats = m->deferred_stats; l->big_emit = m->big_emit; l->keep_sstats = false;
+    l->rs_floor = m->rs_floor; l->lambda_positive = m->lambda_positive;
+    l->lambda_exposed = m->lambda_exposed;           // (the same choice of preamble as the model's own)
     l->lambda_version = m->lambda_version;
     // (not the per-launch event stamps of trlda_model_set_timing: events between a lane's launches
     // would change what they measure -- lane_span above)
