@@ -108,6 +108,50 @@ static int run_golden(const char *path)
     se = max_rel_err(sstats, s_want, (size_t)K * V, &zeros);
     printf("golden handle gamma_err %.3e sstats_err %.3e zeros_agree %d iters_equal %d\n", ge, se, zeros,
            memcmp(iters, iters_want, (size_t)B * sizeof(int32_t)) == 0);
+
+    /* a corpus pass on the fixed lambda as a STREAM: deferred statistics, two calls in flight
+     * (trlda_model_set_stream_lanes, trlda_model_estep_io_ahead), device arrays, one set per call;
+     * every call of the stream is the golden batch, so every call's results are the golden ones */
+    {
+        enum { CALLS = 5 };
+        void *g0_dev = NULL, *g_dev[CALLS], *s_dev[CALLS], *it_dev[CALLS];
+        const size_t gb = (size_t)K * B * sizeof(double), sb = (size_t)K * V * sizeof(double);
+        CHECK(trlda_dev_alloc(0, gb, &g0_dev));
+        CHECK(trlda_dev_upload(0, g0_dev, gamma0, gb));
+        for (int c = 0; c < CALLS; ++c) {
+            CHECK(trlda_dev_alloc(0, gb, &g_dev[c]));
+            CHECK(trlda_dev_alloc(0, sb, &s_dev[c]));
+            CHECK(trlda_dev_alloc(0, (size_t)B * sizeof(int32_t), &it_dev[c]));
+        }
+        CHECK(trlda_model_set_deferred_stats(model, 1));
+        CHECK(trlda_model_set_stream_lanes(model, 2));
+        const trlda_batch *upcoming[2] = {batch, batch};
+        for (int c = 0; c < CALLS; ++c)
+            CHECK(trlda_model_estep_io_ahead(model, batch, upcoming, c + 2 < CALLS ? 2 : CALLS - 1 - c,
+                                             (const double *)g0_dev, (double *)g_dev[c], (double *)s_dev[c],
+                                             max_iter, 1e-3, (int32_t *)it_dev[c]));
+        const long long through = trlda_model_lane_steps(model);
+        CHECK(trlda_model_synchronize(model));        /* joins the lanes */
+        double ge_worst = 0.0, se_worst = 0.0;
+        int its_ok = 1;
+        zeros = 1;
+        for (int c = 0; c < CALLS; ++c) {
+            CHECK(trlda_dev_download(0, gamma, g_dev[c], gb));
+            CHECK(trlda_dev_download(0, sstats, s_dev[c], sb));
+            CHECK(trlda_dev_download(0, iters, it_dev[c], (size_t)B * sizeof(int32_t)));
+            ge = max_rel_err(gamma, g_want, (size_t)K * B, &zeros);
+            se = max_rel_err(sstats, s_want, (size_t)K * V, &zeros);
+            ge_worst = ge > ge_worst ? ge : ge_worst;
+            se_worst = se > se_worst ? se : se_worst;
+            its_ok = its_ok && memcmp(iters, iters_want, (size_t)B * sizeof(int32_t)) == 0;
+            CHECK(trlda_dev_free(0, g_dev[c]));
+            CHECK(trlda_dev_free(0, s_dev[c]));
+            CHECK(trlda_dev_free(0, it_dev[c]));
+        }
+        CHECK(trlda_dev_free(0, g0_dev));
+        printf("golden lanes gamma_err %.3e sstats_err %.3e zeros_agree %d iters_equal %d through %lld of %d\n",
+               ge_worst, se_worst, zeros, its_ok, through, (int)CALLS);
+    }
     CHECK(trlda_batch_destroy(batch));
     CHECK(trlda_model_destroy(model));
     free(indptr); free(ids); free(cnts); free(iters_want); free(iters); free(alpha); free(g_want);

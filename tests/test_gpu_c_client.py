@@ -2,8 +2,9 @@
 and linked to libtrlda_hip.so -- no Python, torch or C++ in the client -- run on the GPU box; its
 output is checked against the size-independent invariants of SURVEY.md a17, and -- VERDICT r4 item
 10 -- against VALUES: the client runs the compiled reference's golden vector f1a (flattened here
-into one binary file) through the one-shot entry and through the handle API and prints the
-largest relative errors of gamma and the statistics."""
+into one binary file) through the one-shot entry, through the handle API and, five times in a row, as
+a stream through two lanes (trlda_model_estep_io_ahead on device arrays), and prints the largest
+relative errors of gamma and the statistics."""
 import os
 import re
 import subprocess
@@ -41,7 +42,9 @@ def test_plain_c_client_of_the_boundary(hip_lib, tmp_path):
     out = subprocess.run([exe, vec], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     text = out.stdout.decode()
-    for api in ("oneshot", "handle"):
+    lanes = re.search(r"golden lanes .* through (\d+) of (\d+)", text)
+    assert lanes and lanes.group(1) == lanes.group(2), text       # every call of the stream went through a lane
+    for api in ("oneshot", "handle", "lanes"):
         g = re.search(r"golden %s gamma_err (\S+) sstats_err (\S+) zeros_agree (\d) iters_equal (\d)" % api, text)
         assert g, text
         assert float(g.group(1)) < TIGHT_RTOL and float(g.group(2)) < TIGHT_RTOL, (api, g.groups())
