@@ -3171,9 +3171,13 @@ int model_create(trlda_model **out, int device, int K, int V, int stream_priorit
     if (!rc) rc = dev_alloc(&m->partial, (size_t)kMaxRowsumBlocks * K);
     if (!rc) rc = dev_alloc(&m->counter, 1);
     if (!rc && !std::getenv("TRLDA_NULL_STREAM")) {
-        const hipError_t e = stream_priority != 0
-                                 ? hipStreamCreateWithPriority(&m->own_stream, hipStreamNonBlocking, stream_priority)
-                                 : hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking);
+        hipError_t e = stream_priority != 0
+                           ? hipStreamCreateWithPriority(&m->own_stream, hipStreamNonBlocking, stream_priority)
+                           : hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking);
+        if (e != hipSuccess && stream_priority != 0) {   // (a runtime without priorities: a plain stream)
+            (void)hipGetLastError();
+            e = hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking);
+        }
         if (e != hipSuccess)
             rc = fail(TRLDA_ERR_HIP, "hipStreamCreateWithFlags failed");
         m->stream = m->own_stream;
