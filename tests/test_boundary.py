@@ -202,6 +202,11 @@ def test_no_gpu_means_loud_failure_not_fallback(hip_lib):
         hip_lib.trlda_last_error()
     h = _ffi.vp()
     assert hip_lib.trlda_model_create(ctypes.byref(h), 0, 2, 3) == _ffi.ERR_NO_DEVICE
+    # the stream entries (deferred statistics, lanes): argument errors, never a silent no-op
+    up = (ctypes.c_void_p * 2)()
+    assert hip_lib.trlda_model_estep_io_ahead(None, None, up, 2, None, None, None, 5, 1e-3, None) < 0
+    assert hip_lib.trlda_model_set_stream_lanes(None, 2) < 0 and hip_lib.trlda_model_flush(None) < 0
+    assert hip_lib.trlda_model_set_deferred_stats(None, 1) < 0 and hip_lib.trlda_model_lane_steps(None) == 0
 
 
 def test_missing_library_is_an_error(tmp_path, monkeypatch):
