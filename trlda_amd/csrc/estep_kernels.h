@@ -1609,8 +1609,21 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
             const int kc = (wid - (W - 2)) * 64 + lane;
             const bool on = kc < K;
             const int ka = on ? kc : 0;
-            const double ga = sum8_strided<kRegPart>(partB + ka) * e_old[ka] + alpha_l[ka];
-            const double v = on ? fabs(g_old[ka] - ga) : 0.0;
+            // (every read requested before the first is consumed -- nothing is scheduled across the
+            // sched_barrier: in the tiered kernels, close to the register limit, the compiler took them
+            // one at a time, six LDS round trips in a row, and these waves needed 927 cycles where the
+            // psi waves need 730 and the stage waits for both: every document of a launch with one
+            // 129-word document paid 220 cycles per iteration, 38 % of the headline's launches;
+            // profiles/r05_stamps_waves.txt.  The same barrier inside sum8_strided, for the psi waves
+            // too: 26.2 against 26.0 us per step -- here only)
+            const double *pp = partB + ka;
+            const double p0v = pp[0], p1v = pp[kRegPart], p2v = pp[2 * kRegPart], p3v = pp[3 * kRegPart],
+                         p4v = pp[4 * kRegPart], p5v = pp[5 * kRegPart], p6v = pp[6 * kRegPart],
+                         p7v = pp[7 * kRegPart];
+            const double eo = e_old[ka], al = alpha_l[ka], go = g_old[ka];
+            __builtin_amdgcn_sched_barrier(0);
+            const double ga = (((p0v + p1v) + (p2v + p3v)) + ((p4v + p5v) + (p6v + p7v))) * eo + al;
+            const double v = on ? fabs(go - ga) : 0.0;
             const double half = wave_sum_dpp(v);
             if (lane == 0)
                 misc[wid - (W - 2)] = half;
