@@ -447,10 +447,15 @@ __device__ __forceinline__ void merged_stats(const MergedArgs &mg, int vb, doubl
                 *reinterpret_cast<double2 *>(lds + (wid + 8 * h) * K + 2 * lane) = acc[h];
         __syncthreads();
         if (tid < K) {
-            double sum = lds[tid];
+            double cv[16];                           // (requested together, added in chunk order)
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                cv[c] = lds[c * K + tid];
+            __builtin_amdgcn_sched_barrier(0);
+            double sum = cv[0];
 #pragma unroll
             for (int c = 1; c < 16; ++c)
-                sum += lds[c * K + tid];
+                sum += cv[c];
             const double s = sum * ek;
             if (o.sstats)
                 o.sstats[i] = s;
@@ -717,10 +722,17 @@ __device__ __forceinline__ void deferred_long_group(const MergedArgs &mg, int t,
     __syncthreads();
     if (fin_on) {
         const double *col = lds + (size_t)(fi * 16) * K + fk;
-        double sum = col[0];
+        // (the sixteen chunk sums requested together, added in chunk order: left to the compiler they
+        // were fifteen LDS round trips one behind the other)
+        double cv[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            cv[c] = col[(size_t)c * K];
+        __builtin_amdgcn_sched_barrier(0);
+        double sum = cv[0];
 #pragma unroll
         for (int c = 1; c < 16; ++c)
-            sum += col[(size_t)c * K];
+            sum += cv[c];
         mg.o.sstats[fidx] = sum * ek;
     }
     __syncthreads();
@@ -1055,10 +1067,17 @@ __device__ __forceinline__ void merged_stats_slots(const MergedArgs &mg, int vb,
     double lam = 0.0;
     if (fin_on) {
         const double *col = lds + (size_t)(fi * 16) * K + fk;
-        double sum = col[0];
+        // (the sixteen chunk sums requested together, added in chunk order: left to the compiler they
+        // were fifteen LDS round trips one behind the other)
+        double cv[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            cv[c] = col[(size_t)c * K];
+        __builtin_amdgcn_sched_barrier(0);
+        double sum = cv[0];
 #pragma unroll
         for (int c = 1; c < 16; ++c)
-            sum += col[(size_t)c * K];
+            sum += cv[c];
         const double sv = sum * ek;
         if (o.sstats)
             o.sstats[fidx] = sv;
