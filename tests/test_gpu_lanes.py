@@ -438,3 +438,33 @@ def test_four_hundred_steps_through_two_lanes(hip, sampler):
     for s in g0_slots + outs:
         s.free()
     m.close()
+
+
+def test_the_python_stream_equals_a_loop_of_do_e_step(hip, sampler):
+    """trlda_amd.stream.EStepStream on torch tensors against the reference's own form of the pass:
+    a Python loop over do_e_step with host arrays (python/src/ldainterface.cpp:311-390)"""
+    import torch
+    from trlda_amd.stream import EStepStream
+    K, V, B = 100, 3000, 160
+    lam = seeded_lambda(sampler, 29, K, V)
+    csrs = [corpus(B, V, seed=300 + i, mean_unique=80) for i in range(5)]
+    g0s = [seeded_gamma(sampler, 310 + i, K, B) for i in range(5)]
+    m = make_model(K, V, lam)
+    dev = torch.device("cuda", 0)
+    batches = [m.upload(c) for c in csrs]
+    g0_t = [torch.from_numpy(np.ascontiguousarray(g.T)).to(dev) for g in g0s]
+    gam = [torch.empty(B, K, dtype=torch.float64, device=dev) for _ in csrs]
+    sst = [torch.full((V, K), float("nan"), dtype=torch.float64, device=dev) for _ in csrs]
+    its = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in csrs]
+    with EStepStream(m) as s:
+        for i, b in enumerate(batches):
+            s.step(b, batches[i + 1:i + 3], g0_t[i], gam[i], sst[i], max_iter=20, iterations=its[i])
+        through = s.steps_through_lanes
+    torch.cuda.synchronize()
+    assert through == len(csrs)
+    for i, c in enumerate(csrs):
+        g, ss, it = m.do_e_step(c, latents=g0s[i], max_iter=20, return_iterations=True)
+        assert np.array_equal(gam[i].cpu().numpy().T, np.asarray(g))
+        assert np.array_equal(sst[i].cpu().numpy().T, np.asarray(ss))
+        assert np.array_equal(its[i].cpu().numpy(), np.asarray(it))
+    m.close()
