@@ -578,13 +578,14 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_tiered_merged_kernel(D
 // round: the lists are in classes by length (they are sorted by it), and a wave takes as many
 // words of a class as keep 16 rows (16-byte gathers per lane) in flight --
 //     entries   9..16 | 5..8 | 3..4 | 1..2          chunk of a long list  9..16 | 5..8 | 3..4 | 1..2
-//     words / wave  1 |   2  |   4  |   8          lists / workgroup          1  |   1  |   2  |   4
+//     words / group 1 |   2  |   4  |   8          lists / workgroup          1  |   1  |   2  |   4
+// (a wave takes TWO groups per item: deferred_short_wave)
 // -- so a workgroup is: descriptors -> (documents, weights, exp(psi(lambda))) -> rows -> store.
 // The zero columns of the words outside the batch: a wave reads 64 flags with ONE load and writes
 // the zeros of those that are clear.  The sums and their order are unchanged (a word's entries in
 // document order; long lists in the sixteen chunks of the 1024-thread kernel, combined in chunk
 // order): bitwise the statistics of sstats_update2_kernel.
-constexpr int kDeferShortNW[4] = {1, 2, 4, 8};   // words per wave, by class
+constexpr int kDeferShortNW[4] = {2, 4, 8, 16};  // words per wave, by class (two groups of 16 slots)
 constexpr int kDeferLongLW[4] = {1, 1, 2, 4};    // lists per workgroup, by class
 constexpr int kDeferLog2R[4] = {4, 3, 2, 1};     // log2 of the longest list / chunk of a class
 
@@ -613,52 +614,75 @@ __host__ __device__ inline int deferred_long_items(const int (&c)[4])
 // (Eight instantiations of the array form, one per class, spilled 60 to 90 vector registers of
 // the whole launch.)
 //
-// short lists: the wave's words [t, t + (16 >> lr)) below t_end
+// short lists: the wave's words [t, t + 2 (16 >> lr)) below t_end, as TWO groups of 16 slots.  A group
+// is three dependent memory latencies (descriptors -> documents and weights -> rows); the second
+// group's first two are requested with the first group's, so that a wave pays four for two groups
+// where two items paid six (round 5: the helpers' CU-time is a sixth of a two-lane step).
 template <class Pub>
 __device__ __forceinline__ void deferred_short_wave(const MergedArgs &mg, int t, int t_end, int lr, int lane,
                                                     int kk, bool k_on, const Pub &pub)
 {
     const int K = mg.K;
-    const int R = 1 << lr;
+    const int R = 1 << lr, nw = 16 >> lr;
     const int sl = min(lane, 15), j = sl >> lr, u = sl & (R - 1);
-    const bool w_on = t + j < t_end;
-    const int4 d = mg.desc[min(t + j, t_end - 1)];                  // (word, first entry, entries, 0)
-    const bool on = lane < 16 && w_on && u < d.z;
-    const int q = on ? d.y + u : 0;
-    const int doc = on ? mg.wdoc[q] : -1;                           // -1: the zero row
-    const double tw = on ? mg.tw_word[q] : 0.0;
-    const int tlo = __double2loint(tw), thi = __double2hiint(tw);
-    const int wword = w_on ? d.x : -1;
-    // exp(psi(lambda)) of the segments' words: requested with the rows
-    double2 e2[8];                                   // (R >= 2: segments start at even slots)
+    const bool second = t + nw < t_end;              // wave-uniform
+    // descriptors of both groups, then their documents and weights
+    int4 d[2];
+    bool w_on[2];
 #pragma unroll
-    for (int s0 = 0; s0 < 16; s0 += 2) {
-        if ((s0 & (R - 1)) == 0) {                   // wave-uniform: a segment starts here
-            const int w = max(__builtin_amdgcn_readlane(wword, s0), 0);
-            e2[s0 >> 1] = *reinterpret_cast<const double2 *>(mg.eeb + (size_t)w * K + kk);
+    for (int g = 0; g < 2; ++g) {
+        const int tg = t + g * nw;
+        w_on[g] = tg + j < t_end;
+        d[g] = mg.desc[min(tg + j, t_end - 1)];      // (word, first entry, entries, 0)
+    }
+    int doc[2], tlo[2], thi[2], wword[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const bool on = lane < 16 && w_on[g] && u < d[g].z;
+        const int q = on ? d[g].y + u : 0;
+        doc[g] = on ? mg.wdoc[q] : -1;               // -1: the zero row
+        const double tw = on ? mg.tw_word[q] : 0.0;
+        tlo[g] = __double2loint(tw);
+        thi[g] = __double2hiint(tw);
+        wword[g] = w_on[g] ? d[g].x : -1;
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        if (g == 1 && !second)
+            break;
+        // exp(psi(lambda)) of the segments' words: requested with the rows
+        double2 e2[8];                               // (R >= 2: segments start at even slots)
+#pragma unroll
+        for (int s0 = 0; s0 < 16; s0 += 2) {
+            if ((s0 & (R - 1)) == 0) {               // wave-uniform: a segment starts here
+                const int w = max(__builtin_amdgcn_readlane(wword[g], s0), 0);
+                e2[s0 >> 1] = *reinterpret_cast<const double2 *>(mg.eeb + (size_t)w * K + kk);
+            }
         }
-    }
-    double2 ev[16];
+        double2 ev[16];
 #pragma unroll
-    for (int s0 = 0; s0 < 16; ++s0) {
-        const long long row = (long long)__builtin_amdgcn_readlane(doc, s0) * K;
-        ev[s0] = *reinterpret_cast<const double2 *>(mg.epg + row + kk);
-    }
-    pub();                                           // (every load requested, no store issued yet)
-    double2 acc = make_double2(0.0, 0.0), ec = make_double2(0.0, 0.0);
+        for (int s0 = 0; s0 < 16; ++s0) {
+            const long long row = (long long)__builtin_amdgcn_readlane(doc[g], s0) * K;
+            ev[s0] = *reinterpret_cast<const double2 *>(mg.epg + row + kk);
+        }
+        if (g == 0)
+            pub();                                   // (the first group's loads requested, no store issued yet)
+        double2 acc = make_double2(0.0, 0.0), ec = make_double2(0.0, 0.0);
 #pragma unroll
-    for (int s0 = 0; s0 < 16; ++s0) {
-        if ((s0 & 1) == 0 && (s0 & (R - 1)) == 0)    // (the segment's exp(psi(lambda)): constant index --
-            ec = e2[s0 >> 1];                        // an index computed at run time would put e2 in scratch)
-        const double tu = __hiloint2double(__builtin_amdgcn_readlane(thi, s0), __builtin_amdgcn_readlane(tlo, s0));
-        acc.x = fma(tu, ev[s0].x, acc.x);            // (+0 * 0 past a list's end)
-        acc.y = fma(tu, ev[s0].y, acc.y);
-        if (((s0 + 1) & (R - 1)) == 0) {             // wave-uniform: the segment ends here
-            const int w = __builtin_amdgcn_readlane(wword, s0);
-            if (w >= 0 && k_on)
-                *reinterpret_cast<double2 *>(mg.o.sstats + (size_t)w * K + 2 * lane) =
-                    make_double2(acc.x * ec.x, acc.y * ec.y);
-            acc = make_double2(0.0, 0.0);
+        for (int s0 = 0; s0 < 16; ++s0) {
+            if ((s0 & 1) == 0 && (s0 & (R - 1)) == 0)    // (the segment's exp(psi(lambda)): constant index --
+                ec = e2[s0 >> 1];                        // an index computed at run time would put e2 in scratch)
+            const double tu = __hiloint2double(__builtin_amdgcn_readlane(thi[g], s0),
+                                               __builtin_amdgcn_readlane(tlo[g], s0));
+            acc.x = fma(tu, ev[s0].x, acc.x);            // (+0 * 0 past a list's end)
+            acc.y = fma(tu, ev[s0].y, acc.y);
+            if (((s0 + 1) & (R - 1)) == 0) {             // wave-uniform: the segment ends here
+                const int w = __builtin_amdgcn_readlane(wword[g], s0);
+                if (w >= 0 && k_on)
+                    *reinterpret_cast<double2 *>(mg.o.sstats + (size_t)w * K + 2 * lane) =
+                        make_double2(acc.x * ec.x, acc.y * ec.y);
+                acc = make_double2(0.0, 0.0);
+            }
         }
     }
 }
@@ -787,7 +811,7 @@ __device__ __forceinline__ void deferred_stats(const MergedArgs &mg, int vb, dou
                 cls = c + 1;
             }
         }
-        const int lr = 4 - cls, nw = 16 >> lr;       // kDeferLog2R / kDeferShortNW
+        const int lr = 4 - cls, nw = 2 * (16 >> lr); // kDeferLog2R / kDeferShortNW
         const int t_end = base + (cls == 0 ? mg.cls_short[0] : cls == 1 ? mg.cls_short[1]
                                   : cls == 2 ? mg.cls_short[2] : mg.cls_short[3]);
         const int t = base + (it * W + wid) * nw;
