@@ -1146,6 +1146,15 @@ def main():
         "settle": dict(settled, rule="samples of min(steps, 20) steps until two consecutive ones agree "
                                      "within 2 %% and %g s have passed, at most %g s; untimed; --no-settle "
                                      "switches it off" % (SETTLE_MIN_S, SETTLE_MAX_S)),
+        # what kind of step `value` times, so that lines of different rounds / switches are compared like
+        # for like: rounds 1-4 = {"deferred_stats": false, "lanes": 1}; the synchronous
+        # forms are `value_one_lane` (absent under --headline-only, whose runs are profiled per kernel)
+        # and `--no-deferred --lanes 1`
+        "mode": {"deferred_stats": bool(carried), "lanes": lanes[0], "announced_preamble": bool(prefetch),
+                 "pipelined": bool(carried or laned),
+                 "results_complete": "at the fence that closes the timed region (trlda_model_flush + "
+                                     "synchronisation), inside the clock" if (carried or laned) else
+                                     "when each step's kernels end"},
         "value_no_prefetch": value_no_prefetch,
         "value_one_lane": value_one_lane,
         "lanes": lanes[0],

@@ -454,3 +454,33 @@ for v in (0, 1, 2):
             assert re.fullmatch(r"\tStep width: " + num, block[j + 1]), block[j + 1]
             assert re.fullmatch(r"\t" + grad + ": " + num, block[j + 2]), block[j + 2]
     assert len(loud[1:eta_at]) == 9 and len(loud[eta_at + 1:]) == 6    # three / two Newton steps
+
+
+def test_stream_rejects_arrays_the_kernels_could_not_read():
+    """EStepStream hands addresses straight to the kernels -- a host tensor, a float32
+    one, one of the wrong size or a non-contiguous view is an error HERE, not a GPU fault."""
+    import torch
+    from trlda_amd.stream import _address
+    ok = torch.zeros(12, dtype=torch.float64)
+    with pytest.raises(TypeError, match="device"):
+        _address(ok, "gamma", 12)                                     # a host tensor
+    assert _address(None) is None and _address(4096) == 4096          # raw addresses: the caller's word
+
+    class Fake(object):                                               # a device tensor, as far as the checks go
+        def __init__(self, n, dtype="torch.float64", contiguous=True, index=0):
+            self.n, self.dtype, self.c, self.is_cuda = n, dtype, contiguous, True
+            self.device = type("D", (), {"index": index})()
+        def data_ptr(self): return 0x1000
+        def is_contiguous(self): return self.c
+        def numel(self): return self.n
+
+    assert _address(Fake(12), "gamma", 12, device=0) == 0x1000
+    with pytest.raises(TypeError, match="float64"):
+        _address(Fake(12, "torch.float32"), "gamma", 12)
+    with pytest.raises(ValueError, match="12 elements"):
+        _address(Fake(11), "gamma", 12)
+    with pytest.raises(TypeError, match="contiguous"):
+        _address(Fake(12, contiguous=False), "gamma", 12)
+    with pytest.raises(ValueError, match="device 1"):
+        _address(Fake(12, index=1), "gamma", 12, device=0)
+    assert _address(Fake(5, "torch.int32"), "iterations", 5, dtype="int32") == 0x1000

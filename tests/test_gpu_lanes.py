@@ -289,6 +289,61 @@ def test_shared_and_chained_arrays_take_one_lane(hip, sampler):
     m.close()
 
 
+@pytest.mark.parametrize("n_sets", [3, 5, 7])
+def test_an_odd_rotation_of_output_sets_meets_the_other_lane(hip, sampler, n_sets):
+    """with deferred statistics the sstats array of call i is written by call i + 2's
+    launch on the same lane.  A caller that rotates an ODD number of output sets hands the set of
+    call i to call i + n_sets, which goes to the OTHER lane -- the library keeps every range a lane
+    has been given since the last join, so that call waits for the lane that may still write the set.
+    Every call's results are read (after a flush) before its set comes round again; the last
+    round's are read at the end: all equal to the plain stream's."""
+    from trlda_amd import _ffi
+    K, V, B = 100, 2500, 100
+    lam = seeded_lambda(sampler, 12, K, V)
+    csrs = [corpus(B, V, seed=140 + i, mean_unique=70) for i in range(4)]
+    g0 = seeded_gamma(sampler, 150, K, B)
+    n_calls = 4 * n_sets + 1
+
+    def stream(lanes, deferred, check_every):
+        m = make_model(K, V, lam)
+        dev = [m.upload(c) for c in csrs]
+        _ffi.check(hip.trlda_model_set_deferred_stats(m._handle, deferred))
+        _ffi.check(hip.trlda_model_set_stream_lanes(m._handle, lanes))
+        slots = [Slots(hip, K, V, csrs[0], g0) for _ in range(n_sets)]
+        up = (C.c_void_p * 2)()
+        out = [None] * n_calls
+        for n in range(n_calls):
+            up[0] = dev[(n + 1) % 4].handle.value
+            up[1] = dev[(n + 2) % 4].handle.value
+            g0d, gd, sd, itd = slots[n % n_sets].ptrs
+            _ffi.check(hip.trlda_model_estep_io_ahead(m._handle, dev[n % 4].handle, up, 2, g0d, gd, sd, 20,
+                                                      1e-3, itd))
+            if check_every and n % n_sets == n_sets - 1:     # a whole round is out: read it
+                _ffi.check(hip.trlda_model_flush(m._handle))
+                _ffi.check(hip.trlda_model_synchronize(m._handle))
+                for q in range(n - n_sets + 1, n + 1):
+                    out[q] = slots[q % n_sets].read()
+        through = hip.trlda_model_lane_steps(m._handle)
+        _ffi.check(hip.trlda_model_synchronize(m._handle))
+        for q in range(n_calls):
+            if out[q] is None and q + n_sets >= n_calls:     # the sets as the last calls left them
+                out[q] = slots[q % n_sets].read()
+        for s in slots:
+            s.free()
+        m.close()
+        return out, through
+
+    ref, _ = stream(1, 0, True)
+    for check_every in (True, False):
+        got, through = stream(2, 1, check_every)
+        assert through == n_calls
+        for n in range(n_calls):
+            if got[n] is None:
+                continue
+            for q in range(3):
+                assert np.array_equal(got[n][q], ref[n][q]), (n_sets, check_every, n, q)
+
+
 def test_the_callers_stream_comes_first(hip, sampler):
     """gamma0 produced by work on the model's stream right before the call (a device copy enqueued on
     torch's current stream, which the model is told to use), results consumed on that stream after

@@ -29,7 +29,7 @@ CONFIGS = {
     "c3": (100, 7000, 1600, "online", 20),
     "c5a": (500, 100000, 512, "online", 6),
     "c5b": (500, 100000, 4096, "online", 8),
-    "c4": (200, 50000, 12500, "batch", 2),
+    "c4": (200, 50000, 12500, "batch", 7),
 }
 
 
@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--configs", default="small,c5a,c5b,c4")
     ap.add_argument("--root", default=ROOT, help="tree to import trlda_amd from")
     ap.add_argument("--modes", default="fused,plain")
+    ap.add_argument("--reps", type=int, default=5, help="timed samples per row (median and max printed)")
+    ap.add_argument("--samples", action="store_true", help="print every sample")
     ap.add_argument("--no-draw-ahead", action="store_true",
                     help="every gamma0 drawn in its turn on the model's stream (trlda_model_set_draw_ahead(0))")
     ap.add_argument("--host-draw", action="store_true",
@@ -102,24 +104,34 @@ def main():
                     m.lambdas = lam
                     m.update_parameters(batches[0], **kw)     # warm-up (allocations, code objects)
                     sync(m)
-                    t = time.perf_counter()
-                    for i in range(calls):
-                        m.update_parameters(batches[1 + i], **kw)
-                    sync(m)
-                    dt = (time.perf_counter() - t) / calls
+                    # (a stream of calls: the host runs ahead of the device, so single calls cannot
+                    # be told apart -- `reps` whole streams instead, median and slowest)
+                    samples = []
+                    for r in range(args.reps):
+                        m.lambdas = lam
+                        sync(m)
+                        t = time.perf_counter()
+                        for i in range(calls):
+                            m.update_parameters(batches[1 + i], **kw)
+                        sync(m)
+                        samples.append((time.perf_counter() - t) / calls)
                 else:
                     m.update_parameters(batches[0], **kw)     # warm-up
-                    dt = 0.0
-                    for i in range(calls):
+                    samples = []
+                    for i in range(max(calls, args.reps)):
                         m.lambdas = lam
                         sync(m)
                         t = time.perf_counter()
                         m.update_parameters(batches[0], **kw)
                         sync(m)
-                        dt += (time.perf_counter() - t) / calls
-                print("%-5s K=%d V=%d B=%d %-6s %-32s %9.3f ms/call  %10.0f docs/s  "
+                        samples.append(time.perf_counter() - t)
+                dt = float(np.median(samples))
+                print("%-5s K=%d V=%d B=%d %-6s %-32s %9.3f ms/call (median of %d; max %.3f)  %10.0f docs/s  "
                       "(sampleGamma(K, B, 100) on the host alone: %.3f ms)"
-                      % (name, K, V, B, mode, label, dt * 1e3, B / dt, draw_ms))
+                      % (name, K, V, B, mode, label, dt * 1e3, len(samples), max(samples) * 1e3, B / dt,
+                         draw_ms))
+                if args.samples:
+                    print("      samples (ms):", " ".join("%.3f" % (x * 1e3) for x in samples))
             m.close()
 
 

@@ -290,7 +290,11 @@ struct trlda_model {
     hipEvent_t lane_in[2] = {nullptr, nullptr}, lane_out[2] = {nullptr, nullptr};
     struct LaneRange {
         const char *lo = nullptr, *hi = nullptr;
-    } lane_writes[2][8];                  // what the lane's outstanding launches write (ring of two calls)
+    };
+    // what the lane's launches since the last join write: the arrays of EVERY call of the stretch (with
+    // deferred statistics a call's sstats are written by the lane's NEXT launch, and any launch since
+    // the join may still be outstanding), each range once -- a streaming caller rotates a few sets
+    std::vector<LaneRange> lane_writes[2];
     int lane_calls[2] = {0, 0};
     LaneRange prev_writes[3];             // the arrays of the stream's last call (whichever way it went)
     // timing (trlda_model_set_timing): a lane's launches run back to back on its stream, so one pair
@@ -2393,8 +2397,7 @@ int lanes_join(trlda_model *m)
             (void)hipStreamSynchronize(l->stream);
         }
         m->lane_calls[p] = 0;
-        for (auto &w : m->lane_writes[p])
-            w = trlda_model::LaneRange{};
+        m->lane_writes[p].clear();
     }
     return rc;
 }
@@ -3081,6 +3084,7 @@ int trlda_batch_destroy(trlda_batch *b)
         (void)hipFree(b->dp_wsrc);                   // (waits for the device)
         (void)hipFree(b->dp_wrow);
     }
+    bool erased = false;
     if (b->blob && hipSetDevice(b->device) == hipSuccess) {
         UploadContext &u = upload_context(b->device);
         std::lock_guard<std::mutex> lock(u.mu);
@@ -3092,6 +3096,7 @@ int trlda_batch_destroy(trlda_batch *b)
         // whose last stream is gone needs none -- and its `done` event, if that stream recorded
         // it, is dropped rather than recycled
         u.live.erase(b);
+        erased = true;
         hipEvent_t guard = b->used ? (settled ? b->done : nullptr) : b->ready;
         if (b->used)
             u.spare(b->ready);                       // (recorded on the upload stream only)
@@ -3112,6 +3117,13 @@ int trlda_batch_destroy(trlda_batch *b)
             u.spare(guard, blob.on, blob.on_owned);
         }
     }
+    if (!erased) {
+        // (whatever kept the branch above from running: no pointer to a deleted batch stays in the
+        // upload context's list -- purge_stream_guards walks it)
+        UploadContext &u = upload_context(b->device);
+        std::lock_guard<std::mutex> lock(u.mu);
+        u.live.erase(b);
+    }
     delete b;
     return TRLDA_OK;
 }
@@ -3130,21 +3142,22 @@ int trlda_batch_num_very_long_words(const trlda_batch *b) { return b ? b->n_vl :
 namespace {
 // (stream_priority != 0: the model's own stream is created with that priority -- the lanes of
 // another model, lanes_ensure)
-int model_create(trlda_model **out, int device, int K, int V, int stream_priority);
+// (lane_of: the model whose lambda and alpha the new one reads instead of allocating its own)
+int model_create(trlda_model **out, int device, int K, int V, int stream_priority, trlda_model *lane_of);
 }  // namespace
 
 extern "C" {
 
 int trlda_model_create(trlda_model **out, int device, int K, int V)
 {
-    return model_create(out, device, K, V, 0);
+    return model_create(out, device, K, V, 0, nullptr);
 }
 
 }  // extern "C"
 
 namespace {
 
-int model_create(trlda_model **out, int device, int K, int V, int stream_priority)
+int model_create(trlda_model **out, int device, int K, int V, int stream_priority, trlda_model *lane_of)
 {
     if (!out)
         return fail(TRLDA_ERR_ARG, "out is NULL");
@@ -3164,9 +3177,19 @@ int model_create(trlda_model **out, int device, int K, int V, int stream_priorit
                                                                        : TRLDA_DOCS_AUTO;
     }
     size_t KV = (size_t)K * V;
-    rc = dev_alloc(&m->lambda, KV);
+    if (lane_of) {
+        // a stream lane: lambda and alpha are its owner's (no allocation of its own); what a
+        // lane does own is its exp E[log beta] buffers -- K x V doubles in `eeb` plus up to three of the
+        // same in eeb_pp on small tables -- and the per-batch workspaces: ~4 x 8 K V bytes per lane
+        // at most (K = 500, V = 100 000: 0.4 GB for `eeb`, no eeb_pp there), of 288 GB
+        m->lambda = lane_of->lambda;
+        m->alpha = lane_of->alpha;
+        m->lane_owner = lane_of;
+    } else {
+        rc = dev_alloc(&m->lambda, KV);
+        if (!rc) rc = dev_alloc(&m->alpha, (size_t)K);
+    }
     if (!rc) rc = dev_alloc(&m->eeb, KV);
-    if (!rc) rc = dev_alloc(&m->alpha, (size_t)K);
     if (!rc) rc = dev_alloc(&m->psi_sum, 3 * (size_t)K);   // psi(row sums), the row sums, exp(-psi)
     if (!rc) rc = dev_alloc(&m->partial, (size_t)kMaxRowsumBlocks * K);
     if (!rc) rc = dev_alloc(&m->counter, 1);
@@ -3588,18 +3611,16 @@ int lanes_ensure(trlda_model *m)
             return greatest;
         }();
         trlda_model *l = nullptr;
-        int rc = model_create(&l, m->device, m->K, m->V, lane_priority);
+        int rc = model_create(&l, m->device, m->K, m->V, lane_priority, m);
         if (rc)
             return rc;
-        (void)hipFree(l->lambda);
-        (void)hipFree(l->alpha);
-        l->lambda = m->lambda;
-        l->alpha = m->alpha;
-        l->lane_owner = m;
-        m->lane[p] = l;
-        if (hipEventCreateWithFlags(&m->lane_in[p], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&m->lane_out[p], hipEventDisableTiming) != hipSuccess)
+        // (the events first: a lane is published whole or not at all)
+        if ((!m->lane_in[p] && hipEventCreateWithFlags(&m->lane_in[p], hipEventDisableTiming) != hipSuccess) ||
+            (!m->lane_out[p] && hipEventCreateWithFlags(&m->lane_out[p], hipEventDisableTiming) != hipSuccess)) {
+            (void)trlda_model_destroy(l);
             return fail(TRLDA_ERR_HIP, "hipEventCreateWithFlags failed");
+        }
+        m->lane[p] = l;
     }
     return TRLDA_OK;
 }
@@ -3697,9 +3718,9 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
     // call's gamma0) has nothing to run side by side: one lane, as without the switch
     const size_t g_bytes = (size_t)b->B * m->K * sizeof(double), s_bytes = (size_t)m->K * m->V * sizeof(double);
     const size_t i_bytes = (size_t)b->B * sizeof(int32_t);
-    auto meets_any = [&](const trlda_model::LaneRange *w, int n) {
+    auto meets_any = [&](const trlda_model::LaneRange *w, size_t n) {
         bool hit = false;
-        for (int i = 0; i < n; ++i)
+        for (size_t i = 0; i < n; ++i)
             hit = hit || ranges_meet(w[i], gamma_dev, g_bytes) || ranges_meet(w[i], gamma0_dev, g_bytes) ||
                   ranges_meet(w[i], sstats_dev, s_bytes) || ranges_meet(w[i], iters_dev, i_bytes);
         return hit;
@@ -3748,13 +3769,16 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
     // the OTHER lane's outstanding launches write arrays this call reads or writes (a caller that
     // hands the same gamma / sstats to consecutive calls): they go first -- correct, and serial
     tr.mark();
-    if (meets_any(m->lane_writes[1 - p], 8)) {
+    // (a caller that hands every call arrays of its own lets the list grow: past kLaneRangeCap ranges
+    // the other lane is waited for once, as if they met, and its list starts again)
+    constexpr size_t kLaneRangeCap = 96;
+    if (meets_any(m->lane_writes[1 - p].data(), m->lane_writes[1 - p].size()) ||
+        m->lane_writes[1 - p].size() > kLaneRangeCap) {
         if ((rc = flush_pending(o)))
             return rc;
         HIP_TRY(hipEventRecord(m->lane_out[1 - p], o->stream));
         HIP_TRY(hipStreamWaitEvent(l->stream, m->lane_out[1 - p], 0));
-        for (auto &w : m->lane_writes[1 - p])
-            w = trlda_model::LaneRange{};
+        m->lane_writes[1 - p].clear();
     }
     if (m->timing && !m->lane_span_open[p]) {        // (the first call of a stretch on this lane)
         lane_spans_collect(m);
@@ -3779,12 +3803,21 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
         return rc;
     }
     {
-        trlda_model::LaneRange *w = m->lane_writes[p] + 4 * (m->lane_calls[p] & 1);
-        const char *g = reinterpret_cast<const char *>(gamma_dev), *s = reinterpret_cast<const char *>(sstats_dev),
-                   *it = reinterpret_cast<const char *>(iters_dev);
-        w[0] = {g, g + g_bytes};
-        w[1] = {s, s + s_bytes};
-        w[2] = it ? trlda_model::LaneRange{it, it + i_bytes} : trlda_model::LaneRange{};
+        // (kept until the other lane has waited for this one or the lanes are joined: the sstats of
+        // this call are written by the lane's next launch)
+        std::vector<trlda_model::LaneRange> &w = m->lane_writes[p];
+        auto note = [&w](const void *ptr, size_t bytes) {
+            const char *lo = static_cast<const char *>(ptr);
+            if (!lo || !bytes)
+                return;
+            for (const auto &r : w)
+                if (r.lo == lo && r.hi == lo + bytes)
+                    return;
+            w.push_back(trlda_model::LaneRange{lo, lo + bytes});
+        };
+        note(gamma_dev, g_bytes);
+        note(sstats_dev, s_bytes);
+        note(iters_dev, i_bytes);
         ++m->lane_calls[p];
     }
     m->lane_turn = 1 - p;

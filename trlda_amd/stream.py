@@ -12,7 +12,9 @@ batch.  Results are complete after :meth:`flush` (or when the ``with`` block end
     with EStepStream(model) as s:
         for i, b in enumerate(batches):                    # DeviceBatch objects (model.upload)
             s.step(b, batches[i + 1:i + 3], gamma0[i], gamma[i], sstats[i])
-    # gamma[i] (B x K, a document's K values contiguous) and sstats[i] (V x K) are complete here
+    # gamma[i] (K x B column-major: a document's K values contiguous) and sstats[i] (K x V column-major:
+    # a word's K values contiguous) are complete here.  As row-major torch tensors these are shapes
+    # (B, K) and (V, K).
 
 Consecutive calls must write different arrays (two are in flight); a caller that reuses one set
 of arrays is recognised by the library and goes one call at a time.
@@ -24,13 +26,28 @@ from . import _ffi
 __all__ = ["EStepStream"]
 
 
-def _address(x):
-    """device address of a torch tensor (or anything with data_ptr()), or an int / None"""
+def _address(x, what="array", numel=None, dtype="float64", device=None):
+    """device address of a torch tensor (or anything with data_ptr()), or an int / None.
+
+    A tensor is checked before its address is handed to the kernels -- on the device (the model's),
+    of the element type the kernels read (`dtype`), contiguous, of exactly `numel` elements: a host
+    tensor or a float32 one would otherwise be a GPU fault or silent garbage, not an error.  A raw
+    address (int) is the caller's word."""
     if x is None:
         return None
     if hasattr(x, "data_ptr"):
         if hasattr(x, "is_contiguous") and not x.is_contiguous():
-            raise TypeError("device arrays must be contiguous.")
+            raise TypeError("%s must be contiguous." % what)
+        if hasattr(x, "is_cuda") and not x.is_cuda:
+            raise TypeError("%s must live on the device (got a host tensor)." % what)
+        got = str(getattr(x, "dtype", dtype)).replace("torch.", "")
+        if got != dtype:
+            raise TypeError("%s must be %s (got %s)." % (what, dtype, got))
+        if numel is not None and hasattr(x, "numel") and int(x.numel()) != int(numel):
+            raise ValueError("%s must have %d elements (got %d)." % (what, numel, int(x.numel())))
+        dev = getattr(getattr(x, "device", None), "index", None)
+        if device is not None and dev is not None and int(dev) != int(device):
+            raise ValueError("%s lives on device %d, the model on device %d." % (what, dev, device))
         return x.data_ptr()
     return int(x)
 
@@ -61,9 +78,13 @@ class EStepStream(object):
                 break
             self._up[n] = b.handle.value
             n += 1
+        K, V, B = self._model.num_topics, self._model.num_words, len(batch)
+        dev = getattr(self._model, "_device", None)
         _ffi.check(self._lib.trlda_model_estep_io_ahead(
-            self._model._handle, batch.handle, self._up, n, _address(gamma0), _address(gamma),
-            _address(sstats), int(max_iter), float(threshold), _address(iterations)))
+            self._model._handle, batch.handle, self._up, n,
+            _address(gamma0, "gamma0", K * B, device=dev), _address(gamma, "gamma", K * B, device=dev),
+            _address(sstats, "sstats", K * V, device=dev), int(max_iter), float(threshold),
+            _address(iterations, "iterations", B, dtype="int32", device=dev)))
         self._steps += 1
 
     def flush(self):
@@ -87,6 +108,12 @@ class EStepStream(object):
     def __enter__(self):
         return self
 
-    def __exit__(self, *exc):
-        self.close()
+    def __exit__(self, exc_type, exc, tb):
+        if exc_type is None:
+            self.close()
+            return False
+        try:                                             # (an exception is on its way out of the block:
+            self.close()                                 # a failing flush must not take its place)
+        except Exception:
+            pass
         return False
