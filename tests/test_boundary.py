@@ -484,3 +484,29 @@ def test_stream_rejects_arrays_the_kernels_could_not_read():
     with pytest.raises(ValueError, match="device 1"):
         _address(Fake(12, index=1), "gamma", 12, device=0)
     assert _address(Fake(5, "torch.int32"), "iterations", 5, dtype="int32") == 0x1000
+
+
+def test_no_sgpr_spill_traffic_inside_the_iteration_loop():
+    """the dominant launches spill 131 / 245 scalar registers (saved in the lanes of a
+    VGPR); none of that traffic may sit inside the fixed point's 20x loop (lda.cpp:185-204).  Read off
+    the compiler's assembly (tools/sgpr_spill_scan.py; profiles/r06_sgpr_spills.txt): the innermost
+    iteration loops of the register bodies -- the ones of at most 400 instructions -- hold no
+    v_writelane and no v_readlane from a spill VGPR."""
+    import shutil
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sgpr_spill_scan as scan
+    lines = scan.device_asm()
+    seen = 0
+    for name, body in scan.kernels(lines):
+        if not any(p in name for p in ("estep_docs_reg_deferred_kernelILi0", "estep_docs_tiered_deferred_kernelILi2",
+                                       "estep_docs_reg_merged_kernelILi0", "estep_docs_reg_kernelILi0")):
+            continue
+        r = scan.scan(name, body)
+        tight = [lp for lp in scan.iteration_loops(r) if lp["len"] <= 400 and lp["barriers"] == 4]
+        assert tight, name
+        for lp in tight:
+            assert lp["saves"] == 0 and lp["restores"] == 0, (name, lp)
+        seen += 1
+    assert seen == 4
