@@ -575,19 +575,36 @@ int trlda_model_set_carry_rowsums(trlda_model *model, int carry);
 int trlda_model_set_keep_sstats(trlda_model *model, int keep);
 /* gamma0 of the update entry points (sampleGamma(K, B, 100) / 100, src/lda.cpp:135) is drawn ON
  * THE DEVICE from the host's libc stream -- the same integers in the same order, hence the same
- * uniforms; the device logarithm may differ from glibc's in the last bit (about 1e-16 relative
- * in gamma0) -- and the host stream is advanced by the same number of draws.  host = 1: draw on
- * the host instead, bit for bit the reference's values (K * B * 100 glibc logarithms per call). */
+ * uniforms u, bit for bit -- and the host stream is advanced by the same number of draws.  The
+ * device forms -sum_p log|u_p| as -sum over blocks of 25 passes of log(prod_p |u_p|) (one
+ * logarithm per 25 draws; the product of 25 values > 2^-31 is a normal double): within 4e-15
+ * relative of the host's sum -- which is itself 7e-16 off the exact value, the product form 2e-16
+ * (csrc/rng_kernels.h).  host = 1: draw on the host instead, bit for bit the reference's values
+ * (K * B * 100 glibc logarithms per call). */
 int trlda_model_set_host_gamma_draw(trlda_model *model, int host);
-/* enabled = 1: the device draw of the NEXT fresh gamma0 of the same shape is made ahead, on a
- * stream of the model's own, while the current call's kernels run, with the host stream advanced
- * ahead of its turn.  Whatever else touches the generator first -- trlda_seed, a host draw, another
- * model, another shape -- puts the stream back and the draw is repeated in its turn: the ORDER of
- * draws is the reference's in every case.  Off by default (TRLDA_DRAW_AHEAD=1 turns it on for
- * every model): it gains 5 % (200 documents) to 13 % (1600) of an update without trust-region
- * loop at K = 100 in a process with few streams, and LOSES 20 % where the process has more
- * streams than hardware queues (bench.py beside torch): the second stream then shares a queue. */
+/* The device draw of the NEXT fresh gamma0 of the same shape, made AHEAD of its turn while the current
+ * call's kernels run, with the host stream advanced ahead of its turn.  Whatever else touches the
+ * generator first -- trlda_seed, a host draw, another model, another shape -- puts the stream back
+ * and the draw is repeated in its turn: the ORDER of draws is the reference's in every case
+ * (src/lda.cpp:135, src/utils.cpp:224-231).
+ *   2 (default)  inside the call's document launch: on small tables (K <= 128, <= 224 document
+ *                workgroups) extra workgroups of the launch draw it on the CUs the documents leave
+ *                free (csrc/rng_kernels.h, aux_draw_workgroup) -- no launch, no stream of its own;
+ *                where the launch cannot carry it the draw is made in its turn;
+ *   1            on a stream of the model's own (TRLDA_DRAW_AHEAD=1): gains 13 % at 1600 documents
+ *                without trust-region loop, loses where the process has more streams than hardware
+ *                queues (bench.py beside torch);
+ *   0            every draw in its turn.
+ * The values are bitwise the same in all three. */
 int trlda_model_set_draw_ahead(trlda_model *model, int enabled);
+/* gamma0 draws made inside a document launch so far (tests) */
+long long trlda_model_inlaunch_draws(const trlda_model *model);
+/* OnlineLDA::updateParameters without trust-region loop (src/onlinelda.cpp:103-109): the decay of the
+ * words outside the mini-batch, lambda = (1 - rho) lambda + rho eta, by auxiliary workgroups of the
+ * call's document launch (1, the default; small tables) or by the streaming kernel behind it (0).
+ * Bitwise the same lambda and row sums either way. */
+int trlda_model_set_aux_decay(trlda_model *model, int enabled);
+long long trlda_model_inlaunch_decays(const trlda_model *model);   /* (tests) */
 /* out_dev[rows x cols] = sampleGamma(rows, cols, passes) / divisor (src/utils.cpp:224-231) on
  * the device, as above (divisor 1 for the bare sum). */
 int trlda_model_sample_gamma(trlda_model *model, int rows, int cols, int passes, double divisor,

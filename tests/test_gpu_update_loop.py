@@ -451,8 +451,11 @@ print("RCCL-C-ABI-OK")
                                               (500, 999, 100), (64, 4, 1)])
 def test_device_gamma_draw_is_the_libc_stream(hip, rows, cols, passes):
     """rng_kernels.h against the host draw (tests/test_boundary.py pins THAT one bit for bit
-    against the reference): the same integers in the same order, so only the logarithm's last
-    bit can differ; and the host generator ends up exactly where the host draw leaves it."""
+    against the reference): the same integers in the same order, hence the same uniforms; the device
+    takes ONE logarithm per block of 25 passes (of the product of their |u|, csrc/rng_kernels.h)
+    where the host adds up 100 -- 1.4e-15 apart at most over 2 * 10^5 elements in a NumPy model of
+    both, the device's form the one closer to the exact sum; and the host generator ends up exactly
+    where the host draw leaves it."""
     import trlda_amd
     from trlda_amd import _ffi
     m = online_model(4, 16, random_lambda(4, 16, 1), 10)
@@ -472,7 +475,7 @@ def test_device_gamma_draw_is_the_libc_stream(hip, rows, cols, passes):
         _ffi.check(hip.trlda_dev_download(0, got.ctypes.data, dev, n * 8))
         after_dev = np.empty((3, 3), order="F")
         hip.trlda_sample_gamma(3, 3, 2, after_dev)
-        assert relerr(got, want) < 2e-15, relerr(got, want)
+        assert relerr(got, want) < 4e-15, relerr(got, want)
         assert np.array_equal(after_dev, after_host)
     hip.trlda_dev_free(0, dev)
 
@@ -481,7 +484,7 @@ def test_device_gamma_draw_is_the_libc_stream(hip, rows, cols, passes):
                                                      (37, 53, 7, 30, 100), (37, 53, 30, 53, 128), (100, 224, 0, 224, 100)])
 def test_device_gamma_draw_summed_where_it_is_formed(hip, rows, cols, lo, hi, passes, monkeypatch):
     """draw_sum_kernel (logarithms summed in the workgroup that forms them, windows in segment-major
-    order) against draw_log_kernel + gamma_sum_kernel: the same values subtracted in the same order --
+    order) against draw_abs_kernel + gamma_sum_kernel: the same products and logarithms in the same order --
     bitwise equal, whole matrices and a data-parallel rank's columns, element counts that are and are
     not multiples of the segment length."""
     import trlda_amd
@@ -504,7 +507,8 @@ def test_device_gamma_draw_summed_where_it_is_formed(hip, rows, cols, lo, hi, pa
 
 
 def test_device_draw_keeps_the_early_exits_at_baseline_size(hip):
-    """The device's gamma0 can differ from glibc's in the last bit of a logarithm (<= 2e-15): at
+    """The device's gamma0 differs from the host's in the last bits (<= 4e-15: one logarithm per 25
+    passes, test_device_gamma_draw_is_the_libc_stream): at
     BASELINE's headline size that must not flip a document's early exit (lda.cpp:202-203) --
     eight mini-batches of 200 documents at K = 100, V = 7000 on a peaked lambda, 300 iterations
     allowed: iteration counts equal document by document, gamma within 1e-10; and eight
@@ -527,7 +531,7 @@ def test_device_draw_keeps_the_early_exits_at_baseline_size(hip):
         _ffi.check(hip.trlda_model_synchronize(m._handle))
         g_dev = np.empty((K, B), order="F")
         _ffi.check(hip.trlda_dev_download(0, g_dev.ctypes.data, dev, K * B * 8))
-        assert relerr(g_dev, g_host) < 2e-15
+        assert relerr(g_dev, g_host) < 4e-15
         a = m.update_variables(docs, latents=g_host, max_iter=300, return_iterations=True)
         b = m.update_variables(docs, latents=g_dev, max_iter=300, return_iterations=True)
         assert np.array_equal(a[2], b[2]), i
@@ -553,7 +557,7 @@ def test_gamma_drawn_ahead_keeps_the_order_of_draws(hip, oracle):
     """The next update's gamma0 is drawn ahead on a stream of its own with the host stream
     advanced before its turn (trlda_model_set_draw_ahead): whatever touches the generator in
     between -- a host draw, a seed, another model, another batch size, a lower bound -- the
-    ORDER of draws stays the reference's (the switch is off by default; here it is forced): the same sequence of calls with drawing ahead on and
+    ORDER of draws stays the reference's: the same sequence of calls with drawing ahead on and
     off ends at bitwise the same lambda, gamma and generator state, for OnlineLDA (with and
     without the trust-region loop), BatchLDA epochs and CumulativeLDA."""
     import trlda_amd
@@ -604,6 +608,59 @@ def test_gamma_drawn_ahead_keeps_the_order_of_draws(hip, oracle):
     on, off = run(1), run(0)
     for a, b in zip(on, off):
         assert np.array_equal(np.asarray(a), np.asarray(b))
+    # ... and drawn ahead INSIDE the call's document launch (mode 2, the default since round 6:
+    # csrc/rng_kernels.h, aux_draw_workgroup): the same sequence, bitwise
+    inside = run(2)
+    for a, b in zip(inside, off):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+@pytest.mark.parametrize("K,V,B", [(100, 7000, 200), (60, 900, 33), (128, 3000, 224), (2, 300, 5), (100, 2000, 97)])
+def test_gamma_drawn_inside_the_document_launch(hip, K, V, B):
+    """Round 6: extra workgroups of an update call's merged document launch draw the NEXT fresh
+    gamma0 (lda.cpp:135) -- per workgroup its own chunks of 124 elements, windows by jump matrices
+    of the chunk stride and of K * B, the walk in registers.  Against every draw in its turn: bitwise
+    the same gamma0 (read back through update trajectories), lambda and generator state, with and
+    without the trust-region loop, with a draw per iteration, and with a batch of another size in
+    between (the speculation is dropped and repeated in its turn); and the launches did carry draws."""
+    import trlda_amd
+    D = 50000
+    lam0 = random_lambda(K, V, 17)
+    batches = [corpus(B, V, seed=400 + i, mean_unique=min(60, V // 6)) for i in range(6)]
+    odd = corpus(max(1, B // 2), V, seed=399, mean_unique=min(60, V // 6))
+
+    def run(mode):
+        trlda_amd.seed(321)
+        m = online_model(K, V, lam0, D)
+        assert hip.trlda_model_set_draw_ahead(m._handle, mode) == 0
+        out = []
+        m.update_parameters(batches[0], max_iter_tr=0, max_iter_inference=20)
+        m.update_parameters(batches[1], max_iter_tr=0, max_iter_inference=20)
+        out.append(m.lambdas)
+        m.update_parameters(batches[2], max_iter_tr=3, max_iter_inference=20)
+        m.update_parameters(batches[3], max_iter_tr=2, max_iter_inference=20, init_gamma=False)
+        out.append(m.lambdas)
+        m.update_parameters(odd, max_iter_tr=0, max_iter_inference=20)      # another shape: not claimed
+        m.update_parameters(batches[4], max_iter_tr=1, max_iter_inference=20)
+        g, _ = m.update_variables(batches[5], max_iter=10)                    # a fresh gamma0 of the same shape
+        out += [m.lambdas, g]
+        drawn = hip.trlda_model_inlaunch_draws(m._handle)
+        state = np.zeros(33, dtype=np.uint32)
+        hip.trlda_rng_get_state(state)
+        out.append(state)
+        m.close()
+        return out, drawn
+
+    (inside, n_in), (turn, n_turn) = run(2), run(0)
+    assert n_turn == 0
+    if B == 224:
+        # 28 free CUs, 232 chunks: nine a workgroup -- drawn in its turn; only the launch of the
+        # half-sized batch carries a draw (for ITS shape: never claimed)
+        assert n_in == 1, n_in
+    else:
+        assert n_in >= 5, n_in              # (the launches of this shape carry them)
+    for a, b in zip(inside, turn):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
 
 
 def test_host_gamma_draw_switch_gives_the_same_update(hip):
@@ -647,7 +704,7 @@ def test_device_gamma_draw_of_a_column_range(hip):
         _ffi.check(hip.trlda_dev_download(0, got.ctypes.data, dev, n * 8))
         hip.trlda_dev_free(0, dev)
         if hi > lo:
-            assert relerr(got[:, :hi - lo], want[:, lo:hi]) < 2e-15, (lo, hi)
+            assert relerr(got[:, :hi - lo], want[:, lo:hi]) < 4e-15, (lo, hi)
         after = np.empty((2, 2), order="F")
         hip.trlda_sample_gamma(2, 2, 3, after)
         assert np.array_equal(after, after_host), (lo, hi)
@@ -831,3 +888,43 @@ def test_deferred_empirical_bayes_step_changes_nothing(hip):
     (a0, e0, l0), (a1, e1, l1) = results
     assert np.array_equal(a0, a1) and e0 == e1 and np.array_equal(l0, l1)
     assert np.all(a0 != .1) and e0 != .3
+
+
+@pytest.mark.parametrize("K,V,B", [(100, 7000, 200), (60, 900, 33), (128, 3000, 150), (2, 300, 5), (64, 20000, 100)])
+def test_decay_of_the_inactive_words_inside_the_document_launch(hip, K, V, B):
+    """Round 6: in update_parameters(max_iter_tr=0) (onlinelda.cpp:103-109) the words outside the
+    mini-batch decay, lambda = (1 - rho) lambda + rho eta, by auxiliary workgroups of the document
+    launch -- inactive_update_stream_kernel's 1024-thread blocks gone through by 512 threads, the same
+    per-thread sums in the same slot order -- instead of a kernel behind it: bitwise the same lambda
+    after every call of a chain (the chain also carries the row sums into the next E-step), the
+    same gamma of an E-step on the result; and the launches did carry the pass."""
+    import trlda_amd
+    D = 30000
+    lam0 = random_lambda(K, V, 23)
+    batches = [corpus(B, V, seed=600 + i, mean_unique=min(60, V // 6)) for i in range(5)]
+    res = []
+    for aux in (1, 0):
+        trlda_amd.seed(55)
+        m = online_model(K, V, lam0, D)
+        assert hip.trlda_model_set_aux_decay(m._handle, aux) == 0
+        out = []
+        for i in range(4):
+            m.update_parameters(batches[i], max_iter_tr=0, max_iter_inference=20)
+            out.append(m.lambdas)
+        m.update_parameters(batches[4], max_iter_tr=2, max_iter_inference=20)
+        m.update_parameters(batches[0], max_iter_tr=0, max_iter_inference=20, rho=1.)   # a = 0: not carried
+        out.append(m.lambdas)
+        g0 = np.asfortranarray(np.random.RandomState(3).gamma(1., 1., (K, B)))
+        out.append(m.update_variables(batches[1], latents=g0, max_iter=10)[0])
+        n = hip.trlda_model_inlaunch_decays(m._handle)
+        assert (n >= 4) if aux else (n == 0), (aux, n)
+        res.append(out)
+        m.close()
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+    # against the oracle's M-step on untouched words: lambda = (1 - rho) lambda0 + rho eta after call 1
+    ids = np.unique(batches[0].ids)
+    untouched = np.setdiff1d(np.arange(V), ids)
+    rho = 100. ** -.7                                          # tau = 100, kappa = .7, the first update
+    if untouched.size:
+        assert relerr(res[0][0][:, untouched], (1. - rho) * lam0[:, untouched] + rho * .3) < 1e-14

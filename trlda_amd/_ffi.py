@@ -67,6 +67,9 @@ _SIGNATURES = {
     "trlda_model_synchronize": (C.c_int, [vp]),
     "trlda_model_set_split_docs": (C.c_int, [vp, C.c_int]),
     "trlda_model_set_draw_ahead": (C.c_int, [vp, C.c_int]),
+    "trlda_model_inlaunch_draws": (C.c_longlong, [vp]),
+    "trlda_model_set_aux_decay": (C.c_int, [vp, C.c_int]),
+    "trlda_model_inlaunch_decays": (C.c_longlong, [vp]),
     "trlda_model_dp_direct_alloc": (C.c_int, [vp, C.c_size_t, C.c_int, vp]),
     "trlda_model_dp_direct_connect": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "trlda_model_dp_direct_close": (C.c_int, [vp]),

@@ -37,6 +37,8 @@
 #pragma once
 #include "estep_kernels.h"
 #include "estep_wide.h"
+#include "rng_kernels.h"
+#include "stream_kernels.h"
 
 namespace trlda {
 
@@ -94,18 +96,49 @@ struct MergedArgs {
                                   // counted] per document workgroup from 3 * 512 on
 };
 
+// AUXILIARY workgroups of a merged launch (round 6): work of the CALL that does not depend on this
+// launch's documents, on the CUs the documents leave free, in front of the statistics workgroups in
+// the grid (which only wait there): the NEXT fresh gamma0 (rng_kernels.h, aux_draw_workgroup).
+// Nothing in the launch waits for them; what they write is read by later kernels of the stream.
+// ... and, in an update call without trust-region loop (onlinelda.cpp:103-109), the decay of the words
+// OUTSIDE the mini-batch, lambda[:, w] = (1 - rho) lambda[:, w] + rho eta: inactive_update_stream_kernel's
+// job (stream_kernels.h, ACT_KEEP), whose 1024-thread workgroups a 512-thread one goes through slot
+// group by slot group -- the same per-thread sums, added up in the same slot order: bitwise the same
+// lambda and the same block rows of its row sums.  (The launch's own preamble has read the old lambda
+// in an earlier kernel; the documents read exp(psi(lambda)), the M-step the ACTIVE columns.)
+struct AuxInactiveArgs {
+    int n_vb;                     // the stream kernel's grid: items (0: none in this launch)
+    int K, V, P, cpb;             // stream_geometry(K, V): vec = 2 (K even)
+    double a, b;                  // lambda = a * lambda + b
+    const uint8_t *active_flag;   // V bytes
+    double *lambda;
+    double *part_static;          // n_vb x K: block rows of the inactive words' row sums
+};
+
+struct AuxArgs {
+    int n;                        // workgroups [first - n, first) of the grid, counted from the first document
+    int n_items;                  // draw.n + inact.n_vb; workgroup v starts with item v, the counter hands
+    unsigned int *work_counter;   // out the items from n on (it only grows: work_base at the launch's start)
+    unsigned int work_base;
+    AuxDrawArgs draw;             // items [0, draw.n)
+    AuxInactiveArgs inact;        // items [draw.n, n_items)
+};
+
 // The kernel's arguments (~700 bytes: three structures) are fetched where they are first used, a
 // scalar load and a wait at a time -- in the helper's path ten of them one behind the other, each a
 // miss in the scalar cache: ~3 us before a helper's first item (profiles/r05_deferred_notes.txt:
 // documents start 0.2 us into the launch, helpers 3.2).  One word of every 64-byte line of the
 // argument segment, all requested at once, brings the lines into the scalar cache.
+template <bool AUX = false>
 __device__ __forceinline__ void warm_kernel_arguments()
 {
     // (the deferred kernels' explicit arguments: 696 bytes in the code object's metadata, the tiered
-    // one with its extra int; eleven lines = 704 bytes, none of them past the segment's last line)
+    // one with its extra int; eleven lines = 704 bytes, none of them past the segment's last line;
+    // AUX: the merged kernels' AuxArgs behind them -- four more lines)
     static_assert(sizeof(DocKernelArgs) + sizeof(PreArgs) + sizeof(MergedArgs) <= 11 * 64 &&
                       sizeof(DocKernelArgs) + sizeof(PreArgs) + sizeof(MergedArgs) > 10 * 64,
                   "eleven lines cover the argument segment and none lies beyond it");
+    static_assert(sizeof(AuxArgs) > 4 * 64 - 8, "the four extra lines of the merged kernels lie inside AuxArgs");
     typedef __attribute__((address_space(4))) const unsigned int *karg_ptr;
     karg_ptr kp = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     unsigned int r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10;
@@ -126,6 +159,17 @@ __device__ __forceinline__ void warm_kernel_arguments()
                    "=&s"(r8), "=&s"(r9), "=&s"(r10)
                  : "s"(kp)
                  : "memory");
+    if constexpr (AUX) {
+        unsigned int a0, a1, a2, a3;
+        asm volatile("s_load_dword %0, %4, 0x2c0\n\t"
+                     "s_load_dword %1, %4, 0x300\n\t"
+                     "s_load_dword %2, %4, 0x340\n\t"
+                     "s_load_dword %3, %4, 0x380\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(a0), "=&s"(a1), "=&s"(a2), "=&s"(a3)
+                     : "s"(kp)
+                     : "memory");
+    }
 }
 
 // ---- the document side --------------------------------------------------------------------
@@ -497,18 +541,88 @@ __device__ __forceinline__ void merged_doc_stamp(const MergedArgs &mg, int which
 }
 
 // Grid of a merged launch: [0, n_comb) topic factors | documents | the next batch's preamble
-// (pre.nb) | statistics (n_short + n_long).  Workgroups are dispatched in this order, and nothing
+// (pre.nb) | auxiliary work of the call (aux.n) | statistics (n_short + n_long).  Workgroups are dispatched in this order, and nothing
 // waits for anything behind it: the topic-factor workgroups wait for nothing, a document only for
 // them, a statistics workgroup only for the documents.  So a merged launch ends whatever part of it
 // is resident at a time -- on a device with fewer CUs than document workgroups, or beside another
 // stream's kernels, it is slower, never stuck (round 4 had the topic factors BEHIND the
 // documents and relied on every document being resident at once).
+// one block of inactive_update_stream_kernel<1024, 2, ACT_KEEP, false> by 512 threads
+__device__ __forceinline__ void aux_inactive_block(const AuxInactiveArgs &x, int vb, double *scratch)
+{
+    constexpr int U = kStreamUnroll, T = kRegThreads;
+    const int K = x.K, P = x.P, cpb = x.cpb;
+    const int spp = T / P;                           // slots per pass (>= 8: P <= 64)
+    const int sl = threadIdx.x / P, kp = threadIdx.x - sl * P;
+    const int m = x.n_vb * cpb;
+    const size_t off = (size_t)kp * 2;
+    for (int s0 = 0; s0 < cpb; s0 += spp) {          // block-uniform
+        const int slot = s0 + sl;
+        if (sl < spp && slot < cpb) {
+            double acc0 = 0.0, acc1 = 0.0;
+            for (int col = vb * cpb + slot; col < x.V; col += U * m) {
+                double2 v[U];
+                bool fl[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    fl[u] = x.active_flag[min(col + u * m, x.V - 1)] != 0;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    v[u] = make_double2(0.0, 0.0);
+                    if (!fl[u] && col + u * m < x.V)
+                        v[u] = vload_nt<2>(x.lambda + (size_t)(col + u * m) * K + off);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int c = col + u * m;
+                    if (c < x.V && !fl[u]) {
+                        const double y0 = fma(x.a, v[u].x, x.b), y1 = fma(x.a, v[u].y, x.b);   // (as the stream kernel compiles)
+                        acc0 += y0;
+                        acc1 += y1;
+                        *reinterpret_cast<double2 *>(x.lambda + (size_t)c * K + off) = make_double2(y0, y1);
+                    }
+                }
+            }
+            scratch[slot * K + kp * 2] = acc0;
+            scratch[slot * K + kp * 2 + 1] = acc1;
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += T) {       // (the slots in slot order: stream_block_partial)
+        double sum = scratch[k];
+        for (int q = 1; q < cpb; ++q)
+            sum += scratch[q * K + k];
+        x.part_static[(size_t)vb * K + k] = sum;
+    }
+}
+
+// the auxiliary workgroups: [first - aux.n, first)
+__device__ __forceinline__ void merged_aux(const AuxArgs &aux, double *lds, int v)
+{
+    __shared__ unsigned int aux_next;
+    int item = v;
+    while (item < aux.n_items) {                     // block-uniform
+        unsigned int fetched = 0u;
+        if (threadIdx.x == 0)                        // (the next item: requested now, needed at the end)
+            fetched = __hip_atomic_fetch_add(aux.work_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (item < aux.draw.n)
+            aux_draw_workgroup<kRegThreads>(aux.draw, item, lds);
+        else
+            aux_inactive_block(aux.inact, item - aux.draw.n, lds);
+        if (threadIdx.x == 0)
+            aux_next = fetched - aux.work_base + (unsigned int)aux.n;
+        __syncthreads();
+        item = (int)aux_next;
+        __syncthreads();
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_merged_kernel(DocKernelArgs a, PreArgs pre,
-                                                                             MergedArgs mg)
+                                                                             MergedArgs mg, AuxArgs aux)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    warm_kernel_arguments();
+    warm_kernel_arguments<true>();
     if ((int)blockIdx.x < mg.n_comb) {               // block-uniform
         merged_combine(mg, (int)blockIdx.x, lds);
         return;
@@ -516,6 +630,10 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_merged_kernel(DocK
     const int rel = (int)blockIdx.x - mg.n_comb;     // == doc_block(a): a.block0 = mg.n_comb
     if (rel >= mg.first) {
         merged_helper(mg, lds, rel - mg.first);
+        return;
+    }
+    if (rel >= mg.first - aux.n) {
+        merged_aux(aux, lds, rel - (mg.first - aux.n));
         return;
     }
     if (rel >= pre.n_docs) {
@@ -531,10 +649,11 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_merged_kernel(DocK
 
 template <int KS>
 __global__ __launch_bounds__(kRegThreads) void estep_docs_tiered_merged_kernel(DocKernelArgs a, PreArgs pre,
-                                                                                int lds_rows, MergedArgs mg)
+                                                                                int lds_rows, MergedArgs mg,
+                                                                                AuxArgs aux)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    warm_kernel_arguments();
+    warm_kernel_arguments<true>();
     if ((int)blockIdx.x < mg.n_comb) {               // block-uniform
         merged_combine(mg, (int)blockIdx.x, lds);
         return;
@@ -542,6 +661,10 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_tiered_merged_kernel(D
     const int rel = (int)blockIdx.x - mg.n_comb;
     if (rel >= mg.first) {
         merged_helper(mg, lds, rel - mg.first);
+        return;
+    }
+    if (rel >= mg.first - aux.n) {
+        merged_aux(aux, lds, rel - (mg.first - aux.n));
         return;
     }
     if (rel >= pre.n_docs) {

@@ -13,15 +13,23 @@
 //   / window_direct_kernel  radix 16: W_(d 16^l + r) = M[l][d] W_r, one matrix-vector product per
 //                         segment and level (M[l][d] = A^(d 16^l L): 15 matrices per level,
 //                         computed once on the host)
-//   draw_log_kernel       one thread per segment walks its L draws (window in LDS, a rotating
-//                         index) and stores log|u| of every draw -- the same integers, hence
-//                         the same u, as the host stream; the device logarithm may differ from
-//                         glibc's in the last bit
-//   gamma_sum_kernel      out[i] -= log|u_{p,i}| for p = 0, 1, .. in pass order (the host's
-//                         order of subtractions), and the final division by 100
+//   draw_abs_kernel       one thread per segment walks its L draws (window in LDS, a rotating
+//                         index) and stores |u| of every draw -- the same integers, hence the
+//                         same u, bit for bit, as the host stream
+//   gamma_sum_kernel      out[i] = -sum over blocks of kRngProductPasses passes of
+//                         log(prod_p |u_{p,i}|), and the final division by 100
 //
-// Results equal the host draw to ~1e-16 relative per term; the generator state after the call
-// is the host stream's, exactly (the host advances it by the same number of draws).
+// The logarithm of a PRODUCT (round 6): -sum_p log|u_p| is 100 logarithms per element -- 35 of
+// the ~55 instructions a draw costs -- where the gamma0 of a mini-batch is 2 * 10^6 draws per
+// update call.  |u| >= 1 / RAND_MAX > 2^-31, so the product of 25 draws is a normal number
+// (> 2^-775) and -log(prod) needs ONE logarithm per 25 draws.  Against the exact sum the product
+// form is the more accurate one (each multiplication rounds once, 25 x 1.1e-16 relative on the
+// product = 2.8e-15 ABSOLUTE on its logarithm, where the reference's running sum rounds to
+// ulp(100) / 2 = 7e-15 a hundred times): measured against 50-digit arithmetic the reference's own
+// sum is off by up to 7.3e-16 relative, this form by 2.1e-16; the two differ by at most 1.4e-15
+// over 2 * 10^5 elements (tests: < 4e-15 against the host draw, which is the reference's bit for
+// bit).  The integers -- and the generator state after the call -- are the host stream's, exactly
+// (the host advances it by the same number of draws).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -40,6 +48,9 @@ constexpr int kRngSegmentTiny = 32;   // a mini-batch of 200 documents at K = 10
 constexpr long long kRngTinyDraws = (long long)1 << 22;
 constexpr int kRngLevels = 8;         // 16^8 segments: more than any table needs
 constexpr int kRngThreads = 256;
+constexpr int kRngProductPasses = 25; // passes whose |u| are multiplied before ONE logarithm: 25 x 31 bits
+                                      // of exponent stay a normal double (see above); blocks are counted
+                                      // from pass 0, whatever groups of passes a request is worked off in
 
 // u = -1 + 2 rand() / RAND_MAX (utils.cpp:224-231) from the generator's word v (rand() = v >> 1):
 // the host's expression with its IEEE division -- which the compiler expands into a dozen
@@ -208,13 +219,13 @@ __global__ __launch_bounds__(T) void window_walk_kernel(long long S, long long S
 }
 
 // positions [pos_lo, pos_hi) of the stream (a whole number of passes of `total` elements);
-// vbuf[pos - pos_lo] = log|u|.  A data-parallel rank needs the elements [e_lo, e_hi) of every
+// vbuf[pos - pos_lo] = |u|.  A data-parallel rank needs the elements [e_lo, e_hi) of every
 // pass only (its own documents' columns): segments that hold none of them do nothing (the
 // others write all of their draws: vbuf is scratch).  A thread's draws are consecutive
 // positions, so a wave's stores would be 64 separate 8-byte writes 8 L bytes apart: eight
 // draws at a time go through an LDS tile and leave as 64-byte runs, eight per store instruction.
 template <int T, int L>
-__global__ __launch_bounds__(T) void draw_log_kernel(long long S, long long seg_lo, long long seg_hi,
+__global__ __launch_bounds__(T) void draw_abs_kernel(long long S, long long seg_lo, long long seg_hi,
                                                      long long pos_lo, long long pos_hi, long long total,
                                                      long long e_lo, long long e_hi,
                                                      const uint32_t *__restrict__ win,
@@ -250,10 +261,8 @@ __global__ __launch_bounds__(T) void draw_log_kernel(long long S, long long seg_
             x[f * T + threadIdx.x] = v;
             f = f == 30 ? 0 : f + 1;
             b = b == 30 ? 0 : b + 1;
-            // the host's u (unit_draw); |u| is a normal number in [4.6e-10, 1]: the short logarithm
-            // of psi.h (within an ulp of the library's, a third of its instructions)
-            const double u = unit_draw(v);
-            mine[q] = log_normal(fabs(u));
+            // the host's u (unit_draw); |u| is a normal number in [4.6e-10, 1]
+            mine[q] = fabs(unit_draw(v));
         }
         // (LDS traffic of one wave is in order: no barrier between the writes and these reads)
 #pragma unroll
@@ -268,18 +277,48 @@ __global__ __launch_bounds__(T) void draw_log_kernel(long long S, long long seg_
     }
 }
 
-// draw_log_kernel and gamma_sum_kernel in one (round 4), for requests of at most kRngFusedPasses
+// draw_abs_kernel and gamma_sum_kernel in one (round 4), for requests of at most kRngFusedPasses
 // passes whose fine windows come from the walk: a workgroup owns 32 consecutive ELEMENTS and all
 // their passes.  Pass p of element i is draw p * total + i, so the workgroup needs, of every pass, the
 // 32 draws from p * total + i0 on: those of one segment when that position is a multiple of the
 // segment length, of two otherwise -- thread (h, p) walks segment h of pass p in full (a segment's
-// draws come one after the other) and leaves log|u| of the draws that are the workgroup's in an LDS
-// tile; 32 lanes then subtract their element's passes in pass order and divide, as
-// gamma_sum_kernel does: the same values in the same order, bit for bit, without the round trip
-// of passes x total logarithms through memory and without the launch.
+// draws come one after the other) and leaves |u| of the draws that are the workgroup's in an LDS
+// tile; 32 lanes then multiply their element's passes block by block, subtract the blocks'
+// logarithms and divide, as gamma_sum_kernel does: the same values in the same order, bit for bit,
+// without the round trip of passes x total values through memory and without the launch.
 // Windows in segment-major order here (win[s * 32 + j]: a thread's 31 words are one 124-byte run;
 // threads of a wave are total / 32 segments apart).
 constexpr int kRngFusedPasses = 128;
+
+// acc - sum over the blocks of kRngProductPasses passes of log(prod |u|), passes [0, passes) at
+// v[p * stride] (the FIRST of them is pass `p_first` of the request: blocks are counted from pass 0,
+// so p_first is a multiple of the block length), divided by `divisor` (1: not at all).  The block's
+// values are requested together and multiplied in pass order.
+__device__ __forceinline__ double gamma_from_abs(const double *v, size_t stride, int passes, int p_first,
+                                                 double acc, double divisor)
+{
+    constexpr int R = kRngProductPasses;
+    (void)p_first;
+    int q0 = 0;
+    for (; q0 + R <= passes; q0 += R) {
+        double x[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q)
+            x[q] = v[(size_t)(q0 + q) * stride];
+        double prod = x[0];
+#pragma unroll
+        for (int q = 1; q < R; ++q)
+            prod *= x[q];
+        acc -= log_normal(prod);
+    }
+    if (q0 < passes) {
+        double prod = v[(size_t)q0 * stride];
+        for (int q = q0 + 1; q < passes; ++q)
+            prod *= v[(size_t)q * stride];
+        acc -= log_normal(prod);
+    }
+    return divisor != 1.0 ? acc / divisor : acc;
+}
 
 // The launch has kRngFusedPasses threads per workgroup when every pass's share of a chunk is ONE
 // segment (total and e_lo multiples of the segment length), twice that otherwise; LDS (dynamic):
@@ -321,31 +360,17 @@ __global__ __launch_bounds__(2 * kRngFusedPasses) void draw_sum_kernel(
             const double u = unit_draw(v);
             const int e = e_first + q;
             if (on && e >= 0 && e < n_e)
-                vals[p * 33 + e] = log_normal(fabs(u));
+                vals[p * 33 + e] = fabs(u);
         }
     }
     __syncthreads();
-    if ((int)threadIdx.x < n_e) {
-        double acc = 0.0;
-        int q0 = 0;
-        for (; q0 + 20 <= passes; q0 += 20) {        // (in gamma_sum_kernel's order)
-            double v[20];
-#pragma unroll
-            for (int q = 0; q < 20; ++q)
-                v[q] = vals[(q0 + q) * 33 + threadIdx.x];
-#pragma unroll
-            for (int q = 0; q < 20; ++q)
-                acc -= v[q];
-        }
-        for (; q0 < passes; ++q0)
-            acc -= vals[q0 * 33 + threadIdx.x];
-        out[i0 - e_lo + threadIdx.x] = divisor != 1.0 ? acc / divisor : acc;
-    }
+    if ((int)threadIdx.x < n_e)
+        out[i0 - e_lo + threadIdx.x] = gamma_from_abs(vals + threadIdx.x, 33, passes, 0, 0.0, divisor);
 }
 
-// passes [p0, p1) of `total` elements each, elements [e_lo, e_hi): out[i - e_lo] = (first ? 0 :
-// out[i - e_lo]) - sum_p vbuf[p][i], subtracted in pass order; the last group divides by
-// `divisor` (1 for none)
+// passes [p0, p1) of `total` elements each (p0 a multiple of kRngProductPasses), elements [e_lo, e_hi):
+// out[i - e_lo] = (first ? 0 : out[i - e_lo]) - sum over the blocks of log(prod_p vbuf[p][i]); the last
+// group divides by `divisor` (1 for none)
 template <int T>
 __global__ __launch_bounds__(T) void gamma_sum_kernel(long long total, long long e_lo, long long e_hi,
                                                       int passes, int first, double divisor,
@@ -356,20 +381,174 @@ __global__ __launch_bounds__(T) void gamma_sum_kernel(long long total, long long
     if (i >= e_hi)
         return;
     out += -e_lo;
-    double acc = first ? 0.0 : out[i];
-    int p = 0;
-    for (; p + 20 <= passes; p += 20) {              // twenty loads in flight, subtracted in order
-        double v[20];
+    out[i] = gamma_from_abs(vbuf + i, (size_t)total, passes, 0, first ? 0.0 : out[i], divisor);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The NEXT fresh gamma0 drawn inside a document launch (round 6; estep_merged.h, AuxArgs).
+//
+// An update call's document launch leaves ~50 CUs without a document for ~35 us, and the gamma0 of
+// the next fresh E-step needs nothing but the generator's state -- so `n` extra workgroups of the
+// launch draw it, each on its own: workgroup j owns `cpw` consecutive chunks of kAuxChunk = 4 x 31
+// elements from element j * cpw * kAuxChunk on.  Nothing is handed from workgroup to workgroup:
+//   1. the window at the workgroup's first element, W = A^(j stride) W0 (stride = cpw * kAuxChunk:
+//      two radix-16 digits of j, the matrices of `stride`, 32 lanes);
+//   2. the pass windows A^(p total) W, p < passes <= 128: V(d1) = M[1][d1] W (8 groups of 32 lanes),
+//      then W_p = M[0][p & 15] V(p >> 4) (16 groups a round): ~passes + 8 matrix-vector products where
+//      positions taken digit by digit would be six per window;
+//   3. thread (p, h) = (tid & 127, tid >> 7) walks pass p from its window IN REGISTERS -- 31 steps
+//      bring the rotating window back to where it was, so every register index is a constant:
+//      h blocks of 31 skipped, then per chunk 31 draws (|u| into the LDS tile [pass][element]) and
+//      93 skipped;
+//   4. thread (e, g) multiplies block g of 25 passes of element e and takes its logarithm; thread e
+//      subtracts the four and divides -- gamma_from_abs's sequence of operations, so the values are
+//      bitwise those of draw_sum_kernel / gamma_sum_kernel.
+// LDS: the tile (passes x 125 doubles), the pass windows (128 x 33 words), 8 x 32 + 32 words and
+// 4 x 128 doubles: 122 kB at 100 passes, inside the document launch's 154 kB.
+constexpr int kAuxBlock = 31;                     // draws per register block
+constexpr int kAuxChunk = 4 * kAuxBlock;          // elements a workgroup finishes per step (4 threads a pass)
+constexpr int kAuxTileStride = kAuxChunk + 1;
+constexpr int kAuxMaxPasses = 4 * kRngProductPasses;   // four logarithm blocks, one per thread group
+
+struct AuxDrawArgs {
+    int n;                        // workgroups (0: no draw in this launch)
+    int passes, cpw;              // passes <= kAuxMaxPasses; chunks per workgroup
+    long long total;              // elements per pass (all of them are drawn)
+    double divisor;
+    double *out;                  // total doubles
+    const uint32_t *mt_stride;    // 2 x 15 transposed matrices A^(d 16^l stride)
+    const uint32_t *mt_total;     // 2 x 15 transposed matrices A^(d 16^l total)
+    RngSeedWindow w0;             // the generator's window at the request's first draw
+};
+
+// acc_i = sum_j M[i][j] line[j] by lane `row` of a group of 32 (Mt: the transposed matrix, so the
+// lanes of a group read consecutive words)
+__device__ __forceinline__ uint32_t aux_matvec(const uint32_t *__restrict__ Mt, const uint32_t *line, int row)
+{
+    uint32_t m[31];
 #pragma unroll
-        for (int q = 0; q < 20; ++q)
-            v[q] = vbuf[(size_t)(p + q) * total + i];
+    for (int j = 0; j < 31; ++j)
+        m[j] = Mt[j * 31 + row];
+    uint32_t acc = 0;
 #pragma unroll
-        for (int q = 0; q < 20; ++q)
-            acc -= v[q];
+    for (int j = 0; j < 31; ++j)
+        acc += m[j] * line[j];
+    return acc;
+}
+
+template <int T>
+__device__ __forceinline__ void aux_draw_workgroup(const AuxDrawArgs &x, int j, double *lds)
+{
+    static_assert(T == 512, "four threads a pass, 128 passes");
+    const int tid = threadIdx.x;
+    const int row = min(tid & 31, 30), grp = tid >> 5;
+    double *tile = lds;                                                        // passes x kAuxTileStride
+    double *lgs = tile + (size_t)kAuxMaxPasses * kAuxTileStride;               // 4 x 128
+    uint32_t *pwin = reinterpret_cast<uint32_t *>(lgs + 4 * 128);              // 128 x 33
+    uint32_t *vwin = pwin + 128 * 33;                                          // 8 x 32
+    uint32_t *base = vwin + 8 * 32;                                            // 32
+    const long long e0 = (long long)j * x.cpw * kAuxChunk;
+    // 1. W = A^(j stride) W0
+    if (grp == 0) {                                  // (the 32 lanes of a group are one half of a wave:
+        uint32_t w = x.w0.w[row];                    //  LDS traffic of a wave is in order, no barrier)
+        const int d0 = j & 15, d1 = (j >> 4) & 15;
+        if (d0) {
+            base[tid] = w;
+            __builtin_amdgcn_wave_barrier();
+            w = aux_matvec(x.mt_stride + (size_t)(d0 - 1) * 961, base, row);
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (d1) {
+            base[tid] = w;
+            __builtin_amdgcn_wave_barrier();
+            w = aux_matvec(x.mt_stride + (size_t)(15 + d1 - 1) * 961, base, row);
+            __builtin_amdgcn_wave_barrier();
+        }
+        base[tid] = w;
     }
-    for (; p < passes; ++p)
-        acc -= vbuf[(size_t)p * total + i];
-    out[i] = divisor != 1.0 ? acc / divisor : acc;
+    __syncthreads();
+    // 2. V(d1) = A^(16 d1 total) W, then W_p = A^((p & 15) total) V(p >> 4)
+    if (grp < 8) {
+        const uint32_t w = grp ? aux_matvec(x.mt_total + (size_t)(15 + grp - 1) * 961, base, row) : base[row];
+        vwin[grp * 32 + (tid & 31)] = w;
+    }
+    __syncthreads();
+    for (int p = grp; p < x.passes; p += T / 32) {
+        const int d0 = p & 15, d1 = p >> 4;
+        const uint32_t w = d0 ? aux_matvec(x.mt_total + (size_t)(d0 - 1) * 961, vwin + d1 * 32, row)
+                              : vwin[d1 * 32 + row];
+        if ((tid & 31) < 31)
+            pwin[p * 33 + (tid & 31)] = w;
+    }
+    __syncthreads();
+    // 3. the walk: thread (p, h)
+    const int p = tid & 127, h = tid >> 7;
+    const bool on = p < x.passes;
+    uint32_t r[31];
+#pragma unroll
+    for (int q = 0; q < 31; ++q)
+        r[q] = on ? pwin[p * 33 + q] : 0u;
+    for (int s = 0; s < h; ++s) {
+#pragma unroll
+        for (int t = 0; t < kAuxBlock; ++t)          // s_n = s_(n-31) + s_(n-3): the oldest word becomes the newest
+            r[t] += r[(t + 28) % 31];
+    }
+    for (int c = 0; c < x.cpw; ++c) {                // block-uniform
+        const long long ec = e0 + (long long)c * kAuxChunk;
+        if (ec >= x.total)
+            break;
+        const int n_e = (int)min((long long)kAuxChunk, x.total - ec);
+#pragma unroll
+        for (int t = 0; t < kAuxBlock; ++t) {
+            r[t] += r[(t + 28) % 31];
+            const int e = kAuxBlock * h + t;
+            if (on && e < n_e)
+                tile[(size_t)p * kAuxTileStride + e] = fabs(unit_draw(r[t]));
+        }
+        __syncthreads();
+        // 4. thread (e, g): block g of the element's passes
+        {
+            const int e = tid & 127, g = tid >> 7;
+            const int q0 = g * kRngProductPasses, qn = min(kRngProductPasses, x.passes - q0);
+            if (e < n_e && qn > 0) {
+                const double *v = tile + (size_t)q0 * kAuxTileStride + e;
+                double prod;
+                if (qn == kRngProductPasses) {
+                    double xv[kRngProductPasses];
+#pragma unroll
+                    for (int q = 0; q < kRngProductPasses; ++q)
+                        xv[q] = v[(size_t)q * kAuxTileStride];
+                    prod = xv[0];
+#pragma unroll
+                    for (int q = 1; q < kRngProductPasses; ++q)
+                        prod *= xv[q];
+                } else {
+                    prod = v[0];
+                    for (int q = 1; q < qn; ++q)
+                        prod *= v[(size_t)q * kAuxTileStride];
+                }
+                lgs[g * 128 + e] = log_normal(prod);
+            }
+        }
+        // (the walk to the next chunk does not touch the tile: it runs under the others' logarithms)
+        if (c + 1 < x.cpw) {
+            for (int s = 0; s < 3; ++s) {
+#pragma unroll
+                for (int t = 0; t < kAuxBlock; ++t)
+                    r[t] += r[(t + 28) % 31];
+            }
+        }
+        __syncthreads();
+        if (tid < n_e) {
+            double acc = 0.0;
+            const int nb = (x.passes + kRngProductPasses - 1) / kRngProductPasses;
+            for (int g = 0; g < nb; ++g)             // (in block order, as gamma_from_abs subtracts them)
+                acc -= lgs[g * 128 + tid];
+            x.out[ec + tid] = x.divisor != 1.0 ? acc / x.divisor : acc;
+        }
+        // (the next chunk's draws write the tile: every thread has read its products above, behind
+        // the barrier; lgs is rewritten only behind the next chunk's first barrier)
+    }
 }
 
 }  // namespace trlda

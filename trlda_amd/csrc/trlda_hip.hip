@@ -465,13 +465,28 @@ struct trlda_model {
         uint64_t token = 0;
         int which = 0;
         long long total = 0, lo = 0, hi = 0;
+        bool in_launch = false;                 // drawn by a document launch of the model's stream: no event
     } spec;
     const double *gamma0_src = nullptr;         // the next E-step on m->gamma reads gamma0 here
+    // ... or INSIDE this call's document launch (round 6; estep_merged.h, AuxArgs): extra workgroups of
+    // a merged launch draw it on the CUs the documents leave free.  `aux_draw_req`: the fresh draw of
+    // this call asks the call's next document launch to carry the draw of the next one (same shape);
+    // that launch answers it or drops it.  TRLDA_DRAW_INLAUNCH=0 / trlda_model_set_draw_ahead(m, 0 | 1)
+    // with bit 2 clear: every draw in its turn (or on the side stream).
+    bool draw_inlaunch = true;
+    struct {
+        bool valid = false;
+        long long total = 0;
+    } aux_draw_req;
+    int64_t inlaunch_draws = 0;                 // draws made inside a document launch so far (tests)
+    unsigned int aux_work_total = 0;            // what sync_counters[48] holds: the auxiliary workgroups' items so far
+    int64_t inlaunch_decays = 0;                // inactive-word passes made inside a document launch (tests)
+    bool aux_decay = true;                      // trlda_model_set_aux_decay / TRLDA_AUX_DECAY=0
     uint32_t *rng_win2 = nullptr;               // scratch of the draw stream
     size_t cap_rng_win2 = 0;
     double *rng_vbuf2 = nullptr;
     size_t cap_rng_vbuf2 = 0;
-    // device-side sampleGamma (rng_kernels.h): segment windows, log|u| of a group of passes
+    // device-side sampleGamma (rng_kernels.h): segment windows, |u| of a group of passes
     bool host_gamma_draw = false;               // true: the bit-exact host draw (glibc log)
     uint32_t *rng_win = nullptr;
     size_t cap_rng_win = 0;
@@ -735,6 +750,9 @@ int ensure_gamma_staging(trlda_model *m, size_t count)
 // stream, which is advanced by passes * total draws (defined below, after the generator)
 int sample_gamma_on_device(trlda_model *m, long long total, int passes, double divisor, double *out_dev,
                            long long e_lo = 0, long long e_hi = -1, bool ahead = false);
+// two levels of transposed jump matrices A^(d 16^l L) on the device (rng_kernels.h, AuxDrawArgs), or
+// *out = nullptr when the cache is full (the caller then draws in its turn)
+int rng_aux_matrices(int device, long long L, const uint32_t **out);
 
 // gamma = sampleGamma(K, B, 100) / 100 (lda.cpp:135).  Default: drawn on the device from the same
 // integer stream (rng_kernels.h).  host_gamma_draw: on the host (glibc's logarithm, bit for bit
@@ -780,6 +798,7 @@ int draw_gamma_ahead(trlda_model *m, long long total, long long lo, long long hi
     m->spec.token = token;
     m->spec.which = which;
     m->spec.total = total; m->spec.lo = lo; m->spec.hi = hi;
+    m->spec.in_launch = false;
     return TRLDA_OK;
 }
 
@@ -793,7 +812,8 @@ int device_gamma_now_or_ahead(trlda_model *m, long long total, long long lo, lon
         m->spec.valid = false;
         if (m->spec.total == total && m->spec.lo == lo && m->spec.hi == hi &&
             trlda_host::rng_speculation_claim(m->spec.token)) {
-            HIP_TRY(hipStreamWaitEvent(m->stream, m->ev_draw, 0));
+            if (!m->spec.in_launch)                  // (in_launch: an earlier kernel of this stream)
+                HIP_TRY(hipStreamWaitEvent(m->stream, m->ev_draw, 0));
             m->gamma0_src = m->gspec[m->spec.which];
             have = true;
         }
@@ -802,8 +822,15 @@ int device_gamma_now_or_ahead(trlda_model *m, long long total, long long lo, lon
     int rc = TRLDA_OK;
     if (!have)
         rc = sample_gamma_on_device(m, total, 100, 100., m->gamma, lo, hi);
-    if (!rc)
+    m->aux_draw_req.valid = false;
+    if (!rc && m->draw_ahead)
         rc = draw_gamma_ahead(m, total, lo, hi);
+    else if (!rc && m->draw_inlaunch && !m->host_gamma_draw && lo == 0 && hi == total) {
+        // the next fresh gamma0 of this shape: by the call's next document launch, if it is one that
+        // can carry it (estep_device)
+        m->aux_draw_req.valid = true;
+        m->aux_draw_req.total = total;
+    }
     return rc;
 }
 
@@ -915,6 +942,14 @@ struct EstepOut {
     bool no_rows = false;       // out: no row sums were left behind (the next E-step adds lambda up)
     bool emit_u = false;        // in: big tables -- also leave exp(psi(lambda)) of the written words in eeb
     bool u_emitted = false;     // out: it did
+    // in: the words OUTSIDE the batch, lambda = inact_a lambda + inact_b in place (the update call
+    // without trust-region loop, onlinelda.cpp:103-109), may be written by auxiliary workgroups of
+    // the document launch (estep_merged.h, AuxInactiveArgs); out: it was, the block rows of their
+    // row sums are the inact_rows rows at inact_part
+    bool inact_wanted = false;
+    double inact_a = 0.0, inact_b = 0.0;
+    int inact_rows = 0;
+    const double *inact_part = nullptr;
     EstepOut() { upd = trlda::UpdateOut{}; }
     explicit EstepOut(double *sstats) : EstepOut() { upd.sstats = sstats; }
 };
@@ -2059,6 +2094,69 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                     return rc;
                 mg.xerr = m->xerr;
                 a.xerr = m->xerr;
+                // auxiliary workgroups (estep_merged.h, AuxArgs): the next fresh gamma0, when this call's
+                // draw asked for it and the CUs the documents leave free take the workgroups in ONE round
+                // of at most kAuxMaxChunks chunks each (~2 us a chunk under ~33 us of documents)
+                trlda::AuxArgs aux{};
+                constexpr int kAuxMaxChunks = 6;
+                const int aux_room = cus - n_wgs - mg.n_comb - pre.nb;
+                if (m->aux_draw_req.valid && aux_room >= 24 && merged_stats) {
+                    const long long total = m->aux_draw_req.total;
+                    const long long chunks = (total + trlda::kAuxChunk - 1) / trlda::kAuxChunk;
+                    const int cpw = (int)((chunks + aux_room - 1) / aux_room);
+                    const int n_draw = (int)((chunks + cpw - 1) / cpw);
+                    // (which buffer: not the one this call's E-steps read their gamma0 from)
+                    const int which = (a.gamma_in == m->gspec[0] && m->gspec[0]) ? 1 : 0;
+                    const uint32_t *mt_stride = nullptr, *mt_total = nullptr;
+                    if (cpw <= kAuxMaxChunks && n_draw < 256 &&
+                        !(rc = rng_aux_matrices(m->device, (long long)cpw * trlda::kAuxChunk, &mt_stride)) &&
+                        !(rc = rng_aux_matrices(m->device, total, &mt_total)) && mt_stride && mt_total &&
+                        !(rc = grow(&m->gspec[which], &m->cap_gspec[which], (size_t)total))) {
+                        aux.draw.n = n_draw;
+                        aux.draw.passes = 100; aux.draw.cpw = cpw;
+                        aux.draw.total = total; aux.draw.divisor = 100.;
+                        aux.draw.out = m->gspec[which];
+                        aux.draw.mt_stride = mt_stride; aux.draw.mt_total = mt_total;
+                        // the host stream moves on ahead of its turn (host_rng.cpp: whoever touches the
+                        // generator before the claim puts it back, and the draw is repeated in its turn)
+                        const uint64_t token = trlda_host::rng_speculate_begin();
+                        trlda_host::rng_current_window(aux.draw.w0.w);
+                        trlda_host::rng_advance((uint64_t)(100 * total));
+                        m->spec.valid = true; m->spec.token = token; m->spec.which = which;
+                        m->spec.total = total; m->spec.lo = 0; m->spec.hi = total;
+                        m->spec.in_launch = true;
+                        ++m->inlaunch_draws;
+                    }
+                    if (rc)
+                        return rc;
+                }
+                m->aux_draw_req.valid = false;
+                // ... and the decay of the words outside the batch (K even: merged_stats), which the
+                // caller would otherwise launch behind this kernel
+                if (out.inact_wanted && m->aux_decay && merged_stats && aux_room >= 24 && out.inact_a != 0.0 &&
+                    b->n_active < V) {
+                    const trlda::StreamGeom g = trlda::stream_geometry(K, V);
+                    if (g.vec == 2 && g.P <= 64) {
+                        aux.inact.n_vb = g.G;
+                        aux.inact.K = K; aux.inact.V = V; aux.inact.P = g.P; aux.inact.cpb = g.cpb;
+                        aux.inact.a = out.inact_a; aux.inact.b = out.inact_b;
+                        aux.inact.active_flag = b->active_flag;
+                        aux.inact.lambda = m->lambda;
+                        // (not rows [0, 64) of m->partial: this launch's documents may be adding up the
+                        // row sums its preamble left there)
+                        aux.inact.part_static = m->partial + (size_t)trlda::kStreamMaxBlocks * K;
+                        out.inact_rows = g.G;
+                        out.inact_part = aux.inact.part_static;
+                        ++m->inlaunch_decays;
+                    }
+                }
+                aux.n_items = aux.draw.n + aux.inact.n_vb;
+                aux.n = std::min(aux.n_items, std::max(aux_room, 0));
+                aux.work_counter = m->sync_counters + 48;        // (a cache line of its own)
+                aux.work_base = m->aux_work_total;
+                m->aux_work_total += (unsigned int)aux.n_items;  // (one fetch per item in all: each
+                                                                 //  workgroup's last one finds nothing)
+                mg.first += aux.n;
                 const void *mk = !tiered ? reinterpret_cast<const void *>(estep_docs_reg_merged_kernel<0>)
                                  : KS == 1 ? reinterpret_cast<const void *>(estep_docs_tiered_merged_kernel<1>)
                                            : reinterpret_cast<const void *>(estep_docs_tiered_merged_kernel<2>);
@@ -2068,13 +2166,13 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                 const dim3 grid((unsigned)(mg.first + n_help));
                 if (!tiered)
                     hipLaunchKernelGGL(estep_docs_reg_merged_kernel<0>, grid, dim3(kRegThreads), lds_bytes,
-                                       m->stream, a, pre, mg);
+                                       m->stream, a, pre, mg, aux);
                 else if (KS == 1)
                     hipLaunchKernelGGL(estep_docs_tiered_merged_kernel<1>, grid, dim3(kRegThreads), lds_bytes,
-                                       m->stream, a, pre, lds_rows, mg);
+                                       m->stream, a, pre, lds_rows, mg, aux);
                 else
                     hipLaunchKernelGGL(estep_docs_tiered_merged_kernel<2>, grid, dim3(kRegThreads), lds_bytes,
-                                       m->stream, a, pre, lds_rows, mg);
+                                       m->stream, a, pre, lds_rows, mg, aux);
                 if (merged_stats)
                     m->docs_done_total += (unsigned int)n_wgs;
                 m->c_ready_total += (unsigned int)mg.n_comb;
@@ -2185,6 +2283,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
     // event records cost on an otherwise idle stream position (which = 4)
     if (m->timing && ((rc = stamp(m)) || (rc = stamp(m))))
         return rc;
+    m->aux_draw_req.valid = false;                   // (a launch that could not carry it: drawn in its turn)
     return batch_end(m, b);
 }
 
@@ -2477,6 +2576,37 @@ int rng_device_matrices(int device, int L, const uint32_t **out)
     return TRLDA_OK;
 }
 
+int rng_aux_matrices(int device, long long L, const uint32_t **out)
+{
+    static std::mutex mu;
+    static std::map<std::tuple<pid_t, int, long long>, uint32_t *> all;
+    constexpr size_t kMaxShapes = 64;                // (a stream of mini-batches has a few sizes)
+    *out = nullptr;
+    if (L <= 0 || L > 0x7fffffff)
+        return TRLDA_OK;
+    std::lock_guard<std::mutex> lock(mu);
+    auto key = std::make_tuple(getpid(), device, L);
+    auto it = all.find(key);
+    if (it == all.end()) {
+        if (all.size() >= kMaxShapes)
+            return TRLDA_OK;
+        const std::vector<uint32_t> &h = trlda_host::rng_level_matrices((int)L, 2);
+        std::vector<uint32_t> t(h.size());
+        for (size_t mtx = 0; mtx < h.size() / 961; ++mtx)
+            for (int i = 0; i < 31; ++i)
+                for (int j = 0; j < 31; ++j)
+                    t[mtx * 961 + (size_t)j * 31 + i] = h[mtx * 961 + (size_t)i * 31 + j];
+        uint32_t *d = nullptr;
+        int rc = dev_alloc(&d, t.size());
+        if (rc)
+            return rc;
+        HIP_TRY(hipMemcpy(d, t.data(), t.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        it = all.emplace(key, d).first;
+    }
+    *out = it->second;
+    return TRLDA_OK;
+}
+
 // elements [e_lo, e_hi) only (out_dev compact, e_hi - e_lo values); e_hi < 0: all of them.  The
 // stream always advances by passes * total draws.
 int sample_gamma_on_device(trlda_model *m, long long total, int passes, double divisor, double *out_dev,
@@ -2508,8 +2638,11 @@ int sample_gamma_on_device(trlda_model *m, long long total, int passes, double d
     const long long Sm = walk ? (S + trlda::kRngWalk - 1) / trlda::kRngWalk : S;
     const uint32_t *mats = nullptr;
     int rc = rng_device_matrices(m->device, Lm, &mats);
-    // log|u| of a group of passes: at most ~1 GB at a time
-    const long long group = std::max<long long>(1, std::min<long long>(passes, ((long long)1 << 27) / total));
+    // |u| of a group of passes: at most ~1 GB at a time -- whole blocks of kRngProductPasses passes (the
+    // passes of a block are multiplied before their one logarithm, rng_kernels.h)
+    long long group = std::max<long long>(1, std::min<long long>(passes, ((long long)1 << 27) / total));
+    if (group < passes)
+        group = std::max<long long>(trlda::kRngProductPasses, group / trlda::kRngProductPasses * trlda::kRngProductPasses);
     // small requests (a mini-batch's gamma0): the logarithms are summed where they are formed
     // (rng_kernels.h, draw_sum_kernel), fine windows in segment-major order
     const char *fused_env = std::getenv("TRLDA_RNG_FUSED");      // (read per call: the tests switch it)
@@ -2586,15 +2719,15 @@ int sample_gamma_on_device(trlda_model *m, long long total, int passes, double d
         const long long seg_lo = pos_lo / L, seg_hi = (pos_hi + L - 1) / L;
         const dim3 dgrid((unsigned)((seg_hi - seg_lo + T - 1) / T));
         if (L == trlda::kRngSegment)
-            hipLaunchKernelGGL((trlda::draw_log_kernel<T, trlda::kRngSegment>), dgrid, dim3(T), 0,
+            hipLaunchKernelGGL((trlda::draw_abs_kernel<T, trlda::kRngSegment>), dgrid, dim3(T), 0,
                                stream, S, seg_lo, std::min(S, seg_hi), pos_lo, pos_hi, total, e_lo,
                                e_hi, win, vbuf);
         else if (L == trlda::kRngSegmentTiny)
-            hipLaunchKernelGGL((trlda::draw_log_kernel<T, trlda::kRngSegmentTiny>), dgrid, dim3(T), 0,
+            hipLaunchKernelGGL((trlda::draw_abs_kernel<T, trlda::kRngSegmentTiny>), dgrid, dim3(T), 0,
                                stream, S, seg_lo, std::min(S, seg_hi), pos_lo, pos_hi, total, e_lo,
                                e_hi, win, vbuf);
         else
-            hipLaunchKernelGGL((trlda::draw_log_kernel<T, trlda::kRngSegmentSmall>), dgrid, dim3(T), 0,
+            hipLaunchKernelGGL((trlda::draw_abs_kernel<T, trlda::kRngSegmentSmall>), dgrid, dim3(T), 0,
                                stream, S, seg_lo, std::min(S, seg_hi), pos_lo, pos_hi, total, e_lo,
                                e_hi, win, vbuf);
         if (e_hi > e_lo)
@@ -3243,8 +3376,12 @@ int model_create(trlda_model **out, int device, int K, int V, int stream_priorit
         trlda_model_destroy(m);
         return rc;
     }
-    if (const char *env = std::getenv("TRLDA_DRAW_AHEAD"))       // 1 = draw the next gamma0 ahead
-        m->draw_ahead = env[0] != '0';
+    if (const char *env = std::getenv("TRLDA_AUX_DECAY"))        // 0: the streaming kernel behind the launch
+        m->aux_decay = env[0] != '0';
+    if (const char *env = std::getenv("TRLDA_DRAW_AHEAD")) {     // 0 / 1 / 2: trlda_model_set_draw_ahead
+        m->draw_ahead = env[0] == '1';
+        m->draw_inlaunch = env[0] == '2';
+    }
     if (const char *env = std::getenv("TRLDA_SPLIT_LISTS"))
         m->split_long_lists = env[0] != '0';
     if (const char *env = std::getenv("TRLDA_TILED_TASKS"))
@@ -4151,16 +4288,24 @@ int online_update_fused(trlda_model *m, const trlda_batch *b, int num_documents,
     }
     out.active_only = true;
     out.upd.lambda_prime = m->lambda;                        // in place
+    // the words outside the batch: lambda = (1 - rho) lambda + rho eta.  After the E-step's row-sum
+    // stage (small tables: it reads all of lambda) -- by auxiliary workgroups of its document launch
+    // where that is a merged one (the row sums were read by the kernel before it), else by the
+    // streaming kernel behind it
+    out.inact_wanted = true;
+    out.inact_a = 1. - rho; out.inact_b = rho * eta;
     rc = estep_device(m, b, m->gamma, out, max_iter_inference, threshold, nullptr);
-    // the words outside the batch: lambda = (1 - rho) lambda + rho eta.  After the E-step: its
-    // row-sum stage (small tables) reads all of lambda.
-    if (!rc)
+    const double *part_static = m->partial;
+    if (!rc && out.inact_rows > 0) {
+        G = out.inact_rows;
+        part_static = out.inact_part;
+    } else if (!rc)
         rc = launch_inactive_update<trlda::ACT_KEEP, false>(m, 1. - rho, rho * eta, rho, eta, 0.,
                                                             b->active_flag, nullptr, m->lambda,
                                                             nullptr, &G);
     if (!rc) rc = batch_end(m, b);                           // the pass above read its flags
     invalidate_rowsums(m);
-    if (!rc) rc = combine_rowsums(m, m->partial, G, nullptr, m->rs_static);
+    if (!rc) rc = combine_rowsums(m, part_static, G, nullptr, m->rs_static);
     if (!rc) rc = finish_rowsums(m, out, m->rs_static, floor_after);
     return rc;
 }
@@ -4900,9 +5045,25 @@ int trlda_model_set_draw_ahead(trlda_model *m, int enabled)
 {
     if (!m)
         return fail(TRLDA_ERR_ARG, "model is NULL");
-    m->draw_ahead = enabled != 0;
+    // 0: every draw in its turn; 1: ahead on a side stream; 2 (the default): ahead inside the call's
+    // document launch where that launch can carry it (estep_merged.h, AuxArgs), in its turn elsewhere
+    m->draw_ahead = enabled == 1;
+    m->draw_inlaunch = enabled == 2;
+    m->aux_draw_req.valid = false;
     return TRLDA_OK;
 }
+
+long long trlda_model_inlaunch_draws(const trlda_model *m) { return m ? (long long)m->inlaunch_draws : 0; }
+
+int trlda_model_set_aux_decay(trlda_model *m, int enabled)
+{
+    if (!m)
+        return fail(TRLDA_ERR_ARG, "model is NULL");
+    m->aux_decay = enabled != 0;
+    return TRLDA_OK;
+}
+
+long long trlda_model_inlaunch_decays(const trlda_model *m) { return m ? (long long)m->inlaunch_decays : 0; }
 
 int trlda_model_set_host_gamma_draw(trlda_model *m, int host)
 {
