@@ -16,7 +16,8 @@ _CSRC = os.path.join(_PKG, "csrc")
 LIB_PATH = os.path.join(_PKG, "libtrlda_hip.so")
 # the HIP translation unit (kernels, launch sequences, the C ABI over them) and the host-only
 # ones (no HIP: they also build with a plain C++ compiler under the sanitizers, `--sanitize`)
-SOURCES = ["trlda_hip.hip", "host_common.cpp", "host_rng.cpp", "text_docs.cpp", "eb_steps.cpp"]
+SOURCES = ["trlda_hip.hip", "host_common.cpp", "host_rng.cpp", "text_docs.cpp", "eb_steps.cpp",
+           "batch_index.cpp"]
 HOST_SOURCES = SOURCES[1:]
 
 

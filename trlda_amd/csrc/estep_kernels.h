@@ -21,6 +21,7 @@
 
 #include <type_traits>
 
+#include "index_params.h"
 #include "psi.h"
 
 namespace trlda {
@@ -1006,12 +1007,11 @@ __global__ __launch_bounds__(T) void estep_docs_kernel(DocKernelArgs a)
 // ---------------------------------------------------------------------------
 constexpr int kRegThreads = 512;
 constexpr int kRegMaxK = 128;
-constexpr int kRegMaxN = 144;      // words of the longest register variant (8 waves x 18)
 constexpr int kRegStride = 129;    // LDS row stride of the transposition / tail buffer (odd)
 constexpr int kRegPart = 192;      // row length of the partial-sum arrays
-constexpr int kSplitMinN = 192;    // documents longer than this are split over several workgroups,
-constexpr int kSplitSegN = 128;    // ceil(n / 128) segments of at most 128 words each,
-constexpr int kSplitMaxSeg = 16;   // up to 16 of them (2048 words; longer documents: one workgroup)
+// (kRegMaxN = 144 words of the longest register variant, 8 waves x 18; documents of more than kSplitMinN
+// = 192 words are split into ceil(n / kSplitSegN) segments of at most 128 words, up to kSplitMaxSeg = 16
+// of them: index_params.h)
 
 // g[2] | alpha | e[2] (+16 zero pad each) | tw (+16 zero pad) | cnt | part[8][192] | misc[8] |
 // buffer [128][129]: transposition scratch while the registers are filled, then the rows
@@ -1778,8 +1778,7 @@ __device__ __forceinline__ void word_segment_sum(int q0, int q1, int K, int kbas
 // A block per word pays off for the few hundred longest lists; at 12 500 documents most active
 // words have more than 16 entries, and walking ~20 000 of them with 256 blocks, a few dependent
 // latencies per word, was the whole 430 us of the kernel.
-constexpr int kLongWord = 16;
-constexpr int kLongWordsTarget = 512;
+// (kLongWord = 16, kLongWordsTarget = 512: index_params.h)
 
 // VERY long lists (round 4).  A word present in all 12 500 documents of a BatchLDA shard kept ONE
 // workgroup busy for ~100 us -- 98 passes of 16 entries per wave, each a dependent gather -- while
@@ -1798,8 +1797,8 @@ constexpr int kLongWordsTarget = 512;
 // there are a million of them and a task's fixed costs (~3 us of barriers and round trips) would
 // otherwise dominate (256 everywhere: K = 100 / 6400 documents 60 -> 70 us; 1024 everywhere: one
 // rank of eight at 8 x 200 documents 7.7 -> 15 us).
-constexpr int kSegMin = 256, kSegMax = 1024, kSegTasks = 512;
-constexpr int kOneWaveMax = 256;             // long_len never exceeds this: a wave walks 16 entries per pass
+// (kSegMin = 256, kSegMax = 1024, kSegTasks = 512; kOneWaveMax = 256 -- long_len never exceeds it: a wave
+// walks 16 entries per pass: index_params.h)
 struct VeryLongArgs {
     int G_seg;                    // workgroups walking the segment tasks (0: none)
     int seg_len;                  // lists of more than this many entries are cut into segments

@@ -34,6 +34,7 @@
 
 #include "../../include/trlda_hip.h"
 #include "host_common.h"
+#include "batch_index.h"
 #include "estep_kernels.h"
 #include "estep_wide.h"
 #include "estep_merged.h"
@@ -565,7 +566,7 @@ int take_event(UploadContext &u, hipEvent_t *ev)
     return TRLDA_OK;
 }
 
-inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
 
 // the models' own streams that still exist (a destroyed model has synchronised its stream:
 // nothing of it can still be reading a batch)
@@ -2803,113 +2804,18 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     if (!out)
         return fail(TRLDA_ERR_ARG, "out is NULL");
     *out = nullptr;
-    if (V <= 0 || B < 0 || !indptr)
-        return fail(TRLDA_ERR_ARG, "bad batch dimensions");
-    if (indptr[0] != 0)
-        return fail(TRLDA_ERR_ARG, "indptr[0] must be 0");
-    int max_n = 0;
-    for (int d = 0; d < B; ++d) {
-        if (indptr[d + 1] < indptr[d])
-            return fail(TRLDA_ERR_ARG, "indptr must be non-decreasing");
-        max_n = std::max(max_n, indptr[d + 1] - indptr[d]);
-    }
-    const int64_t nnz = indptr[B];
-    if (nnz > 0 && (!ids || !cnts))
-        return fail(TRLDA_ERR_ARG, "ids / cnts are NULL");
-    for (int64_t i = 0; i < nnz; ++i)
-        if (ids[i] < 0 || ids[i] >= V)
-            return fail(TRLDA_ERR_WORD_ID, "word id outside [0, num_words)");
-
-    int rc = use_device(device);
+    // validation, the histogram of the word ids and the layout of the allocation (batch_index.cpp:
+    // host only); the index itself is written straight into pinned memory below
+    trlda_host::BatchIndex x;
+    int rc = trlda_host::batch_index_plan(V, B, indptr, ids, cnts, &x);
     if (rc)
         return rc;
-
-    // word-major segment offsets first: they give the number of active and long words, i.e.
-    // the layout of the allocation
-    std::vector<int32_t> wptr((size_t)V + 1, 0);
-    for (int64_t i = 0; i < nnz; ++i)
-        ++wptr[(size_t)ids[i] + 1];
-    int n_active = 0, n_long = 0;
-    int long_len = trlda::kLongWord;
-    {
-        // over[i]: words with more than kLongWord << i entries
-        constexpr int kLevels = 16;
-        int over[kLevels] = {0};
-        for (int w = 0; w < V; ++w) {
-            const int len = wptr[(size_t)w + 1];
-            n_active += len > 0;
-            for (int i = 0; i < kLevels && len > (trlda::kLongWord << i); ++i)
-                ++over[i];
-            wptr[(size_t)w + 1] += wptr[(size_t)w];
-        }
-        int level = 0;
-        while (level + 1 < kLevels && over[level] > trlda::kLongWordsTarget)
-            ++level;
-        long_len = trlda::kLongWord << level;
-        n_long = over[level];
-        // (the longest lists are cut into segments, estep_kernels.h: the one-wave range stays short)
-        if (long_len > trlda::kOneWaveMax) {
-            long_len = trlda::kOneWaveMax;
-            n_long = 0;
-            for (int w = 0; w < V; ++w)
-                n_long += wptr[(size_t)w + 1] - wptr[(size_t)w] > long_len;
-        }
-    }
-    // the longest lists as segment tasks (estep_kernels.h, VeryLongArgs): segment length per batch
-    int n_vl = 0, n_vl_tasks = 0, seg_len = trlda::kSegMin;
-    {
-        long long heavy = 0;
-        for (int w = 0; w < V; ++w) {
-            const int len = wptr[(size_t)w + 1] - wptr[(size_t)w];
-            heavy += len > trlda::kSegMin ? len : 0;
-        }
-        static const long long seg_tasks = std::getenv("TRLDA_SEG_TASKS") ? std::atoll(std::getenv("TRLDA_SEG_TASKS"))
-                                                                          : (long long)trlda::kSegTasks;
-        while (seg_len < trlda::kSegMax && heavy / seg_len > seg_tasks)
-            seg_len *= 2;
-    }
-    for (int w = 0; w < V; ++w) {
-        const int len = wptr[(size_t)w + 1] - wptr[(size_t)w];
-        if (len > seg_len) {
-            ++n_vl;
-            n_vl_tasks += (len + seg_len - 1) / seg_len;
-        }
-    }
-
-    // documents of more than kSplitMinN words take several workgroups (segments)
-    auto segments_of = [](int n) {
-        if (n <= trlda::kSplitMinN)
-            return 1;
-        const int c = (n + trlda::kSplitSegN - 1) / trlda::kSplitSegN;
-        return c <= trlda::kSplitMaxSeg ? c : 1;
-    };
-    int n_wg = 0, n_xrows = 0;
-    for (int d = 0; d < B; ++d) {
-        const int c = segments_of(indptr[d + 1] - indptr[d]);
-        n_wg += c;
-        n_xrows += c > 1 ? c : 0;
-    }
-    if (n_xrows == 0)
-        n_wg = 0;                                    // no split document: no second layout
-
-    // layout (bytes, 256-aligned sections)
-    size_t off = 0;
-    auto section = [&](size_t bytes) {
-        const size_t at = off;
-        off = align256(off + std::max<size_t>(bytes, 4));
-        return at;
-    };
-    const size_t nz = (size_t)nnz, Bz = (size_t)B;
-    const size_t o_indptr = section((Bz + 1) * 4), o_ids = section(nz * 4), o_cnts = section(nz * 4),
-                 o_order = section(Bz * 4), o_wrank = section(nz * 4),
-                 o_wptr = section(((size_t)V + 1) * 4), o_wdoc = section(nz * 4),
-                 o_meta = section(Bz * 16), o_pids = section(Bz * trlda::kRegMaxN * 4),
-                 o_smeta = section((size_t)n_wg * 32), o_spids = section((size_t)n_wg * trlda::kRegMaxN * 4),
-                 o_active = section((size_t)n_active * 4), o_long = section((size_t)n_long * 4),
-                 o_flag = section((size_t)V), o_wc32 = section((size_t)V * 4),
-                 o_mdesc = section((size_t)n_active * 16), o_vlw = section((size_t)n_vl * 16),
-                 o_vlt = section((size_t)n_vl_tasks * 16), o_vltt = section((size_t)n_vl_tasks * 16);
-    const size_t total = off;
+    rc = use_device(device);
+    if (rc)
+        return rc;
+    const size_t total = x.total;
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
 
     UploadContext &u = upload_context(device);
     std::lock_guard<std::mutex> lock(u.mu);
@@ -2930,208 +2836,27 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     }
     if (!st.ev)
         HIP_TRY(hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
-    char *h = static_cast<char *>(st.host);
-    auto I = [&](size_t o) { return reinterpret_cast<int32_t *>(h + o); };
-
-    std::memcpy(I(o_indptr), indptr, (Bz + 1) * 4);
-    if (nz) {
-        std::memcpy(I(o_ids), ids, nz * 4);
-        std::memcpy(I(o_cnts), cnts, nz * 4);
-    }
-    std::memcpy(I(o_wptr), wptr.data(), ((size_t)V + 1) * 4);
-    // stable counting sort of the CSR positions by word id, and the words' count sums
-    bool wc32_ok = true, cnts_nonneg = true;
-    {
-        int32_t *wrank = I(o_wrank), *wdoc = I(o_wdoc), *wc32 = I(o_wc32);
-        std::vector<int32_t> cursor(wptr.begin(), wptr.end() - 1);
-        std::vector<int64_t> wsum((size_t)V, 0);
-        for (int d = 0; d < B; ++d)
-            for (int32_t p = indptr[d]; p < indptr[d + 1]; ++p) {
-                const int32_t q = cursor[(size_t)ids[p]]++;
-                wrank[p] = q;
-                wdoc[q] = d;
-                wsum[(size_t)ids[p]] += cnts[p];
-                cnts_nonneg = cnts_nonneg && cnts[p] >= 0;
-            }
-        for (int w = 0; w < V; ++w) {
-            wc32_ok = wc32_ok && wsum[(size_t)w] >= INT32_MIN && wsum[(size_t)w] <= INT32_MAX;
-            wc32[w] = (int32_t)wsum[(size_t)w];
-        }
-    }
-    int32_t *order = I(o_order);
-    std::iota(order, order + B, 0);
-    std::stable_sort(order, order + B, [&](int32_t x, int32_t y) {
-        return indptr[x + 1] - indptr[x] > indptr[y + 1] - indptr[y];
-    });
+    trlda_host::batch_index_fill(&x, indptr, ids, cnts, cus, static_cast<char *>(st.host));
 
     trlda_batch *b = new trlda_batch();
     {
         static std::atomic<uint64_t> next_id{1};
         b->id = next_id.fetch_add(1);
     }
-    b->device = device; b->V = V; b->B = B; b->nnz = nnz; b->max_n = max_n;
-    b->n_active = n_active; b->n_long = n_long; b->long_len = long_len;
-    b->sorted_len.resize(Bz);
-    b->indptr_host.assign(indptr, indptr + Bz + 1);
-    b->wptr_host = wptr;
-    {
-        int32_t *meta = I(o_meta), *pids = I(o_pids);
-        for (int i = 0; i < B; ++i) {
-            const int d = order[i], p0 = indptr[d], n = indptr[d + 1] - p0;
-            b->sorted_len[(size_t)i] = n;
-            meta[(size_t)i * 4] = d;
-            meta[(size_t)i * 4 + 1] = n;
-            meta[(size_t)i * 4 + 2] = p0;
-            meta[(size_t)i * 4 + 3] = 0;
-            // words past the document repeat its last id (rows that exist; masked by length)
-            int32_t *row = pids + (size_t)i * trlda::kRegMaxN;
-            const int m0 = std::min(n, trlda::kRegMaxN);
-            for (int j = 0; j < m0; ++j)
-                row[j] = ids[p0 + j];
-            const int32_t fill = n > 0 ? ids[p0 + std::min(n, trlda::kRegMaxN) - 1] : 0;
-            for (int j = m0; j < trlda::kRegMaxN; ++j)
-                row[j] = fill;
-        }
+    b->device = device; b->V = V; b->B = B; b->nnz = x.nnz; b->max_n = x.max_n;
+    b->n_active = x.n_active; b->n_long = x.n_long; b->long_len = x.long_len;
+    b->split_pays = x.split_pays;
+    b->max_list = x.max_list;
+    for (int c = 0; c < 4; ++c) {
+        b->cls_short[c] = x.cls_short[c];
+        b->cls_long[c] = x.cls_long[c];
     }
-    if (n_wg > 0) {
-        // Does splitting pay for THIS batch?  A launch lasts max(longest workgroup, all work /
-        // CUs).  Per iteration, in microseconds at K = 100 (profiles/r03_length_sweep*.txt; only
-        // the ratios matter): a document on one workgroup costs 1.0 + 0.0025 n up to 128 words,
-        // 1.5 up to 144, 0.013 n up to 192 and 2.5 + 0.025 (n - 192) beyond; a segment 2.6
-        // whatever its document's length -- 1.1 to 1.8 times the CU time of the unsplit form,
-        // which is why a batch of 400-word documents that fills the chip anyway stays unsplit,
-        // and a batch with a few long documents (or, like the reference's test_speed, very
-        // uneven ones) does not.
-        int cus = 256;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-        double sum_u = 0., max_u = 0., sum_s = 0., max_s = 0.;
-        for (int i = 0; i < B; ++i) {
-            const int n = indptr[order[i] + 1] - indptr[order[i]];
-            const double cu = n <= 128 ? 1.0 + 0.0025 * n : n <= 144 ? 1.5 : n <= 192 ? 0.013 * n
-                                                                        : 2.5 + 0.025 * (n - 192);
-            const int c = segments_of(n);
-            sum_u += cu; max_u = std::max(max_u, cu);
-            sum_s += c > 1 ? 2.6 * c : cu; max_s = std::max(max_s, c > 1 ? 2.6 : cu);
-        }
-        b->split_pays = std::max(max_s, sum_s / cus) < 0.95 * std::max(max_u, sum_u / cus);
-        int32_t *meta = I(o_smeta), *pids = I(o_spids);
-        size_t w = 0;
-        int xrow = 0;
-        for (int i = 0; i < B; ++i) {
-            const int d = order[i], p0 = indptr[d], n = indptr[d + 1] - p0;
-            const int c = segments_of(n);
-            const int base = n / c, rem = n % c;
-            int start = 0;
-            for (int sgm = 0; sgm < c; ++sgm, ++w) {
-                const int len = base + (sgm < rem ? 1 : 0);
-                int32_t *mm = meta + w * 8;
-                mm[0] = d; mm[1] = len; mm[2] = p0 + start; mm[3] = 0;
-                mm[4] = sgm; mm[5] = c; mm[6] = c > 1 ? xrow : 0; mm[7] = n;
-                int32_t *row = pids + w * trlda::kRegMaxN;
-                const int m0 = std::min(len, trlda::kRegMaxN);
-                for (int j = 0; j < m0; ++j)
-                    row[j] = ids[p0 + start + j];
-                const int32_t fill = len > 0 ? ids[p0 + start + m0 - 1] : 0;
-                for (int j = m0; j < trlda::kRegMaxN; ++j)
-                    row[j] = fill;
-                start += len;
-            }
-            if (c > 1)
-                xrow += c;
-        }
-    }
-    {
-        int32_t *active = I(o_active), *longw = I(o_long);
-        uint8_t *flag = reinterpret_cast<uint8_t *>(h + o_flag);
-        int na = 0, nl = 0, longest = 0;
-        for (int w = 0; w < V; ++w) {
-            const int len = wptr[(size_t)w + 1] - wptr[(size_t)w];
-            longest = std::max(longest, len);
-            flag[w] = len > 0;
-            if (len > 0)
-                active[na++] = w;
-            if (len > long_len)
-                longw[nl++] = w;
-        }
-        b->long_host.assign(longw, longw + nl);
-        b->max_list = longest;
-        // the very long lists: equal segments of at most seg_len entries
-        int32_t *vw = I(o_vlw), *vt = I(o_vlt);
-        int j = 0, t = 0;
-        for (int w = 0; w < V && n_vl > 0; ++w) {
-            const int q0 = wptr[(size_t)w], len = wptr[(size_t)w + 1] - q0;
-            if (len <= seg_len)
-                continue;
-            const int ns = (len + seg_len - 1) / seg_len;
-            const int base = len / ns, rem = len % ns;
-            vw[4 * j] = w; vw[4 * j + 1] = t; vw[4 * j + 2] = ns; vw[4 * j + 3] = 0;
-            b->vl_host.push_back(w);
-            b->vl_first.push_back(t);
-            int start = 0;
-            for (int sg = 0; sg < ns; ++sg, ++t) {
-                const int sl = base + (sg < rem ? 1 : 0);
-                vt[4 * t] = j; vt[4 * t + 1] = sg; vt[4 * t + 2] = q0 + start; vt[4 * t + 3] = sl;
-                start += sl;
-            }
-            ++j;
-        }
-        b->vl_first.push_back(t);
-        {
-            // (counting sort of the tasks by sixteenth of the list their segment starts in, stable
-            // in the word index)
-            int32_t *vtt = I(o_vltt);
-            int start[17] = {0};
-            auto bucket = [&](int q) { return std::min(15, 16 * vt[4 * q + 1] / std::max(1, vw[4 * vt[4 * q] + 2])); };
-            for (int q = 0; q < t; ++q)
-                ++start[bucket(q) + 1];
-            for (int i = 0; i < 16; ++i)
-                start[i + 1] += start[i];
-            for (int q = 0; q < t; ++q) {
-                int32_t *e = vtt + 4 * (size_t)start[bucket(q)]++;
-                e[0] = vt[4 * q]; e[1] = vt[4 * q + 1]; e[2] = vt[4 * q + 2]; e[3] = vt[4 * q + 3];
-            }
-        }
-        // descriptors for the merged launch: counting sort by length, longest first, the short
-        // lists (<= long_len entries) before the long ones
-        int32_t *md = I(o_mdesc);
-        const int n_short = n_active - n_long;
-        std::vector<int32_t> at((size_t)long_len + 2, 0);        // at[len]: next slot of a short list of `len`
-        for (int a = 0; a < na; ++a) {
-            const int len = wptr[(size_t)active[a] + 1] - wptr[(size_t)active[a]];
-            if (len <= long_len)
-                ++at[(size_t)len];
-        }
-        int run = 0;
-        for (int len = long_len; len >= 1; --len) {
-            const int c = at[(size_t)len];
-            at[(size_t)len] = run;
-            run += c;
-        }
-        std::vector<int32_t> longs;
-        for (int a = 0; a < na; ++a) {
-            const int w = active[a], q0 = wptr[(size_t)w], len = wptr[(size_t)w + 1] - q0;
-            if (len > long_len) {
-                longs.push_back(w);
-                continue;
-            }
-            int32_t *e = md + 4 * (size_t)at[(size_t)len]++;
-            e[0] = w; e[1] = q0; e[2] = len; e[3] = 0;
-        }
-        for (int a = 0; a < na; ++a) {
-            const int len = wptr[(size_t)active[a] + 1] - wptr[(size_t)active[a]];
-            const int unit = len <= long_len ? len : (len + 15) / 16;       // a list, or a chunk of one
-            const int c = unit > 8 ? 0 : unit > 4 ? 1 : unit > 2 ? 2 : 3;
-            ++(len <= long_len ? b->cls_short : b->cls_long)[c];
-        }
-        std::stable_sort(longs.begin(), longs.end(), [&](int32_t x, int32_t y) {
-            return wptr[(size_t)x + 1] - wptr[(size_t)x] > wptr[(size_t)y + 1] - wptr[(size_t)y];
-        });
-        for (size_t i = 0; i < longs.size(); ++i) {
-            const int w = longs[i];
-            int32_t *e = md + 4 * ((size_t)n_short + i);
-            e[0] = w; e[1] = wptr[(size_t)w]; e[2] = wptr[(size_t)w + 1] - wptr[(size_t)w]; e[3] = 0;
-        }
-    }
+    b->sorted_len.swap(x.sorted_len);
+    b->indptr_host.swap(x.indptr_host);
+    b->wptr_host.swap(x.wptr);
+    b->long_host.swap(x.long_host);
+    b->vl_host.swap(x.vl_host);
+    b->vl_first.swap(x.vl_first);
 
     // a device allocation: from the cache when one fits, else new
     // (one whose last reader has finished, if there is one: an upload into an allocation that
@@ -3186,20 +2911,20 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     }
     char *dv = static_cast<char *>(b->blob);
     auto D = [&](size_t o) { return reinterpret_cast<int32_t *>(dv + o); };
-    b->indptr = D(o_indptr); b->ids = D(o_ids); b->cnts = D(o_cnts); b->order = D(o_order);
-    b->wrank = D(o_wrank); b->wptr = D(o_wptr); b->wdoc = D(o_wdoc);
-    b->pad_meta = D(o_meta); b->pad_ids = D(o_pids);
-    b->seg_meta = n_wg ? D(o_smeta) : nullptr; b->seg_ids = n_wg ? D(o_spids) : nullptr;
-    b->n_wg = n_wg; b->n_xrows = n_xrows;
-    b->active = D(o_active); b->long_words = D(o_long);
-    b->active_flag = reinterpret_cast<uint8_t *>(dv + o_flag);
-    b->wc32 = D(o_wc32);
-    b->wc32_ok = wc32_ok;
-    b->cnts_nonneg = cnts_nonneg;
-    b->mdesc = D(o_mdesc);
-    b->n_short = n_active - n_long;
-    b->vl_word = D(o_vlw); b->vl_task = D(o_vlt); b->vl_task_tiled = D(o_vltt);
-    b->n_vl = n_vl; b->n_vl_tasks = n_vl_tasks; b->seg_len = seg_len;
+    b->indptr = D(x.o_indptr); b->ids = D(x.o_ids); b->cnts = D(x.o_cnts); b->order = D(x.o_order);
+    b->wrank = D(x.o_wrank); b->wptr = D(x.o_wptr); b->wdoc = D(x.o_wdoc);
+    b->pad_meta = D(x.o_meta); b->pad_ids = D(x.o_pids);
+    b->seg_meta = x.n_wg ? D(x.o_smeta) : nullptr; b->seg_ids = x.n_wg ? D(x.o_spids) : nullptr;
+    b->n_wg = x.n_wg; b->n_xrows = x.n_xrows;
+    b->active = D(x.o_active); b->long_words = D(x.o_long);
+    b->active_flag = reinterpret_cast<uint8_t *>(dv + x.o_flag);
+    b->wc32 = D(x.o_wc32);
+    b->wc32_ok = x.wc32_ok;
+    b->cnts_nonneg = x.cnts_nonneg;
+    b->mdesc = D(x.o_mdesc);
+    b->n_short = x.n_active - x.n_long;
+    b->vl_word = D(x.o_vlw); b->vl_task = D(x.o_vlt); b->vl_task_tiled = D(x.o_vltt);
+    b->n_vl = x.n_vl; b->n_vl_tasks = x.n_vl_tasks; b->seg_len = x.seg_len;
     u.live.insert(b);
     *out = b;
     return TRLDA_OK;
