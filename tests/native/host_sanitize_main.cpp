@@ -3,6 +3,7 @@
 // sanitizers: trlda_amd/build.py --sanitize address|thread, run by tests/test_host_sanitize.py.
 // Test infrastructure; GPU sanitizers are not available on this pool, the host side is what
 // can be checked -- threads, mmap parsing, the jump-ahead cache, K-sized numerics.
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -183,11 +184,66 @@ static void eb_checks()
     CHECK(trlda_eb_online_alpha_step(0, alpha.data(), pgd.data(), 25., .1, 1e-6, out.data()) != TRLDA_OK);
 }
 
+// the mini-batch index (csrc/batch_index.cpp) into exactly-sized heap buffers -- a write past a
+// section's end into the next allocation is what the sanitizer is here for -- from several threads
+// at once through the work queue that trlda_batch_create builds it on
+extern "C" int trlda_debug_batch_index(int V, int B, const int32_t *indptr, const int32_t *ids,
+                                       const int32_t *cnts, int cus, int64_t *info, void *buffer, size_t cap);
+
+static void index_checks()
+{
+    struct Shape { int V, B, len, dup; };
+    const Shape shapes[] = {{7000, 200, 100, 0}, {30, 6, 9, 1}, {1, 4, 1, 1}, {50, 0, 0, 0}, {9000, 12, 700, 0},
+                            {300, 3000, 60, 1}, {64, 20, 300, 1}, {256, 64, 64, 0}};
+    trlda_host::WorkQueue queue(4);
+    std::atomic<int> built{0};
+    for (int rep = 0; rep < 3; ++rep)
+        for (const Shape &sh : shapes)
+            queue.submit([sh, rep, &built] {
+                std::vector<int32_t> indptr(1, 0), ids, cnts;
+                uint32_t state = 12345u + (uint32_t)sh.V * 7u + (uint32_t)rep;
+                auto next = [&state] { state = state * 1664525u + 1013904223u; return state >> 8; };
+                for (int d = 0; d < sh.B; ++d) {
+                    const int n = sh.len ? (int)(next() % (uint32_t)(2 * sh.len)) : 0;
+                    for (int j = 0; j < n; ++j) {
+                        ids.push_back(sh.dup ? (int32_t)(next() % (uint32_t)sh.V)
+                                             : (int32_t)((next() % (uint32_t)sh.V + (uint32_t)j) % (uint32_t)sh.V));
+                        cnts.push_back((int32_t)(next() % 5u));
+                    }
+                    indptr.push_back((int32_t)ids.size());
+                }
+                int64_t info[64];
+                CHECK(trlda_debug_batch_index(sh.V, sh.B, indptr.data(), ids.data(), cnts.data(), 256, info,
+                                              nullptr, 0) == TRLDA_OK);
+                std::vector<char> buf((size_t)info[24]);
+                CHECK(trlda_debug_batch_index(sh.V, sh.B, indptr.data(), ids.data(), cnts.data(), 256, info,
+                                              buf.data(), buf.size()) == TRLDA_OK);
+                // the word-major ranks are a permutation of the entries
+                const int32_t *wrank = reinterpret_cast<const int32_t *>(buf.data() + info[32 + 4]);
+                std::vector<char> seen(ids.size(), 0);
+                for (size_t p = 0; p < ids.size(); ++p) {
+                    CHECK(wrank[p] >= 0 && (size_t)wrank[p] < ids.size() && !seen[(size_t)wrank[p]]);
+                    seen[(size_t)wrank[p]] = 1;
+                }
+                ++built;
+            });
+    queue.wait_idle();
+    CHECK(built.load() == 3 * (int)(sizeof(shapes) / sizeof(shapes[0])));
+    int64_t info[64];
+    const int32_t ip[2] = {0, 1}, bad_id[1] = {7}, one[1] = {1};
+    CHECK(trlda_debug_batch_index(5, 1, ip, bad_id, one, 256, info, nullptr, 0) == TRLDA_ERR_WORD_ID);
+    trlda_host::WorkQueue inline_queue(0);
+    int ran = 0;
+    inline_queue.submit([&ran] { ++ran; });
+    CHECK(ran == 1);
+}
+
 int main(int argc, char **argv)
 {
     const bool thread_mode = argc > 1 && !std::strcmp(argv[1], "threads");
     parser_checks(thread_mode);
     rng_checks();
+    index_checks();
     if (!thread_mode) {
         speculation_checks();
         eb_checks();

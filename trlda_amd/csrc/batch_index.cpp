@@ -8,6 +8,7 @@
 #include <cstring>
 #include <numeric>
 #include <string>
+#include <time.h>
 
 #include "../../include/trlda_hip.h"
 #include "host_common.h"
@@ -30,6 +31,13 @@ inline int segments_of(int n)
 
 }  // namespace
 
+// Written for the host's time per mini-batch (round 6: 60 us of a 75 us trlda_batch_create were spent
+// here, against 26 us of kernels per 200 documents): every pass over the entries or the vocabulary is
+// branch-free where the data decide (a word is active or not with probability ~1/2: a mispredicted
+// branch per word), the vocabulary is scanned twice in all, scratch lives in the thread, and the
+// rare shapes (very long lists, a word whose counts overflow 32 bits, documents of more than 65 535
+// words) take loops of their own.  What comes out is the index of rounds 1-5 bit for bit
+// (tests/test_batch_index.py, tests/golden/f13_batch_index.json).
 int batch_index_plan(int V, int B, const int32_t *indptr, const int32_t *ids, const int32_t *cnts,
                      BatchIndex *x)
 {
@@ -37,83 +45,99 @@ int batch_index_plan(int V, int B, const int32_t *indptr, const int32_t *ids, co
         return fail(TRLDA_ERR_ARG, "bad batch dimensions");
     if (indptr[0] != 0)
         return fail(TRLDA_ERR_ARG, "indptr[0] must be 0");
-    int max_n = 0;
+    int max_n = 0, n_wg = 0, n_xrows = 0;
     for (int d = 0; d < B; ++d) {
+        const int n = indptr[d + 1] - indptr[d];
         if (indptr[d + 1] < indptr[d])
             return fail(TRLDA_ERR_ARG, "indptr must be non-decreasing");
-        max_n = std::max(max_n, indptr[d + 1] - indptr[d]);
-    }
-    const int64_t nnz = indptr[B];
-    if (nnz > 0 && (!ids || !cnts))
-        return fail(TRLDA_ERR_ARG, "ids / cnts are NULL");
-    for (int64_t i = 0; i < nnz; ++i)
-        if (ids[i] < 0 || ids[i] >= V)
-            return fail(TRLDA_ERR_WORD_ID, "word id outside [0, num_words)");
-    x->V = V; x->B = B; x->max_n = max_n; x->nnz = nnz;
-
-    // word-major segment offsets first: they give the number of active and long words, i.e.
-    // the layout of the allocation
-    std::vector<int32_t> &wptr = x->wptr;
-    wptr.assign((size_t)V + 1, 0);
-    for (int64_t i = 0; i < nnz; ++i)
-        ++wptr[(size_t)ids[i] + 1];
-    int n_active = 0, n_long = 0;
-    int long_len = trlda::kLongWord;
-    {
-        // over[i]: words with more than kLongWord << i entries
-        constexpr int kLevels = 16;
-        int over[kLevels] = {0};
-        for (int w = 0; w < V; ++w) {
-            const int len = wptr[(size_t)w + 1];
-            n_active += len > 0;
-            for (int i = 0; i < kLevels && len > (trlda::kLongWord << i); ++i)
-                ++over[i];
-            wptr[(size_t)w + 1] += wptr[(size_t)w];
-        }
-        int level = 0;
-        while (level + 1 < kLevels && over[level] > trlda::kLongWordsTarget)
-            ++level;
-        long_len = trlda::kLongWord << level;
-        n_long = over[level];
-        // (the longest lists are cut into segments, estep_kernels.h: the one-wave range stays short)
-        if (long_len > trlda::kOneWaveMax) {
-            long_len = trlda::kOneWaveMax;
-            n_long = 0;
-            for (int w = 0; w < V; ++w)
-                n_long += wptr[(size_t)w + 1] - wptr[(size_t)w] > long_len;
-        }
-    }
-    // the longest lists as segment tasks (estep_kernels.h, VeryLongArgs): segment length per batch
-    int n_vl = 0, n_vl_tasks = 0, seg_len = trlda::kSegMin;
-    {
-        long long heavy = 0;
-        for (int w = 0; w < V; ++w) {
-            const int len = wptr[(size_t)w + 1] - wptr[(size_t)w];
-            heavy += len > trlda::kSegMin ? len : 0;
-        }
-        static const long long seg_tasks = std::getenv("TRLDA_SEG_TASKS") ? std::atoll(std::getenv("TRLDA_SEG_TASKS"))
-                                                                          : (long long)trlda::kSegTasks;
-        while (seg_len < trlda::kSegMax && heavy / seg_len > seg_tasks)
-            seg_len *= 2;
-    }
-    for (int w = 0; w < V; ++w) {
-        const int len = wptr[(size_t)w + 1] - wptr[(size_t)w];
-        if (len > seg_len) {
-            ++n_vl;
-            n_vl_tasks += (len + seg_len - 1) / seg_len;
-        }
-    }
-    int n_wg = 0, n_xrows = 0;
-    for (int d = 0; d < B; ++d) {
-        const int c = segments_of(indptr[d + 1] - indptr[d]);
+        max_n = std::max(max_n, n);
+        const int c = segments_of(n);
         n_wg += c;
         n_xrows += c > 1 ? c : 0;
     }
     if (n_xrows == 0)
         n_wg = 0;                                    // no split document: no second layout
+    const int64_t nnz = indptr[B];
+    if (nnz > 0 && (!ids || !cnts))
+        return fail(TRLDA_ERR_ARG, "ids / cnts are NULL");
+    x->V = V; x->B = B; x->max_n = max_n; x->nnz = nnz;
+
+    // word-major segment offsets first: they give the number of active and long words, i.e.
+    // the layout of the allocation.  The histogram of the ids, and their validation on the way: an
+    // id outside [0, V) (one unsigned comparison) is counted as V - 1 and reported after the loop
+    std::vector<int32_t> &wptr = x->wptr;
+    wptr.assign((size_t)V + 1, 0);
+    {
+        int32_t *cnt = wptr.data() + 1;
+        const uint32_t last = (uint32_t)V - 1u;
+        uint32_t worst = 0;
+        for (int64_t i = 0; i < nnz; ++i) {
+            const uint32_t id = (uint32_t)ids[i];
+            worst = std::max(worst, id);
+            ++cnt[std::min(id, last)];
+        }
+        if (nnz > 0 && worst > last)
+            return fail(TRLDA_ERR_WORD_ID, "word id outside [0, num_words)");
+    }
+    // ONE scan of the vocabulary: offsets, active words, the longest list, the entries in lists of more
+    // than kSegMin, and how many lists exceed kLongWord << i for every i (a list of `len` entries
+    // exceeds the first floor(log2((len - 1) / kLongWord)) + 1 of them)
+    constexpr int kLevels = 16;
+    int n_active = 0, longest = 0;
+    long long heavy = 0;
+    int lvl[kLevels + 1] = {0};
+    {
+        int32_t run = 0;
+        for (int w = 0; w < V; ++w) {
+            const int len = wptr[(size_t)w + 1];
+            n_active += len > 0;
+            longest = std::max(longest, len);
+            heavy += len > trlda::kSegMin ? len : 0;
+            if (len > trlda::kLongWord) {            // (a few per cent of the words, or nearly all: predictable)
+                const unsigned t = (unsigned)(len - 1) / (unsigned)trlda::kLongWord;
+                ++lvl[std::min(32 - __builtin_clz(t), kLevels)];  // kLongWord << i < len for i < that
+            }
+            run += len;
+            wptr[(size_t)w + 1] = run;
+        }
+    }
+    int over[kLevels];
+    for (int i = kLevels - 1, acc = 0; i >= 0; --i) {
+        acc += lvl[i + 1];
+        over[i] = acc;
+    }
+    int level = 0;
+    while (level + 1 < kLevels && over[level] > trlda::kLongWordsTarget)
+        ++level;
+    int long_len = trlda::kLongWord << level, n_long = over[level];
+    // (the longest lists are cut into segments, estep_kernels.h: the one-wave range stays short)
+    if (long_len > trlda::kOneWaveMax) {
+        long_len = trlda::kOneWaveMax;
+        n_long = 0;
+        for (int w = 0; w < V; ++w)
+            n_long += wptr[(size_t)w + 1] - wptr[(size_t)w] > long_len;
+    }
+    // the longest lists as segment tasks (estep_kernels.h, VeryLongArgs): segment length per batch
+    int n_vl = 0, n_vl_tasks = 0, seg_len = trlda::kSegMin;
+    {
+        static const long long seg_tasks = std::getenv("TRLDA_SEG_TASKS") ? std::atoll(std::getenv("TRLDA_SEG_TASKS"))
+                                                                          : (long long)trlda::kSegTasks;
+        while (seg_len < trlda::kSegMax && heavy / seg_len > seg_tasks)
+            seg_len *= 2;
+    }
+    if (longest > seg_len) {                         // (else: no list is cut)
+        for (int w = 0; w < V; ++w) {
+            const int len = wptr[(size_t)w + 1] - wptr[(size_t)w];
+            if (len > seg_len) {
+                ++n_vl;
+                n_vl_tasks += (len + seg_len - 1) / seg_len;
+            }
+        }
+    }
     x->n_active = n_active; x->n_long = n_long; x->long_len = long_len;
     x->n_vl = n_vl; x->n_vl_tasks = n_vl_tasks; x->seg_len = seg_len;
     x->n_wg = n_wg; x->n_xrows = n_xrows;
+    x->max_list = longest;
 
     // layout (bytes, 256-aligned sections)
     size_t off = 0;
@@ -136,9 +160,30 @@ int batch_index_plan(int V, int B, const int32_t *indptr, const int32_t *ids, co
     return TRLDA_OK;
 }
 
+namespace {
+
+// a document's (or a segment's) row of kRegMaxN word ids: its first ids, then its last id repeated
+// (rows that exist; masked by length)
+inline void padded_row(int32_t *row, const int32_t *src, int len)
+{
+    const int m0 = std::min(len, trlda::kRegMaxN);
+    std::memcpy(row, src, (size_t)m0 * 4);
+    const int32_t fill = len > 0 ? src[m0 - 1] : 0;
+    for (int j = m0; j < trlda::kRegMaxN; ++j)
+        row[j] = fill;
+}
+
+struct FillScratch {
+    std::vector<int32_t> cursor, bins, alen, awords;
+    std::vector<int64_t> pair;
+};
+
+}  // namespace
+
 void batch_index_fill(BatchIndex *x, const int32_t *indptr, const int32_t *ids, const int32_t *cnts, int cus,
                       char *h)
 {
+    static thread_local FillScratch scratch;
     const int V = x->V, B = x->B;
     const size_t nz = (size_t)x->nnz, Bz = (size_t)B;
     const int n_active = x->n_active, n_long = x->n_long, long_len = x->long_len;
@@ -153,31 +198,81 @@ void batch_index_fill(BatchIndex *x, const int32_t *indptr, const int32_t *ids, 
     }
     std::memcpy(I(x->o_wptr), wptr.data(), ((size_t)V + 1) * 4);
     // stable counting sort of the CSR positions by word id, and the words' count sums
-    bool wc32_ok = true, cnts_nonneg = true;
     {
         int32_t *wrank = I(x->o_wrank), *wdoc = I(x->o_wdoc), *wc32 = I(x->o_wc32);
-        std::vector<int32_t> cursor(wptr.begin(), wptr.end() - 1);
-        std::vector<int64_t> wsum((size_t)V, 0);
-        for (int d = 0; d < B; ++d)
-            for (int32_t p = indptr[d]; p < indptr[d + 1]; ++p) {
-                const int32_t q = cursor[(size_t)ids[p]]++;
-                wrank[p] = q;
-                wdoc[q] = d;
-                wsum[(size_t)ids[p]] += cnts[p];
-                cnts_nonneg = cnts_nonneg && cnts[p] >= 0;
+        std::vector<int32_t> &cursor = scratch.cursor;
+        // (sum |cnt| below 2^31: no word's sum -- nor any partial sum -- leaves 32 bits; bounded first
+        // by entries x the largest |cnt|, exactly only when that does not settle it)
+        // (the OR of all counts: negative exactly when one of them is, and an upper bound of every one
+        // of them when none is -- a reduction the baseline instruction set vectorises)
+        int32_t any = 0;
+        for (size_t p = 0; p < nz; ++p)
+            any |= cnts[p];
+        x->cnts_nonneg = any >= 0;
+        int64_t mass = any >= 0 ? (int64_t)nz * any : (int64_t)INT32_MAX + 1;
+        if (mass > INT32_MAX) {
+            mass = 0;
+            for (size_t p = 0; p < nz; ++p)
+                mass += std::abs((int64_t)cnts[p]);
+        }
+        if (mass <= INT32_MAX) {
+            // (a word's cursor and its running sum side by side: one line, one 8-byte load and store)
+            std::vector<int64_t> &pair = scratch.pair;
+            pair.resize((size_t)V);
+            for (int w = 0; w < V; ++w)
+                pair[(size_t)w] = (int64_t)(uint32_t)wptr[(size_t)w];       // low half: cursor; high half: sum
+            for (int d = 0; d < B; ++d)
+                for (int32_t p = indptr[d]; p < indptr[d + 1]; ++p) {
+                    const size_t w = (size_t)ids[p];
+                    const int64_t v = pair[w];
+                    const int32_t q = (int32_t)(uint32_t)v;
+                    pair[w] = v + 1 + (int64_t)((uint64_t)(int64_t)cnts[p] << 32);
+                    wrank[p] = q;
+                    wdoc[q] = d;
+                }
+            for (int w = 0; w < V; ++w)
+                wc32[w] = (int32_t)(pair[(size_t)w] >> 32);
+            x->wc32_ok = true;
+        } else {
+            std::memset(wc32, 0, (size_t)V * 4);
+            cursor.assign(wptr.begin(), wptr.end() - 1);
+            std::vector<int64_t> wsum((size_t)V, 0);
+            for (int d = 0; d < B; ++d)
+                for (int32_t p = indptr[d]; p < indptr[d + 1]; ++p) {
+                    const int32_t q = cursor[(size_t)ids[p]]++;
+                    wrank[p] = q;
+                    wdoc[q] = d;
+                    wsum[(size_t)ids[p]] += cnts[p];
+                }
+            bool ok = true;
+            for (int w = 0; w < V; ++w) {
+                ok = ok && wsum[(size_t)w] >= INT32_MIN && wsum[(size_t)w] <= INT32_MAX;
+                wc32[w] = (int32_t)wsum[(size_t)w];
             }
-        for (int w = 0; w < V; ++w) {
-            wc32_ok = wc32_ok && wsum[(size_t)w] >= INT32_MIN && wsum[(size_t)w] <= INT32_MAX;
-            wc32[w] = (int32_t)wsum[(size_t)w];
+            x->wc32_ok = ok;
         }
     }
-    x->wc32_ok = wc32_ok;
-    x->cnts_nonneg = cnts_nonneg;
+    // documents by decreasing length, equal lengths in document order: a counting sort by length
     int32_t *order = I(x->o_order);
-    std::iota(order, order + B, 0);
-    std::stable_sort(order, order + B, [&](int32_t a, int32_t b) {
-        return indptr[a + 1] - indptr[a] > indptr[b + 1] - indptr[b];
-    });
+    if (x->max_n <= 65535) {
+        std::vector<int32_t> &bins = scratch.bins;
+        bins.assign((size_t)x->max_n + 2, 0);
+        for (int d = 0; d < B; ++d)
+            ++bins[(size_t)(indptr[d + 1] - indptr[d])];
+        int32_t run = 0;
+        for (int n = x->max_n; n >= 0; --n) {
+            const int32_t c = bins[(size_t)n];
+            bins[(size_t)n] = run;
+            run += c;
+        }
+        for (int d = 0; d < B; ++d)
+            order[bins[(size_t)(indptr[d + 1] - indptr[d])]++] = d;
+    } else {
+        std::iota(order, order + B, 0);
+        std::stable_sort(order, order + B, [&](int32_t a, int32_t b) {
+            return indptr[a + 1] - indptr[a] > indptr[b + 1] - indptr[b];
+        });
+    }
 
     x->sorted_len.resize(Bz);
     x->indptr_host.assign(indptr, indptr + Bz + 1);
@@ -190,14 +285,7 @@ void batch_index_fill(BatchIndex *x, const int32_t *indptr, const int32_t *ids, 
             meta[(size_t)i * 4 + 1] = n;
             meta[(size_t)i * 4 + 2] = p0;
             meta[(size_t)i * 4 + 3] = 0;
-            // words past the document repeat its last id (rows that exist; masked by length)
-            int32_t *row = pids + (size_t)i * trlda::kRegMaxN;
-            const int m0 = std::min(n, trlda::kRegMaxN);
-            for (int j = 0; j < m0; ++j)
-                row[j] = ids[p0 + j];
-            const int32_t fill = n > 0 ? ids[p0 + std::min(n, trlda::kRegMaxN) - 1] : 0;
-            for (int j = m0; j < trlda::kRegMaxN; ++j)
-                row[j] = fill;
+            padded_row(pids + (size_t)i * trlda::kRegMaxN, ids + p0, n);
         }
     }
     x->split_pays = false;
@@ -233,13 +321,7 @@ void batch_index_fill(BatchIndex *x, const int32_t *indptr, const int32_t *ids, 
                 int32_t *mm = meta + w * 8;
                 mm[0] = d; mm[1] = len; mm[2] = p0 + start; mm[3] = 0;
                 mm[4] = sgm; mm[5] = c; mm[6] = c > 1 ? xrow : 0; mm[7] = n;
-                int32_t *row = pids + w * trlda::kRegMaxN;
-                const int m0 = std::min(len, trlda::kRegMaxN);
-                for (int j = 0; j < m0; ++j)
-                    row[j] = ids[p0 + start + j];
-                const int32_t fill = len > 0 ? ids[p0 + start + m0 - 1] : 0;
-                for (int j = m0; j < trlda::kRegMaxN; ++j)
-                    row[j] = fill;
+                padded_row(pids + w * trlda::kRegMaxN, ids + p0 + start, len);
                 start += len;
             }
             if (c > 1)
@@ -247,20 +329,35 @@ void batch_index_fill(BatchIndex *x, const int32_t *indptr, const int32_t *ids, 
         }
     }
     {
+        // the second scan of the vocabulary: flags, the active words (and their lengths, for the
+        // descriptors below), the long words, the lengths' histogram -- a word is active or not about
+        // as often as not: every word is written at the list's end and the end moves on for an active one
         int32_t *active = I(x->o_active), *longw = I(x->o_long);
         uint8_t *flag = reinterpret_cast<uint8_t *>(h + x->o_flag);
-        int na = 0, nl = 0, longest = 0;
+        // (the histogram of the lengths in four copies by the low bits of the word id, and from the
+        // middle of the active list on in a second set of four: a counter that every other word
+        // increments is a chain of store-to-load forwards, ~5 cycles a word)
+        std::vector<int32_t> &alen = scratch.alen, &bins = scratch.bins;
+        alen.resize((size_t)n_active + 1);
+        const int nb = long_len + 2;                 // bins [len]: short lists of `len` entries; [long_len + 1]: longer
+        bins.assign((size_t)nb * 8, 0);
+        const int half = (n_active + 1) / 2;
+        std::vector<int32_t> &awords = scratch.awords;
+        awords.resize((size_t)n_active + 1);
+        int na = 0, nl = 0;
         for (int w = 0; w < V; ++w) {
             const int len = wptr[(size_t)w + 1] - wptr[(size_t)w];
-            longest = std::max(longest, len);
-            flag[w] = len > 0;
-            if (len > 0)
-                active[na++] = w;
-            if (len > long_len)
+            const bool on = len > 0;
+            flag[w] = on;
+            awords[(size_t)na] = w;                  // (written for every word, kept when it is active: the
+            alen[(size_t)na] = len;                  //  slot past the end exists, overwritten or unused)
+            ++bins[(size_t)(((na >= half) * 4 + (w & 3)) * nb + std::min(len, long_len + 1))];
+            na += on;
+            if (len > long_len)                      // (few words, or most of them: predictable either way)
                 longw[nl++] = w;
         }
+        std::memcpy(active, awords.data(), (size_t)n_active * 4);
         x->long_host.assign(longw, longw + nl);
-        x->max_list = longest;
         // the very long lists: equal segments of at most seg_len entries
         int32_t *vw = I(x->o_vlw), *vt = I(x->o_vlt);
         int j = 0, t = 0;
@@ -300,39 +397,51 @@ void batch_index_fill(BatchIndex *x, const int32_t *indptr, const int32_t *ids, 
             }
         }
         // descriptors for the merged launch: counting sort by length, longest first, the short
-        // lists (<= long_len entries) before the long ones
+        // lists (<= long_len entries) before the long ones; and the lists by length class
+        // (entries of a short list, or of a sixteenth of a long one: 9..16 | 5..8 | 3..4 | 1..2)
         int32_t *md = I(x->o_mdesc);
         const int n_short = n_active - n_long;
-        std::vector<int32_t> at((size_t)long_len + 2, 0);        // at[len]: next slot of a short list of `len`
-        for (int a = 0; a < na; ++a) {
-            const int len = wptr[(size_t)active[a] + 1] - wptr[(size_t)active[a]];
-            if (len <= long_len)
-                ++at[(size_t)len];
-        }
-        int run = 0;
-        for (int len = long_len; len >= 1; --len) {
-            const int c = at[(size_t)len];
-            at[(size_t)len] = run;
-            run += c;
-        }
-        std::vector<int32_t> longs;
-        for (int a = 0; a < na; ++a) {
-            const int w = active[a], q0 = wptr[(size_t)w], len = wptr[(size_t)w + 1] - q0;
-            if (len > long_len) {
-                longs.push_back(w);
-                continue;
-            }
-            int32_t *e = md + 4 * (size_t)at[(size_t)len]++;
-            e[0] = w; e[1] = q0; e[2] = len; e[3] = 0;
-        }
         for (int c = 0; c < 4; ++c)
             x->cls_short[c] = x->cls_long[c] = 0;
-        for (int a = 0; a < na; ++a) {
-            const int len = wptr[(size_t)active[a] + 1] - wptr[(size_t)active[a]];
-            const int unit = len <= long_len ? len : (len + 15) / 16;       // a list, or a chunk of one
-            const int c = unit > 8 ? 0 : unit > 4 ? 1 : unit > 2 ? 2 : 3;
-            ++(len <= long_len ? x->cls_short : x->cls_long)[c];
+        // cur[0 | 1][len]: the next slot of a short list of `len` entries in the first | second half of the
+        // active list (two cursors: two chains of dependent increments instead of one)
+        int32_t *cur0 = bins.data(), *cur1 = bins.data() + nb;
+        {
+            int32_t run = 0;
+            for (int len = long_len; len >= 1; --len) {
+                int32_t c0 = 0, c1 = 0;
+                for (int q = 0; q < 4; ++q) {
+                    c0 += bins[(size_t)(q * nb + len)];
+                    c1 += bins[(size_t)((4 + q) * nb + len)];
+                }
+                x->cls_short[len > 8 ? 0 : len > 4 ? 1 : len > 2 ? 2 : 3] += c0 + c1;
+                cur0[len] = run;                     // (rows 0 and 1 of `bins`: their counts for this and the
+                cur1[len] = run + c0;                //  lengths still to come have been read)
+                run += c0 + c1;
+            }
         }
+        std::vector<int32_t> longs;
+        auto place = [&](int a, int32_t *cur) {
+            const int w = active[a], len = alen[(size_t)a];
+            if (len > long_len)
+                return;
+            const int32_t e[4] = {w, wptr[(size_t)w], len, 0};
+            std::memcpy(md + 4 * (size_t)cur[len]++, e, 16);     // (one 16-byte store)
+        };
+        for (int a = 0; a < half; ++a) {
+            place(a, cur0);
+            if (half + a < na)
+                place(half + a, cur1);
+        }
+        if (n_long > 0)
+            for (int a = 0; a < na; ++a) {
+                const int len = alen[(size_t)a];
+                if (len > long_len) {
+                    longs.push_back(active[a]);
+                    const int unit = (len + 15) / 16;
+                    ++x->cls_long[unit > 8 ? 0 : unit > 4 ? 1 : unit > 2 ? 2 : 3];
+                }
+            }
         std::stable_sort(longs.begin(), longs.end(), [&](int32_t a, int32_t b) {
             return wptr[(size_t)a + 1] - wptr[(size_t)a] > wptr[(size_t)b + 1] - wptr[(size_t)b];
         });
@@ -378,4 +487,26 @@ extern "C" int trlda_debug_batch_index(int V, int B, const int32_t *indptr, cons
     for (int i = 0; i < 20; ++i)
         info[32 + i] = (int64_t)offs[i];
     return TRLDA_OK;
+}
+
+// microseconds per call of the index builder on this batch (tools/index_rate.py): `reps` calls into one
+// buffer; mode 0: batch_index_plan alone, 1: plan + fill
+extern "C" double trlda_debug_batch_index_rate(int V, int B, const int32_t *indptr, const int32_t *ids,
+                                               const int32_t *cnts, int cus, int reps, int mode)
+{
+    using namespace trlda_host;
+    BatchIndex probe;
+    if (batch_index_plan(V, B, indptr, ids, cnts, &probe))
+        return -1.0;
+    std::vector<char> buf(probe.total);
+    timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int r = 0; r < reps; ++r) {
+        BatchIndex x;
+        (void)batch_index_plan(V, B, indptr, ids, cnts, &x);
+        if (mode)
+            batch_index_fill(&x, indptr, ids, cnts, cus, buf.data());
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return ((t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3) / reps;
 }

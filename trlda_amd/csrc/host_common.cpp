@@ -110,6 +110,75 @@ HostPool &host_pool()
     return *pool;
 }
 
+// ---- WorkQueue ---------------------------------------------------------------------------------
+struct WorkQueue::Impl {
+    explicit Impl(int n) : n_(n) {}
+    ~Impl()
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_)
+            t.join();
+    }
+    void submit(std::function<void()> job)
+    {
+        if (n_ <= 0) {
+            job();
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            if ((int)workers_.size() < n_ && (int)workers_.size() < (int)jobs_.size() + running_ + 1)
+                workers_.emplace_back([this] { loop(); });     // (one more thread while there is a backlog)
+            jobs_.push_back(std::move(job));
+        }
+        cv_.notify_one();
+    }
+    void wait_idle()
+    {
+        std::unique_lock<std::mutex> lock(mu_);
+        idle_.wait(lock, [this] { return jobs_.empty() && running_ == 0; });
+    }
+    void loop()
+    {
+        for (;;) {
+            std::function<void()> job;
+            {
+                std::unique_lock<std::mutex> lock(mu_);
+                cv_.wait(lock, [this] { return stop_ || !jobs_.empty(); });
+                if (stop_ && jobs_.empty())
+                    return;
+                job = std::move(jobs_.front());
+                jobs_.erase(jobs_.begin());
+                ++running_;
+            }
+            job();
+            {
+                std::lock_guard<std::mutex> lock(mu_);
+                --running_;
+                if (jobs_.empty() && running_ == 0)
+                    idle_.notify_all();
+            }
+        }
+    }
+    const int n_;
+    std::mutex mu_;
+    std::condition_variable cv_, idle_;
+    std::vector<std::thread> workers_;
+    std::vector<std::function<void()>> jobs_;
+    int running_ = 0;
+    bool stop_ = false;
+};
+
+WorkQueue::WorkQueue(int threads) : impl_(new Impl(threads)) {}
+WorkQueue::~WorkQueue() { delete impl_; }
+int WorkQueue::threads() const { return impl_->n_; }
+void WorkQueue::submit(std::function<void()> job) { impl_->submit(std::move(job)); }
+void WorkQueue::wait_idle() { impl_->wait_idle(); }
+
 }  // namespace trlda_host
 
 extern "C" const char *trlda_last_error(void) { return trlda_host::g_error.c_str(); }

@@ -29,6 +29,23 @@ private:
 };
 HostPool &host_pool();
 
+// A queue of jobs worked off by a few threads of its own, in the order they were submitted (each
+// thread takes the next job): the mini-batch index of trlda_batch_create is built here while the
+// caller goes on (trlda_hip.hip).  Threads start with the first job; `threads` <= 0: submit()
+// runs the job on the caller.  wait_idle(): every submitted job has finished.
+class WorkQueue {
+public:
+    explicit WorkQueue(int threads);
+    ~WorkQueue();
+    int threads() const;
+    void submit(std::function<void()> job);
+    void wait_idle();
+
+private:
+    struct Impl;
+    Impl *impl_;
+};
+
 // ---- the generator behind trlda_seed / trlda_sample_gamma (glibc's TYPE_3 rand()) ----------
 struct JumpMatrix {
     uint32_t a[31][31];
