@@ -31,6 +31,60 @@ inline int segments_of(int n)
 
 }  // namespace
 
+int batch_index_check_lengths(int V, int B, const int32_t *indptr, int *max_n_out, int *n_wg_out)
+{
+    if (V <= 0 || B < 0 || !indptr)
+        return fail(TRLDA_ERR_ARG, "bad batch dimensions");
+    if (indptr[0] != 0)
+        return fail(TRLDA_ERR_ARG, "indptr[0] must be 0");
+    int max_n = 0, n_wg = 0, n_xrows = 0;
+    for (int d = 0; d < B; ++d) {
+        const int n = indptr[d + 1] - indptr[d];
+        if (indptr[d + 1] < indptr[d])
+            return fail(TRLDA_ERR_ARG, "indptr must be non-decreasing");
+        max_n = std::max(max_n, n);
+        const int c = segments_of(n);
+        n_wg += c;
+        n_xrows += c > 1 ? c : 0;
+    }
+    *max_n_out = max_n;
+    *n_wg_out = n_xrows ? n_wg : 0;
+    return TRLDA_OK;
+}
+
+int batch_index_check_ids(int V, int64_t nnz, const int32_t *ids)
+{
+    // (the OR of the ids and of V - 1 - id: some id outside [0, V) sets the sign bit of one of them)
+    uint32_t any = 0;
+    const uint32_t last = (uint32_t)V - 1u;
+    for (int64_t i = 0; i < nnz; ++i)
+        any |= (uint32_t)ids[i] | (last - (uint32_t)ids[i]);
+    if (any & 0x80000000u)
+        return fail(TRLDA_ERR_WORD_ID, "word id outside [0, num_words)");
+    return TRLDA_OK;
+}
+
+void batch_index_csr_offsets(int B, int64_t nnz, size_t *o_ids, size_t *o_cnts)
+{
+    *o_ids = align256(std::max<size_t>(((size_t)B + 1) * 4, 4));
+    *o_cnts = *o_ids + align256(std::max<size_t>((size_t)nnz * 4, 4));
+}
+
+size_t batch_index_size_bound(int V, int B, int64_t nnz, int n_wg)
+{
+    const size_t nz = (size_t)nnz, Bz = (size_t)B, Vz = (size_t)V;
+    const size_t n_active = std::min(Vz, nz), n_long = std::min(Vz, nz / (trlda::kLongWord + 1));
+    const size_t n_vl = nz / (trlda::kSegMin + 1), n_tasks = nz / trlda::kSegMin + n_vl;
+    const size_t sizes[] = {(Bz + 1) * 4, nz * 4, nz * 4, Bz * 4, nz * 4, (Vz + 1) * 4, nz * 4, Bz * 16,
+                            Bz * trlda::kRegMaxN * 4, (size_t)n_wg * 32, (size_t)n_wg * trlda::kRegMaxN * 4,
+                            n_active * 4, n_long * 4, Vz, Vz * 4, n_active * 16, n_vl * 16, n_tasks * 16,
+                            n_tasks * 16};
+    size_t total = 0;
+    for (size_t b : sizes)
+        total += align256(std::max<size_t>(b, 4));
+    return total;
+}
+
 // Written for the host's time per mini-batch (round 6: 60 us of a 75 us trlda_batch_create were spent
 // here, against 26 us of kernels per 200 documents): every pass over the entries or the vocabulary is
 // branch-free where the data decide (a word is active or not with probability ~1/2: a mispredicted
@@ -191,11 +245,12 @@ void batch_index_fill(BatchIndex *x, const int32_t *indptr, const int32_t *ids, 
     const std::vector<int32_t> &wptr = x->wptr;
     auto I = [&](size_t o) { return reinterpret_cast<int32_t *>(h + o); };
 
-    std::memcpy(I(x->o_indptr), indptr, (Bz + 1) * 4);
-    if (nz) {
+    if (I(x->o_indptr) != indptr)
+        std::memcpy(I(x->o_indptr), indptr, (Bz + 1) * 4);
+    if (nz && I(x->o_ids) != ids)
         std::memcpy(I(x->o_ids), ids, nz * 4);
+    if (nz && I(x->o_cnts) != cnts)
         std::memcpy(I(x->o_cnts), cnts, nz * 4);
-    }
     std::memcpy(I(x->o_wptr), wptr.data(), ((size_t)V + 1) * 4);
     // stable counting sort of the CSR positions by word id, and the words' count sums
     {
@@ -345,16 +400,24 @@ void batch_index_fill(BatchIndex *x, const int32_t *indptr, const int32_t *ids, 
         std::vector<int32_t> &awords = scratch.awords;
         awords.resize((size_t)n_active + 1);
         int na = 0, nl = 0;
-        for (int w = 0; w < V; ++w) {
-            const int len = wptr[(size_t)w + 1] - wptr[(size_t)w];
-            const bool on = len > 0;
-            flag[w] = on;
-            awords[(size_t)na] = w;                  // (written for every word, kept when it is active: the
-            alen[(size_t)na] = len;                  //  slot past the end exists, overwritten or unused)
-            ++bins[(size_t)(((na >= half) * 4 + (w & 3)) * nb + std::min(len, long_len + 1))];
-            na += on;
-            if (len > long_len)                      // (few words, or most of them: predictable either way)
-                longw[nl++] = w;
+        {
+            // (local, restrict-qualified pointers: `flag` is a byte pointer, which the compiler must
+            // otherwise assume to alias every vector's bookkeeping -- a reload of each per word)
+            const int32_t *__restrict wp = wptr.data();
+            int32_t *__restrict aw = awords.data(), *__restrict al = alen.data(), *__restrict hist = bins.data();
+            uint8_t *__restrict fl = flag;
+            const int cap = long_len + 1;
+            for (int w = 0; w < V; ++w) {
+                const int len = wp[w + 1] - wp[w];
+                const bool on = len > 0;
+                fl[w] = on;
+                aw[na] = w;                          // (written for every word, kept when it is active: the
+                al[na] = len;                        //  slot past the end exists, overwritten or unused)
+                ++hist[((na >= half) * 4 + (w & 3)) * nb + (len < cap ? len : cap)];
+                na += on;
+                if (len > long_len)                  // (few words, or most of them: predictable either way)
+                    longw[nl++] = w;
+            }
         }
         std::memcpy(active, awords.data(), (size_t)n_active * 4);
         x->long_host.assign(longw, longw + nl);
@@ -421,17 +484,23 @@ void batch_index_fill(BatchIndex *x, const int32_t *indptr, const int32_t *ids, 
             }
         }
         std::vector<int32_t> longs;
-        auto place = [&](int a, int32_t *cur) {
-            const int w = active[a], len = alen[(size_t)a];
-            if (len > long_len)
-                return;
-            const int32_t e[4] = {w, wptr[(size_t)w], len, 0};
-            std::memcpy(md + 4 * (size_t)cur[len]++, e, 16);     // (one 16-byte store)
-        };
-        for (int a = 0; a < half; ++a) {
-            place(a, cur0);
-            if (half + a < na)
-                place(half + a, cur1);
+        {
+            const int32_t *__restrict wp = wptr.data(), *__restrict aw = awords.data(), *__restrict al = alen.data();
+            int32_t *__restrict c0 = cur0, *__restrict c1 = cur1;
+            int64_t *__restrict md2 = reinterpret_cast<int64_t *>(md);       // a descriptor: two 8-byte halves
+            auto place = [&](int a, int32_t *__restrict cur) {
+                const int w = aw[a], len = al[a];
+                if (len > long_len)
+                    return;
+                const size_t slot = (size_t)cur[len]++;
+                md2[2 * slot] = (int64_t)(uint32_t)w | ((int64_t)(uint32_t)wp[w] << 32);     // (word, first entry)
+                md2[2 * slot + 1] = (int64_t)(uint32_t)len;                                  // (entries, 0)
+            };
+            for (int a = 0; a < half; ++a) {
+                place(a, c0);
+                if (half + a < na)
+                    place(half + a, c1);
+            }
         }
         if (n_long > 0)
             for (int a = 0; a < na; ++a) {

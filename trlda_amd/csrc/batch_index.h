@@ -38,11 +38,21 @@ struct BatchIndex {
     std::vector<int32_t> sorted_len, indptr_host, long_host, vl_host, vl_first;
 };
 
+// What a caller can know before the index is planned (trlda_batch_create's own thread, while the
+// index is built on another): the lengths' validation with the longest document and the split layout's
+// workgroups; the word ids' range; where the CSR arrays lie in the buffer (their offsets depend on B and
+// the number of entries alone) and an upper bound of the buffer's size.
+int batch_index_check_lengths(int V, int B, const int32_t *indptr, int *max_n, int *n_wg);
+int batch_index_check_ids(int V, int64_t nnz, const int32_t *ids);
+void batch_index_csr_offsets(int B, int64_t nnz, size_t *o_ids, size_t *o_cnts);
+size_t batch_index_size_bound(int V, int B, int64_t nnz, int n_wg);
+
 // TRLDA_OK, or TRLDA_ERR_ARG / TRLDA_ERR_WORD_ID with the message set (host_common.h, fail)
 int batch_index_plan(int V, int B, const int32_t *indptr, const int32_t *ids, const int32_t *cnts,
                      BatchIndex *x);
 // writes x->total bytes at `h` (the gaps between sections are left as they are); `cus`: the device's
-// compute units (whether splitting long documents pays depends on how full the chip is)
+// compute units (whether splitting long documents pays depends on how full the chip is).  The three
+// CSR arrays may already lie where they belong (indptr == h + o_indptr, ...): they are left alone then.
 void batch_index_fill(BatchIndex *x, const int32_t *indptr, const int32_t *ids, const int32_t *cnts, int cus,
                       char *h);
 

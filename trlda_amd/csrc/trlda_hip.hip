@@ -129,6 +129,25 @@ int use_device(int device)
 }  // namespace
 
 struct trlda_batch {
+    // The index is built and uploaded by a worker thread of the library while trlda_batch_create's caller
+    // goes on (round 6): what the caller's thread has established itself -- device, V, B, nnz, max_n, id --
+    // is valid from the start, everything else once the ticket's state is kBuilt.  Every entry point that is
+    // handed a batch waits for that first (batch_wait); a failed build (out of device memory) fails
+    // the entry point with the build's status and message.
+    // kQueued: nobody has started on it -- whoever needs the batch first (batch_wait) takes the build
+    // from the queue and runs it on its own thread, so that "create, use at once" costs what it cost
+    // when trlda_batch_create built the index itself; and a batch destroyed before anybody needed it
+    // is never indexed at all (kCancelled).  The state lives in a ticket the queued job shares: the
+    // job may outlive the batch.
+    enum { kBuilt = 0, kQueued = 1, kFailed = 2, kBuilding = 3, kCancelled = 4 };
+    struct Ticket {
+        std::atomic<int> state{kBuilt};
+    };
+    std::shared_ptr<Ticket> ticket = std::make_shared<Ticket>();
+    void *slot = nullptr;              // the staging buffer that holds its CSR arrays until the build
+    int build_rc = 0;
+    std::string build_msg;
+    bool destroy_when_built = false;   // trlda_batch_destroy came while a worker was building: the worker destroys it
     // Every array below lives in ONE device allocation (`blob`), filled by ONE host-to-device
     // copy from pinned memory on the upload stream; `ready` marks the end of that copy and
     // `done` the last kernel that read the batch (recorded by every entry point that uses it),
@@ -509,12 +528,16 @@ namespace {
 struct UploadContext {
     std::mutex mu;
     hipStream_t stream = nullptr;
+    // pinned staging buffers: one is a build's from stage_acquire until its copy is enqueued (`busy`),
+    // and anybody's again once that copy has left (`ev`)
     struct Stage {
         void *host = nullptr;
         size_t cap = 0;
         hipEvent_t ev = nullptr;
-    } stage[2];
-    int next = 0;
+        bool busy = false;
+    };
+    std::vector<std::unique_ptr<Stage>> stages;
+    std::condition_variable stage_cv;
     struct Blob {
         void *ptr;
         size_t bytes;
@@ -552,7 +575,7 @@ UploadContext &upload_context(int device)
     return *it->second;
 }
 
-constexpr size_t kBlobCacheMax = 8;
+constexpr size_t kBlobCacheMax = 16;   // (several indices are in the making at a time: stage_acquire)
 constexpr size_t kBlobCacheBytes = (size_t)1 << 30;
 
 int take_event(UploadContext &u, hipEvent_t *ev)
@@ -2798,52 +2821,128 @@ int trlda_dev_synchronize(int device)
 
 // ---- batches ------------------------------------------------------------------
 
-int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_t *indptr,
-                       const int32_t *ids, const int32_t *cnts)
+}  // extern "C"
+
+namespace {
+
+constexpr size_t kStageSlots = 8;
+
+// workers that build and upload the indices (TRLDA_INDEX_THREADS, default 4 -- fewer on a small host;
+// 0: trlda_batch_create builds on its caller's thread, as in rounds 1-5)
+trlda_host::WorkQueue &index_queue()
 {
-    if (!out)
-        return fail(TRLDA_ERR_ARG, "out is NULL");
-    *out = nullptr;
-    // validation, the histogram of the word ids and the layout of the allocation (batch_index.cpp:
-    // host only); the index itself is written straight into pinned memory below
+    // (on the heap, per process: a child of fork() has none of the parent's threads -- host_pool's note)
+    static trlda_host::WorkQueue *queue = nullptr;
+    static pid_t owner = 0;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!queue || owner != getpid()) {
+        int n = 4;
+        if (const char *e = std::getenv("TRLDA_INDEX_THREADS"))
+            n = std::max(0, std::min(std::atoi(e), 32));
+        const int hw = (int)std::thread::hardware_concurrency();
+        if (hw > 0 && n > 0)
+            n = std::max(1, std::min(n, hw - 1));
+        queue = new trlda_host::WorkQueue(n);
+        owner = getpid();
+        if (n > 0)                                   // (no index in the making while the runtime goes away)
+            std::atexit([] { index_queue().wait_idle(); });
+    }
+    return *queue;
+}
+
+// publication of a build's end (state, destroy_when_built) and the consumers' wait for it
+std::mutex g_build_mu;
+std::condition_variable g_build_cv;
+
+// a staging buffer of at least `bytes` that is nobody else's until stage_release
+int stage_acquire(UploadContext &u, size_t bytes, UploadContext::Stage **out)
+{
+    std::unique_lock<std::mutex> lock(u.mu);
+    for (;;) {
+        UploadContext::Stage *pick = nullptr, *late = nullptr;
+        for (auto &sp : u.stages) {
+            UploadContext::Stage *st = sp.get();
+            if (st->busy)
+                continue;
+            if (st->ev && hipEventQuery(st->ev) != hipSuccess) {
+                (void)hipGetLastError();
+                late = late ? late : st;             // (its last upload is still on its way)
+                continue;
+            }
+            if (!pick || (pick->cap < bytes && st->cap > pick->cap))
+                pick = st;
+            if (pick->cap >= bytes)
+                break;                               // (large enough: no need to ask the others' events)
+        }
+        if (!pick && u.stages.size() < kStageSlots) {
+            u.stages.emplace_back(new UploadContext::Stage());
+            pick = u.stages.back().get();
+        }
+        if (!pick && late) {
+            HIP_TRY(hipEventSynchronize(late->ev));
+            pick = late;
+        }
+        if (!pick) {                                 // every buffer is some build's: wait for one
+            u.stage_cv.wait(lock);
+            continue;
+        }
+        if (pick->cap < bytes) {
+            if (pick->host)
+                (void)hipHostFree(pick->host);
+            pick->host = nullptr;
+            pick->cap = 0;
+            const size_t want = std::max<size_t>(bytes + bytes / 2, (size_t)1 << 20);
+            HIP_TRY(hipHostMalloc(&pick->host, want, hipHostMallocDefault));
+            pick->cap = want;
+        }
+        if (!pick->ev)
+            HIP_TRY(hipEventCreateWithFlags(&pick->ev, hipEventDisableTiming));
+        pick->busy = true;
+        *out = pick;
+        return TRLDA_OK;
+    }
+}
+
+void stage_release(UploadContext &u, UploadContext::Stage *st)   // (u.mu held)
+{
+    st->busy = false;
+    u.stage_cv.notify_one();
+}
+
+// The index of batch `b` from the CSR arrays at the head of staging buffer `st`, into a device
+// allocation, the copy enqueued on the upload stream: on a worker thread, or on trlda_batch_create's
+int batch_build(trlda_batch *b, UploadContext::Stage *st)
+{
+    UploadContext &u = upload_context(b->device);
+    auto give_up = [&](int rc) {
+        std::lock_guard<std::mutex> lock(u.mu);
+        stage_release(u, st);
+        return rc;
+    };
+    HIP_TRY(hipSetDevice(b->device));
+    static std::atomic<int> cus_cache[64];
+    int cus = b->device < 64 ? cus_cache[b->device].load(std::memory_order_relaxed) : 0;
+    if (cus <= 0) {
+        cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
+        if (b->device < 64)
+            cus_cache[b->device].store(cus, std::memory_order_relaxed);
+    }
+    char *h = static_cast<char *>(st->host);
+    size_t o_ids = 0, o_cnts = 0;
+    trlda_host::batch_index_csr_offsets(b->B, b->nnz, &o_ids, &o_cnts);
+    const int32_t *indptr = reinterpret_cast<const int32_t *>(h), *ids = reinterpret_cast<const int32_t *>(h + o_ids),
+                  *cnts = reinterpret_cast<const int32_t *>(h + o_cnts);
     trlda_host::BatchIndex x;
-    int rc = trlda_host::batch_index_plan(V, B, indptr, ids, cnts, &x);
+    int rc = trlda_host::batch_index_plan(b->V, b->B, indptr, ids, cnts, &x);
     if (rc)
-        return rc;
-    rc = use_device(device);
-    if (rc)
-        return rc;
+        return give_up(rc);
+    if (x.total > st->cap || x.o_ids != o_ids || x.o_cnts != o_cnts)
+        return give_up(fail(TRLDA_ERR_ARG, "internal: the index outgrew its staging buffer"));
     const size_t total = x.total;
-    int cus = 256;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    trlda_host::batch_index_fill(&x, indptr, ids, cnts, cus, h);
 
-    UploadContext &u = upload_context(device);
-    std::lock_guard<std::mutex> lock(u.mu);
-    if (!u.stream)
-        HIP_TRY(hipStreamCreateWithFlags(&u.stream, hipStreamNonBlocking));
-    UploadContext::Stage &st = u.stage[u.next];
-    u.next ^= 1;
-    if (st.ev)
-        HIP_TRY(hipEventSynchronize(st.ev));         // the slot's previous upload has left
-    if (st.cap < total) {
-        if (st.host)
-            (void)hipHostFree(st.host);
-        st.host = nullptr;
-        st.cap = 0;
-        const size_t want = std::max<size_t>(total + total / 2, (size_t)1 << 20);
-        HIP_TRY(hipHostMalloc(&st.host, want, hipHostMallocDefault));
-        st.cap = want;
-    }
-    if (!st.ev)
-        HIP_TRY(hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
-    trlda_host::batch_index_fill(&x, indptr, ids, cnts, cus, static_cast<char *>(st.host));
-
-    trlda_batch *b = new trlda_batch();
-    {
-        static std::atomic<uint64_t> next_id{1};
-        b->id = next_id.fetch_add(1);
-    }
-    b->device = device; b->V = V; b->B = B; b->nnz = x.nnz; b->max_n = x.max_n;
     b->n_active = x.n_active; b->n_long = x.n_long; b->long_len = x.long_len;
     b->split_pays = x.split_pays;
     b->max_list = x.max_list;
@@ -2858,6 +2957,11 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     b->vl_host.swap(x.vl_host);
     b->vl_first.swap(x.vl_first);
 
+    std::lock_guard<std::mutex> lock(u.mu);
+    if (!u.stream && hipStreamCreateWithFlags(&u.stream, hipStreamNonBlocking) != hipSuccess) {
+        stage_release(u, st);
+        return fail(TRLDA_ERR_HIP, "hipStreamCreateWithFlags failed");
+    }
     // a device allocation: from the cache when one fits, else new
     // (one whose last reader has finished, if there is one: an upload into an allocation that
     // the previous call's kernels still read would have to wait for them; with two or three
@@ -2877,13 +2981,14 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
             u.cache.erase(u.cache.begin() + (long)i);
             break;
         }
+    (void)hipGetLastError();                         // (hipErrorNotReady of the queries above)
     if (!blob.ptr) {
         size_t want = (size_t)1 << 16;
         while (want < total)
             want <<= 1;
         hipError_t e = hipMalloc(&blob.ptr, want);
         if (e != hipSuccess) {
-            delete b;
+            stage_release(u, st);
             return fail(TRLDA_ERR_HIP, std::string("hipMalloc (batch): ") + hipGetErrorString(e));
         }
         blob.bytes = want;
@@ -2896,9 +3001,9 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
         u.spare(blob.done, blob.on, blob.on_owned);
     }                                                // (else: that stream and its work are gone; the event is dropped)
     if (err == hipSuccess)
-        err = hipMemcpyAsync(b->blob, st.host, total, hipMemcpyHostToDevice, u.stream);
+        err = hipMemcpyAsync(b->blob, st->host, total, hipMemcpyHostToDevice, u.stream);
     if (err == hipSuccess)
-        err = hipEventRecord(st.ev, u.stream);
+        err = hipEventRecord(st->ev, u.stream);
     if (err == hipSuccess && take_event(u, &b->ready) == TRLDA_OK && take_event(u, &b->done) == TRLDA_OK)
         err = hipEventRecord(b->ready, u.stream);
     else if (err == hipSuccess)
@@ -2906,9 +3011,11 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     if (err != hipSuccess) {
         (void)hipStreamSynchronize(u.stream);
         (void)hipFree(b->blob);
-        delete b;
+        b->blob = nullptr;
+        stage_release(u, st);
         return fail(TRLDA_ERR_HIP, std::string("batch upload: ") + hipGetErrorString(err));
     }
+    stage_release(u, st);
     char *dv = static_cast<char *>(b->blob);
     auto D = [&](size_t o) { return reinterpret_cast<int32_t *>(dv + o); };
     b->indptr = D(x.o_indptr); b->ids = D(x.o_ids); b->cnts = D(x.o_cnts); b->order = D(x.o_order);
@@ -2926,6 +3033,117 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     b->vl_word = D(x.o_vlw); b->vl_task = D(x.o_vlt); b->vl_task_tiled = D(x.o_vltt);
     b->n_vl = x.n_vl; b->n_vl_tasks = x.n_vl_tasks; b->seg_len = x.seg_len;
     u.live.insert(b);
+    return TRLDA_OK;
+}
+
+// the build's end: its status becomes the batch's, whoever waits is woken; a batch whose owner has
+// let go of it in the meantime is destroyed here
+void batch_publish(trlda_batch *b, int rc)
+{
+    bool destroy = false;
+    {
+        std::lock_guard<std::mutex> lock(g_build_mu);
+        if (rc) {
+            b->build_rc = rc;
+            b->build_msg = trlda_last_error();
+        }
+        b->slot = nullptr;
+        b->ticket->state.store(rc ? trlda_batch::kFailed : trlda_batch::kBuilt, std::memory_order_release);
+        destroy = b->destroy_when_built;
+    }
+    g_build_cv.notify_all();
+    if (destroy)
+        (void)trlda_batch_destroy(b);
+}
+
+// every entry point that is handed a batch: its index is there (or the build's failure is the call's).
+// A build that no worker has started on yet is taken over by the caller.
+int batch_wait(const trlda_batch *cb)
+{
+    if (!cb)
+        return TRLDA_OK;
+    trlda_batch *b = const_cast<trlda_batch *>(cb);
+    std::atomic<int> &state = b->ticket->state;
+    int st = state.load(std::memory_order_acquire);
+    if (st == trlda_batch::kQueued) {
+        int expect = trlda_batch::kQueued;
+        if (state.compare_exchange_strong(expect, trlda_batch::kBuilding, std::memory_order_acq_rel))
+            batch_publish(b, batch_build(b, static_cast<UploadContext::Stage *>(b->slot)));
+        st = state.load(std::memory_order_acquire);
+    }
+    if (st == trlda_batch::kBuilding) {
+        std::unique_lock<std::mutex> lock(g_build_mu);
+        g_build_cv.wait(lock, [&] { return state.load(std::memory_order_acquire) != trlda_batch::kBuilding; });
+        st = state.load(std::memory_order_acquire);
+    }
+    if (st == trlda_batch::kFailed)
+        return fail(b->build_rc, "the batch's index could not be built: " + b->build_msg);
+    return TRLDA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_t *indptr,
+                       const int32_t *ids, const int32_t *cnts)
+{
+    if (!out)
+        return fail(TRLDA_ERR_ARG, "out is NULL");
+    *out = nullptr;
+    // On this thread: what can fail because of the arguments -- lengths, word ids (the reference has
+    // undefined behaviour there: lda.cpp:108) -- and a copy of the CSR arrays into pinned memory, at
+    // the place they have in the index (the caller's arrays are the caller's again on return).  The
+    // index itself (csrc/batch_index.cpp) and the upload: on a worker thread.
+    int max_n = 0, n_wg = 0;
+    int rc = trlda_host::batch_index_check_lengths(V, B, indptr, &max_n, &n_wg);
+    if (rc)
+        return rc;
+    const int64_t nnz = indptr[B];
+    if (nnz > 0 && (!ids || !cnts))
+        return fail(TRLDA_ERR_ARG, "ids / cnts are NULL");
+    if ((rc = trlda_host::batch_index_check_ids(V, nnz, ids)))
+        return rc;
+    if ((rc = use_device(device)))
+        return rc;
+    UploadContext &u = upload_context(device);
+    UploadContext::Stage *st = nullptr;
+    if ((rc = stage_acquire(u, trlda_host::batch_index_size_bound(V, B, nnz, n_wg), &st)))
+        return rc;
+    {
+        char *h = static_cast<char *>(st->host);
+        size_t o_ids = 0, o_cnts = 0;
+        trlda_host::batch_index_csr_offsets(B, nnz, &o_ids, &o_cnts);
+        std::memcpy(h, indptr, ((size_t)B + 1) * 4);
+        if (nnz) {
+            std::memcpy(h + o_ids, ids, (size_t)nnz * 4);
+            std::memcpy(h + o_cnts, cnts, (size_t)nnz * 4);
+        }
+    }
+    trlda_batch *b = new trlda_batch();
+    {
+        static std::atomic<uint64_t> next_id{1};
+        b->id = next_id.fetch_add(1);
+    }
+    b->device = device; b->V = V; b->B = B; b->nnz = nnz; b->max_n = max_n;
+    trlda_host::WorkQueue &queue = index_queue();
+    if (queue.threads() <= 0) {
+        rc = batch_build(b, st);
+        if (rc) {                                    // (as in rounds 1-5: the failure is this call's)
+            delete b;
+            return rc;
+        }
+    } else {
+        b->slot = st;
+        b->ticket->state.store(trlda_batch::kQueued, std::memory_order_release);
+        std::shared_ptr<trlda_batch::Ticket> ticket = b->ticket;
+        queue.submit([b, st, ticket] {
+            int expect = trlda_batch::kQueued;       // (taken over by its first user, or cancelled: nothing to do --
+            if (ticket->state.compare_exchange_strong(expect, trlda_batch::kBuilding,   //  `b` may be gone)
+                                                      std::memory_order_acq_rel))
+                batch_publish(b, batch_build(b, st));
+        });
+    }
     *out = b;
     return TRLDA_OK;
 }
@@ -2934,6 +3152,27 @@ int trlda_batch_destroy(trlda_batch *b)
 {
     if (!b)
         return TRLDA_OK;
+    {
+        // Nobody has started on its index: it is never built (the queued job finds the ticket
+        // cancelled).  A worker is building it: the worker destroys it when it is done.
+        int expect = trlda_batch::kQueued;
+        if (b->ticket->state.compare_exchange_strong(expect, trlda_batch::kCancelled, std::memory_order_acq_rel)) {
+            UploadContext &u = upload_context(b->device);
+            {
+                std::lock_guard<std::mutex> lock(u.mu);
+                stage_release(u, static_cast<UploadContext::Stage *>(b->slot));
+            }
+            delete b;
+            return TRLDA_OK;
+        }
+        if (expect == trlda_batch::kBuilding) {
+            std::lock_guard<std::mutex> lock(g_build_mu);
+            if (b->ticket->state.load(std::memory_order_acquire) == trlda_batch::kBuilding) {
+                b->destroy_when_built = true;
+                return TRLDA_OK;
+            }
+        }
+    }
     // a model's deferred statistics still read this batch: they are launched first (the guard
     // event below then covers them)
     if (b->pending_in && hipSetDevice(b->device) == hipSuccess)
@@ -2989,9 +3228,10 @@ int trlda_batch_destroy(trlda_batch *b)
 int trlda_batch_num_docs(const trlda_batch *b) { return b ? b->B : 0; }
 int64_t trlda_batch_nnz(const trlda_batch *b) { return b ? b->nnz : 0; }
 int trlda_batch_max_doc_len(const trlda_batch *b) { return b ? b->max_n : 0; }
-int trlda_batch_long_word_len(const trlda_batch *b) { return b ? b->long_len : 0; }
-int trlda_batch_num_long_words(const trlda_batch *b) { return b ? b->n_long : 0; }
-int trlda_batch_num_very_long_words(const trlda_batch *b) { return b ? b->n_vl : 0; }
+// (what the index build establishes: waited for)
+int trlda_batch_long_word_len(const trlda_batch *b) { return b && !batch_wait(b) ? b->long_len : 0; }
+int trlda_batch_num_long_words(const trlda_batch *b) { return b && !batch_wait(b) ? b->n_long : 0; }
+int trlda_batch_num_very_long_words(const trlda_batch *b) { return b && !batch_wait(b) ? b->n_vl : 0; }
 
 // ---- model --------------------------------------------------------------------
 
@@ -3379,6 +3619,9 @@ int trlda_model_get_sstats(trlda_model *m, double *host_sstats)
 int trlda_model_estep(trlda_model *m, const trlda_batch *b, double *gamma_dev, double *sstats_dev,
                       int max_iter, double threshold, int32_t *iters_dev)
 {
+    // (the batches' indices are built on worker threads: trlda_batch_create)
+    if (int rc_built = batch_wait(b))
+        return rc_built;
     int rc = check_model(m);
     if (rc)
         return rc;
@@ -3391,6 +3634,9 @@ int trlda_model_estep_io(trlda_model *m, const trlda_batch *b, const double *gam
                          double *gamma_dev, double *sstats_dev, int max_iter, double threshold,
                          int32_t *iters_dev)
 {
+    // (the batches' indices are built on worker threads: trlda_batch_create)
+    if (int rc_built = batch_wait(b))
+        return rc_built;
     int rc = check_model(m);
     if (rc)
         return rc;
@@ -3403,6 +3649,11 @@ int trlda_model_estep_io_next(trlda_model *m, const trlda_batch *b, const trlda_
                               const double *gamma0_dev, double *gamma_dev, double *sstats_dev,
                               int max_iter, double threshold, int32_t *iters_dev)
 {
+    // (the batches' indices are built on worker threads: trlda_batch_create)
+    if (int rc_built = batch_wait(b))
+        return rc_built;
+    if (int rc_built = batch_wait(next))
+        return rc_built;
     // (the next E-step of a deferred stream: estep_device decides whether its launch carries the
     // statistics the call before left pending, or launches them first)
     int rc = check_model(m, true);
@@ -3568,6 +3819,12 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
                                int n_upcoming, const double *gamma0_dev, double *gamma_dev,
                                double *sstats_dev, int max_iter, double threshold, int32_t *iters_dev)
 {
+    // (the batches' indices are built on worker threads: trlda_batch_create)
+    if (int rc_built = batch_wait(b))
+        return rc_built;
+    for (int i_up = 0; upcoming && i_up < n_upcoming; ++i_up)
+        if (int rc_built = batch_wait(upcoming[i_up]))
+            return rc_built;
     if (!m)
         return fail(TRLDA_ERR_ARG, "model is NULL");
     if (n_upcoming < 0 || (n_upcoming > 0 && !upcoming))
@@ -3702,6 +3959,9 @@ int trlda_model_set_prefetch(trlda_model *m, int enabled)
 int trlda_model_estep_host(trlda_model *m, const trlda_batch *b, double *gamma, double *sstats,
                            int max_iter, double threshold, int32_t *iters_out)
 {
+    // (the batches' indices are built on worker threads: trlda_batch_create)
+    if (int rc_built = batch_wait(b))
+        return rc_built;
     int rc = check_model(m);
     if (rc)
         return rc;
@@ -3742,6 +4002,9 @@ int trlda_model_estep_host(trlda_model *m, const trlda_batch *b, double *gamma, 
 int trlda_model_lower_bound(trlda_model *m, const trlda_batch *b, double *gamma, double eta,
                             double factor, int max_iter, double threshold, double *bound_out)
 {
+    // (the batches' indices are built on worker threads: trlda_batch_create)
+    if (int rc_built = batch_wait(b))
+        return rc_built;
     int rc = check_model(m);
     if (rc)
         return rc;
@@ -3821,6 +4084,9 @@ int trlda_model_blend(trlda_model *m, const double *lambda_prime_dev, const doub
 int trlda_model_tr_init(trlda_model *m, const trlda_batch *b, const double *lambda_prime_dev,
                         double rho, double eta, int num_documents)
 {
+    // (the batches' indices are built on worker threads: trlda_batch_create)
+    if (int rc_built = batch_wait(b))
+        return rc_built;
     int rc = check_model(m);
     if (rc)
         return rc;
@@ -3831,6 +4097,9 @@ int trlda_model_tr_init(trlda_model *m, const trlda_batch *b, const double *lamb
 
 int trlda_model_wordcounts(trlda_model *m, const trlda_batch *b, double *wordcounts_dev)
 {
+    // (the batches' indices are built on worker threads: trlda_batch_create)
+    if (int rc_built = batch_wait(b))
+        return rc_built;
     int rc = check_model(m);
     if (rc)
         return rc;
@@ -4044,6 +4313,9 @@ int trlda_model_online_update(trlda_model *m, const trlda_batch *b, int num_docu
                               double rho, int init_gamma, int update_lambda, double threshold,
                               int *update_count, double *rho_out, double *gamma_out)
 {
+    // (the batches' indices are built on worker threads: trlda_batch_create)
+    if (int rc_built = batch_wait(b))
+        return rc_built;
     int rc = check_model(m);
     if (rc)
         return rc;
@@ -4114,6 +4386,9 @@ int trlda_model_batch_update(trlda_model *m, const trlda_batch *b, double eta, i
                              int max_iter_inference, int update_lambda, double threshold,
                              double *gamma_out)
 {
+    // (the batches' indices are built on worker threads: trlda_batch_create)
+    if (int rc_built = batch_wait(b))
+        return rc_built;
     int rc = check_model(m);
     if (rc)
         return rc;
@@ -4190,6 +4465,9 @@ int trlda_model_cumulative_update(trlda_model *m, const trlda_batch *b, int max_
                                   int max_iter_inference, int update_lambda, double threshold,
                                   double *gamma_out)
 {
+    // (the batches' indices are built on worker threads: trlda_batch_create)
+    if (int rc_built = batch_wait(b))
+        return rc_built;
     int rc = check_model(m);
     if (rc)
         return rc;
@@ -4377,6 +4655,9 @@ int trlda_model_online_update_multi(trlda_model *m, const trlda_batch *shard, vo
                                     double rho, int init_gamma, double threshold, int *update_count,
                                     double *rho_out)
 {
+    // (the batches' indices are built on worker threads: trlda_batch_create)
+    if (int rc_built = batch_wait(shard))
+        return rc_built;
     int rc = check_model(m);
     if (rc)
         return rc;
@@ -4438,6 +4719,9 @@ int trlda_model_batch_update_multi(trlda_model *m, const trlda_batch *shard, voi
                                    int total_docs, int doc_lo, double eta, int max_epochs,
                                    int max_iter_inference, int update_lambda, double threshold)
 {
+    // (the batches' indices are built on worker threads: trlda_batch_create)
+    if (int rc_built = batch_wait(shard))
+        return rc_built;
     int rc = check_model(m);
     if (rc)
         return rc;
@@ -4475,6 +4759,9 @@ int trlda_model_batch_update_multi(trlda_model *m, const trlda_batch *shard, voi
 int trlda_model_estep_resident_shard(trlda_model *m, const trlda_batch *shard, int total_docs,
                                      int doc_lo, int max_iter, double threshold)
 {
+    // (the batches' indices are built on worker threads: trlda_batch_create)
+    if (int rc_built = batch_wait(shard))
+        return rc_built;
     int rc = check_model(m);
     if (rc)
         return rc;
@@ -4656,6 +4943,11 @@ int trlda_model_online_update_dp(trlda_model *m, const trlda_batch *batch, const
                                  double kappa, double tau, double rho, int init_gamma, double threshold,
                                  int *update_count, double *rho_out)
 {
+    // (the batches' indices are built on worker threads: trlda_batch_create)
+    if (int rc_built = batch_wait(batch))
+        return rc_built;
+    if (int rc_built = batch_wait(shard))
+        return rc_built;
     int rc = check_model(m);
     if (rc)
         return rc;
@@ -4676,6 +4968,11 @@ int trlda_model_batch_update_dp(trlda_model *m, const trlda_batch *batch, const 
                                 double eta, int max_epochs, int max_iter_inference, int update_lambda,
                                 double threshold)
 {
+    // (the batches' indices are built on worker threads: trlda_batch_create)
+    if (int rc_built = batch_wait(batch))
+        return rc_built;
+    if (int rc_built = batch_wait(shard))
+        return rc_built;
     int rc = check_model(m);
     if (rc)
         return rc;
@@ -4695,6 +4992,11 @@ int trlda_model_estep_dp(trlda_model *m, const trlda_batch *batch, const trlda_b
                          double threshold, int32_t *iters_dev, int mstep,
                          const double *lambda_prime_dev, double rho, double eta, double scale)
 {
+    // (the batches' indices are built on worker threads: trlda_batch_create)
+    if (int rc_built = batch_wait(batch))
+        return rc_built;
+    if (int rc_built = batch_wait(shard))
+        return rc_built;
     int rc = check_model(m);
     if (rc)
         return rc;
@@ -4819,6 +5121,9 @@ int trlda_model_sample_gamma_cols(trlda_model *m, int rows, int cols, int col_lo
 
 int trlda_model_estep_resident(trlda_model *m, const trlda_batch *b, int max_iter, double threshold)
 {
+    // (the batches' indices are built on worker threads: trlda_batch_create)
+    if (int rc_built = batch_wait(b))
+        return rc_built;
     int rc = check_model(m);
     if (rc)
         return rc;
@@ -5203,6 +5508,7 @@ int trlda_tr_init(int K, int V, int B, int num_documents, double rho, double eta
     trlda_batch *b = nullptr;
     int rc = trlda_model_create(&m, device, K, V);
     if (!rc) rc = trlda_batch_create(&b, device, V, B, indptr, ids, cnts);
+    if (!rc) rc = batch_wait(b);                     // (tr_init_device is not an entry point: it does not wait)
     if (!rc) rc = ensure_update_workspace(m, B);
     if (!rc && hipMemcpy(m->lambda_prime, lambda_prime, (size_t)K * V * sizeof(double),
                          hipMemcpyHostToDevice) != hipSuccess)
@@ -5222,6 +5528,9 @@ int trlda_tr_init(int K, int V, int B, int num_documents, double rho, double eta
 extern "C" int trlda_debug_graph_update(trlda_model *m, const trlda_batch *b, int num_documents, double eta,
                                         int max_iter_tr, int max_iter_inference, int reps, double *usec_out)
 {
+    // (the batches' indices are built on worker threads: trlda_batch_create)
+    if (int rc_built = batch_wait(b))
+        return rc_built;
     int rc = check_model(m);
     if (rc)
         return rc;
@@ -5279,6 +5588,11 @@ extern "C" int trlda_debug_graph_update2(trlda_model *m, const trlda_batch *b0, 
                                          int num_documents, double eta, int max_iter_tr, int max_iter_inference,
                                          int reps, double *usec_out)
 {
+    // (the batches' indices are built on worker threads: trlda_batch_create)
+    if (int rc_built = batch_wait(b0))
+        return rc_built;
+    if (int rc_built = batch_wait(b1))
+        return rc_built;
     int rc = check_model(m);
     if (rc)
         return rc;
