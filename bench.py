@@ -122,6 +122,8 @@ def parse():
                          "(trlda_model_set_stream_lanes: the steps go in turn to two streams of the "
                          "library's own, output arrays alternate between two sets; every fence() joins "
                          "them before the clock stops).  1 = one launch at a time, as in rounds 1-4")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="skip the leg that starts every mini-batch from CSR arrays in host memory")
     ap.add_argument("--no-settle", action="store_true",
                     help="skip the untimed settle phase in front of the first timed region (clock ramp "
                          "after the set-up; reported as settle_steps / settle_ms)")
@@ -767,6 +769,60 @@ def main():
             step(pos[0] + i)
         pos[0] += 2
 
+    # N = 1: the same stream of steps with NOTHING pre-uploaded: every mini-batch
+    # starts as CSR arrays in host memory, goes through trlda_batch_create (validation + a copy on this
+    # thread; the word-major index and the upload on the library's worker threads) two steps before
+    # its E-step, and is destroyed four steps after it.  PCIe and host work inclusive: reported beside
+    # `value`, never as it.
+    value_end_to_end = None
+    if not collective and prefetch and not args.headline_only and not args.no_end_to_end:
+        from trlda_amd.documents import DeviceBatch
+        fence()
+        nb = args.num_batches
+        window = {}
+        AHEAD = 4
+
+        def e2e_run(n_steps):
+            first = pos[0]
+            pos[0] += n_steps
+            for i in range(first, first + AHEAD):                    # the first ones of the stretch
+                if i not in window:
+                    window[i] = DeviceBatch(csrs[i % nb], V, local_rank)
+            t0 = time.perf_counter()
+            for i in range(first, first + n_steps):
+                # (made AHEAD steps before its E-step, announced two steps before it: the workers have
+                # two steps' time for its index -- an announced batch whose index is not there yet
+                # counts as not announced)
+                window[i + AHEAD] = DeviceBatch(csrs[(i + AHEAD) % nb], V, local_rank)
+                upcoming[0] = window[i + 1].handle.value
+                upcoming[1] = window[i + 2].handle.value
+                g_out, s_out, _ = out_sets[i & 1 if lanes[0] > 1 else 0]
+                _ffi.check(L.trlda_model_estep_io_ahead(model, window[i].handle, upcoming, 2,
+                                                        gamma0s[i % nb].data_ptr(), g_out.data_ptr(),
+                                                        s_out.data_ptr(), args.max_iter, args.threshold, None))
+                old = window.pop(i - 4, None)
+                if old is not None:
+                    old.close()
+            fence()
+            return time.perf_counter() - t0
+
+        e2e_run(max(args.steps, 40))                                  # staging buffers, allocations, workers
+        s_e2e = sorted(e2e_run(args.steps) for _ in range(max(1, args.repeats)))
+        for b_ in window.values():
+            b_.close()
+        window.clear()
+        value_end_to_end = {"value": round(B * args.steps / s_e2e[len(s_e2e) // 2], 1), "unit": "docs/s",
+                            "ms_per_step": round(1e3 * s_e2e[len(s_e2e) // 2] / args.steps, 5),
+                            "ms_per_step_min": round(1e3 * s_e2e[0] / args.steps, 5),
+                            "what": "CSR arrays in host memory -> trlda_batch_create (index + upload on the "
+                                    "library's worker threads, TRLDA_INDEX_THREADS, default 4) four steps "
+                                    "before its E-step, announced two steps before it -> E-step -> "
+                                    "trlda_batch_destroy four steps after it; one Python thread drives it",
+                            "host_threads": 1 + int(os.environ.get("TRLDA_INDEX_THREADS", "4"))}
+        for i in range(4):
+            step(pos[0] + i)
+        pos[0] += 4
+
     # N > 1: the identical step (documents -> statistics -> M-step, no prefetch) WITHOUT the
     # exchange, timed on rank 0 alone while the other ranks wait: the like-for-like one-GPU
     # figure that the N-GPU value is to be divided by
@@ -1159,6 +1215,7 @@ def main():
         "value_one_lane": value_one_lane,
         "lanes": lanes[0],
         "value_fixed_work": value_fixed_work,
+        "value_end_to_end": value_end_to_end,
         "rccl_ranks": rccl_ranks,
         "same_step_n1": same_step_n1,
         "roofline": roofline,

@@ -148,7 +148,18 @@ int trlda_dev_synchronize(int device);
 /* Validates (monotone indptr, 0 <= id < V), uploads the CSR arrays and builds the
  * word-major index (stable counting sort by word id) used by the segmented
  * sufficient-statistics kernel.  Replaces PyList_ToDocuments' deep copy
- * (python/src/ldainterface.cpp:152-190). */
+ * (python/src/ldainterface.cpp:152-190).
+ *
+ * On the caller's thread: the validation -- every error of the arguments is this call's -- and one
+ * copy of the three arrays into pinned memory (they are the caller's again on return).  The index
+ * (csrc/batch_index.cpp) and the upload happen on the library's worker threads (TRLDA_INDEX_THREADS,
+ * default 4; 0: on this thread, as before round 6), up to eight batches at a time; every entry point
+ * that is handed the batch waits for them -- or, when no worker has started on it yet, does the
+ * work itself, so that "create, use at once" costs what it did.  A batch destroyed before anybody
+ * used it is never indexed.  A stream that makes its batches a few steps ahead of their use
+ * (bench.py, value_end_to_end) pays ~12 us per 200 documents here instead of ~75.  A failed upload
+ * (out of device memory) fails the batch's first use, with the build's status and message.
+ * An announced batch (`next`, `upcoming[]` below) whose index is not there yet counts as not announced. */
 int trlda_batch_create(trlda_batch **out, int device, int V, int B,
                        const int32_t *indptr, const int32_t *ids, const int32_t *cnts);
 int trlda_batch_destroy(trlda_batch *batch);

@@ -68,6 +68,11 @@ def test_bench_line_contract(hip_lib):
     assert fw["threshold"] == 0.0 and fw["iterations_per_document"] == 20
     assert abs(fw["value"] - j["value"]) < 0.12 * j["value"]     # every document runs 20 iterations anyway
     assert r["traffic_in_run"] is False
+    # nothing pre-uploaded (round 6): CSR in host memory -> batch -> E-step -> destroy, PCIe and host
+    # work inclusive -- reported beside the headline, below it, and tagged with the threads it used
+    e2e = j["value_end_to_end"]
+    assert 0 < e2e["value"] <= j["value"] * 1.02 and e2e["host_threads"] >= 1 and "trlda_batch_create" in e2e["what"]
+    assert j["mode"]["deferred_stats"] is True and j["mode"]["lanes"] == 2 and j["mode"]["pipelined"] is True
     assert j["repeats"]["n"] == 3 and j["repeats"]["ms_per_step_min"] <= j["ms_per_step"] <= \
         j["repeats"]["ms_per_step_max"]
     u = j["update_parameters"]

@@ -1,0 +1,155 @@
+"""trlda_batch_create since round 6: the index (csrc/batch_index.cpp, held to golden digests by
+tests/test_batch_index.py) is built and uploaded on worker threads while the caller goes on; the
+first user of a batch takes over a build nobody has started; a batch destroyed unused is never
+indexed.  Here, on the device: what the kernels see IS that index, bitwise, whoever built it and
+in whatever order batches are made, used and dropped; E-steps on batches used the moment they are
+created equal E-steps on batches that had time to be built; errors stay synchronous.
+(reference: the Documents argument of LDA::updateVariables, python/src/ldainterface.cpp:152-190)"""
+import ctypes as C
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from helpers import HipSampler, relerr, seeded_gamma, seeded_lambda
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("make_index_golden",
+                                              os.path.join(ROOT, "tests", "golden", "make_index_golden.py"))
+gold = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(gold)
+
+
+@pytest.fixture(scope="module")
+def hip(hip_lib):
+    from trlda_amd import _ffi
+    assert _ffi.device_count() >= 1, "GPU tests need a visible MI355X"
+    return hip_lib
+
+
+@pytest.fixture(scope="module")
+def raw(hip):
+    from trlda_amd import _ffi
+    lib = C.CDLL(_ffi.LIB_PATH)
+    lib.trlda_debug_batch_blob.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]
+    lib.trlda_batch_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p]
+    lib.trlda_batch_destroy.argtypes = [C.c_void_p]
+    return lib
+
+
+def host_index(raw, V, ip, ii, cc, cus):
+    info = np.zeros(64, np.int64)
+    p32 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    pi = info.ctypes.data_as(C.POINTER(C.c_int64))
+    f = raw.trlda_debug_batch_index
+    f.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int,
+                  C.POINTER(C.c_int64), C.c_void_p, C.c_size_t]
+    assert f(V, len(ip) - 1, p32(ip), p32(ii), p32(cc), cus, pi, None, 0) == 0
+    buf = np.zeros(int(info[24]), np.uint8)
+    assert f(V, len(ip) - 1, p32(ip), p32(ii), p32(cc), cus, pi, buf.ctypes.data, buf.size) == 0
+    head = {k: int(info[i]) for i, k in enumerate(gold.HEAD)}
+    return buf, [int(v) for v in info[32:52]], gold.section_bytes(head)
+
+
+def test_the_device_sees_the_host_index_whoever_built_it(hip, raw):
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    cases = {k: v for k, v in gold.cases().items() if k != "very_long_lists"}
+    names = sorted(cases)
+    handles, states = {}, {}
+    # made back to back (the workers get behind), read in another order, some of them at once
+    for n in names:
+        V, (ip, ii, cc) = cases[n]
+        ip, ii, cc = (np.array(a, dtype=np.int32, copy=True) for a in (ip, ii, cc))
+        h = C.c_void_p()
+        assert raw.trlda_batch_create(C.byref(h), 0, V, len(ip) - 1, ip.ctypes.data, ii.ctypes.data,
+                                      cc.ctypes.data) == 0, n
+        handles[n] = h
+        ii[:] = -5                                   # (the caller's arrays are the caller's again)
+        del ip, ii, cc
+    for n in names[::-1]:
+        V, (ip, ii, cc) = cases[n]
+        want, offs, sizes = host_index(raw, V, np.ascontiguousarray(ip, np.int32), np.ascontiguousarray(ii, np.int32),
+                                       np.ascontiguousarray(cc, np.int32), cus)
+        got = np.empty_like(want)
+        st = C.c_int(-1)
+        assert raw.trlda_debug_batch_blob(handles[n], got.ctypes.data, got.size, C.byref(st)) == 0, n
+        states[n] = st.value
+        for name, o, nb in zip(gold.SECTIONS, offs, sizes):
+            assert np.array_equal(got[o:o + nb], want[o:o + nb]), (n, name)
+    for h in handles.values():
+        raw.trlda_batch_destroy(h)
+    assert set(states.values()) <= {0, 1, 3}
+
+
+def test_batches_dropped_before_and_while_they_are_built(hip, raw):
+    """destroyed at once (never indexed), destroyed while a worker is on it, thousands in a row: no
+    staging buffer is lost (the pool has eight) and the next batch is as good as any"""
+    from trlda_amd.utils.synthetic import make_corpus
+    V = 3000
+    ip, ii, cc = make_corpus(150, V, seed=5, mean_unique=60)
+    for r in range(3000):
+        h = C.c_void_p()
+        assert raw.trlda_batch_create(C.byref(h), 0, V, 150, ip.ctypes.data, ii.ctypes.data, cc.ctypes.data) == 0
+        if r % 3 == 1:
+            raw.trlda_batch_long_word_len(h)         # (takes the build over, or waits for the worker)
+        if r % 7 == 3:
+            import time
+            time.sleep(2e-5)                         # (a worker has started on it)
+        raw.trlda_batch_destroy(h)
+    import torch
+    want, offs, sizes = host_index(raw, V, ip, ii, cc, torch.cuda.get_device_properties(0).multi_processor_count)
+    h = C.c_void_p()
+    assert raw.trlda_batch_create(C.byref(h), 0, V, 150, ip.ctypes.data, ii.ctypes.data, cc.ctypes.data) == 0
+    got = np.empty_like(want)
+    assert raw.trlda_debug_batch_blob(h, got.ctypes.data, got.size, None) == 0
+    for name, o, nb in zip(gold.SECTIONS, offs, sizes):
+        assert np.array_equal(got[o:o + nb], want[o:o + nb]), name
+    raw.trlda_batch_destroy(h)
+
+
+def test_errors_of_the_arguments_stay_with_the_call(hip, raw):
+    ip = np.array([0, 2, 3], np.int32); cc = np.ones(3, np.int32)
+    for bad in ([0, 9, 1], [0, -1, 1]):
+        h = C.c_void_p()
+        ii = np.array(bad, np.int32)
+        assert raw.trlda_batch_create(C.byref(h), 0, 9, 2, ip.ctypes.data, ii.ctypes.data, cc.ctypes.data) == -3
+        assert not h.value
+    h = C.c_void_p()
+    assert raw.trlda_batch_create(C.byref(h), 0, 9, 2, np.array([0, 2, 1], np.int32).ctypes.data,
+                                  np.zeros(3, np.int32).ctypes.data, cc.ctypes.data) != 0
+
+
+def test_used_at_once_or_after_a_while_the_same_e_step(hip, oracle):
+    """an E-step on a batch the moment it is made (the call takes the build over) and on one that was
+    made first, among thirty others: bitwise the same gamma and statistics, equal to the oracle's"""
+    import time
+    from trlda_amd.documents import CSRDocuments
+    from trlda_amd.models import OnlineLDA
+    from trlda_amd.utils.synthetic import make_corpus
+    sampler = HipSampler(hip)
+    K, V, B = 50, 2000, 80
+    lam = seeded_lambda(sampler, 4, K, V)
+    g0 = seeded_gamma(sampler, 5, K, B)
+    m = OnlineLDA.__new__(OnlineLDA)
+    m._num_documents, m._update_count = 1000, 0
+    m._ada_tau, m._ada_rho, m._ada_sq_norm = 1000., 1e-3, 1.
+    m._setup(V, K, .1, .3, None, _lambda=lam)
+    corpora = [CSRDocuments(*make_corpus(B, V, seed=900 + i, mean_unique=40)) for i in range(30)]
+    early = [m.upload(c) for c in corpora]
+    time.sleep(.01)
+    a = [m.update_variables(b, latents=g0, max_iter=15) for b in early]
+    b_ = [m.update_variables(m.upload(c), latents=g0, max_iter=15) for c in corpora]
+    for (ga, sa), (gb, sb) in zip(a, b_):
+        assert np.array_equal(ga, gb) and np.array_equal(sa, sb)
+    c = corpora[7]
+    go, so, _ = oracle.estep(lam, .1, c.indptr, c.ids, c.cnts, g0, 15, 1e-3)
+    assert relerr(a[7][0], go) < 1e-9
+    nz = so > 0
+    assert relerr(a[7][1][nz], so[nz]) < 1e-9
+    for b in early:
+        b.close()
+    m.close()

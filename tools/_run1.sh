@@ -1,5 +1,8 @@
 export TMPDIR=/tmp; o=gpurun_out
-timeout 3000 python -X faulthandler -m pytest tests -x -q -m gpu 2>&1 | tail -12 > $o/r06_t4.txt
-for sd in 1 2 3; do timeout 900 python tests/fuzz_lifecycle.py --steps 300 --seed $sd 2>&1 | tail -1; done > $o/r06_fuzz_lifecycle.txt
-timeout 600 python tests/fuzz_deferred.py --lanes 2>&1 | tail -2 >> $o/r06_fuzz_lifecycle.txt
-cat $o/r06_t4.txt $o/r06_fuzz_lifecycle.txt | cut -c1-200
+python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-update-rates 2>/dev/null | tail -1 > $o/r06_bench_e2e.json
+python bench.py --gpus 1 --steps 200 --warmup 20 --no-cpu-baseline --no-update-rates 2>/dev/null | tail -1 > $o/r06_bench_e2e_200.json
+python bench.py --gpus 1 --steps 1000 --warmup 20 --repeats 3 --no-cpu-baseline --no-update-rates 2>/dev/null | tail -1 > $o/r06_bench_e2e_1000.json
+python3 -c "
+import json
+for f in ('r06_bench_e2e.json','r06_bench_e2e_200.json','r06_bench_e2e_1000.json'):
+    j=json.loads(open('$o/'+f).read()); e=j['value_end_to_end']; print(f, j['value'], j['ms_per_step'], 'e2e', e['value'], e['ms_per_step'], e['ms_per_step_min'], 'one lane', j['value_one_lane']['value'])"

@@ -50,8 +50,40 @@ def rate(label, fn, n, unit_docs=B, drain=None):
 
 # ---- ingestion ---------------------------------------------------------------------------
 rate("list of tuples -> CSR (as_csr)", lambda: as_csr(lst), 50)
-rate("list of tuples -> device batch (DeviceBatch)", lambda: DeviceBatch(lst, V, 0).close(), 50)
-rate("CSR -> device batch", lambda: DeviceBatch(docs, V, 0).close(), 50)
+# (round 6: trlda_batch_create validates and copies on the caller's thread and hands the index to the
+# library's worker threads; a batch destroyed before anybody used it is never indexed -- so the
+# "made and dropped" loop measures the caller's share only, "made, used, dropped" the whole build on
+# the caller's thread (its first user takes over a build no worker has started), and "a stream of
+# them" what a pipeline gets: made four ahead of their use by the workers)
+
+
+def made_used_dropped(src):
+    b = DeviceBatch(src, V, 0)
+    L.trlda_batch_long_word_len(b.handle)           # (the first use: waits for / builds the index)
+    b.close()
+
+
+def stream_of(n=400, ahead=4):
+    win = [DeviceBatch(docs, V, 0) for _ in range(ahead)]
+    t = time.perf_counter()
+    for i in range(n):
+        win.append(DeviceBatch(docs, V, 0))
+        b = win.pop(0)
+        L.trlda_batch_long_word_len(b.handle)
+        b.close()
+    dt = (time.perf_counter() - t) / n
+    for b in win:
+        b.close()
+    return dt
+
+
+rate("list of tuples -> device batch, made and dropped", lambda: DeviceBatch(lst, V, 0).close(), 50)
+rate("list of tuples -> device batch, made, used, dropped", lambda: made_used_dropped(lst), 50)
+rate("CSR -> device batch, made and dropped (caller's share)", lambda: DeviceBatch(docs, V, 0).close(), 50)
+rate("CSR -> device batch, made, used, dropped (index on the caller)", lambda: made_used_dropped(docs), 50)
+stream_of(100)
+dt = stream_of()
+print("%-58s %9.1f us/call -> %10.0f docs/s" % ("CSR -> device batch, a stream made 4 ahead of its use", dt * 1e6, B / dt))
 big = CSRDocuments(*make_corpus(20000, V, seed=1, mean_unique=100))
 with tempfile.TemporaryDirectory() as tmp:
     path = os.path.join(tmp, "corpus.dat")

@@ -2,6 +2,8 @@
 // host_common.h).
 #include "host_common.h"
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -129,13 +131,17 @@ struct WorkQueue::Impl {
             job();
             return;
         }
+        bool wake = false;
         {
             std::lock_guard<std::mutex> lock(mu_);
             if ((int)workers_.size() < n_ && (int)workers_.size() < (int)jobs_.size() + running_ + 1)
                 workers_.emplace_back([this] { loop(); });     // (one more thread while there is a backlog)
             jobs_.push_back(std::move(job));
+            pending_.store((int)jobs_.size(), std::memory_order_release);
+            wake = sleepers_ > 0;
         }
-        cv_.notify_one();
+        if (wake)
+            cv_.notify_one();
     }
     void wait_idle()
     {
@@ -148,11 +154,23 @@ struct WorkQueue::Impl {
             std::function<void()> job;
             {
                 std::unique_lock<std::mutex> lock(mu_);
+                if (jobs_.empty() && !stop_) {
+                    // (a stream of jobs a few microseconds apart: look again for a while before going
+                    // to sleep -- waking a sleeper is a system call on the submitter's thread)
+                    lock.unlock();
+                    const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(150);
+                    while (pending_.load(std::memory_order_acquire) == 0 && std::chrono::steady_clock::now() < until)
+                        cpu_relax();
+                    lock.lock();
+                }
+                ++sleepers_;
                 cv_.wait(lock, [this] { return stop_ || !jobs_.empty(); });
+                --sleepers_;
                 if (stop_ && jobs_.empty())
                     return;
                 job = std::move(jobs_.front());
                 jobs_.erase(jobs_.begin());
+                pending_.store((int)jobs_.size(), std::memory_order_release);
                 ++running_;
             }
             job();
@@ -169,8 +187,15 @@ struct WorkQueue::Impl {
     std::condition_variable cv_, idle_;
     std::vector<std::thread> workers_;
     std::vector<std::function<void()>> jobs_;
-    int running_ = 0;
+    std::atomic<int> pending_{0};                    // jobs_.size(), for the workers that look without the lock
+    int running_ = 0, sleepers_ = 0;
     bool stop_ = false;
+    static void cpu_relax()
+    {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+    }
 };
 
 WorkQueue::WorkQueue(int threads) : impl_(new Impl(threads)) {}

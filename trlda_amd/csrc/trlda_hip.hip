@@ -2827,6 +2827,12 @@ namespace {
 
 constexpr size_t kStageSlots = 8;
 
+// what the ingestion did so far (trlda_debug_ingest_counters): [0] indices built by a worker, [1] taken over
+// by their first user, [2] cancelled (destroyed unused), [3] built on the creating thread (no workers),
+// [4] hipMalloc of a batch allocation, [5] hipFree of one, [6] waits for a staging buffer held by a
+// build, [7] waits for a staging buffer's last upload
+std::atomic<long long> g_ingest[8];
+
 // workers that build and upload the indices (TRLDA_INDEX_THREADS, default 4 -- fewer on a small host;
 // 0: trlda_batch_create builds on its caller's thread, as in rounds 1-5)
 trlda_host::WorkQueue &index_queue()
@@ -2880,10 +2886,12 @@ int stage_acquire(UploadContext &u, size_t bytes, UploadContext::Stage **out)
             pick = u.stages.back().get();
         }
         if (!pick && late) {
+            ++g_ingest[7];
             HIP_TRY(hipEventSynchronize(late->ev));
             pick = late;
         }
         if (!pick) {                                 // every buffer is some build's: wait for one
+            ++g_ingest[6];
             u.stage_cv.wait(lock);
             continue;
         }
@@ -2912,7 +2920,7 @@ void stage_release(UploadContext &u, UploadContext::Stage *st)   // (u.mu held)
 
 // The index of batch `b` from the CSR arrays at the head of staging buffer `st`, into a device
 // allocation, the copy enqueued on the upload stream: on a worker thread, or on trlda_batch_create's
-int batch_build(trlda_batch *b, UploadContext::Stage *st)
+int batch_build(trlda_batch *b, UploadContext::Stage *st, bool on_worker = false)
 {
     UploadContext &u = upload_context(b->device);
     auto give_up = [&](int rc) {
@@ -2957,64 +2965,79 @@ int batch_build(trlda_batch *b, UploadContext::Stage *st)
     b->vl_host.swap(x.vl_host);
     b->vl_first.swap(x.vl_first);
 
-    std::lock_guard<std::mutex> lock(u.mu);
-    if (!u.stream && hipStreamCreateWithFlags(&u.stream, hipStreamNonBlocking) != hipSuccess) {
-        stage_release(u, st);
-        return fail(TRLDA_ERR_HIP, "hipStreamCreateWithFlags failed");
-    }
-    // a device allocation: from the cache when one fits, else new
-    // (one whose last reader has finished, if there is one: an upload into an allocation that
-    // the previous call's kernels still read would have to wait for them; with two or three
-    // allocations in rotation the upload of call n + 1 runs under the kernels of call n)
+    // Under the upload context's lock only what is shared: the allocation (from the cache when one fits)
+    // and two events.  The stream operations -- each on this batch's own objects -- run outside it:
+    // trlda_batch_create and trlda_batch_destroy of the caller's thread take the same lock.
     UploadContext::Blob blob{nullptr, 0, nullptr};
-    for (int pass = 0; pass < 2 && !blob.ptr; ++pass)
-        for (size_t i = 0; i < u.cache.size(); ++i) {
-            const UploadContext::Blob &c = u.cache[i];
-            if (c.bytes < total || c.bytes > 4 * total + ((size_t)1 << 20))
-                continue;
-            if (pass == 0 && c.done && stream_alive(c.on, c.on_owned) && hipEventQuery(c.done) != hipSuccess)
-                continue;
-            if (pass == 1 && u.cache.size() < kBlobCacheMax / 2)
-                break;                               // rather a new allocation than a wait
-            blob = c;
-            u.cached_bytes -= blob.bytes;
-            u.cache.erase(u.cache.begin() + (long)i);
-            break;
+    {
+        std::lock_guard<std::mutex> lock(u.mu);
+        if (!u.stream && hipStreamCreateWithFlags(&u.stream, hipStreamNonBlocking) != hipSuccess) {
+            stage_release(u, st);
+            return fail(TRLDA_ERR_HIP, "hipStreamCreateWithFlags failed");
         }
-    (void)hipGetLastError();                         // (hipErrorNotReady of the queries above)
+        // (an allocation whose last reader has finished, if there is one: an upload into an allocation
+        // that the previous call's kernels still read would have to wait for them; with a few
+        // allocations in rotation the upload of call n + 1 runs under the kernels of call n)
+        for (int pass = 0; pass < 2 && !blob.ptr; ++pass)
+            for (size_t i = 0; i < u.cache.size(); ++i) {
+                const UploadContext::Blob &c = u.cache[i];
+                if (c.bytes < total || c.bytes > 4 * total + ((size_t)1 << 20))
+                    continue;
+                if (pass == 0 && c.done && stream_alive(c.on, c.on_owned) && hipEventQuery(c.done) != hipSuccess)
+                    continue;
+                if (pass == 1 && u.cache.size() < kBlobCacheMax / 2)
+                    break;                           // rather a new allocation than a wait
+                blob = c;
+                u.cached_bytes -= blob.bytes;
+                u.cache.erase(u.cache.begin() + (long)i);
+                break;
+            }
+        (void)hipGetLastError();                     // (hipErrorNotReady of the queries above)
+        if (take_event(u, &b->ready) != TRLDA_OK || take_event(u, &b->done) != TRLDA_OK) {
+            if (blob.ptr) {                          // (back where it came from)
+                u.cache.push_back(blob);
+                u.cached_bytes += blob.bytes;
+            }
+            stage_release(u, st);
+            return fail(TRLDA_ERR_HIP, "hipEventCreate failed");
+        }
+    }
     if (!blob.ptr) {
         size_t want = (size_t)1 << 16;
         while (want < total)
             want <<= 1;
+        ++g_ingest[4];
         hipError_t e = hipMalloc(&blob.ptr, want);
-        if (e != hipSuccess) {
-            stage_release(u, st);
-            return fail(TRLDA_ERR_HIP, std::string("hipMalloc (batch): ") + hipGetErrorString(e));
-        }
+        if (e != hipSuccess)
+            return give_up(fail(TRLDA_ERR_HIP, std::string("hipMalloc (batch): ") + hipGetErrorString(e)));
         blob.bytes = want;
     }
     b->blob = blob.ptr;
     b->blob_bytes = blob.bytes;
     hipError_t err = hipSuccess;
-    if (blob.done && stream_alive(blob.on, blob.on_owned)) {   // the previous owner's last reader
+    const bool guard_wait = blob.done && stream_alive(blob.on, blob.on_owned);
+    if (guard_wait)                                  // the previous owner's last reader
         err = hipStreamWaitEvent(u.stream, blob.done, 0);
-        u.spare(blob.done, blob.on, blob.on_owned);
-    }                                                // (else: that stream and its work are gone; the event is dropped)
+    // (else: that stream and its work are gone; the event is dropped)
     if (err == hipSuccess)
         err = hipMemcpyAsync(b->blob, st->host, total, hipMemcpyHostToDevice, u.stream);
     if (err == hipSuccess)
         err = hipEventRecord(st->ev, u.stream);
-    if (err == hipSuccess && take_event(u, &b->ready) == TRLDA_OK && take_event(u, &b->done) == TRLDA_OK)
+    if (err == hipSuccess)
         err = hipEventRecord(b->ready, u.stream);
-    else if (err == hipSuccess)
-        err = hipErrorOutOfMemory;
     if (err != hipSuccess) {
         (void)hipStreamSynchronize(u.stream);
         (void)hipFree(b->blob);
         b->blob = nullptr;
-        stage_release(u, st);
-        return fail(TRLDA_ERR_HIP, std::string("batch upload: ") + hipGetErrorString(err));
+        return give_up(fail(TRLDA_ERR_HIP, std::string("batch upload: ") + hipGetErrorString(err)));
     }
+    // (on a worker thread: the copy is seen out before the staging buffer goes back -- the next
+    // trlda_batch_create then never finds a buffer whose upload it would have to wait for, on ITS thread)
+    if (on_worker)
+        (void)hipEventSynchronize(st->ev);
+    std::lock_guard<std::mutex> lock(u.mu);
+    if (guard_wait)
+        u.spare(blob.done, blob.on, blob.on_owned);
     stage_release(u, st);
     char *dv = static_cast<char *>(b->blob);
     auto D = [&](size_t o) { return reinterpret_cast<int32_t *>(dv + o); };
@@ -3067,8 +3090,10 @@ int batch_wait(const trlda_batch *cb)
     int st = state.load(std::memory_order_acquire);
     if (st == trlda_batch::kQueued) {
         int expect = trlda_batch::kQueued;
-        if (state.compare_exchange_strong(expect, trlda_batch::kBuilding, std::memory_order_acq_rel))
+        if (state.compare_exchange_strong(expect, trlda_batch::kBuilding, std::memory_order_acq_rel)) {
+            ++g_ingest[1];
             batch_publish(b, batch_build(b, static_cast<UploadContext::Stage *>(b->slot)));
+        }
         st = state.load(std::memory_order_acquire);
     }
     if (st == trlda_batch::kBuilding) {
@@ -3128,6 +3153,7 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
     b->device = device; b->V = V; b->B = B; b->nnz = nnz; b->max_n = max_n;
     trlda_host::WorkQueue &queue = index_queue();
     if (queue.threads() <= 0) {
+        ++g_ingest[3];
         rc = batch_build(b, st);
         if (rc) {                                    // (as in rounds 1-5: the failure is this call's)
             delete b;
@@ -3140,8 +3166,10 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
         queue.submit([b, st, ticket] {
             int expect = trlda_batch::kQueued;       // (taken over by its first user, or cancelled: nothing to do --
             if (ticket->state.compare_exchange_strong(expect, trlda_batch::kBuilding,   //  `b` may be gone)
-                                                      std::memory_order_acq_rel))
-                batch_publish(b, batch_build(b, st));
+                                                      std::memory_order_acq_rel)) {
+                ++g_ingest[0];
+                batch_publish(b, batch_build(b, st, /*on_worker=*/true));
+            }
         });
     }
     *out = b;
@@ -3157,6 +3185,7 @@ int trlda_batch_destroy(trlda_batch *b)
         // cancelled).  A worker is building it: the worker destroys it when it is done.
         int expect = trlda_batch::kQueued;
         if (b->ticket->state.compare_exchange_strong(expect, trlda_batch::kCancelled, std::memory_order_acq_rel)) {
+            ++g_ingest[2];
             UploadContext &u = upload_context(b->device);
             {
                 std::lock_guard<std::mutex> lock(u.mu);
@@ -3210,6 +3239,7 @@ int trlda_batch_destroy(trlda_batch *b)
             u.cache.push_back(blob);
             u.cached_bytes += b->blob_bytes;
         } else {
+            ++g_ingest[5];
             (void)hipFree(b->blob);                  // waits for the device: nothing reads it after
             u.spare(guard, blob.on, blob.on_owned);
         }
@@ -3652,8 +3682,8 @@ int trlda_model_estep_io_next(trlda_model *m, const trlda_batch *b, const trlda_
     // (the batches' indices are built on worker threads: trlda_batch_create)
     if (int rc_built = batch_wait(b))
         return rc_built;
-    if (int rc_built = batch_wait(next))
-        return rc_built;
+    if (next && next->ticket->state.load(std::memory_order_acquire) != trlda_batch::kBuilt)
+        next = nullptr;                              // (not indexed yet: as good as not announced)
     // (the next E-step of a deferred stream: estep_device decides whether its launch carries the
     // statistics the call before left pending, or launches them first)
     int rc = check_model(m, true);
@@ -3822,13 +3852,22 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
     // (the batches' indices are built on worker threads: trlda_batch_create)
     if (int rc_built = batch_wait(b))
         return rc_built;
-    for (int i_up = 0; upcoming && i_up < n_upcoming; ++i_up)
-        if (int rc_built = batch_wait(upcoming[i_up]))
-            return rc_built;
     if (!m)
         return fail(TRLDA_ERR_ARG, "model is NULL");
     if (n_upcoming < 0 || (n_upcoming > 0 && !upcoming))
         return fail(TRLDA_ERR_ARG, "upcoming batches: a count without a list");
+    // An announced batch whose index is not there yet counts as not announced (the call that gets it
+    // prepares its own preamble: the same results): an announcement is not worth taking a build over
+    // from the workers for, let alone waiting for one.
+    const trlda_batch *ready_up[2] = {nullptr, nullptr};
+    for (int i_up = 0; i_up < n_upcoming && i_up < 2; ++i_up) {
+        const trlda_batch *up = upcoming[i_up];
+        if (up && up->ticket->state.load(std::memory_order_acquire) == trlda_batch::kBuilt)
+            ready_up[i_up] = up;
+    }
+    if (n_upcoming > 2)
+        n_upcoming = 2;
+    upcoming = ready_up;
     const trlda_batch *next = n_upcoming > 0 ? upcoming[0] : nullptr;
     if (!b || !sstats_dev || (b->B > 0 && (!gamma_dev || !gamma0_dev)))
         return trlda_model_estep_io_next(m, b, next, gamma0_dev, gamma_dev, sstats_dev, max_iter,
@@ -5705,6 +5744,32 @@ extern "C" int trlda_debug_peek(trlda_model *m, int which, double *host, size_t 
         return TRLDA_ERR_ARG;
     HIP_TRY(hipStreamSynchronize(m->stream));
     HIP_TRY(hipMemcpy(host, src, count * sizeof(double), hipMemcpyDeviceToHost));
+    return TRLDA_OK;
+}
+
+extern "C" void trlda_debug_ingest_counters(long long *out8)
+{
+    for (int i = 0; i < 8; ++i)
+        out8[i] = g_ingest[i].load();
+}
+
+// tests: the first `bytes` bytes of a batch's device allocation (its index as the kernels see it), after
+// its upload; state_out (may be NULL): the build ticket's state when the call arrived (trlda_batch::kQueued:
+// this call took the build over; kBuilding: a worker had it; kBuilt: it was ready)
+extern "C" int trlda_debug_batch_blob(const trlda_batch *b, void *host, size_t bytes, int *state_out)
+{
+    if (!b || !host)
+        return TRLDA_ERR_ARG;
+    if (state_out)
+        *state_out = b->ticket->state.load(std::memory_order_acquire);
+    if (int rc = batch_wait(b))
+        return rc;
+    if (bytes > b->blob_bytes)
+        return fail(TRLDA_ERR_ARG, "more bytes than the batch's allocation holds");
+    HIP_TRY(hipSetDevice(b->device));
+    if (b->ready)
+        HIP_TRY(hipEventSynchronize(b->ready));
+    HIP_TRY(hipMemcpy(host, b->blob, bytes, hipMemcpyDeviceToHost));
     return TRLDA_OK;
 }
 

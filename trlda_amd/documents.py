@@ -223,6 +223,21 @@ def as_csr(docs):
     return CSRDocuments(indptr.astype(np.int32), flat[:, 0], flat[:, 1])
 
 
+_BATCH_CREATE = None
+
+
+def _batch_create():
+    """trlda_batch_create taking plain addresses (a second ctypes object for the same symbol)"""
+    global _BATCH_CREATE
+    if _BATCH_CREATE is None:
+        C = _ffi.C
+        f = _ffi.lib()["trlda_batch_create"]
+        f.restype = C.c_int
+        f.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _BATCH_CREATE = f
+    return _BATCH_CREATE
+
+
 class DeviceBatch(object):
     """A batch resident in HBM (``trlda_batch``): CSR arrays + word-major index.
 
@@ -231,14 +246,14 @@ class DeviceBatch(object):
     """
 
     def __init__(self, docs, num_words, device):
-        self.csr = as_csr(docs)
+        self.csr = csr = as_csr(docs)
         self.device = device
         self.num_words = num_words
         self.handle = _ffi.vp()
-        L = _ffi.lib()
-        _ffi.check(L.trlda_batch_create(_ffi.C.byref(self.handle), device, num_words,
-                                        len(self.csr), self.csr.indptr, self.csr.ids,
-                                        self.csr.cnts))
+        # (CSRDocuments has made its arrays int32 and C-contiguous: their addresses go straight in --
+        # numpy's ndpointer checks cost more per call than the library spends on this thread)
+        _ffi.check(_batch_create()(_ffi.C.byref(self.handle), device, num_words, len(csr),
+                                   csr.indptr.ctypes.data, csr.ids.ctypes.data, csr.cnts.ctypes.data))
 
     def __len__(self):
         return len(self.csr)
