@@ -336,6 +336,19 @@ int trlda_model_estep_io_ahead(trlda_model *model, const trlda_batch *batch,
                                const double *gamma0_dev, double *gamma_dev, double *sstats_dev,
                                int max_iter, double threshold, int32_t *iters_dev);
 long long trlda_model_lane_steps(const trlda_model *model);
+/* What became of the lanes: 0 none made yet (they are made by the first call that goes through them);
+ * 2 two lanes on streams that were SEEN to run side by side with each other and with the model's stream
+ * -- the runtime hands out hardware queues that are in use once a priority's pool is exhausted, and two
+ * lanes on one queue are slower than one lane, so the library makes streams until it holds such a pair
+ * (a ~40 us probe kernel on each of two streams: 40 us in all or 80); 1 the lanes were given up -- no
+ * such pair was to be had, or the MEASUREMENT said so: after 96 steps through the lanes a window of
+ * them is timed on the device, then 16 steps go one launch at a time and are timed, and two lanes
+ * that are not 2 % faster are dropped (a model on the legacy null stream in a process that has made
+ * and destroyed streams: 33 us per step against 30.5) -- the stream of calls goes one launch at a time,
+ * as without the switch; 3 two lanes, not looked at (TRLDA_LANE_VERIFY=0).  trlda_model_lane_timing:
+ * what the measurement found, microseconds per step (0: not measured yet). */
+int trlda_model_lane_state(const trlda_model *model);
+int trlda_model_lane_timing(const trlda_model *model, double *us_two_lanes, double *us_one_lane);
 /* with trlda_model_set_timing on: the summed duration (HIP events on the lanes' streams, one pair per
  * lane around each stretch of calls between joins -- a lane's launches run back to back) and the
  * number of the document launches that went through the lanes; joins the lanes */

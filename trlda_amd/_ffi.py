@@ -67,6 +67,8 @@ _SIGNATURES = {
     "trlda_model_synchronize": (C.c_int, [vp]),
     "trlda_model_set_split_docs": (C.c_int, [vp, C.c_int]),
     "trlda_model_set_draw_ahead": (C.c_int, [vp, C.c_int]),
+    "trlda_model_lane_state": (C.c_int, [vp]),
+    "trlda_model_lane_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "trlda_model_inlaunch_draws": (C.c_longlong, [vp]),
     "trlda_model_set_aux_decay": (C.c_int, [vp, C.c_int]),
     "trlda_model_inlaunch_decays": (C.c_longlong, [vp]),

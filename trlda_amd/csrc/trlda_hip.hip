@@ -303,6 +303,24 @@ struct trlda_model {
     // next launch's workgroups take the CUs as they come free.  Nothing of a lane's work is on this
     // model's stream until lanes_join() (every entry point except the next E-step of the stream).
     int lanes_wanted = 1;
+    // 0: no lanes made yet; 2: two lanes whose streams were SEEN to run side by side with each other and
+    // with the model's stream (lanes_ensure); 3: two lanes, not looked at (TRLDA_LANE_VERIFY=0); 1: no such
+    // pair of streams was to be had from the runtime -- the stream goes one launch at a time
+    int lane_state = 0;
+    // ... and MEASURED (trlda_model_estep_io_ahead): what the probe kernels of lanes_ensure cannot see
+    // -- round 5's failing case, a model on the legacy null stream in a process that had made and
+    // destroyed streams: 33.2 us per step through two lanes against 30.5 through one -- shows in the
+    // stream's own steps.  After kLaneCalAfter steps through the lanes a window of lane 0's launches
+    // is timed (events on its stream), then the lanes are joined and a window of steps goes one launch
+    // at a time, timed on the model's stream; two lanes that are not at least 2 % faster are given up
+    // (lane_state 1).  Once per model (again after trlda_model_set_stream); the one-lane window costs
+    // 16 steps x 4 us.  TRLDA_LANE_CALIBRATE=0: never.
+    struct {
+        int phase = 0;                    // 0 counting | 2 two-lane window | 1 one-lane window | 3 waiting for the events | 4 done
+        int n = 0;                        // calls into the current window (lane 0's calls in phase 2)
+        hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+        float us_two = 0.f, us_one = 0.f; // per step
+    } lane_cal;
     trlda_model *lane[2] = {nullptr, nullptr};
     trlda_model *lane_owner = nullptr;    // set in a lane: whose lambda / alpha it reads
     int lane_turn = 0;
@@ -2500,6 +2518,8 @@ int sync_model(trlda_model *m)
 // their streams -- and the model's stream continues behind all of it.
 int lanes_join(trlda_model *m)
 {
+    if (m->lane_cal.phase == 1 || m->lane_cal.phase == 2)
+        m->lane_cal.n = 0;                           // (a window with a join in it measures the join: again)
     if (!m->lanes_live)
         return TRLDA_OK;
     m->lanes_live = false;
@@ -3270,8 +3290,10 @@ int trlda_batch_num_very_long_words(const trlda_batch *b) { return b && !batch_w
 namespace {
 // (stream_priority != 0: the model's own stream is created with that priority -- the lanes of
 // another model, lanes_ensure)
-// (lane_of: the model whose lambda and alpha the new one reads instead of allocating its own)
-int model_create(trlda_model **out, int device, int K, int V, int stream_priority, trlda_model *lane_of);
+// (lane_of: the model whose lambda and alpha the new one reads instead of allocating its own;
+// adopt: a stream made by the caller that becomes the model's own -- lanes_ensure picks its streams)
+int model_create(trlda_model **out, int device, int K, int V, int stream_priority, trlda_model *lane_of,
+                 hipStream_t adopt = nullptr);
 }  // namespace
 
 extern "C" {
@@ -3285,7 +3307,8 @@ int trlda_model_create(trlda_model **out, int device, int K, int V)
 
 namespace {
 
-int model_create(trlda_model **out, int device, int K, int V, int stream_priority, trlda_model *lane_of)
+int model_create(trlda_model **out, int device, int K, int V, int stream_priority, trlda_model *lane_of,
+                 hipStream_t adopt)
 {
     if (!out)
         return fail(TRLDA_ERR_ARG, "out is NULL");
@@ -3321,7 +3344,13 @@ int model_create(trlda_model **out, int device, int K, int V, int stream_priorit
     if (!rc) rc = dev_alloc(&m->psi_sum, 3 * (size_t)K);   // psi(row sums), the row sums, exp(-psi)
     if (!rc) rc = dev_alloc(&m->partial, (size_t)kMaxRowsumBlocks * K);
     if (!rc) rc = dev_alloc(&m->counter, 1);
-    if (!rc && !std::getenv("TRLDA_NULL_STREAM")) {
+    if (!rc && adopt) {
+        m->own_stream = adopt;
+        m->stream = adopt;
+        LiveStreams &ls = live_own_streams();
+        std::lock_guard<std::mutex> lock(ls.mu);
+        ls.own.insert(m->own_stream);
+    } else if (!rc && !std::getenv("TRLDA_NULL_STREAM")) {
         hipError_t e = stream_priority != 0
                            ? hipStreamCreateWithPriority(&m->own_stream, hipStreamNonBlocking, stream_priority)
                            : hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking);
@@ -3409,6 +3438,9 @@ int trlda_model_destroy(trlda_model *m)
                 (void)hipEventDestroy(m->lane_in[p]);
             if (m->lane_out[p])
                 (void)hipEventDestroy(m->lane_out[p]);
+            for (int q = 2 * p; q < 2 * p + 2; ++q)
+                if (m->lane_cal.e[q])
+                    (void)hipEventDestroy(m->lane_cal.e[q]);
             for (int q = 0; q < 2; ++q)
                 if (m->lane_span[p][q])
                     (void)hipEventDestroy(m->lane_span[p][q]);
@@ -3487,6 +3519,13 @@ int trlda_model_set_stream(trlda_model *m, void *hip_stream)
     if (int rc_sync = sync_model(m))
         return rc_sync;
     m->stream = static_cast<hipStream_t>(hip_stream);
+    // (what was seen and measured of the lanes was against the old stream: measured again)
+    if (m->lane_cal.phase != 0 || m->lane_state == 1) {
+        m->lane_cal.phase = 0;
+        m->lane_cal.n = 0;
+        if (m->lane_state == 1)
+            m->lane_state = m->lane[0] ? 2 : 0;
+    }
     return TRLDA_OK;
 }
 
@@ -3729,42 +3768,167 @@ namespace {
 // apply (small tables, K <= 128, <= 256 documents), the kernels of their own elsewhere.
 bool lane_takes(const trlda_model *m, const trlda_batch *b)
 {
-    return m->lanes_wanted >= 2 && !m->dp && !m->eb.active && !rowsums_carried(m) && b->B > 0 &&
+    // (not on the legacy null stream: its waits for the lanes' events are resolved by the HOST, which then
+    // stands behind the GPU at every join -- round 5's failing case, 33 us per step against 30.5)
+    return m->lanes_wanted >= 2 && m->lane_state != 1 && m->stream != nullptr && !m->dp && !m->eb.active &&
+           !rowsums_carried(m) && b->B > 0 &&
            b->V == m->V && b->device == m->device;
+}
+
+// ---- which streams may be lanes ------------------------------------------------------------------
+// Two launches overlap only if their streams sit on two hardware queues, and the runtime hands a
+// stream a queue that is in use as soon as a priority's pool (four by default) is exhausted: two lanes
+// on ONE queue -- or a lane on the queue of the caller's stream, whose event records then queue up
+// behind the lane's launches -- are SLOWER than one lane (round 5: 31.9-35.3 us per step against 30.9;
+// a process that had made other streams first got exactly that).  The assignment
+// cannot be asked for or read; it can be seen: a kernel that waits ~40 us on each of two streams --
+// they run side by side (40 us in all) or one behind the other (80).  lanes_ensure makes streams of the
+// device's high priority until it holds two that run side by side with each other and with the
+// model's stream; the ones it had to reject stay alive until it is done (each holds its queue's turn
+// in the runtime's round robin) and go then.  No such pair among kLaneCandidates: no lanes for this
+// model -- the stream goes one launch at a time, as fast as it ever was (trlda_model_lane_state).
+__global__ void lane_probe_kernel(unsigned long long ticks)   // (s_memrealtime: 100 MHz)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks)
+        __builtin_amdgcn_s_sleep(32);
+}
+
+constexpr int kLaneCandidates = 10;
+
+// do kernels of streams a and b run side by side?  (ev: four timing events)
+int streams_overlap(hipStream_t a, hipStream_t b, hipEvent_t (&ev)[4], bool *overlap)
+{
+    constexpr unsigned long long kTicks = 4000;      // 40 us
+    for (int warm = 1; warm >= 0; --warm) {          // (the first launch on a new stream binds its queue)
+        HIP_TRY(hipEventRecord(ev[0], a));
+        hipLaunchKernelGGL(lane_probe_kernel, dim3(1), dim3(64), 0, a, warm ? 100ull : kTicks);
+        HIP_TRY(hipEventRecord(ev[1], a));
+        HIP_TRY(hipEventRecord(ev[2], b));
+        hipLaunchKernelGGL(lane_probe_kernel, dim3(1), dim3(64), 0, b, warm ? 100ull : kTicks);
+        HIP_TRY(hipEventRecord(ev[3], b));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventSynchronize(ev[1]));
+        HIP_TRY(hipEventSynchronize(ev[3]));
+    }
+    float one = 0.f, span = 0.f;
+    HIP_TRY(hipEventElapsedTime(&one, ev[0], ev[1]));
+    HIP_TRY(hipEventElapsedTime(&span, ev[0], ev[3]));
+    *overlap = span < 1.6f * std::max(one, 0.04f);   // (side by side: ~1.1 x; one behind the other: >= 2 x)
+    if (!*overlap)
+        return TRLDA_OK;
+    // ... and a MARKER on a while b's kernel runs: two streams on one hardware queue may still run small
+    // kernels side by side (no barrier between their dispatch packets), but an event record is a
+    // barrier packet, and a barrier packet waits for everything in front of it in ITS queue -- which
+    // is what costs the lanes their gain there (the model's stream records and waits for events
+    // between the lanes' 50 us launches).  Recorded on an idle stream it is through in a few
+    // microseconds; behind the other stream's kernel it takes the kernel's 40.
+    HIP_TRY(hipEventRecord(ev[0], b));
+    hipLaunchKernelGGL(lane_probe_kernel, dim3(1), dim3(64), 0, b, kTicks);
+    HIP_TRY(hipEventRecord(ev[1], b));
+    HIP_TRY(hipEventRecord(ev[2], a));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventSynchronize(ev[1]));
+    HIP_TRY(hipEventSynchronize(ev[2]));
+    float marker = 0.f;
+    HIP_TRY(hipEventElapsedTime(&marker, ev[0], ev[2]));
+    *overlap = marker < 0.6f * std::max(one, 0.04f);
+    return TRLDA_OK;
 }
 
 int lanes_ensure(trlda_model *m)
 {
-    for (int p = 0; p < 2; ++p) {
-        if (m->lane[p])
-            continue;
-        // The lanes' streams get the device's HIGH priority: the runtime keeps a pool of hardware queues
-        // per priority (four each by default) and hands a stream beyond the pool's size a queue that
-        // another stream of that priority already has -- two lanes on ONE queue run one after the other,
-        // and a lane sharing the queue of the caller's stream has that stream's event records queue up
-        // behind its launches (measured: 35.3 us per step, against 26.8 with queues of their own and
-        // 30.9 with one lane; profiles/r05_lanes_queues.txt).  Nobody else in the process normally asks
-        // for that priority, so the two lanes have two queues to themselves.
-        static const int lane_priority = [] {
-            if (const char *e = std::getenv("TRLDA_LANE_PRIORITY"))   // (A/B; 0: the default priority)
-                return std::atoi(e);
-            int least = 0, greatest = 0;
-            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess)
-                return 0;
-            return greatest;
-        }();
+    if (m->lane[0] && m->lane[1])
+        return TRLDA_OK;
+    if (m->lane_state == 1)
+        return TRLDA_OK;
+    // The lanes' streams get the device's HIGH priority: a pool of hardware queues nobody else in the
+    // process normally draws from (TRLDA_LANE_PRIORITY: A/B; 0: the default priority)
+    static const int lane_priority = [] {
+        if (const char *e = std::getenv("TRLDA_LANE_PRIORITY"))
+            return std::atoi(e);
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess)
+            return 0;
+        return greatest;
+    }();
+    static const bool verify = [] {
+        const char *e = std::getenv("TRLDA_LANE_VERIFY");
+        return !(e && e[0] == '0');
+    }();
+    auto make_stream = [&](hipStream_t *s) {
+        hipError_t e = lane_priority != 0 ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, lane_priority)
+                                          : hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+        if (e != hipSuccess && lane_priority != 0) { // (a runtime without priorities: a plain stream)
+            (void)hipGetLastError();
+            e = hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+        }
+        return e;
+    };
+    hipStream_t chosen[2] = {nullptr, nullptr};
+    std::vector<hipStream_t> rejected;
+    int found = 0, rc = TRLDA_OK;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    for (auto &e : ev)
+        if (verify && hipEventCreate(&e) != hipSuccess)
+            rc = fail(TRLDA_ERR_HIP, "hipEventCreate failed");
+    // (the caller's stream is waited for first: the probe's kernels are timed against an idle device)
+    if (!rc && verify && hipStreamSynchronize(m->stream) != hipSuccess)
+        rc = fail(TRLDA_ERR_HIP, "hipStreamSynchronize failed");
+    for (int c = 0; !rc && found < 2 && c < (verify ? kLaneCandidates : 2); ++c) {
+        hipStream_t s = nullptr;
+        if (make_stream(&s) != hipSuccess) {
+            rc = fail(TRLDA_ERR_HIP, "hipStreamCreate failed");
+            break;
+        }
+        bool ok = true;
+        if (verify) {
+            rc = streams_overlap(m->stream, s, ev, &ok);
+            if (!rc && ok && found == 1)
+                rc = streams_overlap(chosen[0], s, ev, &ok);
+        }
+        if (!rc && ok)
+            chosen[found++] = s;
+        else
+            rejected.push_back(s);
+    }
+    for (hipStream_t s : rejected)
+        (void)hipStreamDestroy(s);
+    for (auto &e : ev)
+        if (e)
+            (void)hipEventDestroy(e);
+    if (!rc && found < 2) {
+        for (int p = 0; p < found; ++p)
+            (void)hipStreamDestroy(chosen[p]);
+        m->lane_state = 1;                           // no pair of queues: one launch at a time
+        return TRLDA_OK;
+    }
+    for (int p = 0; !rc && p < 2; ++p) {
         trlda_model *l = nullptr;
-        int rc = model_create(&l, m->device, m->K, m->V, lane_priority, m);
+        rc = model_create(&l, m->device, m->K, m->V, lane_priority, m, chosen[p]);
         if (rc)
-            return rc;
+            break;
+        chosen[p] = nullptr;                         // (the lane's own now)
         // (the events first: a lane is published whole or not at all)
         if ((!m->lane_in[p] && hipEventCreateWithFlags(&m->lane_in[p], hipEventDisableTiming) != hipSuccess) ||
             (!m->lane_out[p] && hipEventCreateWithFlags(&m->lane_out[p], hipEventDisableTiming) != hipSuccess)) {
             (void)trlda_model_destroy(l);
-            return fail(TRLDA_ERR_HIP, "hipEventCreateWithFlags failed");
+            rc = fail(TRLDA_ERR_HIP, "hipEventCreateWithFlags failed");
+            break;
         }
         m->lane[p] = l;
     }
+    if (rc) {
+        for (int p = 0; p < 2; ++p) {
+            if (chosen[p])
+                (void)hipStreamDestroy(chosen[p]);
+            if (m->lane[p])
+                (void)trlda_model_destroy(m->lane[p]);
+            m->lane[p] = nullptr;
+        }
+        return rc;
+    }
+    m->lane_state = verify ? 2 : 3;
     return TRLDA_OK;
 }
 
@@ -3825,6 +3989,17 @@ int trlda_model_set_stream_lanes(trlda_model *m, int lanes)
 }
 
 long long trlda_model_lane_steps(const trlda_model *m) { return m ? (long long)m->lane_steps : 0; }
+
+int trlda_model_lane_state(const trlda_model *m) { return m ? m->lane_state : 0; }
+
+int trlda_model_lane_timing(const trlda_model *m, double *us_two_lanes, double *us_one_lane)
+{
+    if (!m || !us_two_lanes || !us_one_lane)
+        return fail(TRLDA_ERR_ARG, "NULL model / output");
+    *us_two_lanes = m->lane_cal.us_two;
+    *us_one_lane = m->lane_cal.us_one;
+    return TRLDA_OK;
+}
 
 namespace {
 // TRLDA_LANE_TRACE=1: host time of the phases of the first calls after a join (stderr)
@@ -3902,6 +4077,63 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
         rc = lanes_ensure(m);
     if (rc)
         return rc;
+    if (m->lane_state == 1)                          // (no two streams that run side by side: lanes_ensure)
+        return trlda_model_estep_io_next(m, b, next, gamma0_dev, gamma_dev, sstats_dev, max_iter,
+                                         threshold, iters_dev);
+    // the calibration (trlda_model::lane_cal): its one-lane window, and its verdict
+    constexpr int kLaneCalAfter = 96, kLaneCalSkip = 4, kLaneCalOne = 12, kLaneCalTwo = 6;
+    static const bool calibrate = [] {
+        const char *e = std::getenv("TRLDA_LANE_CALIBRATE");
+        return !(e && e[0] == '0');
+    }();
+    auto &cal = m->lane_cal;
+    if (calibrate && cal.phase == 0 && m->lane_steps >= kLaneCalAfter) {
+        for (auto &e : cal.e)
+            if (!e && hipEventCreate(&e) != hipSuccess)
+                cal.phase = 4;                       // (no events: no calibration)
+        if (cal.phase == 0) {
+            cal.phase = 2;
+            cal.n = 0;
+        }
+    }
+    if (cal.phase == 1) {
+        // one launch at a time, on the model's stream, behind everything the lanes hold
+        if ((rc = check_model(m)))                   // (joins the lanes; resets cal.n when it had to)
+            return rc;
+        rc = trlda_model_estep_io_next(m, b, next, gamma0_dev, gamma_dev, sstats_dev, max_iter, threshold,
+                                       iters_dev);
+        if (rc)
+            return rc;
+        ++cal.n;
+        if (cal.n == kLaneCalSkip)
+            HIP_TRY(hipEventRecord(cal.e[0], m->stream));
+        if (cal.n == kLaneCalSkip + kLaneCalOne) {
+            HIP_TRY(hipEventRecord(cal.e[1], m->stream));
+            cal.phase = 3;
+        }
+        return TRLDA_OK;
+    }
+    if (cal.phase == 3 && hipEventQuery(cal.e[1]) == hipSuccess && hipEventQuery(cal.e[3]) == hipSuccess) {
+        float one = 0.f, two = 0.f;
+        if (hipEventElapsedTime(&one, cal.e[0], cal.e[1]) == hipSuccess &&
+            hipEventElapsedTime(&two, cal.e[2], cal.e[3]) == hipSuccess) {
+            cal.us_one = 1e3f * one / kLaneCalOne;
+            cal.us_two = 1e3f * two / (2 * kLaneCalTwo);
+            // (TRLDA_LANE_CAL_MARGIN: what "faster" means -- tests make the lanes lose with 0.5)
+            const char *me = std::getenv("TRLDA_LANE_CAL_MARGIN");
+            const float margin = me ? (float)std::atof(me) : 0.98f;
+            if (cal.us_two > margin * cal.us_one) {  // two launches in flight gain nothing here
+                cal.phase = 4;
+                if ((rc = check_model(m)))           // (joins)
+                    return rc;
+                m->lane_state = 1;
+                return trlda_model_estep_io_next(m, b, next, gamma0_dev, gamma_dev, sstats_dev, max_iter,
+                                                 threshold, iters_dev);
+            }
+        }
+        cal.phase = 4;
+    }
+    (void)hipGetLastError();                         // (hipErrorNotReady of the queries above)
     const int p = m->lane_turn;
     trlda_model *l = m->lane[p], *o = m->lane[1 - p];
     lane_follow(m, l);
@@ -3977,6 +4209,16 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
         note(sstats_dev, s_bytes);
         note(iters_dev, i_bytes);
         ++m->lane_calls[p];
+    }
+    if (cal.phase == 2 && p == 0) {                  // (after lane 0's launch: its stream's position)
+        ++cal.n;
+        if (cal.n == 2)
+            HIP_TRY(hipEventRecord(cal.e[2], l->stream));
+        if (cal.n == 2 + kLaneCalTwo) {
+            HIP_TRY(hipEventRecord(cal.e[3], l->stream));
+            cal.phase = 1;
+            cal.n = 0;
+        }
     }
     m->lane_turn = 1 - p;
     ++m->lane_steps;
