@@ -122,6 +122,8 @@ def parse():
                          "(trlda_model_set_stream_lanes: the steps go in turn to two streams of the "
                          "library's own, output arrays alternate between two sets; every fence() joins "
                          "them before the clock stops).  1 = one launch at a time, as in rounds 1-4")
+    ap.add_argument("--no-exchange-ab", action="store_true",
+                    help="N > 1: do not time the other exchange plans after the run's own")
     ap.add_argument("--no-end-to-end", action="store_true",
                     help="skip the leg that starts every mini-batch from CSR arrays in host memory")
     ap.add_argument("--no-settle", action="store_true",
@@ -164,10 +166,17 @@ def exchange_plan(args, world, virtual_world=0):
         ("factors" if factors_bytes < sstats_bytes or args.exchange == "direct" else "sstats")
     if virtual_world:
         exchange = "factors"
+    sharded = bool(exchange == "factors" and not args.whole_stats)
+    own = ("direct" if args.exchange == "direct" else "factors_word_sharded" if sharded
+           else "factors_whole_stats" if exchange == "factors" else "sstats_allreduce")
     return {"exchange": exchange, "slot_doubles": slot, "batch_per_gpu": B,
             "factors_bytes_per_rank": factors_bytes, "allreduce_bytes_per_rank": sstats_bytes,
-            "word_sharded_m_step": bool(exchange == "factors" and not args.whole_stats),
-            "direct_requested": args.exchange == "direct"}
+            "word_sharded_m_step": sharded,
+            "direct_requested": args.exchange == "direct",
+            # the plans timed in one run (`exchange_ab` of the result line): the run's own first, then
+            # the others -- the same list on every rank
+            "exchange_ab": [] if (virtual_world or getattr(args, "no_exchange_ab", False)) else
+            [own] + [p for p in ("sstats_allreduce", "factors_whole_stats", "factors_word_sharded") if p != own]}
 
 
 def launch_ranks(n, argv, timeout_s):
@@ -706,12 +715,19 @@ def main():
                 "settle_last_ms_per_step": round(1e3 * last / chunk, 5)}
 
     settled = settle()
+    def lane_report():
+        two, one = C.c_double(), C.c_double()
+        L.trlda_model_lane_timing(model, C.byref(two), C.byref(one))
+        return int(L.trlda_model_lane_state(model)), {"launch_us": round(two.value, 3), "step_us": round(one.value, 3),
+                                                      "launches_in_flight": round(two.value / one.value, 3) if one.value else None}
+
     # the timed region, `--repeats` times back to back: the median is the result (20 steps of
     # 40 us are under a millisecond -- one scheduling hiccup moves a single sample by 10 %)
     samples = sorted(timed() for _ in range(max(1, args.repeats)))
     # (did the last launch of a timed region carry the statistics of an earlier step? -- asked here:
     # the first launches after a fence never do)
     carried_flag = bool(deferred and L.trlda_model_last_deferred(model) & 2)
+    lane_state, lane_cal = lane_report()
     elapsed = samples[len(samples) // 2]
     docs_per_s = world * B * args.steps / elapsed
     repeats = {"n": len(samples), "value": "median",
@@ -847,6 +863,63 @@ def main():
                             "what": "rank 0 alone, same kernels and M-step, no exchange"}
         dist.barrier()
         _ffi.check(L.trlda_model_set_lambda(model, lam))   # every rank back on the common lambda
+
+    # N > 1: the OTHER transports of the same step, a few steps each, in the same run (VERDICT r5 item 8:
+    # the first lease of an 8-GPU node should answer "which exchange" at once): the all-reduce of the
+    # K x V statistics | the factor exchange with every rank forming the whole mini-batch's statistics |
+    # the factor exchange with the M-step sharded by vocabulary range (+ the lambda columns exchanged).
+    # Decided from the arguments and the communicator alone, so every rank walks the same list; the
+    # direct pushes are timed only when they are the run's own plan (--exchange direct: their regions
+    # are mapped at start-up).  Reported, never `value`.
+    exchange_ab = None
+    if collective and not vworld and not args.no_exchange_ab:
+        exchange_ab = {}
+        word_sharded = bool(exchange == "factors" and L.trlda_model_last_word_sharded(model))
+        plan_now = ("direct" if direct else "factors_word_sharded" if (exchange == "factors" and word_sharded)
+                    else "factors_whole_stats" if exchange == "factors" else "sstats_allreduce")
+        exchange_ab[plan_now] = round(1e6 * elapsed / args.steps, 3)
+        keep_exchange, keep_sharding = exchange, int(bool(word_sharded))
+        can_factors = rccl_comm is not None and not direct
+        for name, ex, sh in (("sstats_allreduce", "sstats", None), ("factors_whole_stats", "factors", 0),
+                             ("factors_word_sharded", "factors", 1)):
+            if name == plan_now:
+                continue
+            if ex == "factors" and not can_factors:
+                exchange_ab[name] = None             # (ncclAllGather needs the library's own communicator)
+                continue
+            try:
+                if ex == "factors" and not gbatches:
+                    for i in range(args.num_batches):    # every rank holds the whole mini-batch's word lists
+                        parts = [csrs[i] if r == rank else rank_corpus(r, i) for r in range(xworld)]
+                        off = np.concatenate([[0], np.cumsum([int(p_.indptr[-1]) for p_ in parts])])
+                        whole = CSRDocuments(
+                            np.concatenate([parts[0].indptr] + [p_.indptr[1:] + off[r] for r, p_ in enumerate(parts) if r]),
+                            np.concatenate([p_.ids for p_ in parts]), np.concatenate([p_.cnts for p_ in parts]))
+                        gbatches.append(DeviceBatch(whole, V, local_rank))
+                exchange = ex
+                if sh is not None:
+                    _ffi.check(L.trlda_model_set_word_sharding(model, sh))
+                _ffi.check(L.trlda_model_set_lambda(model, lam))
+                n_ab = max(4, min(args.steps, 20))
+                for i in range(3):
+                    step(i)
+                fence()
+                t0 = time.perf_counter()
+                for i in range(n_ab):
+                    step(3 + i)
+                fence()
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                exchange_ab[name] = round(1e6 * float(t.item()) / n_ab, 3)
+            except Exception as exc:                  # noqa: BLE001 (a transport that cannot run here)
+                exchange_ab[name] = "failed: " + repr(exc)[:120]
+        exchange = keep_exchange
+        _ffi.check(L.trlda_model_set_word_sharding(model, keep_sharding))
+        _ffi.check(L.trlda_model_set_lambda(model, lam))
+        exchange_ab = {"us_per_step": exchange_ab, "plan_of_the_run": plan_now,
+                       "steps_each": max(4, min(args.steps, 20)),
+                       "note": "the run's own plan: its timed regions; the others: one region each after 3 "
+                               "warm-up steps, maximum over ranks"}
 
     # ---- per-kernel durations: HIP events on the launch stream, same steps replayed -------
     # (two lanes whose steps are several kernels -- shapes outside the deferred statistics' range --
@@ -1214,9 +1287,13 @@ def main():
         "value_no_prefetch": value_no_prefetch,
         "value_one_lane": value_one_lane,
         "lanes": lanes[0],
+        # what became of the lanes (include/trlda_hip.h, trlda_model_lane_state: 2 = two lanes on streams
+        # seen to run side by side, 1 = given up) and what the library's own measurement found
+        "lane_state": lane_state, "lane_calibration": lane_cal,
         "value_fixed_work": value_fixed_work,
         "value_end_to_end": value_end_to_end,
         "rccl_ranks": rccl_ranks,
+        "exchange_ab": exchange_ab,
         "same_step_n1": same_step_n1,
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,

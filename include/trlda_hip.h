@@ -340,15 +340,16 @@ long long trlda_model_lane_steps(const trlda_model *model);
  * 2 two lanes on streams that were SEEN to run side by side with each other and with the model's stream
  * -- the runtime hands out hardware queues that are in use once a priority's pool is exhausted, and two
  * lanes on one queue are slower than one lane, so the library makes streams until it holds such a pair
- * (a ~40 us probe kernel on each of two streams: 40 us in all or 80); 1 the lanes were given up -- no
- * such pair was to be had, or the MEASUREMENT said so: after 96 steps through the lanes a window of
- * them is timed on the device, then 16 steps go one launch at a time and are timed, and two lanes
- * that are not 2 % faster are dropped (a model on the legacy null stream in a process that has made
- * and destroyed streams: 33 us per step against 30.5) -- the stream of calls goes one launch at a time,
- * as without the switch; 3 two lanes, not looked at (TRLDA_LANE_VERIFY=0).  trlda_model_lane_timing:
- * what the measurement found, microseconds per step (0: not measured yet). */
+ * (a ~40 us probe kernel on each of two streams: 40 us in all or 80; a marker on one behind a kernel
+ * on the other); 1 the lanes were given up -- no such pair was to be had, or the MEASUREMENT said so:
+ * after 96 steps through the lanes one launch of a lane and the four that follow it are timed on the
+ * device; two launches in flight means a launch LASTS about two steps (51 us where one starts every
+ * 26), lanes that do not overlap have launches of one step's length, and below 1.4 launches in
+ * flight the lanes are dropped -- the stream of calls goes one launch at a time, as without the
+ * switch; 3 two lanes, not looked at (TRLDA_LANE_VERIFY=0).  trlda_model_lane_timing: what the
+ * measurement found, microseconds (0: not measured yet). */
 int trlda_model_lane_state(const trlda_model *model);
-int trlda_model_lane_timing(const trlda_model *model, double *us_two_lanes, double *us_one_lane);
+int trlda_model_lane_timing(const trlda_model *model, double *us_per_launch, double *us_per_step);
 /* with trlda_model_set_timing on: the summed duration (HIP events on the lanes' streams, one pair per
  * lane around each stretch of calls between joins -- a lane's launches run back to back) and the
  * number of the document launches that went through the lanes; joins the lanes */

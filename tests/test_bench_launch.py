@@ -77,6 +77,8 @@ def test_eight_ranks_build_the_same_exchange_plan(tmp_path):
     assert p["exchange"] == "factors" and p["word_sharded_m_step"] is True and p["direct_requested"] is False
     assert p["batch_per_gpu"] == 200 and p["factors_bytes_per_rank"] < p["allreduce_bytes_per_rank"]
     assert json.loads(r.stdout)["plan"] == p
+    # ... and at the same list of plans to time one after the other in that run (`exchange_ab`)
+    assert p["exchange_ab"] == ["factors_word_sharded", "sstats_allreduce", "factors_whole_stats"]
     for extra, want in ((["--whole-stats"], ("factors", False, False)),
                         (["--exchange", "sstats"], ("sstats", False, False)),
                         (["--exchange", "direct"], ("factors", True, True)),

@@ -113,6 +113,13 @@ def test_bench_forced_distributed_line(hip_lib):
     finally:
         del os.environ[env_key]
         del os.environ["TRLDA_BENCH_SHARD_CHECK"]
+    # the other exchange plans timed in the same run (round 6): every plan a number (one rank: the
+    # library's own one-rank ncclComm_t carries the all-gather), the run's own among them
+    ab = j["exchange_ab"]
+    assert ab["plan_of_the_run"] in ab["us_per_step"]
+    assert set(ab["us_per_step"]) == {"sstats_allreduce", "factors_whole_stats", "factors_word_sharded"}
+    for name, us in ab["us_per_step"].items():
+        assert isinstance(us, float) and 10. < us < 5000., (name, us)
     chk = j["config"]["exchange_check"]["word_sharded_m_step"]
     assert chk["word_sharded"] is False and chk["replicas_equal"] is True
     assert j["config"]["word_sharded_m_step"] is False

@@ -126,9 +126,26 @@ def main():
             fence()
             samples.append((time.perf_counter() - t0) / steps * 1e6)
             pos += steps
-        print("one model, %d lane(s)%s: %s us per step (median %.2f); %d steps through the lanes"
+        if os.environ.get("TRACE_CALLS"):            # where a slow region loses its time: call by call
+            fence()
+            ts = []
+            for i in range(pos, pos + steps):
+                t0 = time.perf_counter()
+                run(i, 1)
+                ts.append((time.perf_counter() - t0) * 1e6)
+            t0 = time.perf_counter(); fence(); tf = (time.perf_counter() - t0) * 1e6
+            pos += steps
+            ts = np.array(ts)
+            slow = np.nonzero(ts > 150)[0]
+            print("   calls: median %.1f us, sum %.0f us, fence %.0f us; calls > 150 us: %s" % (
+                np.median(ts), ts.sum(), tf, [(int(i), int(ts[i])) for i in slow[:20]]))
+        two, one = C.c_double(), C.c_double()
+        L.trlda_model_lane_timing(m, C.byref(two), C.byref(one))
+        print("one model, %d lane(s)%s: %s us per step (median %.2f); %d steps through the lanes; lane state %d, "
+              "the library's own measurement: a launch %.2f us, a step %.2f us"
               % (lanes, ", ONE set of output arrays" if shared else "", " ".join("%.2f" % x for x in samples),
-                 sorted(samples)[2], L.trlda_model_lane_steps(m)), flush=True)
+                 sorted(samples)[2], L.trlda_model_lane_steps(m), L.trlda_model_lane_state(m), two.value, one.value),
+              flush=True)
         L.trlda_model_destroy(m)
 
 

@@ -308,18 +308,22 @@ struct trlda_model {
     // pair of streams was to be had from the runtime -- the stream goes one launch at a time
     int lane_state = 0;
     // ... and MEASURED (trlda_model_estep_io_ahead): what the probe kernels of lanes_ensure cannot see
-    // -- round 5's failing case, a model on the legacy null stream in a process that had made and
-    // destroyed streams: 33.2 us per step through two lanes against 30.5 through one -- shows in the
-    // stream's own steps.  After kLaneCalAfter steps through the lanes a window of lane 0's launches
-    // is timed (events on its stream), then the lanes are joined and a window of steps goes one launch
-    // at a time, timed on the model's stream; two lanes that are not at least 2 % faster are given up
-    // (lane_state 1).  Once per model (again after trlda_model_set_stream); the one-lane window costs
-    // 16 steps x 4 us.  TRLDA_LANE_CALIBRATE=0: never.
+    // -- round 5's failing case, a model in a process that had made and destroyed streams: 33.2 us per
+    // step through two lanes against 30.5 through one -- shows in the stream's own launches.  Two
+    // launches in flight means: a launch LASTS about two steps (51 us where a new one starts every
+    // 26); lanes that do not overlap have launches of one step's length (30 us every 30-34).  After
+    // kLaneCalAfter steps through the lanes, eight steps into a stretch, one launch of lane 0 is timed
+    // (an event before it, one behind it) together with the four launches that follow it on that lane
+    // (an event behind the last): launches_in_flight = duration / step interval; below 1.4 the lanes
+    // are given up (lane_state 1).  Three events, no step taken out of the lanes, once per model (again
+    // after trlda_model_set_stream); a window a join falls into is started again, at most eight
+    // times.  TRLDA_LANE_CALIBRATE=0: never.
     struct {
-        int phase = 0;                    // 0 counting | 2 two-lane window | 1 one-lane window | 3 waiting for the events | 4 done
-        int n = 0;                        // calls into the current window (lane 0's calls in phase 2)
-        hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
-        float us_two = 0.f, us_one = 0.f; // per step
+        int phase = 0;                    // 0 counting | 2 the window | 3 waiting for the events | 4 done
+        int n = 0;                        // lane 0's calls into the window
+        int tries = 0;                    // windows broken by a join so far
+        hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+        float us_launch = 0.f, us_step = 0.f;
     } lane_cal;
     trlda_model *lane[2] = {nullptr, nullptr};
     trlda_model *lane_owner = nullptr;    // set in a lane: whose lambda / alpha it reads
@@ -2518,8 +2522,13 @@ int sync_model(trlda_model *m)
 // their streams -- and the model's stream continues behind all of it.
 int lanes_join(trlda_model *m)
 {
-    if (m->lane_cal.phase == 1 || m->lane_cal.phase == 2)
-        m->lane_cal.n = 0;                           // (a window with a join in it measures the join: again)
+    if (m->lane_cal.phase == 2 && m->lane_cal.n > 0) {
+        // (a window with a join in it measures the join: again -- a caller whose stretches are
+        // shorter than the windows never gets a measurement, and keeps its lanes)
+        m->lane_cal.n = 0;
+        if (++m->lane_cal.tries > 8)
+            m->lane_cal.phase = 4;
+    }
     if (!m->lanes_live)
         return TRLDA_OK;
     m->lanes_live = false;
@@ -3438,9 +3447,10 @@ int trlda_model_destroy(trlda_model *m)
                 (void)hipEventDestroy(m->lane_in[p]);
             if (m->lane_out[p])
                 (void)hipEventDestroy(m->lane_out[p]);
-            for (int q = 2 * p; q < 2 * p + 2; ++q)
-                if (m->lane_cal.e[q])
-                    (void)hipEventDestroy(m->lane_cal.e[q]);
+            if (p == 0)
+                for (auto &e : m->lane_cal.e)
+                    if (e)
+                        (void)hipEventDestroy(e);
             for (int q = 0; q < 2; ++q)
                 if (m->lane_span[p][q])
                     (void)hipEventDestroy(m->lane_span[p][q]);
@@ -3523,6 +3533,7 @@ int trlda_model_set_stream(trlda_model *m, void *hip_stream)
     if (m->lane_cal.phase != 0 || m->lane_state == 1) {
         m->lane_cal.phase = 0;
         m->lane_cal.n = 0;
+        m->lane_cal.tries = 0;
         if (m->lane_state == 1)
             m->lane_state = m->lane[0] ? 2 : 0;
     }
@@ -3768,10 +3779,7 @@ namespace {
 // apply (small tables, K <= 128, <= 256 documents), the kernels of their own elsewhere.
 bool lane_takes(const trlda_model *m, const trlda_batch *b)
 {
-    // (not on the legacy null stream: its waits for the lanes' events are resolved by the HOST, which then
-    // stands behind the GPU at every join -- round 5's failing case, 33 us per step against 30.5)
-    return m->lanes_wanted >= 2 && m->lane_state != 1 && m->stream != nullptr && !m->dp && !m->eb.active &&
-           !rowsums_carried(m) && b->B > 0 &&
+    return m->lanes_wanted >= 2 && m->lane_state != 1 && !m->dp && !m->eb.active && !rowsums_carried(m) && b->B > 0 &&
            b->V == m->V && b->device == m->device;
 }
 
@@ -3992,12 +4000,12 @@ long long trlda_model_lane_steps(const trlda_model *m) { return m ? (long long)m
 
 int trlda_model_lane_state(const trlda_model *m) { return m ? m->lane_state : 0; }
 
-int trlda_model_lane_timing(const trlda_model *m, double *us_two_lanes, double *us_one_lane)
+int trlda_model_lane_timing(const trlda_model *m, double *us_launch, double *us_step)
 {
-    if (!m || !us_two_lanes || !us_one_lane)
+    if (!m || !us_launch || !us_step)
         return fail(TRLDA_ERR_ARG, "NULL model / output");
-    *us_two_lanes = m->lane_cal.us_two;
-    *us_one_lane = m->lane_cal.us_one;
+    *us_launch = m->lane_cal.us_launch;
+    *us_step = m->lane_cal.us_step;
     return TRLDA_OK;
 }
 
@@ -4080,8 +4088,8 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
     if (m->lane_state == 1)                          // (no two streams that run side by side: lanes_ensure)
         return trlda_model_estep_io_next(m, b, next, gamma0_dev, gamma_dev, sstats_dev, max_iter,
                                          threshold, iters_dev);
-    // the calibration (trlda_model::lane_cal): its one-lane window, and its verdict
-    constexpr int kLaneCalAfter = 96, kLaneCalSkip = 4, kLaneCalOne = 12, kLaneCalTwo = 6;
+    // the calibration (trlda_model::lane_cal): its verdict
+    constexpr int kLaneCalAfter = 96, kLaneCalLaunches = 4;
     static const bool calibrate = [] {
         const char *e = std::getenv("TRLDA_LANE_CALIBRATE");
         return !(e && e[0] == '0');
@@ -4096,42 +4104,24 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
             cal.n = 0;
         }
     }
-    if (cal.phase == 1) {
-        // one launch at a time, on the model's stream, behind everything the lanes hold
-        if ((rc = check_model(m)))                   // (joins the lanes; resets cal.n when it had to)
-            return rc;
-        rc = trlda_model_estep_io_next(m, b, next, gamma0_dev, gamma_dev, sstats_dev, max_iter, threshold,
-                                       iters_dev);
-        if (rc)
-            return rc;
-        ++cal.n;
-        if (cal.n == kLaneCalSkip)
-            HIP_TRY(hipEventRecord(cal.e[0], m->stream));
-        if (cal.n == kLaneCalSkip + kLaneCalOne) {
-            HIP_TRY(hipEventRecord(cal.e[1], m->stream));
-            cal.phase = 3;
-        }
-        return TRLDA_OK;
-    }
-    if (cal.phase == 3 && hipEventQuery(cal.e[1]) == hipSuccess && hipEventQuery(cal.e[3]) == hipSuccess) {
-        float one = 0.f, two = 0.f;
-        if (hipEventElapsedTime(&one, cal.e[0], cal.e[1]) == hipSuccess &&
-            hipEventElapsedTime(&two, cal.e[2], cal.e[3]) == hipSuccess) {
-            cal.us_one = 1e3f * one / kLaneCalOne;
-            cal.us_two = 1e3f * two / (2 * kLaneCalTwo);
-            // (TRLDA_LANE_CAL_MARGIN: what "faster" means -- tests make the lanes lose with 0.5)
-            const char *me = std::getenv("TRLDA_LANE_CAL_MARGIN");
-            const float margin = me ? (float)std::atof(me) : 0.98f;
-            if (cal.us_two > margin * cal.us_one) {  // two launches in flight gain nothing here
-                cal.phase = 4;
-                if ((rc = check_model(m)))           // (joins)
+    if (cal.phase == 3 && hipEventQuery(cal.e[2]) == hipSuccess) {
+        float launch = 0.f, steps = 0.f;
+        cal.phase = 4;
+        if (hipEventElapsedTime(&launch, cal.e[0], cal.e[1]) == hipSuccess &&
+            hipEventElapsedTime(&steps, cal.e[1], cal.e[2]) == hipSuccess && steps > 0.f) {
+            cal.us_launch = 1e3f * launch;
+            cal.us_step = 1e3f * steps / (2 * kLaneCalLaunches);
+            // (TRLDA_LANE_CAL_MIN_IN_FLIGHT: tests make the lanes lose with 100, win with 0)
+            const char *me = std::getenv("TRLDA_LANE_CAL_MIN_IN_FLIGHT");
+            const float need = me ? (float)std::atof(me) : 1.4f;
+            if (cal.us_launch < need * cal.us_step) {       // the launches do not overlap: nothing gained
+                if ((rc = check_model(m, /*keep_pending=*/true)))   // (joins the lanes)
                     return rc;
                 m->lane_state = 1;
                 return trlda_model_estep_io_next(m, b, next, gamma0_dev, gamma_dev, sstats_dev, max_iter,
                                                  threshold, iters_dev);
             }
         }
-        cal.phase = 4;
     }
     (void)hipGetLastError();                         // (hipErrorNotReady of the queries above)
     const int p = m->lane_turn;
@@ -4181,6 +4171,11 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
     if (m->lane_span_open[p])
         ++m->lane_span_launches[p];
     m->lanes_live = true;
+    // (the calibration's window opens eight steps into a stretch: the first launches after a join do
+    // not overlap yet, and a stretch shorter than that is never measured)
+    const bool cal_first = cal.phase == 2 && p == 0 && cal.n == 0 && m->lane_calls[0] + m->lane_calls[1] >= 8;
+    if (cal_first)
+        HIP_TRY(hipEventRecord(cal.e[0], l->stream));
     EstepOut out(sstats_dev);
     rc = estep_device(l, b, gamma_dev, out, max_iter, threshold, iters_dev, gamma0_dev,
                       n_upcoming > 1 ? upcoming[1] : nullptr);
@@ -4211,12 +4206,12 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
         ++m->lane_calls[p];
     }
     if (cal.phase == 2 && p == 0) {                  // (after lane 0's launch: its stream's position)
-        ++cal.n;
-        if (cal.n == 2)
+        if (cal_first) {
+            HIP_TRY(hipEventRecord(cal.e[1], l->stream));
+            cal.n = 1;
+        } else if (cal.n > 0 && ++cal.n == 1 + kLaneCalLaunches) {
             HIP_TRY(hipEventRecord(cal.e[2], l->stream));
-        if (cal.n == 2 + kLaneCalTwo) {
-            HIP_TRY(hipEventRecord(cal.e[3], l->stream));
-            cal.phase = 1;
+            cal.phase = 3;
             cal.n = 0;
         }
     }
