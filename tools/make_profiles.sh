@@ -18,8 +18,12 @@
 #              the two-stream probes
 #   probes     graph probe, any-order probe, xcu probe (stand-alone HIP programs under tools/probes)
 #   fuzz       the four fuzzers at a few seeds each (long: ~15 min)
-#   core       check headline pmc configs updates dp stamps lengths deferred
-tag=${1:-r05}; commit=${2:-unknown}; shift; shift
+#   ingest     round 6: the index builder's host time and phases, the ingestion rates (made / used /
+#              streamed), the end-to-end stream call by call
+#   lanes      round 6: the hostile set-ups (streams made first, default-priority lanes), round 5's failing
+#              case over six process starts
+#   core       check headline pmc configs updates dp stamps lengths deferred ingest lanes
+tag=${1:-r06}; commit=${2:-unknown}; shift; shift
 targets=${@:-core}
 export TMPDIR=/tmp
 o=gpurun_out
@@ -79,7 +83,11 @@ t_configs() { bash tools/sweep_configs.sh 2>&1 | clean > $o/${tag}_configs.txt; 
 
 t_updates() {
   python3 tools/update_rate.py --configs small,c3,c5a,c5b,c4 --modes fused,plain 2>&1 | clean > $o/${tag}_update_rates.txt
-  python3 tools/host_rate.py 2>&1 | clean > $o/${tag}_host_rates.txt
+  ( echo "# TRLDA_AUX_DECAY=0 (the inactive words' decay by the streaming kernel behind the launch)"
+    TRLDA_AUX_DECAY=0 python3 tools/update_rate.py --configs small --modes fused 2>&1 | clean | tail -2
+    echo "# TRLDA_AUX_DECAY=0 TRLDA_DRAW_AHEAD=0 (every gamma0 drawn in its turn; round 5: 0.427 / 0.087 ms)"
+    TRLDA_AUX_DECAY=0 TRLDA_DRAW_AHEAD=0 python3 tools/update_rate.py --configs small --modes fused 2>&1 | clean | tail -2
+  ) > $o/${tag}_update_rates_aux_ab.txt
   for cfg in small c5a; do tools/prof_update.sh ${tag}_${cfg}_fused $cfg fused > /dev/null 2>&1; done
   for sl in 1 0; do
     TRLDA_MERGED_SLOTS=$sl python3 tools/update_rate.py --configs small --modes fused 2>&1 | clean | tail -2
@@ -158,6 +166,30 @@ t_probes() {
   tail -3 $o/${tag}_graph_probe.txt
 }
 
+t_ingest() {
+  ( python3 tools/index_rate.py; python3 tools/probes/index_phases.py ) 2>&1 | clean > $o/${tag}_index_rate.txt
+  python3 tools/host_rate.py 2>&1 | clean > $o/${tag}_host_rates.txt
+  ( for a in 4 8; do AHEAD=$a STEPS=6000 python3 tools/probes/e2e_trace.py 2>&1 | clean | tail -3; done
+    TRLDA_INDEX_THREADS=0 STEPS=3000 python3 tools/probes/e2e_trace.py 2>&1 | clean | tail -3 ) > $o/${tag}_e2e_trace.txt
+  cat $o/${tag}_index_rate.txt $o/${tag}_host_rates.txt $o/${tag}_e2e_trace.txt
+}
+
+t_lanes() {
+  ( for a in "--hostile 12" "--hostile 0" "--hostile 40" "--hostile 12 --lengths lognormal"; do
+      echo "== $a"; python3 tools/probes/lanes_hostile.py $a 2>&1 | clean; done
+    echo "== TRLDA_LANE_PRIORITY=0 --hostile 12   (lanes on the default priority, where torch's streams live)"
+    TRLDA_LANE_PRIORITY=0 python3 tools/probes/lanes_hostile.py --hostile 12 2>&1 | clean
+    echo "== TRLDA_LANE_PRIORITY=0 TRLDA_LANE_VERIFY=0 TRLDA_LANE_CALIBRATE=0 --hostile 12   (round 5's behaviour there)"
+    TRLDA_LANE_PRIORITY=0 TRLDA_LANE_VERIFY=0 TRLDA_LANE_CALIBRATE=0 python3 tools/probes/lanes_hostile.py --hostile 12 2>&1 | clean
+  ) > $o/${tag}_lanes_hostile.txt
+  ( echo "== tools/probes/two_streams.py x 6 process starts (round 5's failing case), the one-lane and two-lane lines"
+    for i in 1 2 3 4 5 6; do python3 tools/probes/two_streams.py 2>&1 | clean | tail -3 | head -2 | cut -c1-330; done
+    echo "== the same with TRLDA_LANE_VERIFY=0 TRLDA_LANE_CALIBRATE=0 (round 5's library)"
+    for i in 1 2; do TRLDA_LANE_VERIFY=0 TRLDA_LANE_CALIBRATE=0 python3 tools/probes/two_streams.py 2>&1 | clean | tail -3 | head -2 | cut -c1-330; done
+  ) > $o/${tag}_lanes_two_streams.txt
+  cat $o/${tag}_lanes_hostile.txt $o/${tag}_lanes_two_streams.txt
+}
+
 t_fuzz() {
   ( for sd in 401 402; do timeout 1200 python tests/fuzz_estep.py --cases 120 --seed $sd 2>&1 | tail -1; done
     for sd in 501 502; do timeout 1500 python tests/fuzz_update.py --cases 120 --seed $sd 2>&1 | tail -1; done
@@ -166,6 +198,6 @@ t_fuzz() {
 }
 
 for t in $targets; do
-  if [ $t = core ]; then set -- check headline pmc configs updates dp stamps lengths deferred; else set -- $t; fi
+  if [ $t = core ]; then set -- check headline pmc configs updates dp stamps lengths deferred ingest lanes; else set -- $t; fi
   for u in "$@"; do echo "#### $u"; t_$u; done
 done
