@@ -835,6 +835,44 @@ def main():
                                     "before its E-step, announced two steps before it -> E-step -> "
                                     "trlda_batch_destroy four steps after it; one Python thread drives it",
                             "host_threads": 1 + int(os.environ.get("TRLDA_INDEX_THREADS", "4"))}
+        # ... and the same pass as ONE library call (trlda_model_estep_corpus: the loop over the
+        # mini-batches inside the library, no Python between the steps): the corpus' CSR arrays in
+        # host memory, gamma0 / gamma for all of it on the device, a ring of four statistics arrays
+        try:
+            n_c = min(nb, max(args.steps, 1))
+            offs = np.zeros(n_c * B + 1, dtype=np.int64)
+            at = 0
+            for i in range(n_c):
+                ip_ = csrs[i].indptr.astype(np.int64)
+                offs[i * B:(i + 1) * B + 1] = ip_ + at
+                at += int(ip_[-1])
+            ids_c = np.concatenate([csrs[i].ids for i in range(n_c)])
+            cnts_c = np.concatenate([csrs[i].cnts for i in range(n_c)])
+            g0_c = torch.cat([gamma0s[i] for i in range(n_c)]).contiguous()
+            g_c = torch.empty_like(g0_c)
+            ring_t = [torch.empty(KV, dtype=torch.float64, device=device) for _ in range(4)]
+            ring = (C.c_void_p * 4)(*[t_.data_ptr() for t_ in ring_t])
+
+            def corpus_run():
+                fence()
+                t0 = time.perf_counter()
+                _ffi.check(L.trlda_model_estep_corpus(model, n_c * B, offs.ctypes.data, ids_c.ctypes.data,
+                                                      cnts_c.ctypes.data, B, g0_c.data_ptr(), g_c.data_ptr(), ring,
+                                                      4, args.max_iter, args.threshold, None))
+                fence()
+                return time.perf_counter() - t0
+            corpus_run()
+            s_c = sorted(corpus_run() for _ in range(max(1, args.repeats)))
+            value_end_to_end["one_call"] = {
+                "value": round(B * n_c / s_c[len(s_c) // 2], 1), "unit": "docs/s", "mini_batches": n_c,
+                "ms_per_step": round(1e3 * s_c[len(s_c) // 2] / n_c, 5),
+                "what": "trlda_model_estep_corpus: the same pass over %d mini-batches from one CSR corpus in host "
+                        "memory, the loop inside the library" % n_c}
+            del g0_c, g_c, ring_t
+            _ffi.check(L.trlda_model_set_deferred_stats(model, int(deferred)))
+            _ffi.check(L.trlda_model_set_stream_lanes(model, lanes[0]))
+        except Exception as exc:                      # noqa: BLE001
+            value_end_to_end["one_call"] = {"error": repr(exc)[:200]}
         for i in range(4):
             step(pos[0] + i)
         pos[0] += 4

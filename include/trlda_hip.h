@@ -335,6 +335,23 @@ int trlda_model_estep_io_ahead(trlda_model *model, const trlda_batch *batch,
                                const trlda_batch *const *upcoming, int n_upcoming,
                                const double *gamma0_dev, double *gamma_dev, double *sstats_dev,
                                int max_iter, double threshold, int32_t *iters_dev);
+/* A corpus pass in ONE call (round 6): LDA::updateVariablesVI (src/lda.cpp:160-220) on an unchanged
+ * lambda for every mini-batch of a corpus whose documents lie in HOST memory in CSR form -- `offsets`
+ * (n_docs + 1, as trlda_docs_offsets), `ids`, `cnts`; mini-batch i = documents [i * batch_size,
+ * min((i + 1) * batch_size, n_docs)) -- the reference's Python loop over do_e_step
+ * (python/src/ldainterface.cpp:311-390) with the loop inside the library: batches are made four ahead
+ * of their E-step (trlda_batch_create: index and upload on the worker threads), announced two ahead,
+ * stepped through deferred statistics and two lanes (both switched on for the call and put back),
+ * destroyed four steps later.  gamma0_dev / gamma_dev: K x n_docs on the device (a document's K
+ * values contiguous; gamma0 is only read); the statistics of mini-batch i go to
+ * sstats_ring[i % n_ring] (K x V each, n_ring >= 3: whoever wants every batch's statistics passes as
+ * many arrays as there are batches); iters_dev: n_docs counts, or NULL.  Everything is complete on
+ * the model's stream when the call returns (enqueued: trlda_model_synchronize to wait).  Bitwise the
+ * results of the loop of trlda_model_estep_io calls. */
+int trlda_model_estep_corpus(trlda_model *model, int64_t n_docs, const int64_t *offsets,
+                             const int32_t *ids, const int32_t *cnts, int batch_size,
+                             const double *gamma0_dev, double *gamma_dev, double *const *sstats_ring,
+                             int n_ring, int max_iter, double threshold, int32_t *iters_dev);
 long long trlda_model_lane_steps(const trlda_model *model);
 /* What became of the lanes: 0 none made yet (they are made by the first call that goes through them);
  * 2 two lanes on streams that were SEEN to run side by side with each other and with the model's stream

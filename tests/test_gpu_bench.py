@@ -72,6 +72,7 @@ def test_bench_line_contract(hip_lib):
     # work inclusive -- reported beside the headline, below it, and tagged with the threads it used
     e2e = j["value_end_to_end"]
     assert 0 < e2e["value"] <= j["value"] * 1.02 and e2e["host_threads"] >= 1 and "trlda_batch_create" in e2e["what"]
+    assert 0 < e2e["one_call"]["value"] <= j["value"] * 1.02 and e2e["one_call"]["mini_batches"] == 10
     assert j["mode"]["deferred_stats"] is True and j["mode"]["lanes"] == 2 and j["mode"]["pipelined"] is True
     assert j["repeats"]["n"] == 3 and j["repeats"]["ms_per_step_min"] <= j["ms_per_step"] <= \
         j["repeats"]["ms_per_step_max"]

@@ -153,3 +153,50 @@ def test_used_at_once_or_after_a_while_the_same_e_step(hip, oracle):
     for b in early:
         b.close()
     m.close()
+
+
+def test_a_corpus_pass_in_one_call(hip, oracle):
+    """trlda_model_estep_corpus: a CSR corpus in host memory, the loop over its mini-batches inside the
+    library (batches made four ahead on the worker threads, deferred statistics, two lanes) -- gamma,
+    iteration counts and every mini-batch's statistics bitwise those of a Python loop of do_e_step
+    (python/src/ldainterface.cpp:311-390), a ragged last batch, a ring of statistics arrays shorter
+    than the corpus; and against the oracle."""
+    import torch
+    from trlda_amd.documents import CSRDocuments
+    from trlda_amd.models import OnlineLDA
+    from trlda_amd.stream import corpus_pass
+    from trlda_amd.utils.synthetic import make_corpus
+    sampler = HipSampler(hip)
+    K, V, N, BS = 100, 3000, 1130, 200
+    lam = seeded_lambda(sampler, 14, K, V)
+    m = OnlineLDA.__new__(OnlineLDA)
+    m._num_documents, m._update_count = 1000, 0
+    m._ada_tau, m._ada_rho, m._ada_sq_norm = 1000., 1e-3, 1.
+    m._setup(V, K, .1, .3, None, _lambda=lam)
+    ip, ii, cc = make_corpus(N, V, seed=77, mean_unique=70)
+    g0 = seeded_gamma(sampler, 15, K, N)
+    dev = torch.device("cuda", 0)
+    g0_d = torch.from_numpy(np.ascontiguousarray(g0.T)).to(dev)
+    nb = (N + BS - 1) // BS
+    for n_ring in (nb, 3):
+        gam = torch.full((N, K), float("nan"), dtype=torch.float64, device=dev)
+        its = torch.full((N,), -1, dtype=torch.int32, device=dev)
+        ring = [torch.full((V, K), float("nan"), dtype=torch.float64, device=dev) for _ in range(n_ring)]
+        corpus_pass(m, ip.astype(np.int64), ii, cc, BS, g0_d, gam, ring, max_iter=20, iterations=its)
+        from trlda_amd import _ffi
+        _ffi.check(hip.trlda_model_synchronize(m._handle))
+        got_g = gam.cpu().numpy().T
+        got_it = its.cpu().numpy()
+        for b in range(nb):
+            lo, hi = b * BS, min(N, (b + 1) * BS)
+            docs = CSRDocuments(ip[lo:hi + 1] - ip[lo], ii[ip[lo]:ip[hi]], cc[ip[lo]:ip[hi]])
+            g, s, it = m.update_variables(docs, latents=g0[:, lo:hi], max_iter=20, return_iterations=True)
+            assert np.array_equal(got_g[:, lo:hi], g) and np.array_equal(got_it[lo:hi], it), (n_ring, b)
+            if n_ring == nb or b >= nb - 3:            # (a ring of three holds the last three batches)
+                assert np.array_equal(ring[b % n_ring].cpu().numpy().T, s), (n_ring, b)
+    go, so, ito = oracle.estep(lam, .1, (ip[:BS + 1]).astype(np.int32), ii[:ip[BS]], cc[:ip[BS]], g0[:, :BS], 20, 1e-3)
+    assert relerr(got_g[:, :BS], go) < 1e-9 and np.array_equal(got_it[:BS], ito)
+    # arguments: fewer than three arrays, a NULL among them
+    with pytest.raises(ValueError):
+        corpus_pass(m, ip.astype(np.int64), ii, cc, BS, g0_d, gam, ring[:2])
+    m.close()

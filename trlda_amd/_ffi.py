@@ -98,6 +98,8 @@ _SIGNATURES = {
     "trlda_model_set_stream_lanes": (C.c_int, [vp, C.c_int]),
     "trlda_model_estep_io_ahead": (C.c_int, [vp, vp, C.POINTER(C.c_void_p), C.c_int, vp, vp, vp, C.c_int,
                                              C.c_double, vp]),
+    "trlda_model_estep_corpus": (C.c_int, [vp, C.c_int64, vp, vp, vp, C.c_int, vp, vp, C.POINTER(C.c_void_p),
+                                           C.c_int, C.c_int, C.c_double, vp]),
     "trlda_model_lane_steps": (C.c_longlong, [vp]),
     "trlda_model_get_lane_timing": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "trlda_model_estep_host": (C.c_int, [vp, vp, f64p, f64p, C.c_int, C.c_double, vp]),

@@ -4223,6 +4223,67 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
     return TRLDA_OK;
 }
 
+int trlda_model_estep_corpus(trlda_model *m, int64_t n_docs, const int64_t *offsets, const int32_t *ids,
+                             const int32_t *cnts, int batch_size, const double *gamma0_dev, double *gamma_dev,
+                             double *const *sstats_ring, int n_ring, int max_iter, double threshold,
+                             int32_t *iters_dev)
+{
+    int rc = check_model(m);
+    if (rc)
+        return rc;
+    if (n_docs < 0 || batch_size <= 0 || !offsets || !sstats_ring || n_ring < 3 ||
+        (n_docs > 0 && (!gamma0_dev || !gamma_dev)))
+        return fail(TRLDA_ERR_ARG, "corpus pass: NULL arrays, a batch size <= 0 or fewer than three statistics arrays");
+    for (int r = 0; r < n_ring; ++r)
+        if (!sstats_ring[r])
+            return fail(TRLDA_ERR_ARG, "corpus pass: a NULL statistics array");
+    const int64_t n_batches = (n_docs + batch_size - 1) / batch_size;
+    constexpr int kAhead = 4, kBehind = 4;
+    const bool was_deferred = m->deferred_stats;
+    const int was_lanes = m->lanes_wanted;
+    m->deferred_stats = true;
+    m->lanes_wanted = 2;
+    std::vector<trlda_batch *> batch((size_t)n_batches, nullptr);
+    std::vector<int32_t> indptr;
+    auto make = [&](int64_t i) {
+        const int64_t d0 = i * batch_size, d1 = std::min<int64_t>(n_docs, d0 + batch_size);
+        indptr.resize((size_t)(d1 - d0) + 1);
+        for (int64_t d = d0; d <= d1; ++d) {
+            const int64_t at = offsets[d] - offsets[d0];
+            if (at < 0 || at > INT32_MAX)
+                return fail(TRLDA_ERR_ARG, "corpus pass: offsets must not decrease, a mini-batch holds < 2^31 entries");
+            indptr[(size_t)(d - d0)] = (int32_t)at;
+        }
+        return trlda_batch_create(&batch[(size_t)i], m->device, m->V, (int)(d1 - d0), indptr.data(),
+                                  ids ? ids + offsets[d0] : nullptr, cnts ? cnts + offsets[d0] : nullptr);
+    };
+    for (int64_t i = 0; !rc && i < std::min<int64_t>(kAhead, n_batches); ++i)
+        rc = make(i);
+    for (int64_t i = 0; !rc && i < n_batches; ++i) {
+        if (i + kAhead < n_batches)
+            rc = make(i + kAhead);
+        const trlda_batch *up[2] = {i + 1 < n_batches ? batch[(size_t)i + 1] : nullptr,
+                                    i + 2 < n_batches ? batch[(size_t)i + 2] : nullptr};
+        const int n_up = (up[0] != nullptr) + (up[0] && up[1]);
+        const size_t at = (size_t)i * (size_t)batch_size;
+        if (!rc)
+            rc = trlda_model_estep_io_ahead(m, batch[(size_t)i], up, n_up, gamma0_dev + at * m->K,
+                                            gamma_dev + at * m->K, sstats_ring[i % n_ring], max_iter, threshold,
+                                            iters_dev ? iters_dev + at : nullptr);
+        if (i >= kBehind) {                          // (its statistics rode on launch i - 2)
+            (void)trlda_batch_destroy(batch[(size_t)(i - kBehind)]);
+            batch[(size_t)(i - kBehind)] = nullptr;
+        }
+    }
+    const int rc_flush = check_model(m);             // flushes, joins the lanes: all of it on the model's stream
+    for (trlda_batch *b : batch)
+        if (b)
+            (void)trlda_batch_destroy(b);
+    m->deferred_stats = was_deferred;
+    m->lanes_wanted = was_lanes;
+    return rc ? rc : rc_flush;
+}
+
 int trlda_model_set_prefetch(trlda_model *m, int enabled)
 {
     if (!m)

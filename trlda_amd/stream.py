@@ -23,7 +23,7 @@ import ctypes as C
 
 from . import _ffi
 
-__all__ = ["EStepStream"]
+__all__ = ["EStepStream", "corpus_pass"]
 
 
 def _address(x, what="array", numel=None, dtype="float64", device=None):
@@ -117,3 +117,32 @@ class EStepStream(object):
         except Exception:
             pass
         return False
+
+
+def corpus_pass(model, offsets, ids, cnts, batch_size, gamma0, gamma, sstats_ring, max_iter=100,
+                threshold=1e-3, iterations=None):
+    """The same pass from documents in HOST memory, the loop inside the library
+    (``trlda_model_estep_corpus``, include/trlda_hip.h): ``offsets`` (int64, n_docs + 1), ``ids``,
+    ``cnts`` (int32) are one CSR corpus -- what ``load_documents_csr`` / ``trlda_docs_from_text`` hand
+    out; mini-batch i is documents [i * batch_size, (i + 1) * batch_size).  ``gamma0`` / ``gamma``:
+    K x n_docs on the device; the statistics of mini-batch i go to ``sstats_ring[i % len(sstats_ring)]``
+    (at least three K x V device arrays).  Batches are indexed and uploaded by the library's worker
+    threads four steps ahead of their E-step.  Returns when everything is enqueued; the results
+    are complete on the model's stream (``model.lambdas`` or ``EStepStream.synchronize`` wait)."""
+    import numpy as np
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    cnts = np.ascontiguousarray(cnts, dtype=np.int32)
+    n_docs = len(offsets) - 1
+    if n_docs < 0 or len(ids) != offsets[-1] or len(cnts) != offsets[-1]:
+        raise TypeError("offsets / ids / cnts do not describe one CSR corpus.")
+    if len(sstats_ring) < 3:
+        raise ValueError("at least three statistics arrays (two E-steps are in flight).")
+    K, V = model.num_topics, model.num_words
+    dev = getattr(model, "_device", None)
+    ring = (C.c_void_p * len(sstats_ring))(*[_address(s, "sstats", K * V, device=dev) for s in sstats_ring])
+    _ffi.check(_ffi.lib().trlda_model_estep_corpus(
+        model._handle, n_docs, offsets.ctypes.data, ids.ctypes.data, cnts.ctypes.data, int(batch_size),
+        _address(gamma0, "gamma0", K * n_docs, device=dev), _address(gamma, "gamma", K * n_docs, device=dev),
+        ring, len(sstats_ring), int(max_iter), float(threshold),
+        _address(iterations, "iterations", n_docs, dtype="int32", device=dev)))
