@@ -5,6 +5,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <mutex>
 #include <thread>
 #include <unistd.h>
@@ -158,7 +159,11 @@ struct WorkQueue::Impl {
                     // (a stream of jobs a few microseconds apart: look again for a while before going
                     // to sleep -- waking a sleeper is a system call on the submitter's thread)
                     lock.unlock();
-                    const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(150);
+                    static const int spin_us = [] {
+                        const char *e = std::getenv("TRLDA_QUEUE_SPIN_US");
+                        return e ? std::atoi(e) : 150;
+                    }();
+                    const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us);
                     while (pending_.load(std::memory_order_acquire) == 0 && std::chrono::steady_clock::now() < until)
                         cpu_relax();
                     lock.lock();
