@@ -361,9 +361,9 @@ long long trlda_model_lane_steps(const trlda_model *model);
  * on the other); 1 the lanes were given up -- no such pair was to be had, or the MEASUREMENT said so:
  * after 96 steps through the lanes one launch of a lane and the four that follow it are timed on the
  * device; two launches in flight means a launch LASTS about two steps (51 us where one starts every
- * 26), lanes that do not overlap have launches of one step's length, and below 1.4 launches in
- * flight the lanes are dropped -- the stream of calls goes one launch at a time, as without the
- * switch; 3 two lanes, not looked at (TRLDA_LANE_VERIFY=0).  trlda_model_lane_timing: what the
+ * 26), lanes that do not overlap have launches of one step's length; below 1.0 launches in flight
+ * the lanes are dropped -- the stream of calls goes one launch at a time, as without the switch --
+ * from 1.4 on they are kept, in between the measurement is repeated (at most eight times); 3 two lanes, not looked at (TRLDA_LANE_VERIFY=0).  trlda_model_lane_timing: what the
  * measurement found, microseconds (0: not measured yet). */
 int trlda_model_lane_state(const trlda_model *model);
 int trlda_model_lane_timing(const trlda_model *model, double *us_per_launch, double *us_per_step);
