@@ -209,6 +209,15 @@ int trlda_model_set_doc_threads(trlda_model *model, int threads);
 #define TRLDA_DOCS_AUTO 0
 #define TRLDA_DOCS_GENERAL 1
 #define TRLDA_DOCS_WIDE 2
+/* K <= 32 (even), every document <= 128 words: a WAVE per document, eight documents per workgroup, no
+ * LDS or barrier inside the fixed point (csrc/estep_kernels.h, estep_docs_small_body; round 6).  A
+ * throughput form -- a document takes 46-55 us on one wave against 30 on eight, but a CU holds eight
+ * of them: the default for batches of more documents than the device has CUs (K = 10, 6400 documents:
+ * 38.5 against 9.7 M docs/s); _SMALL asks for it at any batch size, _REG for the
+ * workgroup-per-document body of K <= 128.  Both leave everything around the body (fused preamble,
+ * merged / deferred statistics, lanes) alone. */
+#define TRLDA_DOCS_SMALL 3
+#define TRLDA_DOCS_REG 4
 int trlda_model_set_doc_kernel(trlda_model *model, int kind);
 /* name (as a profiler lists it, without template arguments) of the document kernel that
  * took most documents of the model's last E-step; "" before the first */

@@ -483,8 +483,11 @@ def test_four_hundred_steps_through_two_lanes(hip, sampler):
     assert state in (1, 2) and (through == N if state == 2 else 96 <= through < N), (state, through)
     launch, stepus = C.c_double(), C.c_double()
     _ffi.check(hip.trlda_model_lane_timing(m._handle, C.byref(launch), C.byref(stepus)))
-    assert 5. < launch.value < 1000. and 5. < stepus.value < 500., (launch.value, stepus.value)
-    assert (launch.value >= 1.0 * stepus.value) == (state == 2)
+    if launch.value > 0:                             # (0: every window was host-bound -- no verdict, lanes kept)
+        assert 5. < launch.value < 1000. and 5. < stepus.value < 500., (launch.value, stepus.value)
+        assert (launch.value >= 1.0 * stepus.value) == (state == 2)
+    else:
+        assert state == 2
     _ffi.check(hip.trlda_model_synchronize(m._handle))
     got = {(N - 1) & 1: outs[(N - 1) & 1].read(), (N - 2) & 1: outs[(N - 2) & 1].read()}
     _ffi.check(hip.trlda_model_set_stream_lanes(m._handle, 1))
@@ -549,7 +552,8 @@ def test_lanes_that_do_not_pay_are_given_up(hip, sampler, monkeypatch):
     g0s = [seeded_gamma(sampler, 310 + i, K, B) for i in range(5)]
     N, S = 200, 20
     ref, _ = run_stream(hip, K, V, lam, csrs, g0s, [q % 5 for q in range(S)], lanes=1, deferred=0, announce=0)
-    for bar, want_state in (("100", 1), ("0", 2)):
+    monkeypatch.setenv("TRLDA_LANE_CAL_HOST_SHARE", "1e9")   # (this loop reads arrays back between calls: its
+    for bar, want_state in (("100", 1), ("0", 2)):           #  windows would otherwise count as host-bound)
         monkeypatch.setenv("TRLDA_LANE_CAL_MIN_IN_FLIGHT", bar)
         m = make_model(K, V, lam)
         dev = [m.upload(c) for c in csrs]

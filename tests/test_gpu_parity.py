@@ -989,3 +989,54 @@ print("RCCL1-OK")
 """ % ROOT_DIR)
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
     assert "RCCL1-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("K,V,B,mean", [(10, 1000, 100, 60), (20, 300, 64, 40), (32, 2000, 37, 100), (2, 50, 9, 6),
+                                        (16, 500, 200, 120), (10, 1000, 700, 50)])
+def test_a_wave_per_document_at_small_k(hip, oracle, K, V, B, mean):
+    """Round 6: at K <= 32 a document is one WAVE -- rows in registers, the sums over
+    the words by a transposing butterfly, no LDS or barrier inside the fixed point
+    (estep_docs_small_body; lda.cpp:174-204).  Against the oracle at 1e-9 with identical iteration
+    counts, against the workgroup-per-document body (TRLDA_DOCS_REG) at 1e-12 with identical
+    counts, with early exits (max_iter 60), through plain E-steps, an update loop (merged launches)
+    and a fixed-lambda stream (deferred statistics, two lanes)."""
+    import trlda_amd
+    from trlda_amd import _ffi
+    from trlda_amd.documents import CSRDocuments
+    from trlda_amd.utils.synthetic import make_corpus
+    lens = np.clip(np.random.RandomState(K).poisson(mean, B), 0, 128)
+    lens[:3] = [0, 1, 128]
+    ip, ii, cc = make_corpus(B, V, seed=5 + K, mean_unique=mean, lengths=np.minimum(lens, V))
+    docs = CSRDocuments(ip, ii, cc)
+    lam = seeded_lambda(oracle, 31 + K, K, V)
+    g0 = seeded_gamma(oracle, 32 + K, K, B)
+    out = {}
+    for kind, name in ((3, "small"), (4, "reg")):
+        m = make_model(K, V, lam, D=5000)
+        _ffi.check(hip.trlda_model_set_doc_kernel(m._handle, kind))
+        g, s, it = m.update_variables(docs, latents=g0, max_iter=60, return_iterations=True)
+        used = hip.trlda_model_last_doc_kernel(m._handle)
+        used = used.decode() if isinstance(used, bytes) else used
+        assert ("small" in used) == (name == "small"), used
+        trlda_amd.seed(77)
+        m.update_parameters(docs, max_iter_tr=3, max_iter_inference=20)
+        m.update_parameters(docs, max_iter_tr=0, max_iter_inference=20)
+        out[name] = (g, s, it, m.lambdas)
+        m.close()
+    go, so, ito = oracle.estep(lam, .1, ip, ii, cc, g0, 60, 1e-3)
+    g, s, it, lam_s = out["small"]
+    assert np.array_equal(it, ito) and (it < 60).any()
+    assert relerr(g, go) < TIGHT_RTOL
+    check_sstats(s, so)
+    gr, sr, itr, lam_r = out["reg"]
+    assert np.array_equal(it, itr) and relerr(g, gr) < 1e-12 and relerr(lam_s, lam_r) < 1e-9
+    # the default: a wave per document where the batch has more documents than the device has CUs
+    m = make_model(K, V, lam, D=5000)
+    g_d, _, it_d = m.update_variables(docs, latents=g0, max_iter=60, return_iterations=True)
+    used = hip.trlda_model_last_doc_kernel(m._handle)
+    used = used.decode() if isinstance(used, bytes) else used
+    assert ("small" in used) == (B > 256), (B, used)
+    assert np.array_equal(g_d, g if B > 256 else gr) and np.array_equal(it_d, it)
+    m.close()
+    nz = sr > 0
+    assert relerr(s[nz], sr[nz]) < 1e-11 and np.array_equal(s == 0, sr == 0)

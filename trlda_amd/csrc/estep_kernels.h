@@ -661,6 +661,7 @@ struct DocKernelArgs {
     int block0;                           // workgroups of the grid in front of the documents (a merged
                                           // launch's topic-factor workgroups come FIRST, so that nothing
                                           // a document waits for can be queued behind it); else 0
+    int docs_per_wg;                      // 1; 8: a WAVE per document (estep_docs_small_body, K <= 32)
 };
 
 // the document workgroup's index among the launch's document workgroups
@@ -1679,6 +1680,157 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
     TRLDA_STAMP_FLUSH;
 }
 
+// ---------------------------------------------------------------------------
+// K <= 32 (round 6): a WAVE per document, eight documents per workgroup.
+//
+// The register body above spends a document's 27 us on 20 x (four barriers, three LDS round trips,
+// exp(psi) on two of eight waves): none of it shrinks with K -- at K = 10 or 20 (the reference's own
+// tests, onlinelda_test.py:39-68; BASELINE config 1) 54 or 44 of a product's 64 topic lanes idle and
+// the document takes as long as at K = 128.  With few topics a document fits ONE wave, and a wave
+// needs neither LDS nor barriers inside the loop:
+//   * lane l holds the exp(psi(lambda)) rows of words l and l + 64 (K doubles each, in registers);
+//   * phinorm_j = sum_k e_k u_jk: 2 K fmas per lane, e_k handed out by v_readlane (a scalar operand);
+//   * acc_k = sum_j tw_j u_jk: per lane tw_l u_lk + tw_(l+64) u_(l+64)k, then ONE transposing
+//     butterfly over the 32 topic vectors (fold<32> .. fold<1>: 16 + 8 + 4 + 2 + 1 + 1 steps) -- lane l
+//     ends with the total of topic l >> 1;
+//   * gamma, exp(psi(gamma)) and the change sum live in those lanes (each topic twice).
+// The fixed point, its break test (sum |gamma - last| < threshold K, strict) and what is left behind
+// -- gamma, c_k exp(psi(gamma)) rows, cnt / phinorm in word-major order, iteration counts -- are the
+// register body's (lda.cpp:174-204); the sums are taken in another order (butterfly instead of eight
+// partials), so the results agree to rounding, the iteration counts in every test.  The topic factors
+// of the fused preamble are formed once per workgroup by the same code as above.  Every document of
+// the launch has at most 128 words (the host checks); a.docs_per_wg = 8.
+__device__ __forceinline__ void estep_docs_small_body(const DocKernelArgs &a, double *lds)
+{
+    constexpr int T = kRegThreads, KM = 32;
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wid = __builtin_amdgcn_readfirstlane(tid / kWave);
+    const int K = a.K;
+    double pv[2][8];
+    if (a.partial && !a.scale_in)                    // launch-uniform
+        topic_scale_load<T>(K, a.G, a.partial, pv);
+
+    const int bid = doc_block(a);
+    const int di = bid * 8 + wid;                    // this wave's document, in the batch's sorted order
+    const bool doc_on = di < a.B;                    // wave-uniform
+    const int dc = min(di, a.B - 1);
+    const int4 meta = reinterpret_cast<const int4 *>(a.pad_meta)[dc];
+    const int32_t *__restrict__ pids = a.pad_ids + (size_t)dc * kRegMaxN;
+    const int id0 = pids[lane], id1 = pids[64 + lane];
+    const int d = meta.x, n = doc_on ? meta.y : 0, p0 = meta.z;
+    const int kt = lane >> 1;                        // this lane's topic (lanes 2 k and 2 k + 1: topic k)
+    const bool k_on = kt < K;
+    const int kc = k_on ? kt : 0;
+    double g = a.gamma_in[(size_t)d * K + kc];
+    const double ak = a.alpha[kc];
+    const double cnt0 = lane < n ? (double)a.cnts[p0 + lane] : 0.0;
+    const double cnt1 = lane + 64 < n ? (double)a.cnts[p0 + 64 + lane] : 0.0;
+    double ck0 = 1.0;
+    if (tid < K && a.scale_in && !a.scale_wait) {    // finished by the launch that prepared them
+        ck0 = a.scale_in[2 * K + tid];
+        if (bid == 0 && a.scale_out) {
+            a.scale_out[tid] = a.scale_in[tid];
+            a.scale_out[K + tid] = a.scale_in[K + tid];
+            a.scale_out[2 * K + tid] = ck0;
+        }
+    }
+    // the rows: K contiguous doubles per word (K is even: 16-byte loads), zero past the document's end
+    double u0[KM], u1[KM];
+    {
+        const double *r0 = a.eeb + (size_t)id0 * K, *r1 = a.eeb + (size_t)id1 * K;
+        const bool on0 = lane < n, on1 = lane + 64 < n;
+#pragma unroll
+        for (int k = 0; k < KM; k += 2) {
+            double2 v0 = make_double2(0.0, 0.0), v1 = make_double2(0.0, 0.0);
+            if (k < K) {                             // launch-uniform
+                v0 = *reinterpret_cast<const double2 *>(r0 + k);
+                v1 = *reinterpret_cast<const double2 *>(r1 + k);
+            }
+            u0[k] = on0 ? v0.x : 0.0; u0[k + 1] = on0 ? v0.y : 0.0;
+            u1[k] = on1 ? v1.x : 0.0; u1[k + 1] = on1 ? v1.y : 0.0;
+        }
+    }
+    // topic factors: once per workgroup, the register body's code (bitwise its c)
+    double *part = lds, *c_l = lds + 8 * 128;
+    if (a.partial && !a.scale_in)
+        topic_scale_partials<T>(K, a.G, pv, part);
+    __syncthreads();
+    if (tid < K) {
+        double ck = 1.0;
+        if (a.partial)
+            ck = a.scale_in ? (a.scale_wait ? scale_wait_load(a, K, tid) : ck0)
+                            : topic_scale_combine(K, tid, part, a.scale_out);
+        c_l[tid] = ck;
+    }
+    __syncthreads();
+    if (!doc_on)                                     // (a wave without a document: it meets the others at the
+        return;                                      //  barriers behind the body)
+    const double ck = c_l[kc];
+    double e = k_on ? exp_digamma(g) * ck : 0.0;     // e is kept as c_k exp(psi(gamma_k)) throughout
+    const int elo0 = 0;
+    (void)elo0;
+    double tw0 = 0.0, tw1 = 0.0;
+    auto weights = [&]() {                           // tw_j = cnt_j / (sum_k e_k u_jk + 1e-100)   lda.cpp:183 / :199
+        const int lo = __double2loint(e), hi = __double2hiint(e);
+        double s0[2] = {0.0, 0.0}, s1[2] = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+            if (k < K) {                             // launch-uniform
+                const double ek = __hiloint2double(__builtin_amdgcn_readlane(hi, 2 * k),
+                                                   __builtin_amdgcn_readlane(lo, 2 * k));
+                s0[k & 1] = fma(ek, u0[k], s0[k & 1]);
+                s1[k & 1] = fma(ek, u1[k], s1[k & 1]);
+            }
+        }
+        tw0 = cnt0 * rcp_pos<true>((s0[0] + s0[1]) + 1e-100);
+        tw1 = cnt1 * rcp_pos<true>((s1[0] + s1[1]) + 1e-100);
+    };
+    weights();
+    const double thresholdK = a.threshold * (double)K;
+    int it = 0;
+    while (it < a.max_iter) {                        // lda.cpp:185-204 (wave-uniform: no barrier inside)
+        // acc_k = sum_j tw_j u_jk: this lane's two words, then the transposing butterfly
+        double q16[16], q8[8], q4[4], q2[2];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const double pa = i < K ? fma(tw1, u1[i], tw0 * u0[i]) : 0.0;
+            const double pb = i + 16 < K ? fma(tw1, u1[i + 16], tw0 * u0[i + 16]) : 0.0;
+            q16[i] = fold<32>(pa, pb);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            q8[i] = fold<16>(q16[i], q16[i + 8]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            q4[i] = fold<8>(q8[i], q8[i + 4]);
+        q2[0] = fold<4>(q4[0], q4[2]);
+        q2[1] = fold<4>(q4[1], q4[3]);
+        const double q1 = fold<2>(q2[0], q2[1]);
+        const double acc = fold<1>(q1, q1);          // lane l: topic 16 b5 + 8 b4 + 4 b3 + 2 b2 + b1 = l >> 1
+        const double gnew = acc * e + ak;            // lda.cpp:193
+        const double enew = k_on ? exp_digamma(gnew) * ck : 0.0;
+        const double change_sum = wave_sum_dpp((k_on && !(lane & 1)) ? fabs(g - gnew) : 0.0);
+        g = gnew;
+        e = enew;
+        weights();
+        ++it;
+        if (change_sum < thresholdK)                 // lda.cpp:202-203: mean < threshold
+            break;
+    }
+    if (k_on && !(lane & 1)) {
+        a.gamma[(size_t)d * K + kt] = g;
+        merged_store(a.epg + (size_t)d * K + kt, e, a.done_counter != nullptr);
+    }
+    if (lane == 0 && a.iters_out)
+        a.iters_out[d] = it;
+    if (lane < n)
+        merged_store(a.tw_word + (a.wrank ? a.wrank[p0 + lane] : p0 + lane), tw0, a.done_counter != nullptr);
+    if (lane + 64 < n)
+        merged_store(a.tw_word + (a.wrank ? a.wrank[p0 + 64 + lane] : p0 + 64 + lane), tw1,
+                     a.done_counter != nullptr);
+}
+
 template <int MODE>
 __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelArgs a, PreArgs pre)
 {
@@ -1687,7 +1839,10 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_kernel(DocKernelAr
         docs_launch_preamble(pre, lds, (int)blockIdx.x);
         return;
     }
-    estep_docs_reg_body<MODE>(a, lds);
+    if (a.docs_per_wg == 8)                          // launch-uniform
+        estep_docs_small_body(a, lds);
+    else
+        estep_docs_reg_body<MODE>(a, lds);
 }
 
 // ---------------------------------------------------------------------------

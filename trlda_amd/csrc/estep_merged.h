@@ -641,7 +641,10 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_merged_kernel(DocK
         return;
     }
     merged_doc_stamp(mg, 0);
-    estep_docs_reg_body<MODE>(a, lds);
+    if (a.docs_per_wg == 8)                          // launch-uniform: a wave per document (K <= 32)
+        estep_docs_small_body(a, lds);
+    else
+        estep_docs_reg_body<MODE>(a, lds);
     merged_doc_stamp(mg, 1);
     docs_done_signal(a);
     merged_doc_stamp(mg, 2);
@@ -1306,7 +1309,10 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_reg_deferred_kernel(Do
         return;
     }
     DeferredStamp st(mg, 1024 + min(bid, 1023));
-    estep_docs_reg_body<MODE>(a, lds);
+    if (a.docs_per_wg == 8)                          // launch-uniform: a wave per document (K <= 32)
+        estep_docs_small_body(a, lds);
+    else
+        estep_docs_reg_body<MODE>(a, lds);
     st.end();
 }
 

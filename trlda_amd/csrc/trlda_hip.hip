@@ -363,6 +363,8 @@ struct trlda_model {
     int sstats_mode = TRLDA_SSTATS_SEGMENTED;
     int doc_threads = 0;
     int doc_kernel = 0;    // TRLDA_DOCS_*
+    int small_k = -1;      // a wave per document at K <= 32 (estep_docs_small_body): -1 where it applies, 0 never,
+                           // 1 asked for (trlda_model_set_doc_kernel(TRLDA_DOCS_SMALL / _REG); TRLDA_SMALL_K)
     const char *last_doc_kernel = "";   // kernel that took most documents of the last E-step
     bool last_preamble_fused = false;
     bool split_preamble = false;        // never fuse kernels 1 and 2 (tests, comparisons)
@@ -1588,7 +1590,16 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
     const size_t xcount_m = (size_t)db->n_xrows * (size_t)(max_iter + 1) * (size_t)K;
     const bool will_split = db->max_n > 128 && m->split_docs && db->n_wg > 0 && db->split_pays &&
                             max_iter > 0 && xcount_m * sizeof(double) <= ((size_t)256 << 20);
-    const int doc_wgs = will_split ? db->n_wg : B;
+    // K <= 32: a wave per document, eight documents per workgroup (estep_kernels.h, estep_docs_small_body).
+    // A throughput form: a lone wave takes 46-55 us for a document the eight-wave body finishes in 30, but a
+    // CU holds eight such documents -- taken where the documents would not fit the chip one per CU
+    // (K = 10: 512 documents 15.4 against 8.4 M docs/s, 6400 documents 38.5 against 9.7 M; 100
+    // documents 3.7 against 5.6 M: profiles/r06_small_k.txt), or when asked for
+    int cus_now = 256;
+    (void)hipDeviceGetAttribute(&cus_now, hipDeviceAttributeMultiprocessorCount, m->device);
+    const bool small = (m->small_k > 0 || (m->small_k < 0 && B > cus_now)) && K <= 32 && K % 2 == 0 && B > 0 &&
+                       db->max_n <= 128 && !atomic && m->doc_threads == 0 && m->doc_kernel == TRLDA_DOCS_AUTO;
+    const int doc_wgs = small ? (B + 7) / 8 : will_split ? db->n_wg : B;
     // (... a matter of speed: the helpers run UNDER the documents only when the documents leave
     // CUs free -- a document workgroup fills one.  Safety does not depend on it: estep_merged.h)
     int cus = 256;
@@ -1797,6 +1808,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         a.scale_in = fused_big ? m->psi_sum : prefetched ? m->scale_pp[cur_buf] : nullptr;
         a.done_counter = nullptr; a.scale_wait = nullptr; a.done_target = 0;
         a.go_flags = nullptr; a.n_go = 0; a.block0 = 0;
+        a.docs_per_wg = small ? 8 : 1;
         a.epoch = m->merged_epoch + 1u;              // (of this launch, if it turns out to be merged)
         if (comb) {                                  // finished by workgroups of this launch
             a.scale_in = m->scale_comb;
@@ -1910,7 +1922,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
             // per-workgroup layout; one row of K doubles per (segment, iteration), NaN before
             // the launch.  Not with an exchange buffer beyond 256 MB (max_iter in the thousands):
             // those batches keep one workgroup per document.
-            int n_wgs = n_reg;                                   // document workgroups of the launch
+            int n_wgs = small ? (n_reg + 7) / 8 : n_reg;        // document workgroups of the launch
             const size_t xcount = (size_t)db->n_xrows * (size_t)(max_iter + 1) * (size_t)K;
             if (tiered && m->split_docs && db->n_wg > 0 && db->split_pays && max_iter > 0 &&
                 xcount * sizeof(double) <= ((size_t)256 << 20)) {
@@ -1927,7 +1939,9 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                 n_wgs = db->n_wg;
             }
             const bool split = a.meta_i4 == 2;
-            m->last_split_wgs = n_wgs - n_reg;
+            m->last_split_wgs = small ? 0 : n_wgs - n_reg;
+            if (small)
+                m->last_doc_kernel = "estep_docs_small_body";
             int lds_rows = 0;
             size_t lds_bytes = kRegLdsBytes;
             // (LDS rows only for what the single-orientation body cannot hold in registers:
@@ -3427,6 +3441,8 @@ int model_create(trlda_model **out, int device, int K, int V, int stream_priorit
         trlda_model_destroy(m);
         return rc;
     }
+    if (const char *env = std::getenv("TRLDA_SMALL_K"))          // 0: never a wave per document (A/B)
+        m->small_k = env[0] == '0' ? 0 : -1;
     if (const char *env = std::getenv("TRLDA_AUX_DECAY"))        // 0: the streaming kernel behind the launch
         m->aux_decay = env[0] != '0';
     if (const char *env = std::getenv("TRLDA_DRAW_AHEAD")) {     // 0 / 1 / 2: trlda_model_set_draw_ahead
@@ -3592,8 +3608,17 @@ int trlda_model_set_doc_kernel(trlda_model *m, int kind)
 {
     if (!m)
         return fail(TRLDA_ERR_ARG, "null model");
+    if (kind == TRLDA_DOCS_SMALL || kind == TRLDA_DOCS_REG) {
+        // (the choice between the two bodies of the K <= 128 launch forms: everything around them --
+        // fused preamble, merged / deferred statistics, lanes -- stays as it is)
+        m->small_k = kind == TRLDA_DOCS_SMALL ? 1 : 0;
+        m->doc_kernel = TRLDA_DOCS_AUTO;
+        return TRLDA_OK;
+    }
     if (kind != TRLDA_DOCS_AUTO && kind != TRLDA_DOCS_GENERAL && kind != TRLDA_DOCS_WIDE)
-        return fail(TRLDA_ERR_ARG, "doc_kernel must be TRLDA_DOCS_AUTO, _GENERAL or _WIDE");
+        return fail(TRLDA_ERR_ARG, "doc_kernel must be TRLDA_DOCS_AUTO, _GENERAL, _WIDE, _SMALL or _REG");
+    if (kind == TRLDA_DOCS_AUTO)
+        m->small_k = -1;
     m->doc_kernel = kind;
     return TRLDA_OK;
 }
@@ -3963,6 +3988,7 @@ int lanes_ensure(trlda_model *m)
 void lane_follow(const trlda_model *m, trlda_model *l)
 {
     l->sstats_mode = m->sstats_mode; l->doc_threads = m->doc_threads; l->doc_kernel = m->doc_kernel;
+    l->small_k = m->small_k;
     l->split_preamble = m->split_preamble; l->dense_preamble = m->dense_preamble;
     l->pair_gathers = m->pair_gathers; l->prefetch_next = m->prefetch_next; l->split_docs = m->split_docs;
     l->merged_launch = m->merged_launch; l->split_long_lists = m->split_long_lists;
@@ -4129,7 +4155,10 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
             hipEventElapsedTime(&steps, cal.e[1], cal.e[2]) == hipSuccess && steps > 0.f) {
             cal.us_launch = 1e3f * launch;
             cal.us_step = 1e3f * steps / (2 * kLaneCalLaunches);
-            if (cal.host_us_step > 0.7f * cal.us_step) {     // the host did not keep the lanes fed: no verdict
+            // (TRLDA_LANE_CAL_HOST_SHARE: tests take every window for a verdict with 1e9)
+            const char *he = std::getenv("TRLDA_LANE_CAL_HOST_SHARE");
+            const float host_share = he ? (float)std::atof(he) : 0.7f;
+            if (cal.host_us_step > host_share * cal.us_step) {   // the host did not keep the lanes fed: no verdict
                 cal.phase = ++cal.tries > 8 ? 4 : 2;
                 cal.n = 0;
                 cal.us_launch = cal.us_step = 0.f;
