@@ -787,8 +787,8 @@ def main():
 
     # N = 1: the same stream of steps with NOTHING pre-uploaded: every mini-batch
     # starts as CSR arrays in host memory, goes through trlda_batch_create (validation + a copy on this
-    # thread; the word-major index and the upload on the library's worker threads) two steps before
-    # its E-step, and is destroyed four steps after it.  PCIe and host work inclusive: reported beside
+    # thread; the word-major index on the library's worker threads; its upload enqueued by this thread
+    # again, in a later call) eight steps before its E-step, and is destroyed four steps after it.  PCIe and host work inclusive: reported beside
     # `value`, never as it.
     value_end_to_end = None
     if not collective and prefetch and not args.headline_only and not args.no_end_to_end:
@@ -796,7 +796,7 @@ def main():
         fence()
         nb = args.num_batches
         window = {}
-        AHEAD = 4
+        AHEAD = 8
 
         def e2e_run(n_steps):
             first = pos[0]
@@ -806,8 +806,8 @@ def main():
                     window[i] = DeviceBatch(csrs[i % nb], V, local_rank)
             t0 = time.perf_counter()
             for i in range(first, first + n_steps):
-                # (made AHEAD steps before its E-step, announced two steps before it: the workers have
-                # two steps' time for its index -- an announced batch whose index is not there yet
+                # (made AHEAD steps before its E-step, announced two steps before it: an index is there
+                # ~170 us after its trlda_batch_create -- an announced batch whose index is not there yet
                 # counts as not announced)
                 window[i + AHEAD] = DeviceBatch(csrs[(i + AHEAD) % nb], V, local_rank)
                 upcoming[0] = window[i + 1].handle.value
@@ -822,16 +822,22 @@ def main():
             fence()
             return time.perf_counter() - t0
 
-        e2e_run(max(args.steps, 40))                                  # staging buffers, allocations, workers
-        s_e2e = sorted(e2e_run(args.steps) for _ in range(max(1, args.repeats)))
+        # (a stretch of at least 128 mini-batches: the stream ends with a fence -- two launches and the last
+        # statistics drain with nothing behind them, ~100 us -- which a 20-step window would show as 5 us
+        # per step; `mini_batches` in the line)
+        n_e2e = max(args.steps, 128)
+        e2e_run(max(n_e2e, 40))                                       # staging buffers, allocations, workers
+        s_e2e = sorted(e2e_run(n_e2e) for _ in range(max(1, args.repeats)))
         for b_ in window.values():
             b_.close()
         window.clear()
-        value_end_to_end = {"value": round(B * args.steps / s_e2e[len(s_e2e) // 2], 1), "unit": "docs/s",
-                            "ms_per_step": round(1e3 * s_e2e[len(s_e2e) // 2] / args.steps, 5),
-                            "ms_per_step_min": round(1e3 * s_e2e[0] / args.steps, 5),
-                            "what": "CSR arrays in host memory -> trlda_batch_create (index + upload on the "
-                                    "library's worker threads, TRLDA_INDEX_THREADS, default 4) four steps "
+        value_end_to_end = {"value": round(B * n_e2e / s_e2e[len(s_e2e) // 2], 1), "unit": "docs/s",
+                            "mini_batches": n_e2e,
+                            "ms_per_step": round(1e3 * s_e2e[len(s_e2e) // 2] / n_e2e, 5),
+                            "ms_per_step_min": round(1e3 * s_e2e[0] / n_e2e, 5),
+                            "what": "CSR arrays in host memory -> trlda_batch_create (index on the library's "
+                                    "worker threads, TRLDA_INDEX_THREADS, default 4; uploads enqueued by the "
+                                    "caller's thread) eight steps "
                                     "before its E-step, announced two steps before it -> E-step -> "
                                     "trlda_batch_destroy four steps after it; one Python thread drives it",
                             "host_threads": 1 + int(os.environ.get("TRLDA_INDEX_THREADS", "4"))}
@@ -839,7 +845,7 @@ def main():
         # mini-batches inside the library, no Python between the steps): the corpus' CSR arrays in
         # host memory, gamma0 / gamma for all of it on the device, a ring of four statistics arrays
         try:
-            n_c = min(nb, max(args.steps, 1))
+            n_c = min(nb, n_e2e)
             offs = np.zeros(n_c * B + 1, dtype=np.int64)
             at = 0
             for i in range(n_c):

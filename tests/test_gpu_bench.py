@@ -71,8 +71,13 @@ def test_bench_line_contract(hip_lib):
     # nothing pre-uploaded (round 6): CSR in host memory -> batch -> E-step -> destroy, PCIe and host
     # work inclusive -- reported beside the headline, below it, and tagged with the threads it used
     e2e = j["value_end_to_end"]
-    assert 0 < e2e["value"] <= j["value"] * 1.02 and e2e["host_threads"] >= 1 and "trlda_batch_create" in e2e["what"]
-    assert 0 < e2e["one_call"]["value"] <= j["value"] * 1.02 and e2e["one_call"]["mini_batches"] == 10
+    # (a stretch of its own length, >= 128 mini-batches -- against this run's 10-step headline, whose two
+    # ramps are a fifth of the region, it is not bounded by `value`; by the launches' device time it is)
+    floor_ms = sum(r["kernels_us"].values()) / r["launches_in_flight"] * 1e-3
+    assert e2e["value"] > 0 and e2e["ms_per_step"] >= 0.9 * floor_ms and e2e["mini_batches"] == 128
+    assert e2e["host_threads"] >= 1 and "trlda_batch_create" in e2e["what"]
+    assert e2e["one_call"]["value"] > 0 and e2e["one_call"]["ms_per_step"] >= 0.9 * floor_ms
+    assert e2e["one_call"]["mini_batches"] == 128
     assert j["mode"]["deferred_stats"] is True and j["mode"]["lanes"] == 2 and j["mode"]["pipelined"] is True
     assert j["repeats"]["n"] == 3 and j["repeats"]["ms_per_step_min"] <= j["ms_per_step"] <= \
         j["repeats"]["ms_per_step_max"]

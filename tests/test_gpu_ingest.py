@@ -82,12 +82,12 @@ def test_the_device_sees_the_host_index_whoever_built_it(hip, raw):
             assert np.array_equal(got[o:o + nb], want[o:o + nb]), (n, name)
     for h in handles.values():
         raw.trlda_batch_destroy(h)
-    assert set(states.values()) <= {0, 1, 3}
+    assert set(states.values()) <= {0, 1, 3, 5, 6}   # built | queued | being indexed | indexed, not uploaded | being uploaded
 
 
 def test_batches_dropped_before_and_while_they_are_built(hip, raw):
     """destroyed at once (never indexed), destroyed while a worker is on it, thousands in a row: no
-    staging buffer is lost (the pool has eight) and the next batch is as good as any"""
+    staging buffer is lost (the pool has two dozen) and the next batch is as good as any"""
     from trlda_amd.utils.synthetic import make_corpus
     V = 3000
     ip, ii, cc = make_corpus(150, V, seed=5, mean_unique=60)
@@ -109,6 +109,34 @@ def test_batches_dropped_before_and_while_they_are_built(hip, raw):
     for name, o, nb in zip(gold.SECTIONS, offs, sizes):
         assert np.array_equal(got[o:o + nb], want[o:o + nb]), name
     raw.trlda_batch_destroy(h)
+
+
+@pytest.mark.timeout(300)
+def test_a_corpus_of_batches_made_before_the_first_is_used(hip, raw):
+    """The workers only index; the uploads are enqueued by the caller's thread -- trlda_batch_create for
+    the batches made before it, an E-step for the batches announced to it, a batch's first user.  A
+    caller that makes far more batches than there are staging buffers before it touches one of them
+    (every mini-batch of an epoch up front) neither blocks nor loses one: every index reaches the device
+    as the host builds it (ldainterface.cpp:152-190 -- the reference converts every document up front)."""
+    import torch
+    from trlda_amd.utils.synthetic import make_corpus
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    V, N = 2500, 150
+    made = []
+    for n in range(N):
+        ip, ii, cc = make_corpus(60 + n % 7, V, seed=100 + n, mean_unique=40 + n % 5)
+        h = C.c_void_p()
+        assert raw.trlda_batch_create(C.byref(h), 0, V, len(ip) - 1, ip.ctypes.data, ii.ctypes.data, cc.ctypes.data) == 0
+        made.append((h, ip, ii, cc))
+    for n in list(range(0, N, 13)) + [N - 1, N - 2]:
+        h, ip, ii, cc = made[n]
+        want, offs, sizes = host_index(raw, V, ip, ii, cc, cus)
+        got = np.empty_like(want)
+        assert raw.trlda_debug_batch_blob(h, got.ctypes.data, got.size, None) == 0, n
+        for name, o, nb in zip(gold.SECTIONS, offs, sizes):
+            assert np.array_equal(got[o:o + nb], want[o:o + nb]), (n, name)
+    for h, *_ in made:
+        raw.trlda_batch_destroy(h)
 
 
 def test_errors_of_the_arguments_stay_with_the_call(hip, raw):

@@ -171,6 +171,45 @@ def test_hoffman_cross_implementation(hip):
     assert np.corrcoef(f["sstats_hoffman"].ravel(), s.ravel())[0, 1] > 0.99
 
 
+def test_goldens_through_the_wave_per_document_body(hip, sampler):
+    """VERDICT r5 item 5's gate: the reference's own vectors f1a (K = 10), f1b (K = 20) and the Hoffman
+    cross-check f7 (K = 20; onlinelda_test.py:39-68) through estep_docs_small_body, forced with
+    trlda_model_set_doc_kernel(TRLDA_DOCS_SMALL), at 1e-9 with the golden iteration counts
+    (lda.cpp:185-204)."""
+    from trlda_amd import _ffi
+
+    def used(m):
+        u = hip.trlda_model_last_doc_kernel(m._handle)
+        return u.decode() if isinstance(u, bytes) else u
+
+    for name in ("f1a_estep", "f1b_estep"):
+        f = golden(name)
+        K, V, B = int(f["K"]), int(f["V"]), int(f["B"])
+        lam = seeded_lambda(sampler, f["lambda_seed"], K, V)
+        g0 = seeded_gamma(sampler, f["gamma0_seed"], K, B)
+        m = make_model(K, V, lam, alpha=f["alpha"])
+        _ffi.check(hip.trlda_model_set_doc_kernel(m._handle, 3))
+        batch = m.upload(csr(f))
+        for (it, thr) in [(0, 1e-3), (1, 1e-3), (20, 1e-3), (50, 0.0), (100, 1e-3)]:
+            key = "it%d_thr%g" % (it, thr)
+            g, s, iters = m.update_variables(batch, latents=g0, max_iter=it, threshold=thr,
+                                             return_iterations=True)
+            assert "small" in used(m), used(m)
+            assert relerr(g, f["gamma_" + key]) < TIGHT_RTOL
+            check_sstats(s, f["sstats_" + key])
+            assert np.array_equal(iters, f["iters_" + key])
+        m.close()
+    f = golden("f7_hoffman_test_vi")
+    m = make_model(int(f["K"]), int(f["V"]), f["lam"], D=int(f["B"]))
+    _ffi.check(hip.trlda_model_set_doc_kernel(m._handle, 3))
+    g, s = m.do_e_step(csr(f).to_list(), max_iter=50, latents=f["gamma0"])
+    assert "small" in used(m), used(m)
+    for tag in ("hoffman", "ref"):
+        assert relerr(g, f["gamma_" + tag]) < TIGHT_RTOL
+        check_sstats(s, f["sstats_" + tag])
+    m.close()
+
+
 def test_one_shot_c_abi(hip, oracle, sampler):
     """trlda_estep / trlda_mstep_blend / trlda_tr_init with plain host pointers."""
     from trlda_amd.utils.synthetic import make_corpus

@@ -54,7 +54,8 @@ rate("list of tuples -> CSR (as_csr)", lambda: as_csr(lst), 50)
 # library's worker threads; a batch destroyed before anybody used it is never indexed -- so the
 # "made and dropped" loop measures the caller's share only, "made, used, dropped" the whole build on
 # the caller's thread (its first user takes over a build no worker has started), and "a stream of
-# them" what a pipeline gets: made four ahead of their use by the workers)
+# them" what a pipeline gets: made eight ahead of their use, indexed by the workers, each upload
+# enqueued by a later trlda_batch_create on the caller's thread)
 
 
 def made_used_dropped(src):
@@ -63,7 +64,7 @@ def made_used_dropped(src):
     b.close()
 
 
-def stream_of(n=400, ahead=4):
+def stream_of(n=400, ahead=8):
     win = [DeviceBatch(docs, V, 0) for _ in range(ahead)]
     t = time.perf_counter()
     for i in range(n):
@@ -83,7 +84,7 @@ rate("CSR -> device batch, made and dropped (caller's share)", lambda: DeviceBat
 rate("CSR -> device batch, made, used, dropped (index on the caller)", lambda: made_used_dropped(docs), 50)
 stream_of(100)
 dt = stream_of()
-print("%-58s %9.1f us/call -> %10.0f docs/s" % ("CSR -> device batch, a stream made 4 ahead of its use", dt * 1e6, B / dt))
+print("%-58s %9.1f us/call -> %10.0f docs/s" % ("CSR -> device batch, a stream made 8 ahead of its use", dt * 1e6, B / dt))
 big = CSRDocuments(*make_corpus(20000, V, seed=1, mean_unique=100))
 with tempfile.TemporaryDirectory() as tmp:
     path = os.path.join(tmp, "corpus.dat")

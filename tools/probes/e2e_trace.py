@@ -24,6 +24,9 @@ MODE = os.environ.get("MODE", "full")
 pre = [DeviceBatch(c, V, 0) for c in csrs] if MODE == "nocreate" else None
 win = {i: DeviceBatch(csrs[i % N], V, 0) for i in range(AHEAD)}
 rows = []
+if os.environ.get("NOGC"):
+    import gc
+    gc.collect(); gc.freeze(); gc.disable()
 steps = int(os.environ.get("STEPS", "400"))
 torch.cuda.synchronize()
 T0 = time.perf_counter()
@@ -51,9 +54,22 @@ T = time.perf_counter() - T0
 r = np.array(rows[50:])
 print(MODE, "AHEAD %d: %.1f us per step (%.2f M docs/s); host medians: create %.1f  estep %.1f  destroy %.1f; means %.1f %.1f %.1f; lane steps %d" % (
     AHEAD, T / steps * 1e6, B * steps / T / 1e6, *np.median(r, axis=0), *r.mean(axis=0), L.trlda_model_lane_steps(model)))
+ul, us = C.c_double(), C.c_double()
+L.trlda_model_lane_timing(model, C.byref(ul), C.byref(us))
+print("   lane state %d, calibration: launch %.1f us, step %.1f us" % (L.trlda_model_lane_state(model), ul.value, us.value))
 cnt = (C.c_longlong * 8)()
 C.CDLL(_ffi.LIB_PATH).trlda_debug_ingest_counters(cnt)
 print("   ingest counters [worker, taken over, cancelled, inline, hipMalloc, hipFree, stage held, stage upload]:", list(cnt))
+ct = (C.c_double * 16)()
+raw = C.CDLL(_ffi.LIB_PATH)
+if hasattr(raw, "trlda_debug_call_times"):
+    raw.trlda_debug_call_times(ct)
+    n = max(ct[7], 1.0)
+    print("   lane call, us per call: wait for the index %.1f, set-up %.1f, launch sequence %.1f (upload events %.1f, launch %.1f, reader marks %.1f), rest %.1f" % (
+        ct[0] / n, ct[1] / n, ct[2] / n, ct[4] / n, ct[5] / n, ct[6] / n, ct[3] / n))
+    nb_ = max(ct[15], 1.0)
+    print("   a worker's build, us: queue %.1f, grace %.1f, plan + fill %.1f, allocation %.1f, stream calls %.1f, upload wait %.1f, publication %.1f (%d builds)" % (
+        *[ct[8 + i] / nb_ for i in range(7)], int(ct[15])))
 c = np.array(rows)[:, 0]
 big = np.nonzero(c > 100)[0]
 print("   creates > 100 us: %d of %d, at steps %s ..., sizes %s" % (len(big), len(c), list(big[:25]), [int(x) for x in c[big[:25]]]))

@@ -139,15 +139,21 @@ struct trlda_batch {
     // when trlda_batch_create built the index itself; and a batch destroyed before anybody needed it
     // is never indexed at all (kCancelled).  The state lives in a ticket the queued job shares: the
     // job may outlive the batch.
-    enum { kBuilt = 0, kQueued = 1, kFailed = 2, kBuilding = 3, kCancelled = 4 };
+    // kBuilding: a thread is at the index (host work only: batch_fill).  kFilled: the index lies in the
+    // staging buffer; the upload -- allocation, one copy, two events -- is enqueued by a CALLER's thread
+    // (kUploading: batch_upload), never by a worker: the next trlda_batch_create, the E-step the batch is
+    // announced to, or its first user.
+    enum { kBuilt = 0, kQueued = 1, kFailed = 2, kBuilding = 3, kCancelled = 4, kFilled = 5, kUploading = 6 };
     struct Ticket {
         std::atomic<int> state{kBuilt};
     };
     std::shared_ptr<Ticket> ticket = std::make_shared<Ticket>();
-    void *slot = nullptr;              // the staging buffer that holds its CSR arrays until the build
+    void *slot = nullptr;              // the staging buffer that holds its CSR arrays, then its index, until the upload
+    std::unique_ptr<trlda_host::BatchIndex> index;   // the layout, between batch_fill and batch_upload
+    int cus = 256;                     // the device's compute units (whether splitting long documents pays)
     int build_rc = 0;
     std::string build_msg;
-    bool destroy_when_built = false;   // trlda_batch_destroy came while a worker was building: the worker destroys it
+    bool destroy_when_built = false;   // trlda_batch_destroy came while a thread was at it: that thread destroys it
     // Every array below lives in ONE device allocation (`blob`), filled by ONE host-to-device
     // copy from pinned memory on the upload stream; `ready` marks the end of that copy and
     // `done` the last kernel that read the batch (recorded by every entry point that uses it),
@@ -586,6 +592,9 @@ struct UploadContext {
     };
     std::vector<Spare> events;
     std::set<trlda_batch *> live;     // batches that exist (their `done` may sit on a model's stream)
+    // indices the workers have finished and nobody has uploaded yet (uploads_drain); a batch that was
+    // used or destroyed in the meantime is recognised by its ticket
+    std::vector<std::pair<trlda_batch *, std::shared_ptr<trlda_batch::Ticket>>> filled;
     void spare(hipEvent_t ev, hipStream_t on = nullptr, bool owned = false)
     {
         if (ev)
@@ -605,7 +614,7 @@ UploadContext &upload_context(int device)
     return *it->second;
 }
 
-constexpr size_t kBlobCacheMax = 16;   // (several indices are in the making at a time: stage_acquire)
+constexpr size_t kBlobCacheMax = 32;   // (several indices are in the making at a time: stage_acquire)
 constexpr size_t kBlobCacheBytes = (size_t)1 << 30;
 
 int take_event(UploadContext &u, hipEvent_t *ev)
@@ -703,9 +712,29 @@ void purge_stream_guards(int device, hipStream_t s)
         }
 }
 
+// TRLDA_CALL_TIMES=1: host time of a lane call's sections, summed (trlda_debug_call_times): [0] the wait
+// for the batch's index, [1] set-up, [2] the launch sequence (estep_device), [3] the rest; of [2]: [4] the
+// batches' upload events, [5] the document launch itself, [6] the batches' reader marks; [7] calls
+double g_call_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+const bool g_call_times = std::getenv("TRLDA_CALL_TIMES") != nullptr;
+struct CallClock {
+    std::chrono::steady_clock::time_point t;
+    CallClock() { if (g_call_times) t = std::chrono::steady_clock::now(); }
+    void to(int i)
+    {
+        if (!g_call_times)
+            return;
+        const auto n = std::chrono::steady_clock::now();
+        g_call_us[i] += std::chrono::duration<double, std::micro>(n - t).count();
+        t = n;
+    }
+};
+
 // every reader of a batch: wait for its upload, and leave a mark behind
 int batch_begin(trlda_model *m, const trlda_batch *b)
 {
+    CallClock clock;
+    struct Done { CallClock &c; ~Done() { c.to(4); } } done{clock};
     if (b && b->ready && !b->ready_seen) {
         if (hipEventQuery(b->ready) == hipSuccess)
             const_cast<trlda_batch *>(b)->ready_seen = true;
@@ -716,6 +745,8 @@ int batch_begin(trlda_model *m, const trlda_batch *b)
 }
 int batch_end(trlda_model *m, const trlda_batch *b)
 {
+    CallClock clock;
+    struct Done { CallClock &c; ~Done() { c.to(6); } } done{clock};
     if (b && b->done) {
         trlda_batch *bb = const_cast<trlda_batch *>(b);
         if (bb->used && bb->last_stream != m->stream) {
@@ -2142,6 +2173,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                 dg.first_static = (!no_static && free_cus >= 32 && H <= free_cus) ? H : 0;
                 m->defer_work_total += (unsigned int)(dg.first_static ? n_items : n_items + H);
                 const dim3 grid((unsigned)(n_wgs + H));
+                CallClock launch_clock;
                 if (!tiered)
                     hipLaunchKernelGGL(estep_docs_reg_deferred_kernel<0>, grid, dim3(kRegThreads), lds_bytes,
                                        m->stream, a, pre, dg);
@@ -2151,6 +2183,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                 else
                     hipLaunchKernelGGL(estep_docs_tiered_deferred_kernel<2>, grid, dim3(kRegThreads), lds_bytes,
                                        m->stream, a, pre, lds_rows, dg);
+                launch_clock.to(5);
                 m->pending.valid = false;
                 const_cast<trlda_batch *>(pb)->pending_in = nullptr;
                 if ((rc = batch_end(m, pb)))
@@ -2874,7 +2907,7 @@ int trlda_dev_synchronize(int device)
 
 namespace {
 
-constexpr size_t kStageSlots = 8;
+constexpr size_t kStageSlots = 24;
 
 // what the ingestion did so far (trlda_debug_ingest_counters): [0] indices built by a worker, [1] taken over
 // by their first user, [2] cancelled (destroyed unused), [3] built on the creating thread (no workers),
@@ -2910,7 +2943,20 @@ trlda_host::WorkQueue &index_queue()
 std::mutex g_build_mu;
 std::condition_variable g_build_cv;
 
+// TRLDA_CALL_TIMES=1: where a worker's build spends its time, ns summed over the builds
+// (trlda_debug_call_times, [8..15]): [8] submit -> a worker has the job, [9] the grace period, [10] plan +
+// fill, [11] the allocation (upload context's lock, cache, hipMalloc), [12] the stream calls, [13] the wait
+// for the upload, [14] publication, [15] builds
+std::atomic<long long> g_build_ns[8];
+inline long long now_ns()
+{
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(
+               std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 // a staging buffer of at least `bytes` that is nobody else's until stage_release
+int uploads_drain(UploadContext &u);
+
 int stage_acquire(UploadContext &u, size_t bytes, UploadContext::Stage **out)
 {
     std::unique_lock<std::mutex> lock(u.mu);
@@ -2939,9 +2985,19 @@ int stage_acquire(UploadContext &u, size_t bytes, UploadContext::Stage **out)
             HIP_TRY(hipEventSynchronize(late->ev));
             pick = late;
         }
-        if (!pick) {                                 // every buffer is some build's: wait for one
+        if (!pick) {
+            // every buffer holds an index that has not been uploaded: those that are finished are uploaded
+            // now, by this thread (a caller that makes a whole corpus' batches before it uses the first);
+            // if none is, a worker is still at one
             ++g_ingest[6];
-            u.stage_cv.wait(lock);
+            if (!u.filled.empty()) {
+                lock.unlock();
+                if (int rc = uploads_drain(u))
+                    return rc;
+                lock.lock();
+            } else {
+                u.stage_cv.wait(lock);
+            }
             continue;
         }
         if (pick->cap < bytes) {
@@ -2964,41 +3020,39 @@ int stage_acquire(UploadContext &u, size_t bytes, UploadContext::Stage **out)
 void stage_release(UploadContext &u, UploadContext::Stage *st)   // (u.mu held)
 {
     st->busy = false;
-    u.stage_cv.notify_one();
+    u.stage_cv.notify_all();
 }
 
-// The index of batch `b` from the CSR arrays at the head of staging buffer `st`, into a device
-// allocation, the copy enqueued on the upload stream: on a worker thread, or on trlda_batch_create's
-int batch_build(trlda_batch *b, UploadContext::Stage *st, bool on_worker = false)
+// The index of batch `b` from the CSR arrays at the head of its staging buffer, into that buffer
+// (csrc/batch_index.cpp): host work only, NO HIP call -- on a worker thread, or on the thread of
+// whoever needs the batch first.  (Round 6, first form: the workers also enqueued the upload.  Four
+// threads calling hipMemcpyAsync / hipEventRecord on one stream beside the caller's launches: 32-175 us
+// per build in those calls, the caller's launch sequence 13 us instead of 8 -- the runtime's locks;
+// profiles/r06_e2e_trace.txt.  The uploads are now enqueued by the caller's thread, batch_upload.)
+int batch_fill(trlda_batch *b)
 {
-    UploadContext &u = upload_context(b->device);
-    auto give_up = [&](int rc) {
-        std::lock_guard<std::mutex> lock(u.mu);
-        stage_release(u, st);
-        return rc;
-    };
-    HIP_TRY(hipSetDevice(b->device));
-    static std::atomic<int> cus_cache[64];
-    int cus = b->device < 64 ? cus_cache[b->device].load(std::memory_order_relaxed) : 0;
-    if (cus <= 0) {
-        cus = 256;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b->device);
-        if (b->device < 64)
-            cus_cache[b->device].store(cus, std::memory_order_relaxed);
-    }
+    UploadContext::Stage *st = static_cast<UploadContext::Stage *>(b->slot);
     char *h = static_cast<char *>(st->host);
     size_t o_ids = 0, o_cnts = 0;
     trlda_host::batch_index_csr_offsets(b->B, b->nnz, &o_ids, &o_cnts);
     const int32_t *indptr = reinterpret_cast<const int32_t *>(h), *ids = reinterpret_cast<const int32_t *>(h + o_ids),
                   *cnts = reinterpret_cast<const int32_t *>(h + o_cnts);
-    trlda_host::BatchIndex x;
+    b->index.reset(new trlda_host::BatchIndex());
+    trlda_host::BatchIndex &x = *b->index;
+    long long t_mark = g_call_times ? now_ns() : 0;
     int rc = trlda_host::batch_index_plan(b->V, b->B, indptr, ids, cnts, &x);
-    if (rc)
-        return give_up(rc);
-    if (x.total > st->cap || x.o_ids != o_ids || x.o_cnts != o_cnts)
-        return give_up(fail(TRLDA_ERR_ARG, "internal: the index outgrew its staging buffer"));
-    const size_t total = x.total;
-    trlda_host::batch_index_fill(&x, indptr, ids, cnts, cus, h);
+    if (!rc && (x.total > st->cap || x.o_ids != o_ids || x.o_cnts != o_cnts))
+        rc = fail(TRLDA_ERR_ARG, "internal: the index outgrew its staging buffer");
+    if (rc) {
+        UploadContext &u = upload_context(b->device);
+        std::lock_guard<std::mutex> lock(u.mu);
+        stage_release(u, st);
+        b->slot = nullptr;
+        return rc;
+    }
+    trlda_host::batch_index_fill(&x, indptr, ids, cnts, b->cus, h);
+    if (g_call_times)
+        g_build_ns[2] += now_ns() - t_mark;
 
     b->n_active = x.n_active; b->n_long = x.n_long; b->long_len = x.long_len;
     b->split_pays = x.split_pays;
@@ -3013,15 +3067,42 @@ int batch_build(trlda_batch *b, UploadContext::Stage *st, bool on_worker = false
     b->long_host.swap(x.long_host);
     b->vl_host.swap(x.vl_host);
     b->vl_first.swap(x.vl_first);
+    return TRLDA_OK;
+}
 
-    // Under the upload context's lock only what is shared: the allocation (from the cache when one fits)
-    // and two events.  The stream operations -- each on this batch's own objects -- run outside it:
-    // trlda_batch_create and trlda_batch_destroy of the caller's thread take the same lock.
+// ... and its way to the device: an allocation (from the cache when one fits), ONE copy on the upload
+// stream, the events.  On the thread of a caller of the library (trlda_batch_create for the batches made
+// before, the E-step a batch is announced to, its first user).
+int batch_upload(trlda_batch *b)
+{
+    UploadContext &u = upload_context(b->device);
+    UploadContext::Stage *st = static_cast<UploadContext::Stage *>(b->slot);
+    const trlda_host::BatchIndex &x = *b->index;
+    const size_t total = x.total;
+    long long t_mark = g_call_times ? now_ns() : 0;
+    auto mark = [&](int i) {
+        if (!g_call_times)
+            return;
+        const long long n = now_ns();
+        g_build_ns[i] += n - t_mark;
+        t_mark = n;
+    };
+    auto give_up = [&](int rc) {
+        std::lock_guard<std::mutex> lock(u.mu);
+        stage_release(u, st);
+        b->slot = nullptr;
+        b->index.reset();
+        return rc;
+    };
+    if (hipSetDevice(b->device) != hipSuccess)
+        return give_up(fail(TRLDA_ERR_HIP, "hipSetDevice failed"));
+    // Under the upload context's lock only what is shared: the allocation and two events.
     UploadContext::Blob blob{nullptr, 0, nullptr};
     {
         std::lock_guard<std::mutex> lock(u.mu);
         if (!u.stream && hipStreamCreateWithFlags(&u.stream, hipStreamNonBlocking) != hipSuccess) {
             stage_release(u, st);
+            b->slot = nullptr;
             return fail(TRLDA_ERR_HIP, "hipStreamCreateWithFlags failed");
         }
         // (an allocation whose last reader has finished, if there is one: an upload into an allocation
@@ -3048,6 +3129,7 @@ int batch_build(trlda_batch *b, UploadContext::Stage *st, bool on_worker = false
                 u.cached_bytes += blob.bytes;
             }
             stage_release(u, st);
+            b->slot = nullptr;
             return fail(TRLDA_ERR_HIP, "hipEventCreate failed");
         }
     }
@@ -3063,6 +3145,7 @@ int batch_build(trlda_batch *b, UploadContext::Stage *st, bool on_worker = false
     }
     b->blob = blob.ptr;
     b->blob_bytes = blob.bytes;
+    mark(3);
     hipError_t err = hipSuccess;
     const bool guard_wait = blob.done && stream_alive(blob.on, blob.on_owned);
     if (guard_wait)                                  // the previous owner's last reader
@@ -3071,7 +3154,7 @@ int batch_build(trlda_batch *b, UploadContext::Stage *st, bool on_worker = false
     if (err == hipSuccess)
         err = hipMemcpyAsync(b->blob, st->host, total, hipMemcpyHostToDevice, u.stream);
     if (err == hipSuccess)
-        err = hipEventRecord(st->ev, u.stream);
+        err = hipEventRecord(st->ev, u.stream);      // (the staging buffer is anybody's once this has passed)
     if (err == hipSuccess)
         err = hipEventRecord(b->ready, u.stream);
     if (err != hipSuccess) {
@@ -3080,18 +3163,12 @@ int batch_build(trlda_batch *b, UploadContext::Stage *st, bool on_worker = false
         b->blob = nullptr;
         return give_up(fail(TRLDA_ERR_HIP, std::string("batch upload: ") + hipGetErrorString(err)));
     }
-    // (on a worker thread: the copy is seen out before the staging buffer goes back -- the next
-    // trlda_batch_create then never finds a buffer whose upload it would have to wait for, on ITS thread)
-    static const bool upload_wait = [] {
-        const char *e = std::getenv("TRLDA_INDEX_UPLOAD_WAIT");
-        return !(e && e[0] == '0');
-    }();
-    if (on_worker && upload_wait)
-        (void)hipEventSynchronize(st->ev);
+    mark(4);
     std::lock_guard<std::mutex> lock(u.mu);
     if (guard_wait)
         u.spare(blob.done, blob.on, blob.on_owned);
     stage_release(u, st);
+    b->slot = nullptr;
     char *dv = static_cast<char *>(b->blob);
     auto D = [&](size_t o) { return reinterpret_cast<int32_t *>(dv + o); };
     b->indptr = D(x.o_indptr); b->ids = D(x.o_ids); b->cnts = D(x.o_cnts); b->order = D(x.o_order);
@@ -3108,13 +3185,15 @@ int batch_build(trlda_batch *b, UploadContext::Stage *st, bool on_worker = false
     b->n_short = x.n_active - x.n_long;
     b->vl_word = D(x.o_vlw); b->vl_task = D(x.o_vlt); b->vl_task_tiled = D(x.o_vltt);
     b->n_vl = x.n_vl; b->n_vl_tasks = x.n_vl_tasks; b->seg_len = x.seg_len;
+    b->index.reset();
     u.live.insert(b);
     return TRLDA_OK;
 }
 
-// the build's end: its status becomes the batch's, whoever waits is woken; a batch whose owner has
-// let go of it in the meantime is destroyed here
-void batch_publish(trlda_batch *b, int rc)
+// the end of a build's step (the index filled: kFilled; uploaded: kBuilt; either failed: kFailed): its
+// status becomes the batch's, whoever waits is woken; a batch whose owner has let go of it in the
+// meantime is destroyed here
+void batch_publish(trlda_batch *b, int rc, int state_ok)
 {
     bool destroy = false;
     {
@@ -3123,40 +3202,79 @@ void batch_publish(trlda_batch *b, int rc)
             b->build_rc = rc;
             b->build_msg = trlda_last_error();
         }
-        b->slot = nullptr;
-        b->ticket->state.store(rc ? trlda_batch::kFailed : trlda_batch::kBuilt, std::memory_order_release);
+        b->ticket->state.store(rc ? trlda_batch::kFailed : state_ok, std::memory_order_release);
         destroy = b->destroy_when_built;
+        b->destroy_when_built = false;
     }
     g_build_cv.notify_all();
     if (destroy)
         (void)trlda_batch_destroy(b);
 }
 
-// every entry point that is handed a batch: its index is there (or the build's failure is the call's).
-// A build that no worker has started on yet is taken over by the caller.
+// kFilled -> kBuilt on this thread, if nobody else is at it; false: somebody else has it (or had)
+bool batch_take_upload(trlda_batch *b, const std::shared_ptr<trlda_batch::Ticket> &ticket)
+{
+    int expect = trlda_batch::kFilled;
+    if (!ticket->state.compare_exchange_strong(expect, trlda_batch::kUploading, std::memory_order_acq_rel))
+        return false;
+    batch_publish(b, batch_upload(b), trlda_batch::kBuilt);
+    return true;
+}
+
+// every index the workers have finished: uploaded now, by this thread
+int uploads_drain(UploadContext &u)
+{
+    std::vector<std::pair<trlda_batch *, std::shared_ptr<trlda_batch::Ticket>>> todo;
+    {
+        std::lock_guard<std::mutex> lock(u.mu);
+        todo.swap(u.filled);
+    }
+    // (an entry whose batch was used or destroyed in the meantime: its ticket says so, the batch is not touched)
+    for (auto &e : todo)
+        (void)batch_take_upload(e.first, e.second);
+    return TRLDA_OK;
+}
+
+// an announced batch: uploaded now if its index is there; true: it can be announced to a launch
+bool batch_announced(const trlda_batch *cb)
+{
+    if (!cb)
+        return false;
+    trlda_batch *b = const_cast<trlda_batch *>(cb);
+    if (b->ticket->state.load(std::memory_order_acquire) == trlda_batch::kFilled)
+        (void)batch_take_upload(b, b->ticket);
+    return b->ticket->state.load(std::memory_order_acquire) == trlda_batch::kBuilt;
+}
+
+// every entry point that is handed a batch: its index is there and on its way to the device (or the
+// build's failure is the call's).  A build that no worker has started on yet is taken over by the caller.
 int batch_wait(const trlda_batch *cb)
 {
     if (!cb)
         return TRLDA_OK;
     trlda_batch *b = const_cast<trlda_batch *>(cb);
     std::atomic<int> &state = b->ticket->state;
-    int st = state.load(std::memory_order_acquire);
-    if (st == trlda_batch::kQueued) {
-        int expect = trlda_batch::kQueued;
-        if (state.compare_exchange_strong(expect, trlda_batch::kBuilding, std::memory_order_acq_rel)) {
-            ++g_ingest[1];
-            batch_publish(b, batch_build(b, static_cast<UploadContext::Stage *>(b->slot)));
+    for (;;) {
+        int st = state.load(std::memory_order_acquire);
+        if (st == trlda_batch::kBuilt)
+            return TRLDA_OK;
+        if (st == trlda_batch::kFailed)
+            return fail(b->build_rc, "the batch's index could not be built: " + b->build_msg);
+        if (st == trlda_batch::kQueued) {
+            int expect = trlda_batch::kQueued;
+            if (state.compare_exchange_strong(expect, trlda_batch::kBuilding, std::memory_order_acq_rel)) {
+                ++g_ingest[1];
+                batch_publish(b, batch_fill(b), trlda_batch::kFilled);
+            }
+        } else if (st == trlda_batch::kFilled) {
+            (void)batch_take_upload(b, b->ticket);
+        } else if (st == trlda_batch::kBuilding || st == trlda_batch::kUploading) {
+            std::unique_lock<std::mutex> lock(g_build_mu);
+            g_build_cv.wait(lock, [&] { return state.load(std::memory_order_acquire) != st; });
+        } else {
+            return fail(TRLDA_ERR_ARG, "the batch was destroyed");
         }
-        st = state.load(std::memory_order_acquire);
     }
-    if (st == trlda_batch::kBuilding) {
-        std::unique_lock<std::mutex> lock(g_build_mu);
-        g_build_cv.wait(lock, [&] { return state.load(std::memory_order_acquire) != trlda_batch::kBuilding; });
-        st = state.load(std::memory_order_acquire);
-    }
-    if (st == trlda_batch::kFailed)
-        return fail(b->build_rc, "the batch's index could not be built: " + b->build_msg);
-    return TRLDA_OK;
 }
 
 }  // namespace
@@ -3204,16 +3322,29 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
         b->id = next_id.fetch_add(1);
     }
     b->device = device; b->V = V; b->B = B; b->nnz = nnz; b->max_n = max_n;
+    {
+        static std::atomic<int> cus_cache[64];
+        int cus = device < 64 ? cus_cache[device].load(std::memory_order_relaxed) : 0;
+        if (cus <= 0) {
+            cus = 256;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+            if (device < 64)
+                cus_cache[device].store(cus, std::memory_order_relaxed);
+        }
+        b->cus = cus;
+    }
+    b->slot = st;
     trlda_host::WorkQueue &queue = index_queue();
     if (queue.threads() <= 0) {
         ++g_ingest[3];
-        rc = batch_build(b, st);
+        rc = batch_fill(b);
+        if (!rc)
+            rc = batch_upload(b);
         if (rc) {                                    // (as in rounds 1-5: the failure is this call's)
             delete b;
             return rc;
         }
     } else {
-        b->slot = st;
         b->ticket->state.store(trlda_batch::kQueued, std::memory_order_release);
         std::shared_ptr<trlda_batch::Ticket> ticket = b->ticket;
         // (a worker leaves a fresh ticket alone for kGraceUs: a caller that uses its batch at once --
@@ -3221,7 +3352,10 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
         // what it paid when trlda_batch_create built the index, not a sleeping thread's wake-up on top:
         // 389 against 425-494 us per do_e_step; a pipeline makes its batches hundreds of us ahead)
         const auto start = std::chrono::steady_clock::now() + std::chrono::microseconds(40);
-        queue.submit([b, st, ticket, start] {
+        const long long t_submit = g_call_times ? now_ns() : 0;
+        UploadContext *up = &u;
+        queue.submit([b, up, ticket, start, t_submit] {
+            const long long t_got = g_call_times ? now_ns() : 0;
             while (std::chrono::steady_clock::now() < start &&
                    ticket->state.load(std::memory_order_acquire) == trlda_batch::kQueued)
                 __builtin_ia32_pause();
@@ -3229,9 +3363,46 @@ int trlda_batch_create(trlda_batch **out, int device, int V, int B, const int32_
             if (ticket->state.compare_exchange_strong(expect, trlda_batch::kBuilding,   //  `b` may be gone)
                                                       std::memory_order_acq_rel)) {
                 ++g_ingest[0];
-                batch_publish(b, batch_build(b, st, /*on_worker=*/true));
+                const long long t_go = g_call_times ? now_ns() : 0;
+                const int rc_fill = batch_fill(b);
+                const long long t_filled = g_call_times ? now_ns() : 0;
+                // (A/B, TRLDA_INDEX_UPLOAD=worker: the worker enqueues the upload too, one worker at a time)
+                static const bool by_worker = [] {
+                    const char *e = std::getenv("TRLDA_INDEX_UPLOAD");
+                    return e && e[0] == 'w';
+                }();
+                if (by_worker) {
+                    static std::mutex upload_mu;
+                    int rc_up = rc_fill;
+                    if (!rc_up) {
+                        std::lock_guard<std::mutex> one(upload_mu);
+                        rc_up = batch_upload(b);
+                    }
+                    batch_publish(b, rc_up, trlda_batch::kBuilt);
+                    if (g_call_times) {
+                        g_build_ns[0] += t_got - t_submit;
+                        g_build_ns[1] += t_go - t_got;
+                        g_build_ns[6] += now_ns() - t_filled;
+                        g_build_ns[7] += 1;
+                    }
+                    return;
+                }
+                batch_publish(b, rc_fill, trlda_batch::kFilled);
+                if (!rc_fill) {                      // (`b` may be uploaded, used, even destroyed by now: the
+                    std::lock_guard<std::mutex> lock(up->mu);   //  ticket tells whoever takes the entry)
+                    up->filled.emplace_back(b, ticket);
+                    up->stage_cv.notify_all();
+                }
+                if (g_call_times) {
+                    g_build_ns[0] += t_got - t_submit;
+                    g_build_ns[1] += t_go - t_got;
+                    g_build_ns[6] += now_ns() - t_filled;
+                    g_build_ns[7] += 1;
+                }
             }
         });
+        // the indices the workers have finished since the last call: uploaded here, on the caller's thread
+        (void)uploads_drain(u);                      // (a failed upload is its batch's failure, not this call's)
     }
     *out = b;
     return TRLDA_OK;
@@ -3241,27 +3412,33 @@ int trlda_batch_destroy(trlda_batch *b)
 {
     if (!b)
         return TRLDA_OK;
-    {
-        // Nobody has started on its index: it is never built (the queued job finds the ticket
-        // cancelled).  A worker is building it: the worker destroys it when it is done.
-        int expect = trlda_batch::kQueued;
-        if (b->ticket->state.compare_exchange_strong(expect, trlda_batch::kCancelled, std::memory_order_acq_rel)) {
+    for (;;) {
+        // Nobody has started on its index (kQueued), or nobody on its upload (kFilled): that is never
+        // done -- the queued job / the list of finished indices find the ticket cancelled.  A thread is
+        // at one of the two: that thread destroys the batch when it is done.
+        int st = b->ticket->state.load(std::memory_order_acquire);
+        if (st == trlda_batch::kQueued || st == trlda_batch::kFilled) {
+            if (!b->ticket->state.compare_exchange_strong(st, trlda_batch::kCancelled, std::memory_order_acq_rel))
+                continue;
             ++g_ingest[2];
             UploadContext &u = upload_context(b->device);
             {
                 std::lock_guard<std::mutex> lock(u.mu);
-                stage_release(u, static_cast<UploadContext::Stage *>(b->slot));
+                if (b->slot)
+                    stage_release(u, static_cast<UploadContext::Stage *>(b->slot));
             }
             delete b;
             return TRLDA_OK;
         }
-        if (expect == trlda_batch::kBuilding) {
+        if (st == trlda_batch::kBuilding || st == trlda_batch::kUploading) {
             std::lock_guard<std::mutex> lock(g_build_mu);
-            if (b->ticket->state.load(std::memory_order_acquire) == trlda_batch::kBuilding) {
+            if (b->ticket->state.load(std::memory_order_acquire) == st) {
                 b->destroy_when_built = true;
                 return TRLDA_OK;
             }
+            continue;
         }
+        break;
     }
     // a model's deferred statistics still read this batch: they are launched first (the guard
     // event below then covers them)
@@ -3775,7 +3952,7 @@ int trlda_model_estep_io_next(trlda_model *m, const trlda_batch *b, const trlda_
     // (the batches' indices are built on worker threads: trlda_batch_create)
     if (int rc_built = batch_wait(b))
         return rc_built;
-    if (next && next->ticket->state.load(std::memory_order_acquire) != trlda_batch::kBuilt)
+    if (next && !batch_announced(next))
         next = nullptr;                              // (not indexed yet: as good as not announced)
     // (the next E-step of a deferred stream: estep_device decides whether its launch carries the
     // statistics the call before left pending, or launches them first)
@@ -4077,8 +4254,10 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
                                double *sstats_dev, int max_iter, double threshold, int32_t *iters_dev)
 {
     // (the batches' indices are built on worker threads: trlda_batch_create)
+    CallClock call_clock;
     if (int rc_built = batch_wait(b))
         return rc_built;
+    call_clock.to(0);
     if (!m)
         return fail(TRLDA_ERR_ARG, "model is NULL");
     if (n_upcoming < 0 || (n_upcoming > 0 && !upcoming))
@@ -4089,7 +4268,7 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
     const trlda_batch *ready_up[2] = {nullptr, nullptr};
     for (int i_up = 0; i_up < n_upcoming && i_up < 2; ++i_up) {
         const trlda_batch *up = upcoming[i_up];
-        if (up && up->ticket->state.load(std::memory_order_acquire) == trlda_batch::kBuilt)
+        if (batch_announced(up))                     // (its upload is enqueued here if its index is there)
             ready_up[i_up] = up;
     }
     if (n_upcoming > 2)
@@ -4238,8 +4417,10 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
     if (cal_first)
         HIP_TRY(hipEventRecord(cal.e[0], l->stream));
     EstepOut out(sstats_dev);
+    call_clock.to(1);
     rc = estep_device(l, b, gamma_dev, out, max_iter, threshold, iters_dev, gamma0_dev,
                       n_upcoming > 1 ? upcoming[1] : nullptr);
+    call_clock.to(2);
     tr.mark();
     if (tr.on)
         std::fprintf(stderr, "lane %d call %d of the stretch: set-up %.1f us, caller's stream %.1f us, "
@@ -4284,6 +4465,8 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
     m->last_deferred = l->last_deferred; m->last_carried = l->last_carried;
     m->last_doc_kernel = l->last_doc_kernel; m->last_preamble_fused = l->last_preamble_fused;
     m->last_split_wgs = l->last_split_wgs; m->last_merged = l->last_merged;
+    call_clock.to(3);
+    g_call_us[7] += 1.0;
     return TRLDA_OK;
 }
 
@@ -4302,7 +4485,13 @@ int trlda_model_estep_corpus(trlda_model *m, int64_t n_docs, const int64_t *offs
         if (!sstats_ring[r])
             return fail(TRLDA_ERR_ARG, "corpus pass: a NULL statistics array");
     const int64_t n_batches = (n_docs + batch_size - 1) / batch_size;
-    constexpr int kAhead = 4, kBehind = 4;
+    // (a build is done ~170 us after its trlda_batch_create -- queue, grace period, index, upload calls: a
+    // batch announced two steps before its E-step at 30-45 us per step has to be made eight steps ahead)
+    static const int kAhead = [] {
+        const char *e = std::getenv("TRLDA_CORPUS_AHEAD");
+        return e ? std::max(1, std::min(16, std::atoi(e))) : 8;
+    }();
+    constexpr int kBehind = 4;
     const bool was_deferred = m->deferred_stats;
     const int was_lanes = m->lanes_wanted;
     m->deferred_stats = true;
@@ -6107,6 +6296,14 @@ extern "C" int trlda_debug_peek(trlda_model *m, int which, double *host, size_t 
     HIP_TRY(hipStreamSynchronize(m->stream));
     HIP_TRY(hipMemcpy(host, src, count * sizeof(double), hipMemcpyDeviceToHost));
     return TRLDA_OK;
+}
+
+extern "C" void trlda_debug_call_times(double *out16)
+{
+    for (int i = 0; i < 8; ++i) {
+        out16[i] = g_call_us[i];
+        out16[8 + i] = i < 7 ? 1e-3 * (double)g_build_ns[i].load() : (double)g_build_ns[i].load();
+    }
 }
 
 extern "C" void trlda_debug_ingest_counters(long long *out8)
