@@ -151,15 +151,23 @@ int trlda_dev_synchronize(int device);
  * (python/src/ldainterface.cpp:152-190).
  *
  * On the caller's thread: the validation -- every error of the arguments is this call's -- and one
- * copy of the three arrays into pinned memory (they are the caller's again on return).  The index
- * (csrc/batch_index.cpp) and the upload happen on the library's worker threads (TRLDA_INDEX_THREADS,
- * default 4; 0: on this thread, as before round 6), up to eight batches at a time; every entry point
- * that is handed the batch waits for them -- or, when no worker has started on it yet, does the
- * work itself, so that "create, use at once" costs what it did.  A batch destroyed before anybody
- * used it is never indexed.  A stream that makes its batches a few steps ahead of their use
- * (bench.py, value_end_to_end) pays ~12 us per 200 documents here instead of ~75.  A failed upload
- * (out of device memory) fails the batch's first use, with the build's status and message.
- * An announced batch (`next`, `upcoming[]` below) whose index is not there yet counts as not announced. */
+ * copy of the three arrays into pinned memory (they are the caller's again on return): ~8-12 us per
+ * 200 documents instead of ~75.  The index (csrc/batch_index.cpp: host work only) is built on the
+ * library's worker threads (TRLDA_INDEX_THREADS, default 4; 0: on this thread, as before round 6), up
+ * to two dozen batches at a time.  The workers make NO HIP call: a finished index is uploaded --
+ * an allocation, one copy on the library's upload stream, two events: ~15 us -- by a caller's thread,
+ * whichever comes first: the next trlda_batch_create (which uploads what was finished since the last
+ * one), the E-step the batch is announced to (`next`, `upcoming[]` below), or the batch's first user.
+ * Every entry point that is handed the batch waits for the index -- or, when no worker has started on
+ * it yet, does the work itself, so that "create, use at once" costs what it did.  A batch destroyed
+ * before anybody used it is never indexed.  An index is there ~170 us after its trlda_batch_create
+ * (a queue, 40 us in which a caller that uses its batch at once is left alone with it, ~80 us of work):
+ * a stream makes its batches eight steps ahead of their use (bench.py, value_end_to_end).  A failed
+ * upload (out of device memory) fails the batch's first use, with the build's status and message.
+ * An announced batch whose index is not there yet counts as not announced.
+ * (TRLDA_INDEX_UPLOAD=worker: the workers enqueue the uploads too, one at a time -- the first form of
+ * round 6, kept for A/B: four threads in hipMemcpyAsync / hipEventRecord beside the caller's launches
+ * spent 32-175 us per build in the runtime's locks.) */
 int trlda_batch_create(trlda_batch **out, int device, int V, int B,
                        const int32_t *indptr, const int32_t *ids, const int32_t *cnts);
 int trlda_batch_destroy(trlda_batch *batch);
@@ -348,8 +356,8 @@ int trlda_model_estep_io_ahead(trlda_model *model, const trlda_batch *batch,
  * lambda for every mini-batch of a corpus whose documents lie in HOST memory in CSR form -- `offsets`
  * (n_docs + 1, as trlda_docs_offsets), `ids`, `cnts`; mini-batch i = documents [i * batch_size,
  * min((i + 1) * batch_size, n_docs)) -- the reference's Python loop over do_e_step
- * (python/src/ldainterface.cpp:311-390) with the loop inside the library: batches are made four ahead
- * of their E-step (trlda_batch_create: index and upload on the worker threads), announced two ahead,
+ * (python/src/ldainterface.cpp:311-390) with the loop inside the library: batches are made eight ahead
+ * of their E-step (trlda_batch_create: index on the worker threads; TRLDA_CORPUS_AHEAD), announced two ahead,
  * stepped through deferred statistics and two lanes (both switched on for the call and put back),
  * destroyed four steps later.  gamma0_dev / gamma_dev: K x n_docs on the device (a document's K
  * values contiguous; gamma0 is only read); the statistics of mini-batch i go to

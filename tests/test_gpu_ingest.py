@@ -185,7 +185,7 @@ def test_used_at_once_or_after_a_while_the_same_e_step(hip, oracle):
 
 def test_a_corpus_pass_in_one_call(hip, oracle):
     """trlda_model_estep_corpus: a CSR corpus in host memory, the loop over its mini-batches inside the
-    library (batches made four ahead on the worker threads, deferred statistics, two lanes) -- gamma,
+    library (batches made eight ahead, indexed on the worker threads, deferred statistics, two lanes) -- gamma,
     iteration counts and every mini-batch's statistics bitwise those of a Python loop of do_e_step
     (python/src/ldainterface.cpp:311-390), a ragged last batch, a ring of statistics arrays shorter
     than the corpus; and against the oracle."""

@@ -1,4 +1,4 @@
-"""Host time of the end-to-end stream's calls one by one (GPU box): create (4 ahead), E-step, destroy."""
+"""Host time of the end-to-end stream's calls one by one (GPU box): create (AHEAD ahead), E-step, destroy."""
 import ctypes as C, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

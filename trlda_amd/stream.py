@@ -127,7 +127,7 @@ def corpus_pass(model, offsets, ids, cnts, batch_size, gamma0, gamma, sstats_rin
     out; mini-batch i is documents [i * batch_size, (i + 1) * batch_size).  ``gamma0`` / ``gamma``:
     K x n_docs on the device; the statistics of mini-batch i go to ``sstats_ring[i % len(sstats_ring)]``
     (at least three K x V device arrays).  Batches are indexed and uploaded by the library's worker
-    threads four steps ahead of their E-step.  Returns when everything is enqueued; the results
+    threads eight steps ahead of their E-step.  Returns when everything is enqueued; the results
     are complete on the model's stream (``model.lambdas`` or ``EStepStream.synchronize`` wait)."""
     import numpy as np
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
