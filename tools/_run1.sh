@@ -1,17 +1,9 @@
 #!/bin/bash
 cd /root/repo; mkdir -p gpurun_out
-out=gpurun_out/r06_k64_skip.txt
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_merged.py tests/test_gpu_deferred.py -q -x -m gpu 2>&1 | tail -2 > $out
-b() { python bench.py --steps 200 --headline-only --no-cpu-baseline --no-update-rates "$@" 2>/dev/null | python -c "
+out=gpurun_out/r06_corpus_thread.txt
+timeout 900 python -m pytest tests/test_gpu_ingest.py -q -x -m gpu 2>&1 | tail -2 > $out
+for rep in 1 2; do for t in 1 0; do
+TRLDA_CORPUS_THREAD=$t python bench.py --steps 200 --no-exchange-ab --no-cpu-baseline --no-update-rates 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.readlines()[-1]); print('$TAG $*', d['value'], d['ms_per_step'])" >> $out; }
-for rep in 1 2; do
-for TAG in new base; do
-export TAG
-if [ $TAG = base ]; then export TRLDA_LIB=/root/repo/trlda_amd/libtrlda_hip.base.so; else unset TRLDA_LIB; fi
-b
-b --topics 10 --words 1000 --batch 100 --mean-unique 50
-b --topics 20 --words 300 --batch 100 --mean-unique 40
-b --topics 50 --words 5000 --batch 200
-b --topics 64 --words 7000 --batch 200
+d=json.loads(sys.stdin.readlines()[-1]); e=d['value_end_to_end']; print('maker thread $t:', d['value'], e['value'], e['ms_per_step'], e['one_call']['value'], e['one_call']['ms_per_step'])" >> $out
 done; done
