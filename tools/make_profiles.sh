@@ -169,9 +169,15 @@ t_probes() {
 t_ingest() {
   ( python3 tools/index_rate.py; python3 tools/probes/index_phases.py ) 2>&1 | clean > $o/${tag}_index_rate.txt
   python3 tools/host_rate.py 2>&1 | clean > $o/${tag}_host_rates.txt
-  ( for a in 4 8; do AHEAD=$a STEPS=6000 python3 tools/probes/e2e_trace.py 2>&1 | clean | tail -3; done
-    TRLDA_INDEX_THREADS=0 STEPS=3000 python3 tools/probes/e2e_trace.py 2>&1 | clean | tail -3 ) > $o/${tag}_e2e_trace.txt
-  cat $o/${tag}_index_rate.txt $o/${tag}_host_rates.txt $o/${tag}_e2e_trace.txt
+  ( export NOGC=1 TRLDA_CALL_TIMES=1
+    for a in 4 8; do AHEAD=$a STEPS=6000 python3 tools/probes/e2e_trace.py 2>&1 | clean | grep -v "creates >"; done
+    echo "== TRLDA_INDEX_UPLOAD=worker (the workers enqueue the uploads, one at a time)"
+    AHEAD=8 TRLDA_INDEX_UPLOAD=worker STEPS=6000 python3 tools/probes/e2e_trace.py 2>&1 | clean | grep -v "creates >"
+    echo "== TRLDA_INDEX_THREADS=0 (index and upload inside trlda_batch_create)"
+    AHEAD=8 TRLDA_INDEX_THREADS=0 STEPS=3000 python3 tools/probes/e2e_trace.py 2>&1 | clean | grep -v "creates >"
+    echo "== resident batches (MODE=nocreate): the probe's documents on the device alone"
+    MODE=nocreate STEPS=3000 python3 tools/probes/e2e_trace.py 2>&1 | clean | grep -v "creates >" ) > $o/${tag}_e2e_trace_final.txt
+  cat $o/${tag}_index_rate.txt $o/${tag}_host_rates.txt $o/${tag}_e2e_trace_final.txt
 }
 
 t_lanes() {
