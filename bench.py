@@ -872,6 +872,8 @@ def main():
             value_end_to_end["one_call"] = {
                 "value": round(B * n_c / s_c[len(s_c) // 2], 1), "unit": "docs/s", "mini_batches": n_c,
                 "ms_per_step": round(1e3 * s_c[len(s_c) // 2] / n_c, 5),
+                "ms_per_step_all": [round(1e3 * x / n_c, 5) for x in s_c],
+                "lane_state_after": int(L.trlda_model_lane_state(model)),
                 "what": "trlda_model_estep_corpus: the same pass over %d mini-batches from one CSR corpus in host "
                         "memory, the loop inside the library" % n_c}
             del g0_c, g_c, ring_t
