@@ -380,11 +380,14 @@ long long trlda_model_lane_steps(const trlda_model *model);
  * device; two launches in flight means a launch LASTS about two steps (51 us where one starts every
  * 26), lanes that do not overlap have launches of one step's length; below 1.0 launches in flight
  * the lanes are dropped -- the stream of calls goes one launch at a time, as without the switch --
- * from 1.4 on they are kept (on two measurements in a row), in between the measurement is repeated (at
- * most eight times) -- and the lanes are measured AGAIN every 1024 steps for as long as they live: there
- * are process starts in which the launches overlap for a while and then do not; 3 two lanes, not looked
- * at (TRLDA_LANE_VERIFY=0).  trlda_model_lane_timing: what the last measurement found, microseconds
- * (0: not measured yet). */
+ * (the window ends with the later of the two lanes' launches).  Where a stretch of calls is long enough
+ * (64 calls without a flush) every look begins with what the lanes are to beat: eighteen calls in a row
+ * on ONE lane, timed the same way -- two lanes that are not 3 % faster than that on two looks in a row
+ * are dropped too, lanes that pay are kept (on two looks in a row) and looked at AGAIN every 1024 steps
+ * for as long as they live: there are process starts in which the launches overlap for a while and then
+ * do not.  A window during which the host did not keep the lanes fed is no verdict.  3 two lanes, not
+ * looked at (TRLDA_LANE_VERIFY=0).  trlda_model_lane_timing: what the last measurement found,
+ * microseconds (0: not measured yet). */
 int trlda_model_lane_state(const trlda_model *model);
 int trlda_model_lane_timing(const trlda_model *model, double *us_per_launch, double *us_per_step);
 /* with trlda_model_set_timing on: the summed duration (HIP events on the lanes' streams, one pair per
