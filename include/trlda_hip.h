@@ -382,7 +382,7 @@ long long trlda_model_lane_steps(const trlda_model *model);
  * the lanes are dropped -- the stream of calls goes one launch at a time, as without the switch --
  * (the window ends with the later of the two lanes' launches).  Where a stretch of calls is long enough
  * (64 calls without a flush) every look begins with what the lanes are to beat: eighteen calls in a row
- * on ONE lane, timed the same way -- two lanes that are not 3 % faster than that on two looks in a row
+ * on ONE lane, timed the same way -- two lanes that are not 3 % faster than that on two of the last four looks
  * are dropped too, lanes that pay are kept (on two looks in a row) and looked at AGAIN every 1024 steps
  * for as long as they live: there are process starts in which the launches overlap for a while and then
  * do not.  A window during which the host did not keep the lanes fed is no verdict.  3 two lanes, not

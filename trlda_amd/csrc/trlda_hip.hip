@@ -349,7 +349,7 @@ struct trlda_model {
         // they are to beat, measured the same way: phase 6, kLaneSoloLead + kLaneSoloSteps calls in a
         // row on lane 0 alone (no join: the other lane simply gets nothing), events behind the
         // lead-in's launch and the last one -- a step through ONE lane.  Two lanes that are not 3 %
-        // faster than that on two looks in a row are given up.
+        // faster than that on two of the last four looks are given up.
         hipEvent_t s[2] = {nullptr, nullptr};
         // (the window's end is the LATER of the two lanes' last launches: a window timed on lane 0's
         // stream alone reads half the true step when the device runs that lane ahead of the other --
@@ -359,7 +359,7 @@ struct trlda_model {
         float us_solo = 0.f, host_us_solo = 0.f;
         std::chrono::steady_clock::time_point solo_t0;
         int lead = 0;                     // steps through both lanes before the window opens
-        int worse = 0;                    // looks in a row at which two lanes did not pay
+        unsigned worse = 0;               // the last four looks, a bit each: two lanes did not pay
         // (the one-lane stretch is eighteen steps at one lane's speed: it begins kLaneSoloAfter calls
         // into a stretch, never in a caller's short stretches -- bench.py's 20-step regions between
         // fences get the window alone, as before, once a stretch has ended too early)
@@ -3796,7 +3796,7 @@ int trlda_model_set_stream(trlda_model *m, void *hip_stream)
         m->lane_cal.n = 0;
         m->lane_cal.tries = 0;
         m->lane_cal.keeps = 0;
-        m->lane_cal.worse = 0;
+        m->lane_cal.worse = 0u;
         if (m->lane_state == 1)
             m->lane_state = m->lane[0] ? 2 : 0;
     }
@@ -4434,9 +4434,11 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
                 cal.short_stretches = 0;
                 cal.us_solo = solo_ok ? 1e3f * solo_ms / kLaneSoloSteps : 0.f;
                 const bool solo_fed = solo_ok && cal.host_us_solo <= host_share * cal.us_solo;
+                if (solo_fed)                        // (a process whose lanes pay now and then: half its looks say no)
+                    cal.worse = ((cal.worse << 1) | (cal.us_step >= 0.97f * cal.us_solo ? 1u : 0u)) & 0xFu;
                 if (solo_fed && cal.us_step >= 0.97f * cal.us_solo) {
                     cal.keeps = 0;
-                    if (++cal.worse >= 2) {          // two lanes do not beat one: nothing gained
+                    if (__builtin_popcount(cal.worse) >= 2) {   // two of the last four looks: nothing gained
                         if ((rc = check_model(m, /*keep_pending=*/true)))
                             return rc;
                         m->lane_state = 1;
@@ -4446,7 +4448,6 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
                     cal.phase = 6;                   // (looked at again, at once)
                     cal.n = 0;
                 } else if (solo_fed) {               // two lanes pay: kept on two looks in a row
-                    cal.worse = 0;
                     if (++cal.keeps < 2) {
                         cal.phase = 6;
                         cal.n = 0;
