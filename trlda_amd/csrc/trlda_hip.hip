@@ -3067,6 +3067,17 @@ void stage_release(UploadContext &u, UploadContext::Stage *st)   // (u.mu held)
     u.stage_cv.notify_all();
 }
 
+// A batch's index from its pinned staging buffer into its device allocation, as a kernel of the upload
+// stream (16 bytes per lane straight over PCIe: pinned host memory is mapped into the device's address
+// space).  Not hipMemcpyAsync: that call takes 2.7 us of host time -- or 31-42, for whole passes over a
+// corpus at a time (profiles/r06_corpus_passes.txt: the end-to-end stream at 73-95 us per step instead of
+// 40, one pass in three), whatever the runtime waits for inside it.  A launch is 3-4 us, every time.
+__global__ __launch_bounds__(256) void blob_copy_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+        dst[i] = src[i];
+}
+
 // The index of batch `b` from the CSR arrays at the head of its staging buffer, into that buffer
 // (csrc/batch_index.cpp): host work only, NO HIP call -- on a worker thread, or on the thread of
 // whoever needs the batch first.  (Round 6, first form: the workers also enqueued the upload.  Four
@@ -3142,6 +3153,7 @@ int batch_upload(trlda_batch *b)
         return give_up(fail(TRLDA_ERR_HIP, "hipSetDevice failed"));
     // Under the upload context's lock only what is shared: the allocation and two events.
     UploadContext::Blob blob{nullptr, 0, nullptr};
+    bool blob_settled = false;
     {
         std::lock_guard<std::mutex> lock(u.mu);
         if (!u.stream && hipStreamCreateWithFlags(&u.stream, hipStreamNonBlocking) != hipSuccess) {
@@ -3162,6 +3174,7 @@ int batch_upload(trlda_batch *b)
                 if (pass == 1 && u.cache.size() < kBlobCacheMax / 2)
                     break;                           // rather a new allocation than a wait
                 blob = c;
+                blob_settled = pass == 0;            // (its last reader was SEEN to have finished: nothing to wait for)
                 u.cached_bytes -= blob.bytes;
                 u.cache.erase(u.cache.begin() + (long)i);
                 break;
@@ -3191,12 +3204,33 @@ int batch_upload(trlda_batch *b)
     b->blob_bytes = blob.bytes;
     mark(3);
     hipError_t err = hipSuccess;
-    const bool guard_wait = blob.done && stream_alive(blob.on, blob.on_owned);
-    if (guard_wait)                                  // the previous owner's last reader
+    const bool guard = blob.done && stream_alive(blob.on, blob.on_owned);
+    const bool guard_wait = guard && !blob_settled;
+    if (guard_wait)                                  // the previous owner's last reader, where it may still run
         err = hipStreamWaitEvent(u.stream, blob.done, 0);
     // (else: that stream and its work are gone; the event is dropped)
-    if (err == hipSuccess)
+    mark(4);
+    static const bool copy_by_kernel = [] {          // (TRLDA_UPLOAD_COPY=memcpy: hipMemcpyAsync, for A/B)
+        const char *e = std::getenv("TRLDA_UPLOAD_COPY");
+        return !(e && e[0] == 'm');
+    }();
+    if (err == hipSuccess && copy_by_kernel) {
+        // (the sections are 256-byte aligned and both buffers larger than the index: whole 16-byte words)
+        const size_t n16 = (total + 15) / 16;
+        // (sixteen workgroups: enough loads in flight for the PCIe link -- four take 67 us per step -- and
+        // few enough to find free CUs beside the documents: 128 waited for them, 53-64 us per step)
+        static const int copy_wgs = [] {
+            const char *e = std::getenv("TRLDA_UPLOAD_COPY_WGS");
+            return e ? std::max(1, std::atoi(e)) : 16;
+        }();
+        const unsigned grid = (unsigned)std::min<size_t>((n16 + 255) / 256, (size_t)copy_wgs);
+        hipLaunchKernelGGL(blob_copy_kernel, dim3(grid), dim3(256), 0, u.stream, static_cast<uint4 *>(b->blob),
+                           static_cast<const uint4 *>(st->host), n16);
+        err = hipGetLastError();
+    } else if (err == hipSuccess) {
         err = hipMemcpyAsync(b->blob, st->host, total, hipMemcpyHostToDevice, u.stream);
+    }
+    mark(5);
     if (err == hipSuccess)
         err = hipEventRecord(st->ev, u.stream);      // (the staging buffer is anybody's once this has passed)
     if (err == hipSuccess)
@@ -3209,7 +3243,7 @@ int batch_upload(trlda_batch *b)
     }
     mark(4);
     std::lock_guard<std::mutex> lock(u.mu);
-    if (guard_wait)
+    if (guard)
         u.spare(blob.done, blob.on, blob.on_owned);
     stage_release(u, st);
     b->slot = nullptr;
@@ -4624,7 +4658,11 @@ int trlda_model_estep_corpus(trlda_model *m, int64_t n_docs, const int64_t *offs
     const bool was_deferred = m->deferred_stats;
     const int was_lanes = m->lanes_wanted;
     m->deferred_stats = true;
-    m->lanes_wanted = 2;
+    static const int corpus_lanes = [] {             // (A/B: TRLDA_CORPUS_LANES=1)
+        const char *e = std::getenv("TRLDA_CORPUS_LANES");
+        return e && e[0] == '1' ? 1 : 2;
+    }();
+    m->lanes_wanted = corpus_lanes;
     std::vector<trlda_batch *> batch((size_t)n_batches, nullptr);
     std::vector<int32_t> indptr;
     auto make = [&](int64_t i) {
