@@ -155,7 +155,9 @@ int trlda_dev_synchronize(int device);
  * 200 documents instead of ~75.  The index (csrc/batch_index.cpp: host work only) is built on the
  * library's worker threads (TRLDA_INDEX_THREADS, default 4; 0: on this thread, as before round 6), up
  * to two dozen batches at a time.  The workers make NO HIP call: a finished index is uploaded --
- * an allocation, one copy on the library's upload stream, two events: ~15 us -- by a caller's thread,
+ * an allocation, one copy on the library's upload stream (a 16-workgroup kernel that reads the pinned
+ * buffer over PCIe; hipMemcpyAsync's call blocked for milliseconds now and then: TRLDA_UPLOAD_COPY=memcpy
+ * for A/B), two events: ~10 us -- by a caller's thread,
  * whichever comes first: the next trlda_batch_create (which uploads what was finished since the last
  * one), the E-step the batch is announced to (`next`, `upcoming[]` below), or the batch's first user.
  * Every entry point that is handed the batch waits for the index -- or, when no worker has started on
