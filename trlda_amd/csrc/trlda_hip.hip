@@ -3223,7 +3223,9 @@ int batch_upload(trlda_batch *b)
             const char *e = std::getenv("TRLDA_UPLOAD_COPY_WGS");
             return e ? std::max(1, std::atoi(e)) : 16;
         }();
-        const unsigned grid = (unsigned)std::min<size_t>((n16 + 255) / 256, (size_t)copy_wgs);
+        // (an index of megabytes -- a whole corpus as one batch -- is not in a tight pipeline: more loads in flight)
+        const unsigned grid = (unsigned)std::min<size_t>((n16 + 255) / 256,
+                                                         (size_t)copy_wgs * (total > ((size_t)4 << 20) ? 4 : 1));
         hipLaunchKernelGGL(blob_copy_kernel, dim3(grid), dim3(256), 0, u.stream, static_cast<uint4 *>(b->blob),
                            static_cast<const uint4 *>(st->host), n16);
         err = hipGetLastError();
