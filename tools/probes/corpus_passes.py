@@ -47,7 +47,7 @@ for rep in range(int(os.environ.get("PASSES", "12"))):
     d, di = c1 - c0, i1 - i0
     n = max(d[7], 1.0); nb = max(d[15], 1.0)
     print("pass %2d: %.1f us per step (calls returned after %.1f); lane call: wait for index %.1f, set-up %.1f, launch "
-          "sequence %.1f (launch %.1f); builds: queue %.1f grace %.1f index %.1f; uploads: allocation %.1f wait-event + records %.1f copy call %.1f; "
+          "sequence %.1f (launch %.1f); builds: queue %.1f grace %.1f index %.1f; uploads: allocation %.1f wait for the allocation's last reader %.1f copy call %.1f; "
           "ingest [worker %d, taken over %d, hipMalloc %d, stage held %d, stage upload %d]; lane state %d" % (
               rep, (t2 - t0) / N * 1e6, (t1 - t0) / N * 1e6, d[0] / n, d[1] / n, d[2] / n, d[5] / n, d[8] / nb, d[9] / nb,
               d[10] / nb, d[11] / nb, d[12] / nb, d[13] / nb, di[0], di[1], di[4], di[6], di[7], L.trlda_model_lane_state(model)), flush=True)

@@ -68,7 +68,7 @@ if hasattr(raw, "trlda_debug_call_times"):
     print("   lane call, us per call: wait for the index %.1f, set-up %.1f, launch sequence %.1f (upload events %.1f, launch %.1f, reader marks %.1f), rest %.1f" % (
         ct[0] / n, ct[1] / n, ct[2] / n, ct[4] / n, ct[5] / n, ct[6] / n, ct[3] / n))
     nb_ = max(ct[15], 1.0)
-    print("   a worker's build, us: queue %.1f, grace %.1f, plan + fill %.1f, allocation %.1f, stream calls %.1f, upload wait %.1f, publication %.1f (%d builds)" % (
+    print("   a worker's build, us: queue %.1f, grace %.1f, plan + fill %.1f, allocation %.1f, wait for the allocation's last reader %.1f, copy call %.1f, publication %.1f (%d builds)" % (
         *[ct[8 + i] / nb_ for i in range(7)], int(ct[15])))
 c = np.array(rows)[:, 0]
 big = np.nonzero(c > 100)[0]
