@@ -139,6 +139,65 @@ def test_a_corpus_of_batches_made_before_the_first_is_used(hip, raw):
         raw.trlda_batch_destroy(h)
 
 
+@pytest.mark.timeout(300)
+def test_four_threads_make_use_and_drop_batches_at_once(hip, raw):
+    """The build tickets under real concurrency: four caller threads (ctypes releases the GIL) make
+    batches ahead, read some at once and some late, drop some unused and some while a worker or another
+    thread's trlda_batch_create is at them (that call uploads whatever index is finished, whoever made
+    the batch).  Every index read back is the host's, bitwise; nothing hangs, nothing is lost
+    (ldainterface.cpp:152-190)."""
+    import threading
+    import torch
+    from trlda_amd.utils.synthetic import make_corpus
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    V = 2000
+    cases = [make_corpus(40 + 11 * q, V, seed=900 + q, mean_unique=30 + 7 * q) for q in range(6)]
+    want = [host_index(raw, V, *c, cus) for c in cases]
+    errors = []
+
+    def worker(t):
+        try:
+            rng = np.random.RandomState(t)
+            window = []
+            for n in range(400):
+                q = int(rng.randint(len(cases)))
+                ip, ii, cc = cases[q]
+                h = C.c_void_p()
+                assert raw.trlda_batch_create(C.byref(h), 0, V, len(ip) - 1, ip.ctypes.data, ii.ctypes.data,
+                                              cc.ctypes.data) == 0
+                window.append((h, q))
+                act = rng.randint(4)
+                if act == 0:                         # read the newest at once (takes the build over, or waits)
+                    hh, qq = window.pop()
+                elif act == 1 and len(window) > 6:   # read one made a while ago
+                    hh, qq = window.pop(0)
+                elif act == 2:                       # drop the newest unread
+                    raw.trlda_batch_destroy(window.pop()[0])
+                    continue
+                else:
+                    if len(window) > 10:
+                        raw.trlda_batch_destroy(window.pop(0)[0])
+                    continue
+                buf, offs, sizes = want[qq]
+                got = np.empty_like(buf)
+                assert raw.trlda_debug_batch_blob(hh, got.ctypes.data, got.size, None) == 0
+                for name, o, nb in zip(gold.SECTIONS, offs, sizes):
+                    assert np.array_equal(got[o:o + nb], buf[o:o + nb]), (t, n, name)
+                raw.trlda_batch_destroy(hh)
+            for hh, _ in window:
+                raw.trlda_batch_destroy(hh)
+        except BaseException as exc:                 # noqa: BLE001 (reported by the main thread)
+            errors.append((t, repr(exc)[:300]))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(240)
+    assert not any(th.is_alive() for th in threads), "a thread hangs"
+    assert not errors, errors
+
+
 def test_errors_of_the_arguments_stay_with_the_call(hip, raw):
     ip = np.array([0, 2, 3], np.int32); cc = np.ones(3, np.int32)
     for bad in ([0, 9, 1], [0, -1, 1]):
