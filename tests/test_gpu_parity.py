@@ -171,6 +171,62 @@ def test_hoffman_cross_implementation(hip):
     assert np.corrcoef(f["sstats_hoffman"].ravel(), s.ravel())[0, 1] > 0.99
 
 
+@pytest.mark.parametrize("K,V,B,mean,long_lens", [(10, 1000, 700, 50, (190, 160, 145, 144, 129)),
+                                                  (20, 3000, 400, 60, (191, 150, 150, 140, 133, 130, 129, 129)),
+                                                  (32, 2000, 64, 40, (180, 130, 129)),
+                                                  (16, 1500, 300, 50, (600, 400))])
+def test_a_wave_per_document_beside_long_documents(hip, oracle, K, V, B, mean, long_lens):
+    """The wave-per-document form does not depend on EVERY document being short: the documents of more
+    than 128 words (they lead the batch's sorted order) keep a workgroup each -- the tiered launch's
+    register / single-orientation bodies -- and the workgroups behind them take eight short documents
+    each (DocKernelArgs::small_block0).  Plain E-steps, an update loop (merged launches), early exits:
+    against the oracle at 1e-9 with identical iteration counts, against the tiered launch without the
+    form at 1e-12.  Where long documents are split over workgroups (the last case: > 192 words) the form
+    is not taken (lda.cpp:174-204)."""
+    import trlda_amd
+    from trlda_amd import _ffi
+    from trlda_amd.documents import CSRDocuments
+    from trlda_amd.utils.synthetic import make_corpus
+    lens = np.clip(np.random.RandomState(K + B).poisson(mean, B), 1, 128)
+    where = np.random.RandomState(B).choice(B, len(long_lens), replace=False)
+    lens[where] = long_lens
+    ip, ii, cc = make_corpus(B, V, seed=15 + K, mean_unique=mean, lengths=np.minimum(lens, V))
+    docs = CSRDocuments(ip, ii, cc)
+    lam = seeded_lambda(oracle, 41 + K, K, V)
+    g0 = seeded_gamma(oracle, 42 + K, K, B)
+    split_case = max(long_lens) > 192
+    out = {}
+    for kind, name in ((3, "small"), (4, "reg")):
+        m = make_model(K, V, lam, D=5000)
+        _ffi.check(hip.trlda_model_set_doc_kernel(m._handle, kind))
+        g, s, it = m.update_variables(docs, latents=g0, max_iter=60, return_iterations=True)
+        used = hip.trlda_model_last_doc_kernel(m._handle)
+        used = used.decode() if isinstance(used, bytes) else used
+        if not split_case:
+            assert ("small" in used) == (name == "small"), used
+        trlda_amd.seed(78)
+        m.update_parameters(docs, max_iter_tr=3, max_iter_inference=20)
+        m.update_parameters(docs, max_iter_tr=0, max_iter_inference=20)
+        out[name] = (g, s, it, m.lambdas, used)
+        m.close()
+    go, so, ito = oracle.estep(lam, .1, ip, ii, cc, g0, 60, 1e-3)
+    g, s, it, lam_s, used = out["small"]
+    assert np.array_equal(it, ito) and (it < 60).any()
+    assert relerr(g, go) < TIGHT_RTOL
+    check_sstats(s, so)
+    gr, sr, itr, lam_r, _ = out["reg"]
+    assert np.array_equal(it, itr) and relerr(g, gr) < 1e-12 and relerr(lam_s, lam_r) < 1e-9
+    # the default: taken where the SHORT documents alone outnumber the CUs
+    m = make_model(K, V, lam, D=5000)
+    g_d, _, it_d = m.update_variables(docs, latents=g0, max_iter=60, return_iterations=True)
+    used_d = hip.trlda_model_last_doc_kernel(m._handle)
+    used_d = used_d.decode() if isinstance(used_d, bytes) else used_d
+    if not split_case:
+        assert ("small" in used_d) == (B - len(long_lens) > 256), (B, used_d)
+    assert np.array_equal(it_d, it)
+    m.close()
+
+
 def test_goldens_through_the_wave_per_document_body(hip, sampler):
     """VERDICT r5 item 5's gate: the reference's own vectors f1a (K = 10), f1b (K = 20) and the Hoffman
     cross-check f7 (K = 20; onlinelda_test.py:39-68) through estep_docs_small_body, forced with

@@ -662,6 +662,9 @@ struct DocKernelArgs {
                                           // launch's topic-factor workgroups come FIRST, so that nothing
                                           // a document waits for can be queued behind it); else 0
     int docs_per_wg;                      // 1; 8: a WAVE per document (estep_docs_small_body, K <= 32)
+    // ... from document workgroup small_block0 on (a tiered launch: the workgroups before it take one
+    // document of more than 128 words each, the batch's first small_first in its sorted order)
+    int small_block0, small_first;
 };
 
 // the document workgroup's index among the launch's document workgroups
@@ -1699,7 +1702,8 @@ __device__ __forceinline__ void estep_docs_reg_body(const DocKernelArgs &a, doub
 // register body's (lda.cpp:174-204); the sums are taken in another order (butterfly instead of eight
 // partials), so the results agree to rounding, the iteration counts in every test.  The topic factors
 // of the fused preamble are formed once per workgroup by the same code as above.  Every document of
-// the launch has at most 128 words (the host checks); a.docs_per_wg = 8.
+// the body's workgroups has at most 128 words (the host checks); a.docs_per_wg = 8.  In a tiered launch the
+// longer documents -- the first of the batch's sorted order -- keep a workgroup each in front of them.
 __device__ __forceinline__ void estep_docs_small_body(const DocKernelArgs &a, double *lds)
 {
     constexpr int T = kRegThreads, KM = 32;
@@ -1712,7 +1716,7 @@ __device__ __forceinline__ void estep_docs_small_body(const DocKernelArgs &a, do
         topic_scale_load<T>(K, a.G, a.partial, pv);
 
     const int bid = doc_block(a);
-    const int di = bid * 8 + wid;                    // this wave's document, in the batch's sorted order
+    const int di = a.small_first + (bid - a.small_block0) * 8 + wid;   // this wave's document, in the batch's sorted order
     const bool doc_on = di < a.B;                    // wave-uniform
     const int dc = min(di, a.B - 1);
     const int4 meta = reinterpret_cast<const int4 *>(a.pad_meta)[dc];
@@ -1729,7 +1733,7 @@ __device__ __forceinline__ void estep_docs_small_body(const DocKernelArgs &a, do
     double ck0 = 1.0;
     if (tid < K && a.scale_in && !a.scale_wait) {    // finished by the launch that prepared them
         ck0 = a.scale_in[2 * K + tid];
-        if (bid == 0 && a.scale_out) {
+        if (bid == 0 && a.scale_out) {               // (a tiered launch: document workgroup 0 is a register body's)
             a.scale_out[tid] = a.scale_in[tid];
             a.scale_out[K + tid] = a.scale_in[K + tid];
             a.scale_out[2 * K + tid] = ck0;

@@ -676,7 +676,9 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_tiered_merged_kernel(D
     }
     merged_doc_stamp(mg, 0);
     const int n = a.pad_meta[4 * (size_t)rel * a.meta_i4 + 1];
-    if (a.meta_i4 == 2 && a.pad_meta[4 * ((size_t)rel * 2 + 1) + 1] > 1) {
+    if (a.docs_per_wg == 8 && rel >= a.small_block0) {   // block-uniform: K <= 32, eight short documents
+        estep_docs_small_body(a, lds);
+    } else if (a.meta_i4 == 2 && a.pad_meta[4 * ((size_t)rel * 2 + 1) + 1] > 1) {
         estep_docs_reg_body<0, true>(a, lds);        // one segment of a document split over CUs
     } else if (n <= 128) {
         estep_docs_reg_body<0>(a, lds);
@@ -1328,7 +1330,9 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_tiered_deferred_kernel
         return;
     }
     const int n = a.pad_meta[4 * (size_t)bid * a.meta_i4 + 1];
-    if (a.meta_i4 == 2 && a.pad_meta[4 * ((size_t)bid * 2 + 1) + 1] > 1) {
+    if (a.docs_per_wg == 8 && bid >= a.small_block0) {   // block-uniform: K <= 32, eight short documents
+        estep_docs_small_body(a, lds);
+    } else if (a.meta_i4 == 2 && a.pad_meta[4 * ((size_t)bid * 2 + 1) + 1] > 1) {
         estep_docs_reg_body<0, true>(a, lds);        // one segment of a document split over CUs
     } else if (n <= 128) {
         estep_docs_reg_body<0>(a, lds);

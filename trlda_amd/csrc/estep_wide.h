@@ -672,6 +672,10 @@ __global__ __launch_bounds__(kRegThreads) void estep_docs_tiered_kernel(DocKerne
         docs_launch_preamble(pre, lds, (int)blockIdx.x);
         return;
     }
+    if (a.docs_per_wg == 8 && (int)blockIdx.x >= a.small_block0) {   // block-uniform: K <= 32, eight short documents
+        estep_docs_small_body(a, lds);
+        return;
+    }
     // (document, length, CSR offset, 0) [, (segment, segments, exchange row, document length)]
     const int n = a.pad_meta[4 * (size_t)blockIdx.x * a.meta_i4 + 1];
     if (a.meta_i4 == 2 && a.pad_meta[4 * ((size_t)blockIdx.x * 2 + 1) + 1] > 1) {

@@ -1657,9 +1657,18 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
     // documents 3.7 against 5.6 M: profiles/r06_small_k.txt), or when asked for
     int cus_now = 256;
     (void)hipDeviceGetAttribute(&cus_now, hipDeviceAttributeMultiprocessorCount, m->device);
-    const bool small = (m->small_k > 0 || (m->small_k < 0 && B > cus_now)) && K <= 32 && K % 2 == 0 && B > 0 &&
-                       db->max_n <= 128 && !atomic && m->doc_threads == 0 && m->doc_kernel == TRLDA_DOCS_AUTO;
-    const int doc_wgs = small ? (B + 7) / 8 : will_split ? db->n_wg : B;
+    // Documents of more than 128 words -- they lead the batch's sorted order -- keep a workgroup each, in
+    // front of the waves' workgroups of the same (tiered) launch: a batch does not lose the form to a
+    // few long documents (not where they are split over workgroups, or one in sixteen and more)
+    int n_long = 0;
+    if (db->max_n > 128)
+        while (n_long < B && db->sorted_len[(size_t)n_long] > 128)
+            ++n_long;
+    const bool small = (m->small_k > 0 || (m->small_k < 0 && B - n_long > cus_now)) && K <= 32 && K % 2 == 0 && B > 0 &&
+                       (n_long == 0 || (!will_split && n_long * 16 <= B)) && !atomic && m->doc_threads == 0 &&
+                       m->doc_kernel == TRLDA_DOCS_AUTO;
+    const int small_wgs = n_long + (B - n_long + 7) / 8;
+    const int doc_wgs = small ? small_wgs : will_split ? db->n_wg : B;
     // (... a matter of speed: the helpers run UNDER the documents only when the documents leave
     // CUs free -- a document workgroup fills one.  Safety does not depend on it: estep_merged.h)
     int cus = 256;
@@ -1869,6 +1878,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         a.done_counter = nullptr; a.scale_wait = nullptr; a.done_target = 0;
         a.go_flags = nullptr; a.n_go = 0; a.block0 = 0;
         a.docs_per_wg = small ? 8 : 1;
+        a.small_block0 = a.small_first = small ? n_long : 0;
         a.epoch = m->merged_epoch + 1u;              // (of this launch, if it turns out to be merged)
         if (comb) {                                  // finished by workgroups of this launch
             a.scale_in = m->scale_comb;
@@ -1982,7 +1992,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
             // per-workgroup layout; one row of K doubles per (segment, iteration), NaN before
             // the launch.  Not with an exchange buffer beyond 256 MB (max_iter in the thousands):
             // those batches keep one workgroup per document.
-            int n_wgs = small ? (n_reg + 7) / 8 : n_reg;        // document workgroups of the launch
+            int n_wgs = small ? small_wgs : n_reg;              // document workgroups of the launch
             const size_t xcount = (size_t)db->n_xrows * (size_t)(max_iter + 1) * (size_t)K;
             if (tiered && m->split_docs && db->n_wg > 0 && db->split_pays && max_iter > 0 &&
                 xcount * sizeof(double) <= ((size_t)256 << 20)) {
