@@ -1658,14 +1658,15 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
     int cus_now = 256;
     (void)hipDeviceGetAttribute(&cus_now, hipDeviceAttributeMultiprocessorCount, m->device);
     // Documents of more than 128 words -- they lead the batch's sorted order -- keep a workgroup each, in
-    // front of the waves' workgroups of the same (tiered) launch: a batch does not lose the form to a
-    // few long documents (not where they are split over workgroups, or one in sixteen and more)
+    // front of the waves' workgroups of the same (tiered) launch: a batch does not lose the form to its
+    // long documents (CU-time: a long one 27-50 us, a short one 46 / 8 -- the form pays as long as most
+    // are short; not where long documents are split over workgroups, whose layout the waves do not read)
     int n_long = 0;
     if (db->max_n > 128)
         while (n_long < B && db->sorted_len[(size_t)n_long] > 128)
             ++n_long;
     const bool small = (m->small_k > 0 || (m->small_k < 0 && B - n_long > cus_now)) && K <= 32 && K % 2 == 0 && B > 0 &&
-                       (n_long == 0 || (!will_split && n_long * 16 <= B)) && !atomic && m->doc_threads == 0 &&
+                       (n_long == 0 || (!will_split && n_long * 2 <= B)) && !atomic && m->doc_threads == 0 &&
                        m->doc_kernel == TRLDA_DOCS_AUTO;
     const int small_wgs = n_long + (B - n_long + 7) / 8;
     const int doc_wgs = small ? small_wgs : will_split ? db->n_wg : B;
