@@ -221,8 +221,8 @@ int trlda_model_set_doc_threads(trlda_model *model, int threads);
 #define TRLDA_DOCS_WIDE 2
 /* K <= 32 (even): a WAVE per document of at most 128 words, eight documents per workgroup, no
  * LDS or barrier inside the fixed point (csrc/estep_kernels.h, estep_docs_small_body; round 6); longer
- * documents keep a workgroup each in the same launch (not where half of them are longer, or where long
- * documents are split over workgroups: then the batch goes without the form).  A
+ * documents keep their workgroups -- one each, or a segment each where they are split -- in front of them
+ * in the same launch (not where more than half of the documents are longer).  A
  * throughput form -- a document takes 46-55 us on one wave against 30 on eight, but a CU holds eight
  * of them: the default for batches with more short documents than the device has CUs (K = 10, 6400
  * documents: 38.5 against 9.7 M docs/s); _SMALL asks for it at any batch size, _REG for the

@@ -174,15 +174,17 @@ def test_hoffman_cross_implementation(hip):
 @pytest.mark.parametrize("K,V,B,mean,long_lens", [(10, 1000, 700, 50, (190, 160, 145, 144, 129)),
                                                   (20, 3000, 400, 60, (191, 150, 150, 140, 133, 130, 129, 129)),
                                                   (32, 2000, 64, 40, (180, 130, 129)),
-                                                  (16, 1500, 300, 50, (600, 400))])
+                                                  (16, 1500, 300, 50, (600, 400)),
+                                                  (10, 1000, 900, 60, (1500, 700, 300, 260, 193, 192, 150)),
+                                                  (20, 2500, 64, 30, (2500, 520))])
 def test_a_wave_per_document_beside_long_documents(hip, oracle, K, V, B, mean, long_lens):
     """The wave-per-document form does not depend on EVERY document being short: the documents of more
     than 128 words (they lead the batch's sorted order) keep a workgroup each -- the tiered launch's
     register / single-orientation bodies -- and the workgroups behind them take eight short documents
     each (DocKernelArgs::small_block0).  Plain E-steps, an update loop (merged launches), early exits:
     against the oracle at 1e-9 with identical iteration counts, against the tiered launch without the
-    form at 1e-12.  Where long documents are split over workgroups (the last case: > 192 words) the form
-    is not taken (lda.cpp:174-204)."""
+    form at 1e-12.  Long documents that are split over workgroups (the last cases: > 192 words) keep
+    their segments' workgroups in front of the waves' (lda.cpp:174-204)."""
     import trlda_amd
     from trlda_amd import _ffi
     from trlda_amd.documents import CSRDocuments
@@ -194,7 +196,7 @@ def test_a_wave_per_document_beside_long_documents(hip, oracle, K, V, B, mean, l
     docs = CSRDocuments(ip, ii, cc)
     lam = seeded_lambda(oracle, 41 + K, K, V)
     g0 = seeded_gamma(oracle, 42 + K, K, B)
-    split_case = max(long_lens) > 192
+    split_case = False                               # (split documents go with the form as well)
     out = {}
     for kind, name in ((3, "small"), (4, "reg")):
         m = make_model(K, V, lam, D=5000)

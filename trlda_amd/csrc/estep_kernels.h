@@ -1719,9 +1719,24 @@ __device__ __forceinline__ void estep_docs_small_body(const DocKernelArgs &a, do
     const int di = a.small_first + (bid - a.small_block0) * 8 + wid;   // this wave's document, in the batch's sorted order
     const bool doc_on = di < a.B;                    // wave-uniform
     const int dc = min(di, a.B - 1);
-    const int4 meta = reinterpret_cast<const int4 *>(a.pad_meta)[dc];
-    const int32_t *__restrict__ pids = a.pad_ids + (size_t)dc * kRegMaxN;
-    const int id0 = pids[lane], id1 = pids[64 + lane];
+    int4 meta;
+    int id0, id1;
+    if (a.meta_i4 == 2) {
+        // (launch-uniform: the workgroups in front hold segments of split documents, pad_meta / pad_ids are
+        // THEIR layout -- the waves find their documents through the batch's order and its CSR arrays)
+        const int dd = a.order[dc];
+        const int q0 = a.indptr[dd], nn = a.indptr[dd + 1] - q0;
+        meta = make_int4(dd, nn, q0, 0);
+        id0 = a.ids[q0 + min(lane, max(nn - 1, 0))];
+        id1 = a.ids[q0 + min(lane + 64, max(nn - 1, 0))];
+        if (nn == 0)
+            id0 = id1 = 0;
+    } else {
+        meta = reinterpret_cast<const int4 *>(a.pad_meta)[dc];
+        const int32_t *__restrict__ pids = a.pad_ids + (size_t)dc * kRegMaxN;
+        id0 = pids[lane];
+        id1 = pids[64 + lane];
+    }
     const int d = meta.x, n = doc_on ? meta.y : 0, p0 = meta.z;
     const int kt = lane >> 1;                        // this lane's topic (lanes 2 k and 2 k + 1: topic k)
     const bool k_on = kt < K;

@@ -1660,15 +1660,19 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
     // Documents of more than 128 words -- they lead the batch's sorted order -- keep a workgroup each, in
     // front of the waves' workgroups of the same (tiered) launch: a batch does not lose the form to its
     // long documents (CU-time: a long one 27-50 us, a short one 46 / 8 -- the form pays as long as most
-    // are short; not where long documents are split over workgroups, whose layout the waves do not read)
-    int n_long = 0;
+    // are short; split documents keep their segments' workgroups, and the waves find their documents
+    // through the batch's order and CSR arrays instead of the padded rows)
+    int n_long = 0, n_long_wgs = 0;                  // ... and the workgroups they take (split: a segment each)
     if (db->max_n > 128)
-        while (n_long < B && db->sorted_len[(size_t)n_long] > 128)
-            ++n_long;
+        for (; n_long < B && db->sorted_len[(size_t)n_long] > 128; ++n_long) {
+            const int n = db->sorted_len[(size_t)n_long];
+            const int c = (n + trlda::kSplitSegN - 1) / trlda::kSplitSegN;
+            n_long_wgs += (will_split && n > trlda::kSplitMinN && c <= trlda::kSplitMaxSeg) ? c : 1;   // (batch_index.cpp)
+        }
     const bool small = (m->small_k > 0 || (m->small_k < 0 && B - n_long > cus_now)) && K <= 32 && K % 2 == 0 && B > 0 &&
-                       (n_long == 0 || (!will_split && n_long * 2 <= B)) && !atomic && m->doc_threads == 0 &&
+                       (n_long == 0 || n_long * 2 <= B) && !atomic && m->doc_threads == 0 &&
                        m->doc_kernel == TRLDA_DOCS_AUTO;
-    const int small_wgs = n_long + (B - n_long + 7) / 8;
+    const int small_wgs = n_long_wgs + (B - n_long + 7) / 8;
     const int doc_wgs = small ? small_wgs : will_split ? db->n_wg : B;
     // (... a matter of speed: the helpers run UNDER the documents only when the documents leave
     // CUs free -- a document workgroup fills one.  Safety does not depend on it: estep_merged.h)
@@ -1879,7 +1883,8 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
         a.done_counter = nullptr; a.scale_wait = nullptr; a.done_target = 0;
         a.go_flags = nullptr; a.n_go = 0; a.block0 = 0;
         a.docs_per_wg = small ? 8 : 1;
-        a.small_block0 = a.small_first = small ? n_long : 0;
+        a.small_block0 = small ? n_long_wgs : 0;
+        a.small_first = small ? n_long : 0;
         a.epoch = m->merged_epoch + 1u;              // (of this launch, if it turns out to be merged)
         if (comb) {                                  // finished by workgroups of this launch
             a.scale_in = m->scale_comb;
@@ -2007,10 +2012,10 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
                 a.meta_i4 = 2;
                 a.xbuf = m->xbuf;
                 a.xerr = m->xerr;
-                n_wgs = db->n_wg;
+                n_wgs = small ? small_wgs : db->n_wg;   // (the waves' workgroups behind the long documents' segments)
             }
             const bool split = a.meta_i4 == 2;
-            m->last_split_wgs = small ? 0 : n_wgs - n_reg;
+            m->last_split_wgs = small ? n_long_wgs - n_long : n_wgs - n_reg;
             if (small)
                 m->last_doc_kernel = "estep_docs_small_body";
             int lds_rows = 0;
