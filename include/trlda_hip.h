@@ -219,7 +219,7 @@ int trlda_model_set_doc_threads(trlda_model *model, int threads);
 #define TRLDA_DOCS_AUTO 0
 #define TRLDA_DOCS_GENERAL 1
 #define TRLDA_DOCS_WIDE 2
-/* K <= 32 (even): a WAVE per document of at most 128 words, eight documents per workgroup, no
+/* K <= 32: a WAVE per document of at most 128 words, eight documents per workgroup, no
  * LDS or barrier inside the fixed point (csrc/estep_kernels.h, estep_docs_small_body; round 6); longer
  * documents keep their workgroups -- one each, or a segment each where they are split -- in front of them
  * in the same launch (not where more than half of the documents are longer).  A

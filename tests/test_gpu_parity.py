@@ -1089,7 +1089,8 @@ print("RCCL1-OK")
 
 
 @pytest.mark.parametrize("K,V,B,mean", [(10, 1000, 100, 60), (20, 300, 64, 40), (32, 2000, 37, 100), (2, 50, 9, 6),
-                                        (16, 500, 200, 120), (10, 1000, 700, 50)])
+                                        (16, 500, 200, 120), (10, 1000, 700, 50),
+                                        (7, 400, 300, 25), (15, 800, 64, 40), (31, 2000, 300, 60)])   # (odd K: 8-byte row loads)
 def test_a_wave_per_document_at_small_k(hip, oracle, K, V, B, mean):
     """Round 6: at K <= 32 a document is one WAVE -- rows in registers, the sums over
     the words by a transposing butterfly, no LDS or barrier inside the fixed point

@@ -1759,12 +1759,20 @@ __device__ __forceinline__ void estep_docs_small_body(const DocKernelArgs &a, do
     {
         const double *r0 = a.eeb + (size_t)id0 * K, *r1 = a.eeb + (size_t)id1 * K;
         const bool on0 = lane < n, on1 = lane + 64 < n;
+        const bool k_even = (K & 1) == 0;            // (rows of an odd K are 8-byte aligned only: a double at a time)
 #pragma unroll
         for (int k = 0; k < KM; k += 2) {
             double2 v0 = make_double2(0.0, 0.0), v1 = make_double2(0.0, 0.0);
-            if (k < K) {                             // launch-uniform
+            if (k < K && k_even) {                   // launch-uniform
                 v0 = *reinterpret_cast<const double2 *>(r0 + k);
                 v1 = *reinterpret_cast<const double2 *>(r1 + k);
+            } else if (k < K) {
+                v0.x = r0[k];
+                v1.x = r1[k];
+                if (k + 1 < K) {
+                    v0.y = r0[k + 1];
+                    v1.y = r1[k + 1];
+                }
             }
             u0[k] = on0 ? v0.x : 0.0; u0[k + 1] = on0 ? v0.y : 0.0;
             u1[k] = on1 ? v1.x : 0.0; u1[k + 1] = on1 ? v1.y : 0.0;

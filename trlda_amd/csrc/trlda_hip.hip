@@ -1669,7 +1669,7 @@ int estep_device(trlda_model *m, const trlda_batch *b, double *gamma_dev, EstepO
             const int c = (n + trlda::kSplitSegN - 1) / trlda::kSplitSegN;
             n_long_wgs += (will_split && n > trlda::kSplitMinN && c <= trlda::kSplitMaxSeg) ? c : 1;   // (batch_index.cpp)
         }
-    const bool small = (m->small_k > 0 || (m->small_k < 0 && B - n_long > cus_now)) && K <= 32 && K % 2 == 0 && B > 0 &&
+    const bool small = (m->small_k > 0 || (m->small_k < 0 && B - n_long > cus_now)) && K <= 32 && B > 0 &&
                        (n_long == 0 || n_long * 2 <= B) && !atomic && m->doc_threads == 0 &&
                        m->doc_kernel == TRLDA_DOCS_AUTO;
     const int small_wgs = n_long_wgs + (B - n_long + 7) / 8;
