@@ -884,6 +884,16 @@ def main():
         for i in range(4):
             step(pos[0] + i)
         pos[0] += 4
+        # (the lanes are judged on the stream they carry: a verdict reached on THIS leg's stream -- host-paced,
+        # uploads beside the launches -- is that leg's; the legs behind it time the resident stream again)
+        if lane_state == 2 and int(L.trlda_model_lane_state(model)) == 1:
+            fence()
+            _ffi.check(L.trlda_model_set_stream(model, _ffi.vp(stream)))   # (its lanes are looked at afresh)
+            value_end_to_end["lanes_given_up_on_this_leg"] = True
+            for i in range(8):
+                step(pos[0] + i)
+            pos[0] += 8
+            fence()
 
     # N > 1: the identical step (documents -> statistics -> M-step, no prefetch) WITHOUT the
     # exchange, timed on rank 0 alone while the other ranks wait: the like-for-like one-GPU

@@ -382,15 +382,16 @@ long long trlda_model_lane_steps(const trlda_model *model);
  * on the other); 1 the lanes were given up -- no such pair was to be had, or the MEASUREMENT said so:
  * after 96 steps through the lanes one launch of a lane and the four that follow it are timed on the
  * device; two launches in flight means a launch LASTS about two steps (51 us where one starts every
- * 26), lanes that do not overlap have launches of one step's length; below 1.0 launches in flight
- * the lanes are dropped -- the stream of calls goes one launch at a time, as without the switch --
- * (the window ends with the later of the two lanes' launches).  Where a stretch of calls is long enough
- * (64 calls without a flush) every look begins with what the lanes are to beat: eighteen calls in a row
- * on ONE lane, timed the same way -- two lanes that are not 3 % faster than that on two of the last four looks
- * are dropped too, lanes that pay are kept (on two looks in a row) and looked at AGAIN every 1024 steps
- * for as long as they live: there are process starts in which the launches overlap for a while and then
- * do not.  A window during which the host did not keep the lanes fed is no verdict.  3 two lanes, not
- * looked at (TRLDA_LANE_VERIFY=0).  trlda_model_lane_timing: what the last measurement found,
+ * 26), lanes that do not overlap have launches of one step's length: below 1.0 launches in flight a
+ * look says NO (the window ends with the later of the two lanes' launches).  Where a stretch of calls is
+ * long enough (64 calls without a flush) every look begins with what the lanes are to beat: eighteen
+ * calls in a row on ONE lane, timed the same way -- two lanes that are not 3 % faster than that: NO.  When
+ * two of the last four looks said no the lanes are dropped -- the stream of calls goes one launch at a
+ * time, as without the switch; a look that said no is followed by the next at once; lanes that pay are
+ * kept (on two looks in a row) and looked at AGAIN every 1024 steps for as long as they live: there are
+ * process starts in which the launches overlap for a while and then do not.  A window during which the
+ * host did not keep the lanes fed is no verdict.  3 two lanes, not looked at (TRLDA_LANE_VERIFY=0).
+ * trlda_model_lane_timing: what the last measurement found,
  * microseconds (0: not measured yet). */
 int trlda_model_lane_state(const trlda_model *model);
 int trlda_model_lane_timing(const trlda_model *model, double *us_per_launch, double *us_per_step);

@@ -550,7 +550,7 @@ def test_lanes_that_do_not_pay_are_given_up(hip, sampler, monkeypatch):
     lam = seeded_lambda(sampler, 23, K, V)
     csrs = [corpus(B, V, seed=300 + i, mean_unique=60) for i in range(5)]
     g0s = [seeded_gamma(sampler, 310 + i, K, B) for i in range(5)]
-    N, S = 280, 20                                   # (a look needs a stretch that ends early, then a window: 3 stretches)
+    N, S = 400, 20                                   # (a look: a stretch that ends early, then a window; two looks say no)
     ref, _ = run_stream(hip, K, V, lam, csrs, g0s, [q % 5 for q in range(S)], lanes=1, deferred=0, announce=0)
     monkeypatch.setenv("TRLDA_LANE_CAL_HOST_SHARE", "1e9")   # (this loop reads arrays back between calls: its
     for bar, want_state in (("100", 1), ("0", 2)):           #  windows would otherwise count as host-bound)

@@ -349,7 +349,8 @@ struct trlda_model {
         // they are to beat, measured the same way: phase 6, kLaneSoloLead + kLaneSoloSteps calls in a
         // row on lane 0 alone (no join: the other lane simply gets nothing), events behind the
         // lead-in's launch and the last one -- a step through ONE lane.  Two lanes that are not 3 %
-        // faster than that on two of the last four looks are given up.
+        // faster than that: a look that says no (as one with less than one launch in flight does); two of
+        // the last four looks: given up.
         hipEvent_t s[2] = {nullptr, nullptr};
         // (the window's end is the LATER of the two lanes' last launches: a window timed on lane 0's
         // stream alone reads half the true step when the device runs that lane ahead of the other --
@@ -4470,13 +4471,6 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
                 // (TRLDA_LANE_CAL_MIN_IN_FLIGHT: tests make the lanes lose with 100, win with 0)
                 const char *me = std::getenv("TRLDA_LANE_CAL_MIN_IN_FLIGHT");
                 const float drop = me ? (float)std::atof(me) : 1.0f, keep = me ? drop : 1.4f;
-                if (cal.us_launch < drop * cal.us_step) {   // the launches do not overlap: nothing gained
-                    if ((rc = check_model(m, /*keep_pending=*/true)))   // (joins the lanes)
-                        return rc;
-                    m->lane_state = 1;
-                    return trlda_model_estep_io_next(m, b, next, gamma0_dev, gamma_dev, sstats_dev, max_iter,
-                                                     threshold, iters_dev);
-                }
                 // ... and against the one-lane stretch in front of the window (no verdict from a
                 // stretch the host did not keep fed, or when a test sets the bar)
                 float solo_ms = 0.f;
@@ -4486,12 +4480,17 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
                 cal.short_stretches = 0;
                 cal.us_solo = solo_ok ? 1e3f * solo_ms / kLaneSoloSteps : 0.f;
                 const bool solo_fed = solo_ok && cal.host_us_solo <= host_share * cal.us_solo;
-                if (solo_fed)                        // (a process whose lanes pay now and then: half its looks say no)
-                    cal.worse = ((cal.worse << 1) | (cal.us_step >= 0.97f * cal.us_solo ? 1u : 0u)) & 0xFu;
-                if (solo_fed && cal.us_step >= 0.97f * cal.us_solo) {
+                // A look says NO when the launches do not overlap (less than one in flight) or when two
+                // lanes are not 3 % faster than one.  One look is one sample -- a stream with uploads
+                // beside its launches has its hiccups: the lanes are given up when two of the last four
+                // looks said no (a look that did is followed by the next at once), kept when two in a
+                // row said yes.  (A process whose lanes pay now and then: half its looks say no.)
+                const bool no = cal.us_launch < drop * cal.us_step || (solo_fed && cal.us_step >= 0.97f * cal.us_solo);
+                cal.worse = ((cal.worse << 1) | (no ? 1u : 0u)) & 0xFu;
+                if (no) {
                     cal.keeps = 0;
-                    if (__builtin_popcount(cal.worse) >= 2) {   // two of the last four looks: nothing gained
-                        if ((rc = check_model(m, /*keep_pending=*/true)))
+                    if (__builtin_popcount(cal.worse) >= 2) {   // nothing gained: one launch at a time
+                        if ((rc = check_model(m, /*keep_pending=*/true)))   // (joins the lanes)
                             return rc;
                         m->lane_state = 1;
                         return trlda_model_estep_io_next(m, b, next, gamma0_dev, gamma_dev, sstats_dev, max_iter,
@@ -4499,12 +4498,7 @@ int trlda_model_estep_io_ahead(trlda_model *m, const trlda_batch *b, const trlda
                     }
                     cal.phase = 6;                   // (looked at again, at once)
                     cal.n = 0;
-                } else if (solo_fed) {               // two lanes pay: kept on two looks in a row
-                    if (++cal.keeps < 2) {
-                        cal.phase = 6;
-                        cal.n = 0;
-                    }
-                } else if (cal.us_launch < keep * cal.us_step) {   // (no one-lane figure: by the launches in flight)
+                } else if (!solo_fed && cal.us_launch < keep * cal.us_step) {   // (no one-lane figure, and between the bars)
                     cal.keeps = 0;
                     if (++cal.tries <= 8) {
                         cal.phase = 6;
