@@ -47,7 +47,13 @@ def test_bench_line_contract(hip_lib):
     assert j["lanes"] == 2 and "two E-steps at a time" in j["config"]["in_flight"]
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["device_time_per_launch_us"] * 1e-6) / 1e9) < 1.0
     assert abs(r["device_time_per_launch_us"] - j["ms_per_step"] * 1e3) < 0.02
-    assert 1.1 < r["launches_in_flight"] < 3.2        # (10-step regions: the ramp at both ends counts)
+    # (where the runtime's hardware queues do not let two launches overlap the library goes one launch
+    # at a time, trlda_model_lane_state 1: a property of the box, reported in the line -- not a failure)
+    assert j["lane_state"] in (1, 2), j["lane_state"]
+    if j["lane_state"] == 2:
+        assert 1.1 < r["launches_in_flight"] < 3.2    # (10-step regions: the ramp at both ends counts)
+    else:
+        assert 0.7 < r["launches_in_flight"] < 3.2
     assert abs(r["launches_in_flight"] - r["avg_launch_us"] / r["device_time_per_launch_us"]) < 0.02
     assert j["value_one_lane"]["value"] < 1.1 * j["value"]
     assert r["frac_documents_only"] < r["frac"]

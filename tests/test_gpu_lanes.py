@@ -485,7 +485,9 @@ def test_four_hundred_steps_through_two_lanes(hip, sampler):
     _ffi.check(hip.trlda_model_lane_timing(m._handle, C.byref(launch), C.byref(stepus)))
     if launch.value > 0:                             # (0: every window was host-bound -- no verdict, lanes kept)
         assert 5. < launch.value < 1000. and 5. < stepus.value < 500., (launch.value, stepus.value)
-        assert (launch.value >= 1.0 * stepus.value) == (state == 2)
+        # (the lanes go when two of the last four looks said no -- launches that do not overlap, or two
+        # lanes not faster than one: one look that said no leaves them, so the last measurement alone
+        # does not tell the state; lanes that are gone have had a look that said no)
     else:
         assert state == 2
     _ffi.check(hip.trlda_model_synchronize(m._handle))
