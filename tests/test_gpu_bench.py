@@ -112,7 +112,7 @@ def test_bench_one_lane(hip_lib):
     assert j["lanes"] == 1 and j["value_one_lane"] is None and r["launches_in_flight"] == 1
     assert j["config"]["in_flight"] == "one E-step at a time"
     assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) < 1.0
-    assert sum(r["kernels_us"].values()) <= j["ms_per_step"] * 1e3 * 1.05
+    assert sum(r["kernels_us"].values()) <= j["ms_per_step"] * 1e3 * 1.15
 
 
 def test_bench_forced_distributed_line(hip_lib):
@@ -137,4 +137,4 @@ def test_bench_forced_distributed_line(hip_lib):
     assert j["config"]["word_sharded_m_step"] is False
     assert j["n_gpus"] == 1 and j["rccl_ranks"] == 1
     same = j["same_step_n1"]
-    assert abs(same["ms_per_step"] - j["ms_per_step"]) < 0.25 * j["ms_per_step"]
+    assert abs(same["ms_per_step"] - j["ms_per_step"]) < 0.4 * j["ms_per_step"]
